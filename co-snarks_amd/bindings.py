@@ -1,0 +1,357 @@
+"""ctypes binding of include/cosnarks_hip.h (one Python function per C entry point, numpy u64 in/out).
+
+Field elements travel as little-endian u64 limb arrays in arkworks (Montgomery) layout, exactly the bytes
+a Rust ``&[Fr]`` holds -- see the header for conventions.  No arithmetic happens in this file.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+BN254, BLS12_381 = 0, 1
+G1, G2 = 0, 1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class CoSnarksHipError(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return os.path.join(_HERE, "lib", "libcosnarks_hip.so")
+
+
+def header_path() -> str:
+    return os.path.join(os.path.dirname(_HERE), "include", "cosnarks_hip.h")
+
+
+def declared_symbols() -> list:
+    """Every function name declared in include/cosnarks_hip.h."""
+    txt = open(header_path()).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(csh_[a-z0-9_]+)\s*\(", txt)))
+
+
+def lib():
+    """Load the HIP library (fails loudly if it has not been built)."""
+    global _LIB
+    if _LIB is None:
+        p = lib_path()
+        if not os.path.exists(p):
+            raise CoSnarksHipError(
+                f"{p} not found: build it with `python co-snarks_amd/build.py` (hipcc, gfx950). "
+                "There is no CPU fallback.")
+        L = C.CDLL(p)
+        L.csh_last_error.restype = C.c_char_p
+        L.csh_version.restype = C.c_char_p
+        _LIB = L
+    return _LIB
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise CoSnarksHipError(f"cosnarks_hip error {rc}: {lib().csh_last_error().decode(errors='replace')}")
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    rc = lib().csh_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def have_device() -> bool:
+    try:
+        return device_count() > 0
+    except CoSnarksHipError:
+        return False
+
+
+def fr_bytes(curve: int) -> int:
+    return 32
+
+
+def fq_bytes(curve: int) -> int:
+    return 32 if curve == BN254 else 48
+
+
+def point_bytes(curve: int, group: int) -> int:
+    return 2 * fq_bytes(curve) * (2 if group == G2 else 1)
+
+
+def _u64(a, copy=False):
+    arr = np.ascontiguousarray(a, dtype=np.uint64)
+    return arr.copy() if copy and arr is a else arr
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class DeviceBuffer:
+    """Raw device allocation through the C ABI (csh_malloc / csh_memcpy_*)."""
+
+    def __init__(self, nbytes: int):
+        self.nbytes = int(nbytes)
+        self.ptr = C.c_void_p()
+        _check(lib().csh_malloc(C.byref(self.ptr), C.c_size_t(self.nbytes)))
+
+    @classmethod
+    def from_host(cls, arr):
+        a = np.ascontiguousarray(arr)
+        b = cls(a.nbytes)
+        _check(lib().csh_memcpy_h2d(b.ptr, _p(a), C.c_size_t(a.nbytes)))
+        return b
+
+    def to_host(self, dtype=np.uint64, count=None):
+        n = self.nbytes // np.dtype(dtype).itemsize if count is None else count
+        out = np.empty(n, dtype=dtype)
+        _check(lib().csh_memcpy_d2h(_p(out), self.ptr, C.c_size_t(out.nbytes)))
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib().csh_free(self.ptr)
+            self.ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _devptr(x):
+    if isinstance(x, DeviceBuffer):
+        return x.ptr
+    if x is None:
+        return None
+    return C.c_void_p(int(x))  # raw address, e.g. torch.Tensor.data_ptr()
+
+
+def _stream(s):
+    return C.c_void_p(int(s)) if s else None
+
+
+class Bases:
+    """Device-resident MSM bases (a proving-key query): csh_bases_upload / csh_msm."""
+
+    def __init__(self, curve: int, group: int, points, stride_bytes: int = 0):
+        self.curve, self.group = curve, group
+        pts = _u64(points)
+        pb = point_bytes(curve, group)
+        stride = stride_bytes or pb
+        assert pts.nbytes % stride == 0
+        self.n = pts.nbytes // stride
+        self.h = C.c_void_p()
+        _check(lib().csh_bases_upload(curve, group, _p(pts), C.c_size_t(self.n), C.c_size_t(stride_bytes), C.byref(self.h)))
+
+    def _out(self):
+        return np.zeros(3 * point_bytes(self.curve, self.group) // 2 // 8, dtype=np.uint64)
+
+    def msm(self, scalars, offset: int = 0, n: int | None = None, montgomery: bool = True):
+        """-> Jacobian (X, Y, Z) limbs (Z in {0, 1}). scalars: (n, 4) u64 host array."""
+        sc = _u64(scalars)
+        cnt = sc.size // 4 if n is None else n
+        out = self._out()
+        _check(lib().csh_msm(self.h, C.c_size_t(offset), C.c_size_t(cnt), _p(sc), int(montgomery), _p(out)))
+        return out
+
+    def msm_dev(self, scalars_dev, n: int, offset: int = 0, montgomery: bool = True, stream=None):
+        out = self._out()
+        _check(lib().csh_msm_dev(self.h, C.c_size_t(offset), C.c_size_t(n), _devptr(scalars_dev), int(montgomery), _p(out), _stream(stream)))
+        return out
+
+    def msm_partial_dev(self, scalars_dev, n: int, out_dev, offset: int = 0, montgomery: bool = True, stream=None):
+        _check(lib().csh_msm_partial_dev(self.h, C.c_size_t(offset), C.c_size_t(n), _devptr(scalars_dev), int(montgomery),
+                                         _devptr(out_dev), _stream(stream)))
+
+    def free(self):
+        if self.h:
+            lib().csh_bases_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def msm_partial_bytes(curve: int, group: int) -> int:
+    n = C.c_size_t(0)
+    _check(lib().csh_msm_partial_bytes(curve, group, C.byref(n)))
+    return n.value
+
+
+def msm_fold_partials(curve: int, group: int, partials: np.ndarray, nparts: int):
+    buf = np.ascontiguousarray(partials)
+    out = np.zeros(3 * point_bytes(curve, group) // 2 // 8, dtype=np.uint64)
+    _check(lib().csh_msm_fold_partials(curve, group, _p(buf), C.c_size_t(nparts), _p(out)))
+    return out
+
+
+def msm_last_timing():
+    out = (C.c_float * 6)()
+    _check(lib().csh_msm_last_timing(out))
+    return list(out)
+
+
+class Domain:
+    """taceo_ark_algebra::fft::Domain equivalent: csh_domain_create + transforms."""
+
+    def __init__(self, curve: int, log_n: int, group_gen=None):
+        self.curve, self.log_n, self.n = curve, log_n, 1 << log_n
+        self.h = C.c_void_p()
+        gg = _u64(group_gen) if group_gen is not None else None
+        _check(lib().csh_domain_create(curve, C.c_uint32(log_n), _p(gg), C.byref(self.h)))
+
+    def _host(self, fn, data, ncomp):
+        d = _u64(data).copy()
+        assert d.size == self.n * ncomp * 4, (d.size, self.n, ncomp)
+        _check(fn(self.h, _p(d), C.c_uint32(ncomp)))
+        return d
+
+    def ifft_in_to_out(self, data, ncomp=1):
+        return self._host(lib().csh_ifft_in_to_out, data, ncomp)
+
+    def fft_out_to_in(self, data, ncomp=1):
+        return self._host(lib().csh_fft_out_to_in, data, ncomp)
+
+    def fft(self, data, ncomp=1):
+        return self._host(lib().csh_fft, data, ncomp)
+
+    def ifft(self, data, ncomp=1):
+        return self._host(lib().csh_ifft, data, ncomp)
+
+    def coset_table(self, shift):
+        out = np.zeros(self.n * 4, dtype=np.uint64)
+        sh = _u64(shift)
+        _check(lib().csh_coset_table(self.h, _p(sh), _p(out)))
+        return out
+
+    # device-pointer variants (asynchronous on `stream`)
+    def ifft_in_to_out_dev(self, data_dev, ncomp=1, stream=None):
+        _check(lib().csh_ifft_in_to_out_dev(self.h, _devptr(data_dev), C.c_uint32(ncomp), _stream(stream)))
+
+    def fft_out_to_in_dev(self, data_dev, ncomp=1, stream=None):
+        _check(lib().csh_fft_out_to_in_dev(self.h, _devptr(data_dev), C.c_uint32(ncomp), _stream(stream)))
+
+    def fft_dev(self, data_dev, ncomp=1, stream=None):
+        _check(lib().csh_fft_dev(self.h, _devptr(data_dev), C.c_uint32(ncomp), _stream(stream)))
+
+    def ifft_dev(self, data_dev, ncomp=1, stream=None):
+        _check(lib().csh_ifft_dev(self.h, _devptr(data_dev), C.c_uint32(ncomp), _stream(stream)))
+
+    def free(self):
+        if self.h:
+            lib().csh_domain_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def bit_reverse(curve: int, data, log_n: int, ncomp: int = 1):
+    d = _u64(data).copy()
+    _check(lib().csh_bit_reverse(curve, _p(d), C.c_uint32(log_n), C.c_uint32(ncomp)))
+    return d
+
+
+def vec_mul(curve: int, a, b):
+    a, b = _u64(a), _u64(b)
+    out = np.empty_like(a)
+    _check(lib().csh_vec_mul(curve, _p(a), _p(b), _p(out), C.c_size_t(a.size // 4)))
+    return out
+
+
+def vec_add(curve: int, a, b, ncomp: int = 1):
+    a, b = _u64(a), _u64(b)
+    out = np.empty_like(a)
+    _check(lib().csh_vec_add(curve, _p(a), _p(b), _p(out), C.c_size_t(a.size // (4 * ncomp)), C.c_uint32(ncomp)))
+    return out
+
+
+def vec_sub(curve: int, a, b, ncomp: int = 1):
+    a, b = _u64(a), _u64(b)
+    out = np.empty_like(a)
+    _check(lib().csh_vec_sub(curve, _p(a), _p(b), _p(out), C.c_size_t(a.size // (4 * ncomp)), C.c_uint32(ncomp)))
+    return out
+
+
+def vec_mul_table(curve: int, v, table, ncomp: int = 1):
+    v = _u64(v).copy()
+    t = _u64(table)
+    _check(lib().csh_vec_mul_table(curve, _p(v), _p(t), C.c_size_t(t.size // 4), C.c_uint32(ncomp)))
+    return v
+
+
+def rep3_local_mul_vec(curve: int, lhs_ab, rhs_ab, mask=None):
+    l, r = _u64(lhs_ab), _u64(rhs_ab)
+    n = l.size // 8
+    m = _u64(mask) if mask is not None else None
+    out = np.empty(n * 4, dtype=np.uint64)
+    _check(lib().csh_rep3_local_mul_vec(curve, _p(l), _p(r), _p(m), _p(out), C.c_size_t(n)))
+    return out
+
+
+def rep3_to_shamir_vec(curve: int, in_ab, x, y):
+    a = _u64(in_ab)
+    n = a.size // 8
+    out = np.empty(n * 4, dtype=np.uint64)
+    xx, yy = _u64(x), _u64(y)
+    _check(lib().csh_rep3_to_shamir_vec(curve, _p(a), _p(xx), _p(yy), _p(out), C.c_size_t(n)))
+    return out
+
+
+def lincomb(curve: int, shares, coeffs):
+    sh = [_u64(s) for s in shares]
+    k = len(sh)
+    n = sh[0].size // 4
+    arr = (C.c_void_p * k)(*[s.ctypes.data for s in sh])
+    co = _u64(coeffs)
+    out = np.empty(n * 4, dtype=np.uint64)
+    _check(lib().csh_lincomb(curve, arr, _p(co), C.c_size_t(k), _p(out), C.c_size_t(n)))
+    return out
+
+
+def groth16_h(dom: Domain, shift, protocol: int, a, b, mask_c=None, mask_ab=None):
+    a, b = _u64(a).copy(), _u64(b).copy()
+    out = np.empty(dom.n * 4, dtype=np.uint64)
+    sh = _u64(shift)
+    mc = _u64(mask_c) if mask_c is not None else None
+    mab = _u64(mask_ab) if mask_ab is not None else None
+    _check(lib().csh_groth16_h(dom.h, _p(sh), int(protocol), _p(a), _p(b), _p(mc), _p(mab), _p(out)))
+    return out
+
+
+def sync(stream=None):
+    _check(lib().csh_sync(_stream(stream)))
+
+
+class Event:
+    def __init__(self):
+        self.h = C.c_void_p()
+        _check(lib().csh_event_create(C.byref(self.h)))
+
+    def record(self, stream=None):
+        _check(lib().csh_event_record(self.h, _stream(stream)))
+
+    def elapsed_ms(self, stop: "Event") -> float:
+        ms = C.c_float(0)
+        _check(lib().csh_event_elapsed_ms(self.h, stop.h, C.byref(ms)))
+        return ms.value
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().csh_event_destroy(self.h)
+        except Exception:
+            pass

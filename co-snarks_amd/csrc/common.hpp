@@ -1,0 +1,99 @@
+// Library-internal plumbing: error state, per-thread device/stream, stream-ordered scratch arenas.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/cosnarks_hip.h"
+
+namespace csh {
+
+void set_error(const char* fmt, ...);
+int ensure_device();                    // lazy csh_init(0) for the calling thread; returns csh_status
+hipStream_t resolve_stream(void* s);    // NULL -> the calling thread's stream on its current device
+
+#define CSH_HIP(call)                                                                 \
+  do {                                                                                \
+    hipError_t e__ = (call);                                                          \
+    if (e__ != hipSuccess) {                                                          \
+      csh::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+      return e__ == hipErrorOutOfMemory ? CSH_ERR_OOM : CSH_ERR_HIP;                  \
+    }                                                                                 \
+  } while (0)
+
+#define CSH_TRY(expr)            \
+  do {                           \
+    int rc__ = (expr);           \
+    if (rc__ != CSH_OK) return rc__; \
+  } while (0)
+
+#define CSH_REQUIRE(cond, msg)      \
+  do {                              \
+    if (!(cond)) {                  \
+      csh::set_error("%s", msg);    \
+      return CSH_ERR_INVALID;       \
+    }                               \
+  } while (0)
+
+// Scratch arena bound to (thread, stream): reuse across calls on the same stream is safe by stream
+// ordering; growing frees the old block (hipFree synchronises).
+struct Arena {
+  char* base = nullptr;
+  size_t cap = 0;
+  size_t off = 0;
+  int reserve(size_t bytes);  // ensure capacity, reset offset
+  template <class T>
+  T* take(size_t count) {
+    size_t bytes = (count * sizeof(T) + 255) & ~size_t(255);
+    T* p = reinterpret_cast<T*>(base + off);
+    off += bytes;
+    return p;
+  }
+  static size_t padded(size_t bytes) { return (bytes + 255) & ~size_t(255); }
+};
+Arena& arena_for(hipStream_t s);
+
+// Host-pointer convenience path: stage inputs into a per-thread arena, run on the thread's stream, copy back.
+struct HostStage {
+  hipStream_t st = nullptr;
+  Arena* ar = nullptr;
+  int begin(size_t total_bytes) {
+    CSH_TRY(ensure_device());
+    st = resolve_stream(nullptr);
+    ar = &arena_for((hipStream_t)((uintptr_t)st ^ 0x1));  // distinct arena from kernel-internal scratch
+    return ar->reserve(total_bytes);
+  }
+  template <class T>
+  int up(T*& dev, const void* host, size_t bytes) {
+    dev = reinterpret_cast<T*>(ar->take<char>(bytes));
+    if (host && bytes) CSH_HIP(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, st));
+    return CSH_OK;
+  }
+  int down(void* host, const void* dev, size_t bytes) {
+    if (bytes) CSH_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, st));
+    CSH_HIP(hipStreamSynchronize(st));
+    return CSH_OK;
+  }
+};
+
+// ntt.hip internals reused by the fused Groth16 pipeline
+struct Domain;
+int ntt_run(const Domain* d, uint64_t* data, uint32_t ncomp, bool dif, hipStream_t st);
+int ntt_coset_table(const Domain* d, const uint64_t* shift, uint64_t* out_dev, hipStream_t st);
+int ntt_bit_reverse(csh_curve_t c, uint64_t* data, uint32_t log_n, uint32_t ncomp, hipStream_t st);
+size_t domain_size_of(const Domain* d);
+csh_curve_t domain_curve_of(const Domain* d);
+
+inline int grid_for(size_t n, int block, int max_blocks = 256 * 16) {
+  size_t g = (n + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > (size_t)max_blocks) g = max_blocks;
+  return (int)g;
+}
+
+}  // namespace csh

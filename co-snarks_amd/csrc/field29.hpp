@@ -1,0 +1,158 @@
+// Lazy-reduction base-field representation for gfx950: NL limbs of B (<32) bits in u32 containers.
+//
+// Why: v_mad_u64_u32 accumulates a 32x32 product into a 64-bit register pair but has no carry-in, so a
+// saturated 32-bit-limb CIOS spends ~3 extra VALU ops per product on carry handling. With 29-bit limbs
+// (BN254 Fq: 9 limbs, R' = 2^261) a whole product column (<= 18 products < 2^58) fits a 64-bit accumulator:
+// every partial product is exactly one v_mad_u64_u32 and carries are resolved once per column.
+// Additions are limb-wise with no carry chain. Montgomery domain is R' = 2^(NL*B); conversion to/from the
+// arkworks 32-bit Montgomery encoding costs one multiplication by a constant each way.
+//
+// Bounds contract (checked by tests/host): mul/sqr operands may have limbs < 2^30 (i.e. a sum of two
+// normalised values) and values < 8p; outputs are normalised (limbs < 2^B) with value < 2p.
+#pragma once
+#include "field.hpp"
+
+namespace csh {
+
+template <class LP, class F32>
+struct FpLazy {
+  static constexpr int NL = LP::NL;
+  static constexpr int B = LP::B;
+  uint32_t l[NL];
+
+  CSH_HD static FpLazy zero() {
+    FpLazy r;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) r.l[i] = 0;
+    return r;
+  }
+  CSH_HD static FpLazy one() {
+    FpLazy r;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) r.l[i] = LP::ONE[i];
+    return r;
+  }
+
+  // limb-wise, no carry propagation: result limbs < sum of operand limb bounds
+  CSH_HD static FpLazy add(const FpLazy& a, const FpLazy& b) {
+    FpLazy r;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) r.l[i] = a.l[i] + b.l[i];
+    return r;
+  }
+
+  // one parallel carry step: limbs < 2^B + 2^(32-B)
+  CSH_HD FpLazy normalized() const {
+    FpLazy r;
+    r.l[0] = l[0] & LP::MASK;
+#pragma unroll
+    for (int i = 1; i < NL - 1; ++i) r.l[i] = (l[i] & LP::MASK) + (l[i - 1] >> B);
+    r.l[NL - 1] = l[NL - 1] + (l[NL - 2] >> B);
+    return r;
+  }
+
+  CSH_HD static FpLazy mul(const FpLazy& a, const FpLazy& b) {
+    uint64_t t[2 * NL];
+#pragma unroll
+    for (int k = 0; k < 2 * NL; ++k) t[k] = 0;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+#pragma unroll
+      for (int j = 0; j < NL; ++j) t[i + j] = (uint64_t)a.l[i] * b.l[j] + t[i + j];
+    }
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const uint32_t m = ((uint32_t)t[i] * LP::INV) & LP::MASK;
+#pragma unroll
+      for (int j = 0; j < NL; ++j) t[i + j] = (uint64_t)m * LP::MOD[j] + t[i + j];
+      t[i + 1] += t[i] >> B;  // low B bits of t[i] are now zero
+    }
+    FpLazy r;
+#pragma unroll
+    for (int k = 0; k < NL - 1; ++k) {
+      r.l[k] = (uint32_t)t[NL + k] & LP::MASK;
+      t[NL + k + 1] += t[NL + k] >> B;
+    }
+    r.l[NL - 1] = (uint32_t)t[2 * NL - 1];
+    return r;
+  }
+  CSH_HD static FpLazy sqr(const FpLazy& a) { return mul(a, a); }
+
+  // full carry propagation + conditional subtractions -> canonical value in [0, p), normalised limbs
+  CSH_HD FpLazy canonical() const {
+    FpLazy r = *this;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < NL - 1; ++i) {
+      uint32_t v = r.l[i] + c;
+      r.l[i] = v & LP::MASK;
+      c = v >> B;
+    }
+    r.l[NL - 1] += c;
+    for (int rep = 0; rep < 8; ++rep) {
+      // r >= p ?  (top limb may exceed B bits: compare as integers limb by limb from the top)
+      uint32_t d[NL];
+      int32_t borrow = 0;
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        int64_t v = (int64_t)r.l[i] - (int64_t)LP::MOD[i] + borrow;
+        if (i < NL - 1) {
+          d[i] = (uint32_t)v & LP::MASK;
+          borrow = (int32_t)(v >> B);
+        } else {
+          d[i] = (uint32_t)v;
+          borrow = v < 0 ? -1 : 0;
+        }
+      }
+      if (borrow < 0) break;
+#pragma unroll
+      for (int i = 0; i < NL; ++i) r.l[i] = d[i];
+    }
+    return r;
+  }
+
+  // arkworks 32-bit Montgomery element (x * 2^(32*N)) -> lazy Montgomery element (x * R')
+  CSH_HD static FpLazy from_fp(const F32& f) {
+    FpLazy s = reslice_in(f);
+    FpLazy c;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) c.l[i] = LP::TO_LAZY[i];
+    return mul(s, c);
+  }
+  CSH_HD F32 to_fp() const {
+    FpLazy c;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) c.l[i] = LP::FROM_LAZY[i];
+    FpLazy v = mul(this->normalized(), c).canonical();
+    return reslice_out(v);
+  }
+
+  CSH_HD static FpLazy reslice_in(const F32& f) {
+    FpLazy r;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int bit = i * B;
+      const int w = bit >> 5, off = bit & 31;
+      uint64_t two = w < F32::N ? f.l[w] : 0;
+      if (w + 1 < F32::N) two |= (uint64_t)f.l[w + 1] << 32;
+      r.l[i] = (uint32_t)(two >> off) & LP::MASK;
+    }
+    return r;
+  }
+  CSH_HD static F32 reslice_out(const FpLazy& v) {
+    F32 f = F32::zero();
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int bit = i * B;
+      const int w = bit >> 5, off = bit & 31;
+      const uint64_t sh = (uint64_t)v.l[i] << off;
+      if (w < F32::N) f.l[w] |= (uint32_t)sh;
+      if (w + 1 < F32::N) f.l[w + 1] |= (uint32_t)(sh >> 32);
+    }
+    return f;
+  }
+};
+
+using Fq29 = FpLazy<Bn254Fq29Params, Bn254Fq>;
+
+}  // namespace csh

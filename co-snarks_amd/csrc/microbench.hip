@@ -1,0 +1,153 @@
+// Integer-pipe micro-benchmarks for gfx950 ("measure, don't guess"): issue rates of the instructions a
+// Montgomery multiplication is made of, and modmul throughput of candidate limb representations.
+// Results drive the choice of field representation in the MSM kernels (DESIGN.md "integer roofline").
+// Not part of include/cosnarks_hip.h; exported for bench/profiling harnesses only.
+#include "common.hpp"
+#include "field.hpp"
+#include "field29.hpp"
+#include <string.h>
+
+namespace csh {
+
+constexpr int UB_BLK = 256;
+constexpr int UB_CHAINS = 8;
+
+// kind: 0 mad_u64_u32, 1 add_u64, 2 addc pair, 3 mul_lo_u32, 4 add_u32, 5 mul_hi_u32
+template <int KIND>
+__global__ __launch_bounds__(UB_BLK) void k_ub(uint32_t* out, int iters, uint32_t seed) {
+  uint32_t a = threadIdx.x * 2654435761u + seed, b = blockIdx.x * 40503u + seed * 3u + 1u;
+  uint64_t acc[UB_CHAINS];
+#pragma unroll
+  for (int k = 0; k < UB_CHAINS; ++k) acc[k] = ((uint64_t)a << 20) + k * 977u + b;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int k = 0; k < UB_CHAINS; ++k) {
+        if (KIND == 0) {
+          acc[k] = (uint64_t)(uint32_t)acc[k] * b + acc[k];
+        } else if (KIND == 1) {
+          acc[k] = acc[k] + (acc[(k + 1) % UB_CHAINS] | 1);
+        } else if (KIND == 2) {
+          unsigned c1, c2;
+          uint32_t lo = __builtin_addc((uint32_t)acc[k], a, 0u, &c1);
+          uint32_t hi = __builtin_addc((uint32_t)(acc[k] >> 32), b, c1, &c2);
+          acc[k] = ((uint64_t)hi << 32) | lo;
+        } else if (KIND == 3) {
+          acc[k] = (uint32_t)acc[k] * (b | 1u);
+        } else if (KIND == 4) {
+          acc[k] = (uint32_t)acc[k] + b;
+        } else {
+          acc[k] = __umulhi((uint32_t)acc[k], b | 0x80000001u) + 3u;
+        }
+      }
+    }
+  }
+  uint64_t s = 0;
+#pragma unroll
+  for (int k = 0; k < UB_CHAINS; ++k) s ^= acc[k];
+  out[blockIdx.x * UB_BLK + threadIdx.x] = (uint32_t)s ^ (uint32_t)(s >> 32);
+}
+
+// modmul chains: kind 10 = Fp<Bn254Fq>::mul (8 x 32-bit CIOS), 11 = Fp29 (9 x 29-bit lazy), 12 = Bls381Fq
+template <class F>
+__global__ __launch_bounds__(UB_BLK) void k_modmul(const F* in, F* out, int iters) {
+  const int i = blockIdx.x * UB_BLK + threadIdx.x;
+  F x = in[i], y = in[i ^ 1];
+  for (int it = 0; it < iters; ++it) {
+    x = F::mul(x, y);
+    y = F::mul(y, x);
+  }
+  out[i] = F::add(x, y);
+}
+
+__global__ __launch_bounds__(UB_BLK) void k_modmul29(const Bn254Fq* in, Bn254Fq* out, int iters) {
+  const int i = blockIdx.x * UB_BLK + threadIdx.x;
+  Fq29 x = Fq29::from_fp(in[i]), y = Fq29::from_fp(in[i ^ 1]);
+  for (int it = 0; it < iters; ++it) {
+    x = Fq29::mul(x, y);
+    y = Fq29::mul(y, x);
+  }
+  out[i] = Fq29::add(x, y).to_fp();
+}
+
+template <class K, class... Args>
+static int time_kernel(K kern, dim3 grid, dim3 blk, float* ms, Args... args) {
+  hipStream_t st = resolve_stream(nullptr);
+  hipEvent_t e0, e1;
+  CSH_HIP(hipEventCreate(&e0));
+  CSH_HIP(hipEventCreate(&e1));
+  hipLaunchKernelGGL(kern, grid, blk, 0, st, args...);  // warm-up
+  CSH_HIP(hipEventRecord(e0, st));
+  hipLaunchKernelGGL(kern, grid, blk, 0, st, args...);
+  CSH_HIP(hipEventRecord(e1, st));
+  CSH_HIP(hipEventSynchronize(e1));
+  CSH_HIP(hipEventElapsedTime(ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return CSH_OK;
+}
+
+}  // namespace csh
+
+using namespace csh;
+
+extern "C" {
+
+// Returns lane-operations per second of the selected instruction / modmul variant.
+int csh_microbench(int kind, int iters, double* ops_per_s) {
+  CSH_REQUIRE(ops_per_s && iters > 0, "bad argument");
+  CSH_TRY(ensure_device());
+  const int blocks = 256 * 8;
+  const size_t threads = (size_t)blocks * UB_BLK;
+  float ms = 0;
+  if (kind < 10) {
+    uint32_t* out;
+    CSH_HIP(hipMalloc((void**)&out, threads * 4));
+    int rc = CSH_OK;
+    switch (kind) {
+      case 0: rc = time_kernel(k_ub<0>, dim3(blocks), dim3(UB_BLK), &ms, out, iters, 7u); break;
+      case 1: rc = time_kernel(k_ub<1>, dim3(blocks), dim3(UB_BLK), &ms, out, iters, 7u); break;
+      case 2: rc = time_kernel(k_ub<2>, dim3(blocks), dim3(UB_BLK), &ms, out, iters, 7u); break;
+      case 3: rc = time_kernel(k_ub<3>, dim3(blocks), dim3(UB_BLK), &ms, out, iters, 7u); break;
+      case 4: rc = time_kernel(k_ub<4>, dim3(blocks), dim3(UB_BLK), &ms, out, iters, 7u); break;
+      default: rc = time_kernel(k_ub<5>, dim3(blocks), dim3(UB_BLK), &ms, out, iters, 7u); break;
+    }
+    (void)hipFree(out);
+    if (rc != CSH_OK) return rc;
+    double per_lane = (double)iters * 4 * UB_CHAINS * (kind == 2 ? 2 : 1);
+    *ops_per_s = per_lane * threads / (ms * 1e-3);
+    return CSH_OK;
+  }
+  // modmul variants: inputs = small Montgomery-form values
+  const size_t esz = kind == 12 ? sizeof(Bls381Fq) : sizeof(Bn254Fq);
+  void *in, *out;
+  CSH_HIP(hipMalloc(&in, threads * esz));
+  CSH_HIP(hipMalloc(&out, threads * esz));
+  CSH_HIP(hipMemset(in, 0x11, threads * esz));  // 0x1111... < p for all fields here
+  int rc;
+  if (kind == 10)
+    rc = time_kernel(k_modmul<Bn254Fq>, dim3(blocks), dim3(UB_BLK), &ms, (const Bn254Fq*)in, (Bn254Fq*)out, iters);
+  else if (kind == 11)
+    rc = time_kernel(k_modmul29, dim3(blocks), dim3(UB_BLK), &ms, (const Bn254Fq*)in, (Bn254Fq*)out, iters);
+  else
+    rc = time_kernel(k_modmul<Bls381Fq>, dim3(blocks), dim3(UB_BLK), &ms, (const Bls381Fq*)in, (Bls381Fq*)out, iters);
+  (void)hipFree(in);
+  (void)hipFree(out);
+  if (rc != CSH_OK) return rc;
+  *ops_per_s = 2.0 * iters * threads / (ms * 1e-3);
+  return CSH_OK;
+}
+
+// Host-side self-check hook for the 29-bit representation: out = to_fp(mul29(from_fp(a), from_fp(b)))
+// (values in the same Montgomery domain as Fp<Bn254Fq>: R = 2^256).
+int csh_test_mul29_host(const uint64_t a[4], const uint64_t b[4], uint64_t out[4]) {
+  Bn254Fq fa, fb;
+  memcpy(&fa, a, 32);
+  memcpy(&fb, b, 32);
+  Bn254Fq r = Fq29::mul(Fq29::from_fp(fa), Fq29::from_fp(fb)).to_fp();
+  memcpy(out, &r, 32);
+  return CSH_OK;
+}
+
+}  // extern "C"

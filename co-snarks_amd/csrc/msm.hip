@@ -1,0 +1,559 @@
+// Pippenger bucket MSM on gfx950 (BN254 / BLS12-381, G1 / G2).
+//
+// Pipeline (all on one HIP stream, no host round-trip until the final W window sums):
+//   1. k_msm_hist     scalar -> canonical -> signed c-bit digits; per-(window,bucket) histogram (L2 atomics)
+//   2. k_msm_scan     per-window exclusive scan of bucket counts; long buckets are cut into tasks of <= L
+//                     entries so a skewed witness (many equal scalars) cannot serialise on one lane
+//   3. k_msm_scatter  counting-sort scatter of (point index | sign) into per-window bucket order
+//   4. k_msm_accum    one lane per task: gather affine bases, XYZZ mixed additions in registers
+//   5. k_msm_reduce   balanced segments over the task list: running-sum  sum_b b*B_b  per segment
+//   6. k_msm_fold     pairwise tree over the segment results -> one XYZZ sum per window
+//   host: Horner over the W window sums (W*c doublings), one inversion, Jacobian (x, y, 1) out.
+//
+// Replaces taceo_ark_algebra::msm::{msm_unchecked, msm_bigint} (see include/cosnarks_hip.h for the call
+// sites). The result is a group element; it is bit-identical to the reference after affine normalisation.
+#include <stdlib.h>
+#include <string.h>
+
+#include "common.hpp"
+#include "curve.hpp"
+#include "msm_digits.hpp"
+
+namespace csh {
+
+struct Bn254G1Cfg { using Fq = Bn254Fq;   using Fr = Bn254Fr; };
+struct Bn254G2Cfg { using Fq = Bn254Fq2;  using Fr = Bn254Fr; };
+struct Bls381G1Cfg { using Fq = Bls381Fq;  using Fr = Bls381Fr; };
+struct Bls381G2Cfg { using Fq = Bls381Fq2; using Fr = Bls381Fr; };
+
+struct Bases {
+  csh_curve_t curve;
+  csh_group_t group;
+  int device;
+  size_t n;
+  size_t point_bytes;
+  void* points;  // packed Affine<Fq>[n] on the device
+};
+
+struct MsmParams {
+  uint32_t n;
+  int c;        // window bits
+  int W;        // windows
+  uint32_t NB;  // buckets per window = 2^(c-1), bucket ids 1..NB
+  uint32_t L;   // max entries per task
+  uint32_t tmax;  // task slots per window
+  uint32_t S;     // reduce segments per window (power of two)
+  int mont;
+};
+
+constexpr int MSM_BLK = 256;
+constexpr int ACC_BLK = 128;
+
+// canonical little-endian limbs of scalar i
+template <class Fr>
+__device__ __forceinline__ void load_scalar(const Fr* __restrict__ scalars, size_t i, int mont, uint32_t* s) {
+  Fr v = scalars[i];
+  if (mont) v = v.from_mont();
+#pragma unroll
+  for (int k = 0; k < Fr::N; ++k) s[k] = v.l[k];
+}
+
+template <class Fr>
+__global__ __launch_bounds__(MSM_BLK) void k_msm_hist(const Fr* __restrict__ scalars, MsmParams p, uint32_t* hist) {
+  for (size_t i = blockIdx.x * (size_t)MSM_BLK + threadIdx.x; i < p.n; i += (size_t)gridDim.x * MSM_BLK) {
+    uint32_t s[Fr::N];
+    load_scalar<Fr>(scalars, i, p.mont, s);
+    for_each_digit<Fr::N>(s, p.c, p.W, [&](int w, uint32_t b, uint32_t) { atomicAdd(&hist[(size_t)w * (p.NB + 2) + b], 1u); });
+  }
+}
+
+// One 1024-thread block per window. In: hist[w][0..NB+1] counts (index 0 and NB+1 unused = 0).
+// Out: start[w][b] = first sorted slot of bucket b (start[w][NB+1] = total), tstart[w][b] = first task id,
+// ntasks[w]; hist is zeroed so the scatter can reuse it as the per-bucket cursor.
+__global__ __launch_bounds__(1024) void k_msm_scan(MsmParams p, uint32_t* hist, uint32_t* start, uint32_t* tstart, uint32_t* ntasks) {
+  __shared__ uint32_t sh_cnt[1024];
+  __shared__ uint32_t sh_tsk[1024];
+  const int w = blockIdx.x;
+  const uint32_t len = p.NB + 2;
+  uint32_t* h = hist + (size_t)w * len;
+  uint32_t* st = start + (size_t)w * len;
+  uint32_t* ts = tstart + (size_t)w * len;
+  const uint32_t per = (len + 1023) / 1024;
+  const uint32_t b0 = threadIdx.x * per;
+  uint32_t cnt = 0, tsk = 0;
+  for (uint32_t k = 0; k < per; ++k) {
+    const uint32_t b = b0 + k;
+    if (b < len) {
+      const uint32_t cv = h[b];
+      cnt += cv;
+      tsk += (cv + p.L - 1) / p.L;
+    }
+  }
+  sh_cnt[threadIdx.x] = cnt;
+  sh_tsk[threadIdx.x] = tsk;
+  __syncthreads();
+  // Hillis-Steele inclusive scan over 1024 partials
+  for (int d = 1; d < 1024; d <<= 1) {
+    uint32_t a = 0, b2 = 0;
+    if ((int)threadIdx.x >= d) {
+      a = sh_cnt[threadIdx.x - d];
+      b2 = sh_tsk[threadIdx.x - d];
+    }
+    __syncthreads();
+    sh_cnt[threadIdx.x] += a;
+    sh_tsk[threadIdx.x] += b2;
+    __syncthreads();
+  }
+  uint32_t run_c = sh_cnt[threadIdx.x] - cnt;
+  uint32_t run_t = sh_tsk[threadIdx.x] - tsk;
+  for (uint32_t k = 0; k < per; ++k) {
+    const uint32_t b = b0 + k;
+    if (b < len) {
+      const uint32_t cv = h[b];
+      st[b] = run_c;
+      ts[b] = run_t;
+      run_c += cv;
+      run_t += (cv + p.L - 1) / p.L;
+      h[b] = 0;
+    }
+  }
+  if (threadIdx.x == 1023) ntasks[w] = sh_tsk[1023];
+}
+
+template <class Fr>
+__global__ __launch_bounds__(MSM_BLK) void k_msm_scatter(const Fr* __restrict__ scalars, MsmParams p, const uint32_t* __restrict__ start,
+                                                         uint32_t* cursor, uint32_t* sorted) {
+  for (size_t i = blockIdx.x * (size_t)MSM_BLK + threadIdx.x; i < p.n; i += (size_t)gridDim.x * MSM_BLK) {
+    uint32_t s[Fr::N];
+    load_scalar<Fr>(scalars, i, p.mont, s);
+    for_each_digit<Fr::N>(s, p.c, p.W, [&](int w, uint32_t b, uint32_t neg) {
+      const size_t hb = (size_t)w * (p.NB + 2) + b;
+      const uint32_t pos = start[hb] + atomicAdd(&cursor[hb], 1u);
+      sorted[(size_t)w * p.n + pos] = (uint32_t)i | (neg << 31);
+    });
+  }
+}
+
+// first index in [lo, hi) with a[idx] > v
+__device__ __forceinline__ uint32_t upper_bound_u32(const uint32_t* __restrict__ a, uint32_t lo, uint32_t hi, uint32_t v) {
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (a[mid] > v) hi = mid; else lo = mid + 1;
+  }
+  return lo;
+}
+
+template <class Cfg>
+__global__ __launch_bounds__(ACC_BLK) void k_msm_accum(const Affine<typename Cfg::Fq>* __restrict__ bases, MsmParams p,
+                                                       const uint32_t* __restrict__ start, const uint32_t* __restrict__ tstart,
+                                                       const uint32_t* __restrict__ ntasks, const uint32_t* __restrict__ sorted,
+                                                       XYZZ<typename Cfg::Fq>* partial, uint32_t* task_bucket) {
+  using Fq = typename Cfg::Fq;
+  const int w = blockIdx.y;
+  const uint32_t t = blockIdx.x * ACC_BLK + threadIdx.x;
+  if (t >= ntasks[w]) return;
+  const uint32_t len = p.NB + 2;
+  const uint32_t* ts = tstart + (size_t)w * len;
+  const uint32_t* st = start + (size_t)w * len;
+  const uint32_t b = upper_bound_u32(ts, 1, p.NB + 1, t) - 1;  // bucket owning task t
+  const uint32_t sub = t - ts[b];
+  const uint32_t lo = st[b] + sub * p.L;
+  uint32_t hi = lo + p.L;
+  const uint32_t end = st[b + 1];
+  if (hi > end) hi = end;
+  const uint32_t* so = sorted + (size_t)w * p.n;
+  XYZZ<Fq> acc = XYZZ<Fq>::inf();
+  for (uint32_t k = lo; k < hi; ++k) {
+    const uint32_t e = so[k];
+    Affine<Fq> pt = bases[e & 0x7fffffffu];
+    if (e >> 31) pt.y = Fq::neg(pt.y);
+    xyzz_madd(acc, pt);
+  }
+  partial[(size_t)w * p.tmax + t] = acc;
+  task_bucket[(size_t)w * p.tmax + t] = b;
+}
+
+// Segment k of window w folds tasks [t0, t1): returns sum_t bucket(t) * partial(t).
+template <class Cfg>
+__global__ __launch_bounds__(64) void k_msm_reduce(MsmParams p, const uint32_t* __restrict__ ntasks,
+                                                   const XYZZ<typename Cfg::Fq>* __restrict__ partial,
+                                                   const uint32_t* __restrict__ task_bucket, XYZZ<typename Cfg::Fq>* segres) {
+  using Fq = typename Cfg::Fq;
+  const int w = blockIdx.y;
+  const uint32_t k = blockIdx.x * 64 + threadIdx.x;
+  if (k >= p.S) return;
+  const uint32_t T = ntasks[w];
+  const uint32_t per = (T + p.S - 1) / p.S;
+  const uint32_t t0 = k * per;
+  uint32_t t1 = t0 + per;
+  if (t1 > T) t1 = T;
+  XYZZ<Fq> running = XYZZ<Fq>::inf(), acc = XYZZ<Fq>::inf();
+  if (t0 < t1) {
+    const XYZZ<Fq>* pw = partial + (size_t)w * p.tmax;
+    const uint32_t* tb = task_bucket + (size_t)w * p.tmax;
+    uint32_t prev_b = tb[t1 - 1];
+    for (uint32_t t = t1; t-- > t0;) {
+      const uint32_t b = tb[t];
+      uint32_t gap = prev_b - b;
+      if (gap) {
+        if (gap <= 4) {
+          while (gap--) xyzz_add(acc, running);
+        } else {
+          XYZZ<Fq> m = xyzz_mul_small(running, gap);
+          xyzz_add(acc, m);
+        }
+      }
+      xyzz_add(running, pw[t]);
+      prev_b = b;
+    }
+    // acc = sum (b_t - bmin) P_t ; add bmin * R
+    XYZZ<Fq> m = xyzz_mul_small(running, prev_b);
+    xyzz_add(acc, m);
+  }
+  segres[(size_t)w * p.S + k] = acc;
+}
+
+// arr[w][i] += arr[w][i + half], i < half
+template <class Cfg>
+__global__ __launch_bounds__(64) void k_msm_fold(XYZZ<typename Cfg::Fq>* arr, uint32_t stride, uint32_t half) {
+  const int w = blockIdx.y;
+  const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= half) return;
+  XYZZ<typename Cfg::Fq>* a = arr + (size_t)w * stride;
+  XYZZ<typename Cfg::Fq> x = a[i];
+  xyzz_add(x, a[i + half]);
+  a[i] = x;
+}
+
+template <class Cfg>
+__global__ void k_msm_gather_windows(const XYZZ<typename Cfg::Fq>* segres, uint32_t stride, int W, XYZZ<typename Cfg::Fq>* out) {
+  const int w = threadIdx.x;
+  if (w < W) out[w] = segres[(size_t)w * stride];
+}
+
+// ---- host side -----------------------------------------------------------------------------------------
+static thread_local float tl_msm_timing[6] = {0, 0, 0, 0, 0, 0};
+
+
+static int choose_c(size_t n, int bits) {
+  const char* env = getenv("CSH_MSM_C");
+  if (env) {
+    int c = atoi(env);
+    if (c >= 2 && c <= 22) return c;
+  }
+  double best = 1e300;
+  int best_c = 4;
+  for (int c = 3; c <= 20; ++c) {
+    const double nb = double(size_t(1) << (c - 1));
+    const double cost = windows_for(bits, c) * (double(n) + 5.0 * nb);
+    if (cost < best) {
+      best = cost;
+      best_c = c;
+    }
+  }
+  return best_c;
+}
+
+struct PartialHeader {
+  uint32_t magic, c, W, reserved;
+  uint32_t pad[4];
+};
+constexpr uint32_t PARTIAL_MAGIC = 0x4d534d50u;  // "PMSM"
+constexpr int MAX_WINDOWS = 128;
+
+template <class Cfg>
+static int msm_windows_dev(const Bases* B, size_t offset, size_t n, const uint64_t* scalars_dev, int mont, hipStream_t st,
+                           XYZZ<typename Cfg::Fq>* win_out_dev /* W entries, device */, MsmParams* p_out) {
+  using Fq = typename Cfg::Fq;
+  using Fr = typename Cfg::Fr;
+  MsmParams p;
+  p.n = (uint32_t)n;
+  p.c = choose_c(n, Fr::Params::BITS);
+  p.W = windows_for(Fr::Params::BITS, p.c);
+  p.NB = 1u << (p.c - 1);
+  const uint64_t avg = n / p.NB;
+  uint64_t L = 2 * avg;
+  if (L < 32) L = 32;
+  const char* envL = getenv("CSH_MSM_L");
+  if (envL && atoi(envL) > 0) L = (uint64_t)atoi(envL);
+  p.L = (uint32_t)L;
+  p.tmax = (uint32_t)(p.NB + n / p.L + 2);
+  p.S = 1024;
+  while (p.S > 64 && p.S > p.tmax) p.S >>= 1;
+  p.mont = mont;
+  *p_out = p;
+
+  const size_t len = (size_t)p.NB + 2;
+  Arena& ar = arena_for(st);
+  size_t need = 0;
+  need += 3 * Arena::padded(sizeof(uint32_t) * len * p.W);       // hist/cursor, start, tstart
+  need += Arena::padded(sizeof(uint32_t) * MAX_WINDOWS);          // ntasks
+  need += Arena::padded(sizeof(uint32_t) * n * p.W);              // sorted
+  need += Arena::padded(sizeof(XYZZ<Fq>) * (size_t)p.tmax * p.W); // partials
+  need += Arena::padded(sizeof(uint32_t) * (size_t)p.tmax * p.W); // task buckets
+  need += Arena::padded(sizeof(XYZZ<Fq>) * (size_t)p.S * p.W);    // segment results
+  CSH_TRY(ar.reserve(need));
+  uint32_t* hist = ar.take<uint32_t>(len * p.W);
+  uint32_t* start = ar.take<uint32_t>(len * p.W);
+  uint32_t* tstart = ar.take<uint32_t>(len * p.W);
+  uint32_t* ntasks = ar.take<uint32_t>(MAX_WINDOWS);
+  uint32_t* sorted = ar.take<uint32_t>(n * p.W);
+  XYZZ<Fq>* partial = ar.take<XYZZ<Fq>>((size_t)p.tmax * p.W);
+  uint32_t* task_bucket = ar.take<uint32_t>((size_t)p.tmax * p.W);
+  XYZZ<Fq>* segres = ar.take<XYZZ<Fq>>((size_t)p.S * p.W);
+
+  const bool timing = getenv("CSH_MSM_TIMING") != nullptr;
+  hipEvent_t ev[7];
+  if (timing)
+    for (auto& e : ev) CSH_HIP(hipEventCreate(&e));
+  auto mark = [&](int i) -> int {
+    if (timing) CSH_HIP(hipEventRecord(ev[i], st));
+    return CSH_OK;
+  };
+
+  const Fr* sc = reinterpret_cast<const Fr*>(scalars_dev);
+  const Affine<Fq>* bases = reinterpret_cast<const Affine<Fq>*>(B->points) + offset;
+  CSH_TRY(mark(0));
+  CSH_HIP(hipMemsetAsync(hist, 0, sizeof(uint32_t) * len * p.W, st));
+  const int g1 = grid_for(n, MSM_BLK, 256 * 8);
+  hipLaunchKernelGGL(k_msm_hist<Fr>, dim3(g1), dim3(MSM_BLK), 0, st, sc, p, hist);
+  CSH_TRY(mark(1));
+  hipLaunchKernelGGL(k_msm_scan, dim3(p.W), dim3(1024), 0, st, p, hist, start, tstart, ntasks);
+  CSH_TRY(mark(2));
+  hipLaunchKernelGGL(k_msm_scatter<Fr>, dim3(g1), dim3(MSM_BLK), 0, st, sc, p, start, hist, sorted);
+  CSH_TRY(mark(3));
+  hipLaunchKernelGGL(k_msm_accum<Cfg>, dim3((p.tmax + ACC_BLK - 1) / ACC_BLK, p.W), dim3(ACC_BLK), 0, st, bases, p, start, tstart, ntasks,
+                     sorted, partial, task_bucket);
+  CSH_TRY(mark(4));
+  hipLaunchKernelGGL(k_msm_reduce<Cfg>, dim3((p.S + 63) / 64, p.W), dim3(64), 0, st, p, ntasks, partial, task_bucket, segres);
+  for (uint32_t half = p.S / 2; half >= 1; half >>= 1)
+    hipLaunchKernelGGL(k_msm_fold<Cfg>, dim3((half + 63) / 64, p.W), dim3(64), 0, st, segres, p.S, half);
+  hipLaunchKernelGGL(k_msm_gather_windows<Cfg>, dim3(1), dim3(MAX_WINDOWS), 0, st, segres, p.S, p.W, win_out_dev);
+  CSH_TRY(mark(5));
+  CSH_HIP(hipGetLastError());
+  if (timing) {
+    CSH_HIP(hipEventSynchronize(ev[5]));
+    for (int i = 0; i < 5; ++i) CSH_HIP(hipEventElapsedTime(&tl_msm_timing[i], ev[i], ev[i + 1]));
+    CSH_HIP(hipEventElapsedTime(&tl_msm_timing[5], ev[0], ev[5]));
+    for (auto& e : ev) (void)hipEventDestroy(e);
+  }
+  return CSH_OK;
+}
+
+// Horner over window sums + affine normalisation -> arkworks Projective (x, y, 1) / (1, 1, 0)
+template <class Fq>
+static void fold_windows_host(const XYZZ<Fq>* wins, int W, int c, void* out_jacobian) {
+  XYZZ<Fq> acc = XYZZ<Fq>::inf();
+  for (int w = W - 1; w >= 0; --w) {
+    for (int k = 0; k < c; ++k) acc = xyzz_dbl(acc);
+    xyzz_add(acc, wins[w]);
+  }
+  Affine<Fq> a = xyzz_to_affine(acc);
+  Jac<Fq> j = a.is_inf() ? Jac<Fq>::inf() : Jac<Fq>{a.x, a.y, Fq::one()};
+  memcpy(out_jacobian, &j, sizeof(j));
+}
+
+template <class Cfg>
+static int msm_t(const Bases* B, size_t offset, size_t n, const uint64_t* scalars_dev, int mont, void* out_host, hipStream_t st) {
+  using Fq = typename Cfg::Fq;
+  if (n == 0) {
+    Jac<Fq> j = Jac<Fq>::inf();
+    memcpy(out_host, &j, sizeof(j));
+    return CSH_OK;
+  }
+  Arena& wa = arena_for((hipStream_t)((uintptr_t)st ^ 0x2));
+  CSH_TRY(wa.reserve(sizeof(XYZZ<Fq>) * MAX_WINDOWS));
+  XYZZ<Fq>* win_dev = wa.take<XYZZ<Fq>>(MAX_WINDOWS);
+  MsmParams p;
+  CSH_TRY((msm_windows_dev<Cfg>(B, offset, n, scalars_dev, mont, st, win_dev, &p)));
+  std::vector<XYZZ<Fq>> wins(p.W);
+  CSH_HIP(hipMemcpyAsync(wins.data(), win_dev, sizeof(XYZZ<Fq>) * p.W, hipMemcpyDeviceToHost, st));
+  CSH_HIP(hipStreamSynchronize(st));
+  fold_windows_host<Fq>(wins.data(), p.W, p.c, out_host);
+  return CSH_OK;
+}
+
+template <class Cfg>
+static int msm_partial_t(const Bases* B, size_t offset, size_t n, const uint64_t* scalars_dev, int mont, void* out_dev, hipStream_t st) {
+  using Fq = typename Cfg::Fq;
+  PartialHeader h;
+  memset(&h, 0, sizeof h);
+  h.magic = PARTIAL_MAGIC;
+  XYZZ<Fq>* wins = reinterpret_cast<XYZZ<Fq>*>(static_cast<char*>(out_dev) + sizeof(PartialHeader));
+  CSH_HIP(hipMemsetAsync(out_dev, 0, sizeof(PartialHeader) + sizeof(XYZZ<Fq>) * MAX_WINDOWS, st));
+  if (n > 0) {
+    MsmParams p;
+    CSH_TRY((msm_windows_dev<Cfg>(B, offset, n, scalars_dev, mont, st, wins, &p)));
+    h.c = p.c;
+    h.W = p.W;
+  }
+  CSH_HIP(hipMemcpyAsync(out_dev, &h, sizeof h, hipMemcpyHostToDevice, st));
+  CSH_HIP(hipStreamSynchronize(st));  // h is on the stack
+  return CSH_OK;
+}
+
+template <class Cfg>
+static int fold_partials_t(const void* partials_host, size_t nparts, void* out_jacobian) {
+  using Fq = typename Cfg::Fq;
+  const size_t stride = sizeof(PartialHeader) + sizeof(XYZZ<Fq>) * MAX_WINDOWS;
+  XYZZ<Fq> total = XYZZ<Fq>::inf();
+  for (size_t k = 0; k < nparts; ++k) {
+    const char* base = static_cast<const char*>(partials_host) + k * stride;
+    PartialHeader h;
+    memcpy(&h, base, sizeof h);
+    CSH_REQUIRE(h.magic == PARTIAL_MAGIC, "fold_partials: bad partial header");
+    if (h.W == 0) continue;
+    CSH_REQUIRE(h.W <= (uint32_t)MAX_WINDOWS && h.c >= 2 && h.c <= 22, "fold_partials: bad window parameters");
+    std::vector<XYZZ<Fq>> wins(h.W);
+    memcpy(wins.data(), base + sizeof h, sizeof(XYZZ<Fq>) * h.W);
+    XYZZ<Fq> acc = XYZZ<Fq>::inf();
+    for (int w = (int)h.W - 1; w >= 0; --w) {
+      for (uint32_t i = 0; i < h.c; ++i) acc = xyzz_dbl(acc);
+      xyzz_add(acc, wins[w]);
+    }
+    xyzz_add(total, acc);
+  }
+  Affine<Fq> a = xyzz_to_affine(total);
+  Jac<Fq> j = a.is_inf() ? Jac<Fq>::inf() : Jac<Fq>{a.x, a.y, Fq::one()};
+  memcpy(out_jacobian, &j, sizeof(j));
+  return CSH_OK;
+}
+
+static size_t point_bytes_of(csh_curve_t c, csh_group_t g) {
+  const size_t fq = c == CSH_BN254 ? 32 : 48;
+  return 2 * fq * (g == CSH_G2 ? 2 : 1);
+}
+
+}  // namespace csh
+
+using namespace csh;
+
+#define CURVE_DISPATCH(curve, group, CALL)                                                      \
+  do {                                                                                          \
+    if ((curve) == CSH_BN254 && (group) == CSH_G1) { using Cfg = Bn254G1Cfg; return CALL; }     \
+    if ((curve) == CSH_BN254 && (group) == CSH_G2) { using Cfg = Bn254G2Cfg; return CALL; }     \
+    if ((curve) == CSH_BLS12_381 && (group) == CSH_G1) { using Cfg = Bls381G1Cfg; return CALL; } \
+    if ((curve) == CSH_BLS12_381 && (group) == CSH_G2) { using Cfg = Bls381G2Cfg; return CALL; } \
+    set_error("unknown curve/group %d/%d", (int)(curve), (int)(group));                          \
+    return CSH_ERR_INVALID;                                                                     \
+  } while (0)
+
+static int valid_cg(csh_curve_t c, csh_group_t g) {
+  CSH_REQUIRE(c == CSH_BN254 || c == CSH_BLS12_381, "unknown curve");
+  CSH_REQUIRE(g == CSH_G1 || g == CSH_G2, "unknown group");
+  return CSH_OK;
+}
+
+extern "C" {
+
+static int bases_upload_common(csh_curve_t curve, csh_group_t group, const void* pts, size_t n, size_t stride, bool src_dev, void* stream,
+                               csh_bases_t* out) {
+  CSH_REQUIRE(out, "out is NULL");
+  CSH_TRY(valid_cg(curve, group));
+  CSH_REQUIRE(n < (size_t(1) << 31), "at most 2^31-1 bases per handle");
+  CSH_REQUIRE(pts || n == 0, "points is NULL");
+  CSH_TRY(ensure_device());
+  const size_t pb = point_bytes_of(curve, group);
+  if (stride == 0) stride = pb;
+  CSH_REQUIRE(stride >= pb, "stride_bytes smaller than a packed affine point");
+  Bases* B = new Bases();
+  B->curve = curve;
+  B->group = group;
+  B->n = n;
+  B->point_bytes = pb;
+  B->points = nullptr;
+  if (hipGetDevice(&B->device) != hipSuccess) B->device = 0;
+  hipError_t e = hipMalloc(&B->points, n ? n * pb : 1);
+  if (e != hipSuccess) {
+    delete B;
+    set_error("hipMalloc(%zu bytes) for bases failed: %s", n * pb, hipGetErrorString(e));
+    return CSH_ERR_OOM;
+  }
+  if (n) {
+    hipStream_t st = resolve_stream(stream);
+    const hipMemcpyKind kind = src_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    e = stride == pb ? hipMemcpyAsync(B->points, pts, n * pb, kind, st) : hipMemcpy2DAsync(B->points, pb, pts, stride, pb, n, kind, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+      (void)hipFree(B->points);
+      delete B;
+      set_error("bases upload failed: %s", hipGetErrorString(e));
+      return CSH_ERR_HIP;
+    }
+  }
+  *out = reinterpret_cast<csh_bases_t>(B);
+  return CSH_OK;
+}
+
+int csh_bases_upload(csh_curve_t curve, csh_group_t group, const void* pts, size_t n, size_t stride, csh_bases_t* out) {
+  return bases_upload_common(curve, group, pts, n, stride, false, nullptr, out);
+}
+int csh_bases_upload_dev(csh_curve_t curve, csh_group_t group, const void* pts, size_t n, size_t stride, void* stream, csh_bases_t* out) {
+  return bases_upload_common(curve, group, pts, n, stride, true, stream, out);
+}
+int csh_bases_len(csh_bases_t bases, size_t* n) {
+  CSH_REQUIRE(bases && n, "NULL argument");
+  *n = reinterpret_cast<Bases*>(bases)->n;
+  return CSH_OK;
+}
+int csh_bases_free(csh_bases_t bases) {
+  if (!bases) return CSH_OK;
+  Bases* B = reinterpret_cast<Bases*>(bases);
+  if (B->points) (void)hipFree(B->points);
+  delete B;
+  return CSH_OK;
+}
+
+static int msm_args(csh_bases_t bases, size_t offset, size_t n, const void* scalars, const void* out) {
+  CSH_REQUIRE(bases, "bases is NULL");
+  CSH_REQUIRE(out, "out is NULL");
+  Bases* B = reinterpret_cast<Bases*>(bases);
+  CSH_REQUIRE(offset <= B->n && n <= B->n - offset, "offset + n exceeds the uploaded bases");
+  CSH_REQUIRE(scalars || n == 0, "scalars is NULL");
+  return CSH_OK;
+}
+
+int csh_msm_dev(csh_bases_t bases, size_t offset, size_t n, const uint64_t* scalars_dev, int mont, void* out_host, void* stream) {
+  CSH_TRY(msm_args(bases, offset, n, scalars_dev, out_host));
+  CSH_TRY(ensure_device());
+  Bases* B = reinterpret_cast<Bases*>(bases);
+  hipStream_t st = resolve_stream(stream);
+  CURVE_DISPATCH(B->curve, B->group, (msm_t<Cfg>(B, offset, n, scalars_dev, mont, out_host, st)));
+}
+
+int csh_msm(csh_bases_t bases, size_t offset, size_t n, const uint64_t* scalars, int mont, void* out) {
+  CSH_TRY(msm_args(bases, offset, n, scalars, out));
+  HostStage h;
+  CSH_TRY(h.begin(Arena::padded(32 * n)));
+  uint64_t* ds;
+  CSH_TRY(h.up(ds, scalars, 32 * n));
+  return csh_msm_dev(bases, offset, n, ds, mont, out, h.st);
+}
+
+int csh_msm_partial_bytes(csh_curve_t curve, csh_group_t group, size_t* bytes) {
+  CSH_REQUIRE(bytes, "bytes is NULL");
+  CSH_TRY(valid_cg(curve, group));
+  *bytes = sizeof(PartialHeader) + 2 * point_bytes_of(curve, group) * MAX_WINDOWS;
+  return CSH_OK;
+}
+
+int csh_msm_partial_dev(csh_bases_t bases, size_t offset, size_t n, const uint64_t* scalars_dev, int mont, void* out_dev, void* stream) {
+  CSH_TRY(msm_args(bases, offset, n, scalars_dev, out_dev));
+  CSH_TRY(ensure_device());
+  Bases* B = reinterpret_cast<Bases*>(bases);
+  hipStream_t st = resolve_stream(stream);
+  CURVE_DISPATCH(B->curve, B->group, (msm_partial_t<Cfg>(B, offset, n, scalars_dev, mont, out_dev, st)));
+}
+
+int csh_msm_fold_partials(csh_curve_t curve, csh_group_t group, const void* partials_host, size_t nparts, void* out_jacobian) {
+  CSH_REQUIRE(partials_host && out_jacobian, "NULL argument");
+  CURVE_DISPATCH(curve, group, (fold_partials_t<Cfg>(partials_host, nparts, out_jacobian)));
+}
+
+int csh_msm_last_timing(float out_ms[6]) {
+  CSH_REQUIRE(out_ms, "out_ms is NULL");
+  for (int i = 0; i < 6; ++i) out_ms[i] = tl_msm_timing[i];
+  return CSH_OK;
+}
+
+}  // extern "C"

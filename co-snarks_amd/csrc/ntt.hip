@@ -1,0 +1,464 @@
+// Radix-2 NTT over Fr (BN254 / BLS12-381) on gfx950, LDS-tiled multi-pass.
+//
+// Conventions (the reference's taceo_ark_algebra::fft::Domain, see include/cosnarks_hip.h):
+//   fft_out_to_in : bit-reversed coefficients -> natural-order evaluations   (decimation in time)
+//   ifft_in_to_out: natural-order evaluations -> bit-reversed coefficients/n (decimation in frequency)
+// Stage s (half-size m = 2^s) pairs index i (bit s clear) with i + m, twiddle w^((i mod m) * n/(2m)).
+//
+// A pass executes stages [s0, s0+k) for one tile entirely in LDS: the tile is the 2^k stage-bit values
+// x 2^cb low "column" entries x ncomp components (ncomp = 2 for Rep3 shares), so every HBM access is a
+// contiguous run of 2^cb * ncomp * 32 bytes (>= 256 B) and a 2^22 transform needs 3 read+write sweeps.
+// LDS keeps each element as two 16-byte halves in separate arrays so lane-consecutive ds_read_b128 /
+// ds_write_b128 are bank-conflict free.
+#include <string.h>
+
+#include "common.hpp"
+#include "field.hpp"
+
+namespace csh {
+
+constexpr int NTT_THREADS = 256;
+constexpr int NTT_TILE_LOG = 11;  // 2^11 field elements = 64 KiB of LDS per workgroup
+
+struct Domain {
+  csh_curve_t curve;
+  int device;
+  uint32_t log_n;
+  size_t n;
+  void* tw_fwd;  // w^j, j < n/2
+  void* tw_inv;  // w^-j
+  uint32_t gen[8], gen_inv[8], n_inv[8];  // Montgomery
+};
+
+template <class F>
+__device__ __forceinline__ F lds_get(const uint4* lo, const uint4* hi, int e) {
+  union { F f; uint4 q[2]; } u;
+  u.q[0] = lo[e];
+  u.q[1] = hi[e];
+  return u.f;
+}
+template <class F>
+__device__ __forceinline__ void lds_put(uint4* lo, uint4* hi, int e, const F& f) {
+  union { F f; uint4 q[2]; } u;
+  u.f = f;
+  lo[e] = u.q[0];
+  hi[e] = u.q[1];
+}
+
+// One pass = stages [s0, s0+k) of a size-2^L transform. CC = 2^cb * ncomp contiguous elements.
+template <class F, bool DIF>
+__global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(F* __restrict__ data, const F* __restrict__ tw, int L, int s0, int k,
+                                                          int cb, int ncomp_log, F scale, int do_scale) {
+  static_assert(sizeof(F) == 32, "Fr is 8 x u32");
+  extern __shared__ uint4 lds_raw[];
+  const int cc_log = cb + ncomp_log;
+  const int CC = 1 << cc_log;
+  const int E = 1 << (k + cc_log);
+  uint4* lo = lds_raw;
+  uint4* hi = lds_raw + E;
+  const int mid_bits = s0 - cb;
+  const size_t tile = blockIdx.x;
+  const size_t mid = tile & ((size_t(1) << mid_bits) - 1);
+  const size_t hi_idx = tile >> mid_bits;
+  const int tid = threadIdx.x;
+
+  // gather tile: lds index e = t * CC + cc ; global element = (((hi << k | t) << mid_bits | mid) * CC + cc
+  for (int e = tid; e < E; e += NTT_THREADS) {
+    const int cc = e & (CC - 1);
+    const size_t t = e >> cc_log;
+    const size_t g = ((((hi_idx << k) | t) << mid_bits) | mid) * CC + cc;
+    lds_put<F>(lo, hi, e, data[g]);
+  }
+  __syncthreads();
+
+  const int half_E = E >> 1;
+  for (int qq = 0; qq < k; ++qq) {
+    const int q = DIF ? (k - 1 - qq) : qq;  // local stage; global stage s = s0 + q
+    const int half = 1 << q;
+    const int tw_shift = L - 1 - (s0 + q);
+    for (int bidx = tid; bidx < half_E; bidx += NTT_THREADS) {
+      const int cc = bidx & (CC - 1);
+      const int tb = bidx >> cc_log;
+      const int t_lo = tb & (half - 1);
+      const int t0 = ((tb >> q) << (q + 1)) | t_lo;
+      const int e0 = (t0 << cc_log) | cc;
+      const int e1 = e0 + (half << cc_log);
+      // i mod 2^s with s = s0+q: (t_lo << s0) | (mid << cb) | col
+      const size_t imod = ((size_t)t_lo << s0) | (mid << cb) | (size_t)(cc >> ncomp_log);
+      const F w = tw[imod << tw_shift];
+      F u = lds_get<F>(lo, hi, e0);
+      F v = lds_get<F>(lo, hi, e1);
+      if (DIF) {
+        F s = F::add(u, v);
+        F d = F::mul(F::sub(u, v), w);
+        lds_put<F>(lo, hi, e0, s);
+        lds_put<F>(lo, hi, e1, d);
+      } else {
+        F x = F::mul(v, w);
+        lds_put<F>(lo, hi, e0, F::add(u, x));
+        lds_put<F>(lo, hi, e1, F::sub(u, x));
+      }
+    }
+    __syncthreads();
+  }
+
+  for (int e = tid; e < E; e += NTT_THREADS) {
+    const int cc = e & (CC - 1);
+    const size_t t = e >> cc_log;
+    const size_t g = ((((hi_idx << k) | t) << mid_bits) | mid) * CC + cc;
+    F f = lds_get<F>(lo, hi, e);
+    if (do_scale) f = F::mul(f, scale);
+    data[g] = f;
+  }
+}
+
+__device__ __forceinline__ uint32_t bitrev_n(uint32_t i, int log_n) { return log_n == 0 ? 0 : (__brev(i) >> (32 - log_n)); }
+
+// in-place bit-reversal permutation of entries (ncomp elements each)
+template <class F>
+__global__ __launch_bounds__(256) void k_bit_reverse(F* data, int log_n, int ncomp) {
+  const size_t n = size_t(1) << log_n;
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const size_t j = bitrev_n((uint32_t)i, log_n);
+    if (i < j) {
+      for (int c = 0; c < ncomp; ++c) {
+        F a = data[i * ncomp + c];
+        F b = data[j * ncomp + c];
+        data[i * ncomp + c] = b;
+        data[j * ncomp + c] = a;
+      }
+    }
+  }
+}
+
+constexpr int POW_CHUNK = 32;
+// out[perm(i)] = base^i, i < n; each thread produces POW_CHUNK consecutive powers
+template <class F, bool BITREV>
+__global__ __launch_bounds__(256) void k_powers(F* out, F base, size_t n, int log_n) {
+  const size_t chunks = (n + POW_CHUNK - 1) / POW_CHUNK;
+  for (size_t c = blockIdx.x * (size_t)256 + threadIdx.x; c < chunks; c += (size_t)gridDim.x * 256) {
+    const size_t i0 = c * POW_CHUNK;
+    F cur = F::pow_u64(base, (uint64_t)i0);
+    for (int k = 0; k < POW_CHUNK; ++k) {
+      const size_t i = i0 + k;
+      if (i >= n) break;
+      const size_t o = BITREV ? (size_t)bitrev_n((uint32_t)i, log_n) : i;
+      out[o] = cur;
+      cur = F::mul(cur, base);
+    }
+  }
+}
+
+// ---- host-side helpers -----------------------------------------------------------------------------
+template <class F>
+static F f_from_words(const void* p) {
+  F f;
+  memcpy(&f, p, sizeof(F));
+  return f;
+}
+
+struct Pass {
+  int s0, k, cb;
+};
+
+static int plan_passes(int L, int ncomp_log, Pass* out) {
+  const int TE = NTT_TILE_LOG - ncomp_log;  // log2(entries per tile)
+  const int cb_min = 3 - ncomp_log;         // >= 256 contiguous bytes
+  int np = 0;
+  int k0 = L < TE ? L : TE;
+  out[np++] = {0, k0, 0};
+  int rem = L - k0;
+  if (rem > 0) {
+    const int kmax = TE - cb_min;
+    const int npass = (rem + kmax - 1) / kmax;
+    int s0 = k0;
+    for (int i = 0; i < npass; ++i) {
+      int k = rem / (npass - i);
+      if (rem % (npass - i)) ++k;
+      int cb = TE - k;
+      if (cb > s0) cb = s0;
+      out[np++] = {s0, k, cb};
+      s0 += k;
+      rem -= k;
+    }
+  }
+  return np;
+}
+
+template <class F>
+static int run_ntt(const Domain* d, F* data, uint32_t ncomp, bool dif, hipStream_t st) {
+  const int L = (int)d->log_n;
+  if (L == 0) return CSH_OK;  // size-1 transform is the identity (1/n = 1)
+  const int ncomp_log = ncomp == 2 ? 1 : 0;
+  Pass passes[8];
+  const int np = plan_passes(L, ncomp_log, passes);
+  const F* tw = reinterpret_cast<const F*>(dif ? d->tw_inv : d->tw_fwd);
+  F scale = f_from_words<F>(d->n_inv);
+  for (int pi = 0; pi < np; ++pi) {
+    const Pass& p = dif ? passes[np - 1 - pi] : passes[pi];
+    const int tile_log = p.k + p.cb;  // entries
+    const size_t tiles = d->n >> tile_log;
+    const size_t lds_bytes = (size_t(32) << (tile_log + ncomp_log));
+    const int do_scale = dif && (p.s0 == 0);
+    if (lds_bytes > 48 * 1024) {
+      static thread_local bool raised[2] = {false, false};
+      if (!raised[dif ? 1 : 0]) {
+        const void* fn = dif ? (const void*)k_ntt_pass<F, true> : (const void*)k_ntt_pass<F, false>;
+        CSH_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 32 << NTT_TILE_LOG));
+        raised[dif ? 1 : 0] = true;
+      }
+    }
+    if (dif)
+      hipLaunchKernelGGL((k_ntt_pass<F, true>), dim3((unsigned)tiles), dim3(NTT_THREADS), lds_bytes, st, data, tw, L, p.s0, p.k, p.cb,
+                         ncomp_log, scale, do_scale);
+    else
+      hipLaunchKernelGGL((k_ntt_pass<F, false>), dim3((unsigned)tiles), dim3(NTT_THREADS), lds_bytes, st, data, tw, L, p.s0, p.k, p.cb,
+                         ncomp_log, scale, 0);
+    CSH_HIP(hipGetLastError());
+  }
+  return CSH_OK;
+}
+
+template <class F>
+static int run_bit_reverse(F* data, uint32_t log_n, uint32_t ncomp, hipStream_t st) {
+  if (log_n == 0) return CSH_OK;
+  hipLaunchKernelGGL(k_bit_reverse<F>, dim3(grid_for(size_t(1) << log_n, 256)), dim3(256), 0, st, data, (int)log_n, (int)ncomp);
+  CSH_HIP(hipGetLastError());
+  return CSH_OK;
+}
+
+template <class F>
+static int create_domain_t(csh_curve_t curve, uint32_t log_n, const uint64_t* gen_words, uint64_t ark_generator, Domain** out) {
+  if (log_n > (uint32_t)F::Params::TWO_ADICITY) {
+    set_error("Polynomial Degree too large");
+    return CSH_ERR_DOMAIN;
+  }
+  F gen;
+  if (gen_words) {
+    gen = f_from_words<F>(gen_words);
+  } else {
+    // GENERATOR^TRACE has order 2^TWO_ADICITY; TRACE = (p-1) >> TWO_ADICITY
+    uint32_t tr[F::N];
+    uint32_t pm1[F::N];
+    for (int i = 0; i < F::N; ++i) pm1[i] = F::Params::MOD[i];
+    pm1[0] -= 1;  // p is odd
+    const int s = F::Params::TWO_ADICITY;
+    for (int i = 0; i < F::N; ++i) {
+      const int wi = i + s / 32;
+      const uint64_t lo = wi < F::N ? pm1[wi] : 0;
+      const uint64_t hi2 = wi + 1 < F::N ? pm1[wi + 1] : 0;
+      tr[i] = (uint32_t)((lo | (hi2 << 32)) >> (s % 32));
+    }
+    F g = F::from_u64(ark_generator);
+    gen = F::pow_limbs(g, tr, F::N);
+    for (uint32_t i = log_n; i < (uint32_t)s; ++i) gen = F::sqr(gen);
+  }
+  // validate order: gen^(n) == 1 and gen^(n/2) != 1
+  {
+    F t = gen;
+    for (uint32_t i = 0; i + 1 < log_n; ++i) t = F::sqr(t);
+    F one = F::one();
+    if (log_n >= 1) {
+      if (t == one) {
+        set_error("group_gen does not have order 2^%u", log_n);
+        return CSH_ERR_DOMAIN;
+      }
+      t = F::sqr(t);
+    }
+    if (!(t == one)) {
+      set_error("group_gen does not have order 2^%u", log_n);
+      return CSH_ERR_DOMAIN;
+    }
+  }
+  Domain* d = new Domain();
+  d->curve = curve;
+  if (hipGetDevice(&d->device) != hipSuccess) d->device = 0;
+  d->log_n = log_n;
+  d->n = size_t(1) << log_n;
+  F gen_inv = F::inv(gen);
+  F n_inv = F::inv(F::from_u64((uint64_t)d->n));
+  memcpy(d->gen, &gen, 32);
+  memcpy(d->gen_inv, &gen_inv, 32);
+  memcpy(d->n_inv, &n_inv, 32);
+  const size_t half = d->n / 2 ? d->n / 2 : 1;
+  d->tw_fwd = d->tw_inv = nullptr;
+  hipError_t e1 = hipMalloc(&d->tw_fwd, half * sizeof(F));
+  hipError_t e2 = hipMalloc(&d->tw_inv, half * sizeof(F));
+  if (e1 != hipSuccess || e2 != hipSuccess) {
+    if (d->tw_fwd) (void)hipFree(d->tw_fwd);
+    if (d->tw_inv) (void)hipFree(d->tw_inv);
+    delete d;
+    set_error("hipMalloc of twiddle tables failed");
+    return CSH_ERR_OOM;
+  }
+  hipStream_t st = resolve_stream(nullptr);
+  hipLaunchKernelGGL((k_powers<F, false>), dim3(grid_for((half + POW_CHUNK - 1) / POW_CHUNK, 256)), dim3(256), 0, st, (F*)d->tw_fwd, gen, half, 0);
+  hipLaunchKernelGGL((k_powers<F, false>), dim3(grid_for((half + POW_CHUNK - 1) / POW_CHUNK, 256)), dim3(256), 0, st, (F*)d->tw_inv, gen_inv, half, 0);
+  hipError_t e3 = hipStreamSynchronize(st);
+  if (e3 != hipSuccess) {
+    set_error("twiddle generation failed: %s", hipGetErrorString(e3));
+    (void)hipFree(d->tw_fwd);
+    (void)hipFree(d->tw_inv);
+    delete d;
+    return CSH_ERR_HIP;
+  }
+  *out = d;
+  return CSH_OK;
+}
+
+template <class F>
+static int coset_table_t(const Domain* d, const uint64_t* shift, uint64_t* out_dev, hipStream_t st) {
+  F sh = f_from_words<F>(shift);
+  hipLaunchKernelGGL((k_powers<F, true>), dim3(grid_for((d->n + POW_CHUNK - 1) / POW_CHUNK, 256)), dim3(256), 0, st, (F*)out_dev, sh, d->n,
+                     (int)d->log_n);
+  CSH_HIP(hipGetLastError());
+  return CSH_OK;
+}
+
+// exposed to other translation units (fused Groth16 h pipeline)
+int ntt_run(const Domain* d, uint64_t* data, uint32_t ncomp, bool dif, hipStream_t st) {
+  if (d->curve == CSH_BN254) return run_ntt<Bn254Fr>(d, (Bn254Fr*)data, ncomp, dif, st);
+  return run_ntt<Bls381Fr>(d, (Bls381Fr*)data, ncomp, dif, st);
+}
+int ntt_coset_table(const Domain* d, const uint64_t* shift, uint64_t* out_dev, hipStream_t st) {
+  if (d->curve == CSH_BN254) return coset_table_t<Bn254Fr>(d, shift, out_dev, st);
+  return coset_table_t<Bls381Fr>(d, shift, out_dev, st);
+}
+int ntt_bit_reverse(csh_curve_t c, uint64_t* data, uint32_t log_n, uint32_t ncomp, hipStream_t st) {
+  if (c == CSH_BN254) return run_bit_reverse<Bn254Fr>((Bn254Fr*)data, log_n, ncomp, st);
+  return run_bit_reverse<Bls381Fr>((Bls381Fr*)data, log_n, ncomp, st);
+}
+
+size_t domain_size_of(const Domain* d) { return d->n; }
+csh_curve_t domain_curve_of(const Domain* d) { return d->curve; }
+
+}  // namespace csh
+
+using namespace csh;
+
+static int check_dom(csh_domain_t dom, uint32_t ncomp) {
+  CSH_REQUIRE(dom, "domain is NULL");
+  CSH_REQUIRE(ncomp == 1 || ncomp == 2, "ncomp must be 1 or 2");
+  return CSH_OK;
+}
+
+extern "C" {
+
+int csh_domain_create(csh_curve_t field_of, uint32_t log_n, const uint64_t group_gen[4], csh_domain_t* out) {
+  CSH_REQUIRE(out, "out is NULL");
+  CSH_REQUIRE(log_n <= 31, "log_n too large");
+  CSH_TRY(ensure_device());
+  Domain* d = nullptr;
+  int rc;
+  if (field_of == CSH_BN254)
+    rc = create_domain_t<Bn254Fr>(field_of, log_n, group_gen, 5, &d);
+  else if (field_of == CSH_BLS12_381)
+    rc = create_domain_t<Bls381Fr>(field_of, log_n, group_gen, 7, &d);
+  else {
+    set_error("unknown curve %d", (int)field_of);
+    return CSH_ERR_INVALID;
+  }
+  if (rc != CSH_OK) return rc;
+  *out = reinterpret_cast<csh_domain_t>(d);
+  return CSH_OK;
+}
+int csh_domain_size(csh_domain_t dom, size_t* n) {
+  CSH_REQUIRE(dom && n, "NULL argument");
+  *n = reinterpret_cast<Domain*>(dom)->n;
+  return CSH_OK;
+}
+int csh_domain_free(csh_domain_t dom) {
+  if (!dom) return CSH_OK;
+  Domain* d = reinterpret_cast<Domain*>(dom);
+  if (d->tw_fwd) (void)hipFree(d->tw_fwd);
+  if (d->tw_inv) (void)hipFree(d->tw_inv);
+  delete d;
+  return CSH_OK;
+}
+
+int csh_ifft_in_to_out_dev(csh_domain_t dom, uint64_t* data, uint32_t ncomp, void* stream) {
+  CSH_TRY(check_dom(dom, ncomp));
+  CSH_TRY(ensure_device());
+  return ntt_run(reinterpret_cast<Domain*>(dom), data, ncomp, true, resolve_stream(stream));
+}
+int csh_fft_out_to_in_dev(csh_domain_t dom, uint64_t* data, uint32_t ncomp, void* stream) {
+  CSH_TRY(check_dom(dom, ncomp));
+  CSH_TRY(ensure_device());
+  return ntt_run(reinterpret_cast<Domain*>(dom), data, ncomp, false, resolve_stream(stream));
+}
+int csh_fft_dev(csh_domain_t dom, uint64_t* data, uint32_t ncomp, void* stream) {
+  CSH_TRY(check_dom(dom, ncomp));
+  CSH_TRY(ensure_device());
+  Domain* d = reinterpret_cast<Domain*>(dom);
+  hipStream_t st = resolve_stream(stream);
+  CSH_TRY(ntt_bit_reverse(d->curve, data, d->log_n, ncomp, st));
+  return ntt_run(d, data, ncomp, false, st);
+}
+int csh_ifft_dev(csh_domain_t dom, uint64_t* data, uint32_t ncomp, void* stream) {
+  CSH_TRY(check_dom(dom, ncomp));
+  CSH_TRY(ensure_device());
+  Domain* d = reinterpret_cast<Domain*>(dom);
+  hipStream_t st = resolve_stream(stream);
+  CSH_TRY(ntt_run(d, data, ncomp, true, st));
+  return ntt_bit_reverse(d->curve, data, d->log_n, ncomp, st);
+}
+int csh_bit_reverse_dev(csh_curve_t field_of, uint64_t* data, uint32_t log_n, uint32_t ncomp, void* stream) {
+  CSH_REQUIRE(ncomp == 1 || ncomp == 2, "ncomp must be 1 or 2");
+  CSH_REQUIRE(field_of == CSH_BN254 || field_of == CSH_BLS12_381, "unknown curve");
+  CSH_REQUIRE(log_n <= 31, "log_n too large");
+  CSH_TRY(ensure_device());
+  return ntt_bit_reverse(field_of, data, log_n, ncomp, resolve_stream(stream));
+}
+int csh_coset_table_dev(csh_domain_t dom, const uint64_t shift[4], uint64_t* out, void* stream) {
+  CSH_REQUIRE(dom && shift && out, "NULL argument");
+  CSH_TRY(ensure_device());
+  return ntt_coset_table(reinterpret_cast<Domain*>(dom), shift, out, resolve_stream(stream));
+}
+
+// ---- host-pointer wrappers ---------------------------------------------------------------------------
+static int host_transform(csh_domain_t dom, uint64_t* data, uint32_t ncomp, int which) {
+  CSH_TRY(check_dom(dom, ncomp));
+  Domain* d = reinterpret_cast<Domain*>(dom);
+  HostStage h;
+  const size_t bytes = d->n * ncomp * 32;
+  CSH_TRY(h.begin(Arena::padded(bytes)));
+  uint64_t* dd;
+  CSH_TRY(h.up(dd, data, bytes));
+  int rc = CSH_OK;
+  switch (which) {
+    case 0: rc = csh_ifft_in_to_out_dev(dom, dd, ncomp, h.st); break;
+    case 1: rc = csh_fft_out_to_in_dev(dom, dd, ncomp, h.st); break;
+    case 2: rc = csh_fft_dev(dom, dd, ncomp, h.st); break;
+    default: rc = csh_ifft_dev(dom, dd, ncomp, h.st); break;
+  }
+  if (rc != CSH_OK) return rc;
+  return h.down(data, dd, bytes);
+}
+int csh_ifft_in_to_out(csh_domain_t dom, uint64_t* data, uint32_t ncomp) { return host_transform(dom, data, ncomp, 0); }
+int csh_fft_out_to_in(csh_domain_t dom, uint64_t* data, uint32_t ncomp) { return host_transform(dom, data, ncomp, 1); }
+int csh_fft(csh_domain_t dom, uint64_t* data, uint32_t ncomp) { return host_transform(dom, data, ncomp, 2); }
+int csh_ifft(csh_domain_t dom, uint64_t* data, uint32_t ncomp) { return host_transform(dom, data, ncomp, 3); }
+
+int csh_bit_reverse(csh_curve_t field_of, uint64_t* data, uint32_t log_n, uint32_t ncomp) {
+  CSH_REQUIRE(log_n <= 31, "log_n too large");
+  HostStage h;
+  const size_t bytes = (size_t(1) << log_n) * ncomp * 32;
+  CSH_TRY(h.begin(Arena::padded(bytes)));
+  uint64_t* dd;
+  CSH_TRY(h.up(dd, data, bytes));
+  CSH_TRY(csh_bit_reverse_dev(field_of, dd, log_n, ncomp, h.st));
+  return h.down(data, dd, bytes);
+}
+int csh_coset_table(csh_domain_t dom, const uint64_t shift[4], uint64_t* out) {
+  CSH_REQUIRE(dom && shift && out, "NULL argument");
+  Domain* d = reinterpret_cast<Domain*>(dom);
+  HostStage h;
+  const size_t bytes = d->n * 32;
+  CSH_TRY(h.begin(Arena::padded(bytes)));
+  uint64_t* dd;
+  CSH_TRY(h.up(dd, nullptr, bytes));
+  CSH_TRY(csh_coset_table_dev(dom, shift, dd, h.st));
+  return h.down(out, dd, bytes);
+}
+
+}  // extern "C"

@@ -1,0 +1,119 @@
+// Host-executed self-test hooks: the SAME templates the gfx950 kernels instantiate (field.hpp, curve.hpp,
+// field29.hpp, msm_digits.hpp) run on the CPU so that `pytest -m "not gpu"` can check them against the
+// oracle without a device. Test infrastructure; not declared in include/cosnarks_hip.h.
+#include <string.h>
+
+#include "common.hpp"
+#include "curve.hpp"
+#include "field29.hpp"
+#include "msm_digits.hpp"
+
+using namespace csh;
+
+namespace {
+
+template <class F, bool IS_FP = true>
+int field_op(int op, const void* a, const void* b, void* out) {
+  F x, y, r;
+  memcpy(&x, a, sizeof(F));
+  if (b) memcpy(&y, b, sizeof(F)); else y = F::zero();
+  switch (op) {
+    case 0: r = F::add(x, y); break;
+    case 1: r = F::sub(x, y); break;
+    case 2: r = F::mul(x, y); break;
+    case 3: r = F::inv(x); break;
+    case 4: if constexpr (IS_FP) r = x.from_mont(); else return CSH_ERR_INVALID; break;
+    case 5: if constexpr (IS_FP) r = x.to_mont(); else return CSH_ERR_INVALID; break;
+    case 6: r = F::neg(x); break;
+    case 7: r = F::sqr(x); break;
+    default: return CSH_ERR_INVALID;
+  }
+  memcpy(out, &r, sizeof(F));
+  return CSH_OK;
+}
+
+template <class Fq>
+int curve_op(int op, const void* in1, const void* in2, uint32_t k, void* out) {
+  XYZZ<Fq> acc, other;
+  Affine<Fq> p;
+  switch (op) {
+    case 0:  // XYZZ += affine
+      memcpy(&acc, in1, sizeof acc);
+      memcpy(&p, in2, sizeof p);
+      xyzz_madd(acc, p);
+      memcpy(out, &acc, sizeof acc);
+      return CSH_OK;
+    case 1:  // XYZZ += XYZZ
+      memcpy(&acc, in1, sizeof acc);
+      memcpy(&other, in2, sizeof other);
+      xyzz_add(acc, other);
+      memcpy(out, &acc, sizeof acc);
+      return CSH_OK;
+    case 2:
+      memcpy(&acc, in1, sizeof acc);
+      acc = xyzz_dbl(acc);
+      memcpy(out, &acc, sizeof acc);
+      return CSH_OK;
+    case 3:
+      memcpy(&acc, in1, sizeof acc);
+      acc = xyzz_mul_small(acc, k);
+      memcpy(out, &acc, sizeof acc);
+      return CSH_OK;
+    case 4: {  // XYZZ -> affine
+      memcpy(&acc, in1, sizeof acc);
+      Affine<Fq> a = xyzz_to_affine(acc);
+      memcpy(out, &a, sizeof a);
+      return CSH_OK;
+    }
+    case 5: {  // affine -> XYZZ
+      memcpy(&p, in1, sizeof p);
+      acc = XYZZ<Fq>::from_affine(p);
+      memcpy(out, &acc, sizeof acc);
+      return CSH_OK;
+    }
+    default: return CSH_ERR_INVALID;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+// field: 0 BN254 Fq, 1 BN254 Fr, 2 BLS12-381 Fq, 3 BLS12-381 Fr
+int csh_selftest_field_op(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out) {
+  switch (field) {
+    case 0: return field_op<Bn254Fq>(op, a, b, out);
+    case 1: return field_op<Bn254Fr>(op, a, b, out);
+    case 2: return field_op<Bls381Fq>(op, a, b, out);
+    case 3: return field_op<Bls381Fr>(op, a, b, out);
+    default: return CSH_ERR_INVALID;
+  }
+}
+
+int csh_selftest_fp2_op(int curve, int op, const uint64_t* a, const uint64_t* b, uint64_t* out) {
+  if (curve == CSH_BN254) return field_op<Bn254Fq2, false>(op, a, b, out);
+  if (curve == CSH_BLS12_381) return field_op<Bls381Fq2, false>(op, a, b, out);
+  return CSH_ERR_INVALID;
+}
+
+int csh_selftest_curve_op(int curve, int group, int op, const void* in1, const void* in2, uint32_t k, void* out) {
+  if (curve == CSH_BN254 && group == CSH_G1) return curve_op<Bn254Fq>(op, in1, in2, k, out);
+  if (curve == CSH_BN254 && group == CSH_G2) return curve_op<Bn254Fq2>(op, in1, in2, k, out);
+  if (curve == CSH_BLS12_381 && group == CSH_G1) return curve_op<Bls381Fq>(op, in1, in2, k, out);
+  if (curve == CSH_BLS12_381 && group == CSH_G2) return curve_op<Bls381Fq2>(op, in1, in2, k, out);
+  return CSH_ERR_INVALID;
+}
+
+// canonical scalar limbs -> signed digits (digits_out[w], w < *W_out)
+int csh_selftest_digits(int curve, const uint64_t scalar[4], int c, int32_t* digits_out, int* W_out) {
+  const int bits = curve == CSH_BN254 ? Bn254FrParams::BITS : Bls381FrParams::BITS;
+  const int W = windows_for(bits, c);
+  uint32_t s[8];
+  memcpy(s, scalar, 32);
+  for (int w = 0; w < W; ++w) digits_out[w] = 0;
+  for_each_digit<8>(s, c, W, [&](int w, uint32_t b, uint32_t neg) { digits_out[w] = neg ? -(int32_t)b : (int32_t)b; });
+  *W_out = W;
+  return CSH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,269 @@
+// Element-wise secret-shared field arithmetic (Rep3 / Shamir / plain) on gfx950.
+// HBM-bound streaming kernels: one 32-byte field element per lane per step, 2 x 16-byte accesses,
+// grid-stride over <= 4096 workgroups of 256 threads. See DESIGN.md section "share-vector kernels".
+#include "common.hpp"
+#include "field.hpp"
+#include <string.h>
+
+namespace csh {
+
+constexpr int VB = 256;
+
+template <class F>
+__global__ __launch_bounds__(VB) void k_vec_mul(const F* __restrict__ a, const F* __restrict__ b, F* out, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)VB + threadIdx.x; i < n; i += (size_t)gridDim.x * VB) {
+    out[i] = F::mul(a[i], b[i]);
+  }
+}
+
+template <class F, bool SUB>
+__global__ __launch_bounds__(VB) void k_vec_addsub(const F* __restrict__ a, const F* __restrict__ b, F* out, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)VB + threadIdx.x; i < n; i += (size_t)gridDim.x * VB) {
+    out[i] = SUB ? F::sub(a[i], b[i]) : F::add(a[i], b[i]);
+  }
+}
+
+// v[i*ncomp + c] *= table[i]
+template <class F>
+__global__ __launch_bounds__(VB) void k_vec_mul_table(F* v, const F* __restrict__ table, size_t n_elems, uint32_t ncomp) {
+  for (size_t e = blockIdx.x * (size_t)VB + threadIdx.x; e < n_elems; e += (size_t)gridDim.x * VB) {
+    size_t i = ncomp == 1 ? e : e / ncomp;
+    v[e] = F::mul(v[e], table[i]);
+  }
+}
+
+// Rep3 local multiplication (mpc-core rep3/arithmetic/ops.rs:69-76) + mask
+template <class F>
+__global__ __launch_bounds__(VB) void k_rep3_local_mul(const F* __restrict__ lhs, const F* __restrict__ rhs,
+                                                       const F* __restrict__ mask, F* out, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)VB + threadIdx.x; i < n; i += (size_t)gridDim.x * VB) {
+    F la = lhs[2 * i], lb = lhs[2 * i + 1];
+    F ra = rhs[2 * i], rb = rhs[2 * i + 1];
+    // a*a' + a*b' + b*a' = la*(ra+rb) + lb*ra  (2 multiplications instead of 3; same field element)
+    F r = F::add(F::mul(la, F::add(ra, rb)), F::mul(lb, ra));
+    if (mask) r = F::add(r, mask[i]);
+    out[i] = r;
+  }
+}
+
+template <class F>
+__global__ __launch_bounds__(VB) void k_rep3_to_shamir(const F* __restrict__ in, F x, F y, F* out, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)VB + threadIdx.x; i < n; i += (size_t)gridDim.x * VB) {
+    out[i] = F::add(F::mul(in[2 * i], x), F::mul(in[2 * i + 1], y));
+  }
+}
+
+constexpr int MAX_LINCOMB = 16;
+template <class F>
+struct LincombArgs {
+  const F* shares[MAX_LINCOMB];
+  F coeffs[MAX_LINCOMB];
+  int k;
+  int unit;  // all coefficients are 1 (Rep3 combine/open): plain sum
+};
+
+template <class F>
+__global__ __launch_bounds__(VB) void k_lincomb(LincombArgs<F> args, F* out, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)VB + threadIdx.x; i < n; i += (size_t)gridDim.x * VB) {
+    F acc = F::zero();
+    for (int k = 0; k < args.k; ++k) {
+      F s = args.shares[k][i];
+      acc = F::add(acc, args.unit ? s : F::mul(s, args.coeffs[k]));
+    }
+    out[i] = acc;
+  }
+}
+
+// ---- typed launchers ---------------------------------------------------------------------------
+template <class F>
+static int vec_mul_t(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, hipStream_t st) {
+  if (n == 0) return CSH_OK;
+  hipLaunchKernelGGL(k_vec_mul<F>, dim3(grid_for(n, VB)), dim3(VB), 0, st, (const F*)a, (const F*)b, (F*)out, n);
+  CSH_HIP(hipGetLastError());
+  return CSH_OK;
+}
+template <class F>
+static int vec_addsub_t(bool sub, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n_elems, hipStream_t st) {
+  if (n_elems == 0) return CSH_OK;
+  if (sub)
+    hipLaunchKernelGGL((k_vec_addsub<F, true>), dim3(grid_for(n_elems, VB)), dim3(VB), 0, st, (const F*)a, (const F*)b, (F*)out, n_elems);
+  else
+    hipLaunchKernelGGL((k_vec_addsub<F, false>), dim3(grid_for(n_elems, VB)), dim3(VB), 0, st, (const F*)a, (const F*)b, (F*)out, n_elems);
+  CSH_HIP(hipGetLastError());
+  return CSH_OK;
+}
+template <class F>
+static int vec_mul_table_t(uint64_t* v, const uint64_t* table, size_t n, uint32_t ncomp, hipStream_t st) {
+  if (n == 0) return CSH_OK;
+  hipLaunchKernelGGL(k_vec_mul_table<F>, dim3(grid_for(n * ncomp, VB)), dim3(VB), 0, st, (F*)v, (const F*)table, n * ncomp, ncomp);
+  CSH_HIP(hipGetLastError());
+  return CSH_OK;
+}
+template <class F>
+static int rep3_local_mul_t(const uint64_t* l, const uint64_t* r, const uint64_t* m, uint64_t* out, size_t n, hipStream_t st) {
+  if (n == 0) return CSH_OK;
+  hipLaunchKernelGGL(k_rep3_local_mul<F>, dim3(grid_for(n, VB)), dim3(VB), 0, st, (const F*)l, (const F*)r, (const F*)m, (F*)out, n);
+  CSH_HIP(hipGetLastError());
+  return CSH_OK;
+}
+template <class F>
+static int rep3_to_shamir_t(const uint64_t* in, const uint64_t* x, const uint64_t* y, uint64_t* out, size_t n, hipStream_t st) {
+  if (n == 0) return CSH_OK;
+  F fx, fy;
+  memcpy(&fx, x, sizeof(F));
+  memcpy(&fy, y, sizeof(F));
+  hipLaunchKernelGGL(k_rep3_to_shamir<F>, dim3(grid_for(n, VB)), dim3(VB), 0, st, (const F*)in, fx, fy, (F*)out, n);
+  CSH_HIP(hipGetLastError());
+  return CSH_OK;
+}
+template <class F>
+static int lincomb_t(const uint64_t* const* shares, const uint64_t* coeffs, size_t k, uint64_t* out, size_t n, hipStream_t st) {
+  if (n == 0) return CSH_OK;
+  LincombArgs<F> args;
+  args.k = (int)k;
+  F one = F::one();
+  int unit = 1;
+  for (size_t j = 0; j < k; ++j) {
+    args.shares[j] = (const F*)shares[j];
+    memcpy(&args.coeffs[j], coeffs + 4 * j, sizeof(F));
+    if (!(args.coeffs[j] == one)) unit = 0;
+  }
+  args.unit = unit;
+  hipLaunchKernelGGL(k_lincomb<F>, dim3(grid_for(n, VB)), dim3(VB), 0, st, args, (F*)out, n);
+  CSH_HIP(hipGetLastError());
+  return CSH_OK;
+}
+
+}  // namespace csh
+
+using namespace csh;
+
+#define FR_DISPATCH(field_of, CALL)                                  \
+  switch (field_of) {                                                \
+    case CSH_BN254: { using F = Bn254Fr; return CALL; }              \
+    case CSH_BLS12_381: { using F = Bls381Fr; return CALL; }         \
+    default: set_error("unknown curve %d", (int)(field_of)); return CSH_ERR_INVALID; \
+  }
+
+extern "C" {
+
+int csh_vec_mul_dev(csh_curve_t f, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream) {
+  CSH_TRY(ensure_device());
+  hipStream_t st = resolve_stream(stream);
+  FR_DISPATCH(f, vec_mul_t<F>(a, b, out, n, st));
+}
+int csh_vec_add_dev(csh_curve_t f, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, uint32_t ncomp, void* stream) {
+  CSH_TRY(ensure_device());
+  hipStream_t st = resolve_stream(stream);
+  FR_DISPATCH(f, vec_addsub_t<F>(false, a, b, out, n * ncomp, st));
+}
+int csh_vec_sub_dev(csh_curve_t f, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, uint32_t ncomp, void* stream) {
+  CSH_TRY(ensure_device());
+  hipStream_t st = resolve_stream(stream);
+  FR_DISPATCH(f, vec_addsub_t<F>(true, a, b, out, n * ncomp, st));
+}
+int csh_vec_mul_table_dev(csh_curve_t f, uint64_t* v, const uint64_t* table, size_t n, uint32_t ncomp, void* stream) {
+  CSH_REQUIRE(ncomp >= 1 && ncomp <= 2, "ncomp must be 1 or 2");
+  CSH_TRY(ensure_device());
+  hipStream_t st = resolve_stream(stream);
+  FR_DISPATCH(f, vec_mul_table_t<F>(v, table, n, ncomp, st));
+}
+int csh_rep3_local_mul_vec_dev(csh_curve_t f, const uint64_t* l, const uint64_t* r, const uint64_t* m, uint64_t* out, size_t n, void* stream) {
+  CSH_TRY(ensure_device());
+  hipStream_t st = resolve_stream(stream);
+  FR_DISPATCH(f, rep3_local_mul_t<F>(l, r, m, out, n, st));
+}
+int csh_rep3_to_shamir_vec_dev(csh_curve_t f, const uint64_t* in, const uint64_t x[4], const uint64_t y[4], uint64_t* out, size_t n, void* stream) {
+  CSH_REQUIRE(x && y, "translation points are NULL");
+  CSH_TRY(ensure_device());
+  hipStream_t st = resolve_stream(stream);
+  FR_DISPATCH(f, rep3_to_shamir_t<F>(in, x, y, out, n, st));
+}
+int csh_lincomb_dev(csh_curve_t f, const uint64_t* const* shares, const uint64_t* coeffs, size_t k, uint64_t* out, size_t n, void* stream) {
+  CSH_REQUIRE(k >= 1 && k <= (size_t)MAX_LINCOMB, "lincomb: 1 <= k <= 16");
+  CSH_REQUIRE(shares && coeffs, "lincomb: NULL argument");
+  CSH_TRY(ensure_device());
+  hipStream_t st = resolve_stream(stream);
+  FR_DISPATCH(f, lincomb_t<F>(shares, coeffs, k, out, n, st));
+}
+
+// ---- host-pointer convenience wrappers: H2D, compute, D2H on the thread's stream (HostStage) -------
+int csh_vec_mul(csh_curve_t f, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+  HostStage h;
+  size_t eb = 32 * n;
+  CSH_TRY(h.begin(3 * Arena::padded(eb)));
+  uint64_t *da, *db, *dout;
+  CSH_TRY(h.up(da, a, eb));
+  CSH_TRY(h.up(db, b, eb));
+  CSH_TRY(h.up(dout, nullptr, eb));
+  CSH_TRY(csh_vec_mul_dev(f, da, db, dout, n, h.st));
+  return h.down(out, dout, eb);
+}
+static int addsub_host(bool sub, csh_curve_t f, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, uint32_t ncomp) {
+  HostStage h;
+  size_t eb = 32 * n * ncomp;
+  CSH_TRY(h.begin(3 * Arena::padded(eb)));
+  uint64_t *da, *db, *dout;
+  CSH_TRY(h.up(da, a, eb));
+  CSH_TRY(h.up(db, b, eb));
+  CSH_TRY(h.up(dout, nullptr, eb));
+  CSH_TRY(sub ? csh_vec_sub_dev(f, da, db, dout, n, ncomp, h.st) : csh_vec_add_dev(f, da, db, dout, n, ncomp, h.st));
+  return h.down(out, dout, eb);
+}
+int csh_vec_add(csh_curve_t f, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, uint32_t ncomp) {
+  return addsub_host(false, f, a, b, out, n, ncomp);
+}
+int csh_vec_sub(csh_curve_t f, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, uint32_t ncomp) {
+  return addsub_host(true, f, a, b, out, n, ncomp);
+}
+int csh_vec_mul_table(csh_curve_t f, uint64_t* v, const uint64_t* table, size_t n, uint32_t ncomp) {
+  HostStage h;
+  size_t vb = 32 * n * ncomp, tb = 32 * n;
+  CSH_TRY(h.begin(Arena::padded(vb) + Arena::padded(tb)));
+  uint64_t *dv, *dt;
+  CSH_TRY(h.up(dv, v, vb));
+  CSH_TRY(h.up(dt, table, tb));
+  CSH_TRY(csh_vec_mul_table_dev(f, dv, dt, n, ncomp, h.st));
+  return h.down(v, dv, vb);
+}
+int csh_rep3_local_mul_vec(csh_curve_t f, const uint64_t* l, const uint64_t* r, const uint64_t* m, uint64_t* out, size_t n) {
+  HostStage h;
+  size_t sb = 64 * n, eb = 32 * n;
+  CSH_TRY(h.begin(2 * Arena::padded(sb) + 2 * Arena::padded(eb)));
+  uint64_t *dl, *dr, *dm = nullptr, *dout;
+  CSH_TRY(h.up(dl, l, sb));
+  CSH_TRY(h.up(dr, r, sb));
+  if (m) CSH_TRY(h.up(dm, m, eb));
+  CSH_TRY(h.up(dout, nullptr, eb));
+  CSH_TRY(csh_rep3_local_mul_vec_dev(f, dl, dr, dm, dout, n, h.st));
+  return h.down(out, dout, eb);
+}
+int csh_rep3_to_shamir_vec(csh_curve_t f, const uint64_t* in, const uint64_t x[4], const uint64_t y[4], uint64_t* out, size_t n) {
+  HostStage h;
+  size_t sb = 64 * n, eb = 32 * n;
+  CSH_TRY(h.begin(Arena::padded(sb) + Arena::padded(eb)));
+  uint64_t *din, *dout;
+  CSH_TRY(h.up(din, in, sb));
+  CSH_TRY(h.up(dout, nullptr, eb));
+  CSH_TRY(csh_rep3_to_shamir_vec_dev(f, din, x, y, dout, n, h.st));
+  return h.down(out, dout, eb);
+}
+int csh_lincomb(csh_curve_t f, const uint64_t* const* shares, const uint64_t* coeffs, size_t k, uint64_t* out, size_t n) {
+  CSH_REQUIRE(k >= 1 && k <= (size_t)MAX_LINCOMB, "lincomb: 1 <= k <= 16");
+  CSH_REQUIRE(shares && coeffs, "lincomb: NULL argument");
+  HostStage h;
+  size_t eb = 32 * n;
+  CSH_TRY(h.begin((k + 1) * Arena::padded(eb)));
+  const uint64_t* dsh[MAX_LINCOMB];
+  for (size_t j = 0; j < k; ++j) {
+    uint64_t* d;
+    CSH_TRY(h.up(d, shares[j], eb));
+    dsh[j] = d;
+  }
+  uint64_t* dout;
+  CSH_TRY(h.up(dout, nullptr, eb));
+  CSH_TRY(csh_lincomb_dev(f, dsh, coeffs, k, dout, n, h.st));
+  return h.down(out, dout, eb);
+}
+
+}  // extern "C"

@@ -1,0 +1,188 @@
+/*
+ * cosnarks_hip.h -- C ABI of the MI355X (gfx950) proof-generation hot path for co-snarks.
+ *
+ * This is the drop-in boundary: the reference (TaceoLabs/co-snarks, 100 % Rust) has no FFI today; its
+ * hot path sits behind Rust traits/free functions whose arithmetic lives in the un-vendored crates
+ * taceo-ark-algebra 0.1.0 / ark-poly 0.6.0.  Each entry point below names the reference interface it
+ * replaces (paths relative to the reference root).  INTEGRATION.md shows the Rust `extern "C"` block and
+ * the trait implementors (`HipCircomReduction: R1CSToQAP`, `Hip*Groth16Driver: CircomGroth16Prover`)
+ * that bind it.
+ *
+ * Data conventions (identical to arkworks' in-memory layout, so Rust slices can be passed as-is):
+ *  - field element  = N64 little-endian u64 limbs of x*R mod p (Montgomery, R = 2^(64*N64));
+ *                     Fr: 4 limbs (32 B) on both curves; Fq: 4 limbs (BN254) / 6 limbs (BLS12-381).
+ *  - affine point   = x || y (G2: x.c0 || x.c1 || y.c0 || y.c1), Montgomery; infinity = all-zero bytes
+ *                     (the zkey convention).  `stride_bytes` lets the caller pass arkworks `Affine`
+ *                     (x, y, infinity flag, padding) without repacking -- the flag byte is ignored.
+ *  - result point   = arkworks `Projective` = Jacobian (X, Y, Z), Montgomery; infinity = (1, 1, 0).
+ *                     The library always returns Z in {0, 1} (normalised), which is a valid Jacobian
+ *                     representative; the reference compares/serialises affine forms only
+ *                     (co-circom/co-groth16/src/groth16.rs:333-337).
+ *  - Rep3 share     = {a, b} = 2 consecutive Fr elements (64 B)
+ *                     (mpc-core/src/protocols/rep3/arithmetic/types.rs:21-28).
+ *  - Shamir share   = 1 Fr element (repr(transparent), shamir/arithmetic/types.rs:9-13).
+ *
+ * Pointers named `*_dev` / functions suffixed `_dev` take DEVICE pointers and a HIP stream (NULL = the
+ * library's per-thread stream) and are asynchronous unless they return data to the host; all other
+ * pointers are HOST pointers and the call is synchronous.  All functions return 0 on success or a
+ * negative csh_status; csh_last_error() returns a thread-local message.  Every entry point is
+ * re-entrant and thread-safe (the reference calls MSMs/NTTs concurrently from rayon workers:
+ * groth16.rs:227-294, reduction.rs:135-178).  There is no CPU fallback: without a HIP device every
+ * compute entry point fails with CSH_ERR_NO_DEVICE.
+ */
+#ifndef COSNARKS_HIP_H
+#define COSNARKS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { CSH_BN254 = 0, CSH_BLS12_381 = 1 } csh_curve_t;
+typedef enum { CSH_G1 = 0, CSH_G2 = 1 } csh_group_t;
+
+typedef enum {
+  CSH_OK = 0,
+  CSH_ERR_INVALID = -1,    /* bad argument */
+  CSH_ERR_NO_DEVICE = -2,  /* no HIP device / runtime failure at init */
+  CSH_ERR_HIP = -3,        /* a HIP runtime call failed (see csh_last_error) */
+  CSH_ERR_OOM = -4,
+  CSH_ERR_DOMAIN = -5      /* "Polynomial Degree too large" (reduction.rs:87-94) */
+} csh_status;
+
+typedef struct csh_bases_s* csh_bases_t;   /* proving-key query resident on the device */
+typedef struct csh_domain_s* csh_domain_t; /* radix-2 evaluation domain (twiddles on device) */
+
+/* ---- context ------------------------------------------------------------------------------- */
+int csh_init(int device);            /* select device for the calling thread, create context lazily */
+int csh_shutdown(void);              /* free all cached workspaces/streams of every device */
+const char* csh_last_error(void);
+const char* csh_version(void);
+int csh_device_count(int* count);
+
+/* plain device-memory plumbing for harnesses without their own HIP binding (tests, the Rust shim) */
+int csh_malloc(void** dev_ptr, size_t bytes);
+int csh_free(void* dev_ptr);
+int csh_memcpy_h2d(void* dev_dst, const void* host_src, size_t bytes);
+int csh_memcpy_d2h(void* host_dst, const void* dev_src, size_t bytes);
+int csh_sync(void* stream);
+
+/* ---- MSM ------------------------------------------------------------------------------------
+ * Replaces taceo_ark_algebra::msm::msm_unchecked(&[Affine<C>], &[F]) -> Projective<C> and
+ * msm::msm_bigint(&[Affine<C>], &[F::BigInt]); call sites groth16.rs:193-194, mpc/plain.rs:66-74,
+ * mpc/rep3.rs:124-132, mpc/shamir.rs:111-119, mpc-core/src/protocols/rep3/pointshare.rs:201-222,
+ * shamir/pointshare.rs:207-225, co-noir/co-noir-common/src/honk_curve.rs:81-83.
+ * Bases (ProvingKey queries a_query/b_g1_query/b_g2_query/l_query/h_query, groth16.rs:219-290) are
+ * uploaded once and reused across proofs. */
+int csh_bases_upload(csh_curve_t curve, csh_group_t group, const void* affine_points, size_t n,
+                     size_t stride_bytes /* 0 = packed */, csh_bases_t* out);
+int csh_bases_upload_dev(csh_curve_t curve, csh_group_t group, const void* affine_points_dev, size_t n,
+                         size_t stride_bytes, void* stream, csh_bases_t* out);
+int csh_bases_len(csh_bases_t bases, size_t* n);
+int csh_bases_free(csh_bases_t bases);
+
+/* sum_{i<n} scalars[i] * bases[offset+i].  "unchecked": the caller passes the shorter length
+ * (honk_curve.rs:33-34).  scalars_are_montgomery=1 <=> msm_unchecked (&[F]); 0 <=> msm_bigint.
+ * out_jacobian: 3 base-field elements (X, Y, Z) on the host. */
+int csh_msm(csh_bases_t bases, size_t offset, size_t n, const uint64_t* scalars,
+            int scalars_are_montgomery, void* out_jacobian);
+int csh_msm_dev(csh_bases_t bases, size_t offset, size_t n, const uint64_t* scalars_dev,
+                int scalars_are_montgomery, void* out_jacobian_host, void* stream);
+/* Split-MSM support (one MSM over several GPUs): the un-normalised partial result as
+ * `nwindows` XYZZ points (4 base-field elements each) left ON THE DEVICE for an RCCL all-gather, and the
+ * host-side fold of gathered partials. */
+int csh_msm_partial_dev(csh_bases_t bases, size_t offset, size_t n, const uint64_t* scalars_dev,
+                        int scalars_are_montgomery, void* out_xyzz_dev /* csh_msm_partial_bytes */,
+                        void* stream);
+int csh_msm_partial_bytes(csh_curve_t curve, csh_group_t group, size_t* bytes);
+int csh_msm_fold_partials(csh_curve_t curve, csh_group_t group, const void* partials_host, size_t nparts,
+                          void* out_jacobian);
+
+/* ---- NTT ------------------------------------------------------------------------------------
+ * Replaces taceo_ark_algebra::fft::Domain<F>::{new, with_group_gen, size, ifft_in_to_out,
+ * fft_out_to_in}, fft::bit_reverse (reduction.rs:10, 93, 141-174, 249-328) and
+ * ark_poly::EvaluationDomain::{fft, ifft} (co-plonk/src/mpc/plain.rs:149-161).
+ * `ncomp` = field elements per entry: 1 for F / Shamir shares, 2 for Rep3 shares (DomainCoeff<F>). */
+int csh_domain_create(csh_curve_t field_of, uint32_t log_n, const uint64_t group_gen[4] /* Montgomery; NULL =
+                      arkworks default 2-adic root (Domain::new) */, csh_domain_t* out);
+int csh_domain_size(csh_domain_t dom, size_t* n);
+int csh_domain_free(csh_domain_t dom);
+/* natural-order evaluations -> coefficients in bit-reversed order (scaled by 1/n) */
+int csh_ifft_in_to_out(csh_domain_t dom, uint64_t* data, uint32_t ncomp);
+/* bit-reversed coefficients -> natural-order evaluations */
+int csh_fft_out_to_in(csh_domain_t dom, uint64_t* data, uint32_t ncomp);
+/* natural -> natural (EvaluationDomain::{fft, ifft}); data holds exactly domain-size entries */
+int csh_fft(csh_domain_t dom, uint64_t* data, uint32_t ncomp);
+int csh_ifft(csh_domain_t dom, uint64_t* data, uint32_t ncomp);
+int csh_bit_reverse(csh_curve_t field_of, uint64_t* data, uint32_t log_n, uint32_t ncomp);
+/* bit_reversed_coset_table(shift, size) (reduction.rs:45-60): out[bitrev(i)] = shift^i */
+int csh_coset_table(csh_domain_t dom, const uint64_t shift[4], uint64_t* out);
+
+int csh_ifft_in_to_out_dev(csh_domain_t dom, uint64_t* data_dev, uint32_t ncomp, void* stream);
+int csh_fft_out_to_in_dev(csh_domain_t dom, uint64_t* data_dev, uint32_t ncomp, void* stream);
+int csh_fft_dev(csh_domain_t dom, uint64_t* data_dev, uint32_t ncomp, void* stream);
+int csh_ifft_dev(csh_domain_t dom, uint64_t* data_dev, uint32_t ncomp, void* stream);
+int csh_bit_reverse_dev(csh_curve_t field_of, uint64_t* data_dev, uint32_t log_n, uint32_t ncomp, void* stream);
+int csh_coset_table_dev(csh_domain_t dom, const uint64_t shift[4], uint64_t* out_dev, void* stream);
+
+/* ---- element-wise share arithmetic -----------------------------------------------------------
+ * `field_of` selects Fr of the curve.  n = number of entries. In-place allowed (out == an input). */
+/* out[i] = a[i]*b[i]: plain/Shamir local_mul_vec (mpc/plain.rs:83-89, shamir/arithmetic.rs:73-79) */
+int csh_vec_mul(csh_curve_t field_of, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+/* out[i] = a[i] +/- b[i], ncomp components per entry (reduction.rs:185-190, rep3/arithmetic.rs:61-82) */
+int csh_vec_add(csh_curve_t field_of, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, uint32_t ncomp);
+int csh_vec_sub(csh_curve_t field_of, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, uint32_t ncomp);
+/* v[i] *= table[i] for every component: distribute_powers_and_mul_by_const (mpc.rs:90-94,
+ * mpc/rep3.rs:95-106, mpc/shamir.rs:85-96, mpc/plain.rs:91-98; half-share form reduction.rs:166-171) */
+int csh_vec_mul_table(csh_curve_t field_of, uint64_t* v, const uint64_t* table, size_t n, uint32_t ncomp);
+/* out[i] = l.a*r.a + l.a*r.b + l.b*r.a + mask[i]: Rep3 local_mul_vec (rep3/arithmetic.rs:132-146,
+ * arithmetic/ops.rs:69-76); mask = Rep3Rand::masking_field_elements_vec (rngs.rs:137-156), NULL = 0 */
+int csh_rep3_local_mul_vec(csh_curve_t field_of, const uint64_t* lhs_ab, const uint64_t* rhs_ab,
+                           const uint64_t* mask, uint64_t* out, size_t n);
+/* out[i] = in[i].a*x + in[i].b*y: translate_primefield_repshare_vec (bridges/rep3_to_shamir.rs:43-62) */
+int csh_rep3_to_shamir_vec(csh_curve_t field_of, const uint64_t* in_ab, const uint64_t x[4],
+                           const uint64_t y[4], uint64_t* out, size_t n);
+/* out[i] = sum_k coeffs[k] * shares[k][i]: Shamir reconstruct / open_vec (shamir.rs:483-491,
+ * shamir/arithmetic.rs:191-213); with coeffs = 1 it is Rep3 combine/open (rep3.rs:583-605,
+ * rep3/arithmetic.rs:249-271). `shares` = k host pointers. */
+int csh_lincomb(csh_curve_t field_of, const uint64_t* const* shares, const uint64_t* coeffs /* k*4 */,
+                size_t k, uint64_t* out, size_t n);
+
+int csh_vec_mul_dev(csh_curve_t field_of, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream);
+int csh_vec_add_dev(csh_curve_t field_of, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, uint32_t ncomp, void* stream);
+int csh_vec_sub_dev(csh_curve_t field_of, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, uint32_t ncomp, void* stream);
+int csh_vec_mul_table_dev(csh_curve_t field_of, uint64_t* v, const uint64_t* table, size_t n, uint32_t ncomp, void* stream);
+int csh_rep3_local_mul_vec_dev(csh_curve_t field_of, const uint64_t* lhs_ab, const uint64_t* rhs_ab,
+                               const uint64_t* mask, uint64_t* out, size_t n, void* stream);
+int csh_rep3_to_shamir_vec_dev(csh_curve_t field_of, const uint64_t* in_ab, const uint64_t x[4],
+                               const uint64_t y[4], uint64_t* out, size_t n, void* stream);
+int csh_lincomb_dev(csh_curve_t field_of, const uint64_t* const* shares_dev /* host array of k device ptrs */,
+                    const uint64_t* coeffs, size_t k, uint64_t* out, size_t n, void* stream);
+
+/* ---- fused CircomReduction tail (reduction.rs:135-192) -------------------------------------------
+ * Given the constraint evaluations a, b (natural order, n = domain size, ncomp comps per entry) computes
+ * h[i] = (A*B - C)(shift * w^i) entirely on the device: 6 NTTs + 2 local_mul_vec + 3 table muls + 1 sub.
+ * protocol: 0 plain / Shamir (ncomp 1, out = a*b), 1 Rep3 (ncomp 2, local mul with masks).
+ * mask_c / mask_ab: the two mask vectors drawn (in this order) by the two local_mul_vec calls
+ * (reduction.rs:160 then :182); NULL for protocol 0 or zero masks.  a and b are clobbered. */
+int csh_groth16_h(csh_domain_t dom, const uint64_t shift[4], int protocol, uint64_t* a, uint64_t* b,
+                  const uint64_t* mask_c, const uint64_t* mask_ab, uint64_t* h_out);
+int csh_groth16_h_dev(csh_domain_t dom, const uint64_t shift[4], int protocol, uint64_t* a_dev, uint64_t* b_dev,
+                      const uint64_t* mask_c_dev, const uint64_t* mask_ab_dev, uint64_t* h_out_dev, void* stream);
+
+/* ---- measurement hooks (bench.py / profiles) ----------------------------------------------------------
+ * HIP-event timing on the stream the kernels are launched on. */
+int csh_event_create(void** ev);
+int csh_event_record(void* ev, void* stream);
+int csh_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);
+int csh_event_destroy(void* ev);
+/* Per-MSM stage timings (ms) of the last csh_msm*_dev call on this thread: [digits+histogram, scan,
+ * scatter, bucket accumulate, bucket reduce, total]; valid only when CSH_MSM_TIMING=1 in the env. */
+int csh_msm_last_timing(float out_ms[6]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COSNARKS_HIP_H */

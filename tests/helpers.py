@@ -1,0 +1,65 @@
+"""Shared test helpers: seeded inputs and conversions between oracle ints and C-ABI limb arrays."""
+import random
+
+import numpy as np
+
+from oracle import curves as cv
+from oracle import fields as fl
+
+FIELD_IDS = {"bn254.Fq": 0, "bn254.Fr": 1, "bls12_381.Fq": 2, "bls12_381.Fr": 3}
+CURVE_IDS = {"bn254": 0, "bls12_381": 1}
+FR = {"bn254": fl.BN254_FR, "bls12_381": fl.BLS381_FR}
+
+
+def rng(seed):
+    return random.Random(seed)
+
+
+def rand_elems(F, n, r):
+    return [r.randrange(F.p) for _ in range(n)]
+
+
+def edge_elems(F):
+    return [0, 1, 2, F.p - 1, F.p - 2, (F.p - 1) // 2, (1 << 64) - 1, 1 << 64, F.Rmod, F.R2]
+
+
+def pack(F, xs, mont=True):
+    return fl.pack(F, xs, mont).reshape(-1)
+
+
+def unpack(F, arr, mont=True):
+    return fl.unpack(F, arr, mont)
+
+
+def pack_shares(F, shares):
+    """[(a, b)] -> AoS limbs {a, b} per entry."""
+    flat = []
+    for a, b in shares:
+        flat += [a, b]
+    return pack(F, flat)
+
+
+def unpack_shares(F, arr):
+    v = unpack(F, arr)
+    return list(zip(v[0::2], v[1::2]))
+
+
+def rand_points(curve: cv.Curve, n, r, with_inf=False):
+    """n points = random multiples of the generator (in the prime-order subgroup)."""
+    pts = []
+    base = curve.mul(curve.gen, r.randrange(1, curve.order))
+    step = curve.mul(curve.gen, r.randrange(1, curve.order))
+    cur = base
+    for i in range(n):
+        pts.append(cur)
+        cur = curve.add(cur, step)
+    if with_inf and n >= 4:
+        pts[1] = None
+        pts[n // 2] = None
+    return pts
+
+
+def jac_to_affine(curve: cv.Curve, limbs):
+    """C-ABI Jacobian output -> oracle affine point."""
+    (X, Y, Z), = cv.unpack_points(curve, np.asarray(limbs), ncoords=3)
+    return curve.to_affine((X, Y, Z))

@@ -1,0 +1,156 @@
+"""CPU tests: the host-executed instantiations of the kernels' field/curve templates vs the oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import curves as cv
+from oracle import fields as fl
+from tests import helpers as H
+
+FIELDS = [fl.BN254_FQ, fl.BN254_FR, fl.BLS381_FQ, fl.BLS381_FR]
+
+
+def _fop(hip, F, op, a, b=None):
+    L = hip.lib()
+    pa = H.pack(F, [a], mont=False)
+    pb = H.pack(F, [b], mont=False) if b is not None else None
+    out = np.zeros(F.nlimbs, dtype=np.uint64)
+    rc = L.csh_selftest_field_op(H.FIELD_IDS[F.name], op, pa.ctypes.data_as(C.c_void_p),
+                                 pb.ctypes.data_as(C.c_void_p) if pb is not None else None, out.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+    return fl.limbs_to_int(out)
+
+
+@pytest.mark.parametrize("F", FIELDS, ids=lambda f: f.name)
+def test_field_ops_match_oracle(hip, F):
+    r = H.rng(11)
+    vals = H.edge_elems(F) + H.rand_elems(F, 40, r)
+    vals = [v % F.p for v in vals]
+    for i, a in enumerate(vals):
+        b = vals[(i * 7 + 3) % len(vals)]
+        am, bm = F.to_mont(a), F.to_mont(b)
+        assert _fop(hip, F, 0, am, bm) == F.to_mont((a + b) % F.p)
+        assert _fop(hip, F, 1, am, bm) == F.to_mont((a - b) % F.p)
+        assert _fop(hip, F, 2, am, bm) == F.to_mont(a * b % F.p)
+        assert _fop(hip, F, 7, am) == F.to_mont(a * a % F.p)
+        assert _fop(hip, F, 6, am) == F.to_mont(-a % F.p)
+        assert _fop(hip, F, 4, am) == a          # from_mont
+        assert _fop(hip, F, 5, a) == am          # to_mont
+    for a in vals[:12]:
+        if a:
+            assert _fop(hip, F, 3, F.to_mont(a)) == F.to_mont(pow(a, -1, F.p))
+
+
+def test_bn254_fr_mul_known_answer(hip):
+    """The four products hard-coded by the reference: tests/tests/mpc/rep3.rs:286-345."""
+    F = fl.BN254_FR
+    x = [13839525561076761625780930844889299788193703994911163378019280196128582690055,
+         19302971480864839163158232064620707211435225928426123775531639309944891593977,
+         8048717310762513532550620831072439583505607813129662608591015555880153427210,
+         2585271390974436123003027749932103593962191064365118925254473311197989280023]
+    y = [2688648969035332064113669477511029957484512453056743431884706385750388613065,
+         13632770404954969699480437686769008635735921498648460325387842712839596176806,
+         19199593902803943133889170931116903997086625101975591190159463567024116566625,
+         8255472466884305547009533395117607586789669747151273739964395707537515634749]
+    z = [14012338922664984944451142760937475581748095944353358534203030914664561190462,
+         4297594441150501195973997511775989720904927516253689527653694984160382713321,
+         7875903949174289914141782934879682497141865775307179984684659764891697566272,
+         6646526994769136778802685410292764833027657364709823469005920616147071273574]
+    for a, b, c in zip(x, y, z):
+        assert a * b % F.p == c                                   # oracle arithmetic
+        assert _fop(hip, F, 2, F.to_mont(a), F.to_mont(b)) == F.to_mont(c)
+
+
+@pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
+def test_fp2_ops(hip, curve):
+    G2 = cv.CURVES[curve][1]
+    F2, Fq = G2.F, G2.F.base
+    L = hip.lib()
+    r = H.rng(5)
+    for _ in range(20):
+        a = (r.randrange(Fq.p), r.randrange(Fq.p))
+        b = (r.randrange(Fq.p), r.randrange(Fq.p))
+        pa, pb = H.pack(Fq, list(a)), H.pack(Fq, list(b))
+        for op, want in [(0, F2.add(a, b)), (1, F2.sub(a, b)), (2, F2.mul(a, b)), (7, F2.sqr(a)), (3, F2.inv(a)), (6, F2.neg(a))]:
+            out = np.zeros(2 * Fq.nlimbs, dtype=np.uint64)
+            assert L.csh_selftest_fp2_op(H.CURVE_IDS[curve], op, pa.ctypes.data_as(C.c_void_p), pb.ctypes.data_as(C.c_void_p),
+                                         out.ctypes.data_as(C.c_void_p)) == 0
+            assert tuple(H.unpack(Fq, out)) == want
+
+
+def _xyzz_to_affine(hip, curve_id, group, curve, xyzz):
+    out = np.zeros(hip.point_bytes(curve_id, group) // 8, dtype=np.uint64)
+    assert hip.lib().csh_selftest_curve_op(curve_id, group, 4, xyzz.ctypes.data_as(C.c_void_p), None, 0, out.ctypes.data_as(C.c_void_p)) == 0
+    return cv.unpack_points(curve, out)[0]
+
+
+@pytest.mark.parametrize("curve,group", [("bn254", 0), ("bn254", 1), ("bls12_381", 0), ("bls12_381", 1)])
+def test_xyzz_group_law(hip, curve, group):
+    G = cv.CURVES[curve][group]
+    cid = H.CURVE_IDS[curve]
+    L = hip.lib()
+    r = H.rng(3)
+    pts = H.rand_points(G, 6, r)
+    pb = hip.point_bytes(cid, group)
+    acc = np.zeros(2 * pb // 8, dtype=np.uint64)     # XYZZ infinity (all zero)
+    want = None
+    # sequence covers: inf + P, P + Q, P + P (doubling branch), P + (-P) (-> inf), inf handling
+    seq = [pts[0], pts[1], pts[1], pts[2], None, pts[3]]
+    for P in seq:
+        ap = cv.pack_points(G, [P]).reshape(-1)
+        out = np.zeros_like(acc)
+        assert L.csh_selftest_curve_op(cid, group, 0, acc.ctypes.data_as(C.c_void_p), ap.ctypes.data_as(C.c_void_p), 0, out.ctypes.data_as(C.c_void_p)) == 0
+        acc = out
+        want = G.add(want, P)
+        assert G.eq(_xyzz_to_affine(hip, cid, group, G, acc), want)
+    # P + P via madd when acc == P
+    accP = np.zeros_like(acc)
+    ap = cv.pack_points(G, [pts[4]]).reshape(-1)
+    assert L.csh_selftest_curve_op(cid, group, 5, ap.ctypes.data_as(C.c_void_p), None, 0, accP.ctypes.data_as(C.c_void_p)) == 0
+    out = np.zeros_like(acc)
+    assert L.csh_selftest_curve_op(cid, group, 0, accP.ctypes.data_as(C.c_void_p), ap.ctypes.data_as(C.c_void_p), 0, out.ctypes.data_as(C.c_void_p)) == 0
+    assert G.eq(_xyzz_to_affine(hip, cid, group, G, out), G.double(pts[4]))
+    # P + (-P)
+    an = cv.pack_points(G, [G.neg(pts[4])]).reshape(-1)
+    assert L.csh_selftest_curve_op(cid, group, 0, accP.ctypes.data_as(C.c_void_p), an.ctypes.data_as(C.c_void_p), 0, out.ctypes.data_as(C.c_void_p)) == 0
+    assert _xyzz_to_affine(hip, cid, group, G, out) is None
+    # general add, doubling, small multiples
+    out2 = np.zeros_like(acc)
+    assert L.csh_selftest_curve_op(cid, group, 1, acc.ctypes.data_as(C.c_void_p), accP.ctypes.data_as(C.c_void_p), 0, out2.ctypes.data_as(C.c_void_p)) == 0
+    assert G.eq(_xyzz_to_affine(hip, cid, group, G, out2), G.add(want, pts[4]))
+    assert L.csh_selftest_curve_op(cid, group, 1, acc.ctypes.data_as(C.c_void_p), acc.ctypes.data_as(C.c_void_p), 0, out2.ctypes.data_as(C.c_void_p)) == 0
+    assert G.eq(_xyzz_to_affine(hip, cid, group, G, out2), G.double(want))
+    assert L.csh_selftest_curve_op(cid, group, 2, acc.ctypes.data_as(C.c_void_p), None, 0, out2.ctypes.data_as(C.c_void_p)) == 0
+    assert G.eq(_xyzz_to_affine(hip, cid, group, G, out2), G.double(want))
+    for k in [0, 1, 2, 3, 7, 1000, 32768, 65535]:
+        assert L.csh_selftest_curve_op(cid, group, 3, acc.ctypes.data_as(C.c_void_p), None, k, out2.ctypes.data_as(C.c_void_p)) == 0
+        assert G.eq(_xyzz_to_affine(hip, cid, group, G, out2), G.mul(want, k))
+
+
+@pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
+@pytest.mark.parametrize("c", [2, 3, 4, 7, 11, 13, 16, 17, 20])
+def test_signed_digit_recoding(hip, curve, c):
+    F = H.FR[curve]
+    r = H.rng(c)
+    vals = [0, 1, F.p - 1, F.p - 2, (1 << (c - 1)), (1 << (c - 1)) + 1, (1 << c) - 1, (F.p - 1) // 2] + H.rand_elems(F, 50, r)
+    for s in vals:
+        digits = (C.c_int32 * 200)()
+        W = C.c_int(0)
+        sc = H.pack(F, [s], mont=False)
+        assert hip.lib().csh_selftest_digits(H.CURVE_IDS[curve], sc.ctypes.data_as(C.c_void_p), c, digits, C.byref(W)) == 0
+        d = list(digits)[:W.value]
+        assert all(abs(x) <= 1 << (c - 1) for x in d)
+        assert sum(x << (c * w) for w, x in enumerate(d)) == s
+
+
+def test_lazy29_mul_matches_montgomery32(hip):
+    F = fl.BN254_FQ
+    r = H.rng(29)
+    vals = [v % F.p for v in H.edge_elems(F)] + H.rand_elems(F, 200, r)
+    for i, a in enumerate(vals):
+        b = vals[(i * 5 + 1) % len(vals)]
+        pa, pb = H.pack(F, [a]), H.pack(F, [b])
+        out = np.zeros(4, dtype=np.uint64)
+        assert hip.lib().csh_test_mul29_host(pa.ctypes.data_as(C.c_void_p), pb.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)) == 0
+        assert H.unpack(F, out) == [a * b % F.p]
