@@ -182,6 +182,13 @@ int csh_event_destroy(void* ev);
  * scatter, bucket accumulate, bucket reduce, total]; valid only when CSH_MSM_TIMING=1 in the env. */
 int csh_msm_last_timing(float out_ms[6]);
 
+/* ---- synthetic inputs (bench / full-size parity) -------------------------------------------------------
+ * out[i] = k_i * G (affine, packed), k_i = csh_util_splitmix64(seed + i) | 1: known discrete logs, so an MSM
+ * over them has the closed form (sum_i s_i k_i mod r) * G at any size (SURVEY 8d "known-dlog" family). */
+uint64_t csh_util_splitmix64(uint64_t x);
+int csh_util_generate_bases_dev(csh_curve_t curve, csh_group_t group, uint64_t seed, size_t n, void* out_dev,
+                                void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,168 @@
+"""GPU parity (through the C ABI): MSM vs the oracle on all four groups. Bit-exact on the affine result."""
+import numpy as np
+import pytest
+
+from oracle import curves as cv
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+GROUPS = [("bn254", 0), ("bn254", 1), ("bls12_381", 0), ("bls12_381", 1)]
+
+
+def _run(gpu, curve, group, pts, scalars, montgomery=True, offset=0, n=None):
+    G = cv.CURVES[curve][group]
+    F = H.FR[curve]
+    bases = gpu.Bases(H.CURVE_IDS[curve], group, cv.pack_points(G, pts))
+    out = bases.msm(H.pack(F, scalars, mont=montgomery), offset=offset, n=n, montgomery=montgomery)
+    bases.free()
+    return H.jac_to_affine(G, out)
+
+
+@pytest.mark.parametrize("curve,group", GROUPS)
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 33, 257])
+def test_msm_small_matches_oracle(gpu, curve, group, n):
+    G = cv.CURVES[curve][group]
+    F = H.FR[curve]
+    r = H.rng(1000 + n + group)
+    pts = H.rand_points(G, n, r)
+    sc = H.rand_elems(F, n, r)
+    assert G.eq(_run(gpu, curve, group, pts, sc), G.msm(pts, sc))
+    # msm_bigint semantics: canonical (non-Montgomery) scalars give the same group element
+    assert G.eq(_run(gpu, curve, group, pts, sc, montgomery=False), G.msm(pts, sc))
+
+
+@pytest.mark.parametrize("curve,group", GROUPS)
+def test_msm_edge_cases(gpu, curve, group):
+    """Edge suites of SURVEY 8d config 2: zero/one/r-1/small scalars, duplicates, P and -P, infinity bases
+    (the zkey queries contain points at infinity: multiplier2 A-query[3])."""
+    G = cv.CURVES[curve][group]
+    F = H.FR[curve]
+    r = H.rng(42 + group)
+    n = 64
+    pts = H.rand_points(G, n, r, with_inf=True)
+    pts[10] = pts[11]                      # duplicate point
+    pts[20] = G.neg(pts[21])               # P and -P
+    suites = {
+        "zeros": [0] * n,
+        "ones": [1] * n,
+        "r-1": [F.p - 1] * n,
+        "small64": [r.randrange(1 << 64) for _ in range(n)],
+        "mixed": [0, 1, F.p - 1, 2, (F.p - 1) // 2, (F.p + 1) // 2] * 10 + [5, 6, 7, 8],
+        "equal_cancel": [7] * n,
+    }
+    for name, sc in suites.items():
+        got = _run(gpu, curve, group, pts, sc)
+        assert G.eq(got, G.msm(pts, sc)), name
+    # all-infinity bases and empty slices
+    assert _run(gpu, curve, group, [None] * 8, [3] * 8) is None
+    # offset / sub-slice ("unchecked": the caller passes the shorter length, honk_curve.rs:33-34)
+    sc = H.rand_elems(F, n, r)
+    assert G.eq(_run(gpu, curve, group, pts, sc[:20], offset=7, n=20), G.msm(pts[7:27], sc[:20]))
+
+
+def test_msm_window_sizes(gpu, monkeypatch):
+    """Every window width the heuristic can choose gives the same element (CSH_MSM_C forces c)."""
+    G = cv.BN254_G1
+    F = H.FR["bn254"]
+    r = H.rng(8)
+    n = 300
+    pts = H.rand_points(G, n, r, with_inf=True)
+    sc = H.rand_elems(F, n, r)
+    want = G.msm(pts, sc)
+    for c in [2, 3, 5, 8, 11, 13, 16, 17, 20]:
+        monkeypatch.setenv("CSH_MSM_C", str(c))
+        assert G.eq(_run(gpu, "bn254", 0, pts, sc), want), c
+    monkeypatch.delenv("CSH_MSM_C")
+    # tiny task length: forces many tasks per bucket (the skew path) on a skewed scalar set
+    monkeypatch.setenv("CSH_MSM_L", "3")
+    sk = [1] * 150 + [F.p - 1] * 100 + sc[:50]
+    assert G.eq(_run(gpu, "bn254", 0, pts, sk), G.msm(pts, sk))
+
+
+def test_msm_arkworks_affine_stride(gpu):
+    """Bases passed with a stride (arkworks Affine = x, y, infinity flag + padding) need no repacking."""
+    G = cv.BN254_G1
+    F = H.FR["bn254"]
+    r = H.rng(77)
+    n = 50
+    pts = H.rand_points(G, n, r)
+    sc = H.rand_elems(F, n, r)
+    packed = cv.pack_points(G, pts)                          # (n, 8) u64
+    strided = np.zeros((n, 9), dtype=np.uint64)              # 72-byte stride
+    strided[:, :8] = packed
+    strided[:, 8] = 0xDEADBEEF                               # junk where the flag/padding lives
+    bases = gpu.Bases(0, 0, strided, stride_bytes=72)
+    got = H.jac_to_affine(G, bases.msm(H.pack(F, sc)))
+    assert G.eq(got, G.msm(pts, sc))
+
+
+@pytest.mark.parametrize("curve,group,logn", [("bn254", 0, 20), ("bn254", 1, 16), ("bls12_381", 0, 16), ("bls12_381", 1, 14)])
+def test_msm_large_tiled_bases(gpu, curve, group, logn):
+    """BASELINE config 2 size (2^20 for BN254 G1): k distinct bases tiled to n entries, uniform scalars.
+    MSM = sum_j (sum_{i = j mod k} s_i) * P_j, which the oracle evaluates as a k-point MSM."""
+    G = cv.CURVES[curve][group]
+    F = H.FR[curve]
+    r = H.rng(2020 + group)
+    k = 256
+    n = 1 << logn
+    pts = H.rand_points(G, k, r, with_inf=True)
+    tiled = np.tile(cv.pack_points(G, pts), (n // k, 1))
+    rs = np.random.RandomState(7)
+    limbs = rs.randint(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    limbs[:, 3] >>= np.uint64(3)                             # canonical values < 2^253 < r
+    bases = gpu.Bases(H.CURVE_IDS[curve], group, tiled)
+    got = H.jac_to_affine(G, bases.msm(limbs, montgomery=False))
+    # column sums of the scalars, exact big-int arithmetic via 32-bit halves
+    lo = (limbs & np.uint64(0xFFFFFFFF)).reshape(n // k, k, 4)
+    hi = (limbs >> np.uint64(32)).reshape(n // k, k, 4)
+    slo, shi = lo.sum(axis=0, dtype=np.uint64), hi.sum(axis=0, dtype=np.uint64)   # < 2^32 * 2^12: no overflow
+    sums = []
+    for j in range(k):
+        v = 0
+        for l in range(4):
+            v += (int(slo[j, l]) + (int(shi[j, l]) << 32)) << (64 * l)
+        sums.append(v % F.p)
+    assert G.eq(got, G.msm(pts, sums))
+
+
+def _gen_bases(gpu, curve, group, seed, n):
+    import ctypes as C
+    cid = H.CURVE_IDS[curve]
+    buf = gpu.DeviceBuffer(n * gpu.point_bytes(cid, group))
+    gpu.bindings._check(gpu.lib().csh_util_generate_bases_dev(cid, group, C.c_uint64(seed), C.c_size_t(n), buf.ptr, None))
+    gpu.bindings.sync()
+    return buf
+
+
+@pytest.mark.parametrize("curve,group", GROUPS)
+def test_generated_bases_have_known_dlog(gpu, curve, group):
+    from tests.check_closed_form import dlogs
+    G = cv.CURVES[curve][group]
+    n = 5
+    buf = _gen_bases(gpu, curve, group, 99, n)
+    pts = cv.unpack_points(G, buf.to_host())
+    ks = dlogs(99, n)
+    for P, k in zip(pts, ks):
+        assert G.eq(P, G.mul(G.gen, int(k)))
+
+
+@pytest.mark.parametrize("curve,group,logn", [("bn254", 0, 20), ("bn254", 0, 22), ("bls12_381", 0, 18), ("bn254", 1, 17), ("bls12_381", 1, 16)])
+def test_msm_closed_form_full_size(gpu, curve, group, logn):
+    """Known-dlog bases: MSM == (sum s_i k_i) G at BASELINE sizes, uniform scalars, Montgomery input."""
+    import ctypes as C
+    from tests.check_closed_form import closed_form_point
+    G = cv.CURVES[curve][group]
+    cid = H.CURVE_IDS[curve]
+    n = 1 << logn
+    seed = 0xC0FFEE + logn
+    buf = _gen_bases(gpu, curve, group, seed, n)
+    h = C.c_void_p()
+    gpu.bindings._check(gpu.lib().csh_bases_upload_dev(cid, group, buf.ptr, C.c_size_t(n), C.c_size_t(0), None, C.byref(h)))
+    buf.free()
+    rs = np.random.RandomState(logn)
+    limbs = rs.randint(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    limbs[:, 3] >>= np.uint64(3)
+    out = np.zeros(3 * gpu.point_bytes(cid, group) // 16, dtype=np.uint64)
+    gpu.bindings._check(gpu.lib().csh_msm(h, C.c_size_t(0), C.c_size_t(n), limbs.ctypes.data_as(C.c_void_p), 1, out.ctypes.data_as(C.c_void_p)))
+    gpu.lib().csh_bases_free(h)
+    assert G.eq(H.jac_to_affine(G, out), closed_form_point(curve, group, seed, n, limbs, True))

@@ -1,0 +1,151 @@
+"""GPU parity (through the C ABI): share-vector arithmetic and NTT vs the oracle. Bit-exact."""
+import numpy as np
+import pytest
+
+from oracle import fields as fl
+from oracle import mpc, ntt
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+CURVES = ["bn254", "bls12_381"]
+
+
+@pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("n", [0, 1, 7, 1000, 4097])
+def test_vec_ops(gpu, curve, n):
+    F = H.FR[curve]
+    cid = H.CURVE_IDS[curve]
+    r = H.rng(100 + n)
+    edge = [v % F.p for v in H.edge_elems(F)]
+    a = (edge + H.rand_elems(F, n, r))[:n]
+    b = (edge[::-1] + H.rand_elems(F, n, r))[:n]
+    pa, pb = H.pack(F, a), H.pack(F, b)
+    assert H.unpack(F, gpu.vec_mul(cid, pa, pb)) == [x * y % F.p for x, y in zip(a, b)]
+    assert H.unpack(F, gpu.vec_add(cid, pa, pb)) == [(x + y) % F.p for x, y in zip(a, b)]
+    assert H.unpack(F, gpu.vec_sub(cid, pa, pb)) == [(x - y) % F.p for x, y in zip(a, b)]
+    assert H.unpack(F, gpu.vec_mul_table(cid, pa, pb)) == [x * y % F.p for x, y in zip(a, b)]
+
+
+@pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("n", [0, 1, 10, 4095, 4096, 16384])   # sizes of tests/tests/mpc/bridges.rs:11-...
+def test_rep3_ops(gpu, curve, n):
+    F = H.FR[curve]
+    cid = H.CURVE_IDS[curve]
+    r = H.rng(200 + n)
+    lhs = [(r.randrange(F.p), r.randrange(F.p)) for _ in range(n)]
+    rhs = [(r.randrange(F.p), r.randrange(F.p)) for _ in range(n)]
+    masks = H.rand_elems(F, n, r)
+    pl, pr, pm = H.pack_shares(F, lhs), H.pack_shares(F, rhs), H.pack(F, masks)
+    assert H.unpack(F, gpu.rep3_local_mul_vec(cid, pl, pr, pm)) == mpc.rep3_local_mul_vec(F, lhs, rhs, masks)
+    assert H.unpack(F, gpu.rep3_local_mul_vec(cid, pl, pr, None)) == mpc.rep3_local_mul_vec(F, lhs, rhs, [0] * n)
+    tbl = H.rand_elems(F, n, r)
+    got = H.unpack_shares(F, gpu.vec_mul_table(cid, pl, H.pack(F, tbl), ncomp=2))
+    assert got == [mpc.rep3_mul_public(F, s, t) for s, t in zip(lhs, tbl)]
+    assert H.unpack_shares(F, gpu.vec_sub(cid, pl, pr, ncomp=2)) == [mpc.rep3_sub(F, x, y) for x, y in zip(lhs, rhs)]
+    for party in range(3):
+        x, y = mpc.rep3_to_shamir_points(F, party)
+        got = H.unpack(F, gpu.rep3_to_shamir_vec(cid, pl, H.pack(F, [x]), H.pack(F, [y])))
+        assert got == mpc.rep3_to_shamir_vec(F, lhs, party)
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_rep3_mul_and_shamir_reconstruct_roundtrip(gpu, curve):
+    """share -> local mul on 3 'parties' -> combine == plain product (tests/tests/mpc/rep3.rs:286-367);
+    Shamir share -> lincomb with Lagrange coefficients == secret (mpc-core shamir.rs:611-742)."""
+    F = H.FR[curve]
+    cid = H.CURVE_IDS[curve]
+    r = H.rng(77)
+    n = 513
+    xs, ys = H.rand_elems(F, n, r), H.rand_elems(F, n, r)
+    rnd = lambda: r.randrange(F.p)
+    sx, sy = mpc.rep3_share_vec(F, xs, rnd), mpc.rep3_share_vec(F, ys, rnd)
+    t = [H.rand_elems(F, n, r) for _ in range(3)]
+    outs = []
+    for p in range(3):
+        mask = [(t[p][i] - t[(p + 2) % 3][i]) % F.p for i in range(n)]
+        outs.append(gpu.rep3_local_mul_vec(cid, H.pack_shares(F, sx[p]), H.pack_shares(F, sy[p]), H.pack(F, mask)))
+    comb = gpu.lincomb(cid, outs, H.pack(F, [1, 1, 1]))
+    assert H.unpack(F, comb) == [a * b % F.p for a, b in zip(xs, ys)]
+    for (nparties, deg) in [(3, 1), (10, 6)]:
+        shares = [mpc.shamir_share(F, v, nparties, deg, rnd) for v in xs]      # per value: list of party shares
+        use = list(range(1, deg + 2))
+        lag = mpc.lagrange_from_coeff(F, use)
+        per_party = [H.pack(F, [s[p - 1] for s in shares]) for p in use]
+        assert H.unpack(F, gpu.lincomb(cid, per_party, H.pack(F, lag))) == xs
+
+
+def _domain(gpu, curve, logn):
+    F = H.FR[curve]
+    gen = ntt.roots_of_unity(F)[1][logn]
+    return gpu.Domain(H.CURVE_IDS[curve], logn, H.pack(F, [gen])), ntt.Domain(F, 1 << logn, gen)
+
+
+@pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("logn", [0, 1, 2, 3, 5, 8, 10, 11, 12, 13])
+def test_ntt_matches_oracle(gpu, curve, logn):
+    F = H.FR[curve]
+    r = H.rng(300 + logn)
+    n = 1 << logn
+    dg, do = _domain(gpu, curve, logn)
+    v = H.rand_elems(F, n, r)
+    pv = H.pack(F, v)
+    assert H.unpack(F, dg.ifft_in_to_out(pv)) == do.ifft_in_to_out(v)
+    assert H.unpack(F, dg.fft_out_to_in(pv)) == do.fft_out_to_in(v)
+    assert H.unpack(F, dg.fft(pv)) == do.fft(v)
+    assert H.unpack(F, dg.ifft(pv)) == do.ifft(v)
+    shift = ntt.groth16_roots_of_unity(F, logn)[1] if logn < F.two_adicity else 5
+    assert H.unpack(F, dg.coset_table(H.pack(F, [shift]))) == ntt.bit_reversed_coset_table(F, shift, n)
+    assert H.unpack(F, gpu.bindings.bit_reverse(H.CURVE_IDS[curve], pv, logn)) == ntt.bit_reverse(v)
+    # Rep3 shares: DomainCoeff on {a, b} = component-wise transform
+    sh = [(r.randrange(F.p), r.randrange(F.p)) for _ in range(n)]
+    got = H.unpack_shares(F, dg.ifft_in_to_out(H.pack_shares(F, sh), ncomp=2))
+    wa, wb = do.ifft_in_to_out([s[0] for s in sh]), do.ifft_in_to_out([s[1] for s in sh])
+    assert got == list(zip(wa, wb))
+    got = H.unpack_shares(F, dg.fft_out_to_in(H.pack_shares(F, sh), ncomp=2))
+    wa, wb = do.fft_out_to_in([s[0] for s in sh]), do.fft_out_to_in([s[1] for s in sh])
+    assert got == list(zip(wa, wb))
+
+
+def test_ntt_default_root_is_arkworks(gpu):
+    """Domain::new (reduction.rs:249): arkworks 2-adic root = GENERATOR^TRACE squared down; on BN254 it equals
+    the snarkjs root (both derive from 5), on BLS12-381 (generator 7) it does not."""
+    for curve, g in [("bn254", 5), ("bls12_381", 7)]:
+        F = H.FR[curve]
+        logn = 6
+        root = pow(ntt.arkworks_two_adic_root(F, g), 1 << (F.two_adicity - logn), F.p)
+        dg = gpu.Domain(H.CURVE_IDS[curve], logn, None)
+        do = ntt.Domain(F, 1 << logn, root)
+        v = H.rand_elems(F, 1 << logn, H.rng(9))
+        assert H.unpack(F, dg.fft_out_to_in(H.pack(F, v))) == do.fft_out_to_in(v)
+    assert pow(ntt.arkworks_two_adic_root(fl.BN254_FR, 5), 1 << (28 - 6), fl.BN254_FR.p) == ntt.roots_of_unity(fl.BN254_FR)[1][6]
+
+
+def test_ntt_degree_too_large(gpu):
+    with pytest.raises(gpu.CoSnarksHipError, match="Polynomial Degree too large"):
+        gpu.Domain(H.CURVE_IDS["bn254"], 29, None)
+
+
+@pytest.mark.parametrize("logn", [16, 22])
+def test_ntt_roundtrip_and_spot_checks_full_size(gpu, logn):
+    """BASELINE config 3: BN254 NTT 2^22 -- bit-exact round trip + random outputs re-derived by Horner."""
+    F = fl.BN254_FR
+    n = 1 << logn
+    rs = np.random.RandomState(1234)
+    # uniform-ish canonical values < 2^253 < r, stored as-is (any canonical residue is a valid Montgomery form)
+    limbs = rs.randint(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    limbs[:, 3] >>= np.uint64(3)
+    dg, do = _domain(gpu, "bn254", logn)
+    coeffs = dg.ifft_in_to_out(limbs)
+    back = dg.fft_out_to_in(coeffs)
+    assert np.array_equal(back.reshape(n, 4), limbs)
+    # spot-check: evaluations X[k] = sum_i c_i w^{ik}, with c in bit-reversed storage
+    vals = H.unpack(F, limbs)
+    cs = H.unpack(F, coeffs)
+    r = H.rng(5)
+    for k in ([0, 1, n - 1] if logn <= 16 else []) + [r.randrange(n) for _ in range(2)]:
+        wk = pow(do.gen, k, F.p)
+        acc, cur = 0, 1
+        for i in range(n):
+            acc = (acc + cs[ntt.bitrev(i, logn)] * cur) % F.p
+            cur = cur * wk % F.p
+        assert acc == vals[k]
