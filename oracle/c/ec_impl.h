@@ -1,0 +1,163 @@
+/* Short-Weierstrass (a = 0) group in Jacobian coordinates + Pippenger MSM, generic over the base field FE(name)
+ * and scalar field SF(name). Included once per group with EC(name), FE(name), SF(name), SF_BITS. ORACLE ONLY.
+ *
+ * Restates what the reference gets from ark-ec 0.6.0 (Jacobian `Projective`, mixed addition) and the published
+ * arkworks VariableBaseMSM shape behind taceo_ark_algebra::msm::msm_unchecked / msm_bigint (call sites:
+ * co-circom/co-groth16/src/groth16.rs:193-194, mpc/plain.rs:66-74, mpc/rep3.rs:124-132): window
+ * c = ln(n)+2 (3 below 32 points), unsigned c-bit digits, one bucket array per window, running-sum bucket
+ * reduction, Horner over windows; parallel over (window, point-chunk) tasks. Independent of the product code
+ * (which uses XYZZ coordinates, signed digits and a sort-based bucket layout). */
+typedef struct { FE(t) x, y; } EC(aff);          /* infinity = all-zero */
+typedef struct { FE(t) x, y, z; } EC(jac);       /* infinity: z = 0 */
+
+static inline int EC(aff_is_inf)(const EC(aff)* p) { return FE(is_zero)(&p->x) && FE(is_zero)(&p->y); }
+static inline void EC(jac_set_inf)(EC(jac)* p) { FE(set_one)(&p->x); FE(set_one)(&p->y); FE(set_zero)(&p->z); }
+static inline int EC(jac_is_inf)(const EC(jac)* p) { return FE(is_zero)(&p->z); }
+
+static void EC(jac_dbl)(EC(jac)* r, const EC(jac)* p) { /* dbl-2009-l */
+  if (EC(jac_is_inf)(p) || FE(is_zero)(&p->y)) { EC(jac_set_inf)(r); return; }
+  FE(t) A, B, C, D, E, F, t;
+  FE(sqr)(&A, &p->x); FE(sqr)(&B, &p->y); FE(sqr)(&C, &B);
+  FE(add)(&t, &p->x, &B); FE(sqr)(&t, &t); FE(sub)(&t, &t, &A); FE(sub)(&t, &t, &C); FE(dbl)(&D, &t);
+  FE(dbl)(&E, &A); FE(add)(&E, &E, &A);
+  FE(sqr)(&F, &E);
+  FE(t) x3, y3, z3;
+  FE(dbl)(&t, &D); FE(sub)(&x3, &F, &t);
+  FE(mul)(&z3, &p->y, &p->z); FE(dbl)(&z3, &z3);
+  FE(sub)(&t, &D, &x3); FE(mul)(&y3, &E, &t);
+  FE(dbl)(&t, &C); FE(dbl)(&t, &t); FE(dbl)(&t, &t); FE(sub)(&y3, &y3, &t);
+  r->x = x3; r->y = y3; r->z = z3;
+}
+
+static void EC(jac_add_mixed)(EC(jac)* r, const EC(jac)* p, const EC(aff)* q) { /* madd-2007-bl */
+  if (EC(aff_is_inf)(q)) { *r = *p; return; }
+  if (EC(jac_is_inf)(p)) { r->x = q->x; r->y = q->y; FE(set_one)(&r->z); return; }
+  FE(t) z1z1, u2, s2, h, hh, i, j, rr, v, t;
+  FE(sqr)(&z1z1, &p->z);
+  FE(mul)(&u2, &q->x, &z1z1);
+  FE(mul)(&s2, &q->y, &p->z); FE(mul)(&s2, &s2, &z1z1);
+  if (FE(eq)(&u2, &p->x)) {
+    if (FE(eq)(&s2, &p->y)) { EC(jac_dbl)(r, p); return; }
+    EC(jac_set_inf)(r); return;
+  }
+  FE(sub)(&h, &u2, &p->x);
+  FE(sqr)(&hh, &h);
+  FE(dbl)(&i, &hh); FE(dbl)(&i, &i);
+  FE(mul)(&j, &h, &i);
+  FE(sub)(&rr, &s2, &p->y); FE(dbl)(&rr, &rr);
+  FE(mul)(&v, &p->x, &i);
+  FE(t) x3, y3, z3;
+  FE(sqr)(&x3, &rr); FE(sub)(&x3, &x3, &j); FE(dbl)(&t, &v); FE(sub)(&x3, &x3, &t);
+  FE(sub)(&t, &v, &x3); FE(mul)(&y3, &rr, &t);
+  FE(mul)(&t, &p->y, &j); FE(dbl)(&t, &t); FE(sub)(&y3, &y3, &t);
+  FE(add)(&z3, &p->z, &h); FE(sqr)(&z3, &z3); FE(sub)(&z3, &z3, &z1z1); FE(sub)(&z3, &z3, &hh);
+  r->x = x3; r->y = y3; r->z = z3;
+}
+
+static void EC(jac_add)(EC(jac)* r, const EC(jac)* p, const EC(jac)* q) { /* add-2007-bl */
+  if (EC(jac_is_inf)(q)) { *r = *p; return; }
+  if (EC(jac_is_inf)(p)) { *r = *q; return; }
+  FE(t) z1z1, z2z2, u1, u2, s1, s2, h, i, j, rr, v, t;
+  FE(sqr)(&z1z1, &p->z); FE(sqr)(&z2z2, &q->z);
+  FE(mul)(&u1, &p->x, &z2z2); FE(mul)(&u2, &q->x, &z1z1);
+  FE(mul)(&s1, &p->y, &q->z); FE(mul)(&s1, &s1, &z2z2);
+  FE(mul)(&s2, &q->y, &p->z); FE(mul)(&s2, &s2, &z1z1);
+  if (FE(eq)(&u1, &u2)) {
+    if (FE(eq)(&s1, &s2)) { EC(jac_dbl)(r, p); return; }
+    EC(jac_set_inf)(r); return;
+  }
+  FE(sub)(&h, &u2, &u1);
+  FE(dbl)(&i, &h); FE(sqr)(&i, &i);
+  FE(mul)(&j, &h, &i);
+  FE(sub)(&rr, &s2, &s1); FE(dbl)(&rr, &rr);
+  FE(mul)(&v, &u1, &i);
+  FE(t) x3, y3, z3;
+  FE(sqr)(&x3, &rr); FE(sub)(&x3, &x3, &j); FE(dbl)(&t, &v); FE(sub)(&x3, &x3, &t);
+  FE(sub)(&t, &v, &x3); FE(mul)(&y3, &rr, &t);
+  FE(mul)(&t, &s1, &j); FE(dbl)(&t, &t); FE(sub)(&y3, &y3, &t);
+  FE(add)(&z3, &p->z, &q->z); FE(sqr)(&z3, &z3); FE(sub)(&z3, &z3, &z1z1); FE(sub)(&z3, &z3, &z2z2); FE(mul)(&z3, &z3, &h);
+  r->x = x3; r->y = y3; r->z = z3;
+}
+
+static void EC(jac_to_aff)(EC(aff)* r, const EC(jac)* p) {
+  if (EC(jac_is_inf)(p)) { FE(set_zero)(&r->x); FE(set_zero)(&r->y); return; }
+  FE(t) zi, zi2, zi3;
+  FE(inv)(&zi, &p->z); FE(sqr)(&zi2, &zi); FE(mul)(&zi3, &zi2, &zi);
+  FE(mul)(&r->x, &p->x, &zi2); FE(mul)(&r->y, &p->y, &zi3);
+}
+
+/* k * P, k a 64-bit integer */
+static void EC(mul_u64)(EC(jac)* r, const EC(aff)* p, uint64_t k) {
+  EC(jac) acc; EC(jac_set_inf)(&acc);
+  for (int b = 63; b >= 0; b--) {
+    EC(jac_dbl)(&acc, &acc);
+    if ((k >> b) & 1) EC(jac_add_mixed)(&acc, &acc, p);
+  }
+  *r = acc;
+}
+
+static inline uint32_t EC(digit)(const uint64_t* s, int bit, int c) {
+  int limb = bit >> 6, off = bit & 63;
+  if (limb >= SF_N) return 0;
+  unsigned __int128 two = s[limb];
+  if (limb + 1 < SF_N) two |= (unsigned __int128)s[limb + 1] << 64;
+  return (uint32_t)((uint64_t)(two >> off) & ((1ull << c) - 1));
+}
+
+/* out (affine) = sum scalars[i] * points[i]; scalars Montgomery (msm_unchecked) or canonical (msm_bigint) */
+static void EC(msm)(EC(aff)* out, const EC(aff)* points, const uint64_t* scalars, size_t n, int mont, int nthreads) {
+  EC(jac) total; EC(jac_set_inf)(&total);
+  if (n == 0) { EC(jac_to_aff)(out, &total); return; }
+  uint64_t* sc = (uint64_t*)malloc(n * SF_N * 8);
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+  for (size_t i = 0; i < n; i++) {
+    SF(t) v; memcpy(&v, scalars + i * SF_N, SF_N * 8);
+    if (mont) SF(from_mont)(&v, &v);
+    memcpy(sc + i * SF_N, &v, SF_N * 8);
+  }
+  int c = n < 32 ? 3 : (int)(log((double)n)) + 2;
+  int W = (SF_BITS + c - 1) / c;
+  int chunks = (nthreads + W - 1) / W;
+  if (chunks < 1) chunks = 1;
+  if ((size_t)chunks > n) chunks = (int)n;
+  size_t per = (n + chunks - 1) / chunks;
+  size_t nb = ((size_t)1 << c) - 1;
+  EC(jac)* wsum = (EC(jac)*)malloc(sizeof(EC(jac)) * W * chunks);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
+  for (int task = 0; task < W * chunks; task++) {
+    int w = task / chunks, ch = task % chunks;
+    size_t lo = (size_t)ch * per, hi = lo + per; if (hi > n) hi = n;
+    EC(jac)* buckets = (EC(jac)*)malloc(sizeof(EC(jac)) * nb);
+    for (size_t b = 0; b < nb; b++) EC(jac_set_inf)(&buckets[b]);
+    for (size_t i = lo; i < hi; i++) {
+      uint32_t d = EC(digit)(sc + i * SF_N, w * c, c);
+      if (d) EC(jac_add_mixed)(&buckets[d - 1], &buckets[d - 1], &points[i]);
+    }
+    EC(jac) running, acc; EC(jac_set_inf)(&running); EC(jac_set_inf)(&acc);
+    for (size_t b = nb; b-- > 0;) {
+      EC(jac_add)(&running, &running, &buckets[b]);
+      EC(jac_add)(&acc, &acc, &running);
+    }
+    wsum[task] = acc;
+    free(buckets);
+  }
+  for (int w = W - 1; w >= 0; w--) {
+    for (int k = 0; k < c; k++) EC(jac_dbl)(&total, &total);
+    for (int ch = 0; ch < chunks; ch++) EC(jac_add)(&total, &total, &wsum[w * chunks + ch]);
+  }
+  EC(jac_to_aff)(out, &total);
+  free(wsum); free(sc);
+}
+
+/* bases[i] = (splitmix64(seed+i)|1) * G (the product's csh_util_generate_bases_dev family) */
+static void EC(gen_bases)(EC(aff)* out, const EC(aff)* gen, uint64_t seed, size_t n, int nthreads) {
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+  for (size_t i = 0; i < n; i++) {
+    uint64_t x = seed + i + 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    x = (x ^ (x >> 31)) | 1ull;
+    EC(jac) j; EC(mul_u64)(&j, gen, x);
+    EC(jac_to_aff)(&out[i], &j);
+  }
+}
