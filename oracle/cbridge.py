@@ -1,0 +1,139 @@
+"""ctypes bridge to oracle/c/liboracle.so (the plain-C restatement). ORACLE / TEST INFRASTRUCTURE ONLY.
+
+Used by tests/ as the large-size checker and by bench.py's ``cpu_baseline`` leg (kind "port": the reference's
+Rust/arkworks path cannot be built here -- no Rust toolchain, un-vendored crates)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import time
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        p = os.path.join(_HERE, "c", "liboracle.so")
+        if not os.path.exists(p):
+            subprocess.run(["make", "-s", "-C", os.path.join(_HERE, "c")], check=True)
+        _LIB = C.CDLL(p)
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def num_threads() -> int:
+    return lib().oc_num_threads()
+
+
+def point_words(curve: int, group: int) -> int:
+    return (4 if curve == 0 else 6) * 2 * (2 if group else 1)
+
+
+def msm(curve: int, group: int, points, scalars, montgomery=True, threads=0):
+    pts = np.ascontiguousarray(points, dtype=np.uint64)
+    sc = np.ascontiguousarray(scalars, dtype=np.uint64)
+    n = sc.size // 4
+    out = np.zeros(point_words(curve, group), dtype=np.uint64)
+    assert lib().oc_msm(curve, group, _p(pts), _p(sc), C.c_size_t(n), int(montgomery), threads, _p(out)) == 0
+    return out
+
+
+def generate_bases(curve: int, group: int, seed: int, n: int, threads=0):
+    out = np.zeros((n, point_words(curve, group)), dtype=np.uint64)
+    assert lib().oc_generate_bases(curve, group, C.c_uint64(seed), C.c_size_t(n), threads, _p(out)) == 0
+    return out
+
+
+def ntt(curve: int, data, logn: int, gen, ncomp=1, dif=False, threads=0):
+    d = np.ascontiguousarray(data, dtype=np.uint64).copy()
+    g = np.ascontiguousarray(gen, dtype=np.uint64)
+    assert lib().oc_ntt(curve, _p(d), logn, _p(g), ncomp, int(dif), threads) == 0
+    return d
+
+
+def bit_reverse(data, logn: int, ncomp=1):
+    d = np.ascontiguousarray(data, dtype=np.uint64).copy()
+    lib().oc_bit_reverse(_p(d), logn, ncomp)
+    return d
+
+
+def coset_table(curve: int, shift, logn: int):
+    out = np.zeros((1 << logn) * 4, dtype=np.uint64)
+    s = np.ascontiguousarray(shift, dtype=np.uint64)
+    lib().oc_coset_table(curve, _p(s), logn, _p(out))
+    return out
+
+
+def vec_mul(curve, a, b, threads=0):
+    a, b = np.ascontiguousarray(a, dtype=np.uint64), np.ascontiguousarray(b, dtype=np.uint64)
+    out = np.empty_like(a)
+    lib().oc_vec_mul(curve, _p(a), _p(b), _p(out), C.c_size_t(a.size // 4), threads)
+    return out
+
+
+def rep3_local_mul_vec(curve, l, r, mask=None, threads=0):
+    l, r = np.ascontiguousarray(l, dtype=np.uint64), np.ascontiguousarray(r, dtype=np.uint64)
+    m = np.ascontiguousarray(mask, dtype=np.uint64) if mask is not None else None
+    n = l.size // 8
+    out = np.empty(n * 4, dtype=np.uint64)
+    lib().oc_rep3_local_mul_vec(curve, _p(l), _p(r), _p(m), _p(out), C.c_size_t(n), threads)
+    return out
+
+
+def vec_mul_table(curve, v, table, ncomp=1, threads=0):
+    v = np.ascontiguousarray(v, dtype=np.uint64).copy()
+    t = np.ascontiguousarray(table, dtype=np.uint64)
+    lib().oc_vec_mul_table(curve, _p(v), _p(t), C.c_size_t(t.size // 4), ncomp, threads)
+    return v
+
+
+def vec_sub(curve, a, b, threads=0):
+    a, b = np.ascontiguousarray(a, dtype=np.uint64), np.ascontiguousarray(b, dtype=np.uint64)
+    out = np.empty_like(a)
+    lib().oc_vec_sub(curve, _p(a), _p(b), _p(out), C.c_size_t(a.size // 4), threads)
+    return out
+
+
+def rep3_to_shamir_vec(curve, in_ab, x, y, threads=0):
+    a = np.ascontiguousarray(in_ab, dtype=np.uint64)
+    n = a.size // 8
+    out = np.empty(n * 4, dtype=np.uint64)
+    lib().oc_rep3_to_shamir_vec(curve, _p(a), _p(np.ascontiguousarray(x, dtype=np.uint64)), _p(np.ascontiguousarray(y, dtype=np.uint64)),
+                                _p(out), C.c_size_t(n), threads)
+    return out
+
+
+def cpu_msm_baseline(target_seconds: float = 12.0, max_logn: int = 22):
+    """BN254 G1 MSM of the bench workload family (known-dlog bases, uniform 253-bit Montgomery scalars) timed
+    on all host cores, on a bounded sample: the largest 2^k (k <= max_logn) whose estimated time fits
+    ``target_seconds``. Returns the bench.py ``cpu_baseline`` object."""
+    threads = num_threads()
+    rs = np.random.RandomState(99)
+
+    def run(logn):
+        n = 1 << logn
+        pts = generate_bases(0, 0, 0xBA5E, n)
+        sc = rs.randint(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+        sc[:, 3] >>= np.uint64(3)
+        t0 = time.perf_counter()
+        msm(0, 0, pts, sc, True)
+        return time.perf_counter() - t0
+
+    logn = 16
+    t = run(logn)
+    while logn < max_logn and t * 2.6 < target_seconds:
+        logn += 1
+        t = run(logn)
+    t = min(t, run(logn))
+    n = 1 << logn
+    return {"value": n / t, "unit": "points/s", "cores": threads, "kind": "port",
+            "sample": f"BN254 G1 MSM 2^{logn} points, oracle/c Pippenger (Jacobian mixed add, __int128 Montgomery, OpenMP x{threads}), "
+                      f"best of 2 = {t * 1e3:.1f} ms; reference Rust/arkworks path not buildable here"}

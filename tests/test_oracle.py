@@ -1,0 +1,158 @@
+"""CPU tests that PIN the oracle: against the reference's committed fixtures (tests/golden copies of
+test_vectors/Groth16: zkey, wtns, vk, snarkjs proof, public inputs), the BN254 Fr known-answer products,
+and the C restatement against the Python one."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+from oracle import cbridge, groth16, mpc, ntt, zkey
+from oracle import curves as cv
+from oracle import fields as fl
+from tests import helpers as H
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CIRCUITS = [("bn254", "multiplier2"), ("bn254", "poseidon"), ("bls12_381", "multiplier2"), ("bls12_381", "poseidon")]
+
+
+def load(curve, circ):
+    d = os.path.join(GOLD, "Groth16", curve, circ)
+    zk = zkey.parse_zkey(open(os.path.join(d, "circuit.zkey"), "rb").read())
+    w = zkey.parse_wtns(open(os.path.join(d, "witness.wtns"), "rb").read())
+    vk = zkey.parse_vk(open(os.path.join(d, "verification_key.json")).read())
+    pr = zkey.parse_proof(open(os.path.join(d, "circom.proof")).read())
+    pub = zkey.parse_public(open(os.path.join(d, "public.json")).read())
+    return zk, w, vk, pr, pub
+
+
+@pytest.mark.parametrize("curve,circ", CIRCUITS)
+def test_committed_snarkjs_proof_verifies(curve, circ):
+    """co-circom/co-groth16/src/lib.rs:72-91, 123-161: the verifier accepts the snarkjs proof."""
+    zk, w, vk, pr, pub = load(curve, circ)
+    assert groth16.verify(curve, zk.G1, vk, pr, pub)
+    bad = dict(pr)
+    bad["c"] = zk.G1.add(pr["c"], zk.G1.gen)
+    assert not groth16.verify(curve, zk.G1, vk, bad, pub)
+
+
+@pytest.mark.parametrize("curve,circ", [c for c in CIRCUITS if c != ("bls12_381", "poseidon")])
+def test_restated_prover_verifies_and_matches_golden(curve, circ):
+    """lib.rs:41-70, 93-121, 163-229: a proof from (zkey, wtns) verifies; plus the golden h / A / B / C."""
+    zk, w, vk, pr, pub = load(curve, circ)
+    proof, h = groth16.prove_plain(zk, w, 123456789, 987654321)
+    assert groth16.verify(curve, zk.G1, vk, proof, pub)
+    gold = json.load(open(os.path.join(GOLD, "groth16_golden.json")))[f"{curve}/{circ}"]
+    assert [str(x) for x in h] == gold["h"]
+    assert [str(proof["a"][0]), str(proof["a"][1])] == gold["a"]
+    assert [str(proof["c"][0]), str(proof["c"][1])] == gold["c"]
+    assert [[str(proof["b"][0][0]), str(proof["b"][0][1])], [str(proof["b"][1][0]), str(proof["b"][1][1])]] == gold["b"]
+
+
+def test_rep3_three_party_prove_equals_plain():
+    """tests/tests/circom/e2e_tests/rep3.rs:38-86: parties agree on the proof; sum of h half-shares = plain h."""
+    zk, w, vk, pr, pub = load("bn254", "multiplier2")
+    rnd = random.Random(3)
+    p1, h = groth16.prove_plain(zk, w, 11, 22)
+    p3, hs = groth16.prove_rep3(zk, w, 11, 22, lambda: rnd.randrange(zk.Fr.p))
+    assert p1 == p3
+    assert [(a + b + c) % zk.Fr.p for a, b, c in zip(*hs)] == h
+    assert groth16.verify("bn254", zk.G1, vk, p3, pub)
+
+
+def test_bn254_fr_known_answer_products():
+    F = fl.BN254_FR
+    x = 13839525561076761625780930844889299788193703994911163378019280196128582690055
+    y = 2688648969035332064113669477511029957484512453056743431884706385750388613065
+    assert x * y % F.p == 14012338922664984944451142760937475581748095944353358534203030914664561190462
+    got = cbridge.vec_mul(0, H.pack(F, [x]), H.pack(F, [y]))
+    assert H.unpack(F, got) == [x * y % F.p]
+
+
+def test_snarkjs_roots_match_survey_values():
+    q, roots = ntt.roots_of_unity(fl.BN254_FR)
+    assert q == 5 and ntt.roots_of_unity(fl.BLS381_FR)[0] == 5
+    assert roots[2] == 21888242871839275217838484774961031246007050428528088939761107053157389710902
+    assert roots[3] == 19540430494807482326159819597004422086093766032135589407132600596362845576832
+
+
+def test_shamir_share_reconstruct():
+    """mpc-core/src/protocols/shamir.rs:611-742."""
+    F = fl.BN254_FR
+    r = random.Random(4)
+    for (n, t) in [(3, 1), (10, 6)]:
+        s = r.randrange(F.p)
+        sh = mpc.shamir_share(F, s, n, t, lambda: r.randrange(F.p))
+        idx = r.sample(range(1, n + 1), t + 1)
+        assert mpc.shamir_reconstruct(F, [sh[i - 1] for i in idx], mpc.lagrange_from_coeff(F, idx)) == s
+
+
+def test_rep3_to_shamir_translation_is_a_valid_sharing():
+    """tests/tests/mpc/bridges.rs: translated shares reconstruct to the same secret (degree-1 Shamir)."""
+    F = fl.BN254_FR
+    r = random.Random(5)
+    vals = [r.randrange(F.p) for _ in range(10)]
+    sh = mpc.rep3_share_vec(F, vals, lambda: r.randrange(F.p))
+    tr = [mpc.rep3_to_shamir_vec(F, sh[p], p) for p in range(3)]
+    lag = mpc.lagrange_from_coeff(F, [1, 2])
+    assert [mpc.shamir_reconstruct(F, [tr[0][i], tr[1][i]], lag) for i in range(10)] == vals
+    lag = mpc.lagrange_from_coeff(F, [2, 3])
+    assert [mpc.shamir_reconstruct(F, [tr[1][i], tr[2][i]], lag) for i in range(10)] == vals
+
+
+# ---- C restatement vs Python restatement -----------------------------------------------------------------
+@pytest.mark.parametrize("curve,group", [("bn254", 0), ("bn254", 1), ("bls12_381", 0), ("bls12_381", 1)])
+def test_c_msm_matches_python(curve, group):
+    G = cv.CURVES[curve][group]
+    F = H.FR[curve]
+    r = H.rng(group + 10)
+    for n in [0, 1, 5, 40, 200]:
+        pts = H.rand_points(G, n, r, with_inf=True)
+        sc = H.rand_elems(F, n, r)
+        if n >= 5:
+            sc[0], sc[1], sc[2] = 0, 1, F.p - 1
+        want = G.msm(pts, sc)
+        for mont in (True, False):
+            got = cbridge.msm(H.CURVE_IDS[curve], group, cv.pack_points(G, pts), H.pack(F, sc, mont=mont), montgomery=mont)
+            assert G.eq(cv.unpack_points(G, got)[0], want)
+    # naive double-and-add cross-check of the Python Pippenger itself
+    pts = H.rand_points(G, 6, r)
+    sc = H.rand_elems(F, 6, r)
+    assert G.eq(G.msm(pts, sc), G.msm_naive(pts, sc))
+
+
+@pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
+def test_c_ntt_and_vec_ops_match_python(curve):
+    F = H.FR[curve]
+    cid = H.CURVE_IDS[curve]
+    r = H.rng(17)
+    for logn in [0, 1, 3, 8]:
+        n = 1 << logn
+        gen = ntt.roots_of_unity(F)[1][logn]
+        do = ntt.Domain(F, n, gen)
+        v = H.rand_elems(F, n, r)
+        pg = H.pack(F, [gen])
+        assert H.unpack(F, cbridge.ntt(cid, H.pack(F, v), logn, pg, dif=True)) == do.ifft_in_to_out(v)
+        assert H.unpack(F, cbridge.ntt(cid, H.pack(F, v), logn, pg, dif=False)) == do.fft_out_to_in(v)
+        assert H.unpack(F, cbridge.bit_reverse(H.pack(F, v), logn)) == ntt.bit_reverse(v)
+        assert H.unpack(F, cbridge.coset_table(cid, H.pack(F, [7]), logn)) == ntt.bit_reversed_coset_table(F, 7, n)
+    n = 100
+    a = [(r.randrange(F.p), r.randrange(F.p)) for _ in range(n)]
+    b = [(r.randrange(F.p), r.randrange(F.p)) for _ in range(n)]
+    m = H.rand_elems(F, n, r)
+    assert H.unpack(F, cbridge.rep3_local_mul_vec(cid, H.pack_shares(F, a), H.pack_shares(F, b), H.pack(F, m))) == mpc.rep3_local_mul_vec(F, a, b, m)
+    x, y = mpc.rep3_to_shamir_points(F, 1)
+    assert H.unpack(F, cbridge.rep3_to_shamir_vec(cid, H.pack_shares(F, a), H.pack(F, [x]), H.pack(F, [y]))) == mpc.rep3_to_shamir_vec(F, a, 1)
+
+
+def test_c_generated_bases_closed_form():
+    from tests.check_closed_form import closed_form_point
+    G = cv.BN254_G1
+    n = 1 << 10
+    pts = cbridge.generate_bases(0, 0, 77, n)
+    rs = np.random.RandomState(3)
+    sc = rs.randint(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    sc[:, 3] >>= np.uint64(3)
+    got = cv.unpack_points(G, cbridge.msm(0, 0, pts, sc, True))[0]
+    assert G.eq(got, closed_form_point("bn254", 0, 77, n, sc, True))
