@@ -1,10 +1,13 @@
 // Pippenger bucket MSM on gfx950 (BN254 / BLS12-381, G1 / G2).
 //
 // Pipeline (all on one HIP stream, no host round-trip until the final W window sums):
-//   1. k_msm_hist     scalar -> canonical -> signed c-bit digits; per-(window,bucket) histogram (L2 atomics)
+//   1. k_msm_digits   scalar -> canonical -> signed c-bit digit codes (u16 per point and window)
+//      k_msm_hist_lds per-(window, chunk) bucket histogram staged in LDS (<= 128 KiB), wave-aggregated
+//      k_msm_colscan  per-bucket prefix over chunks
 //   2. k_msm_scan     per-window exclusive scan of bucket counts; long buckets are cut into tasks of <= L
 //                     entries so a skewed witness (many equal scalars) cannot serialise on one lane
-//   3. k_msm_scatter  counting-sort scatter of (point index | sign) into per-window bucket order
+//   3. k_msm_scatter_lds  counting-sort scatter of (point index | sign) into per-window bucket order; the
+//                     per-bucket cursors live in LDS, no global atomics
 //   4. k_msm_accum    one lane per task: gather affine bases, XYZZ mixed additions in registers
 //   5. k_msm_reduce   balanced segments over the task list: running-sum  sum_b b*B_b  per segment
 //   6. k_msm_fold     pairwise tree over the segment results -> one XYZZ sum per window
@@ -44,6 +47,8 @@ struct MsmParams {
   uint32_t tmax;  // task slots per window
   uint32_t S;     // reduce segments per window (power of two)
   int mont;
+  uint32_t CH;         // point chunks per window in the LDS counting sort
+  uint32_t chunk_len;  // points per chunk
 };
 
 constexpr int MSM_BLK = 256;
@@ -58,13 +63,86 @@ __device__ __forceinline__ void load_scalar(const Fr* __restrict__ scalars, size
   for (int k = 0; k < Fr::N; ++k) s[k] = v.l[k];
 }
 
+// Digit code (one u16 per point and window): bits 0..14 = bucket-1, bit 15 = negative; 0xFFFF = zero digit.
+constexpr uint32_t DIG_ZERO = 0xFFFFu;
+constexpr int SORT_BLK = 1024;
+
 template <class Fr>
-__global__ __launch_bounds__(MSM_BLK) void k_msm_hist(const Fr* __restrict__ scalars, MsmParams p, uint32_t* hist) {
+__global__ __launch_bounds__(MSM_BLK) void k_msm_digits(const Fr* __restrict__ scalars, MsmParams p, uint16_t* __restrict__ dig) {
   for (size_t i = blockIdx.x * (size_t)MSM_BLK + threadIdx.x; i < p.n; i += (size_t)gridDim.x * MSM_BLK) {
     uint32_t s[Fr::N];
     load_scalar<Fr>(scalars, i, p.mont, s);
-    for_each_digit<Fr::N>(s, p.c, p.W, [&](int w, uint32_t b, uint32_t) { atomicAdd(&hist[(size_t)w * (p.NB + 2) + b], 1u); });
+    int next = 0;
+    for_each_digit<Fr::N>(s, p.c, p.W, [&](int w, uint32_t b, uint32_t neg) {
+      for (; next < w; ++next) dig[(size_t)next * p.n + i] = (uint16_t)DIG_ZERO;
+      dig[(size_t)w * p.n + i] = (uint16_t)((b - 1) | (neg << 15));
+      next = w + 1;
+    });
+    for (; next < p.W; ++next) dig[(size_t)next * p.n + i] = (uint16_t)DIG_ZERO;
   }
+}
+
+// Wave-aggregated LDS counter increment: returns this lane's slot in counter[b] (old value + rank).
+// Lanes that share the wave leader's bucket are peeled off with one atomic per group (up to 4 rounds), so a
+// skewed digit distribution (top window, 0/1-heavy witnesses) does not serialise on one LDS address.
+__device__ __forceinline__ uint32_t lds_slot(uint32_t* counter, uint32_t b, bool valid) {
+  uint32_t slot = 0;
+  bool todo = valid;
+  for (int round = 0; round < 4; ++round) {
+    const unsigned long long act = __ballot(todo);
+    if (!act) return slot;
+    const int leader = __ffsll((long long)act) - 1;
+    const uint32_t lb = (uint32_t)__shfl((int)b, leader);
+    const unsigned long long grp = __ballot(todo && b == lb);
+    const int cnt = __popcll(grp);
+    if (cnt < 8) break;  // wave-uniform: not worth peeling, fall through to per-lane atomics
+    uint32_t base = 0;
+    const int lane = threadIdx.x & 63;
+    if (lane == leader) base = atomicAdd(&counter[lb], (uint32_t)cnt);
+    base = (uint32_t)__shfl((int)base, leader);
+    if (todo && b == lb) {
+      slot = base + (uint32_t)__popcll(grp & ((1ull << lane) - 1ull));
+      todo = false;
+    }
+  }
+  if (todo) slot = atomicAdd(&counter[b], 1u);
+  return slot;
+}
+
+// Block (chunk ch, window w): LDS histogram of the chunk's digits -> blkcnt[w][ch][0..NB)
+__global__ __launch_bounds__(SORT_BLK) void k_msm_hist_lds(MsmParams p, const uint16_t* __restrict__ dig, uint32_t* __restrict__ blkcnt) {
+  extern __shared__ uint32_t lds_cnt[];
+  const uint32_t ch = blockIdx.x, w = blockIdx.y;
+  for (uint32_t b = threadIdx.x; b < p.NB; b += SORT_BLK) lds_cnt[b] = 0;
+  __syncthreads();
+  const size_t lo = (size_t)ch * p.chunk_len;
+  size_t hi = lo + p.chunk_len;
+  if (hi > p.n) hi = p.n;
+  const uint16_t* d = dig + (size_t)w * p.n;
+  for (size_t i0 = lo; i0 < hi; i0 += SORT_BLK) {
+    const size_t i = i0 + threadIdx.x;
+    uint32_t code = DIG_ZERO;
+    if (i < hi) code = d[i];
+    (void)lds_slot(lds_cnt, code & 0x7fffu, code != DIG_ZERO);
+  }
+  __syncthreads();
+  uint32_t* out = blkcnt + ((size_t)w * p.CH + ch) * p.NB;
+  for (uint32_t b = threadIdx.x; b < p.NB; b += SORT_BLK) out[b] = lds_cnt[b];
+}
+
+// Per (window, bucket): exclusive prefix over chunks (in place) and the bucket total -> hist[w][b+1]
+__global__ __launch_bounds__(256) void k_msm_colscan(MsmParams p, uint32_t* __restrict__ blkcnt, uint32_t* __restrict__ hist) {
+  const uint32_t w = blockIdx.y;
+  const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= p.NB) return;
+  uint32_t acc = 0;
+  for (uint32_t ch = 0; ch < p.CH; ++ch) {
+    uint32_t* q = blkcnt + ((size_t)w * p.CH + ch) * p.NB + b;
+    const uint32_t t = *q;
+    *q = acc;
+    acc += t;
+  }
+  hist[(size_t)w * (p.NB + 2) + b + 1] = acc;
 }
 
 // One 1024-thread block per window. In: hist[w][0..NB+1] counts (index 0 and NB+1 unused = 0).
@@ -120,17 +198,29 @@ __global__ __launch_bounds__(1024) void k_msm_scan(MsmParams p, uint32_t* hist, 
   if (threadIdx.x == 1023) ntasks[w] = sh_tsk[1023];
 }
 
-template <class Fr>
-__global__ __launch_bounds__(MSM_BLK) void k_msm_scatter(const Fr* __restrict__ scalars, MsmParams p, const uint32_t* __restrict__ start,
-                                                         uint32_t* cursor, uint32_t* sorted) {
-  for (size_t i = blockIdx.x * (size_t)MSM_BLK + threadIdx.x; i < p.n; i += (size_t)gridDim.x * MSM_BLK) {
-    uint32_t s[Fr::N];
-    load_scalar<Fr>(scalars, i, p.mont, s);
-    for_each_digit<Fr::N>(s, p.c, p.W, [&](int w, uint32_t b, uint32_t neg) {
-      const size_t hb = (size_t)w * (p.NB + 2) + b;
-      const uint32_t pos = start[hb] + atomicAdd(&cursor[hb], 1u);
-      sorted[(size_t)w * p.n + pos] = (uint32_t)i | (neg << 31);
-    });
+// Block (chunk ch, window w): LDS cursors = bucket start + this chunk's prefix; scatter (index | sign) into
+// bucket order. No global atomics; the order inside a bucket is deterministic per chunk.
+__global__ __launch_bounds__(SORT_BLK) void k_msm_scatter_lds(MsmParams p, const uint16_t* __restrict__ dig,
+                                                               const uint32_t* __restrict__ start, const uint32_t* __restrict__ blkcnt,
+                                                               uint32_t* __restrict__ sorted) {
+  extern __shared__ uint32_t lds_cur[];
+  const uint32_t ch = blockIdx.x, w = blockIdx.y;
+  const uint32_t* st = start + (size_t)w * (p.NB + 2) + 1;
+  const uint32_t* pre = blkcnt + ((size_t)w * p.CH + ch) * p.NB;
+  for (uint32_t b = threadIdx.x; b < p.NB; b += SORT_BLK) lds_cur[b] = st[b] + pre[b];
+  __syncthreads();
+  const size_t lo = (size_t)ch * p.chunk_len;
+  size_t hi = lo + p.chunk_len;
+  if (hi > p.n) hi = p.n;
+  const uint16_t* d = dig + (size_t)w * p.n;
+  uint32_t* so = sorted + (size_t)w * p.n;
+  for (size_t i0 = lo; i0 < hi; i0 += SORT_BLK) {
+    const size_t i = i0 + threadIdx.x;
+    uint32_t code = DIG_ZERO;
+    if (i < hi) code = d[i];
+    const bool valid = code != DIG_ZERO;
+    const uint32_t pos = lds_slot(lds_cur, code & 0x7fffu, valid);
+    if (valid) so[pos] = (uint32_t)i | ((code >> 15) << 31);
   }
 }
 
@@ -239,11 +329,11 @@ static int choose_c(size_t n, int bits) {
   const char* env = getenv("CSH_MSM_C");
   if (env) {
     int c = atoi(env);
-    if (c >= 2 && c <= 22) return c;
+    if (c >= 2 && c <= 16) return c;
   }
   double best = 1e300;
   int best_c = 4;
-  for (int c = 3; c <= 20; ++c) {
+  for (int c = 3; c <= 16; ++c) {  // digit codes are 15 bits + sign
     const double nb = double(size_t(1) << (c - 1));
     const double cost = windows_for(bits, c) * (double(n) + 5.0 * nb);
     if (cost < best) {
@@ -281,6 +371,14 @@ static int msm_windows_dev(const Bases* B, size_t offset, size_t n, const uint64
   p.S = 1024;
   while (p.S > 64 && p.S > p.tmax) p.S >>= 1;
   p.mont = mont;
+  {
+    uint64_t ch = 512 / (uint64_t)p.W;
+    const uint64_t by_size = n / (2ull * p.NB);
+    if (ch > by_size) ch = by_size;
+    if (ch < 1) ch = 1;
+    p.CH = (uint32_t)ch;
+    p.chunk_len = (uint32_t)((n + ch - 1) / ch);
+  }
   *p_out = p;
 
   const size_t len = (size_t)p.NB + 2;
@@ -289,6 +387,8 @@ static int msm_windows_dev(const Bases* B, size_t offset, size_t n, const uint64
   need += 3 * Arena::padded(sizeof(uint32_t) * len * p.W);       // hist/cursor, start, tstart
   need += Arena::padded(sizeof(uint32_t) * MAX_WINDOWS);          // ntasks
   need += Arena::padded(sizeof(uint32_t) * n * p.W);              // sorted
+  need += Arena::padded(sizeof(uint16_t) * n * p.W);              // digit codes
+  need += Arena::padded(sizeof(uint32_t) * (size_t)p.NB * p.CH * p.W);  // per-chunk bucket counts / prefixes
   need += Arena::padded(sizeof(XYZZ<Fq>) * (size_t)p.tmax * p.W); // partials
   need += Arena::padded(sizeof(uint32_t) * (size_t)p.tmax * p.W); // task buckets
   need += Arena::padded(sizeof(XYZZ<Fq>) * (size_t)p.S * p.W);    // segment results
@@ -298,6 +398,8 @@ static int msm_windows_dev(const Bases* B, size_t offset, size_t n, const uint64
   uint32_t* tstart = ar.take<uint32_t>(len * p.W);
   uint32_t* ntasks = ar.take<uint32_t>(MAX_WINDOWS);
   uint32_t* sorted = ar.take<uint32_t>(n * p.W);
+  uint16_t* dig = ar.take<uint16_t>(n * p.W);
+  uint32_t* blkcnt = ar.take<uint32_t>((size_t)p.NB * p.CH * p.W);
   XYZZ<Fq>* partial = ar.take<XYZZ<Fq>>((size_t)p.tmax * p.W);
   uint32_t* task_bucket = ar.take<uint32_t>((size_t)p.tmax * p.W);
   XYZZ<Fq>* segres = ar.take<XYZZ<Fq>>((size_t)p.S * p.W);
@@ -316,11 +418,22 @@ static int msm_windows_dev(const Bases* B, size_t offset, size_t n, const uint64
   CSH_TRY(mark(0));
   CSH_HIP(hipMemsetAsync(hist, 0, sizeof(uint32_t) * len * p.W, st));
   const int g1 = grid_for(n, MSM_BLK, 256 * 8);
-  hipLaunchKernelGGL(k_msm_hist<Fr>, dim3(g1), dim3(MSM_BLK), 0, st, sc, p, hist);
+  const size_t sort_lds = sizeof(uint32_t) * p.NB;
+  if (sort_lds > 48 * 1024) {
+    static thread_local bool raised = false;
+    if (!raised) {
+      CSH_HIP(hipFuncSetAttribute((const void*)k_msm_hist_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+      CSH_HIP(hipFuncSetAttribute((const void*)k_msm_scatter_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+      raised = true;
+    }
+  }
+  hipLaunchKernelGGL(k_msm_digits<Fr>, dim3(g1), dim3(MSM_BLK), 0, st, sc, p, dig);
+  hipLaunchKernelGGL(k_msm_hist_lds, dim3(p.CH, p.W), dim3(SORT_BLK), sort_lds, st, p, dig, blkcnt);
+  hipLaunchKernelGGL(k_msm_colscan, dim3((p.NB + 255) / 256, p.W), dim3(256), 0, st, p, blkcnt, hist);
   CSH_TRY(mark(1));
   hipLaunchKernelGGL(k_msm_scan, dim3(p.W), dim3(1024), 0, st, p, hist, start, tstart, ntasks);
   CSH_TRY(mark(2));
-  hipLaunchKernelGGL(k_msm_scatter<Fr>, dim3(g1), dim3(MSM_BLK), 0, st, sc, p, start, hist, sorted);
+  hipLaunchKernelGGL(k_msm_scatter_lds, dim3(p.CH, p.W), dim3(SORT_BLK), sort_lds, st, p, dig, start, blkcnt, sorted);
   CSH_TRY(mark(3));
   hipLaunchKernelGGL(k_msm_accum<Cfg>, dim3((p.tmax + ACC_BLK - 1) / ACC_BLK, p.W), dim3(ACC_BLK), 0, st, bases, p, start, tstart, ntasks,
                      sorted, partial, task_bucket);
