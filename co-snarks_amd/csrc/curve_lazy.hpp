@@ -1,0 +1,79 @@
+// Bucket accumulation in the signed lazy field (field29.hpp FpS): XYZZ += affine, 8M + 2S with limb-wise
+// subtractions and no modular corrections. Same formulas as curve.hpp (EFD madd-2008-s / mdbl-2008-s-1); the
+// explicit `empty` flag replaces the ZZ == 0 test, and the P == 0 (doubling / cancellation) case is detected
+// with a 3-instruction filter on the low limb before the exact check.
+#pragma once
+#include "curve.hpp"
+#include "field29.hpp"
+
+namespace csh {
+
+template <class L>
+struct XYZZLazy {
+  L x, y, zz, zzz;
+  bool empty;
+  CSH_HD static XYZZLazy inf() { return {L::zero(), L::zero(), L::zero(), L::zero(), true}; }
+};
+
+// 2 * (x, y) for an affine point with y != 0 (rare path)
+template <class L>
+CSH_HD_NOINLINE XYZZLazy<L> lazy_mdbl(L x, L y) {
+  L u = L::add(y, y).normalized();
+  L v = L::sqr(u);
+  L w = L::mul(u, v);
+  L s = L::mul(x, v);
+  L xx = L::sqr(x);
+  L m = L::add(L::add(xx, xx), xx).normalized();
+  XYZZLazy<L> r;
+  r.x = L::sub(L::sqr(m), L::add(s, s)).normalized();
+  r.y = L::sub(L::mul(m, L::sub(s, r.x)), L::mul(w, y)).normalized();
+  r.zz = v;
+  r.zzz = w;
+  r.empty = false;
+  return r;
+}
+
+// acc += (x2, y2); the caller has already excluded the point at infinity
+template <class L>
+CSH_HD void lazy_madd(XYZZLazy<L>& acc, const L& x2, const L& y2) {
+  if (acc.empty) {
+    acc.x = x2;
+    acc.y = y2;
+    acc.zz = L::one();
+    acc.zzz = L::one();
+    acc.empty = false;
+    return;
+  }
+  const L u2 = L::mul(x2, acc.zz);
+  const L s2 = L::mul(y2, acc.zzz);
+  const L p = L::sub(u2, acc.x);
+  const L r = L::sub(s2, acc.y);
+  if (p.maybe_zero()) {
+    if (p.is_zero_slow()) {
+      if (r.is_zero()) {
+        if (y2.is_zero()) acc.empty = true;  // 2-torsion cannot occur on these curves; kept for completeness
+        else acc = lazy_mdbl<L>(x2, y2);
+      } else {
+        acc.empty = true;  // P + (-P)
+      }
+      return;
+    }
+  }
+  const L pp = L::sqr(p);
+  const L ppp = L::mul(p, pp);
+  const L q = L::mul(acc.x, pp);
+  const L x3 = L::sub(L::sub(L::sqr(r), ppp), L::add(q, q)).normalized();
+  const L y3 = L::sub(L::mul(r, L::sub(q, x3)), L::mul(acc.y, ppp)).normalized();
+  acc.x = x3;
+  acc.y = y3;
+  acc.zz = L::mul(acc.zz, pp);
+  acc.zzz = L::mul(acc.zzz, ppp);
+}
+
+template <class L, class F32>
+CSH_HD XYZZ<F32> lazy_to_xyzz(const XYZZLazy<L>& a) {
+  if (a.empty) return XYZZ<F32>::inf();
+  return {a.x.to_fp(), a.y.to_fp(), a.zz.to_fp(), a.zzz.to_fp()};
+}
+
+}  // namespace csh

@@ -155,4 +155,183 @@ struct FpLazy {
 
 using Fq29 = FpLazy<Bn254Fq29Params, Bn254Fq>;
 
+// ================================================================================================
+// Signed lazy representation (the one the MSM bucket kernels use).
+//
+// Limbs are int32 in radix 2^B; a value is sum l[i] 2^(B i) and may be NEGATIVE or exceed p: every element
+// is only defined mod p. Subtraction / negation are limb-wise with no modular correction, products use
+// v_mad_i64_i32 into 64-bit column accumulators, and Montgomery reduction (R' = 2^(NL*B)) returns a value in
+// (-p/32, p + p/32) whose limbs 0..NL-2 are in [0, 2^B) and whose top limb carries the sign.
+// Contract: |limb| of mul operands <= 2^B + 2 for both, or <= 2^(B+1) for one of them; operand values within
+// (-8p, 8p). `normalized()` (one parallel signed carry step) restores |limb| <= 2^B + 1 after 2-3 term sums.
+template <class LP, class F32>
+struct FpS {
+  static constexpr int NL = LP::NL;
+  static constexpr int B = LP::B;
+  int32_t l[NL];
+
+  CSH_HD static FpS zero() {
+    FpS r;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) r.l[i] = 0;
+    return r;
+  }
+  CSH_HD static FpS one() {
+    FpS r;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) r.l[i] = (int32_t)LP::ONE[i];
+    return r;
+  }
+  CSH_HD static FpS add(const FpS& a, const FpS& b) {
+    FpS r;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) r.l[i] = a.l[i] + b.l[i];
+    return r;
+  }
+  CSH_HD static FpS sub(const FpS& a, const FpS& b) {
+    FpS r;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) r.l[i] = a.l[i] - b.l[i];
+    return r;
+  }
+  CSH_HD static FpS neg(const FpS& a) {
+    FpS r;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) r.l[i] = -a.l[i];
+    return r;
+  }
+  CSH_HD FpS normalized() const {
+    FpS r;
+    r.l[0] = (int32_t)((uint32_t)l[0] & LP::MASK);
+#pragma unroll
+    for (int i = 1; i < NL - 1; ++i) r.l[i] = (int32_t)((uint32_t)l[i] & LP::MASK) + (l[i - 1] >> B);
+    r.l[NL - 1] = l[NL - 1] + (l[NL - 2] >> B);
+    return r;
+  }
+
+  CSH_HD static FpS mul(const FpS& a, const FpS& b) {
+    int64_t t[2 * NL];
+#pragma unroll
+    for (int k = 0; k < 2 * NL; ++k) t[k] = 0;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+#pragma unroll
+      for (int j = 0; j < NL; ++j) t[i + j] = (int64_t)a.l[i] * (int64_t)b.l[j] + t[i + j];
+    }
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int32_t m = (int32_t)(((uint32_t)t[i] * LP::INV) & LP::MASK);
+#pragma unroll
+      for (int j = 0; j < NL; ++j) t[i + j] = (int64_t)m * (int64_t)(int32_t)LP::MOD[j] + t[i + j];
+      t[i + 1] += t[i] >> B;  // exact: the low B bits of t[i] are zero now
+    }
+    FpS r;
+#pragma unroll
+    for (int k = 0; k < NL - 1; ++k) {
+      r.l[k] = (int32_t)((uint32_t)t[NL + k] & LP::MASK);
+      t[NL + k + 1] += t[NL + k] >> B;
+    }
+    r.l[NL - 1] = (int32_t)t[2 * NL - 1];
+    return r;
+  }
+  CSH_HD static FpS sqr(const FpS& a) { return mul(a, a); }
+
+  // exact value in [0, p) with limbs in [0, 2^B); input value must lie within (-2p, 4p)
+  CSH_HD FpS canonical() const {
+    FpS r;
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < NL - 1; ++i) {
+      const int32_t v = l[i] + c;
+      r.l[i] = (int32_t)((uint32_t)v & LP::MASK);
+      c = v >> B;
+    }
+    r.l[NL - 1] = l[NL - 1] + c;
+    for (int rep = 0; rep < 2 && r.l[NL - 1] < 0; ++rep) {  // negative: add p
+      c = 0;
+#pragma unroll
+      for (int i = 0; i < NL - 1; ++i) {
+        const int32_t v = r.l[i] + (int32_t)LP::MOD[i] + c;
+        r.l[i] = (int32_t)((uint32_t)v & LP::MASK);
+        c = v >> B;
+      }
+      r.l[NL - 1] += (int32_t)LP::MOD[NL - 1] + c;
+    }
+    for (int rep = 0; rep < 4; ++rep) {  // >= p: subtract p
+      int32_t d[NL];
+      c = 0;
+#pragma unroll
+      for (int i = 0; i < NL - 1; ++i) {
+        const int32_t v = r.l[i] - (int32_t)LP::MOD[i] + c;
+        d[i] = (int32_t)((uint32_t)v & LP::MASK);
+        c = v >> B;
+      }
+      d[NL - 1] = r.l[NL - 1] - (int32_t)LP::MOD[NL - 1] + c;
+      if (d[NL - 1] < 0) break;
+#pragma unroll
+      for (int i = 0; i < NL; ++i) r.l[i] = d[i];
+    }
+    return r;
+  }
+
+  // cheap necessary condition for value == 0 (mod p), valid for |value| < 8p: value = k p with |k| < 8
+  CSH_HD bool maybe_zero() const {
+    const uint32_t k = ((uint32_t)l[0] * LP::PINV) & LP::MASK;
+    return ((k + 8u) & LP::MASK) < 16u;
+  }
+  CSH_HD bool is_zero_slow() const {
+    FpS o = one();
+    FpS y = mul(this->normalized(), o).canonical();
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) acc |= (uint32_t)y.l[i];
+    return acc == 0;
+  }
+  CSH_HD bool is_zero() const { return maybe_zero() && is_zero_slow(); }
+
+  // ---- packed storage: canonical x*R' mod p in F32::N 32-bit words (same size as the arkworks encoding)
+  CSH_HD static FpS unpack(const F32& f) {
+    FpS r;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int bit = i * B;
+      const int w = bit >> 5, off = bit & 31;
+      uint64_t two = w < F32::N ? f.l[w] : 0;
+      if (w + 1 < F32::N) two |= (uint64_t)f.l[w + 1] << 32;
+      r.l[i] = (int32_t)((uint32_t)(two >> off) & LP::MASK);
+    }
+    return r;
+  }
+  CSH_HD F32 pack() const {  // requires canonical()
+    F32 f = F32::zero();
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int bit = i * B;
+      const int w = bit >> 5, off = bit & 31;
+      const uint64_t sh = (uint64_t)(uint32_t)l[i] << off;
+      if (w < F32::N) f.l[w] |= (uint32_t)sh;
+      if (w + 1 < F32::N) f.l[w + 1] |= (uint32_t)(sh >> 32);
+    }
+    return f;
+  }
+  // arkworks Montgomery (x * 2^(32N)) <-> lazy Montgomery (x * R')
+  CSH_HD static FpS from_fp(const F32& f) {
+    FpS c;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) c.l[i] = (int32_t)LP::TO_LAZY[i];
+    return mul(unpack(f), c);
+  }
+  CSH_HD F32 to_fp() const {
+    FpS c;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) c.l[i] = (int32_t)LP::FROM_LAZY[i];
+    return mul(this->normalized(), c).canonical().pack();
+  }
+  // x*2^(32N) (arkworks) -> packed canonical x*R' (what Bases keeps on the device for lazy curves)
+  CSH_HD static F32 repack_for_storage(const F32& f) { return from_fp(f).canonical().pack(); }
+};
+
+using Fq29s = FpS<Bn254Fq29Params, Bn254Fq>;
+using Fq28s = FpS<Bls381Fq28Params, Bls381Fq>;
+
 }  // namespace csh

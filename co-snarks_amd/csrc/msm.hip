@@ -20,14 +20,17 @@
 
 #include "common.hpp"
 #include "curve.hpp"
+#include "curve_lazy.hpp"
 #include "msm_digits.hpp"
 
 namespace csh {
 
-struct Bn254G1Cfg { using Fq = Bn254Fq;   using Fr = Bn254Fr; };
-struct Bn254G2Cfg { using Fq = Bn254Fq2;  using Fr = Bn254Fr; };
-struct Bls381G1Cfg { using Fq = Bls381Fq;  using Fr = Bls381Fr; };
-struct Bls381G2Cfg { using Fq = Bls381Fq2; using Fr = Bls381Fr; };
+// LAZY: bucket accumulation runs in the signed lazy field (field29.hpp); Bases then stores the coordinates
+// re-encoded as canonical x*R' (same 32 bytes per coordinate), converted once at upload.
+struct Bn254G1Cfg { using Fq = Bn254Fq;   using Fr = Bn254Fr; static constexpr bool LAZY = true;  using L = Fq29s; };
+struct Bn254G2Cfg { using Fq = Bn254Fq2;  using Fr = Bn254Fr; static constexpr bool LAZY = false; using L = void; };
+struct Bls381G1Cfg { using Fq = Bls381Fq;  using Fr = Bls381Fr; static constexpr bool LAZY = false; using L = void; };
+struct Bls381G2Cfg { using Fq = Bls381Fq2; using Fr = Bls381Fr; static constexpr bool LAZY = false; using L = void; };
 
 struct Bases {
   csh_curve_t curve;
@@ -252,14 +255,35 @@ __global__ __launch_bounds__(ACC_BLK) void k_msm_accum(const Affine<typename Cfg
   const uint32_t end = st[b + 1];
   if (hi > end) hi = end;
   const uint32_t* so = sorted + (size_t)w * p.n;
-  XYZZ<Fq> acc = XYZZ<Fq>::inf();
-  for (uint32_t k = lo; k < hi; ++k) {
-    const uint32_t e = so[k];
-    Affine<Fq> pt = bases[e & 0x7fffffffu];
-    if (e >> 31) pt.y = Fq::neg(pt.y);
-    xyzz_madd(acc, pt);
+  if constexpr (Cfg::LAZY) {
+    using L = typename Cfg::L;
+    XYZZLazy<L> acc = XYZZLazy<L>::inf();
+    uint32_t e_next = so[lo];                       // lo < hi: every task owns >= 1 entry
+    Affine<Fq> pt_next = bases[e_next & 0x7fffffffu];
+    for (uint32_t k = lo; k < hi; ++k) {
+      const uint32_t e = e_next;
+      const Affine<Fq> pt = pt_next;
+      if (k + 1 < hi) {                             // software prefetch of the next gather
+        e_next = so[k + 1];
+        pt_next = bases[e_next & 0x7fffffffu];
+      }
+      if (pt.is_inf()) continue;
+      const L x = L::unpack(pt.x);
+      L y = L::unpack(pt.y);
+      if (e >> 31) y = L::neg(y);
+      lazy_madd(acc, x, y);
+    }
+    partial[(size_t)w * p.tmax + t] = lazy_to_xyzz<L, Fq>(acc);
+  } else {
+    XYZZ<Fq> acc = XYZZ<Fq>::inf();
+    for (uint32_t k = lo; k < hi; ++k) {
+      const uint32_t e = so[k];
+      Affine<Fq> pt = bases[e & 0x7fffffffu];
+      if (e >> 31) pt.y = Fq::neg(pt.y);
+      xyzz_madd(acc, pt);
+    }
+    partial[(size_t)w * p.tmax + t] = acc;
   }
-  partial[(size_t)w * p.tmax + t] = acc;
   task_bucket[(size_t)w * p.tmax + t] = b;
 }
 
@@ -313,6 +337,21 @@ __global__ __launch_bounds__(64) void k_msm_fold(XYZZ<typename Cfg::Fq>* arr, ui
   XYZZ<typename Cfg::Fq> x = a[i];
   xyzz_add(x, a[i + half]);
   a[i] = x;
+}
+
+// In-place re-encoding of uploaded bases for LAZY curves: x*2^(32N) -> canonical x*R' (infinity stays 0,0)
+template <class Cfg>
+__global__ __launch_bounds__(256) void k_bases_repack(Affine<typename Cfg::Fq>* pts, size_t n) {
+  if constexpr (Cfg::LAZY) {
+    using L = typename Cfg::L;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+      Affine<typename Cfg::Fq> p = pts[i];
+      if (p.is_inf()) continue;
+      p.x = L::repack_for_storage(p.x);
+      p.y = L::repack_for_storage(p.y);
+      pts[i] = p;
+    }
+  }
 }
 
 template <class Cfg>
@@ -532,6 +571,19 @@ static int fold_partials_t(const void* partials_host, size_t nparts, void* out_j
   return CSH_OK;
 }
 
+template <class Cfg>
+static int repack_bases_t(Bases* B, hipStream_t st) {
+  if constexpr (Cfg::LAZY) {
+    if (B->n) {
+      hipLaunchKernelGGL(k_bases_repack<Cfg>, dim3(grid_for(B->n, 256)), dim3(256), 0, st, (Affine<typename Cfg::Fq>*)B->points, B->n);
+      CSH_HIP(hipGetLastError());
+      CSH_HIP(hipStreamSynchronize(st));
+    }
+  }
+  return CSH_OK;
+}
+static int repack_bases(Bases* B, hipStream_t st);
+
 static size_t point_bytes_of(csh_curve_t c, csh_group_t g) {
   const size_t fq = c == CSH_BN254 ? 32 : 48;
   return 2 * fq * (g == CSH_G2 ? 2 : 1);
@@ -550,6 +602,10 @@ using namespace csh;
     set_error("unknown curve/group %d/%d", (int)(curve), (int)(group));                          \
     return CSH_ERR_INVALID;                                                                     \
   } while (0)
+
+static int csh::repack_bases(Bases* B, hipStream_t st) {
+  CURVE_DISPATCH(B->curve, B->group, (repack_bases_t<Cfg>(B, st)));
+}
 
 static int valid_cg(csh_curve_t c, csh_group_t g) {
   CSH_REQUIRE(c == CSH_BN254 || c == CSH_BLS12_381, "unknown curve");
@@ -592,6 +648,12 @@ static int bases_upload_common(csh_curve_t curve, csh_group_t group, const void*
       delete B;
       set_error("bases upload failed: %s", hipGetErrorString(e));
       return CSH_ERR_HIP;
+    }
+    int rc = repack_bases(B, st);
+    if (rc != CSH_OK) {
+      (void)hipFree(B->points);
+      delete B;
+      return rc;
     }
   }
   *out = reinterpret_cast<csh_bases_t>(B);

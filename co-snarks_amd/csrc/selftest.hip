@@ -5,6 +5,7 @@
 
 #include "common.hpp"
 #include "curve.hpp"
+#include "curve_lazy.hpp"
 #include "field29.hpp"
 #include "msm_digits.hpp"
 
@@ -102,6 +103,40 @@ int csh_selftest_curve_op(int curve, int group, int op, const void* in1, const v
   if (curve == CSH_BLS12_381 && group == CSH_G1) return curve_op<Bls381Fq>(op, in1, in2, k, out);
   if (curve == CSH_BLS12_381 && group == CSH_G2) return curve_op<Bls381Fq2>(op, in1, in2, k, out);
   return CSH_ERR_INVALID;
+}
+
+// Lazy (signed 29-bit) bucket accumulation on the host: acc (XYZZ, arkworks Montgomery words, all-zero = empty)
+// += sequence of `npts` affine BN254 G1 points (negated where neg[i] != 0); out = XYZZ in arkworks words.
+// Exercises exactly what k_msm_accum's lazy path does: storage repack, unpack, lazy_madd, export.
+int csh_selftest_lazy_accumulate(const uint64_t* affine_pts, const uint8_t* neg, size_t npts, uint64_t* out_xyzz) {
+  using L = Fq29s;
+  XYZZLazy<L> acc = XYZZLazy<L>::inf();
+  for (size_t i = 0; i < npts; ++i) {
+    Affine<Bn254Fq> p;
+    memcpy(&p, affine_pts + 8 * i, sizeof p);
+    if (p.is_inf()) continue;
+    Bn254Fq sx = L::repack_for_storage(p.x), sy = L::repack_for_storage(p.y);  // what Bases stores
+    L x = L::unpack(sx), y = L::unpack(sy);
+    if (neg && neg[i]) y = L::neg(y);
+    lazy_madd(acc, x, y);
+  }
+  XYZZ<Bn254Fq> r = lazy_to_xyzz<L, Bn254Fq>(acc);
+  memcpy(out_xyzz, &r, sizeof r);
+  return CSH_OK;
+}
+
+// out = to_fp(mul(from_fp(a) (+/-) from_fp(b), from_fp(c))) for the signed lazy field: op 0: (a+b)*c, 1: (a-b)*c
+int csh_selftest_lazys_op(int op, const uint64_t a[4], const uint64_t b[4], const uint64_t c[4], uint64_t out[4]) {
+  using L = Fq29s;
+  Bn254Fq fa, fb, fc;
+  memcpy(&fa, a, 32);
+  memcpy(&fb, b, 32);
+  memcpy(&fc, c, 32);
+  L la = L::from_fp(fa), lb = L::from_fp(fb), lc = L::from_fp(fc);
+  L s = op == 0 ? L::add(la, lb) : L::sub(la, lb);
+  Bn254Fq r = L::mul(s, lc).to_fp();
+  memcpy(out, &r, 32);
+  return s.is_zero() ? 1 : 0;   // also reports the zero test of (a +/- b)
 }
 
 // canonical scalar limbs -> signed digits (digits_out[w], w < *W_out)

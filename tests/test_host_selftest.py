@@ -154,3 +154,56 @@ def test_lazy29_mul_matches_montgomery32(hip):
         out = np.zeros(4, dtype=np.uint64)
         assert hip.lib().csh_test_mul29_host(pa.ctypes.data_as(C.c_void_p), pb.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)) == 0
         assert H.unpack(F, out) == [a * b % F.p]
+
+
+def test_signed_lazy_field_ops(hip):
+    """FpS (signed 29-bit lazy field used by the bucket kernels): (a +/- b) * c and its zero test."""
+    F = fl.BN254_FQ
+    r = H.rng(31)
+    vals = [v % F.p for v in H.edge_elems(F)] + H.rand_elems(F, 300, r)
+    L = hip.lib()
+    for i, a in enumerate(vals):
+        b = vals[(i * 5 + 1) % len(vals)]
+        c = vals[(i * 11 + 2) % len(vals)]
+        for op, want in [(0, (a + b) * c % F.p), (1, (a - b) * c % F.p)]:
+            out = np.zeros(4, dtype=np.uint64)
+            z = L.csh_selftest_lazys_op(op, H.pack(F, [a]).ctypes.data_as(C.c_void_p), H.pack(F, [b]).ctypes.data_as(C.c_void_p),
+                                        H.pack(F, [c]).ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+            assert H.unpack(F, out) == [want]
+            assert z == (1 if ((a + b) if op == 0 else (a - b)) % F.p == 0 else 0)
+    # exact zero / p-multiples must be detected: a - a, a + (p - a)
+    for a in vals[:20]:
+        out = np.zeros(4, dtype=np.uint64)
+        pa = H.pack(F, [a]).ctypes.data_as(C.c_void_p)
+        assert L.csh_selftest_lazys_op(1, pa, pa, pa, out.ctypes.data_as(C.c_void_p)) == 1
+        pn = H.pack(F, [(-a) % F.p]).ctypes.data_as(C.c_void_p)
+        assert L.csh_selftest_lazys_op(0, pa, pn, pa, out.ctypes.data_as(C.c_void_p)) == 1
+
+
+def test_lazy_bucket_accumulation_matches_group_law(hip):
+    """lazy_madd chain (incl. duplicates -> doubling, P + (-P) -> empty, infinity bases, long chains)."""
+    G = cv.BN254_G1
+    r = H.rng(33)
+    pts = H.rand_points(G, 40, r)
+    seqs = [
+        ([pts[0]], [0]),
+        ([pts[0], pts[0]], [0, 0]),                                  # doubling
+        ([pts[0], pts[0]], [0, 1]),                                  # cancellation
+        ([pts[0], pts[0], pts[1]], [0, 1, 0]),                       # empty then restart
+        ([pts[0], pts[1], G.add(pts[0], pts[1])], [0, 0, 0]),        # acc == next point -> doubling mid-chain
+        ([pts[0], pts[1], G.add(pts[0], pts[1])], [0, 0, 1]),        # acc == -next -> empty
+        ([None, pts[2], None, pts[3]], [0, 1, 0, 1]),
+        (pts, [r.randrange(2) for _ in pts]),
+        ([pts[5]] * 33, [0] * 33),                                   # 33 * P
+    ]
+    for seq, neg in seqs:
+        want = None
+        for P, ng in zip(seq, neg):
+            want = G.add(want, G.neg(P) if ng else P)
+        ap = cv.pack_points(G, seq).reshape(-1)
+        ngb = np.array(neg, dtype=np.uint8)
+        out = np.zeros(16, dtype=np.uint64)
+        assert hip.lib().csh_selftest_lazy_accumulate(ap.ctypes.data_as(C.c_void_p), ngb.ctypes.data_as(C.c_void_p), C.c_size_t(len(seq)),
+                                                      out.ctypes.data_as(C.c_void_p)) == 0
+        got = _xyzz_to_affine(hip, 0, 0, G, out)
+        assert G.eq(got, want)
