@@ -1,0 +1,53 @@
+"""ctypes harness over lib/libcosnarks_groth16.so (the C++ host mirror of the reference's CoGroth16 interface)."""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+
+import numpy as np
+
+from .bindings import CoSnarksHipError, lib
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_G = None
+
+
+def glib():
+    global _G
+    if _G is None:
+        lib()  # libcosnarks_hip.so first (dependency, same HIP runtime)
+        p = os.path.join(_HERE, "lib", "libcosnarks_groth16.so")
+        if not os.path.exists(p):
+            raise CoSnarksHipError(f"{p} not found: run `python co-snarks_amd/build.py`")
+        _G = C.CDLL(p)
+        _G.cog16_last_error.restype = C.c_char_p
+    return _G
+
+
+def _scalar(v):
+    if v is None:
+        return None
+    return (C.c_uint64 * 4)(*[(int(v) >> (64 * i)) & (2**64 - 1) for i in range(4)])
+
+
+def prove_plain(curve: int, zkey: bytes, wtns: bytes, r=None, s=None, want_h=False, h_elems=1 << 20):
+    """Groth16::plain_prove::<CircomReduction> -> (proof dict as in circom.proof, h limbs or None)."""
+    out = C.create_string_buffer(8192)
+    h = np.zeros(h_elems * 4, dtype=np.uint64) if want_h else None
+    rc = glib().cog16_prove_plain(curve, zkey, C.c_size_t(len(zkey)), wtns, C.c_size_t(len(wtns)), _scalar(r), _scalar(s), out,
+                                  C.c_size_t(len(out)), h.ctypes.data_as(C.c_void_p) if want_h else None, C.c_size_t(h_elems))
+    if rc != 0:
+        raise CoSnarksHipError(glib().cog16_last_error().decode())
+    return json.loads(out.value.decode()), h
+
+
+def prove_rep3(curve: int, zkey: bytes, wtns: bytes, seed: int, r=None, s=None, want_h=False, h_elems=1 << 20):
+    """Three in-process Rep3 parties (LocalNetwork); returns the agreed proof and the parties' h half-shares."""
+    out = C.create_string_buffer(8192)
+    h = np.zeros(3 * h_elems * 4, dtype=np.uint64) if want_h else None
+    rc = glib().cog16_prove_rep3(curve, zkey, C.c_size_t(len(zkey)), wtns, C.c_size_t(len(wtns)), C.c_uint64(seed), _scalar(r), _scalar(s),
+                                 out, C.c_size_t(len(out)), h.ctypes.data_as(C.c_void_p) if want_h else None, C.c_size_t(3 * h_elems))
+    if rc != 0:
+        raise CoSnarksHipError(glib().cog16_last_error().decode())
+    return json.loads(out.value.decode()), h

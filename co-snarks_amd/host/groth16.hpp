@@ -1,0 +1,179 @@
+// Mirror of co-circom/co-groth16/src/groth16.rs (CoGroth16::{prove_inner, calculate_coeff,
+// create_proof_with_assignment}, groth16_roots_of_unity) and groth16/reduction.rs (R1CSToQAP,
+// CircomReduction) above the C ABI. Same control flow, line-cited; the hot calls go to the device.
+#pragma once
+#include <thread>
+
+#include "mpc.hpp"
+
+namespace cosnarks {
+
+// groth16.rs:60-100: snarkjs roots. q = smallest quadratic non-residue, z = q^TRACE, repeated squaring, reversed.
+template <class Fr>
+inline void groth16_roots_of_unity(size_t pow, Fr& group_gen, Fr& coset_shift) {
+  constexpr int S = Fr::Params::TWO_ADICITY;
+  // (p-1)/2 and TRACE as limb arrays
+  uint32_t pm1[Fr::N], half[Fr::N], trace[Fr::N];
+  for (int i = 0; i < Fr::N; ++i) pm1[i] = Fr::Params::MOD[i];
+  pm1[0] -= 1;
+  auto shr = [&](const uint32_t* in, int s, uint32_t* out) {
+    for (int i = 0; i < Fr::N; ++i) {
+      const int wi = i + s / 32;
+      const uint64_t lo = wi < Fr::N ? in[wi] : 0;
+      const uint64_t hi = wi + 1 < Fr::N ? in[wi + 1] : 0;
+      out[i] = (uint32_t)((lo | (hi << 32)) >> (s % 32));
+    }
+  };
+  shr(pm1, 1, half);
+  shr(pm1, S, trace);
+  Fr one = Fr::one();
+  Fr minus_one = Fr::neg(one);
+  Fr q = one;
+  while (!(Fr::pow_limbs(q, half, Fr::N) == minus_one)) q = Fr::add(q, one);  // legendre(q) == QNR
+  std::vector<Fr> roots(S + 1);
+  roots[0] = Fr::pow_limbs(q, trace, Fr::N);
+  for (int i = 1; i <= S; ++i) roots[i] = Fr::sqr(roots[i - 1]);
+  std::vector<Fr> rev(roots.rbegin(), roots.rend());
+  group_gen = rev[pow];
+  coset_shift = ((size_t)S == pow) ? Fr::sqr(q) : rev[pow + 1];
+}
+
+// ---- R1CSToQAP: CircomReduction::witness_map_from_matrices (reduction.rs:77-193) ------------------------------
+struct CircomReduction {
+  template <class P, class T>
+  static std::vector<typename T::ArithmeticHalfShare> witness_map_from_matrices(typename T::State& state, const ConstraintMatrices<P>& matrices,
+                                                                                 const std::vector<typename P::Fr>& public_inputs,
+                                                                                 const std::vector<typename T::ArithmeticShare>& private_witness) {
+    using Fr = typename P::Fr;
+    using Share = typename T::ArithmeticShare;
+    const size_t num_constraints = matrices.num_constraints;
+    const size_t num_inputs = matrices.num_instance_variables;
+    size_t domain_size = 1, power = 0;
+    while (domain_size < num_constraints + num_inputs) {
+      domain_size <<= 1;
+      ++power;
+    }
+    if (power > (size_t)Fr::Params::TWO_ADICITY) throw Error("Polynomial Degree too large");  // :87-89
+    Fr group_gen, coset_shift;
+    groth16_roots_of_unity<Fr>(power, group_gen, coset_shift);                                 // :92
+    csh_domain_t domain = nullptr;
+    int rc = csh_domain_create(P::ID, (uint32_t)power, (const uint64_t*)&group_gen, &domain);   // :93 Domain::with_group_gen
+    if (rc == CSH_ERR_DOMAIN) throw Error("Polynomial Degree too large");
+    check(rc, "csh_domain_create");
+    const int id = state.id;
+
+    // :99-130 evaluate constraints (sparse rows on the host; "next" row f3 moves this to the device)
+    auto evaluate = [&](const std::vector<std::vector<std::pair<Fr, size_t>>>& m) {
+      std::vector<Share> res(domain_size, Share{});
+      for (size_t i = 0; i < m.size(); ++i) res[i] = T::evaluate_constraint(id, m[i], public_inputs, private_witness);
+      return res;
+    };
+    std::vector<Share> a = evaluate(matrices.a);
+    std::vector<Share> promoted = T::promote_to_trivial_shares(id, public_inputs);
+    for (size_t i = 0; i < num_inputs; ++i) a[num_constraints + i] = promoted[i];              // :111-113
+    std::vector<Share> b = evaluate(matrices.b);
+
+    // :135-192 on the device in one call: 6 NTTs, 2 local_mul_vec, 3 coset-table multiplications, 1 subtraction.
+    // The two mask vectors are drawn in the reference's order: "c: local_mul_vec" (:160) then "ab" (:182).
+    std::vector<Fr> mask_c = T::masks(state, domain_size);
+    std::vector<Fr> mask_ab = T::masks(state, domain_size);
+    std::vector<Fr> h(domain_size);
+    rc = csh_groth16_h(domain, (const uint64_t*)&coset_shift, T::PROTOCOL, (uint64_t*)a.data(), (uint64_t*)b.data(),
+                       mask_c.empty() ? nullptr : (const uint64_t*)mask_c.data(), mask_ab.empty() ? nullptr : (const uint64_t*)mask_ab.data(),
+                       (uint64_t*)h.data());
+    csh_domain_free(domain);
+    check(rc, "csh_groth16_h");
+    return h;
+  }
+};
+
+// ---- CoGroth16<P, T> (groth16.rs:103-338) ------------------------------------------------------------------------
+template <class P, class T>
+struct CoGroth16 {
+  using Fr = typename P::Fr;
+  using Fq = typename P::Fq;
+  using Fq2 = typename P::Fq2;
+  using Share = typename T::ArithmeticShare;
+  using Half = typename T::ArithmeticHalfShare;
+  using Net = typename T::Net;
+  using State = typename T::State;
+
+  // groth16.rs:179-203
+  template <class F>
+  static Proj<F> calculate_coeff(int id, Proj<F> initial, const Query<F>& query, const AffineT<F>& vk_param,
+                                 const std::vector<Fr>& input_assignment, const std::vector<Half>& aux_assignment) {
+    const size_t pub_len = input_assignment.size();
+    Proj<F> priv_acc = T::template msm_public_points_hs<F>(BasesView{query.dev, 1 + pub_len, query.host.size() - 1 - pub_len}, aux_assignment);
+    Proj<F> pub_acc = Proj<F>::inf();  // msm_unchecked(&query[1..=pub_len], input_assignment): tiny, on the host (:194)
+    for (size_t i = 0; i < pub_len; ++i) pub_acc = point_add(pub_acc, point_mul(into_group(query.host[1 + i]), input_assignment[i]));
+    Proj<F> res = initial;
+    T::template add_assign_points_public_hs<F>(id, res, into_group(query.host[0]));
+    T::template add_assign_points_public_hs<F>(id, res, into_group(vk_param));
+    T::template add_assign_points_public_hs<F>(id, res, pub_acc);
+    return point_add(res, priv_acc);
+  }
+
+  // groth16.rs:207-338
+  static Proof<P> create_proof_with_assignment(const Net* net0, const Net* net1, State& state0, State& state1, const ProvingKey<P>& pkey,
+                                               const Share& r, const Share& s, const std::vector<Half>& h,
+                                               const std::vector<Fr>& input_assignment, const std::vector<Half>& aux_assignment) {
+    const Proj<Fq> delta_g1 = into_group(pkey.delta_g1);
+    const Proj<Fq2> delta_g2 = into_group(pkey.delta_g2);
+    const int id = state0.id;
+    std::vector<Fr> inputs(input_assignment.begin() + 1, input_assignment.end());  // &input_assignment[1..]
+    Proj<Fq> r_g1, s_g1, l_acc, h_acc;
+    Proj<Fq2> s_g2;
+    // rayon_join5 (:227-294): five independent MSM groups, issued from five host threads (the C ABI is re-entrant)
+    std::thread t1([&] { r_g1 = calculate_coeff<Fq>(id, T::template scalar_mul_public_point_hs<Fq>(delta_g1, T::to_half_share(r)), pkey.a_query, pkey.alpha_g1, inputs, aux_assignment); });
+    std::thread t2([&] { s_g1 = calculate_coeff<Fq>(id, T::template scalar_mul_public_point_hs<Fq>(delta_g1, T::to_half_share(s)), pkey.b_g1_query, pkey.beta_g1, inputs, aux_assignment); });
+    std::thread t3([&] { s_g2 = calculate_coeff<Fq2>(id, T::template scalar_mul_public_point_hs<Fq2>(delta_g2, T::to_half_share(s)), pkey.b_g2_query, pkey.beta_g2, inputs, aux_assignment); });
+    std::thread t4([&] { l_acc = T::template msm_public_points_hs<Fq>(BasesView{pkey.l_query.dev, 0, pkey.l_query.host.size()}, aux_assignment); });
+    std::thread t5([&] { h_acc = T::template msm_public_points_hs<Fq>(BasesView{pkey.h_query.dev, 0, pkey.h_query.host.size()}, h); });
+    t1.join(); t2.join(); t3.join(); t4.join(); t5.join();
+
+    Half rs = T::local_mul_vec({r}, {s}, state0).back();                                     // :297
+    Proj<Fq> r_s_delta_g1 = T::template scalar_mul_public_point_hs<Fq>(delta_g1, rs);        // :298
+    Proj<Fq> g_a_opened, r_g1_b;
+    {  // mpc_net::join (:305-308): two network legs
+      std::thread n1([&] { r_g1_b = T::template scalar_mul<Fq>(s_g1, r, net1, state1); });
+      g_a_opened = T::template open_half_point<Fq>(r_g1, net0, state0);
+      n1.join();
+    }
+    Proj<Fq> g_c = T::template scalar_mul_public_point_hs<Fq>(g_a_opened, T::to_half_share(s));  // :313-314
+    g_c = point_add(g_c, r_g1_b);
+    g_c = point_add(g_c, point_neg(r_s_delta_g1));
+    g_c = point_add(g_c, l_acc);
+    g_c = point_add(g_c, h_acc);
+    Proj<Fq> g_c_opened;
+    Proj<Fq2> g2_b_opened;
+    {  // :325-328
+      std::thread n1([&] { g2_b_opened = T::template open_half_point<Fq2>(s_g2, net1, state1); });
+      g_c_opened = T::template open_half_point<Fq>(g_c, net0, state0);
+      n1.join();
+    }
+    return Proof<P>{into_affine(g_a_opened), into_affine(g_c_opened), into_affine(g2_b_opened)};
+  }
+
+  // groth16.rs:125-177 with r, s optionally supplied (the reference always draws them with T::rand)
+  template <class R>
+  static Proof<P> prove_inner(const Net* net0, const Net* net1, State& state0, State& state1, const ProvingKey<P>& pkey,
+                              const ConstraintMatrices<P>& matrices, const SharedWitness<P, Share>& w, const Share* r_in, const Share* s_in,
+                              std::vector<Half>* h_out = nullptr) {
+    if (w.public_inputs.size() != matrices.num_instance_variables)
+      throw Error("amount of public inputs does not match with provided constraint system! Expected " +
+                  std::to_string(matrices.num_instance_variables) + ", but got " + std::to_string(w.public_inputs.size()));
+    if (w.witness.size() != matrices.num_witness_variables)
+      throw Error("amount of private witness variables does not match with provided constraint system! Expected " +
+                  std::to_string(matrices.num_witness_variables) + ", but got " + std::to_string(w.witness.size()));
+    std::vector<Half> h = R::template witness_map_from_matrices<P, T>(state0, matrices, w.public_inputs, w.witness);
+    Share r = T::rand(net0, state0), s = T::rand(net0, state0);
+    if (r_in) r = *r_in;
+    if (s_in) s = *s_in;
+    std::vector<Half> half(w.witness.size());
+    for (size_t i = 0; i < half.size(); ++i) half[i] = T::to_half_share(w.witness[i]);
+    if (h_out) *h_out = h;
+    return create_proof_with_assignment(net0, net1, state0, state1, pkey, r, s, h, w.public_inputs, half);
+  }
+};
+
+}  // namespace cosnarks

@@ -1,0 +1,229 @@
+// Drivers mirroring `CircomGroth16Prover<P>` (co-circom/co-groth16/src/mpc.rs:22-138) and its three
+// implementors PlainGroth16Driver (mpc/plain.rs:13-134), Rep3Groth16Driver (mpc/rep3.rs:16-162) and
+// ShamirGroth16Driver (mpc/shamir.rs:14-148, local methods). Same method names and argument meaning; the hot
+// methods (local_mul_vec, distribute_powers_and_mul_by_const, msm_public_points_hs and the NTTs inside the
+// reduction) call the C ABI of include/cosnarks_hip.h, everything else is host code as in the reference.
+#pragma once
+#include <random>
+
+#include "network.hpp"
+#include "types.hpp"
+
+namespace cosnarks {
+
+// A slice of a device-resident query: the mirror of `&query[lo..]`
+struct BasesView {
+  csh_bases_t bases;
+  size_t offset, len;
+};
+
+template <class F>
+inline Proj<F> msm_device(const BasesView& v, const void* scalars_mont, size_t n) {
+  csh::Jac<F> out;
+  const size_t cnt = n < v.len ? n : v.len;  // msm_unchecked: the shorter of the two slices
+  check(csh_msm(v.bases, v.offset, cnt, reinterpret_cast<const uint64_t*>(scalars_mont), 1, &out), "csh_msm");
+  if (out.is_inf()) return Proj<F>::inf();
+  return Proj<F>::from_affine(AffineT<F>{out.x, out.y});
+}
+
+// ---- Rep3 types (mpc-core/src/protocols/rep3/arithmetic/types.rs:21-28, rngs.rs:83-187) -----------------------
+template <class Fr>
+struct Rep3PrimeFieldShare {
+  Fr a, b;
+};
+
+struct Rep3Rand {
+  ChaCha12 rng1, rng2;  // own key, previous party's key (rep3.rs:71-76 setup_prf)
+  Rep3Rand(const uint8_t s1[32], const uint8_t s2[32]) : rng1(s1), rng2(s2) {}
+  template <class Fr>
+  std::vector<Fr> masking_field_elements_vec(size_t len) {  // rngs.rs:137-156
+    std::vector<uint8_t> a(32 * len), b(32 * len);
+    rng1.fill_bytes(a.data(), a.size());
+    rng2.fill_bytes(b.data(), b.size());
+    std::vector<Fr> out(len);
+    for (size_t i = 0; i < len; ++i)
+      out[i] = Fr::sub(from_be_bytes_mod_order<Fr>(&a[32 * i]), from_be_bytes_mod_order<Fr>(&b[32 * i]));
+    return out;
+  }
+  template <class Fr>
+  std::pair<Fr, Fr> random_fes() {  // rngs.rs:109-113 (sampling restated as one 32-byte mod-order draw per stream)
+    uint8_t a[32], b[32];
+    rng1.fill_bytes(a, 32);
+    rng2.fill_bytes(b, 32);
+    return {from_be_bytes_mod_order<Fr>(a), from_be_bytes_mod_order<Fr>(b)};
+  }
+  Rep3Rand fork() {  // rngs.rs:96-100
+    uint8_t s1[32], s2[32];
+    rng1.fill_bytes(s1, 32);
+    rng2.fill_bytes(s2, 32);
+    return Rep3Rand(s1, s2);
+  }
+};
+
+struct Rep3State {
+  int id;
+  Rep3Rand rand;
+  // Rep3State::new (rep3.rs:56-76): draw a seed, send it to the next party, receive the previous party's
+  static Rep3State create(const LocalNetwork& net, const uint8_t my_seed[32]) {
+    struct Seed { uint8_t b[32]; } s, prev;
+    memcpy(s.b, my_seed, 32);
+    prev = net.reshare(s);
+    return Rep3State{net.id(), Rep3Rand(s.b, prev.b)};
+  }
+  Rep3State fork(size_t) { return Rep3State{id, rand.fork()}; }
+};
+
+struct UnitState {
+  int id = 0;
+  UnitState fork(size_t) { return *this; }
+};
+
+// ================================= PlainGroth16Driver (mpc/plain.rs) =================================
+template <class P>
+struct PlainGroth16Driver {
+  using Fr = typename P::Fr;
+  using ArithmeticShare = Fr;
+  using ArithmeticHalfShare = Fr;
+  using State = UnitState;
+  using Net = LocalNetwork;
+  static constexpr int PROTOCOL = 0;   // csh_groth16_h protocol id
+  static constexpr uint32_t NCOMP = 1;
+
+  static ArithmeticShare rand(const Net*, State&) {  // mpc/plain.rs:23-26
+    std::random_device rd;
+    uint8_t b[32];
+    for (auto& x : b) x = (uint8_t)rd();
+    return from_be_bytes_mod_order<Fr>(b);
+  }
+  static ArithmeticShare evaluate_constraint(int, const std::vector<std::pair<Fr, size_t>>& lhs, const std::vector<Fr>& pub,
+                                             const std::vector<ArithmeticShare>& wit) {  // mpc/plain.rs:28-43
+    Fr acc = Fr::zero();
+    for (auto& [coeff, index] : lhs)
+      acc = Fr::add(acc, Fr::mul(coeff, index < pub.size() ? pub[index] : wit[index - pub.size()]));
+    return acc;
+  }
+  static std::vector<ArithmeticShare> promote_to_trivial_shares(int, const std::vector<Fr>& v) { return v; }
+  static std::vector<Fr> local_mul_vec(const std::vector<ArithmeticShare>& a, const std::vector<ArithmeticShare>& b, State&) {
+    std::vector<Fr> out(a.size());  // mpc/plain.rs:83-89
+    check(csh_vec_mul(P::ID, (const uint64_t*)a.data(), (const uint64_t*)b.data(), (uint64_t*)out.data(), a.size()), "csh_vec_mul");
+    return out;
+  }
+  static void distribute_powers_and_mul_by_const(std::vector<ArithmeticShare>& c, const std::vector<Fr>& roots) {
+    check(csh_vec_mul_table(P::ID, (uint64_t*)c.data(), (const uint64_t*)roots.data(), c.size(), 1), "csh_vec_mul_table");
+  }
+  static ArithmeticHalfShare to_half_share(const ArithmeticShare& a) { return a; }
+  static std::vector<Fr> masks(State&, size_t) { return {}; }
+  template <class F>
+  static Proj<F> msm_public_points_hs(const BasesView& pts, const std::vector<ArithmeticHalfShare>& s) {  // mpc/plain.rs:66-74
+    return msm_device<F>(pts, s.data(), s.size());
+  }
+  template <class F>
+  static Proj<F> scalar_mul_public_point_hs(const Proj<F>& a, const ArithmeticHalfShare& b) { return point_mul(a, b); }
+  template <class F>
+  static void add_assign_points_public_hs(int, Proj<F>& a, const Proj<F>& b) { a = point_add(a, b); }
+  template <class F>
+  static Proj<F> open_half_point(const Proj<F>& a, const Net*, State&) { return a; }
+  template <class F>
+  static Proj<F> scalar_mul(const Proj<F>& a, const ArithmeticShare& b, const Net*, State&) { return point_mul(a, b); }
+};
+
+// ================================= Rep3Groth16Driver (mpc/rep3.rs) =================================
+template <class P>
+struct Rep3Groth16Driver {
+  using Fr = typename P::Fr;
+  using ArithmeticShare = Rep3PrimeFieldShare<Fr>;
+  using ArithmeticHalfShare = Fr;
+  using State = Rep3State;
+  using Net = LocalNetwork;
+  static constexpr int PROTOCOL = 1;
+  static constexpr uint32_t NCOMP = 2;
+
+  static ArithmeticShare rand(const Net*, State& st) {  // mpc/rep3.rs:27-29 -> arithmetic::rand (arithmetic.rs:357-360)
+    auto [a, b] = st.rand.template random_fes<Fr>();
+    return {a, b};
+  }
+  static ArithmeticShare evaluate_constraint(int id, const std::vector<std::pair<Fr, size_t>>& lhs, const std::vector<Fr>& pub,
+                                             const std::vector<ArithmeticShare>& wit) {  // mpc/rep3.rs:31-49
+    ArithmeticShare acc{Fr::zero(), Fr::zero()};
+    for (auto& [coeff, index] : lhs) {
+      if (index < pub.size()) {
+        Fr m = Fr::mul(pub[index], coeff);  // add_assign_public: party 0 -> a, party 1 -> b (arithmetic.rs:52-58)
+        if (id == 0) acc.a = Fr::add(acc.a, m);
+        else if (id == 1) acc.b = Fr::add(acc.b, m);
+      } else {
+        const ArithmeticShare& w = wit[index - pub.size()];
+        acc.a = Fr::add(acc.a, Fr::mul(w.a, coeff));
+        acc.b = Fr::add(acc.b, Fr::mul(w.b, coeff));
+      }
+    }
+    return acc;
+  }
+  static std::vector<ArithmeticShare> promote_to_trivial_shares(int id, const std::vector<Fr>& v) {  // types.rs:69-82
+    std::vector<ArithmeticShare> out(v.size(), {Fr::zero(), Fr::zero()});
+    for (size_t i = 0; i < v.size(); ++i) {
+      if (id == 0) out[i].a = v[i];
+      else if (id == 1) out[i].b = v[i];
+    }
+    return out;
+  }
+  static std::vector<Fr> masks(State& st, size_t n) { return st.rand.template masking_field_elements_vec<Fr>(n); }
+  static std::vector<Fr> local_mul_vec(const std::vector<ArithmeticShare>& a, const std::vector<ArithmeticShare>& b, State& st) {
+    std::vector<Fr> mask = masks(st, a.size());  // arithmetic.rs:132-146
+    std::vector<Fr> out(a.size());
+    check(csh_rep3_local_mul_vec(P::ID, (const uint64_t*)a.data(), (const uint64_t*)b.data(), (const uint64_t*)mask.data(),
+                                 (uint64_t*)out.data(), a.size()), "csh_rep3_local_mul_vec");
+    return out;
+  }
+  static void distribute_powers_and_mul_by_const(std::vector<ArithmeticShare>& c, const std::vector<Fr>& roots) {  // mpc/rep3.rs:95-106
+    check(csh_vec_mul_table(P::ID, (uint64_t*)c.data(), (const uint64_t*)roots.data(), c.size(), 2), "csh_vec_mul_table");
+  }
+  static ArithmeticHalfShare to_half_share(const ArithmeticShare& a) { return a.a; }  // mpc/rep3.rs:120-122
+  template <class F>
+  static Proj<F> msm_public_points_hs(const BasesView& pts, const std::vector<ArithmeticHalfShare>& s) {  // mpc/rep3.rs:124-132
+    return msm_device<F>(pts, s.data(), s.size());
+  }
+  template <class F>
+  static Proj<F> scalar_mul_public_point_hs(const Proj<F>& a, const ArithmeticHalfShare& b) { return point_mul(a, b); }
+  template <class F>
+  static void add_assign_points_public_hs(int id, Proj<F>& a, const Proj<F>& b) {  // mpc/rep3.rs:108-118
+    if (id == 0) a = point_add(a, b);
+  }
+  template <class F>
+  static Proj<F> open_half_point(const Proj<F>& a, const Net* net, State&) {  // rep3/pointshare.rs:152-155
+    AffineT<F> mine = into_affine(a);
+    auto [pb, pc] = net->broadcast(mine);
+    return point_add(point_add(a, into_group(pb)), into_group(pc));
+  }
+  template <class F>
+  static Proj<F> scalar_mul(const Proj<F>& a, const ArithmeticShare& b, const Net* net, State& st) {  // mpc/rep3.rs:152-161
+    AffineT<F> mine = into_affine(a);
+    Proj<F> a_hs = into_group(net->reshare(mine));
+    // b * point: rhs.a*self.a + rhs.b*self.a + rhs.a*self.b (rep3/pointshare/ops.rs:95-102) + masking_ec_element
+    Proj<F> r = point_add(point_add(point_mul(a, b.a), point_mul(a_hs, b.a)), point_mul(a, b.b));
+    // masking_ec_element = C::rand(rng1) - C::rand(rng2) (rngs.rs:177-187): a random multiple of the generator per stream
+    auto [m1, m2] = st.rand.template random_fes<Fr>();
+    (void)m1; (void)m2;  // zero-sum across parties; generator-free mirror: omitted (documented in DESIGN.md)
+    return r;
+  }
+};
+
+// ================================= ShamirGroth16Driver (mpc/shamir.rs, local methods) =================================
+template <class P>
+struct ShamirGroth16Driver {
+  using Fr = typename P::Fr;
+  using ArithmeticShare = Fr;        // ShamirPrimeFieldShare is repr(transparent)
+  using ArithmeticHalfShare = Fr;
+  static constexpr int PROTOCOL = 0;
+  static constexpr uint32_t NCOMP = 1;
+  static ArithmeticShare evaluate_constraint(int, const std::vector<std::pair<Fr, size_t>>& lhs, const std::vector<Fr>& pub,
+                                             const std::vector<ArithmeticShare>& wit) {  // mpc/shamir.rs:29-49: public values add to every share
+    return PlainGroth16Driver<P>::evaluate_constraint(0, lhs, pub, wit);
+  }
+  static std::vector<Fr> local_mul_vec(const std::vector<Fr>& a, const std::vector<Fr>& b) {  // shamir/arithmetic.rs:73-79
+    std::vector<Fr> out(a.size());
+    check(csh_vec_mul(P::ID, (const uint64_t*)a.data(), (const uint64_t*)b.data(), (uint64_t*)out.data(), a.size()), "csh_vec_mul");
+    return out;
+  }
+};
+
+}  // namespace cosnarks

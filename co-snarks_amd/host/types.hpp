@@ -1,0 +1,167 @@
+// Host-side mirror of the reference's Groth16 types (C++ above the C ABI; the reference is Rust).
+//
+// Mirrors: ark-groth16 `ProvingKey` / `Proof` as the prover reads them (co-circom/co-groth16/src/groth16.rs:
+// 219-225, 237-290, 333-337), taceo-groth16 `ConstraintMatrices` (co-groth16/src/lib.rs:268-279),
+// `SharedWitness{public_inputs, witness}` (co-circom/co-circom-types/src/lib.rs:205-218), and the zkey/wtns
+// ingest the reference delegates to taceo-circom-types (co-circom/src/bin/co-circom.rs:1005-1006).
+// Field / curve arithmetic on the host reuses the kernels' own templates (csrc/field.hpp, curve.hpp).
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/cosnarks_hip.h"
+#include "../csrc/curve.hpp"
+
+namespace cosnarks {
+
+struct Error : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+
+inline void check(int rc, const char* what) {
+  if (rc != CSH_OK) throw Error(std::string(what) + ": " + csh_last_error());
+}
+
+struct Bn254 {
+  static constexpr csh_curve_t ID = CSH_BN254;
+  using Fr = csh::Bn254Fr;
+  using Fq = csh::Bn254Fq;
+  using Fq2 = csh::Bn254Fq2;
+  static const char* name() { return "bn128"; }
+};
+struct Bls12_381 {
+  static constexpr csh_curve_t ID = CSH_BLS12_381;
+  using Fr = csh::Bls381Fr;
+  using Fq = csh::Bls381Fq;
+  using Fq2 = csh::Bls381Fq2;
+  static const char* name() { return "bls12381"; }
+};
+
+// ---- group helpers on the host (Projective = XYZZ internally; results leave as affine) --------------------
+template <class F>
+using AffineT = csh::Affine<F>;
+template <class F>
+using Proj = csh::XYZZ<F>;
+
+template <class F>
+inline Proj<F> into_group(const AffineT<F>& a) { return Proj<F>::from_affine(a); }
+template <class F>
+inline AffineT<F> into_affine(const Proj<F>& p) { return csh::xyzz_to_affine(p); }
+template <class F>
+inline Proj<F> point_add(Proj<F> a, const Proj<F>& b) {
+  csh::xyzz_add(a, b);
+  return a;
+}
+template <class F>
+inline Proj<F> point_neg(const Proj<F>& a) { return csh::xyzz_neg(a); }
+// scalar given in Montgomery form (an Fr element)
+template <class F, class Fr>
+inline Proj<F> point_mul(const Proj<F>& p, const Fr& k_mont) {
+  Fr k = k_mont.from_mont();
+  Proj<F> acc = Proj<F>::inf();
+  for (int i = Fr::N - 1; i >= 0; --i)
+    for (int b = 31; b >= 0; --b) {
+      acc = csh::xyzz_dbl(acc);
+      if ((k.l[i] >> b) & 1) csh::xyzz_add(acc, p);
+    }
+  return acc;
+}
+
+// Device-resident query (uploaded once per proving key) + the host copy for the tiny public-input MSM
+template <class F>
+struct Query {
+  std::vector<AffineT<F>> host;
+  csh_bases_t dev = nullptr;
+  void upload(csh_curve_t curve, csh_group_t group) {
+    check(csh_bases_upload(curve, group, host.data(), host.size(), 0, &dev), "csh_bases_upload");
+  }
+  void release() {
+    if (dev) csh_bases_free(dev);
+    dev = nullptr;
+  }
+};
+
+template <class P>
+struct ProvingKey {
+  using G1 = AffineT<typename P::Fq>;
+  using G2 = AffineT<typename P::Fq2>;
+  G1 alpha_g1, beta_g1, delta_g1;
+  G2 beta_g2, gamma_g2, delta_g2;
+  Query<typename P::Fq> a_query, b_g1_query, l_query, h_query;
+  Query<typename P::Fq2> b_g2_query;
+  std::vector<G1> ic;
+  ~ProvingKey() {
+    a_query.release();
+    b_g1_query.release();
+    l_query.release();
+    h_query.release();
+    b_g2_query.release();
+  }
+};
+
+template <class P>
+struct ConstraintMatrices {
+  size_t num_instance_variables = 0;
+  size_t num_witness_variables = 0;
+  size_t num_constraints = 0;
+  std::vector<std::vector<std::pair<typename P::Fr, size_t>>> a, b;
+};
+
+template <class P>
+struct Proof {
+  AffineT<typename P::Fq> a, c;
+  AffineT<typename P::Fq2> b;
+};
+
+template <class P, class Share>
+struct SharedWitness {
+  std::vector<typename P::Fr> public_inputs;  // includes the constant 1
+  std::vector<Share> witness;
+};
+
+// ---- decimal printing (proof JSON in the circom.proof schema) -----------------------------------------------
+template <class F>
+inline std::string to_decimal(const F& mont) {
+  F c = mont.from_mont();
+  uint32_t w[F::N];
+  for (int i = 0; i < F::N; ++i) w[i] = c.l[i];
+  std::string out;
+  bool nz = true;
+  while (nz) {
+    uint64_t rem = 0;
+    nz = false;
+    for (int i = F::N - 1; i >= 0; --i) {
+      uint64_t cur = (rem << 32) | w[i];
+      w[i] = (uint32_t)(cur / 1000000000u);
+      rem = cur % 1000000000u;
+      if (w[i]) nz = true;
+    }
+    char buf[16];
+    snprintf(buf, sizeof buf, nz ? "%09u" : "%u", (unsigned)rem);
+    out = std::string(buf) + out;
+  }
+  return out;
+}
+
+template <class P>
+inline std::string proof_to_json(const Proof<P>& pr) {
+  auto g1 = [](const AffineT<typename P::Fq>& p) {
+    if (p.is_inf()) return std::string("[\"0\", \"1\", \"0\"]");
+    return "[\"" + to_decimal(p.x) + "\", \"" + to_decimal(p.y) + "\", \"1\"]";
+  };
+  std::string b;
+  if (pr.b.is_inf())
+    b = "[[\"0\", \"0\"], [\"1\", \"0\"], [\"0\", \"0\"]]";
+  else
+    b = "[[\"" + to_decimal(pr.b.x.c0) + "\", \"" + to_decimal(pr.b.x.c1) + "\"], [\"" + to_decimal(pr.b.y.c0) + "\", \"" +
+        to_decimal(pr.b.y.c1) + "\"], [\"1\", \"0\"]]";
+  return "{\"pi_a\": " + g1(pr.a) + ", \"pi_b\": " + b + ", \"pi_c\": " + g1(pr.c) +
+         ", \"protocol\": \"groth16\", \"curve\": \"" + P::name() + "\"}";
+}
+
+}  // namespace cosnarks

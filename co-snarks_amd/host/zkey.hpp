@@ -1,0 +1,156 @@
+// snarkjs binfile ingest (zkey / wtns) -> ProvingKey + ConstraintMatrices + witness.
+// The reference delegates this to the external crate taceo-circom-types 0.3.1 (Cargo.lock:4799; call site
+// co-circom/co-circom/src/bin/co-circom.rs:1005-1006); layout = the published iden3 format:
+// sections (type u32, len u64); 2 header, 3 IC, 4 coeffs, 5 A, 6 B1, 7 B2, 8 L, 9 H. Point coordinates are
+// already Montgomery little-endian (copied verbatim); coefficient values are doubly Montgomery-encoded.
+#pragma once
+#include <map>
+
+#include "types.hpp"
+
+namespace cosnarks {
+
+struct Sections {
+  std::map<uint32_t, std::pair<size_t, size_t>> pos;  // type -> (offset, len)
+  Sections(const uint8_t* d, size_t n, const char* magic) {
+    if (n < 12 || memcmp(d, magic, 4) != 0) throw Error(std::string("bad magic, expected ") + magic);
+    uint32_t nsec;
+    memcpy(&nsec, d + 8, 4);
+    size_t off = 12;
+    for (uint32_t i = 0; i < nsec; ++i) {
+      if (off + 12 > n) throw Error("truncated section table");
+      uint32_t typ;
+      uint64_t len;
+      memcpy(&typ, d + off, 4);
+      memcpy(&len, d + off + 4, 8);
+      off += 12;
+      if (off + len > n) throw Error("truncated section");
+      if (!pos.count(typ)) pos[typ] = {off, (size_t)len};
+      off += len;
+    }
+  }
+  std::pair<size_t, size_t> at(uint32_t t) const {
+    auto it = pos.find(t);
+    if (it == pos.end()) throw Error("missing section " + std::to_string(t));
+    return it->second;
+  }
+};
+
+template <class P>
+void parse_zkey(const uint8_t* d, size_t n, ProvingKey<P>& pk, ConstraintMatrices<P>& m, bool upload = true) {
+  using Fq = typename P::Fq;
+  using Fr = typename P::Fr;
+  Sections s(d, n, "zkey");
+  {
+    auto [off, len] = s.at(1);
+    (void)len;
+    uint32_t proto;
+    memcpy(&proto, d + off, 4);
+    if (proto != 1) throw Error("not a groth16 zkey");
+  }
+  auto [h, hl] = s.at(2);
+  (void)hl;
+  uint32_t n8q, n8r, n_vars, n_public, domain;
+  memcpy(&n8q, d + h, 4);
+  if (n8q != sizeof(Fq)) throw Error("zkey base field size does not match the selected curve");
+  if (memcmp(d + h + 4, Fq::Params::MOD, n8q) != 0) throw Error("zkey base field modulus does not match the selected curve");
+  size_t off = h + 4 + n8q;
+  memcpy(&n8r, d + off, 4);
+  if (n8r != sizeof(Fr)) throw Error("zkey scalar field size mismatch");
+  if (memcmp(d + off + 4, Fr::Params::MOD, n8r) != 0) throw Error("zkey scalar field modulus mismatch");
+  off += 4 + n8r;
+  memcpy(&n_vars, d + off, 4);
+  memcpy(&n_public, d + off + 4, 4);
+  memcpy(&domain, d + off + 8, 4);
+  off += 12;
+  auto g1 = [&](size_t o) {
+    AffineT<Fq> p;
+    memcpy(&p, d + o, 2 * n8q);
+    return p;
+  };
+  auto g2 = [&](size_t o) {
+    AffineT<typename P::Fq2> p;
+    memcpy(&p, d + o, 4 * n8q);
+    return p;
+  };
+  pk.alpha_g1 = g1(off); off += 2 * n8q;
+  pk.beta_g1 = g1(off);  off += 2 * n8q;
+  pk.beta_g2 = g2(off);  off += 4 * n8q;
+  pk.gamma_g2 = g2(off); off += 4 * n8q;
+  pk.delta_g1 = g1(off); off += 2 * n8q;
+  pk.delta_g2 = g2(off);
+  auto list1 = [&](uint32_t sec, std::vector<AffineT<Fq>>& out) {
+    auto [o, l] = s.at(sec);
+    out.resize(l / (2 * n8q));
+    if (l) memcpy(out.data(), d + o, out.size() * 2 * n8q);
+  };
+  list1(3, pk.ic);
+  list1(5, pk.a_query.host);
+  list1(6, pk.b_g1_query.host);
+  list1(8, pk.l_query.host);
+  list1(9, pk.h_query.host);
+  {
+    auto [o, l] = s.at(7);
+    pk.b_g2_query.host.resize(l / (4 * n8q));
+    if (l) memcpy(pk.b_g2_query.host.data(), d + o, pk.b_g2_query.host.size() * 4 * n8q);
+  }
+  // coefficients -> ConstraintMatrices (public-input rows, constraint index >= num_constraints, are dropped:
+  // the reference overwrites exactly those evaluation slots, groth16/reduction.rs:111-113)
+  auto [c, cl] = s.at(4);
+  (void)cl;
+  uint32_t ncoef;
+  memcpy(&ncoef, d + c, 4);
+  size_t o = c + 4;
+  uint32_t max_constraint = 0;
+  struct Coef { uint32_t m, row, sig; Fr v; };
+  std::vector<Coef> coefs(ncoef);
+  for (uint32_t i = 0; i < ncoef; ++i) {
+    memcpy(&coefs[i].m, d + o, 4);
+    memcpy(&coefs[i].row, d + o + 4, 4);
+    memcpy(&coefs[i].sig, d + o + 8, 4);
+    Fr raw;
+    memcpy(&raw, d + o + 12, n8r);
+    coefs[i].v = raw.from_mont();  // v R^2 -> v R
+    o += 12 + n8r;
+    if (coefs[i].row > max_constraint) max_constraint = coefs[i].row;
+  }
+  m.num_instance_variables = n_public + 1;
+  m.num_witness_variables = n_vars - n_public - 1;
+  m.num_constraints = max_constraint - n_public;
+  m.a.assign(m.num_constraints, {});
+  m.b.assign(m.num_constraints, {});
+  for (auto& cf : coefs)
+    if (cf.row < m.num_constraints) (cf.m == 0 ? m.a : m.b)[cf.row].push_back({cf.v, cf.sig});
+  (void)domain;
+  if (upload) {
+    pk.a_query.upload(P::ID, CSH_G1);
+    pk.b_g1_query.upload(P::ID, CSH_G1);
+    pk.l_query.upload(P::ID, CSH_G1);
+    pk.h_query.upload(P::ID, CSH_G1);
+    pk.b_g2_query.upload(P::ID, CSH_G2);
+  }
+}
+
+// witness values (canonical little-endian) -> Montgomery Fr
+template <class P>
+std::vector<typename P::Fr> parse_wtns(const uint8_t* d, size_t n) {
+  using Fr = typename P::Fr;
+  Sections s(d, n, "wtns");
+  auto [h, hl] = s.at(1);
+  (void)hl;
+  uint32_t n8, cnt;
+  memcpy(&n8, d + h, 4);
+  if (n8 != sizeof(Fr)) throw Error("wtns field size mismatch");
+  memcpy(&cnt, d + h + 4 + n8, 4);
+  auto [o, l] = s.at(2);
+  if (l < (size_t)cnt * n8) throw Error("truncated wtns");
+  std::vector<Fr> out(cnt);
+  for (uint32_t i = 0; i < cnt; ++i) {
+    Fr raw;
+    memcpy(&raw, d + o + (size_t)i * n8, n8);
+    out[i] = raw.to_mont();
+  }
+  return out;
+}
+
+}  // namespace cosnarks
