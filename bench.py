@@ -77,16 +77,14 @@ def main():
     out = np.zeros(12, dtype=np.uint64)
     pbytes = hip.msm_partial_bytes(hip.BN254, hip.G1)
     part = torch.zeros(pbytes, dtype=torch.uint8, device=dev)
-    gathered = torch.zeros(world * pbytes, dtype=torch.uint8, device=dev) if world > 1 else None
+    from cosnarks_amd.distributed import allgather_and_fold
 
     def step():
         if world == 1:
             B._check(L.csh_msm_dev(bases_h, C.c_size_t(0), C.c_size_t(n), C.c_void_p(sc.data_ptr()), 1, out.ctypes.data_as(C.c_void_p), C.c_void_p(stream)))
             return out
         B._check(L.csh_msm_partial_dev(bases_h, C.c_size_t(0), C.c_size_t(n), C.c_void_p(sc.data_ptr()), 1, C.c_void_p(part.data_ptr()), C.c_void_p(stream)))
-        dist.all_gather_into_tensor(gathered, part)              # RCCL over xGMI: world * ~8 KiB
-        host = gathered.cpu().numpy()
-        return hip.msm_fold_partials(hip.BN254, hip.G1, host, world)
+        return allgather_and_fold(part, hip.BN254, hip.G1, world, dist)   # RCCL all-gather over xGMI + host fold
 
     def barrier():
         if world > 1:
@@ -146,7 +144,7 @@ def main():
         line = {
             "metric": "BN254 G1 MSM points/sec", "value": value, "unit": "points/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u32-limb Montgomery (254-bit Fq/Fr)", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "i32x9 29-bit-limb Montgomery, i64 accumulate (BN254 Fq 254-bit)", "data": "synthetic",
             "config": {"workload": f"BN254 G1 Pippenger MSM, 2^{args.log_n} uniform scalars/points per GPU (BASELINE config 2)",
                        "points_per_gpu": n, "split": "contiguous point ranges + RCCL all-gather of window partials" if world > 1 else "single GPU"},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "result_check": check,

@@ -79,5 +79,5 @@ def test_prove_rejects_wrong_witness_length(gpu):
     _, wt_big, _, _ = _load("bn254", "poseidon")
     with pytest.raises(gpu.CoSnarksHipError, match="amount of private witness variables does not match"):
         g.prove_plain(0, zk, wt_big, R, S)
-    with pytest.raises(gpu.CoSnarksHipError, match="modulus does not match"):
+    with pytest.raises(gpu.CoSnarksHipError, match="does not match the selected curve"):
         g.prove_plain(1, zk, wt, R, S)
