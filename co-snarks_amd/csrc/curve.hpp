@@ -101,7 +101,7 @@ CSH_HD_NOINLINE XYZZ<F> xyzz_dbl(XYZZ<F> p) {
 }
 
 template <class F>
-CSH_HD_NOINLINE XYZZ<F> xyzz_add_v(XYZZ<F> acc, XYZZ<F> p) {
+CSH_HD XYZZ<F> xyzz_add_inl(XYZZ<F> acc, const XYZZ<F>& p) {
   if (p.is_inf()) return acc;
   if (acc.is_inf()) return p;
   F u1 = F::mul(acc.x, p.zz);
@@ -124,6 +124,10 @@ CSH_HD_NOINLINE XYZZ<F> xyzz_add_v(XYZZ<F> acc, XYZZ<F> p) {
   acc.zz = F::mul(F::mul(acc.zz, p.zz), pp);
   acc.zzz = F::mul(F::mul(acc.zzz, p.zzz), ppp);
   return acc;
+}
+template <class F>
+CSH_HD_NOINLINE XYZZ<F> xyzz_add_v(XYZZ<F> acc, XYZZ<F> p) {
+  return xyzz_add_inl(acc, p);
 }
 template <class F>
 CSH_HD void xyzz_add(XYZZ<F>& acc, const XYZZ<F>& p) {

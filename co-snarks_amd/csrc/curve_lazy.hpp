@@ -26,7 +26,7 @@ CSH_HD_NOINLINE XYZZLazy<L> lazy_mdbl(L x, L y) {
   L m = L::add(L::add(xx, xx), xx).normalized();
   XYZZLazy<L> r;
   r.x = L::sub(L::sqr(m), L::add(s, s)).normalized();
-  r.y = L::sub(L::mul(m, L::sub(s, r.x)), L::mul(w, y)).normalized();
+  r.y = L::mul_sub(m, L::sub(s, r.x), w, y);
   r.zz = v;
   r.zzz = w;
   r.empty = false;
@@ -63,7 +63,7 @@ CSH_HD void lazy_madd(XYZZLazy<L>& acc, const L& x2, const L& y2) {
   const L ppp = L::mul(p, pp);
   const L q = L::mul(acc.x, pp);
   const L x3 = L::sub(L::sub(L::sqr(r), ppp), L::add(q, q)).normalized();
-  const L y3 = L::sub(L::mul(r, L::sub(q, x3)), L::mul(acc.y, ppp)).normalized();
+  const L y3 = L::mul_sub(r, L::sub(q, x3), acc.y, ppp);   // r*(q - x3) - y1*ppp, one reduction
   acc.x = x3;
   acc.y = y3;
   acc.zz = L::mul(acc.zz, pp);

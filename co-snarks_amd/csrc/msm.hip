@@ -27,10 +27,10 @@ namespace csh {
 
 // LAZY: bucket accumulation runs in the signed lazy field (field29.hpp); Bases then stores the coordinates
 // re-encoded as canonical x*R' (same 32 bytes per coordinate), converted once at upload.
-struct Bn254G1Cfg { using Fq = Bn254Fq;   using Fr = Bn254Fr; static constexpr bool LAZY = true;  using L = Fq29s; };
-struct Bn254G2Cfg { using Fq = Bn254Fq2;  using Fr = Bn254Fr; static constexpr bool LAZY = false; using L = void; };
-struct Bls381G1Cfg { using Fq = Bls381Fq;  using Fr = Bls381Fr; static constexpr bool LAZY = false; using L = void; };
-struct Bls381G2Cfg { using Fq = Bls381Fq2; using Fr = Bls381Fr; static constexpr bool LAZY = false; using L = void; };
+struct Bn254G1Cfg { using Fq = Bn254Fq;   using Fr = Bn254Fr; static constexpr bool LAZY = true;  using L = Fq29s; static constexpr bool INLINE_ADD = true; };
+struct Bn254G2Cfg { using Fq = Bn254Fq2;  using Fr = Bn254Fr; static constexpr bool LAZY = false; using L = void; static constexpr bool INLINE_ADD = false; };
+struct Bls381G1Cfg { using Fq = Bls381Fq;  using Fr = Bls381Fr; static constexpr bool LAZY = false; using L = void; static constexpr bool INLINE_ADD = false; };
+struct Bls381G2Cfg { using Fq = Bls381Fq2; using Fr = Bls381Fr; static constexpr bool LAZY = false; using L = void; static constexpr bool INLINE_ADD = false; };
 
 struct Bases {
   csh_curve_t curve;
@@ -236,8 +236,10 @@ __device__ __forceinline__ uint32_t upper_bound_u32(const uint32_t* __restrict__
   return lo;
 }
 
-template <class Cfg>
-__global__ __launch_bounds__(ACC_BLK) void k_msm_accum(const Affine<typename Cfg::Fq>* __restrict__ bases, MsmParams p,
+// VAR selects an occupancy / prefetch variant (tuning knob CSH_ACC_VARIANT): 0 = prefetch, default registers;
+// 1 = prefetch, >= 3 waves/SIMD; 2 = no prefetch, >= 3 waves/SIMD; 3 = no prefetch, >= 4 waves/SIMD
+template <class Cfg, int VAR>
+__global__ __launch_bounds__(ACC_BLK, (VAR == 0 ? 1 : (VAR == 3 ? 4 : 3))) void k_msm_accum(const Affine<typename Cfg::Fq>* __restrict__ bases, MsmParams p,
                                                        const uint32_t* __restrict__ start, const uint32_t* __restrict__ tstart,
                                                        const uint32_t* __restrict__ ntasks, const uint32_t* __restrict__ sorted,
                                                        XYZZ<typename Cfg::Fq>* partial, uint32_t* task_bucket) {
@@ -261,9 +263,13 @@ __global__ __launch_bounds__(ACC_BLK) void k_msm_accum(const Affine<typename Cfg
     uint32_t e_next = so[lo];                       // lo < hi: every task owns >= 1 entry
     Affine<Fq> pt_next = bases[e_next & 0x7fffffffu];
     for (uint32_t k = lo; k < hi; ++k) {
+      if (VAR >= 2 && k > lo) {
+        e_next = so[k];
+        pt_next = bases[e_next & 0x7fffffffu];
+      }
       const uint32_t e = e_next;
       const Affine<Fq> pt = pt_next;
-      if (k + 1 < hi) {                             // software prefetch of the next gather
+      if ((VAR <= 1) && k + 1 < hi) {               // software prefetch of the next gather
         e_next = so[k + 1];
         pt_next = bases[e_next & 0x7fffffffu];
       }
@@ -285,6 +291,14 @@ __global__ __launch_bounds__(ACC_BLK) void k_msm_accum(const Affine<typename Cfg
     partial[(size_t)w * p.tmax + t] = acc;
   }
   task_bucket[(size_t)w * p.tmax + t] = b;
+}
+
+// Point addition used by the reduction kernels: inlined for the 8-limb base field (2x faster per op than the
+// out-of-line call through scratch), out of line for the wide fields (code size).
+template <class Cfg>
+__device__ __forceinline__ void padd(XYZZ<typename Cfg::Fq>& a, const XYZZ<typename Cfg::Fq>& b) {
+  if constexpr (Cfg::INLINE_ADD) a = xyzz_add_inl(a, b);
+  else xyzz_add(a, b);
 }
 
 // Segment k of window w folds tasks [t0, t1): returns sum_t bucket(t) * partial(t).
@@ -311,18 +325,18 @@ __global__ __launch_bounds__(64) void k_msm_reduce(MsmParams p, const uint32_t* 
       uint32_t gap = prev_b - b;
       if (gap) {
         if (gap <= 4) {
-          while (gap--) xyzz_add(acc, running);
+          while (gap--) padd<Cfg>(acc, running);
         } else {
           XYZZ<Fq> m = xyzz_mul_small(running, gap);
-          xyzz_add(acc, m);
+          padd<Cfg>(acc, m);
         }
       }
-      xyzz_add(running, pw[t]);
+      padd<Cfg>(running, pw[t]);
       prev_b = b;
     }
     // acc = sum (b_t - bmin) P_t ; add bmin * R
     XYZZ<Fq> m = xyzz_mul_small(running, prev_b);
-    xyzz_add(acc, m);
+    padd<Cfg>(acc, m);
   }
   segres[(size_t)w * p.S + k] = acc;
 }
@@ -335,7 +349,7 @@ __global__ __launch_bounds__(64) void k_msm_fold(XYZZ<typename Cfg::Fq>* arr, ui
   if (i >= half) return;
   XYZZ<typename Cfg::Fq>* a = arr + (size_t)w * stride;
   XYZZ<typename Cfg::Fq> x = a[i];
-  xyzz_add(x, a[i + half]);
+  padd<Cfg>(x, a[i + half]);
   a[i] = x;
 }
 
@@ -407,8 +421,8 @@ static int msm_windows_dev(const Bases* B, size_t offset, size_t n, const uint64
   if (envL && atoi(envL) > 0) L = (uint64_t)atoi(envL);
   p.L = (uint32_t)L;
   p.tmax = (uint32_t)(p.NB + n / p.L + 2);
-  p.S = 1024;
-  while (p.S > 64 && p.S > p.tmax) p.S >>= 1;
+  p.S = 4096;
+  while (p.S > 64 && (uint64_t)p.S * 8 > p.tmax) p.S >>= 1;  // >= ~8 tasks per segment
   p.mont = mont;
   {
     uint64_t ch = 512 / (uint64_t)p.W;
@@ -474,8 +488,18 @@ static int msm_windows_dev(const Bases* B, size_t offset, size_t n, const uint64
   CSH_TRY(mark(2));
   hipLaunchKernelGGL(k_msm_scatter_lds, dim3(p.CH, p.W), dim3(SORT_BLK), sort_lds, st, p, dig, start, blkcnt, sorted);
   CSH_TRY(mark(3));
-  hipLaunchKernelGGL(k_msm_accum<Cfg>, dim3((p.tmax + ACC_BLK - 1) / ACC_BLK, p.W), dim3(ACC_BLK), 0, st, bases, p, start, tstart, ntasks,
-                     sorted, partial, task_bucket);
+  {
+    static const int variant = [] {
+      const char* e = getenv("CSH_ACC_VARIANT");
+      return e ? atoi(e) : 0;
+    }();
+    const dim3 ag((p.tmax + ACC_BLK - 1) / ACC_BLK, p.W), ab(ACC_BLK);
+    const int v = Cfg::LAZY ? variant : 0;
+    if (v == 1) hipLaunchKernelGGL((k_msm_accum<Cfg, 1>), ag, ab, 0, st, bases, p, start, tstart, ntasks, sorted, partial, task_bucket);
+    else if (v == 2) hipLaunchKernelGGL((k_msm_accum<Cfg, 2>), ag, ab, 0, st, bases, p, start, tstart, ntasks, sorted, partial, task_bucket);
+    else if (v == 3) hipLaunchKernelGGL((k_msm_accum<Cfg, 3>), ag, ab, 0, st, bases, p, start, tstart, ntasks, sorted, partial, task_bucket);
+    else hipLaunchKernelGGL((k_msm_accum<Cfg, 0>), ag, ab, 0, st, bases, p, start, tstart, ntasks, sorted, partial, task_bucket);
+  }
   CSH_TRY(mark(4));
   hipLaunchKernelGGL(k_msm_reduce<Cfg>, dim3((p.S + 63) / 64, p.W), dim3(64), 0, st, p, ntasks, partial, task_bucket, segres);
   for (uint32_t half = p.S / 2; half >= 1; half >>= 1)

@@ -51,3 +51,14 @@ def prove_rep3(curve: int, zkey: bytes, wtns: bytes, seed: int, r=None, s=None, 
     if rc != 0:
         raise CoSnarksHipError(glib().cog16_last_error().decode())
     return json.loads(out.value.decode()), h
+
+
+def bench_synthetic(curve: int, log_domain: int, iters: int = 3):
+    """Plain Groth16 prove on a synthetic 2^log_domain circuit with a known-dlog key (closed-form check)."""
+    ms = (C.c_double * 4)()
+    ok = C.c_int(0)
+    rc = glib().cog16_bench_synthetic(curve, log_domain, iters, ms, C.byref(ok))
+    if rc != 0:
+        raise CoSnarksHipError(glib().cog16_last_error().decode())
+    return {"log_domain": log_domain, "witness_map_ms": ms[0], "create_proof_ms": ms[1], "prove_ms": ms[2],
+            "key_setup_ms": ms[3], "closed_form_check": bool(ok.value)}

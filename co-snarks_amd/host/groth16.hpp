@@ -103,7 +103,7 @@ struct CoGroth16 {
   static Proj<F> calculate_coeff(int id, Proj<F> initial, const Query<F>& query, const AffineT<F>& vk_param,
                                  const std::vector<Fr>& input_assignment, const std::vector<Half>& aux_assignment) {
     const size_t pub_len = input_assignment.size();
-    Proj<F> priv_acc = T::template msm_public_points_hs<F>(BasesView{query.dev, 1 + pub_len, query.host.size() - 1 - pub_len}, aux_assignment);
+    Proj<F> priv_acc = T::template msm_public_points_hs<F>(BasesView{query.dev, 1 + pub_len, query.size() - 1 - pub_len}, aux_assignment);
     Proj<F> pub_acc = Proj<F>::inf();  // msm_unchecked(&query[1..=pub_len], input_assignment): tiny, on the host (:194)
     for (size_t i = 0; i < pub_len; ++i) pub_acc = point_add(pub_acc, point_mul(into_group(query.host[1 + i]), input_assignment[i]));
     Proj<F> res = initial;
@@ -127,8 +127,8 @@ struct CoGroth16 {
     std::thread t1([&] { r_g1 = calculate_coeff<Fq>(id, T::template scalar_mul_public_point_hs<Fq>(delta_g1, T::to_half_share(r)), pkey.a_query, pkey.alpha_g1, inputs, aux_assignment); });
     std::thread t2([&] { s_g1 = calculate_coeff<Fq>(id, T::template scalar_mul_public_point_hs<Fq>(delta_g1, T::to_half_share(s)), pkey.b_g1_query, pkey.beta_g1, inputs, aux_assignment); });
     std::thread t3([&] { s_g2 = calculate_coeff<Fq2>(id, T::template scalar_mul_public_point_hs<Fq2>(delta_g2, T::to_half_share(s)), pkey.b_g2_query, pkey.beta_g2, inputs, aux_assignment); });
-    std::thread t4([&] { l_acc = T::template msm_public_points_hs<Fq>(BasesView{pkey.l_query.dev, 0, pkey.l_query.host.size()}, aux_assignment); });
-    std::thread t5([&] { h_acc = T::template msm_public_points_hs<Fq>(BasesView{pkey.h_query.dev, 0, pkey.h_query.host.size()}, h); });
+    std::thread t4([&] { l_acc = T::template msm_public_points_hs<Fq>(BasesView{pkey.l_query.dev, 0, pkey.l_query.size()}, aux_assignment); });
+    std::thread t5([&] { h_acc = T::template msm_public_points_hs<Fq>(BasesView{pkey.h_query.dev, 0, pkey.h_query.size()}, h); });
     t1.join(); t2.join(); t3.join(); t4.join(); t5.join();
 
     Half rs = T::local_mul_vec({r}, {s}, state0).back();                                     // :297

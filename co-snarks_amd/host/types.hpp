@@ -75,9 +75,12 @@ inline Proj<F> point_mul(const Proj<F>& p, const Fr& k_mont) {
 // Device-resident query (uploaded once per proving key) + the host copy for the tiny public-input MSM
 template <class F>
 struct Query {
-  std::vector<AffineT<F>> host;
+  std::vector<AffineT<F>> host;  // full copy, or (synthetic keys) only the first few entries the host reads
+  size_t len = 0;                // number of points in the query
   csh_bases_t dev = nullptr;
+  size_t size() const { return len ? len : host.size(); }
   void upload(csh_curve_t curve, csh_group_t group) {
+    len = host.size();
     check(csh_bases_upload(curve, group, host.data(), host.size(), 0, &dev), "csh_bases_upload");
   }
   void release() {

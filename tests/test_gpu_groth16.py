@@ -81,3 +81,11 @@ def test_prove_rejects_wrong_witness_length(gpu):
         g.prove_plain(0, zk, wt_big, R, S)
     with pytest.raises(gpu.CoSnarksHipError, match="does not match the selected curve"):
         g.prove_plain(1, zk, wt, R, S)
+
+
+@pytest.mark.parametrize("curve,logd", [("bn254", 12), ("bn254", 16), ("bls12_381", 12)])
+def test_synthetic_circuit_prove_closed_form(gpu, curve, logd):
+    """SURVEY 8d config 1 (synthetic large circuit, known-dlog key): A, B, C equal their closed-form discrete logs."""
+    from cosnarks_amd import groth16 as g
+    res = g.bench_synthetic(H.CURVE_IDS[curve], logd, iters=1)
+    assert res["closed_form_check"], res

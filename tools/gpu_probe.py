@@ -15,29 +15,34 @@ L = hip.lib()
 res = {"microbench_Gops": {}, "msm": []}
 names = {0: "v_mad_u64_u32", 1: "add_u64", 2: "addc_u32", 3: "v_mul_lo_u32", 4: "v_add_u32", 5: "v_mul_hi_u32",
          10: "modmul_bn254_fq_32x8_cios", 11: "modmul_bn254_fq_29x9_lazy", 12: "modmul_bls381_fq_32x12_cios"}
-for kind, nm in names.items():
+for kind, nm in ([] if os.environ.get("PROBE_SKIP_UB") else names.items()):
     v = C.c_double(0)
     iters = 2000 if kind < 10 else 200
     B._check(L.csh_microbench(kind, iters, C.byref(v)))
     res["microbench_Gops"][nm] = round(v.value / 1e9, 2)
 print(json.dumps(res["microbench_Gops"]), flush=True)
 
+CURVE = int(os.environ.get("PROBE_CURVE", "0"))
+GROUP = int(os.environ.get("PROBE_GROUP", "0"))
+PB = hip.point_bytes(CURVE, GROUP)
+if os.environ.get("PROBE_SKIP_UB"):
+    pass
 sizes = [int(x) for x in os.environ.get("PROBE_LOGN", "20,24").split(",")]
 cs = [int(x) for x in os.environ.get("PROBE_C", "0,13,14,15,16,17,18").split(",")]
 os.environ["CSH_MSM_TIMING"] = "1"
 for logn in sizes:
     n = 1 << logn
-    buf = hip.DeviceBuffer(n * 64)
-    B._check(L.csh_util_generate_bases_dev(0, 0, C.c_uint64(1), C.c_size_t(n), buf.ptr, None))
+    buf = hip.DeviceBuffer(n * PB)
+    B._check(L.csh_util_generate_bases_dev(CURVE, GROUP, C.c_uint64(1), C.c_size_t(n), buf.ptr, None))
     B.sync()
     h = C.c_void_p()
-    B._check(L.csh_bases_upload_dev(0, 0, buf.ptr, C.c_size_t(n), C.c_size_t(0), None, C.byref(h)))
+    B._check(L.csh_bases_upload_dev(CURVE, GROUP, buf.ptr, C.c_size_t(n), C.c_size_t(0), None, C.byref(h)))
     buf.free()
     rs = np.random.RandomState(1)
     limbs = rs.randint(0, 1 << 63, size=(n, 4), dtype=np.uint64)
     limbs[:, 3] >>= np.uint64(3)
     sc = hip.DeviceBuffer.from_host(limbs)
-    out = np.zeros(12, dtype=np.uint64)
+    out = np.zeros(3 * PB // 16, dtype=np.uint64)
     for c in cs:
         if c:
             os.environ["CSH_MSM_C"] = str(c)
@@ -49,7 +54,7 @@ for logn in sizes:
             t = B.msm_last_timing()
             if best is None or t[5] < best[5]:
                 best = t
-        row = {"logn": logn, "c": c, "ms": [round(x, 3) for x in best], "Mpts_s": round(n / best[5] / 1e3, 1)}
+        row = {"curve": CURVE, "group": GROUP, "logn": logn, "c": c, "ms": [round(x, 3) for x in best], "Mpts_s": round(n / best[5] / 1e3, 1)}
         res["msm"].append(row)
         print(json.dumps(row), flush=True)
     L.csh_bases_free(h)
