@@ -23,6 +23,10 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# k_msm_accum HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; see tools/pmc_summary.py).
+# The kernel gathers every 64-byte base once per window (W = 16): 1.07 GB of the 2.68 GB is inherent to Pippenger.
+PMC_TRAFFIC_BYTES = {20: 2682923502}
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -120,8 +124,12 @@ def main():
         t_acc = stage_ms[3] * 1e-3
         alg_bytes = n * 96.0                                 # 32 B scalar + 64 B affine base per point
         achieved = alg_bytes / t_acc / 1e9
+        # HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/ (FETCH_SIZE x2
+        # per the gfx950 correction + WRITE_SIZE, KiB -> bytes); measured for the default 2^20 workload only.
+        traffic = PMC_TRAFFIC_BYTES.get(args.log_n)
         roofline = {"bound": "hbm", "kernel": "k_msm_accum<Bn254G1>", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
-                    "frac": round(achieved / 8000.0, 5), "traffic": None,
+                    "frac": round(achieved / 8000.0, 5), "traffic": traffic,
+                    "traffic_source": "profiles/r01_c_msm_bn254g1_2p20_pmc_hbm_bytes.csv" if traffic else None,
                     "note": "MSM is integer-ALU (v_mad_u64_u32) bound, not HBM bound; see DESIGN.md",
                     "stage_ms": {"hist": stage_ms[0], "scan": stage_ms[1], "scatter": stage_ms[2], "accum": stage_ms[3],
                                  "reduce": stage_ms[4], "total_device": stage_ms[5]}}
