@@ -33,7 +33,9 @@ CSH_HD_NOINLINE XYZZLazy<L> lazy_mdbl(L x, L y) {
   return r;
 }
 
-// acc += (x2, y2); the caller has already excluded the point at infinity
+// acc += (x2, y2); the caller has already excluded the point at infinity. Contract: x2, y2 have limbs in
+// [-2, 2^B + 2] (unpack() output, or neg(..).normalized() for a negated point) -- acc.x / acc.y inherit that bound
+// and are subtracted limb-wise from fresh products below.
 template <class L>
 CSH_HD void lazy_madd(XYZZLazy<L>& acc, const L& x2, const L& y2) {
   if (acc.empty) {

@@ -164,6 +164,26 @@ using Fq29 = FpLazy<Bn254Fq29Params, Bn254Fq>;
 // (-p/32, p + p/32) whose limbs 0..NL-2 are in [0, 2^B) and whose top limb carries the sign.
 // Contract: |limb| of mul operands <= 2^B + 2 for both, or <= 2^(B+1) for one of them; operand values within
 // (-8p, 8p). `normalized()` (one parallel signed carry step) restores |limb| <= 2^B + 1 after 2-3 term sums.
+// Host-only contract checks (enabled by the self-test translation unit): every product routine verifies the
+// limb magnitudes its 63-bit column bound was derived for, so a caller that forgets a normalized() fails loudly
+// in `pytest -m "not gpu"` instead of producing a one-in-10^5 wrong bucket on the device.
+#if defined(CSH_CHECK_BOUNDS) && !defined(__HIP_DEVICE_COMPILE__)
+#include <stdio.h>
+#include <stdlib.h>
+#define CSH_LIMB_BOUND(x, bound, what)                                                        \
+  do {                                                                                        \
+    for (int i__ = 0; i__ < NL; ++i__) {                                                      \
+      const int64_t v__ = (x).l[i__];                                                         \
+      if (v__ > (int64_t)(bound) || v__ < -(int64_t)(bound)) {                                \
+        fprintf(stderr, "FpS bound violation in %s: limb %d = %lld exceeds %lld\n", what, i__, (long long)v__, (long long)(bound)); \
+        abort();                                                                              \
+      }                                                                                       \
+    }                                                                                         \
+  } while (0)
+#else
+#define CSH_LIMB_BOUND(x, bound, what) do { } while (0)
+#endif
+
 template <class LP, class F32>
 struct FpS {
   static constexpr int NL = LP::NL;
@@ -213,7 +233,11 @@ struct FpS {
   struct Wide {
     int64_t t[2 * NL];
   };
+  static constexpr int64_t LIM1 = (int64_t(1) << B) + 8;        // normalised operand
+  static constexpr int64_t LIM2 = (int64_t(1) << (B + 1)) + 16;  // one two-term sum
   CSH_HD static Wide mul_wide(const FpS& a, const FpS& b) {
+    CSH_LIMB_BOUND(a, LIM2, "mul_wide(a)");
+    CSH_LIMB_BOUND(b, LIM1, "mul_wide(b)");
     Wide w;
 #pragma unroll
     for (int k = 0; k < 2 * NL; ++k) w.t[k] = 0;
@@ -226,6 +250,7 @@ struct FpS {
   }
   // a^2 with NL(NL+1)/2 products: squares + doubled cross terms (|2 a_j| <= 2^(B+1))
   CSH_HD static Wide sqr_wide(const FpS& a) {
+    CSH_LIMB_BOUND(a, LIM1, "sqr_wide");
     Wide w;
 #pragma unroll
     for (int k = 0; k < 2 * NL; ++k) w.t[k] = 0;
@@ -240,6 +265,9 @@ struct FpS {
   }
   // w = a*b - c*d accumulated column-wise before ONE reduction (2 * NL^2 products, saves a reduction)
   CSH_HD static Wide mul_sub_wide(const FpS& a, const FpS& b, const FpS& c, const FpS& d) {
+    CSH_LIMB_BOUND(a, LIM1, "mul_sub_wide(a)");
+    CSH_LIMB_BOUND(c, LIM1, "mul_sub_wide(c)");
+    CSH_LIMB_BOUND(d, LIM1, "mul_sub_wide(d)");
     Wide w = mul_wide(a, b);
     FpS nc = neg(c);
 #pragma unroll
@@ -249,6 +277,47 @@ struct FpS {
     }
     return w;
   }
+  // w = a*b + c*d
+  CSH_HD static Wide mul_add_wide(const FpS& a, const FpS& b, const FpS& c, const FpS& d) {
+    CSH_LIMB_BOUND(a, LIM1, "mul_add_wide(a)");
+    CSH_LIMB_BOUND(c, LIM1, "mul_add_wide(c)");
+    CSH_LIMB_BOUND(d, LIM1, "mul_add_wide(d)");
+    Wide w = mul_wide(a, b);
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+#pragma unroll
+      for (int j = 0; j < NL; ++j) w.t[i + j] = (int64_t)c.l[i] * (int64_t)d.l[j] + w.t[i + j];
+    }
+    return w;
+  }
+  // w = a^2 - b^2
+  CSH_HD static Wide sqr_sub_wide(const FpS& a, const FpS& b) {
+    CSH_LIMB_BOUND(b, LIM1, "sqr_sub_wide(b)");
+    Wide w = sqr_wide(a);
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int32_t nb = -b.l[i];
+      w.t[2 * i] = (int64_t)nb * (int64_t)b.l[i] + w.t[2 * i];
+      const int32_t nb2 = nb + nb;
+#pragma unroll
+      for (int j = i + 1; j < NL; ++j) w.t[i + j] = (int64_t)nb2 * (int64_t)b.l[j] + w.t[i + j];
+    }
+    return w;
+  }
+  // accumulate a*b (sign = +1) or -a*b (sign = -1) into w
+  CSH_HD static void mac_wide(Wide& w, const FpS& a, const FpS& b, bool negate) {
+    CSH_LIMB_BOUND(a, LIM1, "mac_wide(a)");
+    CSH_LIMB_BOUND(b, LIM1, "mac_wide(b)");
+    FpS aa = negate ? neg(a) : a;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+#pragma unroll
+      for (int j = 0; j < NL; ++j) w.t[i + j] = (int64_t)aa.l[i] * (int64_t)b.l[j] + w.t[i + j];
+    }
+  }
+  // can four NL-term product sums (+ the reduction's NL terms) share one 63-bit column?
+  static constexpr bool FOUR_PRODUCTS_FIT = (5.0 * NL) * (double)(1ull << (2 * B - 40)) < (double)(1ull << 23);
+
   // Montgomery reduction of a double-width value: (w + m p) / R', result in (-p/16, p + p/16) for |w| < 2^6 p R'/64
   CSH_HD static FpS reduce(Wide w) {
 #pragma unroll
@@ -368,5 +437,47 @@ struct FpS {
 
 using Fq29s = FpS<Bn254Fq29Params, Bn254Fq>;
 using Fq28s = FpS<Bls381Fq28Params, Bls381Fq>;
+
+// ---- Fp2 = Fp[i]/(i^2+1) over the signed lazy field: schoolbook products accumulated double-width with ONE
+// reduction per output component (2 NL^2 + NL^2 mads per component, cheaper than Karatsuba's three full
+// multiplications and free of the 2^(B+1)-limb operand sums Karatsuba needs) -------------------------------------
+template <class LF, class F32x2>
+struct Fp2S {
+  LF c0, c1;
+  CSH_HD static Fp2S zero() { return {LF::zero(), LF::zero()}; }
+  CSH_HD static Fp2S one() { return {LF::one(), LF::zero()}; }
+  CSH_HD static Fp2S add(const Fp2S& a, const Fp2S& b) { return {LF::add(a.c0, b.c0), LF::add(a.c1, b.c1)}; }
+  CSH_HD static Fp2S sub(const Fp2S& a, const Fp2S& b) { return {LF::sub(a.c0, b.c0), LF::sub(a.c1, b.c1)}; }
+  CSH_HD static Fp2S neg(const Fp2S& a) { return {LF::neg(a.c0), LF::neg(a.c1)}; }
+  CSH_HD Fp2S normalized() const { return {c0.normalized(), c1.normalized()}; }
+  CSH_HD static Fp2S mul(const Fp2S& a, const Fp2S& b) {
+    return {LF::reduce(LF::mul_sub_wide(a.c0, b.c0, a.c1, b.c1)), LF::reduce(LF::mul_add_wide(a.c0, b.c1, a.c1, b.c0))};
+  }
+  CSH_HD static Fp2S sqr(const Fp2S& a) {
+    return {LF::reduce(LF::sqr_sub_wide(a.c0, a.c1)), LF::mul(LF::add(a.c0, a.c0), a.c1)};
+  }
+  // a*b - c*d
+  CSH_HD static Fp2S mul_sub(const Fp2S& a, const Fp2S& b, const Fp2S& c, const Fp2S& d) {
+    if constexpr (LF::FOUR_PRODUCTS_FIT) {
+      typename LF::Wide w0 = LF::mul_sub_wide(a.c0, b.c0, a.c1, b.c1);
+      LF::mac_wide(w0, c.c0, d.c0, true);
+      LF::mac_wide(w0, c.c1, d.c1, false);
+      typename LF::Wide w1 = LF::mul_add_wide(a.c0, b.c1, a.c1, b.c0);
+      LF::mac_wide(w1, c.c0, d.c1, true);
+      LF::mac_wide(w1, c.c1, d.c0, true);
+      return {LF::reduce(w0), LF::reduce(w1)};
+    } else {
+      return sub(mul(a, b), mul(c, d)).normalized();
+    }
+  }
+  CSH_HD bool maybe_zero() const { return c0.maybe_zero() && c1.maybe_zero(); }
+  CSH_HD bool is_zero_slow() const { return c0.is_zero_slow() && c1.is_zero_slow(); }
+  CSH_HD bool is_zero() const { return maybe_zero() && is_zero_slow(); }
+  CSH_HD static Fp2S unpack(const F32x2& f) { return {LF::unpack(f.c0), LF::unpack(f.c1)}; }
+  CSH_HD F32x2 to_fp() const { return {c0.to_fp(), c1.to_fp()}; }
+  CSH_HD static F32x2 repack_for_storage(const F32x2& f) { return {LF::repack_for_storage(f.c0), LF::repack_for_storage(f.c1)}; }
+};
+using Fq29s2 = Fp2S<Fq29s, Bn254Fq2>;
+using Fq28s2 = Fp2S<Fq28s, Bls381Fq2>;
 
 }  // namespace csh

@@ -28,9 +28,9 @@ namespace csh {
 // LAZY: bucket accumulation runs in the signed lazy field (field29.hpp); Bases then stores the coordinates
 // re-encoded as canonical x*R' (same 32 bytes per coordinate), converted once at upload.
 struct Bn254G1Cfg { using Fq = Bn254Fq;   using Fr = Bn254Fr; static constexpr bool LAZY = true;  using L = Fq29s; static constexpr bool INLINE_ADD = true; };
-struct Bn254G2Cfg { using Fq = Bn254Fq2;  using Fr = Bn254Fr; static constexpr bool LAZY = false; using L = void; static constexpr bool INLINE_ADD = false; };
-struct Bls381G1Cfg { using Fq = Bls381Fq;  using Fr = Bls381Fr; static constexpr bool LAZY = false; using L = void; static constexpr bool INLINE_ADD = false; };
-struct Bls381G2Cfg { using Fq = Bls381Fq2; using Fr = Bls381Fr; static constexpr bool LAZY = false; using L = void; static constexpr bool INLINE_ADD = false; };
+struct Bn254G2Cfg { using Fq = Bn254Fq2;  using Fr = Bn254Fr; static constexpr bool LAZY = true;  using L = Fq29s2; static constexpr bool INLINE_ADD = false; };
+struct Bls381G1Cfg { using Fq = Bls381Fq;  using Fr = Bls381Fr; static constexpr bool LAZY = true;  using L = Fq28s; static constexpr bool INLINE_ADD = false; };
+struct Bls381G2Cfg { using Fq = Bls381Fq2; using Fr = Bls381Fr; static constexpr bool LAZY = true;  using L = Fq28s2; static constexpr bool INLINE_ADD = false; };
 
 struct Bases {
   csh_curve_t curve;
@@ -236,16 +236,35 @@ __device__ __forceinline__ uint32_t upper_bound_u32(const uint32_t* __restrict__
   return lo;
 }
 
+// One task's bucket accumulation as an out-of-line function (variant 5: isolates its register allocation)
+template <class Cfg>
+__device__ __attribute__((noinline)) XYZZ<typename Cfg::Fq> lazy_task(const Affine<typename Cfg::Fq>* __restrict__ bases,
+                                                                      const uint32_t* __restrict__ so, uint32_t lo, uint32_t hi) {
+  using Fq = typename Cfg::Fq;
+  using L = typename Cfg::L;
+  XYZZLazy<L> acc = XYZZLazy<L>::inf();
+  for (uint32_t k = lo; k < hi; ++k) {
+    const uint32_t e = so[k];
+    const Affine<Fq> pt = bases[e & 0x7fffffffu];
+    if (pt.is_inf()) continue;
+    const L x = L::unpack(pt.x);
+    L y = L::unpack(pt.y);
+    if (e >> 31) y = L::neg(y).normalized();  // keep |limb| <= 2^B + 1: lazy_madd subtracts acc.y limb-wise
+    lazy_madd(acc, x, y);
+  }
+  return lazy_to_xyzz<L, Fq>(acc);
+}
+
 // VAR selects an occupancy / prefetch variant (tuning knob CSH_ACC_VARIANT): 0 = prefetch, default registers;
 // 1 = prefetch, >= 3 waves/SIMD; 2 = no prefetch, >= 3 waves/SIMD; 3 = no prefetch, >= 4 waves/SIMD
 template <class Cfg, int VAR>
-__global__ __launch_bounds__(ACC_BLK, (VAR == 0 ? 1 : (VAR == 3 ? 4 : 3))) void k_msm_accum(const Affine<typename Cfg::Fq>* __restrict__ bases, MsmParams p,
+__global__ __launch_bounds__(ACC_BLK, (VAR == 0 || VAR >= 4 ? 1 : (VAR == 3 ? 4 : 3))) void k_msm_accum(const Affine<typename Cfg::Fq>* __restrict__ bases, MsmParams p,
                                                        const uint32_t* __restrict__ start, const uint32_t* __restrict__ tstart,
                                                        const uint32_t* __restrict__ ntasks, const uint32_t* __restrict__ sorted,
                                                        XYZZ<typename Cfg::Fq>* partial, uint32_t* task_bucket) {
   using Fq = typename Cfg::Fq;
   const int w = blockIdx.y;
-  const uint32_t t = blockIdx.x * ACC_BLK + threadIdx.x;
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= ntasks[w]) return;
   const uint32_t len = p.NB + 2;
   const uint32_t* ts = tstart + (size_t)w * len;
@@ -257,7 +276,9 @@ __global__ __launch_bounds__(ACC_BLK, (VAR == 0 ? 1 : (VAR == 3 ? 4 : 3))) void 
   const uint32_t end = st[b + 1];
   if (hi > end) hi = end;
   const uint32_t* so = sorted + (size_t)w * p.n;
-  if constexpr (Cfg::LAZY) {
+  if constexpr (Cfg::LAZY && VAR == 5) {
+    partial[(size_t)w * p.tmax + t] = lazy_task<Cfg>(bases, so, lo, hi);
+  } else if constexpr (Cfg::LAZY) {
     using L = typename Cfg::L;
     XYZZLazy<L> acc = XYZZLazy<L>::inf();
     uint32_t e_next = so[lo];                       // lo < hi: every task owns >= 1 entry
@@ -276,7 +297,7 @@ __global__ __launch_bounds__(ACC_BLK, (VAR == 0 ? 1 : (VAR == 3 ? 4 : 3))) void 
       if (pt.is_inf()) continue;
       const L x = L::unpack(pt.x);
       L y = L::unpack(pt.y);
-      if (e >> 31) y = L::neg(y);
+      if (e >> 31) y = L::neg(y).normalized();  // keep |limb| <= 2^B + 1: lazy_madd subtracts acc.y limb-wise
       lazy_madd(acc, x, y);
     }
     partial[(size_t)w * p.tmax + t] = lazy_to_xyzz<L, Fq>(acc);
@@ -493,9 +514,19 @@ static int msm_windows_dev(const Bases* B, size_t offset, size_t n, const uint64
       const char* e = getenv("CSH_ACC_VARIANT");
       return e ? atoi(e) : 0;
     }();
-    const dim3 ag((p.tmax + ACC_BLK - 1) / ACC_BLK, p.W), ab(ACC_BLK);
-    const int v = Cfg::LAZY ? variant : 0;
-    if (v == 1) hipLaunchKernelGGL((k_msm_accum<Cfg, 1>), ag, ab, 0, st, bases, p, start, tstart, ntasks, sorted, partial, task_bucket);
+    static const int blk = [] {
+      const char* e = getenv("CSH_ACC_BLK");
+      const int b = e ? atoi(e) : ACC_BLK;
+      return (b == 64 || b == 128) ? b : ACC_BLK;
+    }();
+    const dim3 ag((p.tmax + blk - 1) / blk, p.W), ab(blk);
+    int v = 0;
+    if constexpr (Cfg::INLINE_ADD) v = variant;  // tuning variants exist for the 8-limb G1 configuration only
+    if constexpr (!Cfg::INLINE_ADD) {
+      if (variant == 4) hipLaunchKernelGGL((k_msm_accum<Cfg, 4>), ag, ab, 0, st, bases, p, start, tstart, ntasks, sorted, partial, task_bucket);
+      else if (variant == 5) hipLaunchKernelGGL((k_msm_accum<Cfg, 5>), ag, ab, 0, st, bases, p, start, tstart, ntasks, sorted, partial, task_bucket);
+      else hipLaunchKernelGGL((k_msm_accum<Cfg, 0>), ag, ab, 0, st, bases, p, start, tstart, ntasks, sorted, partial, task_bucket);
+    } else if (v == 1) hipLaunchKernelGGL((k_msm_accum<Cfg, 1>), ag, ab, 0, st, bases, p, start, tstart, ntasks, sorted, partial, task_bucket);
     else if (v == 2) hipLaunchKernelGGL((k_msm_accum<Cfg, 2>), ag, ab, 0, st, bases, p, start, tstart, ntasks, sorted, partial, task_bucket);
     else if (v == 3) hipLaunchKernelGGL((k_msm_accum<Cfg, 3>), ag, ab, 0, st, bases, p, start, tstart, ntasks, sorted, partial, task_bucket);
     else hipLaunchKernelGGL((k_msm_accum<Cfg, 0>), ag, ab, 0, st, bases, p, start, tstart, ntasks, sorted, partial, task_bucket);

@@ -1,7 +1,10 @@
 // Host-executed self-test hooks: the SAME templates the gfx950 kernels instantiate (field.hpp, curve.hpp,
 // field29.hpp, msm_digits.hpp) run on the CPU so that `pytest -m "not gpu"` can check them against the
 // oracle without a device. Test infrastructure; not declared in include/cosnarks_hip.h.
+#define CSH_CHECK_BOUNDS 1  // host-side limb-bound contract checks in field29.hpp
 #include <string.h>
+
+#include <vector>
 
 #include "common.hpp"
 #include "curve.hpp"
@@ -76,9 +79,90 @@ int curve_op(int op, const void* in1, const void* in2, uint32_t k, void* out) {
   }
 }
 
+// Lazy bucket accumulation on the host for any group: acc (empty) += sequence of `npts` affine points (negated
+// where neg[i] != 0); out = XYZZ in arkworks words. Exercises exactly what k_msm_accum's lazy path does: storage
+// repack, unpack, lazy_madd, export.
+template <class L, class Fq>
+int lazy_accumulate_t(const void* affine_pts, const uint8_t* neg, size_t npts, void* out_xyzz) {
+  XYZZLazy<L> acc = XYZZLazy<L>::inf();
+  const Affine<Fq>* pts = reinterpret_cast<const Affine<Fq>*>(affine_pts);
+  for (size_t i = 0; i < npts; ++i) {
+    Affine<Fq> p;
+    memcpy(&p, pts + i, sizeof p);
+    if (p.is_inf()) continue;
+    Fq sx = L::repack_for_storage(p.x), sy = L::repack_for_storage(p.y);  // what Bases stores
+    L x = L::unpack(sx), y = L::unpack(sy);
+    if (neg && neg[i]) y = L::neg(y).normalized();
+    lazy_madd(acc, x, y);
+  }
+  XYZZ<Fq> r = lazy_to_xyzz<L, Fq>(acc);
+  memcpy(out_xyzz, &r, sizeof r);
+  return CSH_OK;
+}
+
+// Device-vs-host determinism check of the lazy bucket arithmetic: thread t accumulates the cyclic chain
+// pts[(t + i) % n], i < len (sign from bit i of a hash) on the GPU; the host recomputes a sample of threads with the
+// very same template code and compares the exported XYZZ words bit for bit.
+template <class L, class Fq>
+__host__ __device__ inline XYZZ<Fq> lazy_chain(const Affine<Fq>* pts, size_t n, size_t t, size_t len) {
+  XYZZLazy<L> acc = XYZZLazy<L>::inf();
+  len = 1 + (size_t)((t * 0x9E3779B1u) >> 8) % len;  // ragged chain lengths: lanes of a wave diverge, as in k_msm_accum
+  for (size_t i = 0; i < len; ++i) {
+    Affine<Fq> p = pts[(t + i) % n];
+    if (p.is_inf()) continue;
+    L x = L::unpack(p.x), y = L::unpack(p.y);
+    if (((t * 2654435761u + i * 40503u) >> 7) & 1) y = L::neg(y).normalized();
+    lazy_madd(acc, x, y);
+  }
+  return lazy_to_xyzz<L, Fq>(acc);
+}
+template <class L, class Fq>
+__global__ void k_lazy_chain(const Affine<Fq>* pts, size_t n, size_t len, size_t nthreads, XYZZ<Fq>* out) {
+  const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (t < nthreads) out[t] = lazy_chain<L, Fq>(pts, n, t, len);
+}
+template <class L, class Fq>
+int lazy_chain_check_t(const void* affine_pts, size_t n, size_t len, size_t nthreads, size_t host_samples, int* mismatches) {
+  std::vector<Affine<Fq>> st(n);
+  const Affine<Fq>* in = reinterpret_cast<const Affine<Fq>*>(affine_pts);
+  for (size_t i = 0; i < n; ++i) {
+    st[i] = in[i];
+    if (!st[i].is_inf()) st[i] = {L::repack_for_storage(in[i].x), L::repack_for_storage(in[i].y)};
+  }
+  Affine<Fq>* dpts;
+  XYZZ<Fq>* dout;
+  CSH_HIP(hipMalloc((void**)&dpts, n * sizeof(Affine<Fq>)));
+  CSH_HIP(hipMalloc((void**)&dout, nthreads * sizeof(XYZZ<Fq>)));
+  CSH_HIP(hipMemcpy(dpts, st.data(), n * sizeof(Affine<Fq>), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL((k_lazy_chain<L, Fq>), dim3((unsigned)((nthreads + 127) / 128)), dim3(128), 0, 0, dpts, n, len, nthreads, dout);
+  std::vector<XYZZ<Fq>> got(nthreads);
+  CSH_HIP(hipMemcpy(got.data(), dout, nthreads * sizeof(XYZZ<Fq>), hipMemcpyDeviceToHost));
+  (void)hipFree(dpts);
+  (void)hipFree(dout);
+  int bad = 0;
+  const size_t step = nthreads / host_samples ? nthreads / host_samples : 1;
+  for (size_t t = 0; t < nthreads; t += step) {
+    XYZZ<Fq> want = lazy_chain<L, Fq>(st.data(), n, t, len);
+    if (memcmp(&want, &got[t], sizeof want) != 0) ++bad;
+  }
+  *mismatches = bad;
+  return CSH_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
+int csh_selftest_lazy_chain_dev(int curve, int group, const void* affine_pts, size_t n, size_t len, size_t nthreads, size_t host_samples,
+                                int* mismatches) {
+  CSH_TRY(ensure_device());
+  if (curve == CSH_BN254 && group == CSH_G1) return lazy_chain_check_t<Fq29s, Bn254Fq>(affine_pts, n, len, nthreads, host_samples, mismatches);
+  if (curve == CSH_BN254 && group == CSH_G2) return lazy_chain_check_t<Fq29s2, Bn254Fq2>(affine_pts, n, len, nthreads, host_samples, mismatches);
+  if (curve == CSH_BLS12_381 && group == CSH_G1) return lazy_chain_check_t<Fq28s, Bls381Fq>(affine_pts, n, len, nthreads, host_samples, mismatches);
+  if (curve == CSH_BLS12_381 && group == CSH_G2) return lazy_chain_check_t<Fq28s2, Bls381Fq2>(affine_pts, n, len, nthreads, host_samples, mismatches);
+  return CSH_ERR_INVALID;
+}
+
 
 // field: 0 BN254 Fq, 1 BN254 Fr, 2 BLS12-381 Fq, 3 BLS12-381 Fr
 int csh_selftest_field_op(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out) {
@@ -105,24 +189,12 @@ int csh_selftest_curve_op(int curve, int group, int op, const void* in1, const v
   return CSH_ERR_INVALID;
 }
 
-// Lazy (signed 29-bit) bucket accumulation on the host: acc (XYZZ, arkworks Montgomery words, all-zero = empty)
-// += sequence of `npts` affine BN254 G1 points (negated where neg[i] != 0); out = XYZZ in arkworks words.
-// Exercises exactly what k_msm_accum's lazy path does: storage repack, unpack, lazy_madd, export.
-int csh_selftest_lazy_accumulate(const uint64_t* affine_pts, const uint8_t* neg, size_t npts, uint64_t* out_xyzz) {
-  using L = Fq29s;
-  XYZZLazy<L> acc = XYZZLazy<L>::inf();
-  for (size_t i = 0; i < npts; ++i) {
-    Affine<Bn254Fq> p;
-    memcpy(&p, affine_pts + 8 * i, sizeof p);
-    if (p.is_inf()) continue;
-    Bn254Fq sx = L::repack_for_storage(p.x), sy = L::repack_for_storage(p.y);  // what Bases stores
-    L x = L::unpack(sx), y = L::unpack(sy);
-    if (neg && neg[i]) y = L::neg(y);
-    lazy_madd(acc, x, y);
-  }
-  XYZZ<Bn254Fq> r = lazy_to_xyzz<L, Bn254Fq>(acc);
-  memcpy(out_xyzz, &r, sizeof r);
-  return CSH_OK;
+int csh_selftest_lazy_accumulate(int curve, int group, const void* affine_pts, const uint8_t* neg, size_t npts, void* out_xyzz) {
+  if (curve == CSH_BN254 && group == CSH_G1) return lazy_accumulate_t<Fq29s, Bn254Fq>(affine_pts, neg, npts, out_xyzz);
+  if (curve == CSH_BN254 && group == CSH_G2) return lazy_accumulate_t<Fq29s2, Bn254Fq2>(affine_pts, neg, npts, out_xyzz);
+  if (curve == CSH_BLS12_381 && group == CSH_G1) return lazy_accumulate_t<Fq28s, Bls381Fq>(affine_pts, neg, npts, out_xyzz);
+  if (curve == CSH_BLS12_381 && group == CSH_G2) return lazy_accumulate_t<Fq28s2, Bls381Fq2>(affine_pts, neg, npts, out_xyzz);
+  return CSH_ERR_INVALID;
 }
 
 // out = to_fp(mul(from_fp(a) (+/-) from_fp(b), from_fp(c))) for the signed lazy field: op 0: (a+b)*c, 1: (a-b)*c

@@ -180,10 +180,12 @@ def test_signed_lazy_field_ops(hip):
         assert L.csh_selftest_lazys_op(0, pa, pn, pa, out.ctypes.data_as(C.c_void_p)) == 1
 
 
-def test_lazy_bucket_accumulation_matches_group_law(hip):
+@pytest.mark.parametrize("curve,group", [("bn254", 0), ("bn254", 1), ("bls12_381", 0), ("bls12_381", 1)])
+def test_lazy_bucket_accumulation_matches_group_law(hip, curve, group):
     """lazy_madd chain (incl. duplicates -> doubling, P + (-P) -> empty, infinity bases, long chains)."""
-    G = cv.BN254_G1
-    r = H.rng(33)
+    G = cv.CURVES[curve][group]
+    cid = H.CURVE_IDS[curve]
+    r = H.rng(33 + group)
     pts = H.rand_points(G, 40, r)
     seqs = [
         ([pts[0]], [0]),
@@ -202,8 +204,8 @@ def test_lazy_bucket_accumulation_matches_group_law(hip):
             want = G.add(want, G.neg(P) if ng else P)
         ap = cv.pack_points(G, seq).reshape(-1)
         ngb = np.array(neg, dtype=np.uint8)
-        out = np.zeros(16, dtype=np.uint64)
-        assert hip.lib().csh_selftest_lazy_accumulate(ap.ctypes.data_as(C.c_void_p), ngb.ctypes.data_as(C.c_void_p), C.c_size_t(len(seq)),
-                                                      out.ctypes.data_as(C.c_void_p)) == 0
-        got = _xyzz_to_affine(hip, 0, 0, G, out)
+        out = np.zeros(2 * hip.point_bytes(cid, group) // 8, dtype=np.uint64)
+        assert hip.lib().csh_selftest_lazy_accumulate(cid, group, ap.ctypes.data_as(C.c_void_p), ngb.ctypes.data_as(C.c_void_p),
+                                                      C.c_size_t(len(seq)), out.ctypes.data_as(C.c_void_p)) == 0
+        got = _xyzz_to_affine(hip, cid, group, G, out)
         assert G.eq(got, want)
