@@ -10,14 +10,45 @@ namespace csh {
 static thread_local std::string tl_error;
 static thread_local int tl_device = -1;
 
-struct ThreadStreams {
-  std::map<int, hipStream_t> by_device;
+// A "lane" = one HIP stream plus the scratch arenas used on it. Lanes are pooled per device and leased to host
+// threads: short-lived callers (the reference spawns rayon tasks / scoped threads per proof) reuse warm streams and
+// already-grown arenas instead of paying hipStreamCreate + hipMalloc on every call.
+struct Lane {
+  int device = 0;
+  hipStream_t stream = nullptr;
   std::map<hipStream_t, Arena> arenas;
-  ~ThreadStreams() {
-    // Process/thread teardown: the HIP runtime may already be gone; leak deliberately.
+};
+static std::mutex g_lane_mu;
+static std::map<int, std::vector<Lane*>> g_free_lanes;
+
+struct LaneHolder {
+  std::map<int, Lane*> by_device;
+  Lane* get(int device) {
+    auto it = by_device.find(device);
+    if (it != by_device.end()) return it->second;
+    Lane* l = nullptr;
+    {
+      std::lock_guard<std::mutex> g(g_lane_mu);
+      auto& fl = g_free_lanes[device];
+      if (!fl.empty()) {
+        l = fl.back();
+        fl.pop_back();
+      }
+    }
+    if (!l) {
+      l = new Lane();
+      l->device = device;
+      if (hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking) != hipSuccess) l->stream = nullptr;  // fall back to the null stream
+    }
+    by_device[device] = l;
+    return l;
+  }
+  ~LaneHolder() {  // thread exit: hand the lanes back (work on them has been synchronised by the API contract)
+    std::lock_guard<std::mutex> g(g_lane_mu);
+    for (auto& kv : by_device) g_free_lanes[kv.first].push_back(kv.second);
   }
 };
-static thread_local ThreadStreams tl_streams;
+static thread_local LaneHolder tl_lanes;
 
 void set_error(const char* fmt, ...) {
   char buf[1024];
@@ -35,12 +66,7 @@ int ensure_device() {
 
 hipStream_t resolve_stream(void* s) {
   if (s) return reinterpret_cast<hipStream_t>(s);
-  auto it = tl_streams.by_device.find(tl_device);
-  if (it != tl_streams.by_device.end()) return it->second;
-  hipStream_t st = nullptr;
-  if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) st = nullptr;  // fall back to the null stream
-  tl_streams.by_device[tl_device] = st;
-  return st;
+  return tl_lanes.get(tl_device)->stream;
 }
 
 int Arena::reserve(size_t bytes) {
@@ -59,7 +85,7 @@ int Arena::reserve(size_t bytes) {
   return CSH_OK;
 }
 
-Arena& arena_for(hipStream_t s) { return tl_streams.arenas[s]; }
+Arena& arena_for(hipStream_t s) { return tl_lanes.get(tl_device)->arenas[s]; }
 
 }  // namespace csh
 
@@ -85,11 +111,15 @@ int csh_init(int device) {
 }
 
 int csh_shutdown(void) {
-  for (auto& kv : tl_streams.arenas) {
-    if (kv.second.base) (void)hipFree(kv.second.base);
-    kv.second = Arena();
-  }
-  tl_streams.arenas.clear();
+  auto drop = [](Lane* l) {
+    for (auto& kv : l->arenas)
+      if (kv.second.base) (void)hipFree(kv.second.base);
+    l->arenas.clear();
+  };
+  for (auto& kv : tl_lanes.by_device) drop(kv.second);
+  std::lock_guard<std::mutex> g(g_lane_mu);
+  for (auto& kv : g_free_lanes)
+    for (Lane* l : kv.second) drop(l);
   return CSH_OK;
 }
 

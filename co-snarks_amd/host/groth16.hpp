@@ -2,6 +2,8 @@
 // create_proof_with_assignment}, groth16_roots_of_unity) and groth16/reduction.rs (R1CSToQAP,
 // CircomReduction) above the C ABI. Same control flow, line-cited; the hot calls go to the device.
 #pragma once
+#include <map>
+#include <mutex>
 #include <thread>
 
 #include "mpc.hpp"
@@ -38,6 +40,30 @@ inline void groth16_roots_of_unity(size_t pow, Fr& group_gen, Fr& coset_shift) {
   coset_shift = ((size_t)S == pow) ? Fr::sqr(q) : rev[pow + 1];
 }
 
+// Domains (device twiddle tables) are reused across proofs: building one costs a hipMalloc + a kernel, a proof of the
+// same circuit needs the same (curve, size, generator) every time.
+struct DomainCache {
+  std::mutex mu;
+  std::map<std::pair<int, uint32_t>, csh_domain_t> doms;
+  static DomainCache& get() {
+    static DomainCache c;
+    return c;
+  }
+  csh_domain_t lookup(csh_curve_t curve, uint32_t log_n, const uint64_t* gen, int* rc_out) {
+    std::lock_guard<std::mutex> g(mu);
+    auto key = std::make_pair((int)curve, log_n);
+    auto it = doms.find(key);
+    if (it != doms.end()) {
+      *rc_out = CSH_OK;
+      return it->second;
+    }
+    csh_domain_t d = nullptr;
+    *rc_out = csh_domain_create(curve, log_n, gen, &d);
+    if (*rc_out == CSH_OK) doms[key] = d;
+    return d;
+  }
+};
+
 // ---- R1CSToQAP: CircomReduction::witness_map_from_matrices (reduction.rs:77-193) ------------------------------
 struct CircomReduction {
   template <class P, class T>
@@ -54,34 +80,45 @@ struct CircomReduction {
       ++power;
     }
     if (power > (size_t)Fr::Params::TWO_ADICITY) throw Error("Polynomial Degree too large");  // :87-89
+    Span span_all("witness map from matrices");
     Fr group_gen, coset_shift;
-    groth16_roots_of_unity<Fr>(power, group_gen, coset_shift);                                 // :92
+    {
+      Span sp("root of unity");
+      groth16_roots_of_unity<Fr>(power, group_gen, coset_shift);                               // :92
+    }
     csh_domain_t domain = nullptr;
-    int rc = csh_domain_create(P::ID, (uint32_t)power, (const uint64_t*)&group_gen, &domain);   // :93 Domain::with_group_gen
+    Span* sp_dom = new Span("domain create (twiddles)");
+    int rc = CSH_OK;
+    domain = DomainCache::get().lookup(P::ID, (uint32_t)power, (const uint64_t*)&group_gen, &rc);  // :93 Domain::with_group_gen (snarkjs root)
     if (rc == CSH_ERR_DOMAIN) throw Error("Polynomial Degree too large");
+    delete sp_dom;
     check(rc, "csh_domain_create");
     const int id = state.id;
+    Span* sp_eval = new Span("evaluate constraints");
 
     // :99-130 evaluate constraints (sparse rows on the host; "next" row f3 moves this to the device)
-    auto evaluate = [&](const std::vector<std::vector<std::pair<Fr, size_t>>>& m) {
+    auto evaluate = [&](const std::vector<std::vector<std::pair<Fr, size_t>>>& m) {  // par_iter().with_min_len(256), :196-210
       std::vector<Share> res(domain_size, Share{});
-      for (size_t i = 0; i < m.size(); ++i) res[i] = T::evaluate_constraint(id, m[i], public_inputs, private_witness);
+      parallel_for(m.size(), 256, [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) res[i] = T::evaluate_constraint(id, m[i], public_inputs, private_witness);
+      });
       return res;
     };
     std::vector<Share> a = evaluate(matrices.a);
     std::vector<Share> promoted = T::promote_to_trivial_shares(id, public_inputs);
     for (size_t i = 0; i < num_inputs; ++i) a[num_constraints + i] = promoted[i];              // :111-113
     std::vector<Share> b = evaluate(matrices.b);
+    delete sp_eval;
 
     // :135-192 on the device in one call: 6 NTTs, 2 local_mul_vec, 3 coset-table multiplications, 1 subtraction.
     // The two mask vectors are drawn in the reference's order: "c: local_mul_vec" (:160) then "ab" (:182).
     std::vector<Fr> mask_c = T::masks(state, domain_size);
     std::vector<Fr> mask_ab = T::masks(state, domain_size);
     std::vector<Fr> h(domain_size);
+    Span sp_h("a/b/c: ifft, distribute powers, fft, local_mul_vec, sub (device)");
     rc = csh_groth16_h(domain, (const uint64_t*)&coset_shift, T::PROTOCOL, (uint64_t*)a.data(), (uint64_t*)b.data(),
                        mask_c.empty() ? nullptr : (const uint64_t*)mask_c.data(), mask_ab.empty() ? nullptr : (const uint64_t*)mask_ab.data(),
                        (uint64_t*)h.data());
-    csh_domain_free(domain);
     check(rc, "csh_groth16_h");
     return h;
   }
@@ -101,7 +138,7 @@ struct CoGroth16 {
   // groth16.rs:179-203
   template <class F>
   static Proj<F> calculate_coeff(int id, Proj<F> initial, const Query<F>& query, const AffineT<F>& vk_param,
-                                 const std::vector<Fr>& input_assignment, const std::vector<Half>& aux_assignment) {
+                                 const std::vector<Fr>& input_assignment, const DeviceScalars& aux_assignment) {
     const size_t pub_len = input_assignment.size();
     Proj<F> priv_acc = T::template msm_public_points_hs<F>(BasesView{query.dev, 1 + pub_len, query.size() - 1 - pub_len}, aux_assignment);
     Proj<F> pub_acc = Proj<F>::inf();  // msm_unchecked(&query[1..=pub_len], input_assignment): tiny, on the host (:194)
@@ -121,15 +158,23 @@ struct CoGroth16 {
     const Proj<Fq2> delta_g2 = into_group(pkey.delta_g2);
     const int id = state0.id;
     std::vector<Fr> inputs(input_assignment.begin() + 1, input_assignment.end());  // &input_assignment[1..]
+    // aux_assignment feeds four MSMs (A, B1, B2, L): upload it once; h feeds one
+    Span* sp_up = new Span("upload aux_assignment + h");
+    const DeviceScalars aux_dev(aux_assignment.data(), aux_assignment.size());
+    const DeviceScalars h_dev(h.data(), h.size());
+    delete sp_up;
     Proj<Fq> r_g1, s_g1, l_acc, h_acc;
     Proj<Fq2> s_g2;
     // rayon_join5 (:227-294): five independent MSM groups, issued from five host threads (the C ABI is re-entrant)
-    std::thread t1([&] { r_g1 = calculate_coeff<Fq>(id, T::template scalar_mul_public_point_hs<Fq>(delta_g1, T::to_half_share(r)), pkey.a_query, pkey.alpha_g1, inputs, aux_assignment); });
-    std::thread t2([&] { s_g1 = calculate_coeff<Fq>(id, T::template scalar_mul_public_point_hs<Fq>(delta_g1, T::to_half_share(s)), pkey.b_g1_query, pkey.beta_g1, inputs, aux_assignment); });
-    std::thread t3([&] { s_g2 = calculate_coeff<Fq2>(id, T::template scalar_mul_public_point_hs<Fq2>(delta_g2, T::to_half_share(s)), pkey.b_g2_query, pkey.beta_g2, inputs, aux_assignment); });
-    std::thread t4([&] { l_acc = T::template msm_public_points_hs<Fq>(BasesView{pkey.l_query.dev, 0, pkey.l_query.size()}, aux_assignment); });
-    std::thread t5([&] { h_acc = T::template msm_public_points_hs<Fq>(BasesView{pkey.h_query.dev, 0, pkey.h_query.size()}, h); });
+    Span* sp_msm = new Span("5 msm groups (compute A, B/G1, B/G2, msm l_query, msm h_query)");
+    std::thread t1([&] { r_g1 = calculate_coeff<Fq>(id, T::template scalar_mul_public_point_hs<Fq>(delta_g1, T::to_half_share(r)), pkey.a_query, pkey.alpha_g1, inputs, aux_dev); });
+    std::thread t2([&] { s_g1 = calculate_coeff<Fq>(id, T::template scalar_mul_public_point_hs<Fq>(delta_g1, T::to_half_share(s)), pkey.b_g1_query, pkey.beta_g1, inputs, aux_dev); });
+    std::thread t3([&] { s_g2 = calculate_coeff<Fq2>(id, T::template scalar_mul_public_point_hs<Fq2>(delta_g2, T::to_half_share(s)), pkey.b_g2_query, pkey.beta_g2, inputs, aux_dev); });
+    std::thread t4([&] { l_acc = T::template msm_public_points_hs<Fq>(BasesView{pkey.l_query.dev, 0, pkey.l_query.size()}, aux_dev); });
+    std::thread t5([&] { h_acc = T::template msm_public_points_hs<Fq>(BasesView{pkey.h_query.dev, 0, pkey.h_query.size()}, h_dev); });
     t1.join(); t2.join(); t3.join(); t4.join(); t5.join();
+    delete sp_msm;
+    Span sp_fin("finish - open two points and some adds");
 
     Half rs = T::local_mul_vec({r}, {s}, state0).back();                                     // :297
     Proj<Fq> r_s_delta_g1 = T::template scalar_mul_public_point_hs<Fq>(delta_g1, rs);        // :298

@@ -26,6 +26,15 @@ inline Proj<F> msm_device(const BasesView& v, const void* scalars_mont, size_t n
   return Proj<F>::from_affine(AffineT<F>{out.x, out.y});
 }
 
+template <class F>
+inline Proj<F> msm_device_resident(const BasesView& v, const DeviceScalars& s) {
+  csh::Jac<F> out;
+  const size_t cnt = s.n < v.len ? s.n : v.len;
+  check(csh_msm_dev(v.bases, v.offset, cnt, reinterpret_cast<const uint64_t*>(s.dev), 1, &out, nullptr), "csh_msm_dev");
+  if (out.is_inf()) return Proj<F>::inf();
+  return Proj<F>::from_affine(AffineT<F>{out.x, out.y});
+}
+
 // ---- Rep3 types (mpc-core/src/protocols/rep3/arithmetic/types.rs:21-28, rngs.rs:83-187) -----------------------
 template <class Fr>
 struct Rep3PrimeFieldShare {
@@ -118,6 +127,10 @@ struct PlainGroth16Driver {
     return msm_device<F>(pts, s.data(), s.size());
   }
   template <class F>
+  static Proj<F> msm_public_points_hs(const BasesView& pts, const DeviceScalars& s) {  // same MSM, scalars already in HBM
+    return msm_device_resident<F>(pts, s);
+  }
+  template <class F>
   static Proj<F> scalar_mul_public_point_hs(const Proj<F>& a, const ArithmeticHalfShare& b) { return point_mul(a, b); }
   template <class F>
   static void add_assign_points_public_hs(int, Proj<F>& a, const Proj<F>& b) { a = point_add(a, b); }
@@ -181,6 +194,10 @@ struct Rep3Groth16Driver {
   template <class F>
   static Proj<F> msm_public_points_hs(const BasesView& pts, const std::vector<ArithmeticHalfShare>& s) {  // mpc/rep3.rs:124-132
     return msm_device<F>(pts, s.data(), s.size());
+  }
+  template <class F>
+  static Proj<F> msm_public_points_hs(const BasesView& pts, const DeviceScalars& s) {  // same MSM, scalars already in HBM
+    return msm_device_resident<F>(pts, s);
   }
   template <class F>
   static Proj<F> scalar_mul_public_point_hs(const Proj<F>& a, const ArithmeticHalfShare& b) { return point_mul(a, b); }

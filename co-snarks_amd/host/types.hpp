@@ -9,8 +9,13 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <algorithm>
+#include <chrono>
+#include <stdio.h>
+#include <stdlib.h>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -40,6 +45,55 @@ struct Bls12_381 {
   using Fq = csh::Bls381Fq;
   using Fq2 = csh::Bls381Fq2;
   static const char* name() { return "bls12381"; }
+};
+
+// Tracing spans mirroring the reference's `tracing::debug_span!` names (groth16.rs:229-331, reduction.rs:97-191):
+// COG16_TRACE=1 prints "<span> took <ms>" on close, like the CLI's FmtSpan::CLOSE layer (co-circom.rs:580-599).
+struct Span {
+  const char* name;
+  std::chrono::steady_clock::time_point t0;
+  bool on;
+  explicit Span(const char* n) : name(n), t0(std::chrono::steady_clock::now()), on(getenv("COG16_TRACE") != nullptr) {}
+  ~Span() {
+    if (on) fprintf(stderr, "[cog16] %s took %.3f ms\n", name, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+  }
+};
+
+// rayon-style parallel for over [0, n) in contiguous chunks (the reference uses par_iter().with_min_len(k))
+template <class Fn>
+inline void parallel_for(size_t n, size_t min_len, Fn fn) {
+  size_t nt = std::thread::hardware_concurrency();
+  if (nt == 0) nt = 1;
+  if (nt > 64) nt = 64;
+  size_t chunks = std::min(nt, std::max<size_t>(1, n / std::max<size_t>(1, min_len)));
+  if (chunks <= 1) {
+    fn(0, n);
+    return;
+  }
+  std::vector<std::thread> th;
+  const size_t per = (n + chunks - 1) / chunks;
+  for (size_t c = 0; c < chunks; ++c) {
+    const size_t lo = c * per, hi = std::min(n, lo + per);
+    if (lo >= hi) break;
+    th.emplace_back([=] { fn(lo, hi); });
+  }
+  for (auto& t : th) t.join();
+}
+
+// scalars uploaded once and shared by several MSMs (the four queries that consume aux_assignment)
+struct DeviceScalars {
+  void* dev = nullptr;
+  size_t n = 0;
+  DeviceScalars() = default;
+  DeviceScalars(const void* host, size_t count) : n(count) {
+    check(csh_malloc(&dev, count * 32 + 32), "csh_malloc");
+    if (count) check(csh_memcpy_h2d(dev, host, count * 32), "csh_memcpy_h2d");
+  }
+  DeviceScalars(const DeviceScalars&) = delete;
+  DeviceScalars& operator=(const DeviceScalars&) = delete;
+  ~DeviceScalars() {
+    if (dev) csh_free(dev);
+  }
 };
 
 // ---- group helpers on the host (Projective = XYZZ internally; results leave as affine) --------------------
