@@ -53,6 +53,16 @@ def prove_rep3(curve: int, zkey: bytes, wtns: bytes, seed: int, r=None, s=None, 
     return json.loads(out.value.decode()), h
 
 
+def prove_shamir(curve: int, zkey: bytes, wtns: bytes, num_parties: int, threshold: int, seed: int, r=None, s=None, bridge=False):
+    """ShamirCoGroth16::prove (or Rep3CoGroth16::prove_with_shamir_bridge when bridge=True) with in-process parties."""
+    out = C.create_string_buffer(8192)
+    rc = glib().cog16_prove_shamir(curve, zkey, C.c_size_t(len(zkey)), wtns, C.c_size_t(len(wtns)), num_parties, threshold, C.c_uint64(seed),
+                                   _scalar(r), _scalar(s), int(bridge), out, C.c_size_t(len(out)))
+    if rc != 0:
+        raise CoSnarksHipError(glib().cog16_last_error().decode())
+    return json.loads(out.value.decode())
+
+
 def bench_synthetic(curve: int, log_domain: int, iters: int = 3):
     """Plain Groth16 prove on a synthetic 2^log_domain circuit with a known-dlog key (closed-form check)."""
     ms = (C.c_double * 4)()

@@ -135,6 +135,103 @@ int prove_rep3_t(const uint8_t* zkey, size_t zlen, const uint8_t* wtns, size_t w
   return write_out(j0, out, cap);
 }
 
+// ShamirCoGroth16::prove (groth16.rs:439-463) and Rep3CoGroth16::prove_with_shamir_bridge (groth16.rs:394-417) with
+// n in-process parties. Preprocessing (ShamirPreprocessing::new, DN07 double sharings) is replaced by a dealer that
+// hands every party its (degree-t, degree-2t) share pairs; with r/s given, the first two pairs share exactly r and s.
+template <class P>
+int prove_shamir_t(const uint8_t* zkey, size_t zlen, const uint8_t* wtns, size_t wlen, int n, int t, uint64_t seed, const uint64_t* r,
+                   const uint64_t* s, int bridge, char* out, size_t cap) {
+  using T = ShamirGroth16Driver<P>;
+  using Fr = typename P::Fr;
+  if (n < 2 * t + 1 || t < 1) throw Error("num_parties must be at least 2 * threshold + 1");
+  if (bridge && (n != 3 || t != 1)) throw Error("the Rep3 -> Shamir bridge is the 3-party, threshold-1 case");
+  ProvingKey<P> pk;
+  ConstraintMatrices<P> m;
+  parse_zkey<P>(zkey, zlen, pk, m);
+  std::vector<Fr> w = parse_wtns<P>(wtns, wlen);
+  std::mt19937_64 gen(seed);
+  auto rnd = [&] {
+    uint8_t b[32];
+    for (int i = 0; i < 4; ++i) {
+      uint64_t v = gen();
+      memcpy(b + 8 * i, &v, 8);
+    }
+    return from_be_bytes_mod_order<Fr>(b);
+  };
+  // shamir::share (shamir.rs:359-376): random degree-`deg` polynomial, shares = evaluations at 1..n
+  auto share = [&](const Fr& secret, int deg) {
+    std::vector<Fr> coeffs{secret};
+    for (int i = 0; i < deg; ++i) coeffs.push_back(rnd());
+    std::vector<Fr> out(n);
+    for (int p = 0; p < n; ++p) {
+      Fr x = Fr::from_u64(p + 1), e = Fr::zero();
+      for (size_t k = coeffs.size(); k-- > 0;) e = Fr::add(Fr::mul(e, x), coeffs[k]);
+      out[p] = e;
+    }
+    return out;
+  };
+  const size_t npub = m.num_instance_variables;
+  std::vector<SharedWitness<P, Fr>> sw(n);
+  for (int p = 0; p < n; ++p) sw[p].public_inputs.assign(w.begin(), w.begin() + npub);
+  if (!bridge) {
+    for (size_t i = npub; i < w.size(); ++i) {
+      auto sh = share(w[i], t);
+      for (int p = 0; p < n; ++p) sw[p].witness.push_back(sh[p]);
+    }
+  } else {
+    // Rep3 shares first (rep3.rs:281-292), then translate_primefield_repshare_vec on the device (bridges/rep3_to_shamir.rs:43-62)
+    std::vector<Rep3PrimeFieldShare<Fr>> rs[3];
+    for (size_t i = npub; i < w.size(); ++i) {
+      Fr a = rnd(), b = rnd(), c = Fr::sub(Fr::sub(w[i], a), b);
+      rs[0].push_back({a, c});
+      rs[1].push_back({b, a});
+      rs[2].push_back({c, b});
+    }
+    for (int p = 0; p < 3; ++p) {
+      const uint64_t e = p + 1, z1 = p == 0 ? 3 : p, z2 = p == 2 ? 1 : p + 2;  // get_translation_points (:14-28): f(X) = 1 - X/z
+      Fr x = Fr::sub(Fr::one(), Fr::mul(Fr::from_u64(e), Fr::inv(Fr::from_u64(z1))));
+      Fr y = Fr::sub(Fr::one(), Fr::mul(Fr::from_u64(e), Fr::inv(Fr::from_u64(z2))));
+      sw[p].witness.resize(rs[p].size());
+      check(csh_rep3_to_shamir_vec(P::ID, (const uint64_t*)rs[p].data(), (const uint64_t*)&x, (const uint64_t*)&y, (uint64_t*)sw[p].witness.data(),
+                                   rs[p].size()), "csh_rep3_to_shamir_vec");
+    }
+  }
+  // dealer: three double sharings per party (two rand calls + one scalar_mul: groth16.rs:448-449)
+  std::vector<std::deque<std::pair<Fr, Fr>>> pairs(n);
+  for (int k = 0; k < 3; ++k) {
+    Fr v = rnd();
+    if (k == 0 && r) v = fr_from_canonical<P>(r);
+    if (k == 1 && s) v = fr_from_canonical<P>(s);
+    auto st = share(v, t), s2t = share(v, 2 * t);
+    for (int p = 0; p < n; ++p) pairs[p].push_back({st[p], s2t[p]});
+  }
+  auto nets0 = LocalNetwork::new_parties(n), nets1 = LocalNetwork::new_parties(n);
+  std::vector<Proof<P>> proofs(n);
+  std::vector<std::string> errs(n);
+  std::vector<std::thread> th;
+  int ndev = 1;
+  csh_device_count(&ndev);
+  for (int p = 0; p < n; ++p) {
+    th.emplace_back([&, p] {
+      try {
+        check(csh_init(ndev > 0 ? p % ndev : 0), "csh_init");
+        auto state0 = ShamirState<Fr>::create(p, n, t, pairs[p]);
+        auto state1 = state0.fork(1);
+        proofs[p] = CoGroth16<P, T>::template prove_inner<CircomReduction>(&nets0[p], &nets1[p], state0, state1, pk, m, sw[p], nullptr, nullptr);
+      } catch (const std::exception& e) {
+        errs[p] = e.what();
+      }
+    });
+  }
+  for (auto& x : th) x.join();
+  for (int p = 0; p < n; ++p)
+    if (!errs[p].empty()) throw Error("party " + std::to_string(p) + ": " + errs[p]);
+  std::string j0 = proof_to_json(proofs[0]);
+  for (int p = 1; p < n; ++p)
+    if (j0 != proof_to_json(proofs[p])) throw Error("the parties disagree on the proof");
+  return write_out(j0, out, cap);
+}
+
 // ---- synthetic large circuit with a known-trapdoor-style key: every query point is
 // k_i * G with k_i = splitmix64(seed + i) | 1, so A, B, C have closed-form discrete logs and are checked with
 // three scalar multiplications instead of a pairing. Constraints: w[j+1] * w[j+2] = w[j+3].
@@ -241,6 +338,19 @@ int bench_synth_t(int log_domain, int iters, double* out_ms, int* check_ok, cons
 }  // namespace
 
 extern "C" {
+
+int cog16_prove_shamir(int curve, const uint8_t* zkey, size_t zlen, const uint8_t* wtns, size_t wlen, int num_parties, int threshold,
+                       uint64_t seed, const uint64_t* r, const uint64_t* s, int bridge, char* out_json, size_t cap) {
+  try {
+    if (curve == 0) return prove_shamir_t<Bn254>(zkey, zlen, wtns, wlen, num_parties, threshold, seed, r, s, bridge, out_json, cap);
+    if (curve == 1) return prove_shamir_t<Bls12_381>(zkey, zlen, wtns, wlen, num_parties, threshold, seed, r, s, bridge, out_json, cap);
+    g_err = "unknown curve";
+    return -1;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return -1;
+  }
+}
 
 // out_ms[4] = {witness_map ms, create_proof ms, total prove ms, key generation+upload ms}; best of `iters`.
 int cog16_bench_synthetic(int curve, int log_domain, int iters, double* out_ms, int* check_ok) {

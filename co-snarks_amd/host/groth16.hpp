@@ -3,6 +3,7 @@
 // CircomReduction) above the C ABI. Same control flow, line-cited; the hot calls go to the device.
 #pragma once
 #include <map>
+#include <type_traits>
 #include <mutex>
 #include <thread>
 
@@ -135,6 +136,17 @@ struct CoGroth16 {
   using Net = typename T::Net;
   using State = typename T::State;
 
+  // T::scalar_mul (mpc.rs:131-137). The Shamir driver's degree_reduce_point needs C::generator() (network.rs:261-262).
+  static Proj<Fq> scalar_mul_dispatch(const Proj<Fq>& a, const Share& b, const Net* net, State& st) {
+    if constexpr (std::is_same<T, ShamirGroth16Driver<P>>::value) {
+      AffineT<Fq> gen;
+      memcpy(&gen, P::g1_generator_words(), sizeof gen);
+      return T::template scalar_mul<Fq>(a, b, net, st, gen);
+    } else {
+      return T::template scalar_mul<Fq>(a, b, net, st);
+    }
+  }
+
   // groth16.rs:179-203
   template <class F>
   static Proj<F> calculate_coeff(int id, Proj<F> initial, const Query<F>& query, const AffineT<F>& vk_param,
@@ -180,7 +192,7 @@ struct CoGroth16 {
     Proj<Fq> r_s_delta_g1 = T::template scalar_mul_public_point_hs<Fq>(delta_g1, rs);        // :298
     Proj<Fq> g_a_opened, r_g1_b;
     {  // mpc_net::join (:305-308): two network legs
-      std::thread n1([&] { r_g1_b = T::template scalar_mul<Fq>(s_g1, r, net1, state1); });
+      std::thread n1([&] { r_g1_b = scalar_mul_dispatch(s_g1, r, net1, state1); });
       g_a_opened = T::template open_half_point<Fq>(r_g1, net0, state0);
       n1.join();
     }

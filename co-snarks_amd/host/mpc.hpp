@@ -4,6 +4,7 @@
 // methods (local_mul_vec, distribute_powers_and_mul_by_const, msm_public_points_hs and the NTTs inside the
 // reduction) call the C ABI of include/cosnarks_hip.h, everything else is host code as in the reference.
 #pragma once
+#include <deque>
 #include <random>
 
 #include "network.hpp"
@@ -224,22 +225,171 @@ struct Rep3Groth16Driver {
   }
 };
 
-// ================================= ShamirGroth16Driver (mpc/shamir.rs, local methods) =================================
+// ================================= Shamir (mpc-core/src/protocols/shamir*.rs) =================================
+// lagrange_from_coeff (shamir.rs:442-460)
+template <class Fr>
+inline std::vector<Fr> lagrange_from_coeff(const std::vector<size_t>& coeffs) {
+  std::vector<Fr> res;
+  for (size_t i : coeffs) {
+    Fr num = Fr::one(), den = Fr::one();
+    const Fr fi = Fr::from_u64(i);
+    for (size_t j : coeffs)
+      if (i != j) {
+        const Fr fj = Fr::from_u64(j);
+        num = Fr::mul(num, fj);
+        den = Fr::mul(den, Fr::sub(fj, fi));
+      }
+    res.push_back(Fr::mul(num, Fr::inv(den)));
+  }
+  return res;
+}
+
+template <class Fr>
+struct ShamirState {
+  int id = 0;
+  size_t num_parties = 0, threshold = 0;
+  std::vector<Fr> open_lagrange_t, open_lagrange_2t, mul_lagrange_2t;
+  std::vector<Fr> mul_reconstruct_with_zeros;       // q(X): q(0) = 1, q(j) = 0 for j in num_non_zero+1..n
+  std::deque<std::pair<Fr, Fr>> rng_buffer;         // (r_t, r_2t) double sharings (shamir/rngs.rs:12-60; dealt here)
+  // From<ShamirPreprocessing> (shamir.rs:66-103)
+  static ShamirState create(int id, size_t n, size_t t, std::deque<std::pair<Fr, Fr>> pairs) {
+    ShamirState s;
+    s.id = id;
+    s.num_parties = n;
+    s.threshold = t;
+    auto ring = [&](size_t cnt) {
+      std::vector<size_t> c;
+      for (size_t i = 0; i < cnt; ++i) c.push_back((id + n - i) % n + 1);
+      return c;
+    };
+    s.open_lagrange_t = lagrange_from_coeff<Fr>(ring(t + 1));
+    s.open_lagrange_2t = lagrange_from_coeff<Fr>(ring(2 * t + 1));
+    std::vector<size_t> first;
+    for (size_t i = 1; i <= 2 * t + 1; ++i) first.push_back(i);
+    s.mul_lagrange_2t = lagrange_from_coeff<Fr>(first);
+    // interpolation_poly_from_zero_points (shamir.rs:568-586)
+    const size_t num_non_zero = n - t;
+    std::vector<Fr> num{Fr::one()};
+    Fr d = Fr::one();
+    for (size_t j = num_non_zero + 1; j <= n; ++j) {
+      const Fr fj = Fr::from_u64(j);
+      num.insert(num.begin(), Fr::zero());  // poly_times_root_inplace: num = num * (X - j)
+      for (size_t k = 1; k < num.size(); ++k) num[k - 1] = Fr::sub(num[k - 1], Fr::mul(num[k], fj));
+      d = Fr::mul(d, Fr::neg(fj));
+    }
+    const Fr c = Fr::inv(d);
+    for (auto& x : num) x = Fr::mul(x, c);
+    s.mul_reconstruct_with_zeros = num;
+    s.rng_buffer = std::move(pairs);
+    return s;
+  }
+  ShamirState fork(size_t amount) {  // ShamirState::fork: hands `amount` pairs to the forked state
+    ShamirState s = *this;
+    s.rng_buffer.clear();
+    for (size_t i = 0; i < amount; ++i) {
+      s.rng_buffer.push_back(rng_buffer.back());
+      rng_buffer.pop_back();
+    }
+    return s;
+  }
+  std::pair<Fr, Fr> get_pair() {
+    if (rng_buffer.empty()) throw Error("Shamir: out of preprocessed double sharings");
+    auto p = rng_buffer.front();
+    rng_buffer.pop_front();
+    return p;
+  }
+};
+
 template <class P>
 struct ShamirGroth16Driver {
   using Fr = typename P::Fr;
   using ArithmeticShare = Fr;        // ShamirPrimeFieldShare is repr(transparent)
-  using ArithmeticHalfShare = Fr;
+  using ArithmeticHalfShare = Fr;    // degree-2t sharing
+  using State = ShamirState<Fr>;
+  using Net = LocalNetwork;
   static constexpr int PROTOCOL = 0;
   static constexpr uint32_t NCOMP = 1;
+
+  static ArithmeticShare rand(const Net*, State& st) { return st.get_pair().first; }  // ShamirState::rand: the degree-t half of a pair
   static ArithmeticShare evaluate_constraint(int, const std::vector<std::pair<Fr, size_t>>& lhs, const std::vector<Fr>& pub,
                                              const std::vector<ArithmeticShare>& wit) {  // mpc/shamir.rs:29-49: public values add to every share
     return PlainGroth16Driver<P>::evaluate_constraint(0, lhs, pub, wit);
   }
-  static std::vector<Fr> local_mul_vec(const std::vector<Fr>& a, const std::vector<Fr>& b) {  // shamir/arithmetic.rs:73-79
+  static std::vector<ArithmeticShare> promote_to_trivial_shares(int, const std::vector<Fr>& v) { return v; }  // shamir/arithmetic.rs:229-231
+  static std::vector<Fr> masks(State&, size_t) { return {}; }
+  static std::vector<Fr> local_mul_vec(const std::vector<Fr>& a, const std::vector<Fr>& b, State&) {  // shamir/arithmetic.rs:73-79
     std::vector<Fr> out(a.size());
     check(csh_vec_mul(P::ID, (const uint64_t*)a.data(), (const uint64_t*)b.data(), (uint64_t*)out.data(), a.size()), "csh_vec_mul");
     return out;
+  }
+  static void distribute_powers_and_mul_by_const(std::vector<ArithmeticShare>& c, const std::vector<Fr>& roots) {  // mpc/shamir.rs:85-96
+    check(csh_vec_mul_table(P::ID, (uint64_t*)c.data(), (const uint64_t*)roots.data(), c.size(), 1), "csh_vec_mul_table");
+  }
+  static ArithmeticHalfShare to_half_share(const ArithmeticShare& a) { return a; }  // mpc/shamir.rs:107-109
+  template <class F>
+  static Proj<F> msm_public_points_hs(const BasesView& pts, const std::vector<ArithmeticHalfShare>& s) {  // mpc/shamir.rs:111-119
+    return msm_device<F>(pts, s.data(), s.size());
+  }
+  template <class F>
+  static Proj<F> msm_public_points_hs(const BasesView& pts, const DeviceScalars& s) { return msm_device_resident<F>(pts, s); }
+  template <class F>
+  static Proj<F> scalar_mul_public_point_hs(const Proj<F>& a, const ArithmeticHalfShare& b) { return point_mul(a, b); }
+  template <class F>
+  static void add_assign_points_public_hs(int, Proj<F>& a, const Proj<F>& b) { a = point_add(a, b); }  // mpc/shamir.rs:98-105
+  // shamir/pointshare.rs:102-110 + network.rs:96-126 broadcast_next(n, 2t+1)
+  template <class F>
+  static Proj<F> open_half_point(const Proj<F>& a, const Net* net, State& st) {
+    const size_t n = st.num_parties, num = 2 * st.threshold + 1;
+    AffineT<F> mine = into_affine(a);
+    Bytes b(sizeof mine);
+    memcpy(b.data(), &mine, sizeof mine);
+    for (size_t s = 1; s < num; ++s) net->send((int)((st.id + s) % n), b);
+    Proj<F> res = point_mul(a, st.open_lagrange_2t[0]);
+    for (size_t r = 1; r < num; ++r) {
+      Bytes rb = net->recv((int)((st.id + n - r) % n));
+      AffineT<F> o;
+      memcpy(&o, rb.data(), sizeof o);
+      res = point_add(res, point_mul(into_group(o), st.open_lagrange_2t[r]));
+    }
+    return res;
+  }
+  // mpc/shamir.rs:139-147: degree_reduce_point (shamir/network.rs:246-309, king = party 0) then (b * a).a
+  template <class F>
+  static Proj<F> scalar_mul(const Proj<F>& a, const ArithmeticShare& b, const Net* net, State& st, const AffineT<F>& generator) {
+    const size_t n = st.num_parties, t = st.threshold, num_non_zero = n - t;
+    auto [r_t, r_2t] = st.get_pair();
+    const Proj<F> g = into_group(generator);
+    Proj<F> input = point_add(a, point_mul(g, r_2t));
+    Proj<F> my_share = Proj<F>::inf();
+    auto send_pt = [&](int to, const Proj<F>& p) {
+      AffineT<F> af = into_affine(p);
+      Bytes bb(sizeof af);
+      memcpy(bb.data(), &af, sizeof af);
+      net->send(to, std::move(bb));
+    };
+    auto recv_pt = [&](int from) {
+      Bytes rb = net->recv(from);
+      AffineT<F> o;
+      memcpy(&o, rb.data(), sizeof o);
+      return into_group(o);
+    };
+    if (st.id == 0) {
+      Proj<F> acc = point_mul(input, st.mul_lagrange_2t[0]);
+      for (size_t other = 1; other < st.mul_lagrange_2t.size(); ++other) acc = point_add(acc, point_mul(recv_pt((int)other), st.mul_lagrange_2t[other]));
+      for (size_t id = 0; id < num_non_zero; ++id) {
+        // evaluate acc * q(X) at X = id + 1 (poly_with_zeros_from_precomputed_point + evaluate_poly_point)
+        Fr x = Fr::from_u64(id + 1), e = Fr::zero();
+        for (size_t k = st.mul_reconstruct_with_zeros.size(); k-- > 0;) e = Fr::add(Fr::mul(e, x), st.mul_reconstruct_with_zeros[k]);
+        Proj<F> val = point_mul(acc, e);
+        if (id == 0) my_share = val;
+        else send_pt((int)id, val);
+      }
+    } else {
+      if ((size_t)st.id <= 2 * t) send_pt(0, input);
+      if ((size_t)st.id < num_non_zero) my_share = recv_pt(0);
+    }
+    Proj<F> reduced = point_add(my_share, point_neg(point_mul(g, r_t)));
+    return point_mul(reduced, b);  // scalar_mul_local (shamir/pointshare.rs:97-99)
   }
 };
 

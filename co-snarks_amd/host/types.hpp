@@ -38,6 +38,7 @@ struct Bn254 {
   using Fq = csh::Bn254Fq;
   using Fq2 = csh::Bn254Fq2;
   static const char* name() { return "bn128"; }
+  static const uint32_t* g1_generator_words() { return csh::Bn254G1Gen; }
 };
 struct Bls12_381 {
   static constexpr csh_curve_t ID = CSH_BLS12_381;
@@ -45,6 +46,7 @@ struct Bls12_381 {
   using Fq = csh::Bls381Fq;
   using Fq2 = csh::Bls381Fq2;
   static const char* name() { return "bls12381"; }
+  static const uint32_t* g1_generator_words() { return csh::Bls381G1Gen; }
 };
 
 // Tracing spans mirroring the reference's `tracing::debug_span!` names (groth16.rs:229-331, reduction.rs:97-191):

@@ -73,6 +73,25 @@ def test_rep3_three_parties_agree_and_match_plain(gpu, curve, circ):
     assert og.verify(curve, zko.G1, vk, _as_points(fresh), pub)
 
 
+@pytest.mark.parametrize("curve,circ,n,t,bridge", [("bn254", "multiplier2", 3, 1, False), ("bn254", "poseidon", 3, 1, False),
+                                                   ("bn254", "multiplier2", 5, 2, False), ("bls12_381", "multiplier2", 3, 1, False),
+                                                   ("bn254", "poseidon", 3, 1, True)])
+def test_shamir_parties_agree_and_match_plain(gpu, curve, circ, n, t, bridge):
+    """tests/tests/circom/e2e_tests/shamir.rs:34-...: n Shamir parties (threshold t) agree on a verifying proof;
+    with the dealt randomness sharing r, s it is the plain proof. bridge=True: prove_with_shamir_bridge
+    (e2e_tests/rep3.rs:88-137), Rep3 shares translated on the device."""
+    from cosnarks_amd import groth16 as g
+    zk, wt, vk, pub = _load(curve, circ)
+    zko = oz.parse_zkey(zk)
+    proof = g.prove_shamir(H.CURVE_IDS[curve], zk, wt, n, t, seed=11, r=R, s=S, bridge=bridge)
+    gold = json.load(open(os.path.join(GOLD, "groth16_golden.json")))[f"{curve}/{circ}"]
+    assert proof["pi_a"][:2] == gold["a"] and proof["pi_b"][:2] == gold["b"] and proof["pi_c"][:2] == gold["c"]
+    fresh = g.prove_shamir(H.CURVE_IDS[curve], zk, wt, n, t, seed=12, bridge=bridge)
+    assert og.verify(curve, zko.G1, vk, _as_points(fresh), pub)
+    with pytest.raises(gpu.CoSnarksHipError, match="at least 2 \\* threshold \\+ 1"):
+        g.prove_shamir(H.CURVE_IDS[curve], zk, wt, 2 * t, t, seed=1)
+
+
 def test_prove_rejects_wrong_witness_length(gpu):
     from cosnarks_amd import groth16 as g
     zk, wt, _, _ = _load("bn254", "multiplier2")
