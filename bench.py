@@ -28,6 +28,76 @@ sys.path.insert(0, ROOT)
 PMC_TRAFFIC_BYTES = {20: 2682923502}
 
 
+def secondary_metrics(hip, B, L, C, np, torch, dev, stream):
+    """MSM at 2^24, NTT/iNTT at 2^22 (BASELINE config 3), Rep3 local_mul_vec, Groth16 prove on a synthetic 2^20 circuit."""
+    out = {}
+    torch.cuda.synchronize()
+    # MSM 2^24
+    n = 1 << 24
+    pts = torch.empty(n * 64, dtype=torch.uint8, device=dev)
+    B._check(L.csh_util_generate_bases_dev(hip.BN254, hip.G1, C.c_uint64(77), C.c_size_t(n), C.c_void_p(pts.data_ptr()), C.c_void_p(stream)))
+    h = C.c_void_p()
+    B._check(L.csh_bases_upload_dev(hip.BN254, hip.G1, C.c_void_p(pts.data_ptr()), C.c_size_t(n), C.c_size_t(0), C.c_void_p(stream), C.byref(h)))
+    del pts
+    sc = torch.randint(0, 1 << 62, (n, 4), dtype=torch.int64, device=dev)
+    sc[:, 3] >>= 1
+    res = np.zeros(12, dtype=np.uint64)
+    run = lambda: B._check(L.csh_msm_dev(h, C.c_size_t(0), C.c_size_t(n), C.c_void_p(sc.data_ptr()), 1, res.ctypes.data_as(C.c_void_p), C.c_void_p(stream)))
+    run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 5
+    out["msm_bn254_g1_2p24"] = {"points_per_s": n / dt, "ms": dt * 1e3}
+    L.csh_bases_free(h)
+    del sc
+    # NTT 2^22 (snarkjs root), data resident
+    logn = 22
+    r = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    g = pow(pow(5, (r - 1) >> 28, r), 1 << (28 - logn), r) * ((1 << 256) % r) % r
+    gen = np.array([(g >> (64 * i)) & (2**64 - 1) for i in range(4)], dtype=np.uint64)
+    dom = hip.Domain(hip.BN254, logn, gen)
+    data = torch.randint(0, 1 << 62, (1 << logn, 4), dtype=torch.int64, device=dev)
+    data[:, 3] >>= 1   # canonical (< r)
+    # HIP events recorded on the stream the kernels run on (torch's default stream handle is 0 = the library's own
+    # per-thread stream here, which torch.cuda.Event would not observe)
+    e0, e1 = B.Event(), B.Event()
+    dom.ifft_in_to_out_dev(data.data_ptr(), 1, stream)
+    e0.record(stream)
+    for _ in range(10):
+        dom.ifft_in_to_out_dev(data.data_ptr(), 1, stream)
+        dom.fft_out_to_in_dev(data.data_ptr(), 1, stream)
+    e1.record(stream)
+    ms = e0.elapsed_ms(e1) / 20
+    out["ntt_bn254_2p22"] = {"elements_per_s": (1 << logn) / ms * 1e3, "ms": ms, "alg_GBps": 64.0 * (1 << logn) / ms / 1e6}
+    dom.free()
+    del data
+    # Rep3 local_mul_vec 2^24 (192 B/element)
+    n = 1 << 24
+    a = torch.randint(0, 1 << 62, (2 * n, 4), dtype=torch.int64, device=dev)
+    b = torch.randint(0, 1 << 62, (2 * n, 4), dtype=torch.int64, device=dev)
+    m = torch.randint(0, 1 << 62, (n, 4), dtype=torch.int64, device=dev)
+    o = torch.empty((n, 4), dtype=torch.int64, device=dev)
+    for x in (a, b, m):
+        x[:, 3] >>= 1
+    f = lambda: B._check(L.csh_rep3_local_mul_vec_dev(hip.BN254, C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(m.data_ptr()),
+                                                       C.c_void_p(o.data_ptr()), C.c_size_t(n), C.c_void_p(stream)))
+    f()
+    e0.record(stream)
+    for _ in range(10):
+        f()
+    e1.record(stream)
+    ms = e0.elapsed_ms(e1) / 10
+    out["rep3_local_mul_vec_2p24"] = {"elements_per_s": n / ms * 1e3, "ms": ms, "alg_GBps": 192.0 * n / ms / 1e6, "hbm_peak_frac": 192.0 * n / ms / 1e6 / 8000.0}
+    del a, b, m, o
+    # Groth16 plain prove, synthetic 2^20-constraint circuit with a known-dlog key (closed-form checked), key resident
+    from cosnarks_amd import groth16 as g16
+    out["groth16_prove_synthetic_2p20"] = g16.bench_synthetic(hip.BN254, 20, 3)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -36,6 +106,7 @@ def main():
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary metrics (MSM 2^24, NTT 2^22, Groth16 prove ms)")
     args = ap.parse_args()
 
     import torch  # FIRST: torch bundles its own libamdhip64.so.7; our library must bind to the same runtime
@@ -148,6 +219,15 @@ def main():
         except Exception as e:  # the baseline is a reported extra, never part of the measured path
             cpu_baseline = {"error": repr(e)}
 
+    # ---- secondary metrics of BASELINE.json (untimed extras, N = 1 only): MSM 2^24, NTT 2^22, Groth16 prove ms
+    extras = None
+    if rank == 0 and world == 1 and not args.no_extras:
+        extras = {}
+        try:
+            extras.update(secondary_metrics(hip, B, L, C, np, torch, dev, stream))
+        except Exception as e:
+            extras["error"] = repr(e)
+
     if rank == 0:
         line = {
             "metric": "BN254 G1 MSM points/sec", "value": value, "unit": "points/s", "n_gpus": world,
@@ -155,7 +235,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "i32x9 29-bit-limb Montgomery, i64 accumulate (BN254 Fq 254-bit)", "data": "synthetic",
             "config": {"workload": f"BN254 G1 Pippenger MSM, 2^{args.log_n} uniform scalars/points per GPU (BASELINE config 2)",
                        "points_per_gpu": n, "split": "contiguous point ranges + RCCL all-gather of window partials" if world > 1 else "single GPU"},
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "result_check": check,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "result_check": check, "secondary": extras,
         }
         print(json.dumps(line))
     if world > 1:
