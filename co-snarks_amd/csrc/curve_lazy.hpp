@@ -16,8 +16,10 @@ struct XYZZLazy {
 };
 
 // 2 * (x, y) for an affine point with y != 0 (rare path)
+// (big aggregates cross the call boundary through memory, by pointer: passing ~450-byte structs by value inside the
+// already register-saturated wide-field kernels proved fragile)
 template <class L>
-CSH_HD_NOINLINE XYZZLazy<L> lazy_mdbl(L x, L y) {
+CSH_HD XYZZLazy<L> lazy_mdbl_inl(const L& x, const L& y) {
   L u = L::add(y, y).normalized();
   L v = L::sqr(u);
   L w = L::mul(u, v);
@@ -31,6 +33,10 @@ CSH_HD_NOINLINE XYZZLazy<L> lazy_mdbl(L x, L y) {
   r.zzz = w;
   r.empty = false;
   return r;
+}
+template <class L>
+CSH_HD_NOINLINE void lazy_mdbl(const L* x, const L* y, XYZZLazy<L>* out) {
+  *out = lazy_mdbl_inl<L>(*x, *y);
 }
 
 // acc += (x2, y2); the caller has already excluded the point at infinity. Contract: x2, y2 have limbs in
@@ -54,7 +60,12 @@ CSH_HD void lazy_madd(XYZZLazy<L>& acc, const L& x2, const L& y2) {
     if (p.is_zero_slow()) {
       if (r.is_zero()) {
         if (y2.is_zero()) acc.empty = true;  // 2-torsion cannot occur on these curves; kept for completeness
-        else acc = lazy_mdbl<L>(x2, y2);
+        else {
+          const L tx = x2, ty = y2;  // private copies: the call takes addresses
+          XYZZLazy<L> d;
+          lazy_mdbl<L>(&tx, &ty, &d);
+          acc = d;
+        }
       } else {
         acc.empty = true;  // P + (-P)
       }

@@ -4,12 +4,13 @@
 //   1. k_msm_digits   scalar -> canonical -> signed c-bit digit codes (u16 per point and window)
 //      k_msm_hist_lds per-(window, chunk) bucket histogram staged in LDS (<= 128 KiB), wave-aggregated
 //      k_msm_colscan  per-bucket prefix over chunks
-//   2. k_msm_scan     per-window exclusive scan of bucket counts; long buckets are cut into tasks of <= L
-//                     entries so a skewed witness (many equal scalars) cannot serialise on one lane
+//   2. k_msm_scan     per-window exclusive scan of bucket counts; lanes per window = ceil(entries / L)
 //   3. k_msm_scatter_lds  counting-sort scatter of (point index | sign) into per-window bucket order; the
 //                     per-bucket cursors live in LDS, no global atomics
-//   4. k_msm_accum    one lane per task: gather affine bases, XYZZ mixed additions in registers
-//   5. k_msm_reduce   balanced segments over the task list: running-sum  sum_b b*B_b  per segment
+//   4. k_msm_accum    one lane per run of L sorted entries (equal work per lane, whatever the bucket sizes):
+//                     gather affine bases, XYZZ mixed additions in registers, one partial per touched bucket
+//      k_msm_merge    per-bucket fold of its partials -> dense bucket sums (block-wide tree for giant buckets)
+//   5. k_msm_reduce   segments of buckets: running-sum  sum_b b*B_b  per segment
 //   6. k_msm_fold     pairwise tree over the segment results -> one XYZZ sum per window
 //   host: Horner over the W window sums (W*c doublings), one inversion, Jacobian (x, y, 1) out.
 //
@@ -149,56 +150,42 @@ __global__ __launch_bounds__(256) void k_msm_colscan(MsmParams p, uint32_t* __re
 }
 
 // One 1024-thread block per window. In: hist[w][0..NB+1] counts (index 0 and NB+1 unused = 0).
-// Out: start[w][b] = first sorted slot of bucket b (start[w][NB+1] = total), tstart[w][b] = first task id,
-// ntasks[w]; hist is zeroed so the scatter can reuse it as the per-bucket cursor.
-__global__ __launch_bounds__(1024) void k_msm_scan(MsmParams p, uint32_t* hist, uint32_t* start, uint32_t* tstart, uint32_t* ntasks) {
+// Out: start[w][b] = first sorted slot of bucket b (start[w][NB+1] = total entries of the window) and
+// nlanes[w] = ceil(total / L): the accumulate kernel cuts the sorted array into equal runs of L entries, one lane
+// each, so every lane of a wave does the same number of mixed additions whatever the bucket sizes are.
+__global__ __launch_bounds__(1024) void k_msm_scan(MsmParams p, uint32_t* hist, uint32_t* start, uint32_t* nlanes) {
   __shared__ uint32_t sh_cnt[1024];
-  __shared__ uint32_t sh_tsk[1024];
   const int w = blockIdx.x;
   const uint32_t len = p.NB + 2;
   uint32_t* h = hist + (size_t)w * len;
   uint32_t* st = start + (size_t)w * len;
-  uint32_t* ts = tstart + (size_t)w * len;
   const uint32_t per = (len + 1023) / 1024;
   const uint32_t b0 = threadIdx.x * per;
-  uint32_t cnt = 0, tsk = 0;
+  uint32_t cnt = 0;
   for (uint32_t k = 0; k < per; ++k) {
     const uint32_t b = b0 + k;
-    if (b < len) {
-      const uint32_t cv = h[b];
-      cnt += cv;
-      tsk += (cv + p.L - 1) / p.L;
-    }
+    if (b < len) cnt += h[b];
   }
   sh_cnt[threadIdx.x] = cnt;
-  sh_tsk[threadIdx.x] = tsk;
   __syncthreads();
-  // Hillis-Steele inclusive scan over 1024 partials
-  for (int d = 1; d < 1024; d <<= 1) {
-    uint32_t a = 0, b2 = 0;
-    if ((int)threadIdx.x >= d) {
-      a = sh_cnt[threadIdx.x - d];
-      b2 = sh_tsk[threadIdx.x - d];
-    }
+  for (int d = 1; d < 1024; d <<= 1) {  // Hillis-Steele inclusive scan over 1024 partials
+    uint32_t a = 0;
+    if ((int)threadIdx.x >= d) a = sh_cnt[threadIdx.x - d];
     __syncthreads();
     sh_cnt[threadIdx.x] += a;
-    sh_tsk[threadIdx.x] += b2;
     __syncthreads();
   }
   uint32_t run_c = sh_cnt[threadIdx.x] - cnt;
-  uint32_t run_t = sh_tsk[threadIdx.x] - tsk;
   for (uint32_t k = 0; k < per; ++k) {
     const uint32_t b = b0 + k;
     if (b < len) {
       const uint32_t cv = h[b];
       st[b] = run_c;
-      ts[b] = run_t;
       run_c += cv;
-      run_t += (cv + p.L - 1) / p.L;
       h[b] = 0;
     }
   }
-  if (threadIdx.x == 1023) ntasks[w] = sh_tsk[1023];
+  if (threadIdx.x == 1023) nlanes[w] = (sh_cnt[1023] + p.L - 1) / p.L;
 }
 
 // Block (chunk ch, window w): LDS cursors = bucket start + this chunk's prefix; scatter (index | sign) into
@@ -227,6 +214,7 @@ __global__ __launch_bounds__(SORT_BLK) void k_msm_scatter_lds(MsmParams p, const
   }
 }
 
+
 // first index in [lo, hi) with a[idx] > v
 __device__ __forceinline__ uint32_t upper_bound_u32(const uint32_t* __restrict__ a, uint32_t lo, uint32_t hi, uint32_t v) {
   while (lo < hi) {
@@ -236,63 +224,52 @@ __device__ __forceinline__ uint32_t upper_bound_u32(const uint32_t* __restrict__
   return lo;
 }
 
-// One task's bucket accumulation as an out-of-line function (variant 5: isolates its register allocation)
+// Export of one finished bucket run (out of line: two call sites, executed once per bucket boundary)
 template <class Cfg>
-__device__ __attribute__((noinline)) XYZZ<typename Cfg::Fq> lazy_task(const Affine<typename Cfg::Fq>* __restrict__ bases,
-                                                                      const uint32_t* __restrict__ so, uint32_t lo, uint32_t hi) {
-  using Fq = typename Cfg::Fq;
-  using L = typename Cfg::L;
-  XYZZLazy<L> acc = XYZZLazy<L>::inf();
-  for (uint32_t k = lo; k < hi; ++k) {
-    const uint32_t e = so[k];
-    const Affine<Fq> pt = bases[e & 0x7fffffffu];
-    if (pt.is_inf()) continue;
-    const L x = L::unpack(pt.x);
-    L y = L::unpack(pt.y);
-    if (e >> 31) y = L::neg(y).normalized();  // keep |limb| <= 2^B + 1: lazy_madd subtracts acc.y limb-wise
-    lazy_madd(acc, x, y);
-  }
-  return lazy_to_xyzz<L, Fq>(acc);
+__device__ __attribute__((noinline)) void flush_partial(XYZZ<typename Cfg::Fq>* dst, const XYZZLazy<typename Cfg::L>* acc) {
+  *dst = lazy_to_xyzz<typename Cfg::L, typename Cfg::Fq>(*acc);
 }
 
-// VAR selects an occupancy / prefetch variant (tuning knob CSH_ACC_VARIANT): 0 = prefetch, default registers;
-// 1 = prefetch, >= 3 waves/SIMD; 2 = no prefetch, >= 3 waves/SIMD; 3 = no prefetch, >= 4 waves/SIMD
-template <class Cfg, int VAR>
-__global__ __launch_bounds__(ACC_BLK, (VAR == 0 || VAR >= 4 ? 1 : (VAR == 3 ? 4 : 3))) void k_msm_accum(const Affine<typename Cfg::Fq>* __restrict__ bases, MsmParams p,
-                                                       const uint32_t* __restrict__ start, const uint32_t* __restrict__ tstart,
-                                                       const uint32_t* __restrict__ ntasks, const uint32_t* __restrict__ sorted,
-                                                       XYZZ<typename Cfg::Fq>* partial, uint32_t* task_bucket) {
+// Bucket accumulation. Lane k of window w owns sorted entries [k*L, (k+1)*L): it walks them in bucket order and
+// emits one partial sum per bucket it touches into slot (bucket + k) -- unique and increasing in (bucket, lane), so
+// the partials of one bucket are consecutive slots. A bucket that spans several lanes (skewed scalars, or simply
+// > L entries) gets one partial per lane; k_msm_merge folds them into the dense per-bucket array.
+template <class Cfg>
+__global__ __launch_bounds__(ACC_BLK) void k_msm_accum(const Affine<typename Cfg::Fq>* __restrict__ bases, MsmParams p,
+                                                       const uint32_t* __restrict__ start, const uint32_t* __restrict__ nlanes,
+                                                       const uint32_t* __restrict__ sorted, XYZZ<typename Cfg::Fq>* partial) {
   using Fq = typename Cfg::Fq;
   const int w = blockIdx.y;
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= ntasks[w]) return;
-  const uint32_t len = p.NB + 2;
-  const uint32_t* ts = tstart + (size_t)w * len;
-  const uint32_t* st = start + (size_t)w * len;
-  const uint32_t b = upper_bound_u32(ts, 1, p.NB + 1, t) - 1;  // bucket owning task t
-  const uint32_t sub = t - ts[b];
-  const uint32_t lo = st[b] + sub * p.L;
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nlanes[w]) return;
+  const uint32_t* st = start + (size_t)w * (p.NB + 2);
+  const uint32_t total = st[p.NB + 1];
+  const uint32_t lo = k * p.L;
   uint32_t hi = lo + p.L;
-  const uint32_t end = st[b + 1];
-  if (hi > end) hi = end;
+  if (hi > total) hi = total;
+  uint32_t b = upper_bound_u32(st, 1, p.NB + 1, lo) - 1;  // bucket containing sorted position lo
+  uint32_t next = st[b + 1];
   const uint32_t* so = sorted + (size_t)w * p.n;
-  if constexpr (Cfg::LAZY && VAR == 5) {
-    partial[(size_t)w * p.tmax + t] = lazy_task<Cfg>(bases, so, lo, hi);
-  } else if constexpr (Cfg::LAZY) {
+  XYZZ<Fq>* pw = partial + (size_t)w * p.tmax;
+  if constexpr (Cfg::LAZY) {
     using L = typename Cfg::L;
     XYZZLazy<L> acc = XYZZLazy<L>::inf();
-    uint32_t e_next = so[lo];                       // lo < hi: every task owns >= 1 entry
+    uint32_t e_next = so[lo];
     Affine<Fq> pt_next = bases[e_next & 0x7fffffffu];
-    for (uint32_t k = lo; k < hi; ++k) {
-      if (VAR >= 2 && k > lo) {
-        e_next = so[k];
-        pt_next = bases[e_next & 0x7fffffffu];
-      }
+    for (uint32_t pos = lo; pos < hi; ++pos) {
       const uint32_t e = e_next;
       const Affine<Fq> pt = pt_next;
-      if ((VAR <= 1) && k + 1 < hi) {               // software prefetch of the next gather
-        e_next = so[k + 1];
+      if (pos + 1 < hi) {                           // software prefetch of the next gather
+        e_next = so[pos + 1];
         pt_next = bases[e_next & 0x7fffffffu];
+      }
+      if (pos == next) {                            // crossed into the next non-empty bucket: flush
+        {
+          const XYZZLazy<L> done = acc;  // private copy: the call takes its address, acc itself stays in registers
+          flush_partial<Cfg>(&pw[b + k], &done);
+        }
+        acc = XYZZLazy<L>::inf();
+        do { ++b; next = st[b + 1]; } while (next <= pos);
       }
       if (pt.is_inf()) continue;
       const L x = L::unpack(pt.x);
@@ -300,18 +277,25 @@ __global__ __launch_bounds__(ACC_BLK, (VAR == 0 || VAR >= 4 ? 1 : (VAR == 3 ? 4 
       if (e >> 31) y = L::neg(y).normalized();  // keep |limb| <= 2^B + 1: lazy_madd subtracts acc.y limb-wise
       lazy_madd(acc, x, y);
     }
-    partial[(size_t)w * p.tmax + t] = lazy_to_xyzz<L, Fq>(acc);
+    {
+      const XYZZLazy<L> done = acc;
+      flush_partial<Cfg>(&pw[b + k], &done);
+    }
   } else {
     XYZZ<Fq> acc = XYZZ<Fq>::inf();
-    for (uint32_t k = lo; k < hi; ++k) {
-      const uint32_t e = so[k];
+    for (uint32_t pos = lo; pos < hi; ++pos) {
+      if (pos == next) {
+        pw[b + k] = acc;
+        acc = XYZZ<Fq>::inf();
+        do { ++b; next = st[b + 1]; } while (next <= pos);
+      }
+      const uint32_t e = so[pos];
       Affine<Fq> pt = bases[e & 0x7fffffffu];
       if (e >> 31) pt.y = Fq::neg(pt.y);
       xyzz_madd(acc, pt);
     }
-    partial[(size_t)w * p.tmax + t] = acc;
+    pw[b + k] = acc;
   }
-  task_bucket[(size_t)w * p.tmax + t] = b;
 }
 
 // Point addition used by the reduction kernels: inlined for the 8-limb base field (2x faster per op than the
@@ -322,28 +306,89 @@ __device__ __forceinline__ void padd(XYZZ<typename Cfg::Fq>& a, const XYZZ<typen
   else xyzz_add(a, b);
 }
 
-// Segment k of window w folds tasks [t0, t1): returns sum_t bucket(t) * partial(t).
+// Bucket merge: the partials of bucket b sit in consecutive slots b + k0 .. b + k1 (k0, k1 = first / last lane that
+// touched it). One lane per bucket folds them into the dense array dense[w][b]; buckets with more than MERGE_CAP
+// partials (heavily repeated scalars) are queued for the block-wide tree kernel below.
+constexpr uint32_t MERGE_CAP = 16;
 template <class Cfg>
-__global__ __launch_bounds__(64) void k_msm_reduce(MsmParams p, const uint32_t* __restrict__ ntasks,
-                                                   const XYZZ<typename Cfg::Fq>* __restrict__ partial,
-                                                   const uint32_t* __restrict__ task_bucket, XYZZ<typename Cfg::Fq>* segres) {
+__global__ __launch_bounds__(64) void k_msm_merge(MsmParams p, const uint32_t* __restrict__ start,
+                                                  const XYZZ<typename Cfg::Fq>* __restrict__ partial, XYZZ<typename Cfg::Fq>* dense,
+                                                  uint32_t* giant_count, uint32_t* giant_list) {
+  using Fq = typename Cfg::Fq;
+  const int w = blockIdx.y;
+  const uint32_t b = blockIdx.x * 64 + threadIdx.x + 1;
+  if (b > p.NB) return;
+  const uint32_t* st = start + (size_t)w * (p.NB + 2);
+  const uint32_t lo = st[b], hi = st[b + 1];
+  XYZZ<Fq> acc = XYZZ<Fq>::inf();
+  if (hi > lo) {
+    const uint32_t k0 = lo / p.L, k1 = (hi - 1) / p.L;
+    const XYZZ<Fq>* pw = partial + (size_t)w * p.tmax + b;
+    if (k1 - k0 >= MERGE_CAP) {
+      const uint32_t g = atomicAdd(giant_count, 1u);
+      giant_list[2 * g] = (uint32_t)w;
+      giant_list[2 * g + 1] = b;
+    } else {
+      acc = pw[k0];
+      for (uint32_t k = k0 + 1; k <= k1; ++k) padd<Cfg>(acc, pw[k]);
+    }
+  }
+  dense[(size_t)w * (p.NB + 1) + b] = acc;
+}
+
+// One 256-thread block per queued bucket: strided private sums, then a tree over global scratch-free LDS-less
+// exchange through the dense array's own slot list (pairwise passes over `tmp`).
+template <class Cfg>
+__global__ __launch_bounds__(256) void k_msm_merge_giant(MsmParams p, const uint32_t* __restrict__ start,
+                                                         const XYZZ<typename Cfg::Fq>* __restrict__ partial, XYZZ<typename Cfg::Fq>* dense,
+                                                         const uint32_t* __restrict__ giant_count, const uint32_t* __restrict__ giant_list,
+                                                         XYZZ<typename Cfg::Fq>* tmp) {
+  using Fq = typename Cfg::Fq;
+  const uint32_t count = *giant_count;
+  XYZZ<Fq>* t = tmp + (size_t)blockIdx.x * 256;
+  for (uint32_t g = blockIdx.x; g < count; g += gridDim.x) {
+    const uint32_t w = giant_list[2 * g], b = giant_list[2 * g + 1];
+    const uint32_t* st = start + (size_t)w * (p.NB + 2);
+    const uint32_t k0 = st[b] / p.L, k1 = (st[b + 1] - 1) / p.L;
+    const XYZZ<Fq>* pw = partial + (size_t)w * p.tmax + b;
+    XYZZ<Fq> acc = XYZZ<Fq>::inf();
+    for (uint32_t k = k0 + threadIdx.x; k <= k1; k += 256) padd<Cfg>(acc, pw[k]);
+    t[threadIdx.x] = acc;
+    __syncthreads();
+    for (uint32_t half = 128; half >= 1; half >>= 1) {
+      if (threadIdx.x < half) {
+        XYZZ<Fq> x = t[threadIdx.x];
+        padd<Cfg>(x, t[threadIdx.x + half]);
+        t[threadIdx.x] = x;
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) dense[(size_t)w * (p.NB + 1) + b] = t[0];
+    __syncthreads();
+  }
+}
+
+// Segment k of window w folds slots [t0, t1) of the (bucket-sorted) partial array: returns sum_t bucket(t) * partial(t)
+// by the running-sum trick with explicit gaps; slots whose bucket id is 0 were never written and are skipped.
+template <class Cfg>
+__global__ __launch_bounds__(64) void k_msm_reduce(MsmParams p, const XYZZ<typename Cfg::Fq>* __restrict__ dense,
+                                                   XYZZ<typename Cfg::Fq>* segres) {
   using Fq = typename Cfg::Fq;
   const int w = blockIdx.y;
   const uint32_t k = blockIdx.x * 64 + threadIdx.x;
   if (k >= p.S) return;
-  const uint32_t T = ntasks[w];
-  const uint32_t per = (T + p.S - 1) / p.S;
-  const uint32_t t0 = k * per;
+  const uint32_t per = (p.NB + p.S - 1) / p.S;  // dense[w][b], b = 1..NB (index 0 unused)
+  const uint32_t t0 = 1 + k * per;
   uint32_t t1 = t0 + per;
-  if (t1 > T) t1 = T;
+  if (t1 > p.NB + 1) t1 = p.NB + 1;
   XYZZ<Fq> running = XYZZ<Fq>::inf(), acc = XYZZ<Fq>::inf();
+  uint32_t prev_b = 0;
   if (t0 < t1) {
-    const XYZZ<Fq>* pw = partial + (size_t)w * p.tmax;
-    const uint32_t* tb = task_bucket + (size_t)w * p.tmax;
-    uint32_t prev_b = tb[t1 - 1];
+    const XYZZ<Fq>* dw = dense + (size_t)w * (p.NB + 1);
     for (uint32_t t = t1; t-- > t0;) {
-      const uint32_t b = tb[t];
-      uint32_t gap = prev_b - b;
+      const XYZZ<Fq> pt = dw[t];
+      if (pt.is_inf()) continue;
+      uint32_t gap = prev_b ? prev_b - t : 0;
       if (gap) {
         if (gap <= 4) {
           while (gap--) padd<Cfg>(acc, running);
@@ -352,12 +397,13 @@ __global__ __launch_bounds__(64) void k_msm_reduce(MsmParams p, const uint32_t* 
           padd<Cfg>(acc, m);
         }
       }
-      padd<Cfg>(running, pw[t]);
-      prev_b = b;
+      padd<Cfg>(running, pt);
+      prev_b = t;
     }
-    // acc = sum (b_t - bmin) P_t ; add bmin * R
-    XYZZ<Fq> m = xyzz_mul_small(running, prev_b);
-    padd<Cfg>(acc, m);
+    if (prev_b) {  // acc = sum (b - bmin) B_b ; add bmin * R
+      XYZZ<Fq> m = xyzz_mul_small(running, prev_b);
+      padd<Cfg>(acc, m);
+    }
   }
   segres[(size_t)w * p.S + k] = acc;
 }
@@ -435,15 +481,18 @@ static int msm_windows_dev(const Bases* B, size_t offset, size_t n, const uint64
   p.c = choose_c(n, Fr::Params::BITS);
   p.W = windows_for(Fr::Params::BITS, p.c);
   p.NB = 1u << (p.c - 1);
-  const uint64_t avg = n / p.NB;
-  uint64_t L = 2 * avg;
-  if (L < 32) L = 32;
+  // L = sorted entries per lane ~ the mean bucket size (power of two in [16, 1024]): lanes stay as numerous as
+  // buckets, the partial-slot array (bucket + lane) stays ~2x the bucket count, and every lane of a wave performs
+  // the same number of mixed additions.
+  uint64_t L = 16;
+  while (L < 1024 && L < (uint64_t)n / p.NB) L <<= 1;
   const char* envL = getenv("CSH_MSM_L");
   if (envL && atoi(envL) > 0) L = (uint64_t)atoi(envL);
   p.L = (uint32_t)L;
-  p.tmax = (uint32_t)(p.NB + n / p.L + 2);
-  p.S = 4096;
-  while (p.S > 64 && (uint64_t)p.S * 8 > p.tmax) p.S >>= 1;  // >= ~8 tasks per segment
+  const uint32_t max_lanes = (uint32_t)((n + L - 1) / L);
+  p.tmax = p.NB + max_lanes + 2;  // partial slots per window: slot = bucket + lane
+  p.S = 64;
+  while (p.S < 8192 && (uint64_t)p.S * 8 < p.NB) p.S <<= 1;  // ~8 buckets per reduction segment
   p.mont = mont;
   {
     uint64_t ch = 512 / (uint64_t)p.W;
@@ -458,25 +507,30 @@ static int msm_windows_dev(const Bases* B, size_t offset, size_t n, const uint64
   const size_t len = (size_t)p.NB + 2;
   Arena& ar = arena_for(st);
   size_t need = 0;
-  need += 3 * Arena::padded(sizeof(uint32_t) * len * p.W);       // hist/cursor, start, tstart
-  need += Arena::padded(sizeof(uint32_t) * MAX_WINDOWS);          // ntasks
+  need += 2 * Arena::padded(sizeof(uint32_t) * len * p.W);       // hist/cursor, start
+  need += Arena::padded(sizeof(uint32_t) * MAX_WINDOWS);          // lanes per window
   need += Arena::padded(sizeof(uint32_t) * n * p.W);              // sorted
   need += Arena::padded(sizeof(uint16_t) * n * p.W);              // digit codes
   need += Arena::padded(sizeof(uint32_t) * (size_t)p.NB * p.CH * p.W);  // per-chunk bucket counts / prefixes
   need += Arena::padded(sizeof(XYZZ<Fq>) * (size_t)p.tmax * p.W); // partials
-  need += Arena::padded(sizeof(uint32_t) * (size_t)p.tmax * p.W); // task buckets
   need += Arena::padded(sizeof(XYZZ<Fq>) * (size_t)p.S * p.W);    // segment results
+  need += Arena::padded(sizeof(XYZZ<Fq>) * (size_t)(p.NB + 1) * p.W);  // dense bucket sums
+  const uint32_t max_giant = (uint32_t)(((uint64_t)max_lanes * p.W) / MERGE_CAP + 1);
+  const uint32_t giant_blocks = max_giant < 1024 ? max_giant : 1024;
+  need += Arena::padded(sizeof(uint32_t) * (2 * (size_t)max_giant + 2));
+  need += Arena::padded(sizeof(XYZZ<Fq>) * 256 * (size_t)giant_blocks);
   CSH_TRY(ar.reserve(need));
   uint32_t* hist = ar.take<uint32_t>(len * p.W);
   uint32_t* start = ar.take<uint32_t>(len * p.W);
-  uint32_t* tstart = ar.take<uint32_t>(len * p.W);
-  uint32_t* ntasks = ar.take<uint32_t>(MAX_WINDOWS);
+  uint32_t* nlanes = ar.take<uint32_t>(MAX_WINDOWS);
   uint32_t* sorted = ar.take<uint32_t>(n * p.W);
   uint16_t* dig = ar.take<uint16_t>(n * p.W);
   uint32_t* blkcnt = ar.take<uint32_t>((size_t)p.NB * p.CH * p.W);
   XYZZ<Fq>* partial = ar.take<XYZZ<Fq>>((size_t)p.tmax * p.W);
-  uint32_t* task_bucket = ar.take<uint32_t>((size_t)p.tmax * p.W);
   XYZZ<Fq>* segres = ar.take<XYZZ<Fq>>((size_t)p.S * p.W);
+  XYZZ<Fq>* dense = ar.take<XYZZ<Fq>>((size_t)(p.NB + 1) * p.W);
+  uint32_t* giant = ar.take<uint32_t>(2 * (size_t)max_giant + 2);  // [0] = count, list from [2]
+  XYZZ<Fq>* giant_tmp = ar.take<XYZZ<Fq>>(256 * (size_t)giant_blocks);
 
   const bool timing = getenv("CSH_MSM_TIMING") != nullptr;
   hipEvent_t ev[7];
@@ -505,34 +559,25 @@ static int msm_windows_dev(const Bases* B, size_t offset, size_t n, const uint64
   hipLaunchKernelGGL(k_msm_hist_lds, dim3(p.CH, p.W), dim3(SORT_BLK), sort_lds, st, p, dig, blkcnt);
   hipLaunchKernelGGL(k_msm_colscan, dim3((p.NB + 255) / 256, p.W), dim3(256), 0, st, p, blkcnt, hist);
   CSH_TRY(mark(1));
-  hipLaunchKernelGGL(k_msm_scan, dim3(p.W), dim3(1024), 0, st, p, hist, start, tstart, ntasks);
+  hipLaunchKernelGGL(k_msm_scan, dim3(p.W), dim3(1024), 0, st, p, hist, start, nlanes);
   CSH_TRY(mark(2));
   hipLaunchKernelGGL(k_msm_scatter_lds, dim3(p.CH, p.W), dim3(SORT_BLK), sort_lds, st, p, dig, start, blkcnt, sorted);
   CSH_TRY(mark(3));
   {
-    static const int variant = [] {
-      const char* e = getenv("CSH_ACC_VARIANT");
-      return e ? atoi(e) : 0;
-    }();
     static const int blk = [] {
       const char* e = getenv("CSH_ACC_BLK");
       const int b = e ? atoi(e) : ACC_BLK;
       return (b == 64 || b == 128) ? b : ACC_BLK;
     }();
-    const dim3 ag((p.tmax + blk - 1) / blk, p.W), ab(blk);
-    int v = 0;
-    if constexpr (Cfg::INLINE_ADD) v = variant;  // tuning variants exist for the 8-limb G1 configuration only
-    if constexpr (!Cfg::INLINE_ADD) {
-      if (variant == 4) hipLaunchKernelGGL((k_msm_accum<Cfg, 4>), ag, ab, 0, st, bases, p, start, tstart, ntasks, sorted, partial, task_bucket);
-      else if (variant == 5) hipLaunchKernelGGL((k_msm_accum<Cfg, 5>), ag, ab, 0, st, bases, p, start, tstart, ntasks, sorted, partial, task_bucket);
-      else hipLaunchKernelGGL((k_msm_accum<Cfg, 0>), ag, ab, 0, st, bases, p, start, tstart, ntasks, sorted, partial, task_bucket);
-    } else if (v == 1) hipLaunchKernelGGL((k_msm_accum<Cfg, 1>), ag, ab, 0, st, bases, p, start, tstart, ntasks, sorted, partial, task_bucket);
-    else if (v == 2) hipLaunchKernelGGL((k_msm_accum<Cfg, 2>), ag, ab, 0, st, bases, p, start, tstart, ntasks, sorted, partial, task_bucket);
-    else if (v == 3) hipLaunchKernelGGL((k_msm_accum<Cfg, 3>), ag, ab, 0, st, bases, p, start, tstart, ntasks, sorted, partial, task_bucket);
-    else hipLaunchKernelGGL((k_msm_accum<Cfg, 0>), ag, ab, 0, st, bases, p, start, tstart, ntasks, sorted, partial, task_bucket);
+    const dim3 ag((max_lanes + blk - 1) / blk, p.W), ab(blk);
+    hipLaunchKernelGGL(k_msm_accum<Cfg>, ag, ab, 0, st, bases, p, start, nlanes, sorted, partial);
   }
   CSH_TRY(mark(4));
-  hipLaunchKernelGGL(k_msm_reduce<Cfg>, dim3((p.S + 63) / 64, p.W), dim3(64), 0, st, p, ntasks, partial, task_bucket, segres);
+  CSH_HIP(hipMemsetAsync(giant, 0, 8, st));
+  hipLaunchKernelGGL(k_msm_merge<Cfg>, dim3((p.NB + 63) / 64, p.W), dim3(64), 0, st, p, start, partial, dense, giant, giant + 2);
+  // buckets with > MERGE_CAP partials (heavily repeated scalars): block-wide tree, grid-stride over the queue
+  hipLaunchKernelGGL(k_msm_merge_giant<Cfg>, dim3(giant_blocks), dim3(256), 0, st, p, start, partial, dense, giant, giant + 2, giant_tmp);
+  hipLaunchKernelGGL(k_msm_reduce<Cfg>, dim3((p.S + 63) / 64, p.W), dim3(64), 0, st, p, dense, segres);
   for (uint32_t half = p.S / 2; half >= 1; half >>= 1)
     hipLaunchKernelGGL(k_msm_fold<Cfg>, dim3((half + 63) / 64, p.W), dim3(64), 0, st, segres, p.S, half);
   hipLaunchKernelGGL(k_msm_gather_windows<Cfg>, dim3(1), dim3(MAX_WINDOWS), 0, st, segres, p.S, p.W, win_out_dev);
