@@ -38,6 +38,10 @@ template <class L>
 CSH_HD_NOINLINE void lazy_mdbl(const L* x, const L* y, XYZZLazy<L>* out) {
   *out = lazy_mdbl_inl<L>(*x, *y);
 }
+template <class L>
+CSH_HD_NOINLINE XYZZLazy<L> lazy_mdbl_v(L x, L y) {  // by value: fine (and faster around the call) for the 9-limb field
+  return lazy_mdbl_inl<L>(x, y);
+}
 
 // acc += (x2, y2); the caller has already excluded the point at infinity. Contract: x2, y2 have limbs in
 // [-2, 2^B + 2] (unpack() output, or neg(..).normalized() for a negated point) -- acc.x / acc.y inherit that bound
@@ -60,7 +64,9 @@ CSH_HD void lazy_madd(XYZZLazy<L>& acc, const L& x2, const L& y2) {
     if (p.is_zero_slow()) {
       if (r.is_zero()) {
         if (y2.is_zero()) acc.empty = true;  // 2-torsion cannot occur on these curves; kept for completeness
-        else {
+        else if constexpr (sizeof(L) <= 40) {
+          acc = lazy_mdbl_v<L>(x2, y2);
+        } else {
           const L tx = x2, ty = y2;  // private copies: the call takes addresses
           XYZZLazy<L> d;
           lazy_mdbl<L>(&tx, &ty, &d);

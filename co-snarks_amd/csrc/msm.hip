@@ -230,6 +230,11 @@ __device__ __attribute__((noinline)) void flush_partial(XYZZ<typename Cfg::Fq>* 
   *dst = lazy_to_xyzz<typename Cfg::L, typename Cfg::Fq>(*acc);
 }
 
+template <class Cfg>
+__device__ __attribute__((noinline)) void flush_partial_v(XYZZ<typename Cfg::Fq>* dst, XYZZLazy<typename Cfg::L> acc) {
+  *dst = lazy_to_xyzz<typename Cfg::L, typename Cfg::Fq>(acc);
+}
+
 // Bucket accumulation. Lane k of window w owns sorted entries [k*L, (k+1)*L): it walks them in bucket order and
 // emits one partial sum per bucket it touches into slot (bucket + k) -- unique and increasing in (bucket, lane), so
 // the partials of one bucket are consecutive slots. A bucket that spans several lanes (skewed scalars, or simply
@@ -264,7 +269,9 @@ __global__ __launch_bounds__(ACC_BLK) void k_msm_accum(const Affine<typename Cfg
         pt_next = bases[e_next & 0x7fffffffu];
       }
       if (pos == next) {                            // crossed into the next non-empty bucket: flush
-        {
+        if constexpr (sizeof(L) <= 40) {
+          flush_partial_v<Cfg>(&pw[b + k], acc);
+        } else {
           const XYZZLazy<L> done = acc;  // private copy: the call takes its address, acc itself stays in registers
           flush_partial<Cfg>(&pw[b + k], &done);
         }
@@ -277,10 +284,7 @@ __global__ __launch_bounds__(ACC_BLK) void k_msm_accum(const Affine<typename Cfg
       if (e >> 31) y = L::neg(y).normalized();  // keep |limb| <= 2^B + 1: lazy_madd subtracts acc.y limb-wise
       lazy_madd(acc, x, y);
     }
-    {
-      const XYZZLazy<L> done = acc;
-      flush_partial<Cfg>(&pw[b + k], &done);
-    }
+    pw[b + k] = lazy_to_xyzz<L, Fq>(acc);  // final run of the lane: exported inline (acc never has its address taken)
   } else {
     XYZZ<Fq> acc = XYZZ<Fq>::inf();
     for (uint32_t pos = lo; pos < hi; ++pos) {
