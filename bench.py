@@ -24,8 +24,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # k_msm_accum HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; see tools/pmc_summary.py).
-# The kernel gathers every 64-byte base once per window (W = 16): 1.07 GB of the 2.68 GB is inherent to Pippenger.
-PMC_TRAFFIC_BYTES = {20: 2682923502}
+# The kernel gathers every 64-byte base once per window (W = 16): 1.07 GB is inherent to Pippenger; the rest is the
+# x2 FETCH_SIZE correction applied to 64-byte gathers (raw counter: 2.0 GB), the sorted-index reads, the partial
+# writes (0.4 GB) and register spill traffic of the rare-path calls.
+PMC_TRAFFIC_BYTES = {20: 4409337024}
 
 
 def secondary_metrics(hip, B, L, C, np, torch, dev, stream):
@@ -200,7 +202,7 @@ def main():
         traffic = PMC_TRAFFIC_BYTES.get(args.log_n)
         roofline = {"bound": "hbm", "kernel": "k_msm_accum<Bn254G1>", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                     "frac": round(achieved / 8000.0, 5), "traffic": traffic,
-                    "traffic_source": "profiles/r01_c_msm_bn254g1_2p20_pmc_hbm_bytes.csv" if traffic else None,
+                    "traffic_source": "profiles/r01_d_msm_bn254g1_2p20_pmc_hbm_bytes.csv" if traffic else None,
                     "note": "MSM is integer-ALU (v_mad_u64_u32) bound, not HBM bound; see DESIGN.md",
                     "stage_ms": {"hist": stage_ms[0], "scan": stage_ms[1], "scatter": stage_ms[2], "accum": stage_ms[3],
                                  "reduce": stage_ms[4], "total_device": stage_ms[5]}}

@@ -13,8 +13,8 @@ timeout 600 python tools/gpu_probe_ntt.py > gpurun_out/probe_ntt.log 2>&1; tail 
 timeout 900 python bench.py > gpurun_out/bench.log 2>&1; tail -2 gpurun_out/bench.log
 R=$PWD
 if [ "${DO_PROF:-1}" = "1" ]; then
-  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof -o msm -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-check > $R/gpurun_out/prof.log 2>&1)
-  (cd /tmp && timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/pmc_fetch -o msm -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-check > $R/gpurun_out/pmc_fetch.log 2>&1)
-  (cd /tmp && timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/gpurun_out/pmc_write -o msm -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-check > $R/gpurun_out/pmc_write.log 2>&1)
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof -o msm -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-check --no-extras > $R/gpurun_out/prof.log 2>&1)
+  (cd /tmp && timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/pmc_fetch -o msm -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-check --no-extras > $R/gpurun_out/pmc_fetch.log 2>&1)
+  (cd /tmp && timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/gpurun_out/pmc_write -o msm -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-check --no-extras > $R/gpurun_out/pmc_write.log 2>&1)
   ls gpurun_out/prof gpurun_out/pmc_fetch gpurun_out/pmc_write
 fi
