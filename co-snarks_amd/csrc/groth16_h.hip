@@ -64,4 +64,25 @@ int csh_groth16_h(csh_domain_t dom, const uint64_t shift[4], int protocol, uint6
   return h.down(h_out, dh, eb);
 }
 
+int csh_groth16_h_rep3_seeded(csh_domain_t dom, const uint64_t shift[4], uint64_t* a, uint64_t* b, const uint8_t seed1[32], uint64_t off1,
+                              const uint8_t seed2[32], uint64_t off2, uint64_t* h_out) {
+  CSH_REQUIRE(dom && shift && a && b && h_out && seed1 && seed2, "NULL argument");
+  const Domain* d = reinterpret_cast<const Domain*>(dom);
+  const size_t n = domain_size_of(d);
+  const csh_curve_t f = domain_curve_of(d);
+  const size_t sb = 64 * n, eb = 32 * n;
+  HostStage h;
+  CSH_TRY(h.begin(2 * Arena::padded(sb) + 3 * Arena::padded(eb)));
+  uint64_t *da, *db, *dmc, *dmab, *dh;
+  CSH_TRY(h.up(da, a, sb));
+  CSH_TRY(h.up(db, b, sb));
+  CSH_TRY(h.up(dmc, nullptr, eb));
+  CSH_TRY(h.up(dmab, nullptr, eb));
+  CSH_TRY(h.up(dh, nullptr, eb));
+  CSH_TRY(csh_rep3_masks_dev(f, seed1, off1, seed2, off2, dmc, n, h.st));
+  CSH_TRY(csh_rep3_masks_dev(f, seed1, off1 + n, seed2, off2 + n, dmab, n, h.st));
+  CSH_TRY(csh_groth16_h_dev(dom, shift, 1, da, db, dmc, dmab, dh, h.st));
+  return h.down(h_out, dh, eb);
+}
+
 }  // extern "C"

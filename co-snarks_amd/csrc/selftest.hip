@@ -9,6 +9,7 @@
 #include "common.hpp"
 #include "curve.hpp"
 #include "curve_lazy.hpp"
+#include "chacha.hpp"
 #include "field29.hpp"
 #include "msm_digits.hpp"
 
@@ -209,6 +210,23 @@ int csh_selftest_lazys_op(int op, const uint64_t a[4], const uint64_t b[4], cons
   Bn254Fq r = L::mul(s, lc).to_fp();
   memcpy(out, &r, 32);
   return s.is_zero() ? 1 : 0;   // also reports the zero test of (a +/- b)
+}
+
+// host execution of the on-device Rep3 mask generator (same template code as k_rep3_masks)
+int csh_selftest_rep3_masks_host(int curve, const uint8_t seed1[32], uint64_t e1, const uint8_t seed2[32], uint64_t e2, uint64_t* out, size_t n) {
+  uint32_t k1[8], k2[8];
+  memcpy(k1, seed1, 32);
+  memcpy(k2, seed2, 32);
+  for (size_t i = 0; i < n; ++i) {
+    if (curve == CSH_BN254) {
+      Bn254Fr v = rep3_mask_element<Bn254Fr>(k1, k2, e1 + i, e2 + i);
+      memcpy(out + 4 * i, &v, 32);
+    } else {
+      Bls381Fr v = rep3_mask_element<Bls381Fr>(k1, k2, e1 + i, e2 + i);
+      memcpy(out + 4 * i, &v, 32);
+    }
+  }
+  return CSH_OK;
 }
 
 // canonical scalar limbs -> signed digits (digits_out[w], w < *W_out)

@@ -3,6 +3,7 @@
 // grid-stride over <= 4096 workgroups of 256 threads. See DESIGN.md section "share-vector kernels".
 #include "common.hpp"
 #include "field.hpp"
+#include "chacha.hpp"
 #include <string.h>
 
 namespace csh {
@@ -50,6 +51,17 @@ template <class F>
 __global__ __launch_bounds__(VB) void k_rep3_to_shamir(const F* __restrict__ in, F x, F y, F* out, size_t n) {
   for (size_t i = blockIdx.x * (size_t)VB + threadIdx.x; i < n; i += (size_t)gridDim.x * VB) {
     out[i] = F::add(F::mul(in[2 * i], x), F::mul(in[2 * i + 1], y));
+  }
+}
+
+// Rep3 correlated masks on the device: out[i] = from_be(stream1 chunk e1+i) - from_be(stream2 chunk e2+i)
+struct ChaChaKeys {
+  uint32_t k1[8], k2[8];
+};
+template <class F>
+__global__ __launch_bounds__(VB) void k_rep3_masks(ChaChaKeys keys, uint64_t e1, uint64_t e2, F* out, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)VB + threadIdx.x; i < n; i += (size_t)gridDim.x * VB) {
+    out[i] = rep3_mask_element<F>(keys.k1, keys.k2, e1 + i, e2 + i);
   }
 }
 
@@ -117,6 +129,16 @@ static int rep3_to_shamir_t(const uint64_t* in, const uint64_t* x, const uint64_
   return CSH_OK;
 }
 template <class F>
+static int rep3_masks_t(const uint8_t* seed1, uint64_t e1, const uint8_t* seed2, uint64_t e2, uint64_t* out, size_t n, hipStream_t st) {
+  if (n == 0) return CSH_OK;
+  ChaChaKeys keys;
+  memcpy(keys.k1, seed1, 32);
+  memcpy(keys.k2, seed2, 32);
+  hipLaunchKernelGGL(k_rep3_masks<F>, dim3(grid_for(n, VB)), dim3(VB), 0, st, keys, e1, e2, (F*)out, n);
+  CSH_HIP(hipGetLastError());
+  return CSH_OK;
+}
+template <class F>
 static int lincomb_t(const uint64_t* const* shares, const uint64_t* coeffs, size_t k, uint64_t* out, size_t n, hipStream_t st) {
   if (n == 0) return CSH_OK;
   LincombArgs<F> args;
@@ -178,6 +200,13 @@ int csh_rep3_to_shamir_vec_dev(csh_curve_t f, const uint64_t* in, const uint64_t
   CSH_TRY(ensure_device());
   hipStream_t st = resolve_stream(stream);
   FR_DISPATCH(f, rep3_to_shamir_t<F>(in, x, y, out, n, st));
+}
+int csh_rep3_masks_dev(csh_curve_t f, const uint8_t seed1[32], uint64_t elem_offset1, const uint8_t seed2[32], uint64_t elem_offset2,
+                       uint64_t* out, size_t n, void* stream) {
+  CSH_REQUIRE(seed1 && seed2 && (out || n == 0), "rep3_masks: NULL argument");
+  CSH_TRY(ensure_device());
+  hipStream_t st = resolve_stream(stream);
+  FR_DISPATCH(f, rep3_masks_t<F>(seed1, elem_offset1, seed2, elem_offset2, out, n, st));
 }
 int csh_lincomb_dev(csh_curve_t f, const uint64_t* const* shares, const uint64_t* coeffs, size_t k, uint64_t* out, size_t n, void* stream) {
   CSH_REQUIRE(k >= 1 && k <= (size_t)MAX_LINCOMB, "lincomb: 1 <= k <= 16");
@@ -247,6 +276,15 @@ int csh_rep3_to_shamir_vec(csh_curve_t f, const uint64_t* in, const uint64_t x[4
   CSH_TRY(h.up(dout, nullptr, eb));
   CSH_TRY(csh_rep3_to_shamir_vec_dev(f, din, x, y, dout, n, h.st));
   return h.down(out, dout, eb);
+}
+int csh_rep3_masks(csh_curve_t f, const uint8_t seed1[32], uint64_t elem_offset1, const uint8_t seed2[32], uint64_t elem_offset2,
+                   uint64_t* out, size_t n) {
+  HostStage h;
+  CSH_TRY(h.begin(Arena::padded(32 * n)));
+  uint64_t* dout;
+  CSH_TRY(h.up(dout, nullptr, 32 * n));
+  CSH_TRY(csh_rep3_masks_dev(f, seed1, elem_offset1, seed2, elem_offset2, dout, n, h.st));
+  return h.down(out, dout, 32 * n);
 }
 int csh_lincomb(csh_curve_t f, const uint64_t* const* shares, const uint64_t* coeffs, size_t k, uint64_t* out, size_t n) {
   CSH_REQUIRE(k >= 1 && k <= (size_t)MAX_LINCOMB, "lincomb: 1 <= k <= 16");

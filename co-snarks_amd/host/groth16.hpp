@@ -113,13 +113,20 @@ struct CircomReduction {
 
     // :135-192 on the device in one call: 6 NTTs, 2 local_mul_vec, 3 coset-table multiplications, 1 subtraction.
     // The two mask vectors are drawn in the reference's order: "c: local_mul_vec" (:160) then "ab" (:182).
-    std::vector<Fr> mask_c = T::masks(state, domain_size);
-    std::vector<Fr> mask_ab = T::masks(state, domain_size);
     std::vector<Fr> h(domain_size);
     Span sp_h("a/b/c: ifft, distribute powers, fft, local_mul_vec, sub (device)");
-    rc = csh_groth16_h(domain, (const uint64_t*)&coset_shift, T::PROTOCOL, (uint64_t*)a.data(), (uint64_t*)b.data(),
-                       mask_c.empty() ? nullptr : (const uint64_t*)mask_c.data(), mask_ab.empty() ? nullptr : (const uint64_t*)mask_ab.data(),
-                       (uint64_t*)h.data());
+    if constexpr (T::DEVICE_MASKS) {
+      // both mask vectors come straight from the party's ChaCha12 keys on the device; the host generators only skip ahead
+      auto run = state.rand.take_device_run(2 * domain_size);
+      rc = csh_groth16_h_rep3_seeded(domain, (const uint64_t*)&coset_shift, (uint64_t*)a.data(), (uint64_t*)b.data(), run.seed1, run.off1,
+                                     run.seed2, run.off2, (uint64_t*)h.data());
+    } else {
+      std::vector<Fr> mask_c = T::masks(state, domain_size);
+      std::vector<Fr> mask_ab = T::masks(state, domain_size);
+      rc = csh_groth16_h(domain, (const uint64_t*)&coset_shift, T::PROTOCOL, (uint64_t*)a.data(), (uint64_t*)b.data(),
+                         mask_c.empty() ? nullptr : (const uint64_t*)mask_c.data(), mask_ab.empty() ? nullptr : (const uint64_t*)mask_ab.data(),
+                         (uint64_t*)h.data());
+    }
     check(rc, "csh_groth16_h");
     return h;
   }

@@ -62,6 +62,25 @@ struct Rep3Rand {
     rng2.fill_bytes(b, 32);
     return {from_be_bytes_mod_order<Fr>(a), from_be_bytes_mod_order<Fr>(b)};
   }
+  // Hand a run of `n` mask elements to the device generator (csh_rep3_masks / csh_groth16_h_rep3_seeded): returns the
+  // chunk offsets of the run in both streams and advances both generators by 32*n bytes, exactly what
+  // masking_field_elements_vec(n) would have consumed.
+  struct DeviceRun {
+    uint8_t seed1[32], seed2[32];
+    uint64_t off1, off2;
+  };
+  DeviceRun take_device_run(size_t n) {
+    DeviceRun r;
+    memcpy(r.seed1, rng1.key, 32);
+    memcpy(r.seed2, rng2.key, 32);
+    const uint64_t p1 = rng1.byte_pos(), p2 = rng2.byte_pos();
+    if (p1 % 32 || p2 % 32) throw Error("Rep3Rand: stream position not aligned to a field-element chunk");
+    r.off1 = p1 / 32;
+    r.off2 = p2 / 32;
+    rng1.seek(p1 + 32 * (uint64_t)n);
+    rng2.seek(p2 + 32 * (uint64_t)n);
+    return r;
+  }
   Rep3Rand fork() {  // rngs.rs:96-100
     uint8_t s1[32], s2[32];
     rng1.fill_bytes(s1, 32);
@@ -98,6 +117,7 @@ struct PlainGroth16Driver {
   using Net = LocalNetwork;
   static constexpr int PROTOCOL = 0;   // csh_groth16_h protocol id
   static constexpr uint32_t NCOMP = 1;
+  static constexpr bool DEVICE_MASKS = false;
 
   static ArithmeticShare rand(const Net*, State&) {  // mpc/plain.rs:23-26
     std::random_device rd;
@@ -151,6 +171,7 @@ struct Rep3Groth16Driver {
   using Net = LocalNetwork;
   static constexpr int PROTOCOL = 1;
   static constexpr uint32_t NCOMP = 2;
+  static constexpr bool DEVICE_MASKS = true;  // masks of the big local_mul_vec calls are generated on the GPU ("next" row f2)
 
   static ArithmeticShare rand(const Net*, State& st) {  // mpc/rep3.rs:27-29 -> arithmetic::rand (arithmetic.rs:357-360)
     auto [a, b] = st.rand.template random_fes<Fr>();
@@ -309,6 +330,7 @@ struct ShamirGroth16Driver {
   using Net = LocalNetwork;
   static constexpr int PROTOCOL = 0;
   static constexpr uint32_t NCOMP = 1;
+  static constexpr bool DEVICE_MASKS = false;
 
   static ArithmeticShare rand(const Net*, State& st) { return st.get_pair().first; }  // ShamirState::rand: the degree-t half of a pair
   static ArithmeticShare evaluate_constraint(int, const std::vector<std::pair<Fr, size_t>>& lhs, const std::vector<Fr>& pub,

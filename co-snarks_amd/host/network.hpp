@@ -114,6 +114,17 @@ struct ChaCha12 {
     ++counter;
     pos = 0;
   }
+  // keystream position in bytes / repositioning (used when a run of the stream is generated on the device instead)
+  uint64_t byte_pos() const { return pos == 64 ? counter * 64 : (counter - 1) * 64 + (uint64_t)pos; }
+  void seek(uint64_t byte_position) {
+    counter = byte_position / 64;
+    pos = 64;
+    const int within = (int)(byte_position % 64);
+    if (within) {
+      block();  // regenerates block `counter`, then counter++
+      pos = within;
+    }
+  }
   void fill_bytes(uint8_t* out, size_t n) {
     while (n) {
       if (pos == 64) block();

@@ -150,6 +150,16 @@ int csh_rep3_to_shamir_vec(csh_curve_t field_of, const uint64_t* in_ab, const ui
 int csh_lincomb(csh_curve_t field_of, const uint64_t* const* shares, const uint64_t* coeffs /* k*4 */,
                 size_t k, uint64_t* out, size_t n);
 
+/* Rep3 correlated masks generated on the device ("next" row f2): out[i] = from_be_bytes_mod_order(a_i) -
+ * from_be_bytes_mod_order(b_i), a_i / b_i = the 32-byte chunks number elem_offset{1,2} + i of the ChaCha12 keystreams
+ * of seed1 (own key) and seed2 (previous party's key): byte-compatible with Rep3Rand::masking_field_elements_vec
+ * (mpc-core/src/protocols/rep3/rngs.rs:137-156; RngType = rand_chacha::ChaCha12Rng, mpc-core/src/lib.rs:13), so the
+ * three parties' masks still cancel. The caller advances its two generators by 32*n bytes. */
+int csh_rep3_masks(csh_curve_t field_of, const uint8_t seed1[32], uint64_t elem_offset1, const uint8_t seed2[32],
+                   uint64_t elem_offset2, uint64_t* out, size_t n);
+int csh_rep3_masks_dev(csh_curve_t field_of, const uint8_t seed1[32], uint64_t elem_offset1, const uint8_t seed2[32],
+                       uint64_t elem_offset2, uint64_t* out_dev, size_t n, void* stream);
+
 int csh_vec_mul_dev(csh_curve_t field_of, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream);
 int csh_vec_add_dev(csh_curve_t field_of, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, uint32_t ncomp, void* stream);
 int csh_vec_sub_dev(csh_curve_t field_of, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, uint32_t ncomp, void* stream);
@@ -171,6 +181,11 @@ int csh_groth16_h(csh_domain_t dom, const uint64_t shift[4], int protocol, uint6
                   const uint64_t* mask_c, const uint64_t* mask_ab, uint64_t* h_out);
 int csh_groth16_h_dev(csh_domain_t dom, const uint64_t shift[4], int protocol, uint64_t* a_dev, uint64_t* b_dev,
                       const uint64_t* mask_c_dev, const uint64_t* mask_ab_dev, uint64_t* h_out_dev, void* stream);
+/* Rep3 variant with the two mask vectors generated on the device from the party's ChaCha12 keys: mask_c = chunks
+ * [off, off+n), mask_ab = chunks [off+n, off+2n) of each stream (the order of the two local_mul_vec calls,
+ * reduction.rs:160 then :182). Host pointers for a, b, h. */
+int csh_groth16_h_rep3_seeded(csh_domain_t dom, const uint64_t shift[4], uint64_t* a, uint64_t* b, const uint8_t seed1[32],
+                              uint64_t elem_offset1, const uint8_t seed2[32], uint64_t elem_offset2, uint64_t* h_out);
 
 /* ---- measurement hooks (bench.py / profiles) ----------------------------------------------------------
  * HIP-event timing on the stream the kernels are launched on. */

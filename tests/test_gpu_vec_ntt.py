@@ -149,3 +149,25 @@ def test_ntt_roundtrip_and_spot_checks_full_size(gpu, logn):
             acc = (acc + cs[ntt.bitrev(i, logn)] * cur) % F.p
             cur = cur * wk % F.p
         assert acc == vals[k]
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_rep3_masks_on_device(gpu, curve):
+    """csh_rep3_masks == Rep3Rand::masking_field_elements_vec (rngs.rs:137-156) and the three parties' masks cancel."""
+    import ctypes as C
+    from oracle import chacha
+    F = H.FR[curve]
+    cid = H.CURVE_IDS[curve]
+    keys = [bytes([k + 1] * 32) for k in range(3)]
+    n = 1000
+    outs = []
+    for p in range(3):                      # party p: rng1 = own key, rng2 = previous party's key
+        out = np.zeros(4 * n, dtype=np.uint64)
+        gpu.bindings._check(gpu.lib().csh_rep3_masks(cid, keys[p], C.c_uint64(5), keys[(p + 2) % 3], C.c_uint64(5),
+                                                      out.ctypes.data_as(C.c_void_p), C.c_size_t(n)))
+        a = chacha.keystream(keys[p], 32 * n, start_byte=160)
+        b = chacha.keystream(keys[(p + 2) % 3], 32 * n, start_byte=160)
+        vals = H.unpack(F, out)
+        assert vals == mpc.masks_from_streams(F, a, b, n)
+        outs.append(vals)
+    assert all((x + y + z) % F.p == 0 for x, y, z in zip(*outs))

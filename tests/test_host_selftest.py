@@ -209,3 +209,19 @@ def test_lazy_bucket_accumulation_matches_group_law(hip, curve, group):
                                                       C.c_size_t(len(seq)), out.ctypes.data_as(C.c_void_p)) == 0
         got = _xyzz_to_affine(hip, cid, group, G, out)
         assert G.eq(got, want)
+
+
+@pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
+def test_rep3_mask_generator_matches_rngs_rs(hip, curve):
+    """The device mask generator's code (run on the host) vs mpc-core/src/protocols/rep3/rngs.rs:137-156 restated:
+    two ChaCha12 keystreams, 32-byte chunks, from_be_bytes_mod_order(a) - from_be_bytes_mod_order(b)."""
+    from oracle import chacha, mpc
+    F = H.FR[curve]
+    s1, s2 = bytes([1] * 32), bytes([2] * 32)        # the fixed seeds of the reference's determinism test (rngs.rs:331-360)
+    for (e1, e2, n) in [(0, 0, 9), (1, 4, 8), (1000001, 77, 5)]:
+        out = np.zeros(4 * n, dtype=np.uint64)
+        assert hip.lib().csh_selftest_rep3_masks_host(H.CURVE_IDS[curve], s1, C.c_uint64(e1), s2, C.c_uint64(e2),
+                                                     out.ctypes.data_as(C.c_void_p), C.c_size_t(n)) == 0
+        a = chacha.keystream(s1, 32 * n, start_byte=32 * e1)
+        b = chacha.keystream(s2, 32 * n, start_byte=32 * e2)
+        assert H.unpack(F, out) == mpc.masks_from_streams(F, a, b, n)

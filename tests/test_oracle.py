@@ -70,6 +70,16 @@ def test_bn254_fr_known_answer_products():
     assert H.unpack(F, got) == [x * y % F.p]
 
 
+def test_chacha_core_rfc7539_vector():
+    """Pins oracle/chacha.py: RFC 7539 section 2.3.2 ChaCha20 block (same state layout as rand_chacha when the stream id
+    words are zero); the Rep3 masks use the 12-round variant of the same core."""
+    from oracle import chacha
+    key = bytes(range(32))
+    blk = chacha.block(key, 1 | (0x09000000 << 32), rounds=20, nonce_words=(0x4A000000, 0))
+    assert blk[:16].hex() == "10f1e7e4d13b5915500fdd1fa32071c4"
+    assert chacha.keystream(key, 100, start_byte=30) == (chacha.block(key, 0) + chacha.block(key, 1) + chacha.block(key, 2))[30:130]
+
+
 def test_snarkjs_roots_match_survey_values():
     q, roots = ntt.roots_of_unity(fl.BN254_FR)
     assert q == 5 and ntt.roots_of_unity(fl.BLS381_FR)[0] == 5
