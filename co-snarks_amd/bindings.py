@@ -355,3 +355,43 @@ class Event:
                 lib().csh_event_destroy(self.h)
         except Exception:
             pass
+
+
+class Matrix:
+    """Device-resident CSR constraint-matrix side (csh_matrix_upload)."""
+
+    def __init__(self, curve: int, rows):
+        """rows: list of rows, each a list of (coeff_limbs (4 u64, Montgomery), column index)."""
+        self.curve = curve
+        row_ptr = np.zeros(len(rows) + 1, dtype=np.uint64)
+        cols, vals = [], []
+        for i, r in enumerate(rows):
+            for c, idx in r:
+                cols.append(idx)
+                vals.append(np.asarray(c, dtype=np.uint64))
+            row_ptr[i + 1] = len(cols)
+        col = np.asarray(cols, dtype=np.uint32)
+        val = np.concatenate(vals).astype(np.uint64) if vals else np.zeros(0, dtype=np.uint64)
+        self.n_rows = len(rows)
+        self.h = C.c_void_p()
+        _check(lib().csh_matrix_upload(curve, _p(row_ptr), _p(col), _p(val), C.c_size_t(len(rows)), C.c_size_t(len(cols)), C.byref(self.h)))
+
+    def evaluate(self, protocol: int, party: int, public, witness, n_out: int):
+        pub, wit = _u64(public), _u64(witness)
+        comp = 2 if protocol == 1 else 1
+        dp, dw = DeviceBuffer.from_host(pub), DeviceBuffer.from_host(wit if wit.size else np.zeros(4, dtype=np.uint64))
+        out = DeviceBuffer(n_out * comp * 32)
+        _check(lib().csh_evaluate_constraints_dev(self.h, protocol, party, dp.ptr, C.c_size_t(pub.size // 4), dw.ptr, out.ptr, C.c_size_t(n_out), None))
+        sync()
+        return out.to_host()
+
+    def free(self):
+        if self.h:
+            lib().csh_matrix_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -1,0 +1,185 @@
+// Sparse constraint evaluation (CSR rows x (public || witness)) on gfx950 and the fully device-resident
+// CircomReduction::witness_map_from_matrices (co-circom/co-groth16/src/groth16/reduction.rs:77-193).
+// One lane per constraint row (circom rows hold a handful of terms); gathers are 32/64-byte reads through L2.
+#include <string.h>
+
+#include "common.hpp"
+#include "field.hpp"
+
+namespace csh {
+
+struct Matrix {
+  csh_curve_t curve;
+  size_t n_rows, nnz;
+  uint64_t* row_ptr;  // device, n_rows + 1
+  uint32_t* col_idx;  // device, nnz
+  void* coeffs;       // device, nnz Montgomery elements
+};
+
+// protocol 0: out[row] = sum c * v ; protocol 1 (Rep3): out[row] = {sum c * v.a (+ public on party 0), sum c * v.b (+ public on party 1)}
+template <class F, int PROTOCOL>
+__global__ __launch_bounds__(256) void k_eval_rows(const uint64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col_idx,
+                                                   const F* __restrict__ coeffs, size_t n_rows, const F* __restrict__ pub, size_t n_public,
+                                                   const F* __restrict__ wit, int party, F* out, size_t n_out) {
+  for (size_t row = blockIdx.x * (size_t)256 + threadIdx.x; row < n_out; row += (size_t)gridDim.x * 256) {
+    F acc_a = F::zero(), acc_b = F::zero();
+    if (row < n_rows) {
+      const uint64_t lo = row_ptr[row], hi = row_ptr[row + 1];
+      for (uint64_t e = lo; e < hi; ++e) {
+        const uint32_t col = col_idx[e];
+        const F c = coeffs[e];
+        if (col < n_public) {
+          const F m = F::mul(pub[col], c);
+          if (PROTOCOL == 0 || party == 0) acc_a = F::add(acc_a, m);
+          else if (party == 1) acc_b = F::add(acc_b, m);
+        } else {
+          const size_t w = col - n_public;
+          if (PROTOCOL == 0) {
+            acc_a = F::add(acc_a, F::mul(wit[w], c));
+          } else {
+            acc_a = F::add(acc_a, F::mul(wit[2 * w], c));
+            acc_b = F::add(acc_b, F::mul(wit[2 * w + 1], c));
+          }
+        }
+      }
+    }
+    if (PROTOCOL == 0) {
+      out[row] = acc_a;
+    } else {
+      out[2 * row] = acc_a;
+      out[2 * row + 1] = acc_b;
+    }
+  }
+}
+
+// a[num_constraints + i] = promote_to_trivial_share(public[i]) (reduction.rs:111-113; rep3 types.rs:69-82)
+template <class F, int PROTOCOL>
+__global__ void k_promote_publics(F* a, size_t num_constraints, const F* __restrict__ pub, size_t n_public, int party) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n_public) return;
+  if (PROTOCOL == 0) {
+    a[num_constraints + i] = pub[i];
+  } else {
+    a[2 * (num_constraints + i)] = party == 0 ? pub[i] : F::zero();
+    a[2 * (num_constraints + i) + 1] = party == 1 ? pub[i] : F::zero();
+  }
+}
+
+template <class F>
+static int eval_t(const Matrix* m, int protocol, int party, const uint64_t* pub, size_t n_public, const uint64_t* wit, uint64_t* out, size_t n_out,
+                  hipStream_t st) {
+  if (n_out == 0) return CSH_OK;
+  const dim3 g(grid_for(n_out, 256)), b(256);
+  if (protocol == 0)
+    hipLaunchKernelGGL((k_eval_rows<F, 0>), g, b, 0, st, m->row_ptr, m->col_idx, (const F*)m->coeffs, m->n_rows, (const F*)pub, n_public,
+                       (const F*)wit, party, (F*)out, n_out);
+  else
+    hipLaunchKernelGGL((k_eval_rows<F, 1>), g, b, 0, st, m->row_ptr, m->col_idx, (const F*)m->coeffs, m->n_rows, (const F*)pub, n_public,
+                       (const F*)wit, party, (F*)out, n_out);
+  CSH_HIP(hipGetLastError());
+  return CSH_OK;
+}
+
+template <class F>
+static int promote_t(int protocol, uint64_t* a, size_t num_constraints, const uint64_t* pub, size_t n_public, int party, hipStream_t st) {
+  if (n_public == 0) return CSH_OK;
+  const dim3 g((unsigned)((n_public + 63) / 64)), b(64);
+  if (protocol == 0)
+    hipLaunchKernelGGL((k_promote_publics<F, 0>), g, b, 0, st, (F*)a, num_constraints, (const F*)pub, n_public, party);
+  else
+    hipLaunchKernelGGL((k_promote_publics<F, 1>), g, b, 0, st, (F*)a, num_constraints, (const F*)pub, n_public, party);
+  CSH_HIP(hipGetLastError());
+  return CSH_OK;
+}
+
+}  // namespace csh
+
+using namespace csh;
+
+extern "C" {
+
+int csh_matrix_upload(csh_curve_t field_of, const uint64_t* row_ptr, const uint32_t* col_idx, const uint64_t* coeffs, size_t n_rows, size_t nnz,
+                      csh_matrix_t* out) {
+  CSH_REQUIRE(out && row_ptr && (nnz == 0 || (col_idx && coeffs)), "matrix_upload: NULL argument");
+  CSH_REQUIRE(field_of == CSH_BN254 || field_of == CSH_BLS12_381, "unknown curve");
+  CSH_REQUIRE(row_ptr[n_rows] == nnz, "matrix_upload: row_ptr[n_rows] != nnz");
+  CSH_TRY(ensure_device());
+  Matrix* m = new Matrix();
+  m->curve = field_of;
+  m->n_rows = n_rows;
+  m->nnz = nnz;
+  m->row_ptr = nullptr;
+  m->col_idx = nullptr;
+  m->coeffs = nullptr;
+  hipError_t e1 = hipMalloc((void**)&m->row_ptr, (n_rows + 1) * 8);
+  hipError_t e2 = hipMalloc((void**)&m->col_idx, (nnz ? nnz : 1) * 4);
+  hipError_t e3 = hipMalloc(&m->coeffs, (nnz ? nnz : 1) * 32);
+  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
+    csh_matrix_free(reinterpret_cast<csh_matrix_t>(m));
+    set_error("matrix_upload: hipMalloc failed");
+    return CSH_ERR_OOM;
+  }
+  CSH_HIP(hipMemcpy(m->row_ptr, row_ptr, (n_rows + 1) * 8, hipMemcpyHostToDevice));
+  if (nnz) {
+    CSH_HIP(hipMemcpy(m->col_idx, col_idx, nnz * 4, hipMemcpyHostToDevice));
+    CSH_HIP(hipMemcpy(m->coeffs, coeffs, nnz * 32, hipMemcpyHostToDevice));
+  }
+  *out = reinterpret_cast<csh_matrix_t>(m);
+  return CSH_OK;
+}
+
+int csh_matrix_free(csh_matrix_t mm) {
+  if (!mm) return CSH_OK;
+  Matrix* m = reinterpret_cast<Matrix*>(mm);
+  if (m->row_ptr) (void)hipFree(m->row_ptr);
+  if (m->col_idx) (void)hipFree(m->col_idx);
+  if (m->coeffs) (void)hipFree(m->coeffs);
+  delete m;
+  return CSH_OK;
+}
+
+int csh_evaluate_constraints_dev(csh_matrix_t mm, int protocol, int party_id, const uint64_t* public_dev, size_t n_public,
+                                 const uint64_t* witness_dev, uint64_t* out_dev, size_t n_out, void* stream) {
+  CSH_REQUIRE(mm && out_dev, "evaluate_constraints: NULL argument");
+  CSH_REQUIRE(protocol == 0 || protocol == 1, "protocol must be 0 (plain/Shamir) or 1 (Rep3)");
+  CSH_TRY(ensure_device());
+  Matrix* m = reinterpret_cast<Matrix*>(mm);
+  hipStream_t st = resolve_stream(stream);
+  if (m->curve == CSH_BN254) return eval_t<Bn254Fr>(m, protocol, party_id, public_dev, n_public, witness_dev, out_dev, n_out, st);
+  return eval_t<Bls381Fr>(m, protocol, party_id, public_dev, n_public, witness_dev, out_dev, n_out, st);
+}
+
+int csh_groth16_witness_map(csh_domain_t dom, const uint64_t shift[4], int protocol, int party_id, csh_matrix_t ma, csh_matrix_t mb,
+                            size_t num_constraints, const uint64_t* public_inputs, size_t n_public, const uint64_t* witness, size_t n_witness,
+                            const uint8_t seed1[32], uint64_t off1, const uint8_t seed2[32], uint64_t off2, uint64_t* h_out) {
+  CSH_REQUIRE(dom && shift && ma && mb && h_out && (public_inputs || n_public == 0) && (witness || n_witness == 0), "witness_map: NULL argument");
+  CSH_REQUIRE(protocol == 0 || protocol == 1, "protocol must be 0 (plain/Shamir) or 1 (Rep3)");
+  const Domain* d = reinterpret_cast<const Domain*>(dom);
+  const size_t n = domain_size_of(d);
+  const csh_curve_t f = domain_curve_of(d);
+  CSH_REQUIRE(num_constraints + n_public <= n, "Polynomial Degree too large");
+  const size_t comp = protocol == 1 ? 2 : 1;
+  const size_t sb = 32 * n * comp, eb = 32 * n;
+  HostStage h;
+  CSH_TRY(h.begin(2 * Arena::padded(sb) + 3 * Arena::padded(eb) + Arena::padded(32 * n_public) + Arena::padded(32 * comp * n_witness)));
+  uint64_t *da, *db, *dmc = nullptr, *dmab = nullptr, *dh, *dpub, *dwit;
+  CSH_TRY(h.up(da, nullptr, sb));
+  CSH_TRY(h.up(db, nullptr, sb));
+  CSH_TRY(h.up(dh, nullptr, eb));
+  CSH_TRY(h.up(dpub, public_inputs, 32 * n_public));
+  CSH_TRY(h.up(dwit, witness, 32 * comp * n_witness));
+  CSH_TRY(csh_evaluate_constraints_dev(ma, protocol, party_id, dpub, n_public, dwit, da, n, h.st));   // reduction.rs:102-110
+  CSH_TRY(csh_evaluate_constraints_dev(mb, protocol, party_id, dpub, n_public, dwit, db, n, h.st));   // :118-127
+  if (f == CSH_BN254) CSH_TRY(promote_t<Bn254Fr>(protocol, da, num_constraints, dpub, n_public, party_id, h.st));  // :111-113
+  else CSH_TRY(promote_t<Bls381Fr>(protocol, da, num_constraints, dpub, n_public, party_id, h.st));
+  if (protocol == 1 && seed1 && seed2) {
+    CSH_TRY(h.up(dmc, nullptr, eb));
+    CSH_TRY(h.up(dmab, nullptr, eb));
+    CSH_TRY(csh_rep3_masks_dev(f, seed1, off1, seed2, off2, dmc, n, h.st));
+    CSH_TRY(csh_rep3_masks_dev(f, seed1, off1 + n, seed2, off2 + n, dmab, n, h.st));
+  }
+  CSH_TRY(csh_groth16_h_dev(dom, shift, protocol, da, db, dmc, dmab, dh, h.st));
+  return h.down(h_out, dh, eb);
+}
+
+}  // extern "C"

@@ -288,6 +288,7 @@ int bench_synth_t(int log_domain, int iters, double* out_ms, int* check_ok, cons
     m.a[j].push_back({one, j + 1});
     m.b[j].push_back({one, j + 2});
   }
+  m.upload();
   std::vector<Fr> w(n_vars);
   w[0] = one;
   w[1] = Fr::from_u64(3);

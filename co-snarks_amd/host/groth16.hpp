@@ -95,6 +95,23 @@ struct CircomReduction {
     delete sp_dom;
     check(rc, "csh_domain_create");
     const int id = state.id;
+    if (matrices.a_dev && matrices.b_dev && !getenv("COG16_HOST_EVAL")) {
+      // "next" row f3: rows evaluated on the device, only the witness shares cross PCIe (reduction.rs:99-192 in one call)
+      Span sp_dev("evaluate constraints + a/b/c pipeline (device)");
+      std::vector<Fr> hd(domain_size);
+      if constexpr (T::DEVICE_MASKS) {
+        auto run = state.rand.take_device_run(2 * domain_size);
+        rc = csh_groth16_witness_map(domain, (const uint64_t*)&coset_shift, T::PROTOCOL, id, matrices.a_dev, matrices.b_dev, num_constraints,
+                                     (const uint64_t*)public_inputs.data(), num_inputs, (const uint64_t*)private_witness.data(),
+                                     private_witness.size(), run.seed1, run.off1, run.seed2, run.off2, (uint64_t*)hd.data());
+      } else {
+        rc = csh_groth16_witness_map(domain, (const uint64_t*)&coset_shift, T::PROTOCOL, id, matrices.a_dev, matrices.b_dev, num_constraints,
+                                     (const uint64_t*)public_inputs.data(), num_inputs, (const uint64_t*)private_witness.data(),
+                                     private_witness.size(), nullptr, 0, nullptr, 0, (uint64_t*)hd.data());
+      }
+      check(rc, "csh_groth16_witness_map");
+      return hd;
+    }
     Span* sp_eval = new Span("evaluate constraints");
 
     // :99-130 evaluate constraints (sparse rows on the host; "next" row f3 moves this to the device)

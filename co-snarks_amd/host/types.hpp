@@ -169,6 +169,32 @@ struct ConstraintMatrices {
   size_t num_witness_variables = 0;
   size_t num_constraints = 0;
   std::vector<std::vector<std::pair<typename P::Fr, size_t>>> a, b;
+  // device-resident CSR copies (uploaded once per circuit) for the on-device constraint evaluation
+  csh_matrix_t a_dev = nullptr, b_dev = nullptr;
+  void upload() {
+    auto up = [&](const std::vector<std::vector<std::pair<typename P::Fr, size_t>>>& m, csh_matrix_t* out) {
+      std::vector<uint64_t> row_ptr(m.size() + 1, 0);
+      std::vector<uint32_t> col;
+      std::vector<typename P::Fr> val;
+      for (size_t i = 0; i < m.size(); ++i) {
+        for (auto& [c, idx] : m[i]) {
+          col.push_back((uint32_t)idx);
+          val.push_back(c);
+        }
+        row_ptr[i + 1] = col.size();
+      }
+      check(csh_matrix_upload(P::ID, row_ptr.data(), col.data(), (const uint64_t*)val.data(), m.size(), col.size(), out), "csh_matrix_upload");
+    };
+    up(a, &a_dev);
+    up(b, &b_dev);
+  }
+  ConstraintMatrices() = default;
+  ConstraintMatrices(const ConstraintMatrices&) = delete;
+  ConstraintMatrices& operator=(const ConstraintMatrices&) = delete;
+  ~ConstraintMatrices() {
+    if (a_dev) csh_matrix_free(a_dev);
+    if (b_dev) csh_matrix_free(b_dev);
+  }
 };
 
 template <class P>

@@ -128,6 +128,7 @@ void parse_zkey(const uint8_t* d, size_t n, ProvingKey<P>& pk, ConstraintMatrice
     pk.l_query.upload(P::ID, CSH_G1);
     pk.h_query.upload(P::ID, CSH_G1);
     pk.b_g2_query.upload(P::ID, CSH_G2);
+    m.upload();
   }
 }
 

@@ -187,6 +187,29 @@ int csh_groth16_h_dev(csh_domain_t dom, const uint64_t shift[4], int protocol, u
 int csh_groth16_h_rep3_seeded(csh_domain_t dom, const uint64_t shift[4], uint64_t* a, uint64_t* b, const uint8_t seed1[32],
                               uint64_t elem_offset1, const uint8_t seed2[32], uint64_t elem_offset2, uint64_t* h_out);
 
+/* ---- sparse constraint evaluation on the device ("next" row f3) ------------------------------------------------
+ * Replaces evaluate_constraint over a ConstraintMatrices side (reduction.rs:196-210) + the driver row kernels
+ * (mpc/plain.rs:28-43, mpc/rep3.rs:31-49, mpc/shamir.rs:29-49). The matrix (CSR: row_ptr[n_rows+1], col_idx[nnz],
+ * Montgomery coeffs[nnz]) is uploaded once per circuit. values = public_inputs || private_witness by column index.
+ * protocol 0: plain / Shamir (1 component per value; public terms are added to every share);
+ * protocol 1: Rep3 (witness entries are {a, b}; a public term coeff*pub goes to component a on party 0, to component
+ *             b on party 1, nowhere on party 2 -- rep3/arithmetic.rs:52-58).
+ * out has n_out entries (ncomp components each); rows >= n_rows are zero (the resize to domain_size). */
+typedef struct csh_matrix_s* csh_matrix_t;
+int csh_matrix_upload(csh_curve_t field_of, const uint64_t* row_ptr, const uint32_t* col_idx, const uint64_t* coeffs,
+                      size_t n_rows, size_t nnz, csh_matrix_t* out);
+int csh_matrix_free(csh_matrix_t m);
+int csh_evaluate_constraints_dev(csh_matrix_t m, int protocol, int party_id, const uint64_t* public_dev, size_t n_public,
+                                 const uint64_t* witness_dev, uint64_t* out_dev, size_t n_out, void* stream);
+/* witness_map_from_matrices of CircomReduction (reduction.rs:77-193) entirely on the device: evaluate A and B rows,
+ * overwrite the public-input slots a[num_constraints .. +n_public] with the promoted public inputs (:111-113), then the
+ * fused pipeline of csh_groth16_h. Host pointers; witness = n_witness entries (1 or 2 components). For protocol 1 the
+ * masks come from the ChaCha12 seeds as in csh_groth16_h_rep3_seeded (seed pointers may be NULL for zero masks). */
+int csh_groth16_witness_map(csh_domain_t dom, const uint64_t shift[4], int protocol, int party_id, csh_matrix_t a, csh_matrix_t b,
+                            size_t num_constraints, const uint64_t* public_inputs, size_t n_public, const uint64_t* witness,
+                            size_t n_witness, const uint8_t seed1[32], uint64_t elem_offset1, const uint8_t seed2[32],
+                            uint64_t elem_offset2, uint64_t* h_out);
+
 /* ---- measurement hooks (bench.py / profiles) ----------------------------------------------------------
  * HIP-event timing on the stream the kernels are launched on. */
 int csh_event_create(void** ev);

@@ -171,3 +171,30 @@ def test_rep3_masks_on_device(gpu, curve):
         assert vals == mpc.masks_from_streams(F, a, b, n)
         outs.append(vals)
     assert all((x + y + z) % F.p == 0 for x, y, z in zip(*outs))
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_sparse_constraint_evaluation_on_device(gpu, curve):
+    """csh_evaluate_constraints_dev vs the driver row kernels restated in the oracle (mpc/plain.rs:28-43,
+    mpc/rep3.rs:31-49): plain and the three Rep3 parties, ragged rows, empty rows, zero-padded tail."""
+    from oracle import groth16 as og
+    F = H.FR[curve]
+    cid = H.CURVE_IDS[curve]
+    r = H.rng(41)
+    n_pub, n_wit, n_rows, n_out = 3, 40, 50, 64
+    rows = []
+    for i in range(n_rows):
+        k = 0 if i % 7 == 3 else r.randrange(1, 6)
+        rows.append([(r.randrange(F.p), r.randrange(n_pub + n_wit)) for _ in range(k)])
+    pub = [1] + H.rand_elems(F, n_pub - 1, r)
+    wit = H.rand_elems(F, n_wit, r)
+    M = gpu.bindings.Matrix(cid, [[(H.pack(F, [c]), idx) for c, idx in row] for row in rows])
+    drv = og.PlainDriver(F)
+    want = [drv.eval_row(row, pub, wit) for row in rows] + [0] * (n_out - n_rows)
+    assert H.unpack(F, M.evaluate(0, 0, H.pack(F, pub), H.pack(F, wit), n_out)) == want
+    shares = mpc.rep3_share_vec(F, wit, lambda: r.randrange(F.p))
+    for party in range(3):
+        d3 = og.Rep3Driver(F, party)
+        want3 = [d3.eval_row(row, pub, shares[party]) for row in rows] + [(0, 0)] * (n_out - n_rows)
+        got = H.unpack_shares(F, M.evaluate(1, party, H.pack(F, pub), H.pack_shares(F, shares[party]), n_out))
+        assert got == want3
