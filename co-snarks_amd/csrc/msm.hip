@@ -23,6 +23,7 @@
 #include "curve.hpp"
 #include "curve_lazy.hpp"
 #include "msm_digits.hpp"
+#include "msm_sort.hpp"
 
 namespace csh {
 
@@ -42,18 +43,7 @@ struct Bases {
   void* points;  // packed Affine<Fq>[n] on the device
 };
 
-struct MsmParams {
-  uint32_t n;
-  int c;        // window bits
-  int W;        // windows
-  uint32_t NB;  // buckets per window = 2^(c-1), bucket ids 1..NB
-  uint32_t L;   // max entries per task
-  uint32_t tmax;  // task slots per window
-  uint32_t S;     // reduce segments per window (power of two)
-  int mont;
-  uint32_t CH;         // point chunks per window in the LDS counting sort
-  uint32_t chunk_len;  // points per chunk
-};
+// MsmParams, the digit-code constants and the sort stage live in msm_sort.hpp / msm_sort.hip
 
 constexpr int MSM_BLK = 256;
 constexpr int ACC_BLK = 128;
@@ -67,9 +57,6 @@ __device__ __forceinline__ void load_scalar(const Fr* __restrict__ scalars, size
   for (int k = 0; k < Fr::N; ++k) s[k] = v.l[k];
 }
 
-// Digit code (one u16 per point and window): bits 0..14 = bucket-1, bit 15 = negative; 0xFFFF = zero digit.
-constexpr uint32_t DIG_ZERO = 0xFFFFu;
-constexpr int SORT_BLK = 1024;
 
 template <class Fr>
 __global__ __launch_bounds__(MSM_BLK) void k_msm_digits(const Fr* __restrict__ scalars, MsmParams p, uint16_t* __restrict__ dig) {
@@ -85,135 +72,6 @@ __global__ __launch_bounds__(MSM_BLK) void k_msm_digits(const Fr* __restrict__ s
     for (; next < p.W; ++next) dig[(size_t)next * p.n + i] = (uint16_t)DIG_ZERO;
   }
 }
-
-// Wave-aggregated LDS counter increment: returns this lane's slot in counter[b] (old value + rank).
-// Lanes that share the wave leader's bucket are peeled off with one atomic per group (up to 4 rounds), so a
-// skewed digit distribution (top window, 0/1-heavy witnesses) does not serialise on one LDS address.
-__device__ __forceinline__ uint32_t lds_slot(uint32_t* counter, uint32_t b, bool valid) {
-  uint32_t slot = 0;
-  bool todo = valid;
-  for (int round = 0; round < 4; ++round) {
-    const unsigned long long act = __ballot(todo);
-    if (!act) return slot;
-    const int leader = __ffsll((long long)act) - 1;
-    const uint32_t lb = (uint32_t)__shfl((int)b, leader);
-    const unsigned long long grp = __ballot(todo && b == lb);
-    const int cnt = __popcll(grp);
-    if (cnt < 8) break;  // wave-uniform: not worth peeling, fall through to per-lane atomics
-    uint32_t base = 0;
-    const int lane = threadIdx.x & 63;
-    if (lane == leader) base = atomicAdd(&counter[lb], (uint32_t)cnt);
-    base = (uint32_t)__shfl((int)base, leader);
-    if (todo && b == lb) {
-      slot = base + (uint32_t)__popcll(grp & ((1ull << lane) - 1ull));
-      todo = false;
-    }
-  }
-  if (todo) slot = atomicAdd(&counter[b], 1u);
-  return slot;
-}
-
-// Block (chunk ch, window w): LDS histogram of the chunk's digits -> blkcnt[w][ch][0..NB)
-__global__ __launch_bounds__(SORT_BLK) void k_msm_hist_lds(MsmParams p, const uint16_t* __restrict__ dig, uint32_t* __restrict__ blkcnt) {
-  extern __shared__ uint32_t lds_cnt[];
-  const uint32_t ch = blockIdx.x, w = blockIdx.y;
-  for (uint32_t b = threadIdx.x; b < p.NB; b += SORT_BLK) lds_cnt[b] = 0;
-  __syncthreads();
-  const size_t lo = (size_t)ch * p.chunk_len;
-  size_t hi = lo + p.chunk_len;
-  if (hi > p.n) hi = p.n;
-  const uint16_t* d = dig + (size_t)w * p.n;
-  for (size_t i0 = lo; i0 < hi; i0 += SORT_BLK) {
-    const size_t i = i0 + threadIdx.x;
-    uint32_t code = DIG_ZERO;
-    if (i < hi) code = d[i];
-    (void)lds_slot(lds_cnt, code & 0x7fffu, code != DIG_ZERO);
-  }
-  __syncthreads();
-  uint32_t* out = blkcnt + ((size_t)w * p.CH + ch) * p.NB;
-  for (uint32_t b = threadIdx.x; b < p.NB; b += SORT_BLK) out[b] = lds_cnt[b];
-}
-
-// Per (window, bucket): exclusive prefix over chunks (in place) and the bucket total -> hist[w][b+1]
-__global__ __launch_bounds__(256) void k_msm_colscan(MsmParams p, uint32_t* __restrict__ blkcnt, uint32_t* __restrict__ hist) {
-  const uint32_t w = blockIdx.y;
-  const uint32_t b = blockIdx.x * 256 + threadIdx.x;
-  if (b >= p.NB) return;
-  uint32_t acc = 0;
-  for (uint32_t ch = 0; ch < p.CH; ++ch) {
-    uint32_t* q = blkcnt + ((size_t)w * p.CH + ch) * p.NB + b;
-    const uint32_t t = *q;
-    *q = acc;
-    acc += t;
-  }
-  hist[(size_t)w * (p.NB + 2) + b + 1] = acc;
-}
-
-// One 1024-thread block per window. In: hist[w][0..NB+1] counts (index 0 and NB+1 unused = 0).
-// Out: start[w][b] = first sorted slot of bucket b (start[w][NB+1] = total entries of the window) and
-// nlanes[w] = ceil(total / L): the accumulate kernel cuts the sorted array into equal runs of L entries, one lane
-// each, so every lane of a wave does the same number of mixed additions whatever the bucket sizes are.
-__global__ __launch_bounds__(1024) void k_msm_scan(MsmParams p, uint32_t* hist, uint32_t* start, uint32_t* nlanes) {
-  __shared__ uint32_t sh_cnt[1024];
-  const int w = blockIdx.x;
-  const uint32_t len = p.NB + 2;
-  uint32_t* h = hist + (size_t)w * len;
-  uint32_t* st = start + (size_t)w * len;
-  const uint32_t per = (len + 1023) / 1024;
-  const uint32_t b0 = threadIdx.x * per;
-  uint32_t cnt = 0;
-  for (uint32_t k = 0; k < per; ++k) {
-    const uint32_t b = b0 + k;
-    if (b < len) cnt += h[b];
-  }
-  sh_cnt[threadIdx.x] = cnt;
-  __syncthreads();
-  for (int d = 1; d < 1024; d <<= 1) {  // Hillis-Steele inclusive scan over 1024 partials
-    uint32_t a = 0;
-    if ((int)threadIdx.x >= d) a = sh_cnt[threadIdx.x - d];
-    __syncthreads();
-    sh_cnt[threadIdx.x] += a;
-    __syncthreads();
-  }
-  uint32_t run_c = sh_cnt[threadIdx.x] - cnt;
-  for (uint32_t k = 0; k < per; ++k) {
-    const uint32_t b = b0 + k;
-    if (b < len) {
-      const uint32_t cv = h[b];
-      st[b] = run_c;
-      run_c += cv;
-      h[b] = 0;
-    }
-  }
-  if (threadIdx.x == 1023) nlanes[w] = (sh_cnt[1023] + p.L - 1) / p.L;
-}
-
-// Block (chunk ch, window w): LDS cursors = bucket start + this chunk's prefix; scatter (index | sign) into
-// bucket order. No global atomics; the order inside a bucket is deterministic per chunk.
-__global__ __launch_bounds__(SORT_BLK) void k_msm_scatter_lds(MsmParams p, const uint16_t* __restrict__ dig,
-                                                               const uint32_t* __restrict__ start, const uint32_t* __restrict__ blkcnt,
-                                                               uint32_t* __restrict__ sorted) {
-  extern __shared__ uint32_t lds_cur[];
-  const uint32_t ch = blockIdx.x, w = blockIdx.y;
-  const uint32_t* st = start + (size_t)w * (p.NB + 2) + 1;
-  const uint32_t* pre = blkcnt + ((size_t)w * p.CH + ch) * p.NB;
-  for (uint32_t b = threadIdx.x; b < p.NB; b += SORT_BLK) lds_cur[b] = st[b] + pre[b];
-  __syncthreads();
-  const size_t lo = (size_t)ch * p.chunk_len;
-  size_t hi = lo + p.chunk_len;
-  if (hi > p.n) hi = p.n;
-  const uint16_t* d = dig + (size_t)w * p.n;
-  uint32_t* so = sorted + (size_t)w * p.n;
-  for (size_t i0 = lo; i0 < hi; i0 += SORT_BLK) {
-    const size_t i = i0 + threadIdx.x;
-    uint32_t code = DIG_ZERO;
-    if (i < hi) code = d[i];
-    const bool valid = code != DIG_ZERO;
-    const uint32_t pos = lds_slot(lds_cur, code & 0x7fffu, valid);
-    if (valid) so[pos] = (uint32_t)i | ((code >> 15) << 31);
-  }
-}
-
 
 // first index in [lo, hi) with a[idx] > v
 __device__ __forceinline__ uint32_t upper_bound_u32(const uint32_t* __restrict__ a, uint32_t lo, uint32_t hi, uint32_t v) {
@@ -473,7 +331,6 @@ struct PartialHeader {
   uint32_t pad[4];
 };
 constexpr uint32_t PARTIAL_MAGIC = 0x4d534d50u;  // "PMSM"
-constexpr int MAX_WINDOWS = 128;
 
 template <class Cfg>
 static int msm_windows_dev(const Bases* B, size_t offset, size_t n, const uint64_t* scalars_dev, int mont, hipStream_t st,
@@ -516,6 +373,7 @@ static int msm_windows_dev(const Bases* B, size_t offset, size_t n, const uint64
   need += Arena::padded(sizeof(uint32_t) * n * p.W);              // sorted
   need += Arena::padded(sizeof(uint16_t) * n * p.W);              // digit codes
   need += Arena::padded(sizeof(uint32_t) * (size_t)p.NB * p.CH * p.W);  // per-chunk bucket counts / prefixes
+  need += msm_sort_extra_bytes(p);  // level-1 records + partition offsets (two-level scatter, large n)
   need += Arena::padded(sizeof(XYZZ<Fq>) * (size_t)p.tmax * p.W); // partials
   need += Arena::padded(sizeof(XYZZ<Fq>) * (size_t)p.S * p.W);    // segment results
   need += Arena::padded(sizeof(XYZZ<Fq>) * (size_t)(p.NB + 1) * p.W);  // dense bucket sums
@@ -530,6 +388,9 @@ static int msm_windows_dev(const Bases* B, size_t offset, size_t n, const uint64
   uint32_t* sorted = ar.take<uint32_t>(n * p.W);
   uint16_t* dig = ar.take<uint16_t>(n * p.W);
   uint32_t* blkcnt = ar.take<uint32_t>((size_t)p.NB * p.CH * p.W);
+  const bool two_level = msm_sort_two_level(p);
+  uint64_t* inter = two_level ? ar.take<uint64_t>(n * p.W) : nullptr;
+  uint32_t* part_cnt = two_level ? ar.take<uint32_t>((size_t)(p.NB / 256) * p.CH * p.W) : nullptr;
   XYZZ<Fq>* partial = ar.take<XYZZ<Fq>>((size_t)p.tmax * p.W);
   XYZZ<Fq>* segres = ar.take<XYZZ<Fq>>((size_t)p.S * p.W);
   XYZZ<Fq>* dense = ar.take<XYZZ<Fq>>((size_t)(p.NB + 1) * p.W);
@@ -550,23 +411,11 @@ static int msm_windows_dev(const Bases* B, size_t offset, size_t n, const uint64
   CSH_TRY(mark(0));
   CSH_HIP(hipMemsetAsync(hist, 0, sizeof(uint32_t) * len * p.W, st));
   const int g1 = grid_for(n, MSM_BLK, 256 * 8);
-  const size_t sort_lds = sizeof(uint32_t) * p.NB;
-  if (sort_lds > 48 * 1024) {
-    static thread_local bool raised = false;
-    if (!raised) {
-      CSH_HIP(hipFuncSetAttribute((const void*)k_msm_hist_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-      CSH_HIP(hipFuncSetAttribute((const void*)k_msm_scatter_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-      raised = true;
-    }
-  }
   hipLaunchKernelGGL(k_msm_digits<Fr>, dim3(g1), dim3(MSM_BLK), 0, st, sc, p, dig);
-  hipLaunchKernelGGL(k_msm_hist_lds, dim3(p.CH, p.W), dim3(SORT_BLK), sort_lds, st, p, dig, blkcnt);
-  hipLaunchKernelGGL(k_msm_colscan, dim3((p.NB + 255) / 256, p.W), dim3(256), 0, st, p, blkcnt, hist);
-  CSH_TRY(mark(1));
-  hipLaunchKernelGGL(k_msm_scan, dim3(p.W), dim3(1024), 0, st, p, hist, start, nlanes);
-  CSH_TRY(mark(2));
-  hipLaunchKernelGGL(k_msm_scatter_lds, dim3(p.CH, p.W), dim3(SORT_BLK), sort_lds, st, p, dig, start, blkcnt, sorted);
-  CSH_TRY(mark(3));
+  {
+    SortBuffers sb{hist, start, nlanes, sorted, dig, blkcnt, inter, part_cnt};
+    CSH_TRY(msm_sort_launch(p, sb, st, timing ? ev : nullptr));
+  }
   {
     static const int blk = [] {
       const char* e = getenv("CSH_ACC_BLK");

@@ -1,0 +1,42 @@
+// Counting-sort stage of the Pippenger MSM (msm.hip): digit codes -> per-window bucket-ordered index lists.
+// Kept in its own translation unit: the kernels are field-independent.
+#pragma once
+#include "common.hpp"
+
+namespace csh {
+
+struct MsmParams {
+  uint32_t n;
+  int c;        // window bits
+  int W;        // windows
+  uint32_t NB;  // buckets per window = 2^(c-1), bucket ids 1..NB
+  uint32_t L;   // max entries per task
+  uint32_t tmax;  // task slots per window
+  uint32_t S;     // reduce segments per window (power of two)
+  int mont;
+  uint32_t CH;         // point chunks per window in the LDS counting sort
+  uint32_t chunk_len;  // points per chunk
+};
+
+// Digit code (one u16 per point and window): bits 0..14 = bucket-1, bit 15 = negative; 0xFFFF = zero digit.
+constexpr uint32_t DIG_ZERO = 0xFFFFu;
+constexpr int MAX_WINDOWS = 128;
+
+struct SortBuffers {
+  uint32_t* hist;      // [W][NB+2] scratch (zeroed by the caller)
+  uint32_t* start;     // [W][NB+2] out: first sorted slot per bucket; [NB+1] = entries of the window
+  uint32_t* nlanes;    // [MAX_WINDOWS] out: ceil(entries / L) per window
+  uint32_t* sorted;    // [W][n] out: (point index | sign << 31) in bucket order
+  const uint16_t* dig; // [W][n] in: digit codes
+  uint32_t* blkcnt;    // [W][CH][NB] scratch
+  uint64_t* inter;     // [W][n] scratch (two-level mode only)
+  uint32_t* part_cnt;  // [W][CH][NB/256] scratch (two-level mode only)
+};
+
+bool msm_sort_two_level(const MsmParams& p);
+size_t msm_sort_extra_bytes(const MsmParams& p);  // arena bytes for inter + part_cnt (0 in single-level mode)
+// Launches hist -> colscan -> scan -> scatter on `st`. ev (nullable): records ev[1] after the histogram, ev[2] after
+// the scan, ev[3] after the scatter.
+int msm_sort_launch(const MsmParams& p, const SortBuffers& b, hipStream_t st, hipEvent_t* ev);
+
+}  // namespace csh

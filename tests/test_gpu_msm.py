@@ -72,6 +72,16 @@ def test_msm_window_sizes(gpu, monkeypatch):
     for c in [2, 3, 5, 8, 11, 13, 16, 17, 20]:
         monkeypatch.setenv("CSH_MSM_C", str(c))
         assert G.eq(_run(gpu, "bn254", 0, pts, sc), want), c
+    # both scatter variants (single-level LDS cursors / two-level tile sort), uniform and skewed digits
+    sk2 = [1] * 120 + [F.p - 1] * 80 + [5 << 200] * 60 + sc[:40]
+    want2 = G.msm(pts, sk2)
+    for mode in ["0", "1"]:
+        monkeypatch.setenv("CSH_SORT_TWO_LEVEL", mode)
+        for c in [11, 14, 16]:
+            monkeypatch.setenv("CSH_MSM_C", str(c))
+            assert G.eq(_run(gpu, "bn254", 0, pts, sc), want), (mode, c)
+            assert G.eq(_run(gpu, "bn254", 0, pts, sk2), want2), (mode, c)
+    monkeypatch.delenv("CSH_SORT_TWO_LEVEL")
     monkeypatch.delenv("CSH_MSM_C")
     # tiny task length: forces many tasks per bucket (the skew path) on a skewed scalar set
     monkeypatch.setenv("CSH_MSM_L", "3")
