@@ -89,6 +89,95 @@ CSH_HD void lazy_madd(XYZZLazy<L>& acc, const L& x2, const L& y2) {
   acc.zzz = L::mul(acc.zzz, ppp);
 }
 
+// ---- general XYZZ arithmetic in the lazy field (bucket merge / window reduction kernels) -------------------------
+// Stored points are XYZZLazy values exactly as the accumulate kernel leaves them: x normalised, y / zz / zzz straight
+// out of a Montgomery reduction (|limb| <= 2^B + 1), so they are valid product operands again with no canonical form
+// in between.
+
+// 2 * P (EFD dbl-2008-s-1, a = 0): 6M + 3S... here 5 products + 3 squares with the fused M*(S - X3) - W*Y1
+template <class L>
+CSH_HD XYZZLazy<L> lazy_dbl_inl(const XYZZLazy<L>& p) {
+  if (p.empty) return p;
+  if (p.y.is_zero()) return XYZZLazy<L>::inf();  // 2-torsion: not on these curves, kept for completeness
+  const L u = L::add(p.y, p.y).normalized();
+  const L v = L::sqr(u);
+  const L w = L::mul(u, v);
+  const L s = L::mul(p.x, v);
+  const L xx = L::sqr(p.x);
+  const L m = L::add(L::add(xx, xx), xx).normalized();
+  XYZZLazy<L> r;
+  r.x = L::sub(L::sqr(m), L::add(s, s)).normalized();
+  r.y = L::mul_sub(m, L::sub(s, r.x), w, p.y);
+  r.zz = L::mul(v, p.zz);
+  r.zzz = L::mul(w, p.zzz);
+  r.empty = false;
+  return r;
+}
+template <class L>
+CSH_HD_NOINLINE void lazy_dbl_p(const XYZZLazy<L>* p, XYZZLazy<L>* out) {
+  *out = lazy_dbl_inl<L>(*p);
+}
+
+// acc += p (EFD add-2008-s): 12 products + 2 squares, 13 reductions
+template <class L>
+CSH_HD void lazy_add_inl(XYZZLazy<L>& acc, const XYZZLazy<L>& p) {
+  if (p.empty) return;
+  if (acc.empty) {
+    acc = p;
+    return;
+  }
+  const L u1 = L::mul(acc.x, p.zz);
+  const L u2 = L::mul(p.x, acc.zz);
+  const L s1 = L::mul(acc.y, p.zzz);
+  const L s2 = L::mul(p.y, acc.zzz);
+  const L pd = L::sub(u2, u1);
+  const L r = L::sub(s2, s1);
+  if (pd.maybe_zero()) {
+    if (pd.is_zero_slow()) {
+      if (r.is_zero()) {
+        const XYZZLazy<L> t = acc;
+        lazy_dbl_p<L>(&t, &acc);
+      } else {
+        acc.empty = true;  // P + (-P)
+      }
+      return;
+    }
+  }
+  const L pp = L::sqr(pd);
+  const L ppp = L::mul(pd, pp);
+  const L q = L::mul(u1, pp);
+  const L x3 = L::sub(L::sub(L::sqr(r), ppp), L::add(q, q)).normalized();
+  const L y3 = L::mul_sub(r, L::sub(q, x3), s1, ppp);
+  acc.x = x3;
+  acc.y = y3;
+  acc.zz = L::mul(L::mul(acc.zz, p.zz), pp);
+  acc.zzz = L::mul(L::mul(acc.zzz, p.zzz), ppp);
+}
+// out of line, operands through memory (see the note on lazy_mdbl)
+template <class L>
+CSH_HD_NOINLINE void lazy_add_p(XYZZLazy<L>* acc, const XYZZLazy<L>* p) {
+  XYZZLazy<L> a = *acc;
+  lazy_add_inl<L>(a, *p);
+  *acc = a;
+}
+
+// k * P for a small unsigned k (double-and-add, out-of-line pieces: cold relative to the additions)
+template <class L>
+CSH_HD XYZZLazy<L> lazy_mul_small(const XYZZLazy<L>& p, uint32_t k) {
+  XYZZLazy<L> r = XYZZLazy<L>::inf();
+  if (k == 0 || p.empty) return r;
+  int top = 31;
+  while (!((k >> top) & 1)) --top;
+  for (int b = top; b >= 0; --b) {
+    if (!r.empty) {
+      const XYZZLazy<L> t = r;
+      lazy_dbl_p<L>(&t, &r);
+    }
+    if ((k >> b) & 1) lazy_add_p<L>(&r, &p);
+  }
+  return r;
+}
+
 template <class L, class F32>
 CSH_HD XYZZ<F32> lazy_to_xyzz(const XYZZLazy<L>& a) {
   if (a.empty) return XYZZ<F32>::inf();

@@ -82,16 +82,10 @@ __device__ __forceinline__ uint32_t upper_bound_u32(const uint32_t* __restrict__
   return lo;
 }
 
-// Export of one finished bucket run (out of line: two call sites, executed once per bucket boundary)
+// Everything between the accumulate kernel and the final window sums stays in the lazy field: a stored partial /
+// bucket sum / segment sum is the XYZZLazy value as the arithmetic left it (no canonical form, no domain change).
 template <class Cfg>
-__device__ __attribute__((noinline)) void flush_partial(XYZZ<typename Cfg::Fq>* dst, const XYZZLazy<typename Cfg::L>* acc) {
-  *dst = lazy_to_xyzz<typename Cfg::L, typename Cfg::Fq>(*acc);
-}
-
-template <class Cfg>
-__device__ __attribute__((noinline)) void flush_partial_v(XYZZ<typename Cfg::Fq>* dst, XYZZLazy<typename Cfg::L> acc) {
-  *dst = lazy_to_xyzz<typename Cfg::L, typename Cfg::Fq>(acc);
-}
+using LazyPt = XYZZLazy<typename Cfg::L>;
 
 // Bucket accumulation. Lane k of window w owns sorted entries [k*L, (k+1)*L): it walks them in bucket order and
 // emits one partial sum per bucket it touches into slot (bucket + k) -- unique and increasing in (bucket, lane), so
@@ -100,8 +94,9 @@ __device__ __attribute__((noinline)) void flush_partial_v(XYZZ<typename Cfg::Fq>
 template <class Cfg>
 __global__ __launch_bounds__(ACC_BLK) void k_msm_accum(const Affine<typename Cfg::Fq>* __restrict__ bases, MsmParams p,
                                                        const uint32_t* __restrict__ start, const uint32_t* __restrict__ nlanes,
-                                                       const uint32_t* __restrict__ sorted, XYZZ<typename Cfg::Fq>* partial) {
+                                                       const uint32_t* __restrict__ sorted, LazyPt<Cfg>* partial) {
   using Fq = typename Cfg::Fq;
+  static_assert(Cfg::LAZY, "the bucket pipeline runs in the signed lazy field");
   const int w = blockIdx.y;
   const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= nlanes[w]) return;
@@ -113,8 +108,8 @@ __global__ __launch_bounds__(ACC_BLK) void k_msm_accum(const Affine<typename Cfg
   uint32_t b = upper_bound_u32(st, 1, p.NB + 1, lo) - 1;  // bucket containing sorted position lo
   uint32_t next = st[b + 1];
   const uint32_t* so = sorted + (size_t)w * p.n;
-  XYZZ<Fq>* pw = partial + (size_t)w * p.tmax;
-  if constexpr (Cfg::LAZY) {
+  LazyPt<Cfg>* pw = partial + (size_t)w * p.tmax;
+  {
     using L = typename Cfg::L;
     XYZZLazy<L> acc = XYZZLazy<L>::inf();
     uint32_t e_next = so[lo];
@@ -127,12 +122,7 @@ __global__ __launch_bounds__(ACC_BLK) void k_msm_accum(const Affine<typename Cfg
         pt_next = bases[e_next & 0x7fffffffu];
       }
       if (pos == next) {                            // crossed into the next non-empty bucket: flush
-        if constexpr (sizeof(L) <= 40) {
-          flush_partial_v<Cfg>(&pw[b + k], acc);
-        } else {
-          const XYZZLazy<L> done = acc;  // private copy: the call takes its address, acc itself stays in registers
-          flush_partial<Cfg>(&pw[b + k], &done);
-        }
+        pw[b + k] = acc;
         acc = XYZZLazy<L>::inf();
         do { ++b; next = st[b + 1]; } while (next <= pos);
       }
@@ -142,30 +132,20 @@ __global__ __launch_bounds__(ACC_BLK) void k_msm_accum(const Affine<typename Cfg
       if (e >> 31) y = L::neg(y).normalized();  // keep |limb| <= 2^B + 1: lazy_madd subtracts acc.y limb-wise
       lazy_madd(acc, x, y);
     }
-    pw[b + k] = lazy_to_xyzz<L, Fq>(acc);  // final run of the lane: exported inline (acc never has its address taken)
-  } else {
-    XYZZ<Fq> acc = XYZZ<Fq>::inf();
-    for (uint32_t pos = lo; pos < hi; ++pos) {
-      if (pos == next) {
-        pw[b + k] = acc;
-        acc = XYZZ<Fq>::inf();
-        do { ++b; next = st[b + 1]; } while (next <= pos);
-      }
-      const uint32_t e = so[pos];
-      Affine<Fq> pt = bases[e & 0x7fffffffu];
-      if (e >> 31) pt.y = Fq::neg(pt.y);
-      xyzz_madd(acc, pt);
-    }
     pw[b + k] = acc;
   }
 }
 
-// Point addition used by the reduction kernels: inlined for the 8-limb base field (2x faster per op than the
-// out-of-line call through scratch), out of line for the wide fields (code size).
+// Point addition used by the merge / reduction kernels: inlined for the 9-limb base field, out of line (operands
+// through memory) for the wide fields (code size, and see the note on lazy_mdbl).
 template <class Cfg>
-__device__ __forceinline__ void padd(XYZZ<typename Cfg::Fq>& a, const XYZZ<typename Cfg::Fq>& b) {
-  if constexpr (Cfg::INLINE_ADD) a = xyzz_add_inl(a, b);
-  else xyzz_add(a, b);
+__device__ __forceinline__ void padd(LazyPt<Cfg>& a, const LazyPt<Cfg>& b) {
+  if constexpr (Cfg::INLINE_ADD) {
+    lazy_add_inl<typename Cfg::L>(a, b);
+  } else {
+    const LazyPt<Cfg> t = b;
+    lazy_add_p<typename Cfg::L>(&a, &t);
+  }
 }
 
 // Bucket merge: the partials of bucket b sit in consecutive slots b + k0 .. b + k1 (k0, k1 = first / last lane that
@@ -174,18 +154,17 @@ __device__ __forceinline__ void padd(XYZZ<typename Cfg::Fq>& a, const XYZZ<typen
 constexpr uint32_t MERGE_CAP = 16;
 template <class Cfg>
 __global__ __launch_bounds__(64) void k_msm_merge(MsmParams p, const uint32_t* __restrict__ start,
-                                                  const XYZZ<typename Cfg::Fq>* __restrict__ partial, XYZZ<typename Cfg::Fq>* dense,
+                                                  const LazyPt<Cfg>* __restrict__ partial, LazyPt<Cfg>* dense,
                                                   uint32_t* giant_count, uint32_t* giant_list) {
-  using Fq = typename Cfg::Fq;
   const int w = blockIdx.y;
   const uint32_t b = blockIdx.x * 64 + threadIdx.x + 1;
   if (b > p.NB) return;
   const uint32_t* st = start + (size_t)w * (p.NB + 2);
   const uint32_t lo = st[b], hi = st[b + 1];
-  XYZZ<Fq> acc = XYZZ<Fq>::inf();
+  LazyPt<Cfg> acc = LazyPt<Cfg>::inf();
   if (hi > lo) {
     const uint32_t k0 = lo / p.L, k1 = (hi - 1) / p.L;
-    const XYZZ<Fq>* pw = partial + (size_t)w * p.tmax + b;
+    const LazyPt<Cfg>* pw = partial + (size_t)w * p.tmax + b;
     if (k1 - k0 >= MERGE_CAP) {
       const uint32_t g = atomicAdd(giant_count, 1u);
       giant_list[2 * g] = (uint32_t)w;
@@ -202,24 +181,23 @@ __global__ __launch_bounds__(64) void k_msm_merge(MsmParams p, const uint32_t* _
 // exchange through the dense array's own slot list (pairwise passes over `tmp`).
 template <class Cfg>
 __global__ __launch_bounds__(256) void k_msm_merge_giant(MsmParams p, const uint32_t* __restrict__ start,
-                                                         const XYZZ<typename Cfg::Fq>* __restrict__ partial, XYZZ<typename Cfg::Fq>* dense,
+                                                         const LazyPt<Cfg>* __restrict__ partial, LazyPt<Cfg>* dense,
                                                          const uint32_t* __restrict__ giant_count, const uint32_t* __restrict__ giant_list,
-                                                         XYZZ<typename Cfg::Fq>* tmp) {
-  using Fq = typename Cfg::Fq;
+                                                         LazyPt<Cfg>* tmp) {
   const uint32_t count = *giant_count;
-  XYZZ<Fq>* t = tmp + (size_t)blockIdx.x * 256;
+  LazyPt<Cfg>* t = tmp + (size_t)blockIdx.x * 256;
   for (uint32_t g = blockIdx.x; g < count; g += gridDim.x) {
     const uint32_t w = giant_list[2 * g], b = giant_list[2 * g + 1];
     const uint32_t* st = start + (size_t)w * (p.NB + 2);
     const uint32_t k0 = st[b] / p.L, k1 = (st[b + 1] - 1) / p.L;
-    const XYZZ<Fq>* pw = partial + (size_t)w * p.tmax + b;
-    XYZZ<Fq> acc = XYZZ<Fq>::inf();
+    const LazyPt<Cfg>* pw = partial + (size_t)w * p.tmax + b;
+    LazyPt<Cfg> acc = LazyPt<Cfg>::inf();
     for (uint32_t k = k0 + threadIdx.x; k <= k1; k += 256) padd<Cfg>(acc, pw[k]);
     t[threadIdx.x] = acc;
     __syncthreads();
     for (uint32_t half = 128; half >= 1; half >>= 1) {
       if (threadIdx.x < half) {
-        XYZZ<Fq> x = t[threadIdx.x];
+        LazyPt<Cfg> x = t[threadIdx.x];
         padd<Cfg>(x, t[threadIdx.x + half]);
         t[threadIdx.x] = x;
       }
@@ -233,9 +211,8 @@ __global__ __launch_bounds__(256) void k_msm_merge_giant(MsmParams p, const uint
 // Segment k of window w folds slots [t0, t1) of the (bucket-sorted) partial array: returns sum_t bucket(t) * partial(t)
 // by the running-sum trick with explicit gaps; slots whose bucket id is 0 were never written and are skipped.
 template <class Cfg>
-__global__ __launch_bounds__(64) void k_msm_reduce(MsmParams p, const XYZZ<typename Cfg::Fq>* __restrict__ dense,
-                                                   XYZZ<typename Cfg::Fq>* segres) {
-  using Fq = typename Cfg::Fq;
+__global__ __launch_bounds__(64) void k_msm_reduce(MsmParams p, const LazyPt<Cfg>* __restrict__ dense,
+                                                   LazyPt<Cfg>* segres) {
   const int w = blockIdx.y;
   const uint32_t k = blockIdx.x * 64 + threadIdx.x;
   if (k >= p.S) return;
@@ -243,19 +220,19 @@ __global__ __launch_bounds__(64) void k_msm_reduce(MsmParams p, const XYZZ<typen
   const uint32_t t0 = 1 + k * per;
   uint32_t t1 = t0 + per;
   if (t1 > p.NB + 1) t1 = p.NB + 1;
-  XYZZ<Fq> running = XYZZ<Fq>::inf(), acc = XYZZ<Fq>::inf();
+  LazyPt<Cfg> running = LazyPt<Cfg>::inf(), acc = LazyPt<Cfg>::inf();
   uint32_t prev_b = 0;
   if (t0 < t1) {
-    const XYZZ<Fq>* dw = dense + (size_t)w * (p.NB + 1);
+    const LazyPt<Cfg>* dw = dense + (size_t)w * (p.NB + 1);
     for (uint32_t t = t1; t-- > t0;) {
-      const XYZZ<Fq> pt = dw[t];
-      if (pt.is_inf()) continue;
+      const LazyPt<Cfg> pt = dw[t];
+      if (pt.empty) continue;
       uint32_t gap = prev_b ? prev_b - t : 0;
       if (gap) {
         if (gap <= 4) {
           while (gap--) padd<Cfg>(acc, running);
         } else {
-          XYZZ<Fq> m = xyzz_mul_small(running, gap);
+          LazyPt<Cfg> m = lazy_mul_small<typename Cfg::L>(running, gap);
           padd<Cfg>(acc, m);
         }
       }
@@ -263,7 +240,7 @@ __global__ __launch_bounds__(64) void k_msm_reduce(MsmParams p, const XYZZ<typen
       prev_b = t;
     }
     if (prev_b) {  // acc = sum (b - bmin) B_b ; add bmin * R
-      XYZZ<Fq> m = xyzz_mul_small(running, prev_b);
+      LazyPt<Cfg> m = lazy_mul_small<typename Cfg::L>(running, prev_b);
       padd<Cfg>(acc, m);
     }
   }
@@ -272,12 +249,12 @@ __global__ __launch_bounds__(64) void k_msm_reduce(MsmParams p, const XYZZ<typen
 
 // arr[w][i] += arr[w][i + half], i < half
 template <class Cfg>
-__global__ __launch_bounds__(64) void k_msm_fold(XYZZ<typename Cfg::Fq>* arr, uint32_t stride, uint32_t half) {
+__global__ __launch_bounds__(64) void k_msm_fold(LazyPt<Cfg>* arr, uint32_t stride, uint32_t half) {
   const int w = blockIdx.y;
   const uint32_t i = blockIdx.x * 64 + threadIdx.x;
   if (i >= half) return;
-  XYZZ<typename Cfg::Fq>* a = arr + (size_t)w * stride;
-  XYZZ<typename Cfg::Fq> x = a[i];
+  LazyPt<Cfg>* a = arr + (size_t)w * stride;
+  LazyPt<Cfg> x = a[i];
   padd<Cfg>(x, a[i + half]);
   a[i] = x;
 }
@@ -298,9 +275,9 @@ __global__ __launch_bounds__(256) void k_bases_repack(Affine<typename Cfg::Fq>* 
 }
 
 template <class Cfg>
-__global__ void k_msm_gather_windows(const XYZZ<typename Cfg::Fq>* segres, uint32_t stride, int W, XYZZ<typename Cfg::Fq>* out) {
+__global__ void k_msm_gather_windows(const LazyPt<Cfg>* segres, uint32_t stride, int W, XYZZ<typename Cfg::Fq>* out) {
   const int w = threadIdx.x;
-  if (w < W) out[w] = segres[(size_t)w * stride];
+  if (w < W) out[w] = lazy_to_xyzz<typename Cfg::L, typename Cfg::Fq>(segres[(size_t)w * stride]);  // back to the arkworks encoding
 }
 
 // ---- host side -----------------------------------------------------------------------------------------
@@ -374,13 +351,13 @@ static int msm_windows_dev(const Bases* B, size_t offset, size_t n, const uint64
   need += Arena::padded(sizeof(uint16_t) * n * p.W);              // digit codes
   need += Arena::padded(sizeof(uint32_t) * (size_t)p.NB * p.CH * p.W);  // per-chunk bucket counts / prefixes
   need += msm_sort_extra_bytes(p);  // level-1 records + partition offsets (two-level scatter, large n)
-  need += Arena::padded(sizeof(XYZZ<Fq>) * (size_t)p.tmax * p.W); // partials
-  need += Arena::padded(sizeof(XYZZ<Fq>) * (size_t)p.S * p.W);    // segment results
-  need += Arena::padded(sizeof(XYZZ<Fq>) * (size_t)(p.NB + 1) * p.W);  // dense bucket sums
+  need += Arena::padded(sizeof(LazyPt<Cfg>) * (size_t)p.tmax * p.W); // partials
+  need += Arena::padded(sizeof(LazyPt<Cfg>) * (size_t)p.S * p.W);    // segment results
+  need += Arena::padded(sizeof(LazyPt<Cfg>) * (size_t)(p.NB + 1) * p.W);  // dense bucket sums
   const uint32_t max_giant = (uint32_t)(((uint64_t)max_lanes * p.W) / MERGE_CAP + 1);
   const uint32_t giant_blocks = max_giant < 1024 ? max_giant : 1024;
   need += Arena::padded(sizeof(uint32_t) * (2 * (size_t)max_giant + 2));
-  need += Arena::padded(sizeof(XYZZ<Fq>) * 256 * (size_t)giant_blocks);
+  need += Arena::padded(sizeof(LazyPt<Cfg>) * 256 * (size_t)giant_blocks);
   CSH_TRY(ar.reserve(need));
   uint32_t* hist = ar.take<uint32_t>(len * p.W);
   uint32_t* start = ar.take<uint32_t>(len * p.W);
@@ -391,11 +368,11 @@ static int msm_windows_dev(const Bases* B, size_t offset, size_t n, const uint64
   const bool two_level = msm_sort_two_level(p);
   uint64_t* inter = two_level ? ar.take<uint64_t>(n * p.W) : nullptr;
   uint32_t* part_cnt = two_level ? ar.take<uint32_t>((size_t)(p.NB / 256) * p.CH * p.W) : nullptr;
-  XYZZ<Fq>* partial = ar.take<XYZZ<Fq>>((size_t)p.tmax * p.W);
-  XYZZ<Fq>* segres = ar.take<XYZZ<Fq>>((size_t)p.S * p.W);
-  XYZZ<Fq>* dense = ar.take<XYZZ<Fq>>((size_t)(p.NB + 1) * p.W);
+  LazyPt<Cfg>* partial = ar.take<LazyPt<Cfg>>((size_t)p.tmax * p.W);
+  LazyPt<Cfg>* segres = ar.take<LazyPt<Cfg>>((size_t)p.S * p.W);
+  LazyPt<Cfg>* dense = ar.take<LazyPt<Cfg>>((size_t)(p.NB + 1) * p.W);
   uint32_t* giant = ar.take<uint32_t>(2 * (size_t)max_giant + 2);  // [0] = count, list from [2]
-  XYZZ<Fq>* giant_tmp = ar.take<XYZZ<Fq>>(256 * (size_t)giant_blocks);
+  LazyPt<Cfg>* giant_tmp = ar.take<LazyPt<Cfg>>(256 * (size_t)giant_blocks);
 
   const bool timing = getenv("CSH_MSM_TIMING") != nullptr;
   hipEvent_t ev[7];

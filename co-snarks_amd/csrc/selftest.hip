@@ -101,6 +101,41 @@ int lazy_accumulate_t(const void* affine_pts, const uint8_t* neg, size_t npts, v
   return CSH_OK;
 }
 
+// Host run of the post-accumulation arithmetic (k_msm_merge / k_msm_reduce / k_msm_fold): groups of `group_len`
+// points summed with lazy_madd, the group sums folded pairwise with lazy_add, the result times `weight`.
+template <class L, class Fq>
+int lazy_tree_t(const void* affine_pts, const uint8_t* neg, size_t npts, size_t group_len, uint32_t weight, void* out_xyzz) {
+  const Affine<Fq>* pts = reinterpret_cast<const Affine<Fq>*>(affine_pts);
+  std::vector<XYZZLazy<L>> parts;
+  for (size_t g0 = 0; g0 < npts; g0 += group_len) {
+    XYZZLazy<L> acc = XYZZLazy<L>::inf();
+    for (size_t i = g0; i < npts && i < g0 + group_len; ++i) {
+      Affine<Fq> p;
+      memcpy(&p, pts + i, sizeof p);
+      if (p.is_inf()) continue;
+      L x = L::unpack(L::repack_for_storage(p.x)), y = L::unpack(L::repack_for_storage(p.y));
+      if (neg && neg[i]) y = L::neg(y).normalized();
+      lazy_madd(acc, x, y);
+    }
+    parts.push_back(acc);
+  }
+  if (parts.empty()) parts.push_back(XYZZLazy<L>::inf());
+  while (parts.size() > 1) {
+    std::vector<XYZZLazy<L>> next;
+    for (size_t i = 0; i + 1 < parts.size(); i += 2) {
+      XYZZLazy<L> a = parts[i];
+      if (i & 2) lazy_add_inl<L>(a, parts[i + 1]);  // both entry points
+      else lazy_add_p<L>(&a, &parts[i + 1]);
+      next.push_back(a);
+    }
+    if (parts.size() & 1) next.push_back(parts.back());
+    parts.swap(next);
+  }
+  XYZZ<Fq> r = lazy_to_xyzz<L, Fq>(lazy_mul_small<L>(parts[0], weight));
+  memcpy(out_xyzz, &r, sizeof r);
+  return CSH_OK;
+}
+
 // Device-vs-host determinism check of the lazy bucket arithmetic: thread t accumulates the cyclic chain
 // pts[(t + i) % n], i < len (sign from bit i of a hash) on the GPU; the host recomputes a sample of threads with the
 // very same template code and compares the exported XYZZ words bit for bit.
@@ -195,6 +230,16 @@ int csh_selftest_lazy_accumulate(int curve, int group, const void* affine_pts, c
   if (curve == CSH_BN254 && group == CSH_G2) return lazy_accumulate_t<Fq29s2, Bn254Fq2>(affine_pts, neg, npts, out_xyzz);
   if (curve == CSH_BLS12_381 && group == CSH_G1) return lazy_accumulate_t<Fq28s, Bls381Fq>(affine_pts, neg, npts, out_xyzz);
   if (curve == CSH_BLS12_381 && group == CSH_G2) return lazy_accumulate_t<Fq28s2, Bls381Fq2>(affine_pts, neg, npts, out_xyzz);
+  return CSH_ERR_INVALID;
+}
+
+int csh_selftest_lazy_tree(int curve, int group, const void* affine_pts, const uint8_t* neg, size_t npts, size_t group_len, uint32_t weight,
+                           void* out_xyzz) {
+  if (group_len == 0) return CSH_ERR_INVALID;
+  if (curve == CSH_BN254 && group == CSH_G1) return lazy_tree_t<Fq29s, Bn254Fq>(affine_pts, neg, npts, group_len, weight, out_xyzz);
+  if (curve == CSH_BN254 && group == CSH_G2) return lazy_tree_t<Fq29s2, Bn254Fq2>(affine_pts, neg, npts, group_len, weight, out_xyzz);
+  if (curve == CSH_BLS12_381 && group == CSH_G1) return lazy_tree_t<Fq28s, Bls381Fq>(affine_pts, neg, npts, group_len, weight, out_xyzz);
+  if (curve == CSH_BLS12_381 && group == CSH_G2) return lazy_tree_t<Fq28s2, Bls381Fq2>(affine_pts, neg, npts, group_len, weight, out_xyzz);
   return CSH_ERR_INVALID;
 }
 

@@ -211,6 +211,39 @@ def test_lazy_bucket_accumulation_matches_group_law(hip, curve, group):
         assert G.eq(got, want)
 
 
+@pytest.mark.parametrize("curve,group", [("bn254", 0), ("bn254", 1), ("bls12_381", 0), ("bls12_381", 1)])
+def test_lazy_point_tree_matches_group_law(hip, curve, group):
+    """General XYZZ + XYZZ / doubling / small scalar in the lazy field (what the merge and reduce kernels run):
+    group sums folded pairwise, incl. equal sums (-> doubling), opposite sums (-> infinity), empty groups."""
+    G = cv.CURVES[curve][group]
+    cid = H.CURVE_IDS[curve]
+    r = H.rng(91 + group)
+    pts = H.rand_points(G, 24, r)
+    cases = [
+        (pts, [r.randrange(2) for _ in pts], 3, 1),
+        (pts, [0] * len(pts), 5, 29),
+        (pts[:4] + pts[:4], [0] * 8, 4, 7),                 # two equal group sums -> lazy_dbl inside lazy_add
+        (pts[:4] + pts[:4], [0] * 4 + [1] * 4, 4, 3),       # S + (-S) -> infinity
+        (pts[:4] + pts[:4] + pts[4:8], [0] * 4 + [1] * 4 + [0] * 4, 4, 32767),
+        ([None, None, pts[0], pts[1], None, None], [0] * 6, 2, 12345),  # empty groups around a real one
+        ([pts[0]], [1], 1, 65535),
+        (pts[:2], [0, 0], 1, 0),
+    ]
+    for seq, neg, glen, weight in cases:
+        want = None
+        for P, ng in zip(seq, neg):
+            want = G.add(want, G.neg(P) if ng else P)
+        want = G.mul(want, weight)
+        ap = cv.pack_points(G, seq).reshape(-1)
+        ngb = np.array(neg, dtype=np.uint8)
+        out = np.zeros(2 * hip.point_bytes(cid, group) // 8, dtype=np.uint64)
+        assert hip.lib().csh_selftest_lazy_tree(cid, group, ap.ctypes.data_as(C.c_void_p), ngb.ctypes.data_as(C.c_void_p),
+                                                C.c_size_t(len(seq)), C.c_size_t(glen), C.c_uint32(weight),
+                                                out.ctypes.data_as(C.c_void_p)) == 0
+        got = _xyzz_to_affine(hip, cid, group, G, out)
+        assert G.eq(got, want), (glen, weight)
+
+
 @pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
 def test_rep3_mask_generator_matches_rngs_rs(hip, curve):
     """The device mask generator's code (run on the host) vs mpc-core/src/protocols/rep3/rngs.rs:137-156 restated:
