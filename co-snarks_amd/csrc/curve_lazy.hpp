@@ -161,19 +161,25 @@ CSH_HD_NOINLINE void lazy_add_p(XYZZLazy<L>* acc, const XYZZLazy<L>* p) {
   *acc = a;
 }
 
-// k * P for a small unsigned k (double-and-add, out-of-line pieces: cold relative to the additions)
-template <class L>
+// k * P for a small unsigned k (double-and-add). INL: both steps inlined into the loop body (9-limb field; the
+// window reduction spends half its time here), otherwise out-of-line pieces.
+template <class L, bool INL = false>
 CSH_HD XYZZLazy<L> lazy_mul_small(const XYZZLazy<L>& p, uint32_t k) {
   XYZZLazy<L> r = XYZZLazy<L>::inf();
   if (k == 0 || p.empty) return r;
   int top = 31;
   while (!((k >> top) & 1)) --top;
   for (int b = top; b >= 0; --b) {
-    if (!r.empty) {
-      const XYZZLazy<L> t = r;
-      lazy_dbl_p<L>(&t, &r);
+    if constexpr (INL) {
+      r = lazy_dbl_inl<L>(r);
+      if ((k >> b) & 1) lazy_add_inl<L>(r, p);
+    } else {
+      if (!r.empty) {
+        const XYZZLazy<L> t = r;
+        lazy_dbl_p<L>(&t, &r);
+      }
+      if ((k >> b) & 1) lazy_add_p<L>(&r, &p);
     }
-    if ((k >> b) & 1) lazy_add_p<L>(&r, &p);
   }
   return r;
 }

@@ -30,9 +30,9 @@ namespace csh {
 // LAZY: bucket accumulation runs in the signed lazy field (field29.hpp); Bases then stores the coordinates
 // re-encoded as canonical x*R' (same 32 bytes per coordinate), converted once at upload.
 struct Bn254G1Cfg { using Fq = Bn254Fq;   using Fr = Bn254Fr; static constexpr bool LAZY = true;  using L = Fq29s; static constexpr bool INLINE_ADD = true; };
-struct Bn254G2Cfg { using Fq = Bn254Fq2;  using Fr = Bn254Fr; static constexpr bool LAZY = true;  using L = Fq29s2; static constexpr bool INLINE_ADD = false; };
-struct Bls381G1Cfg { using Fq = Bls381Fq;  using Fr = Bls381Fr; static constexpr bool LAZY = true;  using L = Fq28s; static constexpr bool INLINE_ADD = false; };
-struct Bls381G2Cfg { using Fq = Bls381Fq2; using Fr = Bls381Fr; static constexpr bool LAZY = true;  using L = Fq28s2; static constexpr bool INLINE_ADD = false; };
+struct Bn254G2Cfg { using Fq = Bn254Fq2;  using Fr = Bn254Fr; static constexpr bool LAZY = true;  using L = Fq29s2; static constexpr bool INLINE_ADD = true; };
+struct Bls381G1Cfg { using Fq = Bls381Fq;  using Fr = Bls381Fr; static constexpr bool LAZY = true;  using L = Fq28s; static constexpr bool INLINE_ADD = true; };
+struct Bls381G2Cfg { using Fq = Bls381Fq2; using Fr = Bls381Fr; static constexpr bool LAZY = true;  using L = Fq28s2; static constexpr bool INLINE_ADD = true; };
 
 struct Bases {
   csh_curve_t curve;
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(64) void k_msm_reduce(MsmParams p, const LazyPt<Cfg
         if (gap <= 4) {
           while (gap--) padd<Cfg>(acc, running);
         } else {
-          LazyPt<Cfg> m = lazy_mul_small<typename Cfg::L>(running, gap);
+          LazyPt<Cfg> m = lazy_mul_small<typename Cfg::L, Cfg::INLINE_ADD>(running, gap);
           padd<Cfg>(acc, m);
         }
       }
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(64) void k_msm_reduce(MsmParams p, const LazyPt<Cfg
       prev_b = t;
     }
     if (prev_b) {  // acc = sum (b - bmin) B_b ; add bmin * R
-      LazyPt<Cfg> m = lazy_mul_small<typename Cfg::L>(running, prev_b);
+      LazyPt<Cfg> m = lazy_mul_small<typename Cfg::L, Cfg::INLINE_ADD>(running, prev_b);
       padd<Cfg>(acc, m);
     }
   }
