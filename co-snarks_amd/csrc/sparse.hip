@@ -149,37 +149,61 @@ int csh_evaluate_constraints_dev(csh_matrix_t mm, int protocol, int party_id, co
   return eval_t<Bls381Fr>(m, protocol, party_id, public_dev, n_public, witness_dev, out_dev, n_out, st);
 }
 
-int csh_groth16_witness_map(csh_domain_t dom, const uint64_t shift[4], int protocol, int party_id, csh_matrix_t ma, csh_matrix_t mb,
-                            size_t num_constraints, const uint64_t* public_inputs, size_t n_public, const uint64_t* witness, size_t n_witness,
-                            const uint8_t seed1[32], uint64_t off1, const uint8_t seed2[32], uint64_t off2, uint64_t* h_out) {
-  CSH_REQUIRE(dom && shift && ma && mb && h_out && (public_inputs || n_public == 0) && (witness || n_witness == 0), "witness_map: NULL argument");
+// Device-resident core: witness already on the device, h stays on the device (scratch from the stream's arena)
+int csh_groth16_witness_map_dev(csh_domain_t dom, const uint64_t shift[4], int protocol, int party_id, csh_matrix_t ma, csh_matrix_t mb,
+                                size_t num_constraints, const uint64_t* public_inputs, size_t n_public, const uint64_t* witness_dev,
+                                const uint8_t seed1[32], uint64_t off1, const uint8_t seed2[32], uint64_t off2, uint64_t* h_out_dev, void* stream) {
+  CSH_REQUIRE(dom && shift && ma && mb && h_out_dev && (public_inputs || n_public == 0) && witness_dev, "witness_map_dev: NULL argument");
   CSH_REQUIRE(protocol == 0 || protocol == 1, "protocol must be 0 (plain/Shamir) or 1 (Rep3)");
+  CSH_TRY(ensure_device());
   const Domain* d = reinterpret_cast<const Domain*>(dom);
   const size_t n = domain_size_of(d);
   const csh_curve_t f = domain_curve_of(d);
   CSH_REQUIRE(num_constraints + n_public <= n, "Polynomial Degree too large");
   const size_t comp = protocol == 1 ? 2 : 1;
   const size_t sb = 32 * n * comp, eb = 32 * n;
-  HostStage h;
-  CSH_TRY(h.begin(2 * Arena::padded(sb) + 3 * Arena::padded(eb) + Arena::padded(32 * n_public) + Arena::padded(32 * comp * n_witness)));
-  uint64_t *da, *db, *dmc = nullptr, *dmab = nullptr, *dh, *dpub, *dwit;
-  CSH_TRY(h.up(da, nullptr, sb));
-  CSH_TRY(h.up(db, nullptr, sb));
-  CSH_TRY(h.up(dh, nullptr, eb));
-  CSH_TRY(h.up(dpub, public_inputs, 32 * n_public));
-  CSH_TRY(h.up(dwit, witness, 32 * comp * n_witness));
-  CSH_TRY(csh_evaluate_constraints_dev(ma, protocol, party_id, dpub, n_public, dwit, da, n, h.st));   // reduction.rs:102-110
-  CSH_TRY(csh_evaluate_constraints_dev(mb, protocol, party_id, dpub, n_public, dwit, db, n, h.st));   // :118-127
-  if (f == CSH_BN254) CSH_TRY(promote_t<Bn254Fr>(protocol, da, num_constraints, dpub, n_public, party_id, h.st));  // :111-113
-  else CSH_TRY(promote_t<Bls381Fr>(protocol, da, num_constraints, dpub, n_public, party_id, h.st));
+  hipStream_t st = resolve_stream(stream);
+  Arena& ar = arena_for((hipStream_t)((uintptr_t)st ^ 0x1));  // distinct arena from kernel-internal scratch
+  CSH_TRY(ar.reserve(2 * Arena::padded(sb) + 2 * Arena::padded(eb) + Arena::padded(32 * n_public + 32)));
+  uint64_t* da = reinterpret_cast<uint64_t*>(ar.take<char>(sb));
+  uint64_t* db = reinterpret_cast<uint64_t*>(ar.take<char>(sb));
+  uint64_t* dpub = reinterpret_cast<uint64_t*>(ar.take<char>(32 * n_public + 32));
+  uint64_t *dmc = nullptr, *dmab = nullptr;
+  if (n_public) CSH_HIP(hipMemcpyAsync(dpub, public_inputs, 32 * n_public, hipMemcpyHostToDevice, st));
+  CSH_TRY(csh_evaluate_constraints_dev(ma, protocol, party_id, dpub, n_public, witness_dev, da, n, st));   // reduction.rs:102-110
+  CSH_TRY(csh_evaluate_constraints_dev(mb, protocol, party_id, dpub, n_public, witness_dev, db, n, st));   // :118-127
+  if (f == CSH_BN254) CSH_TRY(promote_t<Bn254Fr>(protocol, da, num_constraints, dpub, n_public, party_id, st));  // :111-113
+  else CSH_TRY(promote_t<Bls381Fr>(protocol, da, num_constraints, dpub, n_public, party_id, st));
   if (protocol == 1 && seed1 && seed2) {
-    CSH_TRY(h.up(dmc, nullptr, eb));
-    CSH_TRY(h.up(dmab, nullptr, eb));
-    CSH_TRY(csh_rep3_masks_dev(f, seed1, off1, seed2, off2, dmc, n, h.st));
-    CSH_TRY(csh_rep3_masks_dev(f, seed1, off1 + n, seed2, off2 + n, dmab, n, h.st));
+    dmc = reinterpret_cast<uint64_t*>(ar.take<char>(eb));
+    dmab = reinterpret_cast<uint64_t*>(ar.take<char>(eb));
+    CSH_TRY(csh_rep3_masks_dev(f, seed1, off1, seed2, off2, dmc, n, st));
+    CSH_TRY(csh_rep3_masks_dev(f, seed1, off1 + n, seed2, off2 + n, dmab, n, st));
   }
-  CSH_TRY(csh_groth16_h_dev(dom, shift, protocol, da, db, dmc, dmab, dh, h.st));
-  return h.down(h_out, dh, eb);
+  CSH_TRY(csh_groth16_h_dev(dom, shift, protocol, da, db, dmc, dmab, h_out_dev, st));
+  if (n_public) CSH_HIP(hipStreamSynchronize(st));  // public_inputs (host) must outlive the async copy
+  return CSH_OK;
+}
+
+int csh_groth16_witness_map(csh_domain_t dom, const uint64_t shift[4], int protocol, int party_id, csh_matrix_t ma, csh_matrix_t mb,
+                            size_t num_constraints, const uint64_t* public_inputs, size_t n_public, const uint64_t* witness, size_t n_witness,
+                            const uint8_t seed1[32], uint64_t off1, const uint8_t seed2[32], uint64_t off2, uint64_t* h_out) {
+  CSH_REQUIRE(dom && h_out && (witness || n_witness == 0), "witness_map: NULL argument");
+  CSH_REQUIRE(protocol == 0 || protocol == 1, "protocol must be 0 (plain/Shamir) or 1 (Rep3)");
+  const size_t n = domain_size_of(reinterpret_cast<const Domain*>(dom));
+  const size_t comp = protocol == 1 ? 2 : 1;
+  CSH_TRY(ensure_device());
+  hipStream_t st = resolve_stream(nullptr);
+  Arena& ar = arena_for((hipStream_t)((uintptr_t)st ^ 0x2));  // staging arena (the _dev core uses ^0x1 and the stream's own)
+  CSH_TRY(ar.reserve(Arena::padded(32 * comp * n_witness + 32) + Arena::padded(32 * n)));
+  uint64_t* dwit = reinterpret_cast<uint64_t*>(ar.take<char>(32 * comp * n_witness + 32));
+  uint64_t* dh = reinterpret_cast<uint64_t*>(ar.take<char>(32 * n));
+  if (n_witness) CSH_HIP(hipMemcpyAsync(dwit, witness, 32 * comp * n_witness, hipMemcpyHostToDevice, st));
+  CSH_TRY(csh_groth16_witness_map_dev(dom, shift, protocol, party_id, ma, mb, num_constraints, public_inputs, n_public, dwit, seed1, off1, seed2, off2,
+                                      dh, st));
+  CSH_HIP(hipMemcpyAsync(h_out, dh, 32 * n, hipMemcpyDeviceToHost, st));
+  CSH_HIP(hipStreamSynchronize(st));
+  return CSH_OK;
 }
 
 }  // extern "C"

@@ -67,6 +67,48 @@ struct DomainCache {
 
 // ---- R1CSToQAP: CircomReduction::witness_map_from_matrices (reduction.rs:77-193) ------------------------------
 struct CircomReduction {
+  static constexpr bool HAS_DEVICE_MAP = true;
+  template <class P>
+  static bool device_map_available(const ConstraintMatrices<P>& m) { return m.a_dev && m.b_dev && !getenv("COG16_HOST_EVAL"); }
+
+  // witness_map_from_matrices (reduction.rs:77-193) with the witness shares already uploaded and h left on the device:
+  // the h_query MSM (groth16.rs:286-292) consumes it in place. Same draws from the party's randomness as the host-facing
+  // variant below.
+  template <class P, class T>
+  static DeviceScalars witness_map_device(typename T::State& state, const ConstraintMatrices<P>& matrices,
+                                          const std::vector<typename P::Fr>& public_inputs, const DeviceScalars& witness_dev) {
+    using Fr = typename P::Fr;
+    const size_t num_constraints = matrices.num_constraints;
+    const size_t num_inputs = matrices.num_instance_variables;
+    size_t domain_size = 1, power = 0;
+    while (domain_size < num_constraints + num_inputs) {
+      domain_size <<= 1;
+      ++power;
+    }
+    if (power > (size_t)Fr::Params::TWO_ADICITY) throw Error("Polynomial Degree too large");  // :87-89
+    Span span_all("witness map from matrices (device resident)");
+    Fr group_gen, coset_shift;
+    groth16_roots_of_unity<Fr>(power, group_gen, coset_shift);                                  // :92
+    int rc = CSH_OK;
+    csh_domain_t domain = DomainCache::get().lookup(P::ID, (uint32_t)power, (const uint64_t*)&group_gen, &rc);  // :93
+    if (rc == CSH_ERR_DOMAIN) throw Error("Polynomial Degree too large");
+    check(rc, "csh_domain_create");
+    DeviceScalars h(domain_size);
+    if constexpr (T::DEVICE_MASKS) {
+      auto run = state.rand.take_device_run(2 * domain_size);
+      rc = csh_groth16_witness_map_dev(domain, (const uint64_t*)&coset_shift, T::PROTOCOL, state.id, matrices.a_dev, matrices.b_dev, num_constraints,
+                                       (const uint64_t*)public_inputs.data(), num_inputs, (const uint64_t*)witness_dev.dev, run.seed1, run.off1,
+                                       run.seed2, run.off2, (uint64_t*)h.dev, nullptr);
+    } else {
+      rc = csh_groth16_witness_map_dev(domain, (const uint64_t*)&coset_shift, T::PROTOCOL, state.id, matrices.a_dev, matrices.b_dev, num_constraints,
+                                       (const uint64_t*)public_inputs.data(), num_inputs, (const uint64_t*)witness_dev.dev, nullptr, 0, nullptr, 0,
+                                       (uint64_t*)h.dev, nullptr);
+    }
+    check(rc, "csh_groth16_witness_map_dev");
+    check(csh_sync(nullptr), "csh_sync");  // the MSM threads run on other streams
+    return h;
+  }
+
   template <class P, class T>
   static std::vector<typename T::ArithmeticHalfShare> witness_map_from_matrices(typename T::State& state, const ConstraintMatrices<P>& matrices,
                                                                                  const std::vector<typename P::Fr>& public_inputs,
@@ -190,15 +232,22 @@ struct CoGroth16 {
   static Proof<P> create_proof_with_assignment(const Net* net0, const Net* net1, State& state0, State& state1, const ProvingKey<P>& pkey,
                                                const Share& r, const Share& s, const std::vector<Half>& h,
                                                const std::vector<Fr>& input_assignment, const std::vector<Half>& aux_assignment) {
-    const Proj<Fq> delta_g1 = into_group(pkey.delta_g1);
-    const Proj<Fq2> delta_g2 = into_group(pkey.delta_g2);
-    const int id = state0.id;
-    std::vector<Fr> inputs(input_assignment.begin() + 1, input_assignment.end());  // &input_assignment[1..]
     // aux_assignment feeds four MSMs (A, B1, B2, L): upload it once; h feeds one
     Span* sp_up = new Span("upload aux_assignment + h");
     const DeviceScalars aux_dev(aux_assignment.data(), aux_assignment.size());
     const DeviceScalars h_dev(h.data(), h.size());
     delete sp_up;
+    return create_proof_device(net0, net1, state0, state1, pkey, r, s, h_dev, input_assignment, aux_dev);
+  }
+
+  // the same with h and aux_assignment already resident on the device
+  static Proof<P> create_proof_device(const Net* net0, const Net* net1, State& state0, State& state1, const ProvingKey<P>& pkey, const Share& r,
+                                      const Share& s, const DeviceScalars& h_dev, const std::vector<Fr>& input_assignment,
+                                      const DeviceScalars& aux_dev) {
+    const Proj<Fq> delta_g1 = into_group(pkey.delta_g1);
+    const Proj<Fq2> delta_g2 = into_group(pkey.delta_g2);
+    const int id = state0.id;
+    std::vector<Fr> inputs(input_assignment.begin() + 1, input_assignment.end());  // &input_assignment[1..]
     Proj<Fq> r_g1, s_g1, l_acc, h_acc;
     Proj<Fq2> s_g2;
     // rayon_join5 (:227-294): five independent MSM groups, issued from five host threads (the C ABI is re-entrant)
@@ -246,6 +295,31 @@ struct CoGroth16 {
     if (w.witness.size() != matrices.num_witness_variables)
       throw Error("amount of private witness variables does not match with provided constraint system! Expected " +
                   std::to_string(matrices.num_witness_variables) + ", but got " + std::to_string(w.witness.size()));
+    if constexpr (R::HAS_DEVICE_MAP) {
+      if (R::template device_map_available<P>(matrices)) {
+        // device-resident proof: the witness shares cross PCIe once, h never leaves the device unless asked for
+        constexpr size_t COMPS = sizeof(Share) / sizeof(Fr);
+        Span* sp_up = new Span("upload witness shares");
+        const DeviceScalars wit_dev(w.witness.data(), w.witness.size(), COMPS);
+        delete sp_up;
+        const DeviceScalars h_dev = R::template witness_map_device<P, T>(state0, matrices, w.public_inputs, wit_dev);
+        Share r = T::rand(net0, state0), s = T::rand(net0, state0);
+        if (r_in) r = *r_in;
+        if (s_in) s = *s_in;
+        if (h_out) {
+          h_out->resize(h_dev.n);
+          check(csh_memcpy_d2h(h_out->data(), h_dev.dev, h_dev.n * sizeof(Half)), "csh_memcpy_d2h");
+        }
+        if constexpr (std::is_same<Share, Half>::value) {
+          return create_proof_device(net0, net1, state0, state1, pkey, r, s, h_dev, w.public_inputs, wit_dev);
+        } else {
+          std::vector<Half> half(w.witness.size());
+          for (size_t i = 0; i < half.size(); ++i) half[i] = T::to_half_share(w.witness[i]);
+          const DeviceScalars aux_dev(half.data(), half.size());
+          return create_proof_device(net0, net1, state0, state1, pkey, r, s, h_dev, w.public_inputs, aux_dev);
+        }
+      }
+    }
     std::vector<Half> h = R::template witness_map_from_matrices<P, T>(state0, matrices, w.public_inputs, w.witness);
     Share r = T::rand(net0, state0), s = T::rand(net0, state0);
     if (r_in) r = *r_in;

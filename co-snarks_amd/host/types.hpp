@@ -17,6 +17,8 @@
 #include <string>
 #include <thread>
 #include <utility>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "../../include/cosnarks_hip.h"
@@ -83,18 +85,58 @@ inline void parallel_for(size_t n, size_t min_len, Fn fn) {
 }
 
 // scalars uploaded once and shared by several MSMs (the four queries that consume aux_assignment)
+// Device buffers are recycled across proofs: hipMalloc / hipFree cost 0.1-1 ms each (hipFree also drains the device),
+// a prover asks for the same few sizes every time.
+struct DevicePool {
+  std::mutex mu;
+  std::multimap<size_t, void*> free_;
+  static DevicePool& get() {
+    static DevicePool p;
+    return p;
+  }
+  void* take(size_t bytes, size_t* cap) {
+    {
+      std::lock_guard<std::mutex> g(mu);
+      auto it = free_.lower_bound(bytes);
+      if (it != free_.end() && it->first <= 2 * bytes + (size_t(1) << 20)) {
+        void* p = it->second;
+        *cap = it->first;
+        free_.erase(it);
+        return p;
+      }
+    }
+    void* p = nullptr;
+    check(csh_malloc(&p, bytes), "csh_malloc");
+    *cap = bytes;
+    return p;
+  }
+  void give(void* p, size_t cap) {
+    std::lock_guard<std::mutex> g(mu);
+    free_.emplace(cap, p);
+  }
+  void trim() {
+    std::lock_guard<std::mutex> g(mu);
+    for (auto& kv : free_) csh_free(kv.second);
+    free_.clear();
+  }
+};
+
+// n field elements (32 * comps bytes each) on the device; the buffer returns to the pool on destruction, so all work
+// reading it must have completed (csh_msm_dev is synchronous; async producers are followed by csh_sync).
 struct DeviceScalars {
   void* dev = nullptr;
   size_t n = 0;
+  size_t cap = 0;
   DeviceScalars() = default;
-  DeviceScalars(const void* host, size_t count) : n(count) {
-    check(csh_malloc(&dev, count * 32 + 32), "csh_malloc");
-    if (count) check(csh_memcpy_h2d(dev, host, count * 32), "csh_memcpy_h2d");
+  explicit DeviceScalars(size_t count, size_t comps = 1) : n(count) { dev = DevicePool::get().take(count * comps * 32 + 32, &cap); }
+  DeviceScalars(const void* host, size_t count, size_t comps = 1) : DeviceScalars(count, comps) {
+    if (count) check(csh_memcpy_h2d(dev, host, count * comps * 32), "csh_memcpy_h2d");
   }
   DeviceScalars(const DeviceScalars&) = delete;
   DeviceScalars& operator=(const DeviceScalars&) = delete;
+  DeviceScalars(DeviceScalars&& o) noexcept : dev(o.dev), n(o.n), cap(o.cap) { o.dev = nullptr; }
   ~DeviceScalars() {
-    if (dev) csh_free(dev);
+    if (dev) DevicePool::get().give(dev, cap);
   }
 };
 

@@ -209,6 +209,12 @@ int csh_groth16_witness_map(csh_domain_t dom, const uint64_t shift[4], int proto
                             size_t num_constraints, const uint64_t* public_inputs, size_t n_public, const uint64_t* witness,
                             size_t n_witness, const uint8_t seed1[32], uint64_t elem_offset1, const uint8_t seed2[32],
                             uint64_t elem_offset2, uint64_t* h_out);
+/* Same with the witness shares already on the device and h left on the device (feeds csh_msm_dev of h_query directly,
+ * groth16.rs:286-292): no PCIe traffic besides the n_public public inputs (host pointer). */
+int csh_groth16_witness_map_dev(csh_domain_t dom, const uint64_t shift[4], int protocol, int party_id, csh_matrix_t a, csh_matrix_t b,
+                                size_t num_constraints, const uint64_t* public_inputs, size_t n_public, const uint64_t* witness_dev,
+                                const uint8_t seed1[32], uint64_t elem_offset1, const uint8_t seed2[32], uint64_t elem_offset2,
+                                uint64_t* h_out_dev, void* stream);
 
 /* ---- measurement hooks (bench.py / profiles) ----------------------------------------------------------
  * HIP-event timing on the stream the kernels are launched on. */
