@@ -28,6 +28,8 @@ sys.path.insert(0, ROOT)
 # x2 FETCH_SIZE correction applied to 64-byte gathers (raw counter: 2.0 GB), the sorted-index reads, the partial
 # writes (0.4 GB) and register spill traffic of the rare-path calls.
 PMC_TRAFFIC_BYTES = {20: 4409337024}
+MADS_PER_MADD = 1467   # 10 products (6 mul 81 + 2 sqr 45 + fused 2x81) + 9 Montgomery reductions x 81, 9-limb 29-bit field
+MAD_PEAK_T = 31.0      # measured v_mad_u64_u32 issue rate, T lane-ops/s
 
 
 def secondary_metrics(hip, B, L, C, np, torch, dev, stream):
@@ -194,6 +196,7 @@ def main():
             acc.append(B.msm_last_timing())
         del os.environ["CSH_MSM_TIMING"]
         stage_ms = [float(np.mean([a[i] for a in acc])) for i in range(6)]
+        c_bits, n_win, lane_len, n_seg = B.msm_last_params()
         t_acc = stage_ms[3] * 1e-3
         alg_bytes = n * 96.0                                 # 32 B scalar + 64 B affine base per point
         achieved = alg_bytes / t_acc / 1e9
@@ -203,7 +206,14 @@ def main():
         roofline = {"bound": "hbm", "kernel": "k_msm_accum<Bn254G1>", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                     "frac": round(achieved / 8000.0, 5), "traffic": traffic,
                     "traffic_source": "profiles/r01_d_msm_bn254g1_2p20_pmc_hbm_bytes.csv" if traffic else None,
-                    "note": "MSM is integer-ALU (v_mad_u64_u32) bound, not HBM bound; see DESIGN.md",
+                    "note": "MSM is integer-ALU (v_mad_u64_u32 / v_mad_i64_i32) bound, not HBM bound; see DESIGN.md 3.1",
+                    # integer roofline of the same kernel: mixed additions x 64-bit multiply-adds per addition (ISA count of
+                    # the k_msm_accum<Bn254G1> loop body) over the measured issue peak of those instructions
+                    # (tools/gpu_probe.py microbench, profiles/*probe*: 31e12 lane-ops/s)
+                    "alu": {"unit": "Tmad/s", "achieved": round(n * n_win * MADS_PER_MADD / t_acc / 1e12, 2), "peak": MAD_PEAK_T,
+                            "frac": round(n * n_win * MADS_PER_MADD / t_acc / 1e12 / MAD_PEAK_T, 3), "mads_per_madd": MADS_PER_MADD,
+                            "madds_per_s": round(n * n_win / t_acc, 0)},
+                    "msm_params": {"c": c_bits, "windows": n_win, "lane_len": lane_len, "segments": n_seg},
                     "stage_ms": {"hist": stage_ms[0], "scan": stage_ms[1], "scatter": stage_ms[2], "accum": stage_ms[3],
                                  "reduce": stage_ms[4], "total_device": stage_ms[5]}}
 

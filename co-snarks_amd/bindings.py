@@ -201,6 +201,13 @@ def msm_last_timing():
     return list(out)
 
 
+def msm_last_params():
+    """[window bits c, windows W, entries per lane L, reduction segments S] of the last MSM on this thread."""
+    out = (C.c_uint32 * 4)()
+    _check(lib().csh_msm_last_params(out))
+    return list(out)
+
+
 class Domain:
     """taceo_ark_algebra::fft::Domain equivalent: csh_domain_create + transforms."""
 

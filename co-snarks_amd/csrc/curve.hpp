@@ -85,7 +85,7 @@ CSH_HD void xyzz_madd(XYZZ<F>& acc, const Affine<F>& p) {
 }
 
 template <class F>
-CSH_HD_NOINLINE XYZZ<F> xyzz_dbl(XYZZ<F> p) {
+CSH_HD XYZZ<F> xyzz_dbl_inl(const XYZZ<F>& p) {
   if (p.is_inf() || p.y.is_zero()) return XYZZ<F>::inf();
   F u = F::mul2(p.y);
   F v = F::sqr(u);
@@ -98,6 +98,10 @@ CSH_HD_NOINLINE XYZZ<F> xyzz_dbl(XYZZ<F> p) {
   r.zz = F::mul(v, p.zz);
   r.zzz = F::mul(w, p.zzz);
   return r;
+}
+template <class F>
+CSH_HD_NOINLINE XYZZ<F> xyzz_dbl(XYZZ<F> p) {
+  return xyzz_dbl_inl(p);
 }
 
 template <class F>

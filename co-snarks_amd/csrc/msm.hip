@@ -22,6 +22,7 @@
 #include "common.hpp"
 #include "curve.hpp"
 #include "curve_lazy.hpp"
+#include "host_fp64.hpp"
 #include "msm_digits.hpp"
 #include "msm_sort.hpp"
 
@@ -282,6 +283,7 @@ __global__ void k_msm_gather_windows(const LazyPt<Cfg>* segres, uint32_t stride,
 
 // ---- host side -----------------------------------------------------------------------------------------
 static thread_local float tl_msm_timing[6] = {0, 0, 0, 0, 0, 0};
+static thread_local uint32_t tl_msm_params[4] = {0, 0, 0, 0};  // c, W, L, S of the last MSM
 
 
 static int choose_c(size_t n, int bits) {
@@ -341,6 +343,10 @@ static int msm_windows_dev(const Bases* B, size_t offset, size_t n, const uint64
     p.chunk_len = (uint32_t)((n + ch - 1) / ch);
   }
   *p_out = p;
+  tl_msm_params[0] = (uint32_t)p.c;
+  tl_msm_params[1] = (uint32_t)p.W;
+  tl_msm_params[2] = p.L;
+  tl_msm_params[3] = p.S;
 
   const size_t len = (size_t)p.NB + 2;
   Arena& ar = arena_for(st);
@@ -422,16 +428,18 @@ static int msm_windows_dev(const Bases* B, size_t offset, size_t n, const uint64
   return CSH_OK;
 }
 
-// Horner over window sums + affine normalisation -> arkworks Projective (x, y, 1) / (1, 1, 0)
+// Horner over window sums + affine normalisation -> arkworks Projective (x, y, 1) / (1, 1, 0). Runs on the host in
+// 64-bit limbs (host_fp64.hpp): W*c sequential doublings are latency, not throughput, and a CPU core does them faster.
+template <class F>
+static XYZZ<F> horner_windows(const XYZZ<F>* wins, int W, int c);
 template <class Fq>
-static void fold_windows_host(const XYZZ<Fq>* wins, int W, int c, void* out_jacobian) {
-  XYZZ<Fq> acc = XYZZ<Fq>::inf();
-  for (int w = W - 1; w >= 0; --w) {
-    for (int k = 0; k < c; ++k) acc = xyzz_dbl(acc);
-    xyzz_add(acc, wins[w]);
-  }
-  Affine<Fq> a = xyzz_to_affine(acc);
-  Jac<Fq> j = a.is_inf() ? Jac<Fq>::inf() : Jac<Fq>{a.x, a.y, Fq::one()};
+static void fold_windows_host(const XYZZ<Fq>* wins32, int W, int c, void* out_jacobian) {
+  using F = typename Host64<Fq>::type;
+  static_assert(sizeof(XYZZ<F>) == sizeof(XYZZ<Fq>) && sizeof(Jac<F>) == sizeof(Jac<Fq>), "64-bit view must alias the device encoding");
+  std::vector<XYZZ<F>> wins(W);
+  memcpy((void*)wins.data(), wins32, sizeof(XYZZ<F>) * W);
+  Affine<F> a = xyzz_to_affine(horner_windows<F>(wins.data(), W, c));
+  Jac<F> j = a.is_inf() ? Jac<F>::inf() : Jac<F>{a.x, a.y, F::one()};
   memcpy(out_jacobian, &j, sizeof(j));
 }
 
@@ -474,11 +482,27 @@ static int msm_partial_t(const Bases* B, size_t offset, size_t n, const uint64_t
   return CSH_OK;
 }
 
+// Horner value (not yet normalised) of one set of window sums, 64-bit host limbs
+template <class F>
+static XYZZ<F> horner_windows(const XYZZ<F>* wins, int W, int c) {
+  XYZZ<F> acc = XYZZ<F>::inf();
+  for (int w = W - 1; w >= 0; --w) {
+    for (int k = 0; k < c; ++k) acc = xyzz_dbl_inl(acc);
+    acc = xyzz_add_inl(acc, wins[w]);
+  }
+  return acc;
+}
+
 template <class Cfg>
 static int fold_partials_t(const void* partials_host, size_t nparts, void* out_jacobian) {
   using Fq = typename Cfg::Fq;
+  using F = typename Host64<Fq>::type;
   const size_t stride = sizeof(PartialHeader) + sizeof(XYZZ<Fq>) * MAX_WINDOWS;
-  XYZZ<Fq> total = XYZZ<Fq>::inf();
+  XYZZ<F> total = XYZZ<F>::inf();
+  // partials with the same window layout (the usual case: equal shares per rank) are summed window by window first,
+  // so the W*c doublings are paid once
+  std::vector<XYZZ<F>> sum;
+  uint32_t sum_c = 0, sum_W = 0;
   for (size_t k = 0; k < nparts; ++k) {
     const char* base = static_cast<const char*>(partials_host) + k * stride;
     PartialHeader h;
@@ -486,17 +510,21 @@ static int fold_partials_t(const void* partials_host, size_t nparts, void* out_j
     CSH_REQUIRE(h.magic == PARTIAL_MAGIC, "fold_partials: bad partial header");
     if (h.W == 0) continue;
     CSH_REQUIRE(h.W <= (uint32_t)MAX_WINDOWS && h.c >= 2 && h.c <= 22, "fold_partials: bad window parameters");
-    std::vector<XYZZ<Fq>> wins(h.W);
-    memcpy(wins.data(), base + sizeof h, sizeof(XYZZ<Fq>) * h.W);
-    XYZZ<Fq> acc = XYZZ<Fq>::inf();
-    for (int w = (int)h.W - 1; w >= 0; --w) {
-      for (uint32_t i = 0; i < h.c; ++i) acc = xyzz_dbl(acc);
-      xyzz_add(acc, wins[w]);
+    std::vector<XYZZ<F>> wins(h.W);
+    memcpy((void*)wins.data(), base + sizeof h, sizeof(XYZZ<F>) * h.W);
+    if (sum.empty()) {
+      sum.swap(wins);
+      sum_c = h.c;
+      sum_W = h.W;
+    } else if (h.c == sum_c && h.W == sum_W) {
+      for (uint32_t w = 0; w < h.W; ++w) sum[w] = xyzz_add_inl(sum[w], wins[w]);
+    } else {
+      total = xyzz_add_inl(total, horner_windows<F>(wins.data(), (int)h.W, (int)h.c));
     }
-    xyzz_add(total, acc);
   }
-  Affine<Fq> a = xyzz_to_affine(total);
-  Jac<Fq> j = a.is_inf() ? Jac<Fq>::inf() : Jac<Fq>{a.x, a.y, Fq::one()};
+  if (!sum.empty()) total = xyzz_add_inl(total, horner_windows<F>(sum.data(), (int)sum_W, (int)sum_c));
+  Affine<F> a = xyzz_to_affine(total);
+  Jac<F> j = a.is_inf() ? Jac<F>::inf() : Jac<F>{a.x, a.y, F::one()};
   memcpy(out_jacobian, &j, sizeof(j));
   return CSH_OK;
 }
@@ -653,6 +681,12 @@ int csh_msm_partial_dev(csh_bases_t bases, size_t offset, size_t n, const uint64
 int csh_msm_fold_partials(csh_curve_t curve, csh_group_t group, const void* partials_host, size_t nparts, void* out_jacobian) {
   CSH_REQUIRE(partials_host && out_jacobian, "NULL argument");
   CURVE_DISPATCH(curve, group, (fold_partials_t<Cfg>(partials_host, nparts, out_jacobian)));
+}
+
+int csh_msm_last_params(uint32_t out[4]) {
+  CSH_REQUIRE(out, "out is NULL");
+  for (int i = 0; i < 4; ++i) out[i] = tl_msm_params[i];
+  return CSH_OK;
 }
 
 int csh_msm_last_timing(float out_ms[6]) {

@@ -225,6 +225,9 @@ int csh_event_destroy(void* ev);
 /* Per-MSM stage timings (ms) of the last csh_msm*_dev call on this thread: [digits+histogram, scan,
  * scatter, bucket accumulate, bucket reduce, total]; valid only when CSH_MSM_TIMING=1 in the env. */
 int csh_msm_last_timing(float out_ms[6]);
+/* Pipeline parameters of the last csh_msm*_dev call on this thread: [window bits c, windows W, entries per lane L,
+ * reduction segments S]. */
+int csh_msm_last_params(uint32_t out[4]);
 
 /* ---- synthetic inputs (bench / full-size parity) -------------------------------------------------------
  * out[i] = k_i * G (affine, packed), k_i = csh_util_splitmix64(seed + i) | 1: known discrete logs, so an MSM

@@ -258,3 +258,53 @@ def test_rep3_mask_generator_matches_rngs_rs(hip, curve):
         a = chacha.keystream(s1, 32 * n, start_byte=32 * e1)
         b = chacha.keystream(s2, 32 * n, start_byte=32 * e2)
         assert H.unpack(F, out) == mpc.masks_from_streams(F, a, b, n)
+
+@pytest.mark.parametrize("curve,group", [("bn254", 0), ("bn254", 1), ("bls12_381", 0), ("bls12_381", 1)])
+def test_host_window_fold_64bit_limbs(hip, curve, group):
+    """csh_msm_fold_partials (host only: Horner over window sums in 64-bit limbs, host_fp64.hpp) for every group:
+    two partials with the same layout (summed window-wise first), one with another layout, one empty."""
+    import struct
+    G = cv.CURVES[curve][group]
+    cid = H.CURVE_IDS[curve]
+    r = H.rng(404 + group)
+    pb = hip.point_bytes(cid, group)                 # affine bytes; an XYZZ entry is twice that
+    one = cv.pack_points(G, [G.gen])                 # only used for its shape
+    F = G.F
+    base = F.base if hasattr(F, "base") else F
+
+    def xyzz(P):
+        if P is None:
+            return bytes(2 * pb)
+        xy = cv.pack_points(G, [P]).tobytes()
+        k = F.ncoeff()
+        mont_one = base.to_mont(1).to_bytes(base.nbytes, "little") + bytes(base.nbytes * (k - 1))
+        return xy + mont_one + mont_one
+
+    hdr_len = hip.msm_partial_bytes(cid, group) - 128 * 2 * pb
+
+    def partial(c, pts):
+        hdr = struct.pack("<4I", 0x4D534D50, c, len(pts), 0).ljust(hdr_len, b"\0")
+        return hdr + b"".join(xyzz(P) for P in pts) + bytes(2 * pb * (128 - len(pts)))
+
+    def horner(c, pts):
+        acc = None
+        for P in reversed(pts):
+            for _ in range(c):
+                acc = G.add(acc, acc)
+            acc = G.add(acc, P)
+        return acc
+
+    pa = [G.mul(G.gen, r.randrange(1, 1 << 64)) for _ in range(5)]
+    pb_ = [G.mul(G.gen, r.randrange(1, 1 << 64)) for _ in range(5)]
+    pb_[2] = None                                    # an empty window
+    pc = [G.mul(G.gen, r.randrange(1, 1 << 64)) for _ in range(3)]
+    empty = partial(0, [])
+    buf = partial(7, pa) + partial(7, pb_) + empty + partial(11, pc)
+    want = G.add(G.add(horner(7, pa), horner(7, pb_)), horner(11, pc))
+    out = np.zeros(3 * pb // 16, dtype=np.uint64)
+    assert hip.lib().csh_msm_fold_partials(cid, group, buf, C.c_size_t(4), out.ctypes.data_as(C.c_void_p)) == 0
+    assert G.eq(H.jac_to_affine(G, out), want)
+    # P + (-P) -> infinity encoding (1, 1, 0)
+    buf = partial(7, pa) + partial(7, [G.neg(P) for P in pa])
+    assert hip.lib().csh_msm_fold_partials(cid, group, buf, C.c_size_t(2), out.ctypes.data_as(C.c_void_p)) == 0
+    assert H.jac_to_affine(G, out) is None
