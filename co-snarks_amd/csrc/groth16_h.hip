@@ -2,9 +2,28 @@
 // evaluations a, b. Mirrors co-circom/co-groth16/src/groth16/reduction.rs:135-192 step by step
 // (6 NTTs, 2 local_mul_vec, 3 coset-table multiplications, 1 subtraction) on one HIP stream, so a proof
 // needs one upload of a, b (+ masks) and one download of h instead of 12 host<->device round trips.
+#include <string.h>
+
 #include "common.hpp"
+#include "field.hpp"
 
 using namespace csh;
+
+namespace {
+template <class F>
+int libsnark_consts(const uint64_t gen_words[4], size_t n, uint64_t v[4], uint64_t neg_v[4], uint64_t g_inv[4]) {
+  F g;
+  memcpy(&g, gen_words, sizeof g);
+  F gn = F::pow_u64(g, (uint64_t)n);
+  F d = F::sub(gn, F::one());
+  if (d.is_zero()) return CSH_ERR_INVALID;
+  F vi = F::inv(d), nv = F::neg(vi), gi = F::inv(g);
+  memcpy(v, &vi, 32);
+  memcpy(neg_v, &nv, 32);
+  memcpy(g_inv, &gi, 32);
+  return CSH_OK;
+}
+}  // namespace
 
 extern "C" {
 
@@ -82,6 +101,78 @@ int csh_groth16_h_rep3_seeded(csh_domain_t dom, const uint64_t shift[4], uint64_
   CSH_TRY(csh_rep3_masks_dev(f, seed1, off1, seed2, off2, dmc, n, h.st));
   CSH_TRY(csh_rep3_masks_dev(f, seed1, off1 + n, seed2, off2 + n, dmab, n, h.st));
   CSH_TRY(csh_groth16_h_dev(dom, shift, 1, da, db, dmc, dmab, dh, h.st));
+  return h.down(h_out, dh, eb);
+}
+
+// ---- LibSnarkReduction tail (reduction.rs:255-342) --------------------------------------------------------------
+// a, b: constraint evaluations (ncomp per entry), c: half-share evaluations of the C matrix (1 component), all natural
+// order over the arkworks domain. h = coefficients (natural order) of (A*B - C) / Z: three coset evaluations, one
+// local_mul_vec, (ab - c) * (g^n - 1)^-1, interpolation over the coset, un-shift. The reference bit-reverses before it
+// multiplies by g^-i sequentially (:327-340); multiplying the bit-reversed vector by the bit-reversed power table and
+// permuting afterwards gives the same field elements.
+
+int csh_groth16_h_libsnark_dev(csh_domain_t dom, const uint64_t generator[4], int protocol, uint64_t* a, uint64_t* b, uint64_t* c,
+                               const uint64_t* mask, uint64_t* h_out, void* stream) {
+  CSH_REQUIRE(dom && generator && a && b && c && h_out, "NULL argument");
+  CSH_REQUIRE(protocol == 0 || protocol == 1, "protocol must be 0 (plain/Shamir) or 1 (Rep3)");
+  CSH_TRY(ensure_device());
+  const Domain* d = reinterpret_cast<const Domain*>(dom);
+  const size_t n = domain_size_of(d);
+  const csh_curve_t f = domain_curve_of(d);
+  const uint32_t ncomp = protocol == 1 ? 2 : 1;
+  uint32_t log_n = 0;
+  while ((size_t(1) << log_n) < n) ++log_n;
+  uint64_t v[4], neg_v[4], g_inv[4];
+  const int crc = f == CSH_BN254 ? libsnark_consts<Bn254Fr>(generator, n, v, neg_v, g_inv) : libsnark_consts<Bls381Fr>(generator, n, v, neg_v, g_inv);
+  CSH_REQUIRE(crc == CSH_OK, "libsnark reduction: the coset generator lies in the domain (g^n == 1)");
+  hipStream_t st = resolve_stream(stream);
+  Arena& ar = arena_for((hipStream_t)((uintptr_t)st ^ 0x4));
+  CSH_TRY(ar.reserve(Arena::padded(32 * n)));
+  uint64_t* table = ar.take<uint64_t>(4 * n);
+
+  CSH_TRY(ntt_coset_table(d, generator, table, st));                                         // reduction.rs:255
+  for (uint64_t* x : {a, b}) {                                                               // :270-272, :283-285
+    CSH_TRY(ntt_run(d, x, ncomp, true, st));
+    CSH_TRY(csh_vec_mul_table_dev(f, x, table, n, ncomp, st));
+    CSH_TRY(ntt_run(d, x, ncomp, false, st));
+  }
+  if (protocol == 1)
+    CSH_TRY(csh_rep3_local_mul_vec_dev(f, a, b, mask, h_out, n, st));                        // :289
+  else
+    CSH_TRY(csh_vec_mul_dev(f, a, b, h_out, n, st));
+  CSH_TRY(ntt_run(d, c, 1, true, st));                                                       // :299
+  CSH_TRY(csh_vec_mul_table_dev(f, c, table, n, 1, st));                                     // :300-305
+  CSH_TRY(ntt_run(d, c, 1, false, st));                                                      // :306
+  {                                                                                          // :311-322: (ab - c) * (g^n - 1)^-1
+    const uint64_t* ptrs[2] = {h_out, c};
+    uint64_t coeffs[8];
+    memcpy(coeffs, v, 32);
+    memcpy(coeffs + 4, neg_v, 32);
+    CSH_TRY(csh_lincomb_dev(f, ptrs, coeffs, 2, h_out, n, st));
+  }
+  CSH_TRY(ntt_run(d, h_out, 1, true, st));                                                   // :327
+  CSH_TRY(ntt_coset_table(d, g_inv, table, st));                                             // :329-340 (see header note)
+  CSH_TRY(csh_vec_mul_table_dev(f, h_out, table, n, 1, st));
+  CSH_TRY(ntt_bit_reverse(f, h_out, log_n, 1, st));                                          // :328
+  return CSH_OK;
+}
+
+int csh_groth16_h_libsnark(csh_domain_t dom, const uint64_t generator[4], int protocol, uint64_t* a, uint64_t* b, uint64_t* c,
+                           const uint64_t* mask, uint64_t* h_out) {
+  CSH_REQUIRE(dom && generator && a && b && c && h_out, "NULL argument");
+  CSH_REQUIRE(protocol == 0 || protocol == 1, "protocol must be 0 (plain/Shamir) or 1 (Rep3)");
+  const Domain* d = reinterpret_cast<const Domain*>(dom);
+  const size_t n = domain_size_of(d);
+  const size_t sb = 32 * n * (protocol == 1 ? 2 : 1), eb = 32 * n;
+  HostStage h;
+  CSH_TRY(h.begin(2 * Arena::padded(sb) + 3 * Arena::padded(eb)));
+  uint64_t *da, *db, *dc, *dm = nullptr, *dh;
+  CSH_TRY(h.up(da, a, sb));
+  CSH_TRY(h.up(db, b, sb));
+  CSH_TRY(h.up(dc, c, eb));
+  if (mask) CSH_TRY(h.up(dm, mask, eb));
+  CSH_TRY(h.up(dh, nullptr, eb));
+  CSH_TRY(csh_groth16_h_libsnark_dev(dom, generator, protocol, da, db, dc, dm, dh, h.st));
   return h.down(h_out, dh, eb);
 }
 

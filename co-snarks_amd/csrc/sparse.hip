@@ -206,4 +206,48 @@ int csh_groth16_witness_map(csh_domain_t dom, const uint64_t shift[4], int proto
   return CSH_OK;
 }
 
+// LibSnarkReduction::witness_map_from_matrices (reduction.rs:241-342) on the device: a, b as above; c through
+// evaluate_constraint_half_share (mpc/rep3.rs:51-74: the `a` component of the full-share row kernel, public terms on
+// party 0 only; plain / Shamir: the row value itself), then csh_groth16_h_libsnark_dev. One mask vector (one local_mul_vec).
+int csh_groth16_witness_map_libsnark(csh_domain_t dom, const uint64_t generator[4], int protocol, int party_id, csh_matrix_t ma, csh_matrix_t mb,
+                                     csh_matrix_t mc, size_t num_constraints, const uint64_t* public_inputs, size_t n_public,
+                                     const uint64_t* witness, size_t n_witness, const uint8_t seed1[32], uint64_t off1, const uint8_t seed2[32],
+                                     uint64_t off2, uint64_t* h_out) {
+  CSH_REQUIRE(dom && generator && ma && mb && mc && h_out && (public_inputs || n_public == 0) && (witness || n_witness == 0),
+              "witness_map_libsnark: NULL argument");
+  CSH_REQUIRE(protocol == 0 || protocol == 1, "protocol must be 0 (plain/Shamir) or 1 (Rep3)");
+  const Domain* d = reinterpret_cast<const Domain*>(dom);
+  const size_t n = domain_size_of(d);
+  const csh_curve_t f = domain_curve_of(d);
+  CSH_REQUIRE(num_constraints + n_public <= n, "Polynomial Degree too large");
+  const size_t comp = protocol == 1 ? 2 : 1;
+  const size_t sb = 32 * n * comp, eb = 32 * n;
+  HostStage h;
+  CSH_TRY(h.begin(3 * Arena::padded(sb) + 3 * Arena::padded(eb) + Arena::padded(32 * n_public + 32) + Arena::padded(32 * comp * n_witness + 32)));
+  uint64_t *da, *db, *dcf, *dc, *dm = nullptr, *dh, *dpub, *dwit;
+  CSH_TRY(h.up(da, nullptr, sb));
+  CSH_TRY(h.up(db, nullptr, sb));
+  CSH_TRY(h.up(dcf, nullptr, sb));
+  CSH_TRY(h.up(dh, nullptr, eb));
+  CSH_TRY(h.up(dpub, public_inputs, 32 * n_public));
+  CSH_TRY(h.up(dwit, witness, 32 * comp * n_witness));
+  CSH_TRY(csh_evaluate_constraints_dev(ma, protocol, party_id, dpub, n_public, dwit, da, n, h.st));    // reduction.rs:260-266
+  if (f == CSH_BN254) CSH_TRY(promote_t<Bn254Fr>(protocol, da, num_constraints, dpub, n_public, party_id, h.st));  // :267-269
+  else CSH_TRY(promote_t<Bls381Fr>(protocol, da, num_constraints, dpub, n_public, party_id, h.st));
+  CSH_TRY(csh_evaluate_constraints_dev(mb, protocol, party_id, dpub, n_public, dwit, db, n, h.st));    // :276-282
+  CSH_TRY(csh_evaluate_constraints_dev(mc, protocol, party_id, dpub, n_public, dwit, dcf, n, h.st));   // :292-298
+  if (protocol == 1) {  // half share = component a
+    CSH_TRY(h.up(dc, nullptr, eb));
+    CSH_HIP(hipMemcpy2DAsync(dc, 32, dcf, 64, 32, n, hipMemcpyDeviceToDevice, h.st));
+    if (seed1 && seed2) {
+      CSH_TRY(h.up(dm, nullptr, eb));
+      CSH_TRY(csh_rep3_masks_dev(f, seed1, off1, seed2, off2, dm, n, h.st));
+    }
+  } else {
+    dc = dcf;
+  }
+  CSH_TRY(csh_groth16_h_libsnark_dev(dom, generator, protocol, da, db, dc, dm, dh, h.st));
+  return h.down(h_out, dh, eb);
+}
+
 }  // extern "C"

@@ -72,3 +72,48 @@ def bench_synthetic(curve: int, log_domain: int, iters: int = 3):
         raise CoSnarksHipError(glib().cog16_last_error().decode())
     return {"log_domain": log_domain, "witness_map_ms": ms[0], "create_proof_ms": ms[1], "prove_ms": ms[2],
             "key_setup_ms": ms[3], "closed_form_check": bool(ok.value)}
+
+
+CIRCOM_REDUCTION, LIBSNARK_REDUCTION = 0, 1
+
+
+def witness_map(curve: int, reduction: int, rep3: bool, matrices, n_instance: int, witness_mont: np.ndarray, seed: int = 1):
+    """R1CSToQAP::witness_map_from_matrices of the host mirror (CircomReduction / LibSnarkReduction) on explicit matrices.
+    matrices = (A, B, C) rows of (Montgomery coeff limbs as 4-tuple of u64 | int already in Montgomery form, column);
+    C may be None for the circom reduction. witness_mont: (n_vars, 4) u64 Montgomery limbs of public || private values.
+    Returns h limbs: (n, 4) plain, or (3, n, 4) half-share vectors of the three Rep3 parties."""
+    n_rows = len(matrices[0])
+    keep = []
+    rp = (C.POINTER(C.c_uint64) * 3)()
+    cl = (C.POINTER(C.c_uint32) * 3)()
+    cf = (C.POINTER(C.c_uint64) * 3)()
+    for k, m in enumerate(matrices):
+        if m is None:
+            continue
+        assert len(m) == n_rows
+        row_ptr = np.zeros(n_rows + 1, dtype=np.uint64)
+        cols, vals = [], []
+        for i, row in enumerate(m):
+            for coeff, idx in row:
+                cols.append(idx)
+                vals.append([(int(coeff) >> (64 * j)) & (2**64 - 1) for j in range(4)])
+            row_ptr[i + 1] = len(cols)
+        col = np.array(cols, dtype=np.uint32)
+        val = np.array(vals, dtype=np.uint64).reshape(-1, 4)
+        keep += [row_ptr, col, val]
+        rp[k] = row_ptr.ctypes.data_as(C.POINTER(C.c_uint64))
+        cl[k] = col.ctypes.data_as(C.POINTER(C.c_uint32))
+        cf[k] = val.ctypes.data_as(C.POINTER(C.c_uint64))
+    w = np.ascontiguousarray(witness_mont, dtype=np.uint64).reshape(-1, 4)
+    n = 1
+    while n < n_rows + n_instance:
+        n *= 2
+    out = np.zeros((3 if rep3 else 1) * n * 4, dtype=np.uint64)
+    rc = glib().cog16_witness_map(curve, reduction, int(rep3), rp, cl, cf, C.c_size_t(n_rows), C.c_size_t(n_instance),
+                                  w.ctypes.data_as(C.c_void_p), C.c_size_t(len(w)), C.c_uint64(seed), out.ctypes.data_as(C.c_void_p),
+                                  C.c_size_t(len(out) // 4))
+    if rc < 0:
+        raise CoSnarksHipError(glib().cog16_last_error().decode())
+    assert rc == n
+    return out.reshape(3, n, 4) if rep3 else out.reshape(n, 4)
+

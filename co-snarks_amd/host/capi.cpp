@@ -338,9 +338,113 @@ int bench_synth_t(int log_domain, int iters, double* out_ms, int* check_ok, cons
   return 0;
 }
 
+// witness_map_from_matrices of either reduction on caller-supplied matrices (CSR) and a full witness: plain (mode 0) or
+// three in-process Rep3 parties (mode 1; h_out receives the three parties' half-share vectors back to back).
+template <class P>
+int witness_map_t(int reduction, int mode, const uint64_t* const row_ptr[3], const uint32_t* const col[3], const uint64_t* const coef[3],
+                  size_t n_rows, size_t n_instance, const uint64_t* witness_full, size_t n_vars, uint64_t seed, uint64_t* h_out, size_t h_cap) {
+  using Fr = typename P::Fr;
+  ConstraintMatrices<P> m;
+  m.num_instance_variables = n_instance;
+  m.num_witness_variables = n_vars - n_instance;
+  m.num_constraints = n_rows;
+  auto fill = [&](int k, std::vector<std::vector<std::pair<Fr, size_t>>>& dst) {
+    if (!row_ptr[k]) return;
+    dst.resize(n_rows);
+    for (size_t i = 0; i < n_rows; ++i)
+      for (uint64_t e = row_ptr[k][i]; e < row_ptr[k][i + 1]; ++e) {
+        Fr c;
+        memcpy(&c, coef[k] + 4 * e, 32);
+        dst[i].push_back({c, (size_t)col[k][e]});
+      }
+  };
+  fill(0, m.a);
+  fill(1, m.b);
+  fill(2, m.c);
+  m.upload();
+  std::vector<Fr> w(n_vars);
+  memcpy(w.data(), witness_full, 32 * n_vars);
+  std::vector<Fr> pub(w.begin(), w.begin() + n_instance);
+  auto run = [&](auto driver_tag, auto& state, const auto& wit) {
+    using T = decltype(driver_tag);
+    if (reduction == 0) return CircomReduction::witness_map_from_matrices<P, T>(state, m, pub, wit);
+    return LibSnarkReduction::witness_map_from_matrices<P, T>(state, m, pub, wit);
+  };
+  if (mode == 0) {
+    UnitState st;
+    std::vector<Fr> wit(w.begin() + n_instance, w.end());
+    std::vector<Fr> h = run(PlainGroth16Driver<P>{}, st, wit);
+    if (h.size() > h_cap) throw Error("h_out too small");
+    memcpy(h_out, h.data(), 32 * h.size());
+    return (int)h.size();
+  }
+  using Share = Rep3PrimeFieldShare<Fr>;
+  std::mt19937_64 gen(seed);
+  auto rnd = [&] {
+    uint8_t b[32];
+    for (int i = 0; i < 4; ++i) {
+      uint64_t v = gen();
+      memcpy(b + 8 * i, &v, 8);
+    }
+    return from_be_bytes_mod_order<Fr>(b);
+  };
+  std::vector<Share> wit[3];
+  for (size_t i = n_instance; i < n_vars; ++i) {
+    Fr a = rnd(), b = rnd();
+    Fr c = Fr::sub(Fr::sub(w[i], a), b);
+    wit[0].push_back({a, c});
+    wit[1].push_back({b, a});
+    wit[2].push_back({c, b});
+  }
+  auto nets = LocalNetwork::new_parties(3);
+  std::vector<Fr> hs[3];
+  std::string errs[3];
+  std::vector<std::thread> th;
+  for (int p = 0; p < 3; ++p) {
+    th.emplace_back([&, p] {
+      try {
+        check(csh_init(0), "csh_init");
+        uint8_t my_seed[32];
+        std::mt19937_64 g2(seed * 1000003ull + 17 * p + 1);
+        for (int i = 0; i < 4; ++i) {
+          uint64_t v = g2();
+          memcpy(my_seed + 8 * i, &v, 8);
+        }
+        Rep3State state = Rep3State::create(nets[p], my_seed);
+        hs[p] = run(Rep3Groth16Driver<P>{}, state, wit[p]);
+      } catch (const std::exception& e) {
+        errs[p] = e.what();
+      }
+    });
+  }
+  for (auto& t : th) t.join();
+  for (int p = 0; p < 3; ++p)
+    if (!errs[p].empty()) throw Error("party " + std::to_string(p) + ": " + errs[p]);
+  const size_t n = hs[0].size();
+  if (3 * n > h_cap) throw Error("h_out too small");
+  for (int p = 0; p < 3; ++p) memcpy(h_out + 4 * n * p, hs[p].data(), 32 * n);
+  return (int)n;
+}
+
 }  // namespace
 
 extern "C" {
+
+// Returns the domain size (entries per party in h_out) or -1. reduction: 0 CircomReduction, 1 LibSnarkReduction (needs
+// the C matrix); mode: 0 plain, 1 three Rep3 parties. CSR triples for a, b, c (c may be NULL for reduction 0).
+int cog16_witness_map(int curve, int reduction, int mode, const uint64_t* const row_ptr[3], const uint32_t* const col[3],
+                      const uint64_t* const coef[3], size_t n_rows, size_t n_instance, const uint64_t* witness_full, size_t n_vars, uint64_t seed,
+                      uint64_t* h_out, size_t h_cap_elems) {
+  try {
+    if (curve == 0) return witness_map_t<Bn254>(reduction, mode, row_ptr, col, coef, n_rows, n_instance, witness_full, n_vars, seed, h_out, h_cap_elems);
+    if (curve == 1) return witness_map_t<Bls12_381>(reduction, mode, row_ptr, col, coef, n_rows, n_instance, witness_full, n_vars, seed, h_out, h_cap_elems);
+    g_err = "unknown curve";
+    return -1;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return -1;
+  }
+}
 
 int cog16_prove_shamir(int curve, const uint8_t* zkey, size_t zlen, const uint8_t* wtns, size_t wlen, int num_parties, int threshold,
                        uint64_t seed, const uint64_t* r, const uint64_t* s, int bridge, char* out_json, size_t cap) {

@@ -191,6 +191,48 @@ struct CircomReduction {
   }
 };
 
+// ---- R1CSToQAP: LibSnarkReduction::witness_map_from_matrices (reduction.rs:237-342) ---------------------------------
+// The arkworks / libsnark QAP witness map: Domain::new (arkworks' 2-adic root), coset = F::GENERATOR, H = (AB - C)/Z
+// as natural-order coefficients. Needs the C matrix (ConstraintMatrices::c); no fixture in the reference tree pins it
+// (the Penumbra BLS12-377 keys are absent), so parity rests on the oracle restatement + the polynomial identity.
+struct LibSnarkReduction {
+  static constexpr bool HAS_DEVICE_MAP = false;
+  template <class P, class T>
+  static std::vector<typename T::ArithmeticHalfShare> witness_map_from_matrices(typename T::State& state, const ConstraintMatrices<P>& matrices,
+                                                                                 const std::vector<typename P::Fr>& public_inputs,
+                                                                                 const std::vector<typename T::ArithmeticShare>& private_witness) {
+    using Fr = typename P::Fr;
+    const size_t num_constraints = matrices.num_constraints;
+    const size_t num_inputs = matrices.num_instance_variables;
+    size_t domain_size = 1, power = 0;
+    while (domain_size < num_constraints + num_inputs) {  // Domain::new(num_constraints + num_inputs) (:249)
+      domain_size <<= 1;
+      ++power;
+    }
+    if (power > (size_t)Fr::Params::TWO_ADICITY) throw Error("Polynomial Degree too large");  // :250
+    if (!matrices.a_dev || !matrices.b_dev || !matrices.c_dev) throw Error("LibSnarkReduction: constraint matrices a, b, c must be uploaded");
+    Span span_all("witness map from matrices (libsnark)");
+    csh_domain_t domain = nullptr;
+    check(csh_domain_create(P::ID, (uint32_t)power, nullptr, &domain), "csh_domain_create");  // arkworks default root
+    const Fr gen = Fr::from_u64(P::FR_GENERATOR);                                              // P::ScalarField::GENERATOR (:255)
+    std::vector<Fr> h(domain_size);
+    int rc;
+    if constexpr (T::DEVICE_MASKS) {
+      auto run = state.rand.take_device_run(domain_size);  // the one local_mul_vec (:289)
+      rc = csh_groth16_witness_map_libsnark(domain, (const uint64_t*)&gen, T::PROTOCOL, state.id, matrices.a_dev, matrices.b_dev, matrices.c_dev,
+                                            num_constraints, (const uint64_t*)public_inputs.data(), num_inputs, (const uint64_t*)private_witness.data(),
+                                            private_witness.size(), run.seed1, run.off1, run.seed2, run.off2, (uint64_t*)h.data());
+    } else {
+      rc = csh_groth16_witness_map_libsnark(domain, (const uint64_t*)&gen, T::PROTOCOL, state.id, matrices.a_dev, matrices.b_dev, matrices.c_dev,
+                                            num_constraints, (const uint64_t*)public_inputs.data(), num_inputs, (const uint64_t*)private_witness.data(),
+                                            private_witness.size(), nullptr, 0, nullptr, 0, (uint64_t*)h.data());
+    }
+    csh_domain_free(domain);
+    check(rc, "csh_groth16_witness_map_libsnark");
+    return h;
+  }
+};
+
 // ---- CoGroth16<P, T> (groth16.rs:103-338) ------------------------------------------------------------------------
 template <class P, class T>
 struct CoGroth16 {

@@ -39,6 +39,7 @@ struct Bn254 {
   using Fr = csh::Bn254Fr;
   using Fq = csh::Bn254Fq;
   using Fq2 = csh::Bn254Fq2;
+  static constexpr uint64_t FR_GENERATOR = 5;  // ark_bn254::Fr::GENERATOR
   static const char* name() { return "bn128"; }
   static const uint32_t* g1_generator_words() { return csh::Bn254G1Gen; }
 };
@@ -47,6 +48,7 @@ struct Bls12_381 {
   using Fr = csh::Bls381Fr;
   using Fq = csh::Bls381Fq;
   using Fq2 = csh::Bls381Fq2;
+  static constexpr uint64_t FR_GENERATOR = 7;  // ark_bls12_381::Fr::GENERATOR
   static const char* name() { return "bls12381"; }
   static const uint32_t* g1_generator_words() { return csh::Bls381G1Gen; }
 };
@@ -210,9 +212,9 @@ struct ConstraintMatrices {
   size_t num_instance_variables = 0;
   size_t num_witness_variables = 0;
   size_t num_constraints = 0;
-  std::vector<std::vector<std::pair<typename P::Fr, size_t>>> a, b;
+  std::vector<std::vector<std::pair<typename P::Fr, size_t>>> a, b, c;  // c: only LibSnarkReduction reads it (a zkey has no C)
   // device-resident CSR copies (uploaded once per circuit) for the on-device constraint evaluation
-  csh_matrix_t a_dev = nullptr, b_dev = nullptr;
+  csh_matrix_t a_dev = nullptr, b_dev = nullptr, c_dev = nullptr;
   void upload() {
     auto up = [&](const std::vector<std::vector<std::pair<typename P::Fr, size_t>>>& m, csh_matrix_t* out) {
       std::vector<uint64_t> row_ptr(m.size() + 1, 0);
@@ -229,6 +231,7 @@ struct ConstraintMatrices {
     };
     up(a, &a_dev);
     up(b, &b_dev);
+    if (!c.empty()) up(c, &c_dev);
   }
   ConstraintMatrices() = default;
   ConstraintMatrices(const ConstraintMatrices&) = delete;
@@ -236,6 +239,7 @@ struct ConstraintMatrices {
   ~ConstraintMatrices() {
     if (a_dev) csh_matrix_free(a_dev);
     if (b_dev) csh_matrix_free(b_dev);
+    if (c_dev) csh_matrix_free(c_dev);
   }
 };
 

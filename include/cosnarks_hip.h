@@ -187,6 +187,18 @@ int csh_groth16_h_dev(csh_domain_t dom, const uint64_t shift[4], int protocol, u
 int csh_groth16_h_rep3_seeded(csh_domain_t dom, const uint64_t shift[4], uint64_t* a, uint64_t* b, const uint8_t seed1[32],
                               uint64_t elem_offset1, const uint8_t seed2[32], uint64_t elem_offset2, uint64_t* h_out);
 
+/* ---- LibSnarkReduction tail (reduction.rs:255-342) -------------------------------------------------
+ * a, b: constraint evaluations incl. the promoted public inputs (ncomp per entry), c: half-share evaluations of the C
+ * matrix (evaluate_constraint_half_share, 1 component), natural order over Domain::new(n) (csh_domain_create with a
+ * NULL generator). generator = F::GENERATOR (Montgomery). h_out[i] = i-th coefficient of (A*B - C)/Z (natural order):
+ * 7 NTTs, 1 local_mul_vec (mask = its mask vector, NULL for protocol 0), 4 table multiplications. a, b, c are clobbered.
+ * No fixture pins this path in the reference tree (the Penumbra keys are absent): parity is against the oracle's
+ * restatement plus the identity H(t) Z(t) = A(t) B(t) - C(t) at a random point (tests/). */
+int csh_groth16_h_libsnark(csh_domain_t dom, const uint64_t generator[4], int protocol, uint64_t* a, uint64_t* b, uint64_t* c,
+                           const uint64_t* mask, uint64_t* h_out);
+int csh_groth16_h_libsnark_dev(csh_domain_t dom, const uint64_t generator[4], int protocol, uint64_t* a_dev, uint64_t* b_dev,
+                               uint64_t* c_dev, const uint64_t* mask_dev, uint64_t* h_out_dev, void* stream);
+
 /* ---- sparse constraint evaluation on the device ("next" row f3) ------------------------------------------------
  * Replaces evaluate_constraint over a ConstraintMatrices side (reduction.rs:196-210) + the driver row kernels
  * (mpc/plain.rs:28-43, mpc/rep3.rs:31-49, mpc/shamir.rs:29-49). The matrix (CSR: row_ptr[n_rows+1], col_idx[nnz],
@@ -215,6 +227,14 @@ int csh_groth16_witness_map_dev(csh_domain_t dom, const uint64_t shift[4], int p
                                 size_t num_constraints, const uint64_t* public_inputs, size_t n_public, const uint64_t* witness_dev,
                                 const uint8_t seed1[32], uint64_t elem_offset1, const uint8_t seed2[32], uint64_t elem_offset2,
                                 uint64_t* h_out_dev, void* stream);
+/* LibSnarkReduction::witness_map_from_matrices (reduction.rs:241-342) on the device: rows of a, b through
+ * evaluate_constraint, rows of c through evaluate_constraint_half_share (mpc/rep3.rs:51-74, mpc/shamir.rs:51-68,
+ * mpc/plain.rs:45-60), then csh_groth16_h_libsnark. dom = Domain::new (NULL generator at csh_domain_create),
+ * generator = F::GENERATOR. Host pointers; one mask vector from the seeds (NULL seeds = zero mask). */
+int csh_groth16_witness_map_libsnark(csh_domain_t dom, const uint64_t generator[4], int protocol, int party_id, csh_matrix_t a,
+                                     csh_matrix_t b, csh_matrix_t c, size_t num_constraints, const uint64_t* public_inputs,
+                                     size_t n_public, const uint64_t* witness, size_t n_witness, const uint8_t seed1[32],
+                                     uint64_t elem_offset1, const uint8_t seed2[32], uint64_t elem_offset2, uint64_t* h_out);
 
 /* ---- measurement hooks (bench.py / profiles) ----------------------------------------------------------
  * HIP-event timing on the stream the kernels are launched on. */

@@ -42,6 +42,10 @@ class PlainDriver:
             acc = (acc + coeff * v) % p
         return acc
 
+    def eval_row_half(self, row, public_inputs, witness):
+        """mpc/plain.rs:45-60 (and mpc/shamir.rs:51-68): same value as eval_row."""
+        return PlainDriver.eval_row(self, row, public_inputs, witness)
+
     def promote(self, vals):
         return [v % self.F.p for v in vals]
 
@@ -80,6 +84,19 @@ class Rep3Driver:
                 acc = mpc.rep3_add(F, acc, mpc.rep3_mul_public(F, witness[idx - npub], coeff))
         return acc
 
+    def eval_row_half(self, row, public_inputs, witness):
+        """mpc/rep3.rs:51-74: public terms on party 0 only, witness terms through the `a` component."""
+        p = self.F.p
+        acc = 0
+        npub = len(public_inputs)
+        for coeff, idx in row:
+            if idx < npub:
+                if self.party == 0:
+                    acc = (acc + public_inputs[idx] * coeff) % p
+            else:
+                acc = (acc + witness[idx - npub][0] * coeff) % p
+        return acc
+
     def promote(self, vals):
         return [mpc.rep3_promote(self.F, v, self.party) for v in vals]
 
@@ -111,6 +128,7 @@ class ShamirDriver:
         return 0
 
     eval_row = PlainDriver.eval_row
+    eval_row_half = PlainDriver.eval_row_half
     promote = PlainDriver.promote
     local_mul_vec = PlainDriver.local_mul_vec
     mul_table = PlainDriver.mul_table
@@ -158,6 +176,104 @@ def witness_map_circom(zk: ZKey, drv, public_inputs, witness):
     c_c = dom.fft_out_to_in(ab)
     out = drv.local_mul_vec(a_c, b_c)
     return [(x - y) % F.p for x, y in zip(out, c_c)]
+
+
+# ------------------------------------------------------------------ R1CSToQAP (LibSnarkReduction)
+def witness_map_libsnark(F, generator: int, A, B, Cm, num_constraints: int, drv, public_inputs, witness):
+    """reduction.rs:241-342. A, B, Cm: rows of (coeff, index) over public_inputs || witness. `generator` =
+    P::ScalarField::GENERATOR (5 for BN254 Fr, 7 for BLS12-381 Fr). Returns the natural-order coefficients of
+    H = (AB - C) / Z as half shares. No fixture of the reference tree exercises this path (its only tests need the
+    absent Penumbra BLS12-377 keys): parity unpinned; tests check H(t) Z(t) = A(t) B(t) - C(t) instead."""
+    p = F.p
+    num_inputs = len(public_inputs)
+    domain_size = 1
+    while domain_size < num_constraints + num_inputs:          # Domain::new (:249): next power of two
+        domain_size *= 2
+    power = domain_size.bit_length() - 1
+    if power > F.two_adicity:
+        raise ValueError("Polynomial Degree too large")
+    root = pow(ntt.arkworks_two_adic_root(F, generator), 1 << (F.two_adicity - power), p)
+    dom = ntt.Domain(F, domain_size, root)
+    coset_table = ntt.bit_reversed_coset_table(F, generator, domain_size)      # :255
+
+    def coset_eval(v):
+        v = drv.ntt(dom.ifft_in_to_out, v)
+        v = drv.mul_table(v, coset_table)
+        return drv.ntt(dom.fft_out_to_in, v)
+
+    def evaluate(matrix):
+        res = [drv.eval_row(row, public_inputs, witness) for row in matrix]
+        return res + [drv.zero_share()] * (domain_size - len(res))
+
+    a = evaluate(A)                                                             # :260-272
+    promoted = drv.promote(public_inputs)
+    a[num_constraints:num_constraints + num_inputs] = promoted[:num_inputs]
+    a = coset_eval(a)
+    b = coset_eval(evaluate(B))                                                 # :276-286
+    ab = drv.local_mul_vec(a, b)                                                # :289
+    c = [drv.eval_row_half(row, public_inputs, witness) for row in Cm]          # :292-306
+    c += [0] * (domain_size - len(c))
+    c = dom.ifft_in_to_out(c)
+    c = [x * t % p for x, t in zip(c, coset_table)]
+    c = dom.fft_out_to_in(c)
+    v = pow((pow(generator, domain_size, p) - 1) % p, -1, p)                    # :311-314
+    ab = [(x - y) * v % p for x, y in zip(ab, c)]                               # :316-322
+    ab = ntt.bit_reverse(dom.ifft_in_to_out(ab))                                # :327-328
+    g_inv = pow(generator, -1, p)                                               # :329-340
+    cur = 1
+    out = []
+    for x in ab:
+        out.append(x * cur % p)
+        cur = cur * g_inv % p
+    return out
+
+
+def libsnark_identity_holds(F, generator: int, A, B, Cm, num_constraints: int, public_inputs, witness, h, tau: int) -> bool:
+    """H(tau) * (tau^n - 1) == A(tau) * B(tau) - C(tau), with A, B, C interpolated from their evaluations on the arkworks
+    domain (plain values). Independent of the NTT code: Lagrange basis evaluated directly."""
+    p = F.p
+    drv = PlainDriver(F)
+    num_inputs = len(public_inputs)
+    n = 1
+    while n < num_constraints + num_inputs:
+        n *= 2
+    power = n.bit_length() - 1
+    root = pow(ntt.arkworks_two_adic_root(F, generator), 1 << (F.two_adicity - power), p)
+    ev = lambda M: [drv.eval_row(r, public_inputs, witness) for r in M] + [0] * (n - len(M))
+    a, b, c = ev(A), ev(B), ev(Cm)
+    a[num_constraints:num_constraints + num_inputs] = [v % p for v in public_inputs]
+    z = (pow(tau, n, p) - 1) % p
+    n_inv = pow(n, -1, p)
+
+    def interp(vals):
+        acc, w = 0, 1
+        for v in vals:
+            if v:
+                acc = (acc + v * w % p * pow((tau - w) % p, -1, p)) % p
+            w = w * root % p
+        return acc * z % p * n_inv % p
+
+    H = ntt.eval_poly_at(F, h, tau)
+    return H * z % p == (interp(a) * interp(b) - interp(c)) % p
+
+
+def random_r1cs(F, rng, n_public: int, n_constraints: int, fan: int = 3):
+    """A satisfied R1CS for the reduction tests: variable 0 = 1, n_public - 1 public inputs, then one fresh variable per
+    constraint holding (A_j . w)(B_j . w), with C_j selecting it. Returns (A, B, C, w) with rows of (coeff, index)."""
+    p = F.p
+    w = [1] + [rng.randrange(p) for _ in range(n_public - 1)] + [rng.randrange(p) for _ in range(2)]
+    A, B, Cm = [], [], []
+    for _ in range(n_constraints):
+        ra = [(rng.randrange(1, p), rng.randrange(len(w))) for _ in range(rng.randrange(1, fan + 1))]
+        rb = [(rng.randrange(1, p), rng.randrange(len(w))) for _ in range(rng.randrange(1, fan + 1))]
+        va = sum(c * w[i] for c, i in ra) % p
+        vb = sum(c * w[i] for c, i in rb) % p
+        k = rng.randrange(1, p)                      # C row: k * w_new = va * vb
+        w.append(va * vb % p * pow(k, -1, p) % p)
+        A.append(ra)
+        B.append(rb)
+        Cm.append([(k, len(w) - 1)])
+    return A, B, Cm, w
 
 
 # ------------------------------------------------------------------ plain prove

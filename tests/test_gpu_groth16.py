@@ -108,3 +108,32 @@ def test_synthetic_circuit_prove_closed_form(gpu, curve, logd):
     from cosnarks_amd import groth16 as g
     res = g.bench_synthetic(H.CURVE_IDS[curve], logd, iters=1)
     assert res["closed_form_check"], res
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("curve,generator", [("bn254", 5), ("bls12_381", 7)])
+@pytest.mark.parametrize("n_public,n_constraints", [(1, 2), (3, 29), (2, 3000)])
+def test_libsnark_reduction_device_matches_oracle(gpu, curve, generator, n_public, n_constraints):
+    """LibSnarkReduction::witness_map_from_matrices on the device (csh_groth16_witness_map_libsnark through the host
+    mirror) vs the oracle restatement: plain h bit-exact; three Rep3 parties (device ChaCha12 masks) sum to it."""
+    import random
+    from cosnarks_amd import groth16 as dev
+    from oracle import groth16 as g16
+    F = H.FR[curve]
+    cid = H.CURVE_IDS[curve]
+    rng = random.Random(77 + n_constraints)
+    A, B, Cm, w = g16.random_r1cs(F, rng, n_public, n_constraints)
+    pub, wit = w[:n_public], w[n_public:]
+    want = g16.witness_map_libsnark(F, generator, A, B, Cm, n_constraints, g16.PlainDriver(F), pub, wit)
+    mont = lambda M: [[(F.to_mont(c), i) for c, i in row] for row in M]
+    mats = (mont(A), mont(B), mont(Cm))
+    wm = H.pack(F, w)
+    got = dev.witness_map(cid, dev.LIBSNARK_REDUCTION, False, mats, n_public, wm)
+    assert H.unpack(F, got) == want
+    if n_constraints <= 100:
+        assert g16.libsnark_identity_holds(F, generator, A, B, Cm, n_constraints, pub, wit, H.unpack(F, got), rng.randrange(F.p))
+    hs = dev.witness_map(cid, dev.LIBSNARK_REDUCTION, True, mats, n_public, wm, seed=5)
+    parts = [H.unpack(F, hs[p]) for p in range(3)]
+    assert [(x + y + z) % F.p for x, y, z in zip(*parts)] == want
+    assert parts[0] != want                      # masked shares, not the plain vector three times
+

@@ -166,3 +166,28 @@ def test_c_generated_bases_closed_form():
     sc[:, 3] >>= np.uint64(3)
     got = cv.unpack_points(G, cbridge.msm(0, 0, pts, sc, True))[0]
     assert G.eq(got, closed_form_point("bn254", 0, 77, n, sc, True))
+
+
+@pytest.mark.parametrize("curve,generator", [("bn254", 5), ("bls12_381", 7)])
+def test_libsnark_reduction_restatement_satisfies_qap_identity(curve, generator):
+    """LibSnarkReduction (reduction.rs:241-342) has no fixture in the reference tree (parity unpinned): the restatement is
+    checked against the defining identity H(t) Z(t) = A(t) B(t) - C(t) at random points, with A, B, C interpolated by a
+    direct Lagrange sum (no NTT code shared), and the three Rep3 parties' half shares must add up to the plain h."""
+    import random
+    from oracle import groth16 as g16
+    from oracle import mpc
+    F = H.FR[curve]
+    rng = random.Random(2024)
+    for n_public, n_constraints in [(1, 1), (2, 5), (3, 29)]:
+        A, B, Cm, w = g16.random_r1cs(F, rng, n_public, n_constraints)
+        pub, wit = w[:n_public], w[n_public:]
+        h = g16.witness_map_libsnark(F, generator, A, B, Cm, n_constraints, g16.PlainDriver(F), pub, wit)
+        for _ in range(2):
+            assert g16.libsnark_identity_holds(F, generator, A, B, Cm, n_constraints, pub, wit, h, rng.randrange(F.p))
+        bad = list(h)
+        bad[0] = (bad[0] + 1) % F.p
+        assert not g16.libsnark_identity_holds(F, generator, A, B, Cm, n_constraints, pub, wit, bad, rng.randrange(F.p))
+        shares = mpc.rep3_share_vec(F, wit, lambda: rng.randrange(F.p))
+        hs = [g16.witness_map_libsnark(F, generator, A, B, Cm, n_constraints, g16.Rep3Driver(F, pid), pub, shares[pid]) for pid in range(3)]
+        assert [(x + y + z) % F.p for x, y, z in zip(*hs)] == h
+
