@@ -15,6 +15,7 @@ or ``importlib.import_module("co-snarks_amd")``.
 from .bindings import (  # noqa: F401
     BLS12_381,
     BN254,
+    GRUMPKIN,
     G1,
     G2,
     Bases,

@@ -11,7 +11,7 @@ import re
 
 import numpy as np
 
-BN254, BLS12_381 = 0, 1
+BN254, BLS12_381, GRUMPKIN = 0, 1, 2   # GRUMPKIN: MSM entry points only (G1)
 G1, G2 = 0, 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -76,7 +76,7 @@ def fr_bytes(curve: int) -> int:
 
 
 def fq_bytes(curve: int) -> int:
-    return 32 if curve == BN254 else 48
+    return 48 if curve == BLS12_381 else 32
 
 
 def point_bytes(curve: int, group: int) -> int:

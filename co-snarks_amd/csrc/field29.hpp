@@ -437,6 +437,7 @@ struct FpS {
 
 using Fq29s = FpS<Bn254Fq29Params, Bn254Fq>;
 using Fq28s = FpS<Bls381Fq28Params, Bls381Fq>;
+using Fr29s = FpS<Bn254Fr29Params, Bn254Fr>;  // Grumpkin base field
 
 // ---- Fp2 = Fp[i]/(i^2+1) over the signed lazy field: schoolbook products accumulated double-width with ONE
 // reduction per output component (2 NL^2 + NL^2 mads per component, cheaper than Karatsuba's three full

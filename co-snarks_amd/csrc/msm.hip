@@ -33,6 +33,8 @@ namespace csh {
 struct Bn254G1Cfg { using Fq = Bn254Fq;   using Fr = Bn254Fr; static constexpr bool LAZY = true;  using L = Fq29s; static constexpr bool INLINE_ADD = true; };
 struct Bn254G2Cfg { using Fq = Bn254Fq2;  using Fr = Bn254Fr; static constexpr bool LAZY = true;  using L = Fq29s2; static constexpr bool INLINE_ADD = true; };
 struct Bls381G1Cfg { using Fq = Bls381Fq;  using Fr = Bls381Fr; static constexpr bool LAZY = true;  using L = Fq28s; static constexpr bool INLINE_ADD = true; };
+// Grumpkin: base field = BN254 Fr, scalars = BN254 Fq (the 2-cycle partner of BN254)
+struct GrumpkinG1Cfg { using Fq = Bn254Fr;   using Fr = Bn254Fq; static constexpr bool LAZY = true;  using L = Fr29s; static constexpr bool INLINE_ADD = true; };
 struct Bls381G2Cfg { using Fq = Bls381Fq2; using Fr = Bls381Fr; static constexpr bool LAZY = true;  using L = Fq28s2; static constexpr bool INLINE_ADD = true; };
 
 struct Bases {
@@ -543,7 +545,7 @@ static int repack_bases_t(Bases* B, hipStream_t st) {
 static int repack_bases(Bases* B, hipStream_t st);
 
 static size_t point_bytes_of(csh_curve_t c, csh_group_t g) {
-  const size_t fq = c == CSH_BN254 ? 32 : 48;
+  const size_t fq = c == CSH_BLS12_381 ? 48 : 32;
   return 2 * fq * (g == CSH_G2 ? 2 : 1);
 }
 
@@ -557,6 +559,7 @@ using namespace csh;
     if ((curve) == CSH_BN254 && (group) == CSH_G2) { using Cfg = Bn254G2Cfg; return CALL; }     \
     if ((curve) == CSH_BLS12_381 && (group) == CSH_G1) { using Cfg = Bls381G1Cfg; return CALL; } \
     if ((curve) == CSH_BLS12_381 && (group) == CSH_G2) { using Cfg = Bls381G2Cfg; return CALL; } \
+    if ((curve) == CSH_GRUMPKIN && (group) == CSH_G1) { using Cfg = GrumpkinG1Cfg; return CALL; }  \
     set_error("unknown curve/group %d/%d", (int)(curve), (int)(group));                          \
     return CSH_ERR_INVALID;                                                                     \
   } while (0)
@@ -566,8 +569,8 @@ static int csh::repack_bases(Bases* B, hipStream_t st) {
 }
 
 static int valid_cg(csh_curve_t c, csh_group_t g) {
-  CSH_REQUIRE(c == CSH_BN254 || c == CSH_BLS12_381, "unknown curve");
-  CSH_REQUIRE(g == CSH_G1 || g == CSH_G2, "unknown group");
+  CSH_REQUIRE(c == CSH_BN254 || c == CSH_BLS12_381 || c == CSH_GRUMPKIN, "unknown curve");
+  CSH_REQUIRE(g == CSH_G1 || (g == CSH_G2 && c != CSH_GRUMPKIN), "unknown group");
   return CSH_OK;
 }
 

@@ -10,6 +10,7 @@
 // contiguous run of 2^cb * ncomp * 32 bytes (>= 256 B) and a 2^22 transform needs 3 read+write sweeps.
 // LDS keeps each element as two 16-byte halves in separate arrays so lane-consecutive ds_read_b128 /
 // ds_write_b128 are bank-conflict free.
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.hpp"
@@ -17,7 +18,7 @@
 
 namespace csh {
 
-constexpr int NTT_THREADS = 256;
+constexpr int NTT_MAX_THREADS = 1024;
 constexpr int NTT_TILE_LOG = 11;  // 2^11 field elements = 64 KiB of LDS per workgroup
 
 struct Domain {
@@ -47,7 +48,7 @@ __device__ __forceinline__ void lds_put(uint4* lo, uint4* hi, int e, const F& f)
 
 // One pass = stages [s0, s0+k) of a size-2^L transform. CC = 2^cb * ncomp contiguous elements.
 template <class F, bool DIF>
-__global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(F* __restrict__ data, const F* __restrict__ tw, int L, int s0, int k,
+__global__ __launch_bounds__(NTT_MAX_THREADS) void k_ntt_pass(F* __restrict__ data, const F* __restrict__ tw, int L, int s0, int k,
                                                           int cb, int ncomp_log, F scale, int do_scale) {
   static_assert(sizeof(F) == 32, "Fr is 8 x u32");
   extern __shared__ uint4 lds_raw[];
@@ -61,6 +62,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(F* __restrict__ data, 
   const size_t mid = tile & ((size_t(1) << mid_bits) - 1);
   const size_t hi_idx = tile >> mid_bits;
   const int tid = threadIdx.x;
+  const int NTT_THREADS = blockDim.x;
 
   // gather tile: lds index e = t * CC + cc ; global element = (((hi << k | t) << mid_bits | mid) * CC + cc
   for (int e = tid; e < E; e += NTT_THREADS) {
@@ -194,6 +196,11 @@ static int run_ntt(const Domain* d, F* data, uint32_t ncomp, bool dif, hipStream
   const int np = plan_passes(L, ncomp_log, passes);
   const F* tw = reinterpret_cast<const F*>(dif ? d->tw_inv : d->tw_fwd);
   F scale = f_from_words<F>(d->n_inv);
+  static const int NTT_THREADS = [] {
+    const char* e = getenv("CSH_NTT_THREADS");
+    const int v = e ? atoi(e) : 512;
+    return (v == 256 || v == 512 || v == 1024) ? v : 512;
+  }();
   for (int pi = 0; pi < np; ++pi) {
     const Pass& p = dif ? passes[np - 1 - pi] : passes[pi];
     const int tile_log = p.k + p.cb;  // entries

@@ -196,6 +196,7 @@ int csh_selftest_lazy_chain_dev(int curve, int group, const void* affine_pts, si
   if (curve == CSH_BN254 && group == CSH_G2) return lazy_chain_check_t<Fq29s2, Bn254Fq2>(affine_pts, n, len, nthreads, host_samples, mismatches);
   if (curve == CSH_BLS12_381 && group == CSH_G1) return lazy_chain_check_t<Fq28s, Bls381Fq>(affine_pts, n, len, nthreads, host_samples, mismatches);
   if (curve == CSH_BLS12_381 && group == CSH_G2) return lazy_chain_check_t<Fq28s2, Bls381Fq2>(affine_pts, n, len, nthreads, host_samples, mismatches);
+  if (curve == CSH_GRUMPKIN && group == CSH_G1) return lazy_chain_check_t<Fr29s, Bn254Fr>(affine_pts, n, len, nthreads, host_samples, mismatches);
   return CSH_ERR_INVALID;
 }
 
@@ -222,6 +223,7 @@ int csh_selftest_curve_op(int curve, int group, int op, const void* in1, const v
   if (curve == CSH_BN254 && group == CSH_G2) return curve_op<Bn254Fq2>(op, in1, in2, k, out);
   if (curve == CSH_BLS12_381 && group == CSH_G1) return curve_op<Bls381Fq>(op, in1, in2, k, out);
   if (curve == CSH_BLS12_381 && group == CSH_G2) return curve_op<Bls381Fq2>(op, in1, in2, k, out);
+  if (curve == CSH_GRUMPKIN && group == CSH_G1) return curve_op<Bn254Fr>(op, in1, in2, k, out);
   return CSH_ERR_INVALID;
 }
 
@@ -230,6 +232,7 @@ int csh_selftest_lazy_accumulate(int curve, int group, const void* affine_pts, c
   if (curve == CSH_BN254 && group == CSH_G2) return lazy_accumulate_t<Fq29s2, Bn254Fq2>(affine_pts, neg, npts, out_xyzz);
   if (curve == CSH_BLS12_381 && group == CSH_G1) return lazy_accumulate_t<Fq28s, Bls381Fq>(affine_pts, neg, npts, out_xyzz);
   if (curve == CSH_BLS12_381 && group == CSH_G2) return lazy_accumulate_t<Fq28s2, Bls381Fq2>(affine_pts, neg, npts, out_xyzz);
+  if (curve == CSH_GRUMPKIN && group == CSH_G1) return lazy_accumulate_t<Fr29s, Bn254Fr>(affine_pts, neg, npts, out_xyzz);
   return CSH_ERR_INVALID;
 }
 
@@ -240,6 +243,7 @@ int csh_selftest_lazy_tree(int curve, int group, const void* affine_pts, const u
   if (curve == CSH_BN254 && group == CSH_G2) return lazy_tree_t<Fq29s2, Bn254Fq2>(affine_pts, neg, npts, group_len, weight, out_xyzz);
   if (curve == CSH_BLS12_381 && group == CSH_G1) return lazy_tree_t<Fq28s, Bls381Fq>(affine_pts, neg, npts, group_len, weight, out_xyzz);
   if (curve == CSH_BLS12_381 && group == CSH_G2) return lazy_tree_t<Fq28s2, Bls381Fq2>(affine_pts, neg, npts, group_len, weight, out_xyzz);
+  if (curve == CSH_GRUMPKIN && group == CSH_G1) return lazy_tree_t<Fr29s, Bn254Fr>(affine_pts, neg, npts, group_len, weight, out_xyzz);
   return CSH_ERR_INVALID;
 }
 

@@ -40,7 +40,9 @@
 extern "C" {
 #endif
 
-typedef enum { CSH_BN254 = 0, CSH_BLS12_381 = 1 } csh_curve_t;
+/* CSH_GRUMPKIN (MSM entry points only, group CSH_G1): the BN254 cycle curve y^2 = x^3 - 17 over BN254 Fr with scalar field
+ * BN254 Fq -- HonkCurve::fast_msm for short_weierstrass::Projective<GrumpkinConfig> (co-noir-common/src/honk_curve.rs:163-177). */
+typedef enum { CSH_BN254 = 0, CSH_BLS12_381 = 1, CSH_GRUMPKIN = 2 } csh_curve_t;
 typedef enum { CSH_G1 = 0, CSH_G2 = 1 } csh_group_t;
 
 typedef enum {

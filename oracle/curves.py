@@ -220,7 +220,13 @@ BLS381_G2 = Curve(
       0x0606C4A02EA734CC32ACD2B02BC28B99CB3E287E85A763AF267492AB572E99AB3F370D275CEC1DA1AAA9075FF05F79BE)),
     fl.BLS381_R, fl.BLS381_FR, cofactor=None)
 
-CURVES = {"bn254": (BN254_G1, BN254_G2), "bls12_381": (BLS381_G1, BLS381_G2)}
+# Grumpkin, the 2-cycle partner of BN254 (HonkCurve for Projective<GrumpkinConfig>, co-noir-common/src/honk_curve.rs:163):
+# y^2 = x^3 - 17 over BN254 Fr ("grumpkin::b, which is -17", honk_curve.rs:114), prime order = BN254 Fq modulus, scalars
+# in BN254 Fq. Generator (1, sqrt(-16)) as in ark-grumpkin 0.6 / barretenberg.
+GRUMPKIN_G1 = Curve("grumpkin.G1", fl.BN254_FR, fl.BN254_R - 17,
+                    (1, 17631683881184975370165255887551781615748388533673675138860), fl.BN254_Q, fl.BN254_FQ)
+
+CURVES = {"bn254": (BN254_G1, BN254_G2), "bls12_381": (BLS381_G1, BLS381_G2), "grumpkin": (GRUMPKIN_G1,)}
 
 
 # --- wire layout at the C ABI -----------------------------------------------------------------

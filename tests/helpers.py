@@ -7,8 +7,8 @@ from oracle import curves as cv
 from oracle import fields as fl
 
 FIELD_IDS = {"bn254.Fq": 0, "bn254.Fr": 1, "bls12_381.Fq": 2, "bls12_381.Fr": 3}
-CURVE_IDS = {"bn254": 0, "bls12_381": 1}
-FR = {"bn254": fl.BN254_FR, "bls12_381": fl.BLS381_FR}
+CURVE_IDS = {"bn254": 0, "bls12_381": 1, "grumpkin": 2}
+FR = {"bn254": fl.BN254_FR, "bls12_381": fl.BLS381_FR, "grumpkin": fl.BN254_FQ}   # scalar field of each curve
 
 
 def rng(seed):

@@ -1,4 +1,4 @@
-"""GPU parity (through the C ABI): MSM vs the oracle on all four groups. Bit-exact on the affine result."""
+"""GPU parity (through the C ABI): MSM vs the oracle on all four pairing groups and Grumpkin. Bit-exact on the affine result."""
 import numpy as np
 import pytest
 
@@ -6,7 +6,7 @@ from oracle import curves as cv
 from tests import helpers as H
 
 pytestmark = pytest.mark.gpu
-GROUPS = [("bn254", 0), ("bn254", 1), ("bls12_381", 0), ("bls12_381", 1)]
+GROUPS = [("bn254", 0), ("bn254", 1), ("bls12_381", 0), ("bls12_381", 1), ("grumpkin", 0)]
 
 
 def _run(gpu, curve, group, pts, scalars, montgomery=True, offset=0, n=None):
@@ -156,7 +156,8 @@ def test_generated_bases_have_known_dlog(gpu, curve, group):
         assert G.eq(P, G.mul(G.gen, int(k)))
 
 
-@pytest.mark.parametrize("curve,group,logn", [("bn254", 0, 20), ("bn254", 0, 22), ("bls12_381", 0, 18), ("bn254", 1, 17), ("bls12_381", 1, 16)])
+@pytest.mark.parametrize("curve,group,logn", [("bn254", 0, 20), ("bn254", 0, 22), ("bls12_381", 0, 18), ("bn254", 1, 17), ("bls12_381", 1, 16),
+                                               ("grumpkin", 0, 18)])
 def test_msm_closed_form_full_size(gpu, curve, group, logn):
     """Known-dlog bases: MSM == (sum s_i k_i) G at BASELINE sizes, uniform scalars, Montgomery input."""
     import ctypes as C

@@ -180,7 +180,7 @@ def test_signed_lazy_field_ops(hip):
         assert L.csh_selftest_lazys_op(0, pa, pn, pa, out.ctypes.data_as(C.c_void_p)) == 1
 
 
-@pytest.mark.parametrize("curve,group", [("bn254", 0), ("bn254", 1), ("bls12_381", 0), ("bls12_381", 1)])
+@pytest.mark.parametrize("curve,group", [("bn254", 0), ("bn254", 1), ("bls12_381", 0), ("bls12_381", 1), ("grumpkin", 0)])
 def test_lazy_bucket_accumulation_matches_group_law(hip, curve, group):
     """lazy_madd chain (incl. duplicates -> doubling, P + (-P) -> empty, infinity bases, long chains)."""
     G = cv.CURVES[curve][group]
@@ -211,7 +211,7 @@ def test_lazy_bucket_accumulation_matches_group_law(hip, curve, group):
         assert G.eq(got, want)
 
 
-@pytest.mark.parametrize("curve,group", [("bn254", 0), ("bn254", 1), ("bls12_381", 0), ("bls12_381", 1)])
+@pytest.mark.parametrize("curve,group", [("bn254", 0), ("bn254", 1), ("bls12_381", 0), ("bls12_381", 1), ("grumpkin", 0)])
 def test_lazy_point_tree_matches_group_law(hip, curve, group):
     """General XYZZ + XYZZ / doubling / small scalar in the lazy field (what the merge and reduce kernels run):
     group sums folded pairwise, incl. equal sums (-> doubling), opposite sums (-> infinity), empty groups."""
@@ -259,7 +259,7 @@ def test_rep3_mask_generator_matches_rngs_rs(hip, curve):
         b = chacha.keystream(s2, 32 * n, start_byte=32 * e2)
         assert H.unpack(F, out) == mpc.masks_from_streams(F, a, b, n)
 
-@pytest.mark.parametrize("curve,group", [("bn254", 0), ("bn254", 1), ("bls12_381", 0), ("bls12_381", 1)])
+@pytest.mark.parametrize("curve,group", [("bn254", 0), ("bn254", 1), ("bls12_381", 0), ("bls12_381", 1), ("grumpkin", 0)])
 def test_host_window_fold_64bit_limbs(hip, curve, group):
     """csh_msm_fold_partials (host only: Horner over window sums in 64-bit limbs, host_fp64.hpp) for every group:
     two partials with the same layout (summed window-wise first), one with another layout, one empty."""
