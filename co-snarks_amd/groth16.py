@@ -117,3 +117,49 @@ def witness_map(curve: int, reduction: int, rep3: bool, matrices, n_instance: in
     assert rc == n
     return out.reshape(3, n, 4) if rep3 else out.reshape(n, 4)
 
+
+PLAIN, REP3, SHAMIR, FAST_MSM = 0, 1, 2, 3
+
+
+def driver_fft(curve: int, driver: int, data_mont: np.ndarray, domain_size: int, inverse=False, snarkjs=True, seed: int = 1):
+    """CircomPlonkProver / NoirUltraHonkProver ::{fft, ifft} of the host mirror. Returns (domain, 4) limbs, or for Rep3
+    (3, domain, 2, 4): every party's share vector (the values are shared inside with `seed`)."""
+    d = np.ascontiguousarray(data_mont, dtype=np.uint64).reshape(-1, 4)
+    n = 1
+    while n < domain_size:
+        n *= 2
+    out = np.zeros((3 * 2 if driver == REP3 else 1) * n * 4, dtype=np.uint64)
+    rc = glib().cog16_driver_fft(curve, driver, int(inverse), int(snarkjs), d.ctypes.data_as(C.c_void_p), C.c_size_t(len(d)),
+                                 C.c_size_t(domain_size), C.c_uint64(seed), out.ctypes.data_as(C.c_void_p))
+    if rc < 0:
+        raise CoSnarksHipError(glib().cog16_last_error().decode())
+    return out.reshape(3, n, 2, 4) if driver == REP3 else out.reshape(n, 4)
+
+
+def driver_local_mul_vec(curve: int, driver: int, a_mont, b_mont, seed: int = 1):
+    """::local_mul_vec. Plain / Shamir: (n, 4); Rep3: (3, n, 4) additive (masked) shares of the three parties."""
+    a = np.ascontiguousarray(a_mont, dtype=np.uint64).reshape(-1, 4)
+    b = np.ascontiguousarray(b_mont, dtype=np.uint64).reshape(-1, 4)
+    n = len(a)
+    out = np.zeros((3 if driver == REP3 else 1) * n * 4, dtype=np.uint64)
+    rc = glib().cog16_driver_local_mul_vec(curve, driver, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), C.c_size_t(n),
+                                           C.c_uint64(seed), out.ctypes.data_as(C.c_void_p))
+    if rc < 0:
+        raise CoSnarksHipError(glib().cog16_last_error().decode())
+    return out.reshape(3, n, 4) if driver == REP3 else out.reshape(n, 4)
+
+
+def driver_msm(curve: int, driver: int, points: np.ndarray, scalars_mont, seed: int = 1):
+    """::msm_public_points(_g1) / HonkCurve::fast_msm (driver FAST_MSM; curve 2 = Grumpkin). Returns affine limbs:
+    (point_words,) or for Rep3 (3, 2, point_words): the (a, b) point share of every party."""
+    pts = np.ascontiguousarray(points, dtype=np.uint64)
+    sc = np.ascontiguousarray(scalars_mont, dtype=np.uint64).reshape(-1, 4)
+    pw = 12 if curve == 1 else 8
+    npts = pts.size // pw
+    out = np.zeros((6 if driver == REP3 else 1) * pw, dtype=np.uint64)
+    rc = glib().cog16_driver_msm(curve, driver, pts.ctypes.data_as(C.c_void_p), C.c_size_t(npts), sc.ctypes.data_as(C.c_void_p),
+                                 C.c_size_t(len(sc)), C.c_uint64(seed), out.ctypes.data_as(C.c_void_p))
+    if rc < 0:
+        raise CoSnarksHipError(glib().cog16_last_error().decode())
+    return out.reshape(3, 2, pw) if driver == REP3 else out
+

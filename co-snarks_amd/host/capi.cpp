@@ -9,6 +9,7 @@
 #include <random>
 
 #include "groth16.hpp"
+#include "plonk_honk.hpp"
 #include "zkey.hpp"
 
 using namespace cosnarks;
@@ -426,9 +427,176 @@ int witness_map_t(int reduction, int mode, const uint64_t* const row_ptr[3], con
   return (int)n;
 }
 
+// ---- PLONK / UltraHonk driver call sites (plonk_honk.hpp) on caller data: plain values in, shared inside for Rep3 --------
+template <class Fr>
+struct Rep3Sharer {
+  std::mt19937_64 gen;
+  explicit Rep3Sharer(uint64_t seed) : gen(seed) {}
+  Fr rnd() {
+    uint8_t b[32];
+    for (int i = 0; i < 4; ++i) {
+      uint64_t v = gen();
+      memcpy(b + 8 * i, &v, 8);
+    }
+    return from_be_bytes_mod_order<Fr>(b);
+  }
+  void share(const std::vector<Fr>& vals, std::vector<Rep3PrimeFieldShare<Fr>> out[3]) {
+    for (auto& v : vals) {
+      Fr a = rnd(), b = rnd();
+      Fr c = Fr::sub(Fr::sub(v, a), b);
+      out[0].push_back({a, c});
+      out[1].push_back({b, a});
+      out[2].push_back({c, b});
+    }
+  }
+};
+
+template <class Fn>
+void run_three_parties(uint64_t seed, Fn fn) {  // fn(party, Rep3State&)
+  auto nets = LocalNetwork::new_parties(3);
+  std::string errs[3];
+  std::vector<std::thread> th;
+  for (int p = 0; p < 3; ++p) {
+    th.emplace_back([&, p] {
+      try {
+        check(csh_init(0), "csh_init");
+        uint8_t my_seed[32];
+        std::mt19937_64 g2(seed * 1000003ull + 17 * p + 1);
+        for (int i = 0; i < 4; ++i) {
+          uint64_t v = g2();
+          memcpy(my_seed + 8 * i, &v, 8);
+        }
+        Rep3State state = Rep3State::create(nets[p], my_seed);
+        fn(p, state);
+      } catch (const std::exception& e) {
+        errs[p] = e.what();
+      }
+    });
+  }
+  for (auto& t : th) t.join();
+  for (int p = 0; p < 3; ++p)
+    if (!errs[p].empty()) throw Error("party " + std::to_string(p) + ": " + errs[p]);
+}
+
+template <class P>
+int driver_fft_t(int driver, int inverse, int snarkjs, const uint64_t* data, size_t n_in, size_t domain_size, uint64_t seed, uint64_t* out) {
+  using Fr = typename P::Fr;
+  EvaluationDomain<P> d = snarkjs ? EvaluationDomain<P>::snarkjs(domain_size) : EvaluationDomain<P>::arkworks(domain_size);
+  std::vector<Fr> v(n_in);
+  memcpy((void*)v.data(), data, 32 * n_in);
+  if (driver != 1) {
+    std::vector<Fr> r = driver == 0 ? (inverse ? PlainPlonkDriver<P>::ifft(v, d) : PlainPlonkDriver<P>::fft(v, d))
+                                    : (inverse ? ShamirPlonkDriver<P>::ifft(v, d) : ShamirPlonkDriver<P>::fft(v, d));
+    memcpy(out, r.data(), 32 * r.size());
+    return (int)r.size();
+  }
+  std::vector<Rep3PrimeFieldShare<Fr>> sh[3];
+  Rep3Sharer<Fr>(seed).share(v, sh);
+  for (int p = 0; p < 3; ++p) {  // local operation: no network, no randomness
+    auto r = inverse ? Rep3PlonkDriver<P>::ifft(sh[p], d) : Rep3PlonkDriver<P>::fft(sh[p], d);
+    memcpy(out + 8 * d.size * p, r.data(), 64 * r.size());
+  }
+  return (int)d.size;
+}
+
+template <class P>
+int driver_mul_t(int driver, const uint64_t* a, const uint64_t* b, size_t n, uint64_t seed, uint64_t* out) {
+  using Fr = typename P::Fr;
+  std::vector<Fr> va(n), vb(n);
+  memcpy((void*)va.data(), a, 32 * n);
+  memcpy((void*)vb.data(), b, 32 * n);
+  UnitState us;
+  if (driver == 0 || driver == 2) {
+    std::vector<Fr> r = driver == 0 ? PlainPlonkDriver<P>::local_mul_vec(va, vb, us) : ShamirPlonkDriver<P>::local_mul_vec(va, vb, us);
+    memcpy(out, r.data(), 32 * n);
+    return 0;
+  }
+  std::vector<Rep3PrimeFieldShare<Fr>> sa[3], sb[3];
+  Rep3Sharer<Fr> sharer(seed);
+  sharer.share(va, sa);
+  sharer.share(vb, sb);
+  run_three_parties(seed, [&](int p, Rep3State& st) {
+    std::vector<Fr> r = Rep3PlonkDriver<P>::local_mul_vec(sa[p], sb[p], st);
+    memcpy(out + 4 * n * p, r.data(), 32 * n);
+  });
+  return 0;
+}
+
+template <class C, class P>
+int driver_msm_t(int driver, const void* points, size_t n_points, const uint64_t* scalars, size_t n_scalars, uint64_t seed, void* out) {
+  using Fr = typename C::Fr;
+  using Fq = typename C::Fq;
+  std::vector<AffineT<Fq>> pts(n_points);
+  memcpy((void*)pts.data(), points, sizeof(AffineT<Fq>) * n_points);
+  std::vector<Fr> sc(n_scalars);
+  memcpy((void*)sc.data(), scalars, 32 * n_scalars);
+  auto put = [&](size_t slot, const Proj<Fq>& pt) {
+    AffineT<Fq> a = into_affine(pt);
+    memcpy(static_cast<char*>(out) + slot * sizeof a, &a, sizeof a);
+  };
+  if (driver == 3) {  // HonkCurve::fast_msm (BN254 G1 or Grumpkin)
+    put(0, fast_msm<C>(pts, sc));
+    return 0;
+  }
+  if constexpr (!std::is_same<P, void>::value) {
+    if (driver == 0) put(0, PlainPlonkDriver<P>::msm_public_points_g1(pts, sc));
+    else if (driver == 2) put(0, ShamirPlonkDriver<P>::msm_public_points(pts, sc));
+    else {
+      std::vector<Rep3PrimeFieldShare<Fr>> sh[3];
+      Rep3Sharer<Fr>(seed).share(sc, sh);
+      for (int p = 0; p < 3; ++p) {
+        auto r = Rep3PlonkDriver<P>::msm_public_points_g1(pts, sh[p]);
+        put(2 * p, r.a);
+        put(2 * p + 1, r.b);
+      }
+    }
+    return 0;
+  }
+  throw Error("driver not available for this curve");
+}
+
 }  // namespace
 
 extern "C" {
+
+// PLONK / UltraHonk driver methods on caller data. driver: 0 plain, 1 Rep3 (three in-process parties, values shared with
+// `seed`), 2 Shamir (the vector is one party's share vector), 3 (msm only) HonkCurve::fast_msm; curve 2 = Grumpkin (msm).
+int cog16_driver_fft(int curve, int driver, int inverse, int snarkjs, const uint64_t* data, size_t n_in, size_t domain_size, uint64_t seed,
+                     uint64_t* out) {
+  try {
+    if (curve == 0) return driver_fft_t<Bn254>(driver, inverse, snarkjs, data, n_in, domain_size, seed, out);
+    if (curve == 1) return driver_fft_t<Bls12_381>(driver, inverse, snarkjs, data, n_in, domain_size, seed, out);
+    g_err = "unknown curve";
+    return -1;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+int cog16_driver_local_mul_vec(int curve, int driver, const uint64_t* a, const uint64_t* b, size_t n, uint64_t seed, uint64_t* out) {
+  try {
+    if (curve == 0) return driver_mul_t<Bn254>(driver, a, b, n, seed, out);
+    if (curve == 1) return driver_mul_t<Bls12_381>(driver, a, b, n, seed, out);
+    g_err = "unknown curve";
+    return -1;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+int cog16_driver_msm(int curve, int driver, const void* points, size_t n_points, const uint64_t* scalars, size_t n_scalars, uint64_t seed,
+                     void* out) {
+  try {
+    if (curve == 0) return driver_msm_t<G1Of<Bn254>, Bn254>(driver, points, n_points, scalars, n_scalars, seed, out);
+    if (curve == 1) return driver_msm_t<G1Of<Bls12_381>, Bls12_381>(driver, points, n_points, scalars, n_scalars, seed, out);
+    if (curve == 2) return driver_msm_t<GrumpkinCurve, void>(driver, points, n_points, scalars, n_scalars, seed, out);
+    g_err = "unknown curve";
+    return -1;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return -1;
+  }
+}
 
 // Returns the domain size (entries per party in h_out) or -1. reduction: 0 CircomReduction, 1 LibSnarkReduction (needs
 // the C matrix); mode: 0 plain, 1 three Rep3 parties. CSR triples for a, b, c (c may be NULL for reduction 0).
