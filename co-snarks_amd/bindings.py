@@ -11,7 +11,7 @@ import re
 
 import numpy as np
 
-BN254, BLS12_381, GRUMPKIN = 0, 1, 2   # GRUMPKIN: MSM entry points only (G1)
+BN254, BLS12_381, GRUMPKIN, BLS12_377 = 0, 1, 2, 3   # GRUMPKIN: MSM only (G1); BLS12_377: scalar-field entry points only
 G1, G2 = 0, 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

@@ -235,6 +235,7 @@ struct Fp {
 
 using Bn254Fq = Fp<Bn254FqParams>;
 using Bn254Fr = Fp<Bn254FrParams>;
+using Bls377Fr = Fp<Bls377FrParams>;  // scalar field only (no BLS12-377 group arithmetic)
 using Bls381Fq = Fp<Bls381FqParams>;
 using Bls381Fr = Fp<Bls381FrParams>;
 

@@ -123,7 +123,9 @@ int csh_groth16_h_libsnark_dev(csh_domain_t dom, const uint64_t generator[4], in
   uint32_t log_n = 0;
   while ((size_t(1) << log_n) < n) ++log_n;
   uint64_t v[4], neg_v[4], g_inv[4];
-  const int crc = f == CSH_BN254 ? libsnark_consts<Bn254Fr>(generator, n, v, neg_v, g_inv) : libsnark_consts<Bls381Fr>(generator, n, v, neg_v, g_inv);
+  const int crc = f == CSH_BN254       ? libsnark_consts<Bn254Fr>(generator, n, v, neg_v, g_inv)
+                  : f == CSH_BLS12_377 ? libsnark_consts<Bls377Fr>(generator, n, v, neg_v, g_inv)
+                                       : libsnark_consts<Bls381Fr>(generator, n, v, neg_v, g_inv);
   CSH_REQUIRE(crc == CSH_OK, "libsnark reduction: the coset generator lies in the domain (g^n == 1)");
   hipStream_t st = resolve_stream(stream);
   Arena& ar = arena_for((hipStream_t)((uintptr_t)st ^ 0x4));

@@ -325,14 +325,17 @@ static int coset_table_t(const Domain* d, const uint64_t* shift, uint64_t* out_d
 // exposed to other translation units (fused Groth16 h pipeline)
 int ntt_run(const Domain* d, uint64_t* data, uint32_t ncomp, bool dif, hipStream_t st) {
   if (d->curve == CSH_BN254) return run_ntt<Bn254Fr>(d, (Bn254Fr*)data, ncomp, dif, st);
+  if (d->curve == CSH_BLS12_377) return run_ntt<Bls377Fr>(d, (Bls377Fr*)data, ncomp, dif, st);
   return run_ntt<Bls381Fr>(d, (Bls381Fr*)data, ncomp, dif, st);
 }
 int ntt_coset_table(const Domain* d, const uint64_t* shift, uint64_t* out_dev, hipStream_t st) {
   if (d->curve == CSH_BN254) return coset_table_t<Bn254Fr>(d, shift, out_dev, st);
+  if (d->curve == CSH_BLS12_377) return coset_table_t<Bls377Fr>(d, shift, out_dev, st);
   return coset_table_t<Bls381Fr>(d, shift, out_dev, st);
 }
 int ntt_bit_reverse(csh_curve_t c, uint64_t* data, uint32_t log_n, uint32_t ncomp, hipStream_t st) {
   if (c == CSH_BN254) return run_bit_reverse<Bn254Fr>((Bn254Fr*)data, log_n, ncomp, st);
+  if (c == CSH_BLS12_377) return run_bit_reverse<Bls377Fr>((Bls377Fr*)data, log_n, ncomp, st);
   return run_bit_reverse<Bls381Fr>((Bls381Fr*)data, log_n, ncomp, st);
 }
 
@@ -361,6 +364,8 @@ int csh_domain_create(csh_curve_t field_of, uint32_t log_n, const uint64_t group
     rc = create_domain_t<Bn254Fr>(field_of, log_n, group_gen, 5, &d);
   else if (field_of == CSH_BLS12_381)
     rc = create_domain_t<Bls381Fr>(field_of, log_n, group_gen, 7, &d);
+  else if (field_of == CSH_BLS12_377)
+    rc = create_domain_t<Bls377Fr>(field_of, log_n, group_gen, 22, &d);  // ark_bls12_377::Fr::GENERATOR
   else {
     set_error("unknown curve %d", (int)field_of);
     return CSH_ERR_INVALID;
@@ -411,7 +416,7 @@ int csh_ifft_dev(csh_domain_t dom, uint64_t* data, uint32_t ncomp, void* stream)
 }
 int csh_bit_reverse_dev(csh_curve_t field_of, uint64_t* data, uint32_t log_n, uint32_t ncomp, void* stream) {
   CSH_REQUIRE(ncomp == 1 || ncomp == 2, "ncomp must be 1 or 2");
-  CSH_REQUIRE(field_of == CSH_BN254 || field_of == CSH_BLS12_381, "unknown curve");
+  CSH_REQUIRE(field_of == CSH_BN254 || field_of == CSH_BLS12_381 || field_of == CSH_BLS12_377, "unknown curve");
   CSH_REQUIRE(log_n <= 31, "log_n too large");
   CSH_TRY(ensure_device());
   return ntt_bit_reverse(field_of, data, log_n, ncomp, resolve_stream(stream));

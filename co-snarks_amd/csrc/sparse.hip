@@ -101,7 +101,7 @@ extern "C" {
 int csh_matrix_upload(csh_curve_t field_of, const uint64_t* row_ptr, const uint32_t* col_idx, const uint64_t* coeffs, size_t n_rows, size_t nnz,
                       csh_matrix_t* out) {
   CSH_REQUIRE(out && row_ptr && (nnz == 0 || (col_idx && coeffs)), "matrix_upload: NULL argument");
-  CSH_REQUIRE(field_of == CSH_BN254 || field_of == CSH_BLS12_381, "unknown curve");
+  CSH_REQUIRE(field_of == CSH_BN254 || field_of == CSH_BLS12_381 || field_of == CSH_BLS12_377, "unknown curve");
   CSH_REQUIRE(row_ptr[n_rows] == nnz, "matrix_upload: row_ptr[n_rows] != nnz");
   CSH_TRY(ensure_device());
   Matrix* m = new Matrix();
@@ -146,6 +146,7 @@ int csh_evaluate_constraints_dev(csh_matrix_t mm, int protocol, int party_id, co
   Matrix* m = reinterpret_cast<Matrix*>(mm);
   hipStream_t st = resolve_stream(stream);
   if (m->curve == CSH_BN254) return eval_t<Bn254Fr>(m, protocol, party_id, public_dev, n_public, witness_dev, out_dev, n_out, st);
+  if (m->curve == CSH_BLS12_377) return eval_t<Bls377Fr>(m, protocol, party_id, public_dev, n_public, witness_dev, out_dev, n_out, st);
   return eval_t<Bls381Fr>(m, protocol, party_id, public_dev, n_public, witness_dev, out_dev, n_out, st);
 }
 
@@ -173,6 +174,7 @@ int csh_groth16_witness_map_dev(csh_domain_t dom, const uint64_t shift[4], int p
   CSH_TRY(csh_evaluate_constraints_dev(ma, protocol, party_id, dpub, n_public, witness_dev, da, n, st));   // reduction.rs:102-110
   CSH_TRY(csh_evaluate_constraints_dev(mb, protocol, party_id, dpub, n_public, witness_dev, db, n, st));   // :118-127
   if (f == CSH_BN254) CSH_TRY(promote_t<Bn254Fr>(protocol, da, num_constraints, dpub, n_public, party_id, st));  // :111-113
+  else if (f == CSH_BLS12_377) CSH_TRY(promote_t<Bls377Fr>(protocol, da, num_constraints, dpub, n_public, party_id, st));
   else CSH_TRY(promote_t<Bls381Fr>(protocol, da, num_constraints, dpub, n_public, party_id, st));
   if (protocol == 1 && seed1 && seed2) {
     dmc = reinterpret_cast<uint64_t*>(ar.take<char>(eb));
@@ -233,6 +235,7 @@ int csh_groth16_witness_map_libsnark(csh_domain_t dom, const uint64_t generator[
   CSH_TRY(h.up(dwit, witness, 32 * comp * n_witness));
   CSH_TRY(csh_evaluate_constraints_dev(ma, protocol, party_id, dpub, n_public, dwit, da, n, h.st));    // reduction.rs:260-266
   if (f == CSH_BN254) CSH_TRY(promote_t<Bn254Fr>(protocol, da, num_constraints, dpub, n_public, party_id, h.st));  // :267-269
+  else if (f == CSH_BLS12_377) CSH_TRY(promote_t<Bls377Fr>(protocol, da, num_constraints, dpub, n_public, party_id, h.st));
   else CSH_TRY(promote_t<Bls381Fr>(protocol, da, num_constraints, dpub, n_public, party_id, h.st));
   CSH_TRY(csh_evaluate_constraints_dev(mb, protocol, party_id, dpub, n_public, dwit, db, n, h.st));    // :276-282
   CSH_TRY(csh_evaluate_constraints_dev(mc, protocol, party_id, dpub, n_public, dwit, dcf, n, h.st));   // :292-298

@@ -164,6 +164,7 @@ using namespace csh;
   switch (field_of) {                                                \
     case CSH_BN254: { using F = Bn254Fr; return CALL; }              \
     case CSH_BLS12_381: { using F = Bls381Fr; return CALL; }         \
+    case CSH_BLS12_377: { using F = Bls377Fr; return CALL; }         \
     default: set_error("unknown curve %d", (int)(field_of)); return CSH_ERR_INVALID; \
   }
 

@@ -606,6 +606,7 @@ int cog16_witness_map(int curve, int reduction, int mode, const uint64_t* const 
   try {
     if (curve == 0) return witness_map_t<Bn254>(reduction, mode, row_ptr, col, coef, n_rows, n_instance, witness_full, n_vars, seed, h_out, h_cap_elems);
     if (curve == 1) return witness_map_t<Bls12_381>(reduction, mode, row_ptr, col, coef, n_rows, n_instance, witness_full, n_vars, seed, h_out, h_cap_elems);
+    if (curve == 3) return witness_map_t<Bls12_377>(reduction, mode, row_ptr, col, coef, n_rows, n_instance, witness_full, n_vars, seed, h_out, h_cap_elems);
     g_err = "unknown curve";
     return -1;
   } catch (const std::exception& e) {

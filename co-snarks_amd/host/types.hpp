@@ -53,6 +53,15 @@ struct Bls12_381 {
   static const uint32_t* g1_generator_words() { return csh::Bls381G1Gen; }
 };
 
+// scalar field only: the curve of the reference's LibSnarkReduction fixtures (co-groth16/src/lib.rs:231-300); witness maps,
+// no MSM / proof (the C ABI has no BLS12-377 group arithmetic)
+struct Bls12_377 {
+  static constexpr csh_curve_t ID = CSH_BLS12_377;
+  using Fr = csh::Bls377Fr;
+  static constexpr uint64_t FR_GENERATOR = 22;  // ark_bls12_377::Fr::GENERATOR
+  static const char* name() { return "bls12377"; }
+};
+
 // Tracing spans mirroring the reference's `tracing::debug_span!` names (groth16.rs:229-331, reduction.rs:97-191):
 // COG16_TRACE=1 prints "<span> took <ms>" on close, like the CLI's FmtSpan::CLOSE layer (co-circom.rs:580-599).
 struct Span {

@@ -42,7 +42,9 @@ extern "C" {
 
 /* CSH_GRUMPKIN (MSM entry points only, group CSH_G1): the BN254 cycle curve y^2 = x^3 - 17 over BN254 Fr with scalar field
  * BN254 Fq -- HonkCurve::fast_msm for short_weierstrass::Projective<GrumpkinConfig> (co-noir-common/src/honk_curve.rs:163-177). */
-typedef enum { CSH_BN254 = 0, CSH_BLS12_381 = 1, CSH_GRUMPKIN = 2 } csh_curve_t;
+/* CSH_BLS12_377: accepted only as `field_of` (its scalar field Fr) by the NTT / share-vector / sparse-matrix / reduction
+ * entry points -- the field of the reference's LibSnarkReduction fixtures (co-groth16/src/lib.rs:231-300). No MSM. */
+typedef enum { CSH_BN254 = 0, CSH_BLS12_381 = 1, CSH_GRUMPKIN = 2, CSH_BLS12_377 = 3 } csh_curve_t;
 typedef enum { CSH_G1 = 0, CSH_G2 = 1 } csh_group_t;
 
 typedef enum {
@@ -194,8 +196,8 @@ int csh_groth16_h_rep3_seeded(csh_domain_t dom, const uint64_t shift[4], uint64_
  * matrix (evaluate_constraint_half_share, 1 component), natural order over Domain::new(n) (csh_domain_create with a
  * NULL generator). generator = F::GENERATOR (Montgomery). h_out[i] = i-th coefficient of (A*B - C)/Z (natural order):
  * 7 NTTs, 1 local_mul_vec (mask = its mask vector, NULL for protocol 0), 4 table multiplications. a, b, c are clobbered.
- * No fixture pins this path in the reference tree (the Penumbra keys are absent): parity is against the oracle's
- * restatement plus the identity H(t) Z(t) = A(t) B(t) - C(t) at a random point (tests/). */
+ * The reference's fixtures for this path (Penumbra BLS12-377 circuits) lack their proving keys: parity is against the
+ * oracle's restatement, itself checked on that fixture data with the identity H(t) Z(t) = A(t) B(t) - C(t) (tests/). */
 int csh_groth16_h_libsnark(csh_domain_t dom, const uint64_t generator[4], int protocol, uint64_t* a, uint64_t* b, uint64_t* c,
                            const uint64_t* mask, uint64_t* h_out);
 int csh_groth16_h_libsnark_dev(csh_domain_t dom, const uint64_t generator[4], int protocol, uint64_t* a_dev, uint64_t* b_dev,

@@ -1,0 +1,56 @@
+"""ark-serialize (uncompressed) readers for the data files next to the LibSnarkReduction path.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py). Formats restated from ark-serialize 0.5 / 0.6 semantics as the
+reference uses them at co-circom/co-groth16/src/lib.rs:257-262: ``Matrix<F> = Vec<Vec<(F, usize)>>`` is a u64 length
+followed by the rows, each a u64 length followed by (field element: little-endian canonical bytes, usize as u64 LE).
+The Penumbra witness files are snarkjs ``wtns`` containers whose section headers were written as zeros, so they are read
+positionally (magic, version, section count, 12-byte header, n8, prime, count, 12-byte header, values).
+"""
+import struct
+
+
+def parse_matrix(data: bytes, nbytes: int = 32):
+    off = 0
+    (n_rows,) = struct.unpack_from("<Q", data, off)
+    off += 8
+    rows = []
+    for _ in range(n_rows):
+        (m,) = struct.unpack_from("<Q", data, off)
+        off += 8
+        row = []
+        for _ in range(m):
+            v = int.from_bytes(data[off:off + nbytes], "little")
+            off += nbytes
+            (idx,) = struct.unpack_from("<Q", data, off)
+            off += 8
+            row.append((v, idx))
+        rows.append(row)
+    if off != len(data):
+        raise ValueError("trailing bytes after Matrix")
+    return rows
+
+
+def parse_wtns_positional(data: bytes):
+    """-> (prime, values)."""
+    if data[:4] != b"wtns":
+        raise ValueError("bad magic")
+    off = 12 + 12
+    (n8,) = struct.unpack_from("<I", data, off)
+    off += 4
+    prime = int.from_bytes(data[off:off + n8], "little")
+    off += n8
+    (count,) = struct.unpack_from("<I", data, off)
+    off += 4 + 12
+    if off + count * n8 != len(data):
+        raise ValueError("unexpected wtns length")
+    return prime, [int.from_bytes(data[off + i * n8:off + (i + 1) * n8], "little") for i in range(count)]
+
+
+def vk_num_instance_variables(data: bytes, g1_bytes: int, g2_bytes: int) -> int:
+    """ark_groth16::VerifyingKey uncompressed: alpha_g1, beta_g2, gamma_g2, delta_g2, gamma_abc_g1: Vec<G1Affine>;
+    len(gamma_abc_g1) = num_instance_variables (the reference derives the same number from the proving key)."""
+    off = g1_bytes + 3 * g2_bytes
+    (k,) = struct.unpack_from("<Q", data, off)
+    if off + 8 + k * g1_bytes != len(data):
+        raise ValueError("unexpected vk length")
+    return k

@@ -186,6 +186,9 @@ BN254_FQ = PrimeField(BN254_Q, "bn254.Fq")
 BN254_FR = PrimeField(BN254_R, "bn254.Fr")
 BLS381_FQ = PrimeField(BLS381_Q, "bls12_381.Fq")
 BLS381_FR = PrimeField(BLS381_R, "bls12_381.Fr")
+# BLS12-377 scalar field: only the LibSnarkReduction fixture path (Penumbra circuits, co-groth16/src/lib.rs:231-300) uses it
+BLS377_R = 8444461749428370424248824938781546531375899335154063827935233455917409239041
+BLS377_FR = PrimeField(BLS377_R, "bls12_377.Fr")
 BN254_FQ2 = Fp2(BN254_FQ)
 BLS381_FQ2 = Fp2(BLS381_FQ)
 

@@ -7,8 +7,8 @@ from oracle import curves as cv
 from oracle import fields as fl
 
 FIELD_IDS = {"bn254.Fq": 0, "bn254.Fr": 1, "bls12_381.Fq": 2, "bls12_381.Fr": 3}
-CURVE_IDS = {"bn254": 0, "bls12_381": 1, "grumpkin": 2}
-FR = {"bn254": fl.BN254_FR, "bls12_381": fl.BLS381_FR, "grumpkin": fl.BN254_FQ}   # scalar field of each curve
+CURVE_IDS = {"bn254": 0, "bls12_381": 1, "grumpkin": 2, "bls12_377": 3}
+FR = {"bn254": fl.BN254_FR, "bls12_381": fl.BLS381_FR, "grumpkin": fl.BN254_FQ, "bls12_377": fl.BLS377_FR}   # scalar field of each curve
 
 
 def rng(seed):
@@ -63,3 +63,23 @@ def jac_to_affine(curve: cv.Curve, limbs):
     """C-ABI Jacobian output -> oracle affine point."""
     (X, Y, Z), = cv.unpack_points(curve, np.asarray(limbs), ncoords=3)
     return curve.to_affine((X, Y, Z))
+
+
+def load_penumbra_fixture():
+    """tests/golden/Groth16/bls12_377/penumbra_output (made by tests/golden/make_golden_penumbra.py from the reference's own
+    LibSnarkReduction test data): -> (F, A, B, C, public, witness, expected dict)."""
+    import gzip
+    import json
+    import os
+    from oracle import arkfmt
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "Groth16", "bls12_377", "penumbra_output")
+    rd = lambda n: gzip.open(os.path.join(d, n + ".gz"), "rb").read()
+    F = fl.BLS377_FR
+    A, B, Cm = (arkfmt.parse_matrix(rd(n)) for n in ["a.bin", "b.bin", "c.bin"])
+    prime, w = arkfmt.parse_wtns_positional(rd("witness.wtns"))
+    assert prime == F.p
+    exp = json.load(open(os.path.join(d, "expected.json")))
+    ni = arkfmt.vk_num_instance_variables(rd("circuit.vk"), 96, 192)
+    assert ni == exp["num_instance_variables"] and len(A) == exp["num_constraints"]
+    return F, A, B, Cm, w[:ni], w[ni:], exp
+

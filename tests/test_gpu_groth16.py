@@ -137,3 +137,24 @@ def test_libsnark_reduction_device_matches_oracle(gpu, curve, generator, n_publi
     assert [(x + y + z) % F.p for x, y, z in zip(*parts)] == want
     assert parts[0] != want                      # masked shares, not the plain vector three times
 
+
+@pytest.mark.gpu
+def test_libsnark_reduction_device_on_the_reference_penumbra_fixture(gpu):
+    """LibSnarkReduction on the device, BLS12-377 Fr, on the reference's own Penumbra test data (13875 constraints, domain
+    2^14): h bit-exact against expected.json, the QAP identity at the committed point, three Rep3 parties sum to h."""
+    import hashlib
+    from cosnarks_amd import groth16 as dev
+    from oracle import ntt
+    F, A, B, Cm, pub, wit, exp = H.load_penumbra_fixture()
+    cid = H.CURVE_IDS["bls12_377"]
+    mont = lambda M: [[(F.to_mont(c), i) for c, i in row] for row in M]
+    mats = (mont(A), mont(B), mont(Cm))
+    wm = H.pack(F, pub + wit)
+    got = H.unpack(F, dev.witness_map(cid, dev.LIBSNARK_REDUCTION, False, mats, len(pub), wm))
+    assert len(got) == exp["domain_size"]
+    assert hashlib.sha256(b"".join(x.to_bytes(32, "little") for x in got)).hexdigest() == exp["h_sha256"]
+    assert str(ntt.eval_poly_at(F, got, int(exp["tau"]))) == exp["H_at_tau"]
+    hs = dev.witness_map(cid, dev.LIBSNARK_REDUCTION, True, mats, len(pub), wm, seed=11)
+    parts = [H.unpack(F, hs[p]) for p in range(3)]
+    assert [(x + y + z) % F.p for x, y, z in zip(*parts)] == got
+

@@ -191,3 +191,20 @@ def test_libsnark_reduction_restatement_satisfies_qap_identity(curve, generator)
         hs = [g16.witness_map_libsnark(F, generator, A, B, Cm, n_constraints, g16.Rep3Driver(F, pid), pub, shares[pid]) for pid in range(3)]
         assert [(x + y + z) % F.p for x, y, z in zip(*hs)] == h
 
+
+def test_libsnark_reduction_on_the_reference_penumbra_fixture():
+    """The reference's LibSnarkReduction tests (co-groth16/src/lib.rs:231-300) run on Penumbra BLS12-377 circuits whose
+    matrices / witness / vk are in its tree (the proving key is not). On that data: every constraint is satisfied, the
+    oracle's h satisfies the QAP identity, and equals the committed expected.json (tests/golden/make_golden_penumbra.py)."""
+    import hashlib
+    from oracle import groth16 as g16
+    F, A, B, Cm, pub, wit, exp = H.load_penumbra_fixture()
+    drv = g16.PlainDriver(F)
+    for ra, rb, rc in list(zip(A, B, Cm))[::97]:
+        assert drv.eval_row(ra, pub, wit) * drv.eval_row(rb, pub, wit) % F.p == drv.eval_row(rc, pub, wit)
+    h = g16.witness_map_libsnark(F, exp["generator"], A, B, Cm, len(A), drv, pub, wit)
+    assert len(h) == exp["domain_size"]
+    assert hashlib.sha256(b"".join(x.to_bytes(32, "little") for x in h)).hexdigest() == exp["h_sha256"]
+    assert [str(x) for x in h[:4]] == exp["h_first"]
+    assert g16.libsnark_identity_holds(F, exp["generator"], A, B, Cm, len(A), pub, wit, h, 0xDEADBEEF12345)
+
