@@ -121,10 +121,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # One rank per GPU over RCCL is the real configuration. BENCH_DIST_BACKEND=gloo (with ranks folded onto the GPUs
+    # that exist) is a debugging aid to exercise the N > 1 code path on a box with fewer GPUs than ranks.
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import ctypes as C
 
@@ -133,7 +140,7 @@ def main():
     import cosnarks_amd as hip
     from cosnarks_amd import bindings as B
     L = hip.lib()
-    B._check(L.csh_init(local_rank))
+    B._check(L.csh_init(dev_index))
 
     n = 1 << args.log_n
     stream = torch.cuda.current_stream().cuda_stream
@@ -163,12 +170,13 @@ def main():
             B._check(L.csh_msm_dev(bases_h, C.c_size_t(0), C.c_size_t(n), C.c_void_p(sc.data_ptr()), 1, out.ctypes.data_as(C.c_void_p), C.c_void_p(stream)))
             return out
         B._check(L.csh_msm_partial_dev(bases_h, C.c_size_t(0), C.c_size_t(n), C.c_void_p(sc.data_ptr()), 1, C.c_void_p(part.data_ptr()), C.c_void_p(stream)))
-        return allgather_and_fold(part, hip.BN254, hip.G1, world, dist)   # RCCL all-gather over xGMI + host fold
+        return allgather_and_fold(part if backend == "nccl" else part.cpu(), hip.BN254, hip.G1, world, dist)   # RCCL all-gather over xGMI + host fold
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        B.sync()
 
     for _ in range(args.warmup):
         step()
@@ -179,7 +187,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
@@ -188,11 +196,16 @@ def main():
     # ---- per-kernel timing for the roofline object (separate untimed passes, HIP events on `stream`)
     roofline = None
     stage_ms = None
-    if world == 1:
+    def local_msm():  # the device part of a step on this rank (no collective): what the roofline object describes
+        if world == 1:
+            return step()
+        B._check(L.csh_msm_partial_dev(bases_h, C.c_size_t(0), C.c_size_t(n), C.c_void_p(sc.data_ptr()), 1, C.c_void_p(part.data_ptr()), C.c_void_p(stream)))
+
+    if True:  # every rank runs the same untimed passes (keeps the ranks in step); rank 0 reports
         os.environ["CSH_MSM_TIMING"] = "1"
         acc = []
         for _ in range(5):
-            step()
+            local_msm()
             acc.append(B.msm_last_timing())
         del os.environ["CSH_MSM_TIMING"]
         stage_ms = [float(np.mean([a[i] for a in acc])) for i in range(6)]
