@@ -10,6 +10,7 @@
 // Bounds contract (checked by tests/host): mul/sqr operands may have limbs < 2^30 (i.e. a sum of two
 // normalised values) and values < 8p; outputs are normalised (limbs < 2^B) with value < 2p.
 #pragma once
+#include <math.h>
 #include "field.hpp"
 
 namespace csh {
@@ -378,6 +379,39 @@ struct FpS {
     return r;
   }
 
+  // Partial reduction of a sum: full signed carry propagation, then subtract k*p with k estimated from the top limb
+  // (float reciprocal of T + 1, T = top limb of p; exact to +-1 for |k| <= 64). Result: value in (-p - eps, 2p + eps), limbs
+  // 0..NL-2 in [0, 2^B), small signed top limb -- a valid product operand. ~45 simple instructions, no multiplication by
+  // a field constant. Used where sums feed sums (the s = u + v output of a decimation-in-frequency butterfly doubles
+  // per stage and would leave the product routine's value range after ~6 stages).
+  CSH_HD FpS fold_top() const {
+    FpS r;
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < NL - 1; ++i) {
+      const int32_t v = l[i] + c;
+      r.l[i] = (int32_t)((uint32_t)v & LP::MASK);
+      c = v >> B;
+    }
+    r.l[NL - 1] = l[NL - 1] + c;
+    const float inv_t = 1.0f / (float)(LP::MOD[NL - 1] + 1u);
+    const int32_t k = (int32_t)floorf((float)r.l[NL - 1] * inv_t);
+    int64_t cc = 0;
+#pragma unroll
+    for (int i = 0; i < NL - 1; ++i) {
+      const int64_t t = (int64_t)r.l[i] - (int64_t)k * (int64_t)(int32_t)LP::MOD[i] + cc;
+      r.l[i] = (int32_t)((uint32_t)t & LP::MASK);
+      cc = t >> B;
+    }
+    r.l[NL - 1] = (int32_t)((int64_t)r.l[NL - 1] - (int64_t)k * (int64_t)(int32_t)LP::MOD[NL - 1] + cc);
+    return r;
+  }
+
+  // canonical() for values that drifted further from [0, p): |value| < 32p (sums over up to ~11 butterfly stages).
+  // A quotient estimate from the top limb (float reciprocal: off by at most one for |k| <= 32) brings the value into
+  // (-p - eps, 2p + eps), inside canonical()'s range. Dividing by T + 1 instead of T keeps the remainder's sign.
+  CSH_HD FpS canonical_wide() const { return fold_top().canonical(); }
+
   // cheap necessary condition for value == 0 (mod p), valid for |value| < 8p: value = k p with |k| < 8
   CSH_HD bool maybe_zero() const {
     const uint32_t k = ((uint32_t)l[0] * LP::PINV) & LP::MASK;
@@ -437,7 +471,9 @@ struct FpS {
 
 using Fq29s = FpS<Bn254Fq29Params, Bn254Fq>;
 using Fq28s = FpS<Bls381Fq28Params, Bls381Fq>;
-using Fr29s = FpS<Bn254Fr29Params, Bn254Fr>;  // Grumpkin base field
+using Fr29s = FpS<Bn254Fr29Params, Bn254Fr>;  // Grumpkin base field; BN254 NTT butterflies
+using Bls381Fr29s = FpS<Bls381Fr29Params, Bls381Fr>;
+using Bls377Fr29s = FpS<Bls377Fr29Params, Bls377Fr>;
 
 // ---- Fp2 = Fp[i]/(i^2+1) over the signed lazy field: schoolbook products accumulated double-width with ONE
 // reduction per output component (2 NL^2 + NL^2 mads per component, cheaper than Karatsuba's three full

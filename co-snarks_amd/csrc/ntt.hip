@@ -8,13 +8,15 @@
 // A pass executes stages [s0, s0+k) for one tile entirely in LDS: the tile is the 2^k stage-bit values
 // x 2^cb low "column" entries x ncomp components (ncomp = 2 for Rep3 shares), so every HBM access is a
 // contiguous run of 2^cb * ncomp * 32 bytes (>= 256 B) and a 2^22 transform needs 3 read+write sweeps.
-// LDS keeps each element as two 16-byte halves in separate arrays so lane-consecutive ds_read_b128 /
-// ds_write_b128 are bank-conflict free.
+// Default path: butterflies in the signed lazy 9 x 29-bit field (k_ntt_pass_lazy, limb-major LDS arrays); the 32-bit
+// CIOS pass (k_ntt_pass: two 16-byte halves per element, conflict-free ds_read/write_b128) remains selectable with
+// CSH_NTT_LAZY=0 for A/B measurements.
 #include <stdlib.h>
 #include <string.h>
 
 #include "common.hpp"
 #include "field.hpp"
+#include "field29.hpp"
 
 namespace csh {
 
@@ -28,6 +30,9 @@ struct Domain {
   size_t n;
   void* tw_fwd;  // w^j, j < n/2
   void* tw_inv;  // w^-j
+  void* tw_fwd_lazy;  // same powers as packed canonical w^j * R' (R' = 2^261): twiddles of the lazy-field butterflies
+  void* tw_inv_lazy;
+  uint32_t n_inv_lazy[8];  // (1/n) * R', packed
   uint32_t gen[8], gen_inv[8], n_inv[8];  // Montgomery
 };
 
@@ -114,6 +119,108 @@ __global__ __launch_bounds__(NTT_MAX_THREADS) void k_ntt_pass(F* __restrict__ da
   }
 }
 
+// ---- lazy-field pass ---------------------------------------------------------------------------------------------
+// Same tiling, butterflies in the signed 9 x 29-bit representation (field29.hpp): an element x*R (arkworks Montgomery,
+// R = 2^256) is re-sliced into 29-bit limbs as is, the twiddle comes in the R' = 2^261 domain, so the lazy Montgomery
+// product  (x R)(w R') / R' = (x w) R  stays in the arkworks domain with no conversion multiplication. A product costs
+// 162 v_mad_i64_i32 instead of ~136 mads + ~300 carry instructions; sums are limb-wise + one parallel carry step. Values
+// drift to at most ~(1 + k) p over the k <= 11 stages of a decimation-in-time pass (u' = u + v w: limbs stay normalised,
+// the top limb absorbs the growth); in a decimation-in-frequency pass the sum output feeds the next sum and would double
+// per stage, so it is folded back below 2p each stage (fold_top: a top-limb quotient estimate, no multiplication). The
+// tile is brought back to [0, p) once per pass when it is stored (canonical_wide).
+template <class LZ>
+struct LazyLds {
+  int32_t* base;
+  int E;
+  __device__ __forceinline__ LZ get(int e) const {
+    LZ r;
+#pragma unroll
+    for (int i = 0; i < LZ::NL; ++i) r.l[i] = base[i * E + e];
+    return r;
+  }
+  __device__ __forceinline__ void put(int e, const LZ& v) const {
+#pragma unroll
+    for (int i = 0; i < LZ::NL; ++i) base[i * E + e] = v.l[i];
+  }
+};
+
+template <class F, class LZ, bool DIF>
+__global__ __launch_bounds__(NTT_MAX_THREADS) void k_ntt_pass_lazy(F* __restrict__ data, const F* __restrict__ twl, int L, int s0, int k, int cb,
+                                                                    int ncomp_log, F scale_lazy, int do_scale) {
+  extern __shared__ uint4 lds_raw[];
+  const int cc_log = cb + ncomp_log;
+  const int CC = 1 << cc_log;
+  const int E = 1 << (k + cc_log);
+  const LazyLds<LZ> lds{reinterpret_cast<int32_t*>(lds_raw), E};
+  const int mid_bits = s0 - cb;
+  const size_t tile = blockIdx.x;
+  const size_t mid = tile & ((size_t(1) << mid_bits) - 1);
+  const size_t hi_idx = tile >> mid_bits;
+  const int tid = threadIdx.x;
+  const int NT = blockDim.x;
+
+  for (int e = tid; e < E; e += NT) {
+    const int cc = e & (CC - 1);
+    const size_t t = e >> cc_log;
+    const size_t g = ((((hi_idx << k) | t) << mid_bits) | mid) * CC + cc;
+    lds.put(e, LZ::unpack(data[g]));
+  }
+  __syncthreads();
+
+  const int half_E = E >> 1;
+  for (int qq = 0; qq < k; ++qq) {
+    const int q = DIF ? (k - 1 - qq) : qq;
+    const int half = 1 << q;
+    const int tw_shift = L - 1 - (s0 + q);
+    for (int bidx = tid; bidx < half_E; bidx += NT) {
+      const int cc = bidx & (CC - 1);
+      const int tb = bidx >> cc_log;
+      const int t_lo = tb & (half - 1);
+      const int t0 = ((tb >> q) << (q + 1)) | t_lo;
+      const int e0 = (t0 << cc_log) | cc;
+      const int e1 = e0 + (half << cc_log);
+      const size_t imod = ((size_t)t_lo << s0) | (mid << cb) | (size_t)(cc >> ncomp_log);
+      const LZ w = LZ::unpack(twl[imod << tw_shift]);
+      const LZ u = lds.get(e0);
+      const LZ v = lds.get(e1);
+      if (DIF) {
+        lds.put(e0, LZ::add(u, v).fold_top());   // sums feed sums here: keep the value within (-p, 2p) every stage
+        lds.put(e1, LZ::mul(LZ::sub(u, v), w));  // the two-term difference is an admissible product operand as is
+      } else {
+        const LZ x = LZ::mul(v, w);
+        lds.put(e0, LZ::add(u, x).normalized());
+        lds.put(e1, LZ::sub(u, x).normalized());
+      }
+    }
+    __syncthreads();
+  }
+
+  const LZ sc = LZ::unpack(scale_lazy);
+  for (int e = tid; e < E; e += NT) {
+    const int cc = e & (CC - 1);
+    const size_t t = e >> cc_log;
+    const size_t g = ((((hi_idx << k) | t) << mid_bits) | mid) * CC + cc;
+    LZ f = lds.get(e);
+    if (do_scale) f = LZ::mul(f, sc);
+    data[g] = f.canonical_wide().pack();
+  }
+}
+
+// out[i] = in[i] re-encoded from x * 2^256 to packed canonical x * R'
+template <class F, class LZ>
+__global__ __launch_bounds__(256) void k_to_lazy_table(const F* __restrict__ in, F* __restrict__ out, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = LZ::repack_for_storage(in[i]);
+}
+
+template <class F>
+struct LazyOf;
+template <>
+struct LazyOf<Bn254Fr> { using type = Fr29s; };
+template <>
+struct LazyOf<Bls381Fr> { using type = Bls381Fr29s; };
+template <>
+struct LazyOf<Bls377Fr> { using type = Bls377Fr29s; };
+
 __device__ __forceinline__ uint32_t bitrev_n(uint32_t i, int log_n) { return log_n == 0 ? 0 : (__brev(i) >> (32 - log_n)); }
 
 // in-place bit-reversal permutation of entries (ncomp elements each)
@@ -194,19 +301,42 @@ static int run_ntt(const Domain* d, F* data, uint32_t ncomp, bool dif, hipStream
   const int ncomp_log = ncomp == 2 ? 1 : 0;
   Pass passes[8];
   const int np = plan_passes(L, ncomp_log, passes);
-  const F* tw = reinterpret_cast<const F*>(dif ? d->tw_inv : d->tw_fwd);
-  F scale = f_from_words<F>(d->n_inv);
+  static const bool use_lazy = [] {
+    const char* e = getenv("CSH_NTT_LAZY");
+    return !(e && atoi(e) == 0);
+  }();
+  using LZ = typename LazyOf<F>::type;
+  const F* tw = reinterpret_cast<const F*>(use_lazy ? (dif ? d->tw_inv_lazy : d->tw_fwd_lazy) : (dif ? d->tw_inv : d->tw_fwd));
+  F scale = f_from_words<F>(use_lazy ? d->n_inv_lazy : d->n_inv);
   static const int NTT_THREADS = [] {
     const char* e = getenv("CSH_NTT_THREADS");
-    const int v = e ? atoi(e) : 512;
-    return (v == 256 || v == 512 || v == 1024) ? v : 512;
+    const int v = e ? atoi(e) : 1024;  // 16 waves per tile: measured best for both field representations
+    return (v == 256 || v == 512 || v == 1024) ? v : 1024;
   }();
   for (int pi = 0; pi < np; ++pi) {
     const Pass& p = dif ? passes[np - 1 - pi] : passes[pi];
     const int tile_log = p.k + p.cb;  // entries
     const size_t tiles = d->n >> tile_log;
-    const size_t lds_bytes = (size_t(32) << (tile_log + ncomp_log));
+    const size_t lds_bytes = use_lazy ? (size_t(4 * LZ::NL) << (tile_log + ncomp_log)) : (size_t(32) << (tile_log + ncomp_log));
     const int do_scale = dif && (p.s0 == 0);
+    if (use_lazy) {
+      if (lds_bytes > 48 * 1024) {
+        static thread_local bool raised_lazy[2] = {false, false};
+        if (!raised_lazy[dif ? 1 : 0]) {
+          const void* fn = dif ? (const void*)k_ntt_pass_lazy<F, LZ, true> : (const void*)k_ntt_pass_lazy<F, LZ, false>;
+          CSH_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (4 * LZ::NL) << NTT_TILE_LOG));
+          raised_lazy[dif ? 1 : 0] = true;
+        }
+      }
+      if (dif)
+        hipLaunchKernelGGL((k_ntt_pass_lazy<F, LZ, true>), dim3((unsigned)tiles), dim3(NTT_THREADS), lds_bytes, st, data, tw, L, p.s0, p.k, p.cb,
+                           ncomp_log, scale, do_scale);
+      else
+        hipLaunchKernelGGL((k_ntt_pass_lazy<F, LZ, false>), dim3((unsigned)tiles), dim3(NTT_THREADS), lds_bytes, st, data, tw, L, p.s0, p.k, p.cb,
+                           ncomp_log, scale, 0);
+      CSH_HIP(hipGetLastError());
+      continue;
+    }
     if (lds_bytes > 48 * 1024) {
       static thread_local bool raised[2] = {false, false};
       if (!raised[dif ? 1 : 0]) {
@@ -301,13 +431,27 @@ static int create_domain_t(csh_curve_t curve, uint32_t log_n, const uint64_t* ge
   hipStream_t st = resolve_stream(nullptr);
   hipLaunchKernelGGL((k_powers<F, false>), dim3(grid_for((half + POW_CHUNK - 1) / POW_CHUNK, 256)), dim3(256), 0, st, (F*)d->tw_fwd, gen, half, 0);
   hipLaunchKernelGGL((k_powers<F, false>), dim3(grid_for((half + POW_CHUNK - 1) / POW_CHUNK, 256)), dim3(256), 0, st, (F*)d->tw_inv, gen_inv, half, 0);
+  using LZ = typename LazyOf<F>::type;
+  d->tw_fwd_lazy = d->tw_inv_lazy = nullptr;
+  hipError_t e4 = hipMalloc(&d->tw_fwd_lazy, half * sizeof(F));
+  hipError_t e5 = hipMalloc(&d->tw_inv_lazy, half * sizeof(F));
+  if (e4 == hipSuccess && e5 == hipSuccess) {
+    hipLaunchKernelGGL((k_to_lazy_table<F, LZ>), dim3(grid_for(half, 256)), dim3(256), 0, st, (const F*)d->tw_fwd, (F*)d->tw_fwd_lazy, half);
+    hipLaunchKernelGGL((k_to_lazy_table<F, LZ>), dim3(grid_for(half, 256)), dim3(256), 0, st, (const F*)d->tw_inv, (F*)d->tw_inv_lazy, half);
+  }
+  {
+    const F nl = LZ::repack_for_storage(n_inv);  // host evaluation of the same template
+    memcpy(d->n_inv_lazy, &nl, 32);
+  }
   hipError_t e3 = hipStreamSynchronize(st);
-  if (e3 != hipSuccess) {
-    set_error("twiddle generation failed: %s", hipGetErrorString(e3));
+  if (e3 != hipSuccess || e4 != hipSuccess || e5 != hipSuccess) {
+    set_error("twiddle generation failed: %s", hipGetErrorString(e3 != hipSuccess ? e3 : (e4 != hipSuccess ? e4 : e5)));
     (void)hipFree(d->tw_fwd);
     (void)hipFree(d->tw_inv);
+    if (d->tw_fwd_lazy) (void)hipFree(d->tw_fwd_lazy);
+    if (d->tw_inv_lazy) (void)hipFree(d->tw_inv_lazy);
     delete d;
-    return CSH_ERR_HIP;
+    return e3 != hipSuccess ? CSH_ERR_HIP : CSH_ERR_OOM;
   }
   *out = d;
   return CSH_OK;
@@ -384,6 +528,8 @@ int csh_domain_free(csh_domain_t dom) {
   Domain* d = reinterpret_cast<Domain*>(dom);
   if (d->tw_fwd) (void)hipFree(d->tw_fwd);
   if (d->tw_inv) (void)hipFree(d->tw_inv);
+  if (d->tw_fwd_lazy) (void)hipFree(d->tw_fwd_lazy);
+  if (d->tw_inv_lazy) (void)hipFree(d->tw_inv_lazy);
   delete d;
   return CSH_OK;
 }

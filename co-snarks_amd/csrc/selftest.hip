@@ -187,6 +187,39 @@ int lazy_chain_check_t(const void* affine_pts, size_t n, size_t len, size_t nthr
 
 }  // namespace
 
+// Host run of the lazy NTT butterfly arithmetic (ntt.hip k_ntt_pass_lazy): a, b, w arkworks-Montgomery elements of the
+// scalar field; k times  acc = (acc +/- b*w).normalized()  with the twiddle in the R' domain, then canonical_wide().pack().
+// Expected: a +/- k*b*w (still arkworks-Montgomery). Exercises the value drift a pass accumulates and its reduction.
+template <class LZ, class F>
+static int lazy_fr_chain_t(const uint64_t a[4], const uint64_t b[4], const uint64_t w[4], int k, int negative, uint64_t out[4]) {
+  F fa, fb, fw;
+  memcpy(&fa, a, 32);
+  memcpy(&fb, b, 32);
+  memcpy(&fw, w, 32);
+  LZ acc = LZ::unpack(fa);
+  const LZ lb = LZ::unpack(fb);
+  const LZ lw = LZ::unpack(LZ::repack_for_storage(fw));
+  for (int i = 0; i < k; ++i) {
+    const LZ x = LZ::mul(lb, lw);
+    acc = negative ? LZ::sub(acc, x).normalized() : LZ::add(acc, x).normalized();
+  }
+  {  // sums feeding sums (decimation in frequency): doubling with fold_top must stay exact and in range
+    LZ d = acc;
+    for (int i = 0; i < 12; ++i) d = LZ::add(d, d).fold_top();
+    LZ two12 = LZ::unpack(LZ::repack_for_storage(F::from_u64(4096)));
+    const F ra = LZ::mul(acc, two12).canonical_wide().pack(), rb = d.canonical_wide().pack();
+    if (memcmp(&ra, &rb, 32) != 0) return 2;
+  }
+  // one more product with a drifted operand (what the next stage does with it), divided out again by w^-1 is not
+  // available here: multiply by the R'-domain one instead (value unchanged, reduced)
+  const LZ one = LZ::one();
+  const LZ red = LZ::mul(acc, one);
+  const F r1 = acc.canonical_wide().pack(), r2 = red.canonical_wide().pack();
+  if (memcmp(&r1, &r2, 32) != 0) return 1;
+  memcpy(out, &r1, 32);
+  return CSH_OK;
+}
+
 extern "C" {
 
 int csh_selftest_lazy_chain_dev(int curve, int group, const void* affine_pts, size_t n, size_t len, size_t nthreads, size_t host_samples,
@@ -244,6 +277,13 @@ int csh_selftest_lazy_tree(int curve, int group, const void* affine_pts, const u
   if (curve == CSH_BLS12_381 && group == CSH_G1) return lazy_tree_t<Fq28s, Bls381Fq>(affine_pts, neg, npts, group_len, weight, out_xyzz);
   if (curve == CSH_BLS12_381 && group == CSH_G2) return lazy_tree_t<Fq28s2, Bls381Fq2>(affine_pts, neg, npts, group_len, weight, out_xyzz);
   if (curve == CSH_GRUMPKIN && group == CSH_G1) return lazy_tree_t<Fr29s, Bn254Fr>(affine_pts, neg, npts, group_len, weight, out_xyzz);
+  return CSH_ERR_INVALID;
+}
+
+int csh_selftest_lazy_fr_chain(int field_of, const uint64_t a[4], const uint64_t b[4], const uint64_t w[4], int k, int negative, uint64_t out[4]) {
+  if (field_of == CSH_BN254) return lazy_fr_chain_t<Fr29s, Bn254Fr>(a, b, w, k, negative, out);
+  if (field_of == CSH_BLS12_381) return lazy_fr_chain_t<Bls381Fr29s, Bls381Fr>(a, b, w, k, negative, out);
+  if (field_of == CSH_BLS12_377) return lazy_fr_chain_t<Bls377Fr29s, Bls377Fr>(a, b, w, k, negative, out);
   return CSH_ERR_INVALID;
 }
 

@@ -308,3 +308,26 @@ def test_host_window_fold_64bit_limbs(hip, curve, group):
     buf = partial(7, pa) + partial(7, [G.neg(P) for P in pa])
     assert hip.lib().csh_msm_fold_partials(cid, group, buf, C.c_size_t(2), out.ctypes.data_as(C.c_void_p)) == 0
     assert H.jac_to_affine(G, out) is None
+
+
+@pytest.mark.parametrize("curve", ["bn254", "bls12_381", "bls12_377"])
+def test_lazy_ntt_butterfly_arithmetic(hip, curve):
+    """The lazy-field butterfly chain of the NTT kernels (k_ntt_pass_lazy) run on the host with limb-bound assertions:
+    a +/- k * b * w for k up to 24 stages of drift, edge values included, reduced by canonical_wide()."""
+    F = H.FR[curve]
+    cid = H.CURVE_IDS[curve]
+    r = H.rng(1234)
+    vals = [0, 1, F.p - 1, F.p - 2, (F.p - 1) // 2] + H.rand_elems(F, 12, r)
+    L = hip.lib()
+    for i, a in enumerate(vals):
+        b = vals[(3 * i + 1) % len(vals)]
+        w = vals[(5 * i + 2) % len(vals)]
+        for k in (0, 1, 2, 11, 24):
+            for neg in (0, 1):
+                out = np.zeros(4, dtype=np.uint64)
+                rc = L.csh_selftest_lazy_fr_chain(cid, H.pack(F, [a]).ctypes.data_as(C.c_void_p), H.pack(F, [b]).ctypes.data_as(C.c_void_p),
+                                                  H.pack(F, [w]).ctypes.data_as(C.c_void_p), k, neg, out.ctypes.data_as(C.c_void_p))
+                assert rc == 0
+                want = (a - k * b * w) % F.p if neg else (a + k * b * w) % F.p
+                assert H.unpack(F, out) == [want], (a, b, w, k, neg)
+
