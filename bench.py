@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 # The kernel gathers every 64-byte base once per window (W = 17 at 2^20): 1.14 GB is inherent to Pippenger; the rest is
 # the x2 FETCH_SIZE correction applied to 64-byte gathers (raw counter: 1.44 GB), the sorted-index reads and the
 # partial-sum writes (0.14 GB).
-PMC_TRAFFIC_BYTES = {20: 3014443064}
+PMC_TRAFFIC_BYTES = {20: 3006543256}
 MADS_PER_MADD = 1467   # 10 products (6 mul 81 + 2 sqr 45 + fused 2x81) + 9 Montgomery reductions x 81, 9-limb 29-bit field
 MAD_PEAK_T = 31.0      # measured v_mad_u64_u32 issue rate, T lane-ops/s
 
@@ -218,7 +218,7 @@ def main():
         traffic = PMC_TRAFFIC_BYTES.get(args.log_n)
         roofline = {"bound": "hbm", "kernel": "k_msm_accum<Bn254G1>", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                     "frac": round(achieved / 8000.0, 5), "traffic": traffic,
-                    "traffic_source": "profiles/r01_e_msm_bn254g1_2p20_pmc_hbm_bytes.csv" if traffic else None,
+                    "traffic_source": "profiles/r01_f_msm_bn254g1_2p20_pmc_hbm_bytes.csv" if traffic else None,
                     "note": "MSM is integer-ALU (v_mad_u64_u32 / v_mad_i64_i32) bound, not HBM bound; see DESIGN.md 3.1",
                     # integer roofline of the same kernel: mixed additions x 64-bit multiply-adds per addition (ISA count of
                     # the k_msm_accum<Bn254G1> loop body) over the measured issue peak of those instructions
