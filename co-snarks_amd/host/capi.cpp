@@ -9,6 +9,7 @@
 #include <random>
 
 #include "groth16.hpp"
+#include "arkwire.hpp"
 #include "plonk_honk.hpp"
 #include "zkey.hpp"
 
@@ -555,6 +556,33 @@ int driver_msm_t(int driver, const void* points, size_t n_points, const uint64_t
   throw Error("driver not available for this curve");
 }
 
+// LibSnarkReduction straight from the reference's file formats (co-groth16/src/lib.rs:243-262): ark-serialize Matrix<F> blobs
+// for a, b, c and a wtns container. h_out: plain h (Montgomery limbs); returns the domain size or -1.
+template <class P>
+static int libsnark_from_files_t(const uint8_t* const mats[3], const size_t lens[3], const uint8_t* wtns, size_t wlen, size_t n_instance,
+                                 uint64_t* h_out, size_t h_cap) {
+  using Fr = typename P::Fr;
+  ConstraintMatrices<P> m;
+  ark::Reader ra(mats[0], lens[0]), rb(mats[1], lens[1]), rc(mats[2], lens[2]);
+  m.a = ark::read_matrix<Fr>(ra);
+  m.b = ark::read_matrix<Fr>(rb);
+  m.c = ark::read_matrix<Fr>(rc);
+  if (!ra.done() || !rb.done() || !rc.done()) throw Error("trailing bytes after Matrix");
+  if (m.a.size() != m.b.size() || m.a.size() != m.c.size()) throw Error("matrices disagree on the number of constraints");
+  std::vector<Fr> w = ark::read_wtns_positional<Fr>(wtns, wlen);
+  if (n_instance > w.size()) throw Error("more instance variables than witness values");
+  m.num_instance_variables = n_instance;
+  m.num_witness_variables = w.size() - n_instance;
+  m.num_constraints = m.a.size();
+  m.upload();
+  UnitState st;
+  std::vector<Fr> pub(w.begin(), w.begin() + n_instance), wit(w.begin() + n_instance, w.end());
+  std::vector<Fr> h = LibSnarkReduction::witness_map_from_matrices<P, PlainGroth16Driver<P>>(st, m, pub, wit);
+  if (h.size() > h_cap) throw Error("h_out too small");
+  memcpy(h_out, h.data(), 32 * h.size());
+  return (int)h.size();
+}
+
 }  // namespace
 
 extern "C" {
@@ -592,6 +620,63 @@ int cog16_driver_msm(int curve, int driver, const void* points, size_t n_points,
     if (curve == 2) return driver_msm_t<GrumpkinCurve, void>(driver, points, n_points, scalars, n_scalars, seed, out);
     g_err = "unknown curve";
     return -1;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+
+int cog16_libsnark_from_files(int curve, const uint8_t* a, size_t alen, const uint8_t* b, size_t blen, const uint8_t* c, size_t clen,
+                              const uint8_t* wtns, size_t wlen, size_t n_instance, uint64_t* h_out, size_t h_cap_elems) {
+  try {
+    const uint8_t* const mats[3] = {a, b, c};
+    const size_t lens[3] = {alen, blen, clen};
+    if (curve == 0) return libsnark_from_files_t<Bn254>(mats, lens, wtns, wlen, n_instance, h_out, h_cap_elems);
+    if (curve == 1) return libsnark_from_files_t<Bls12_381>(mats, lens, wtns, wlen, n_instance, h_out, h_cap_elems);
+    if (curve == 3) return libsnark_from_files_t<Bls12_377>(mats, lens, wtns, wlen, n_instance, h_out, h_cap_elems);
+    g_err = "unknown curve";
+    return -1;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+
+// ark-serialize round trips of the host mirror (arkwire.hpp): mode 0 Vec<Fr> (in: Montgomery limbs of n elements ->
+// out: serialized bytes, then parsed back and compared), mode 1 G1 affine points (n points, C-ABI layout). Returns the
+// number of bytes written to `out`, or -1.
+int cog16_ark_roundtrip(int curve, int mode, const void* in, size_t n, uint8_t* out, size_t cap) {
+  try {
+    std::vector<uint8_t> buf;
+    auto run = [&](auto tag) {
+      using P = decltype(tag);
+      using Fr = typename P::Fr;
+      using Fq = typename P::Fq;
+      if (mode == 0) {
+        std::vector<Fr> v(n);
+        memcpy((void*)v.data(), in, sizeof(Fr) * n);
+        ark::write_vec(buf, v);
+        ark::Reader r(buf.data(), buf.size());
+        std::vector<Fr> back = ark::read_vec<Fr>(r);
+        if (!r.done() || back.size() != n || memcmp(back.data(), v.data(), sizeof(Fr) * n) != 0) throw Error("Vec<F> round trip mismatch");
+      } else {
+        std::vector<AffineT<Fq>> pts(n);
+        memcpy((void*)pts.data(), in, sizeof(AffineT<Fq>) * n);
+        for (auto& pt : pts) ark::write_g1(buf, pt);
+        ark::Reader r(buf.data(), buf.size());
+        for (auto& pt : pts) {
+          AffineT<Fq> q = ark::read_g1<Fq>(r);
+          if (memcmp(&q, &pt, sizeof q) != 0) throw Error("G1 round trip mismatch");
+        }
+        if (!r.done()) throw Error("trailing bytes");
+      }
+    };
+    if (curve == 0) run(Bn254{});
+    else if (curve == 1) run(Bls12_381{});
+    else throw Error("unknown curve");
+    if (buf.size() > cap) throw Error("output buffer too small");
+    memcpy(out, buf.data(), buf.size());
+    return (int)buf.size();
   } catch (const std::exception& e) {
     g_err = e.what();
     return -1;

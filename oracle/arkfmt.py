@@ -54,3 +54,46 @@ def vk_num_instance_variables(data: bytes, g1_bytes: int, g2_bytes: int) -> int:
     if off + 8 + k * g1_bytes != len(data):
         raise ValueError("unexpected vk length")
     return k
+
+
+# ---- points and vectors ------------------------------------------------------------------------------------------
+def ser_field(v: int, nbytes: int) -> bytes:
+    return int(v).to_bytes(nbytes, "little")
+
+
+def ser_vec(vals, nbytes: int = 32) -> bytes:
+    """Vec<F>: u64 length, canonical little-endian elements."""
+    return struct.pack("<Q", len(vals)) + b"".join(ser_field(v, nbytes) for v in vals)
+
+
+def ser_g1(pt, p: int, nbytes: int) -> bytes:
+    """short-Weierstrass affine, Compress::No: x, then y with SWFlags in the top two bits of the last byte
+    (0x80: y > p - y, 0x40: infinity with zero coordinates)."""
+    if pt is None:
+        b = bytearray(2 * nbytes)
+        b[-1] |= 0x40
+        return bytes(b)
+    x, y = pt
+    b = bytearray(ser_field(x, nbytes) + ser_field(y, nbytes))
+    if y > (p - y) % p:
+        b[-1] |= 0x80
+    return bytes(b)
+
+
+def parse_g1(data: bytes, off: int, p: int, nbytes: int):
+    """-> (point or None, new offset); checks canonical coordinates and the y-sign flag."""
+    xb = data[off:off + nbytes]
+    yb = bytearray(data[off + nbytes:off + 2 * nbytes])
+    flags = yb[-1] >> 6
+    yb[-1] &= 0x3F
+    x, y = int.from_bytes(xb, "little"), int.from_bytes(bytes(yb), "little")
+    if flags & 1:
+        if x or y:
+            raise ValueError("infinity flag with non-zero coordinates")
+        return None, off + 2 * nbytes
+    if x >= p or y >= p:
+        raise ValueError("coordinate not canonical")
+    if bool(flags & 2) != (y > (p - y) % p):
+        raise ValueError("y-sign flag does not match y")
+    return (x, y), off + 2 * nbytes
+

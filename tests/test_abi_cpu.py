@@ -64,3 +64,29 @@ def test_product_does_not_import_the_oracle():
                         continue
                     bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_host_mirror_ark_wire_formats_match_the_oracle_serializer():
+    """arkwire.hpp (ark-serialize uncompressed Vec<F> and G1 points) against the oracle's restatement, byte
+    for byte; host-only code path (no device call)."""
+    import ctypes as C
+    import numpy as np
+    from cosnarks_amd import groth16 as g
+    from oracle import arkfmt, curves as cv
+    from tests import helpers as H
+    L = g.glib()
+    for curve, nb in (("bn254", 32), ("bls12_381", 48)):
+        F = H.FR[curve]
+        G = cv.CURVES[curve][0]
+        cid = H.CURVE_IDS[curve]
+        r = H.rng(17)
+        vals = [0, 1, F.p - 1] + H.rand_elems(F, 9, r)
+        out = (C.c_uint8 * 4096)()
+        n = L.cog16_ark_roundtrip(cid, 0, H.pack(F, vals).ctypes.data_as(C.c_void_p), C.c_size_t(len(vals)), out, C.c_size_t(4096))
+        assert n > 0, L.cog16_last_error()
+        assert bytes(out[:n]) == arkfmt.ser_vec(vals, 32)
+        pts = H.rand_points(G, 7, r, with_inf=True) + [G.neg(G.gen)]
+        n = L.cog16_ark_roundtrip(cid, 1, cv.pack_points(G, pts).ctypes.data_as(C.c_void_p), C.c_size_t(len(pts)), out, C.c_size_t(4096))
+        assert n > 0, L.cog16_last_error()
+        assert bytes(out[:n]) == b"".join(arkfmt.ser_g1(pt, G.F.p, nb) for pt in pts)
+

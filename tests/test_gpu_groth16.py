@@ -158,3 +158,31 @@ def test_libsnark_reduction_device_on_the_reference_penumbra_fixture(gpu):
     parts = [H.unpack(F, hs[p]) for p in range(3)]
     assert [(x + y + z) % F.p for x, y, z in zip(*parts)] == got
 
+
+@pytest.mark.gpu
+def test_libsnark_reduction_from_the_reference_file_formats(gpu):
+    """The host mirror reads the reference's ark-serialize Matrix blobs and wtns container itself (arkwire.hpp)
+    and runs LibSnarkReduction on the device: same h as expected.json."""
+    import ctypes as C
+    import gzip
+    import hashlib
+    import json
+    import os
+    import numpy as np
+    from cosnarks_amd import groth16 as dev
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "Groth16", "bls12_377", "penumbra_output")
+    rd = lambda n: gzip.open(os.path.join(d, n + ".gz"), "rb").read()
+    exp = json.load(open(os.path.join(d, "expected.json")))
+    a, b, c, w = rd("a.bin"), rd("b.bin"), rd("c.bin"), rd("witness.wtns")
+    out = np.zeros(exp["domain_size"] * 4, dtype=np.uint64)
+    L = dev.glib()
+    n = L.cog16_libsnark_from_files(3, a, C.c_size_t(len(a)), b, C.c_size_t(len(b)), c, C.c_size_t(len(c)), w, C.c_size_t(len(w)),
+                                    C.c_size_t(exp["num_instance_variables"]), out.ctypes.data_as(C.c_void_p), C.c_size_t(exp["domain_size"]))
+    assert n == exp["domain_size"], L.cog16_last_error()
+    F = H.FR["bls12_377"]
+    got = H.unpack(F, out)
+    assert hashlib.sha256(b"".join(x.to_bytes(32, "little") for x in got)).hexdigest() == exp["h_sha256"]
+    # a truncated blob is rejected, not mis-parsed
+    assert L.cog16_libsnark_from_files(3, a[:-5], C.c_size_t(len(a) - 5), b, C.c_size_t(len(b)), c, C.c_size_t(len(c)), w, C.c_size_t(len(w)),
+                                       C.c_size_t(3), out.ctypes.data_as(C.c_void_p), C.c_size_t(exp["domain_size"])) == -1
+

@@ -208,3 +208,28 @@ def test_libsnark_reduction_on_the_reference_penumbra_fixture():
     assert [str(x) for x in h[:4]] == exp["h_first"]
     assert g16.libsnark_identity_holds(F, exp["generator"], A, B, Cm, len(A), pub, wit, h, 0xDEADBEEF12345)
 
+
+def test_ark_point_wire_format_on_the_reference_vk_fixture():
+    """ark-serialize uncompressed G1 points (SWFlags in the top bits of y) as they appear in the reference's own
+    circuit.vk (BLS12-377, tests/golden copy): every G1 point parses with consistent flags and lies on y^2 = x^3 + 1."""
+    import gzip
+    import os
+    from oracle import arkfmt
+    q = 258664426012969094010652733694893533536393512754914660539884262666720468348340822774968888139573360124440321458177
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "Groth16", "bls12_377", "penumbra_output")
+    vk = gzip.open(os.path.join(d, "circuit.vk.gz"), "rb").read()
+    pts = []
+    pt, off = arkfmt.parse_g1(vk, 0, q, 48)            # alpha_g1
+    pts.append(pt)
+    off += 3 * 192                                     # beta_g2, gamma_g2, delta_g2
+    (k,) = __import__("struct").unpack_from("<Q", vk, off)
+    off += 8
+    for _ in range(k):                                 # gamma_abc_g1
+        pt, off = arkfmt.parse_g1(vk, off, q, 48)
+        pts.append(pt)
+    assert off == len(vk) and k == 3
+    for x, y in pts:
+        assert (y * y - x * x * x - 1) % q == 0
+    # the serializer is the exact inverse
+    assert b"".join(arkfmt.ser_g1(pt, q, 48) for pt in pts[1:]) == vk[-3 * 96:]
+
