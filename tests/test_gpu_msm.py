@@ -177,3 +177,48 @@ def test_msm_closed_form_full_size(gpu, curve, group, logn):
     gpu.bindings._check(gpu.lib().csh_msm(h, C.c_size_t(0), C.c_size_t(n), limbs.ctypes.data_as(C.c_void_p), 1, out.ctypes.data_as(C.c_void_p)))
     gpu.lib().csh_bases_free(h)
     assert G.eq(H.jac_to_affine(G, out), closed_form_point(curve, group, seed, n, limbs, True))
+
+
+def test_concurrent_callers_share_the_device(gpu):
+    """The reference calls the hot path from rayon workers and scoped threads at once (5 MSM closures, 3 NTT pipelines,
+    SURVEY 8b "Threading"): eight host threads issue MSMs of different sizes on two curves plus NTT round trips
+    concurrently, several rounds each (stream lanes and arenas are leased per thread); every result must be exact."""
+    import threading
+    from oracle import ntt as ontt
+    jobs = []
+    r = H.rng(99)
+    for i, (curve, group, n) in enumerate([("bn254", 0, 3000), ("bn254", 0, 41), ("bn254", 1, 500), ("bls12_381", 0, 900),
+                                           ("grumpkin", 0, 1200), ("bn254", 0, 7000)]):
+        G = cv.CURVES[curve][group]
+        F = H.FR[curve]
+        pts = H.rand_points(G, n, r, with_inf=True)
+        sc = H.rand_elems(F, n, r)
+        jobs.append(("msm", curve, group, pts, sc, G.msm(pts, sc)))
+    Fr = H.FR["bn254"]
+    for logn in (9, 12):
+        v = H.rand_elems(Fr, 1 << logn, r)
+        jobs.append(("ntt", logn, v))
+    errors = []
+
+    def run(job):
+        try:
+            for _ in range(4):
+                if job[0] == "msm":
+                    _, curve, group, pts, sc, want = job
+                    assert cv.CURVES[curve][group].eq(_run(gpu, curve, group, pts, sc), want)
+                else:
+                    _, logn, v = job
+                    dom = gpu.Domain(gpu.BN254, logn, H.pack(Fr, [ontt.Domain.snarkjs(Fr, 1 << logn).gen]))
+                    x = dom.ifft_in_to_out(H.pack(Fr, v))
+                    assert H.unpack(Fr, dom.fft_out_to_in(x)) == v
+                    dom.free()
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=run, args=(j,)) for j in jobs]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+
