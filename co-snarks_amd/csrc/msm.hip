@@ -1,18 +1,18 @@
-// Pippenger bucket MSM on gfx950 (BN254 / BLS12-381, G1 / G2).
+// Pippenger bucket MSM on gfx950 (BN254 / BLS12-381 G1 and G2, Grumpkin G1).
 //
 // Pipeline (all on one HIP stream, no host round-trip until the final W window sums):
 //   1. k_msm_digits   scalar -> canonical -> signed c-bit digit codes (u16 per point and window)
-//      k_msm_hist_lds per-(window, chunk) bucket histogram staged in LDS (<= 128 KiB), wave-aggregated
-//      k_msm_colscan  per-bucket prefix over chunks
-//   2. k_msm_scan     per-window exclusive scan of bucket counts; lanes per window = ceil(entries / L)
-//   3. k_msm_scatter_lds  counting-sort scatter of (point index | sign) into per-window bucket order; the
-//                     per-bucket cursors live in LDS, no global atomics
-//   4. k_msm_accum    one lane per run of L sorted entries (equal work per lane, whatever the bucket sizes):
-//                     gather affine bases, XYZZ mixed additions in registers, one partial per touched bucket
+//   2. sort stage (msm_sort.hip): LDS histogram per (window, chunk), prefix over chunks, per-window scan (lanes per
+//                     window = ceil(entries / L)), counting-sort scatter of (point index | sign) into bucket order --
+//                     single level with LDS cursors for small n, two-level LDS tile sort for n >= 2^20; no global atomics
+//   3. k_msm_accum    one lane per run of L sorted entries (equal work per lane, whatever the bucket sizes):
+//                     gather affine bases, XYZZ mixed additions in registers in the signed lazy field, one partial per
+//                     touched bucket, stored as the lazy value
 //      k_msm_merge    per-bucket fold of its partials -> dense bucket sums (block-wide tree for giant buckets)
-//   5. k_msm_reduce   segments of buckets: running-sum  sum_b b*B_b  per segment
-//   6. k_msm_fold     pairwise tree over the segment results -> one XYZZ sum per window
-//   host: Horner over the W window sums (W*c doublings), one inversion, Jacobian (x, y, 1) out.
+//   4. k_msm_reduce   segments of buckets: running-sum  sum_b b*B_b  per segment
+//      k_msm_fold     pairwise tree over the segment results -> one sum per window (all still lazy-field XYZZ),
+//      k_msm_gather_windows converts the W window sums back to the arkworks encoding
+//   host: Horner over the W window sums (W*c doublings) in 64-bit limbs, one inversion, Jacobian (x, y, 1) out.
 //
 // Replaces taceo_ark_algebra::msm::{msm_unchecked, msm_bigint} (see include/cosnarks_hip.h for the call
 // sites). The result is a group element; it is bit-identical to the reference after affine normalisation.
