@@ -23,7 +23,7 @@ ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 CFLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 
-HIP_SOURCES = ["capi.hip", "vec_ops.hip", "ntt.hip", "msm.hip", "msm_sort.hip", "groth16_h.hip", "microbench.hip", "selftest.hip", "util.hip", "sparse.hip"]
+HIP_SOURCES = ["capi.hip", "vec_ops.hip", "ntt.hip", "msm.hip", "msm_inst_bn254g1.hip", "msm_inst_bn254g2.hip", "msm_inst_bls381g1.hip", "msm_inst_bls381g2.hip", "msm_inst_grumpking1.hip", "msm_sort.hip", "groth16_h.hip", "microbench.hip", "selftest.hip", "util.hip", "sparse.hip"]
 COMPILE_TIMEOUT_S = 1500
 
 
@@ -63,7 +63,7 @@ def build_all(force: bool = False, verbose: bool = True):
     os.makedirs(OBJDIR, exist_ok=True)
     hdrs = _headers(CSRC, HOST)
     srcs = [s for s in HIP_SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(os.cpu_count() or 8, len(srcs))) as ex:
         objs = list(ex.map(lambda s: _compile(CSRC, s, force, hdrs), srcs))
     lib = os.path.join(LIBDIR, "libcosnarks_hip.so")
     if force or _newer(lib, objs):

@@ -16,532 +16,19 @@
 //
 // Replaces taceo_ark_algebra::msm::{msm_unchecked, msm_bigint} (see include/cosnarks_hip.h for the call
 // sites). The result is a group element; it is bit-identical to the reference after affine normalisation.
-#include <stdlib.h>
-#include <string.h>
-
-#include "common.hpp"
-#include "curve.hpp"
-#include "curve_lazy.hpp"
-#include "host_fp64.hpp"
-#include "msm_digits.hpp"
-#include "msm_sort.hpp"
+#include "msm_impl.hpp"
 
 namespace csh {
 
-// LAZY: bucket accumulation runs in the signed lazy field (field29.hpp); Bases then stores the coordinates
-// re-encoded as canonical x*R' (same 32 bytes per coordinate), converted once at upload.
-struct Bn254G1Cfg { using Fq = Bn254Fq;   using Fr = Bn254Fr; static constexpr bool LAZY = true;  using L = Fq29s; static constexpr bool INLINE_ADD = true; };
-struct Bn254G2Cfg { using Fq = Bn254Fq2;  using Fr = Bn254Fr; static constexpr bool LAZY = true;  using L = Fq29s2; static constexpr bool INLINE_ADD = true; };
-struct Bls381G1Cfg { using Fq = Bls381Fq;  using Fr = Bls381Fr; static constexpr bool LAZY = true;  using L = Fq28s; static constexpr bool INLINE_ADD = true; };
-// Grumpkin: base field = BN254 Fr, scalars = BN254 Fq (the 2-cycle partner of BN254)
-struct GrumpkinG1Cfg { using Fq = Bn254Fr;   using Fr = Bn254Fq; static constexpr bool LAZY = true;  using L = Fr29s; static constexpr bool INLINE_ADD = true; };
-struct Bls381G2Cfg { using Fq = Bls381Fq2; using Fr = Bls381Fr; static constexpr bool LAZY = true;  using L = Fq28s2; static constexpr bool INLINE_ADD = true; };
+thread_local float tl_msm_timing[6] = {0, 0, 0, 0, 0, 0};
+thread_local uint32_t tl_msm_params[4] = {0, 0, 0, 0};
 
-struct Bases {
-  csh_curve_t curve;
-  csh_group_t group;
-  int device;
-  size_t n;
-  size_t point_bytes;
-  void* points;  // packed Affine<Fq>[n] on the device
-};
+CSH_MSM_INSTANTIATE(extern, Bn254G1Cfg)
+CSH_MSM_INSTANTIATE(extern, Bn254G2Cfg)
+CSH_MSM_INSTANTIATE(extern, Bls381G1Cfg)
+CSH_MSM_INSTANTIATE(extern, Bls381G2Cfg)
+CSH_MSM_INSTANTIATE(extern, GrumpkinG1Cfg)
 
-// MsmParams, the digit-code constants and the sort stage live in msm_sort.hpp / msm_sort.hip
-
-constexpr int MSM_BLK = 256;
-constexpr int ACC_BLK = 128;
-
-// canonical little-endian limbs of scalar i
-template <class Fr>
-__device__ __forceinline__ void load_scalar(const Fr* __restrict__ scalars, size_t i, int mont, uint32_t* s) {
-  Fr v = scalars[i];
-  if (mont) v = v.from_mont();
-#pragma unroll
-  for (int k = 0; k < Fr::N; ++k) s[k] = v.l[k];
-}
-
-
-template <class Fr>
-__global__ __launch_bounds__(MSM_BLK) void k_msm_digits(const Fr* __restrict__ scalars, MsmParams p, uint16_t* __restrict__ dig) {
-  for (size_t i = blockIdx.x * (size_t)MSM_BLK + threadIdx.x; i < p.n; i += (size_t)gridDim.x * MSM_BLK) {
-    uint32_t s[Fr::N];
-    load_scalar<Fr>(scalars, i, p.mont, s);
-    int next = 0;
-    for_each_digit<Fr::N>(s, p.c, p.W, [&](int w, uint32_t b, uint32_t neg) {
-      for (; next < w; ++next) dig[(size_t)next * p.n + i] = (uint16_t)DIG_ZERO;
-      dig[(size_t)w * p.n + i] = (uint16_t)((b - 1) | (neg << 15));
-      next = w + 1;
-    });
-    for (; next < p.W; ++next) dig[(size_t)next * p.n + i] = (uint16_t)DIG_ZERO;
-  }
-}
-
-// first index in [lo, hi) with a[idx] > v
-__device__ __forceinline__ uint32_t upper_bound_u32(const uint32_t* __restrict__ a, uint32_t lo, uint32_t hi, uint32_t v) {
-  while (lo < hi) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (a[mid] > v) hi = mid; else lo = mid + 1;
-  }
-  return lo;
-}
-
-// Everything between the accumulate kernel and the final window sums stays in the lazy field: a stored partial /
-// bucket sum / segment sum is the XYZZLazy value as the arithmetic left it (no canonical form, no domain change).
-template <class Cfg>
-using LazyPt = XYZZLazy<typename Cfg::L>;
-
-// Bucket accumulation. Lane k of window w owns sorted entries [k*L, (k+1)*L): it walks them in bucket order and
-// emits one partial sum per bucket it touches into slot (bucket + k) -- unique and increasing in (bucket, lane), so
-// the partials of one bucket are consecutive slots. A bucket that spans several lanes (skewed scalars, or simply
-// > L entries) gets one partial per lane; k_msm_merge folds them into the dense per-bucket array.
-template <class Cfg>
-__global__ __launch_bounds__(ACC_BLK) void k_msm_accum(const Affine<typename Cfg::Fq>* __restrict__ bases, MsmParams p,
-                                                       const uint32_t* __restrict__ start, const uint32_t* __restrict__ nlanes,
-                                                       const uint32_t* __restrict__ sorted, LazyPt<Cfg>* partial) {
-  using Fq = typename Cfg::Fq;
-  static_assert(Cfg::LAZY, "the bucket pipeline runs in the signed lazy field");
-  const int w = blockIdx.y;
-  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= nlanes[w]) return;
-  const uint32_t* st = start + (size_t)w * (p.NB + 2);
-  const uint32_t total = st[p.NB + 1];
-  const uint32_t lo = k * p.L;
-  uint32_t hi = lo + p.L;
-  if (hi > total) hi = total;
-  uint32_t b = upper_bound_u32(st, 1, p.NB + 1, lo) - 1;  // bucket containing sorted position lo
-  uint32_t next = st[b + 1];
-  const uint32_t* so = sorted + (size_t)w * p.n;
-  LazyPt<Cfg>* pw = partial + (size_t)w * p.tmax;
-  {
-    using L = typename Cfg::L;
-    XYZZLazy<L> acc = XYZZLazy<L>::inf();
-    uint32_t e_next = so[lo];
-    Affine<Fq> pt_next = bases[e_next & 0x7fffffffu];
-    for (uint32_t pos = lo; pos < hi; ++pos) {
-      const uint32_t e = e_next;
-      const Affine<Fq> pt = pt_next;
-      if (pos + 1 < hi) {                           // software prefetch of the next gather
-        e_next = so[pos + 1];
-        pt_next = bases[e_next & 0x7fffffffu];
-      }
-      if (pos == next) {                            // crossed into the next non-empty bucket: flush
-        pw[b + k] = acc;
-        acc = XYZZLazy<L>::inf();
-        do { ++b; next = st[b + 1]; } while (next <= pos);
-      }
-      if (pt.is_inf()) continue;
-      const L x = L::unpack(pt.x);
-      L y = L::unpack(pt.y);
-      if (e >> 31) y = L::neg(y).normalized();  // keep |limb| <= 2^B + 1: lazy_madd subtracts acc.y limb-wise
-      lazy_madd(acc, x, y);
-    }
-    pw[b + k] = acc;
-  }
-}
-
-// Point addition used by the merge / reduction kernels: inlined for the 9-limb base field, out of line (operands
-// through memory) for the wide fields (code size, and see the note on lazy_mdbl).
-template <class Cfg>
-__device__ __forceinline__ void padd(LazyPt<Cfg>& a, const LazyPt<Cfg>& b) {
-  if constexpr (Cfg::INLINE_ADD) {
-    lazy_add_inl<typename Cfg::L>(a, b);
-  } else {
-    const LazyPt<Cfg> t = b;
-    lazy_add_p<typename Cfg::L>(&a, &t);
-  }
-}
-
-// Bucket merge: the partials of bucket b sit in consecutive slots b + k0 .. b + k1 (k0, k1 = first / last lane that
-// touched it). One lane per bucket folds them into the dense array dense[w][b]; buckets with more than MERGE_CAP
-// partials (heavily repeated scalars) are queued for the block-wide tree kernel below.
-constexpr uint32_t MERGE_CAP = 16;
-template <class Cfg>
-__global__ __launch_bounds__(64) void k_msm_merge(MsmParams p, const uint32_t* __restrict__ start,
-                                                  const LazyPt<Cfg>* __restrict__ partial, LazyPt<Cfg>* dense,
-                                                  uint32_t* giant_count, uint32_t* giant_list) {
-  const int w = blockIdx.y;
-  const uint32_t b = blockIdx.x * 64 + threadIdx.x + 1;
-  if (b > p.NB) return;
-  const uint32_t* st = start + (size_t)w * (p.NB + 2);
-  const uint32_t lo = st[b], hi = st[b + 1];
-  LazyPt<Cfg> acc = LazyPt<Cfg>::inf();
-  if (hi > lo) {
-    const uint32_t k0 = lo / p.L, k1 = (hi - 1) / p.L;
-    const LazyPt<Cfg>* pw = partial + (size_t)w * p.tmax + b;
-    if (k1 - k0 >= MERGE_CAP) {
-      const uint32_t g = atomicAdd(giant_count, 1u);
-      giant_list[2 * g] = (uint32_t)w;
-      giant_list[2 * g + 1] = b;
-    } else {
-      acc = pw[k0];
-      for (uint32_t k = k0 + 1; k <= k1; ++k) padd<Cfg>(acc, pw[k]);
-    }
-  }
-  dense[(size_t)w * (p.NB + 1) + b] = acc;
-}
-
-// One 256-thread block per queued bucket: strided private sums, then a tree over global scratch-free LDS-less
-// exchange through the dense array's own slot list (pairwise passes over `tmp`).
-template <class Cfg>
-__global__ __launch_bounds__(256) void k_msm_merge_giant(MsmParams p, const uint32_t* __restrict__ start,
-                                                         const LazyPt<Cfg>* __restrict__ partial, LazyPt<Cfg>* dense,
-                                                         const uint32_t* __restrict__ giant_count, const uint32_t* __restrict__ giant_list,
-                                                         LazyPt<Cfg>* tmp) {
-  const uint32_t count = *giant_count;
-  LazyPt<Cfg>* t = tmp + (size_t)blockIdx.x * 256;
-  for (uint32_t g = blockIdx.x; g < count; g += gridDim.x) {
-    const uint32_t w = giant_list[2 * g], b = giant_list[2 * g + 1];
-    const uint32_t* st = start + (size_t)w * (p.NB + 2);
-    const uint32_t k0 = st[b] / p.L, k1 = (st[b + 1] - 1) / p.L;
-    const LazyPt<Cfg>* pw = partial + (size_t)w * p.tmax + b;
-    LazyPt<Cfg> acc = LazyPt<Cfg>::inf();
-    for (uint32_t k = k0 + threadIdx.x; k <= k1; k += 256) padd<Cfg>(acc, pw[k]);
-    t[threadIdx.x] = acc;
-    __syncthreads();
-    for (uint32_t half = 128; half >= 1; half >>= 1) {
-      if (threadIdx.x < half) {
-        LazyPt<Cfg> x = t[threadIdx.x];
-        padd<Cfg>(x, t[threadIdx.x + half]);
-        t[threadIdx.x] = x;
-      }
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) dense[(size_t)w * (p.NB + 1) + b] = t[0];
-    __syncthreads();
-  }
-}
-
-// Segment k of window w folds slots [t0, t1) of the (bucket-sorted) partial array: returns sum_t bucket(t) * partial(t)
-// by the running-sum trick with explicit gaps; slots whose bucket id is 0 were never written and are skipped.
-template <class Cfg>
-__global__ __launch_bounds__(64) void k_msm_reduce(MsmParams p, const LazyPt<Cfg>* __restrict__ dense,
-                                                   LazyPt<Cfg>* segres) {
-  const int w = blockIdx.y;
-  const uint32_t k = blockIdx.x * 64 + threadIdx.x;
-  if (k >= p.S) return;
-  const uint32_t per = (p.NB + p.S - 1) / p.S;  // dense[w][b], b = 1..NB (index 0 unused)
-  const uint32_t t0 = 1 + k * per;
-  uint32_t t1 = t0 + per;
-  if (t1 > p.NB + 1) t1 = p.NB + 1;
-  LazyPt<Cfg> running = LazyPt<Cfg>::inf(), acc = LazyPt<Cfg>::inf();
-  uint32_t prev_b = 0;
-  if (t0 < t1) {
-    const LazyPt<Cfg>* dw = dense + (size_t)w * (p.NB + 1);
-    for (uint32_t t = t1; t-- > t0;) {
-      const LazyPt<Cfg> pt = dw[t];
-      if (pt.empty) continue;
-      uint32_t gap = prev_b ? prev_b - t : 0;
-      if (gap) {
-        if (gap <= 4) {
-          while (gap--) padd<Cfg>(acc, running);
-        } else {
-          LazyPt<Cfg> m = lazy_mul_small<typename Cfg::L, Cfg::INLINE_ADD>(running, gap);
-          padd<Cfg>(acc, m);
-        }
-      }
-      padd<Cfg>(running, pt);
-      prev_b = t;
-    }
-    if (prev_b) {  // acc = sum (b - bmin) B_b ; add bmin * R
-      LazyPt<Cfg> m = lazy_mul_small<typename Cfg::L, Cfg::INLINE_ADD>(running, prev_b);
-      padd<Cfg>(acc, m);
-    }
-  }
-  segres[(size_t)w * p.S + k] = acc;
-}
-
-// arr[w][i] += arr[w][i + half], i < half
-template <class Cfg>
-__global__ __launch_bounds__(64) void k_msm_fold(LazyPt<Cfg>* arr, uint32_t stride, uint32_t half) {
-  const int w = blockIdx.y;
-  const uint32_t i = blockIdx.x * 64 + threadIdx.x;
-  if (i >= half) return;
-  LazyPt<Cfg>* a = arr + (size_t)w * stride;
-  LazyPt<Cfg> x = a[i];
-  padd<Cfg>(x, a[i + half]);
-  a[i] = x;
-}
-
-// In-place re-encoding of uploaded bases for LAZY curves: x*2^(32N) -> canonical x*R' (infinity stays 0,0)
-template <class Cfg>
-__global__ __launch_bounds__(256) void k_bases_repack(Affine<typename Cfg::Fq>* pts, size_t n) {
-  if constexpr (Cfg::LAZY) {
-    using L = typename Cfg::L;
-    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-      Affine<typename Cfg::Fq> p = pts[i];
-      if (p.is_inf()) continue;
-      p.x = L::repack_for_storage(p.x);
-      p.y = L::repack_for_storage(p.y);
-      pts[i] = p;
-    }
-  }
-}
-
-template <class Cfg>
-__global__ void k_msm_gather_windows(const LazyPt<Cfg>* segres, uint32_t stride, int W, XYZZ<typename Cfg::Fq>* out) {
-  const int w = threadIdx.x;
-  if (w < W) out[w] = lazy_to_xyzz<typename Cfg::L, typename Cfg::Fq>(segres[(size_t)w * stride]);  // back to the arkworks encoding
-}
-
-// ---- host side -----------------------------------------------------------------------------------------
-static thread_local float tl_msm_timing[6] = {0, 0, 0, 0, 0, 0};
-static thread_local uint32_t tl_msm_params[4] = {0, 0, 0, 0};  // c, W, L, S of the last MSM
-
-
-static int choose_c(size_t n, int bits) {
-  const char* env = getenv("CSH_MSM_C");
-  if (env) {
-    int c = atoi(env);
-    if (c >= 2 && c <= 16) return c;
-  }
-  double best = 1e300;
-  int best_c = 4;
-  for (int c = 3; c <= 16; ++c) {  // digit codes are 15 bits + sign
-    const double nb = double(size_t(1) << (c - 1));
-    const double cost = windows_for(bits, c) * (double(n) + 5.0 * nb);
-    if (cost < best) {
-      best = cost;
-      best_c = c;
-    }
-  }
-  return best_c;
-}
-
-struct PartialHeader {
-  uint32_t magic, c, W, reserved;
-  uint32_t pad[4];
-};
-constexpr uint32_t PARTIAL_MAGIC = 0x4d534d50u;  // "PMSM"
-
-template <class Cfg>
-static int msm_windows_dev(const Bases* B, size_t offset, size_t n, const uint64_t* scalars_dev, int mont, hipStream_t st,
-                           XYZZ<typename Cfg::Fq>* win_out_dev /* W entries, device */, MsmParams* p_out) {
-  using Fq = typename Cfg::Fq;
-  using Fr = typename Cfg::Fr;
-  MsmParams p;
-  p.n = (uint32_t)n;
-  p.c = choose_c(n, Fr::Params::BITS);
-  p.W = windows_for(Fr::Params::BITS, p.c);
-  p.NB = 1u << (p.c - 1);
-  // L = sorted entries per lane (power of two in [8, 1024]): as long as possible (fewer partial sums to merge) while
-  // the W windows together still launch >= 2^19 lanes, ~8 waves per SIMD of the 256 CUs (measured optimum: 2^18 -> 16,
-  // 2^20 -> 32, 2^22 -> 128, 2^24 -> 256..512). Every lane of a wave performs the same number of mixed additions.
-  uint64_t L = 8;
-  while (L < 1024 && 2 * L * (uint64_t(1) << 19) <= (uint64_t)n * p.W) L <<= 1;
-  const char* envL = getenv("CSH_MSM_L");
-  if (envL && atoi(envL) > 0) L = (uint64_t)atoi(envL);
-  p.L = (uint32_t)L;
-  const uint32_t max_lanes = (uint32_t)((n + L - 1) / L);
-  p.tmax = p.NB + max_lanes + 2;  // partial slots per window: slot = bucket + lane
-  p.S = 64;
-  while (p.S < 8192 && (uint64_t)p.S * 8 < p.NB) p.S <<= 1;  // ~8 buckets per reduction segment
-  p.mont = mont;
-  {
-    uint64_t ch = 512 / (uint64_t)p.W;
-    const uint64_t by_size = n / (2ull * p.NB);
-    if (ch > by_size) ch = by_size;
-    if (ch < 1) ch = 1;
-    p.CH = (uint32_t)ch;
-    p.chunk_len = (uint32_t)((n + ch - 1) / ch);
-  }
-  *p_out = p;
-  tl_msm_params[0] = (uint32_t)p.c;
-  tl_msm_params[1] = (uint32_t)p.W;
-  tl_msm_params[2] = p.L;
-  tl_msm_params[3] = p.S;
-
-  const size_t len = (size_t)p.NB + 2;
-  Arena& ar = arena_for(st);
-  size_t need = 0;
-  need += 2 * Arena::padded(sizeof(uint32_t) * len * p.W);       // hist/cursor, start
-  need += Arena::padded(sizeof(uint32_t) * MAX_WINDOWS);          // lanes per window
-  need += Arena::padded(sizeof(uint32_t) * n * p.W);              // sorted
-  need += Arena::padded(sizeof(uint16_t) * n * p.W);              // digit codes
-  need += Arena::padded(sizeof(uint32_t) * (size_t)p.NB * p.CH * p.W);  // per-chunk bucket counts / prefixes
-  need += msm_sort_extra_bytes(p);  // level-1 records + partition offsets (two-level scatter, large n)
-  need += Arena::padded(sizeof(LazyPt<Cfg>) * (size_t)p.tmax * p.W); // partials
-  need += Arena::padded(sizeof(LazyPt<Cfg>) * (size_t)p.S * p.W);    // segment results
-  need += Arena::padded(sizeof(LazyPt<Cfg>) * (size_t)(p.NB + 1) * p.W);  // dense bucket sums
-  const uint32_t max_giant = (uint32_t)(((uint64_t)max_lanes * p.W) / MERGE_CAP + 1);
-  const uint32_t giant_blocks = max_giant < 1024 ? max_giant : 1024;
-  need += Arena::padded(sizeof(uint32_t) * (2 * (size_t)max_giant + 2));
-  need += Arena::padded(sizeof(LazyPt<Cfg>) * 256 * (size_t)giant_blocks);
-  CSH_TRY(ar.reserve(need));
-  uint32_t* hist = ar.take<uint32_t>(len * p.W);
-  uint32_t* start = ar.take<uint32_t>(len * p.W);
-  uint32_t* nlanes = ar.take<uint32_t>(MAX_WINDOWS);
-  uint32_t* sorted = ar.take<uint32_t>(n * p.W);
-  uint16_t* dig = ar.take<uint16_t>(n * p.W);
-  uint32_t* blkcnt = ar.take<uint32_t>((size_t)p.NB * p.CH * p.W);
-  const bool two_level = msm_sort_two_level(p);
-  uint64_t* inter = two_level ? ar.take<uint64_t>(n * p.W) : nullptr;
-  uint32_t* part_cnt = two_level ? ar.take<uint32_t>((size_t)(p.NB / 256) * p.CH * p.W) : nullptr;
-  LazyPt<Cfg>* partial = ar.take<LazyPt<Cfg>>((size_t)p.tmax * p.W);
-  LazyPt<Cfg>* segres = ar.take<LazyPt<Cfg>>((size_t)p.S * p.W);
-  LazyPt<Cfg>* dense = ar.take<LazyPt<Cfg>>((size_t)(p.NB + 1) * p.W);
-  uint32_t* giant = ar.take<uint32_t>(2 * (size_t)max_giant + 2);  // [0] = count, list from [2]
-  LazyPt<Cfg>* giant_tmp = ar.take<LazyPt<Cfg>>(256 * (size_t)giant_blocks);
-
-  const bool timing = getenv("CSH_MSM_TIMING") != nullptr;
-  hipEvent_t ev[7];
-  if (timing)
-    for (auto& e : ev) CSH_HIP(hipEventCreate(&e));
-  auto mark = [&](int i) -> int {
-    if (timing) CSH_HIP(hipEventRecord(ev[i], st));
-    return CSH_OK;
-  };
-
-  const Fr* sc = reinterpret_cast<const Fr*>(scalars_dev);
-  const Affine<Fq>* bases = reinterpret_cast<const Affine<Fq>*>(B->points) + offset;
-  CSH_TRY(mark(0));
-  CSH_HIP(hipMemsetAsync(hist, 0, sizeof(uint32_t) * len * p.W, st));
-  const int g1 = grid_for(n, MSM_BLK, 256 * 8);
-  hipLaunchKernelGGL(k_msm_digits<Fr>, dim3(g1), dim3(MSM_BLK), 0, st, sc, p, dig);
-  {
-    SortBuffers sb{hist, start, nlanes, sorted, dig, blkcnt, inter, part_cnt};
-    CSH_TRY(msm_sort_launch(p, sb, st, timing ? ev : nullptr));
-  }
-  {
-    static const int blk = [] {
-      const char* e = getenv("CSH_ACC_BLK");
-      const int b = e ? atoi(e) : ACC_BLK;
-      return (b == 64 || b == 128) ? b : ACC_BLK;
-    }();
-    const dim3 ag((max_lanes + blk - 1) / blk, p.W), ab(blk);
-    hipLaunchKernelGGL(k_msm_accum<Cfg>, ag, ab, 0, st, bases, p, start, nlanes, sorted, partial);
-  }
-  CSH_TRY(mark(4));
-  CSH_HIP(hipMemsetAsync(giant, 0, 8, st));
-  hipLaunchKernelGGL(k_msm_merge<Cfg>, dim3((p.NB + 63) / 64, p.W), dim3(64), 0, st, p, start, partial, dense, giant, giant + 2);
-  // buckets with > MERGE_CAP partials (heavily repeated scalars): block-wide tree, grid-stride over the queue
-  hipLaunchKernelGGL(k_msm_merge_giant<Cfg>, dim3(giant_blocks), dim3(256), 0, st, p, start, partial, dense, giant, giant + 2, giant_tmp);
-  hipLaunchKernelGGL(k_msm_reduce<Cfg>, dim3((p.S + 63) / 64, p.W), dim3(64), 0, st, p, dense, segres);
-  for (uint32_t half = p.S / 2; half >= 1; half >>= 1)
-    hipLaunchKernelGGL(k_msm_fold<Cfg>, dim3((half + 63) / 64, p.W), dim3(64), 0, st, segres, p.S, half);
-  hipLaunchKernelGGL(k_msm_gather_windows<Cfg>, dim3(1), dim3(MAX_WINDOWS), 0, st, segres, p.S, p.W, win_out_dev);
-  CSH_TRY(mark(5));
-  CSH_HIP(hipGetLastError());
-  if (timing) {
-    CSH_HIP(hipEventSynchronize(ev[5]));
-    for (int i = 0; i < 5; ++i) CSH_HIP(hipEventElapsedTime(&tl_msm_timing[i], ev[i], ev[i + 1]));
-    CSH_HIP(hipEventElapsedTime(&tl_msm_timing[5], ev[0], ev[5]));
-    for (auto& e : ev) (void)hipEventDestroy(e);
-  }
-  return CSH_OK;
-}
-
-// Horner over window sums + affine normalisation -> arkworks Projective (x, y, 1) / (1, 1, 0). Runs on the host in
-// 64-bit limbs (host_fp64.hpp): W*c sequential doublings are latency, not throughput, and a CPU core does them faster.
-template <class F>
-static XYZZ<F> horner_windows(const XYZZ<F>* wins, int W, int c);
-template <class Fq>
-static void fold_windows_host(const XYZZ<Fq>* wins32, int W, int c, void* out_jacobian) {
-  using F = typename Host64<Fq>::type;
-  static_assert(sizeof(XYZZ<F>) == sizeof(XYZZ<Fq>) && sizeof(Jac<F>) == sizeof(Jac<Fq>), "64-bit view must alias the device encoding");
-  std::vector<XYZZ<F>> wins(W);
-  memcpy((void*)wins.data(), wins32, sizeof(XYZZ<F>) * W);
-  Affine<F> a = xyzz_to_affine(horner_windows<F>(wins.data(), W, c));
-  Jac<F> j = a.is_inf() ? Jac<F>::inf() : Jac<F>{a.x, a.y, F::one()};
-  memcpy(out_jacobian, &j, sizeof(j));
-}
-
-template <class Cfg>
-static int msm_t(const Bases* B, size_t offset, size_t n, const uint64_t* scalars_dev, int mont, void* out_host, hipStream_t st) {
-  using Fq = typename Cfg::Fq;
-  if (n == 0) {
-    Jac<Fq> j = Jac<Fq>::inf();
-    memcpy(out_host, &j, sizeof(j));
-    return CSH_OK;
-  }
-  Arena& wa = arena_for((hipStream_t)((uintptr_t)st ^ 0x2));
-  CSH_TRY(wa.reserve(sizeof(XYZZ<Fq>) * MAX_WINDOWS));
-  XYZZ<Fq>* win_dev = wa.take<XYZZ<Fq>>(MAX_WINDOWS);
-  MsmParams p;
-  CSH_TRY((msm_windows_dev<Cfg>(B, offset, n, scalars_dev, mont, st, win_dev, &p)));
-  std::vector<XYZZ<Fq>> wins(p.W);
-  CSH_HIP(hipMemcpyAsync(wins.data(), win_dev, sizeof(XYZZ<Fq>) * p.W, hipMemcpyDeviceToHost, st));
-  CSH_HIP(hipStreamSynchronize(st));
-  fold_windows_host<Fq>(wins.data(), p.W, p.c, out_host);
-  return CSH_OK;
-}
-
-template <class Cfg>
-static int msm_partial_t(const Bases* B, size_t offset, size_t n, const uint64_t* scalars_dev, int mont, void* out_dev, hipStream_t st) {
-  using Fq = typename Cfg::Fq;
-  PartialHeader h;
-  memset(&h, 0, sizeof h);
-  h.magic = PARTIAL_MAGIC;
-  XYZZ<Fq>* wins = reinterpret_cast<XYZZ<Fq>*>(static_cast<char*>(out_dev) + sizeof(PartialHeader));
-  CSH_HIP(hipMemsetAsync(out_dev, 0, sizeof(PartialHeader) + sizeof(XYZZ<Fq>) * MAX_WINDOWS, st));
-  if (n > 0) {
-    MsmParams p;
-    CSH_TRY((msm_windows_dev<Cfg>(B, offset, n, scalars_dev, mont, st, wins, &p)));
-    h.c = p.c;
-    h.W = p.W;
-  }
-  CSH_HIP(hipMemcpyAsync(out_dev, &h, sizeof h, hipMemcpyHostToDevice, st));
-  CSH_HIP(hipStreamSynchronize(st));  // h is on the stack
-  return CSH_OK;
-}
-
-// Horner value (not yet normalised) of one set of window sums, 64-bit host limbs
-template <class F>
-static XYZZ<F> horner_windows(const XYZZ<F>* wins, int W, int c) {
-  XYZZ<F> acc = XYZZ<F>::inf();
-  for (int w = W - 1; w >= 0; --w) {
-    for (int k = 0; k < c; ++k) acc = xyzz_dbl_inl(acc);
-    acc = xyzz_add_inl(acc, wins[w]);
-  }
-  return acc;
-}
-
-template <class Cfg>
-static int fold_partials_t(const void* partials_host, size_t nparts, void* out_jacobian) {
-  using Fq = typename Cfg::Fq;
-  using F = typename Host64<Fq>::type;
-  const size_t stride = sizeof(PartialHeader) + sizeof(XYZZ<Fq>) * MAX_WINDOWS;
-  XYZZ<F> total = XYZZ<F>::inf();
-  // partials with the same window layout (the usual case: equal shares per rank) are summed window by window first,
-  // so the W*c doublings are paid once
-  std::vector<XYZZ<F>> sum;
-  uint32_t sum_c = 0, sum_W = 0;
-  for (size_t k = 0; k < nparts; ++k) {
-    const char* base = static_cast<const char*>(partials_host) + k * stride;
-    PartialHeader h;
-    memcpy(&h, base, sizeof h);
-    CSH_REQUIRE(h.magic == PARTIAL_MAGIC, "fold_partials: bad partial header");
-    if (h.W == 0) continue;
-    CSH_REQUIRE(h.W <= (uint32_t)MAX_WINDOWS && h.c >= 2 && h.c <= 22, "fold_partials: bad window parameters");
-    std::vector<XYZZ<F>> wins(h.W);
-    memcpy((void*)wins.data(), base + sizeof h, sizeof(XYZZ<F>) * h.W);
-    if (sum.empty()) {
-      sum.swap(wins);
-      sum_c = h.c;
-      sum_W = h.W;
-    } else if (h.c == sum_c && h.W == sum_W) {
-      for (uint32_t w = 0; w < h.W; ++w) sum[w] = xyzz_add_inl(sum[w], wins[w]);
-    } else {
-      total = xyzz_add_inl(total, horner_windows<F>(wins.data(), (int)h.W, (int)h.c));
-    }
-  }
-  if (!sum.empty()) total = xyzz_add_inl(total, horner_windows<F>(sum.data(), (int)sum_W, (int)sum_c));
-  Affine<F> a = xyzz_to_affine(total);
-  Jac<F> j = a.is_inf() ? Jac<F>::inf() : Jac<F>{a.x, a.y, F::one()};
-  memcpy(out_jacobian, &j, sizeof(j));
-  return CSH_OK;
-}
-
-template <class Cfg>
-static int repack_bases_t(Bases* B, hipStream_t st) {
-  if constexpr (Cfg::LAZY) {
-    if (B->n) {
-      hipLaunchKernelGGL(k_bases_repack<Cfg>, dim3(grid_for(B->n, 256)), dim3(256), 0, st, (Affine<typename Cfg::Fq>*)B->points, B->n);
-      CSH_HIP(hipGetLastError());
-      CSH_HIP(hipStreamSynchronize(st));
-    }
-  }
-  return CSH_OK;
-}
 static int repack_bases(Bases* B, hipStream_t st);
 
 static size_t point_bytes_of(csh_curve_t c, csh_group_t g) {

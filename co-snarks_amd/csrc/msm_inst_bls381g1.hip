@@ -1,0 +1,6 @@
+// Explicit instantiation of the MSM templates for one group configuration (see msm_impl.hpp).
+#include "msm_impl.hpp"
+
+namespace csh {
+CSH_MSM_INSTANTIATE(, Bls381G1Cfg)
+}  // namespace csh

@@ -1,0 +1,6 @@
+// Explicit instantiation of the MSM templates for one group configuration (see msm_impl.hpp).
+#include "msm_impl.hpp"
+
+namespace csh {
+CSH_MSM_INSTANTIATE(, Bn254G1Cfg)
+}  // namespace csh
