@@ -117,7 +117,7 @@ static void EC(msm)(EC(aff)* out, const EC(aff)* points, const uint64_t* scalars
   }
   int c = n < 32 ? 3 : (int)(log((double)n)) + 2;
   int W = (SF_BITS + c - 1) / c;
-  int chunks = (nthreads + W - 1) / W;
+  int chunks = nthreads / W; /* W * chunks tasks <= threads: one wave of tasks, no straggler round */
   if (chunks < 1) chunks = 1;
   if ((size_t)chunks > n) chunks = (int)n;
   size_t per = (n + chunks - 1) / chunks;
