@@ -108,6 +108,8 @@ static inline uint32_t EC(digit)(const uint64_t* s, int bit, int c) {
 static void EC(msm)(EC(aff)* out, const EC(aff)* points, const uint64_t* scalars, size_t n, int mont, int nthreads) {
   EC(jac) total; EC(jac_set_inf)(&total);
   if (n == 0) { EC(jac_to_aff)(out, &total); return; }
+  const int dbg = getenv("OC_DEBUG") != NULL;
+  double t_0 = omp_get_wtime();
   uint64_t* sc = (uint64_t*)malloc(n * SF_N * 8);
 #pragma omp parallel for schedule(static) num_threads(nthreads)
   for (size_t i = 0; i < n; i++) {
@@ -115,19 +117,39 @@ static void EC(msm)(EC(aff)* out, const EC(aff)* points, const uint64_t* scalars
     if (mont) SF(from_mont)(&v, &v);
     memcpy(sc + i * SF_N, &v, SF_N * 8);
   }
+  /* arkworks picks c = ln(n) + 2 and parallelises over the W windows only; with many more threads than windows the
+   * points are also cut into chunks, each (window, chunk) task owning a private bucket set. The window width is then
+   * the one minimising a task's cost  n/chunks mixed additions + 2 * 2^c full additions (~1.4x a mixed one)  subject
+   * to W * chunks <= threads -- for few threads this returns arkworks' own choice. */
   int c = n < 32 ? 3 : (int)(log((double)n)) + 2;
   int W = (SF_BITS + c - 1) / c;
-  int chunks = nthreads / W; /* W * chunks tasks <= threads: one wave of tasks, no straggler round */
+  int chunks = nthreads / W;
   if (chunks < 1) chunks = 1;
+  if (nthreads > W && n >= 1024) {
+    double best = 1e300;
+    for (int cc = 4; cc <= 20; cc++) {
+      int ww = (SF_BITS + cc - 1) / cc;
+      int ch = nthreads / ww;
+      if (ch < 1) ch = 1;
+      double rounds = ceil((double)ww * ch / nthreads);
+      double cost = rounds * ((double)n / ch + 2.8 * (double)((size_t)1 << cc));
+      if (cost < best) { best = cost; c = cc; W = ww; chunks = ch; }
+    }
+  }
   if ((size_t)chunks > n) chunks = (int)n;
+  if (getenv("OC_DEBUG")) fprintf(stderr, "[oc_msm] n=%zu threads=%d c=%d W=%d chunks=%d\n", n, nthreads, c, W, chunks);
   size_t per = (n + chunks - 1) / chunks;
   size_t nb = ((size_t)1 << c) - 1;
+  double t_1 = omp_get_wtime();
   EC(jac)* wsum = (EC(jac)*)malloc(sizeof(EC(jac)) * W * chunks);
+  /* one allocation for every task's bucket set: per-task malloc/free of MB-sized blocks serialises the threads on the
+   * process's mmap lock (measured: negative scaling beyond 32 threads) */
+  EC(jac)* all_buckets = (EC(jac)*)malloc(sizeof(EC(jac)) * nb * (size_t)W * chunks);
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
   for (int task = 0; task < W * chunks; task++) {
     int w = task / chunks, ch = task % chunks;
     size_t lo = (size_t)ch * per, hi = lo + per; if (hi > n) hi = n;
-    EC(jac)* buckets = (EC(jac)*)malloc(sizeof(EC(jac)) * nb);
+    EC(jac)* buckets = all_buckets + (size_t)task * nb;
     for (size_t b = 0; b < nb; b++) EC(jac_set_inf)(&buckets[b]);
     for (size_t i = lo; i < hi; i++) {
       uint32_t d = EC(digit)(sc + i * SF_N, w * c, c);
@@ -139,14 +161,15 @@ static void EC(msm)(EC(aff)* out, const EC(aff)* points, const uint64_t* scalars
       EC(jac_add)(&acc, &acc, &running);
     }
     wsum[task] = acc;
-    free(buckets);
   }
+  double t_2 = omp_get_wtime();
   for (int w = W - 1; w >= 0; w--) {
     for (int k = 0; k < c; k++) EC(jac_dbl)(&total, &total);
     for (int ch = 0; ch < chunks; ch++) EC(jac_add)(&total, &total, &wsum[w * chunks + ch]);
   }
   EC(jac_to_aff)(out, &total);
-  free(wsum); free(sc);
+  if (dbg) fprintf(stderr, "[oc_msm] convert %.1f ms, bucket tasks %.1f ms, fold %.1f ms\n", (t_1 - t_0) * 1e3, (t_2 - t_1) * 1e3, (omp_get_wtime() - t_2) * 1e3);
+  free(all_buckets); free(wsum); free(sc);
 }
 
 /* bases[i] = (splitmix64(seed+i)|1) * G (the product's csh_util_generate_bases_dev family) */
