@@ -99,6 +99,30 @@ def secondary_metrics(hip, B, L, C, np, torch, dev, stream):
     # Groth16 plain prove, synthetic 2^20-constraint circuit with a known-dlog key (closed-form checked), key resident
     from cosnarks_amd import groth16 as g16
     out["groth16_prove_synthetic_2p20"] = g16.bench_synthetic(hip.BN254, 20, 3)
+    # BASELINE configs 1 and 4 on the reference's own circuits (tests/golden copies of test_vectors/Groth16/bn254): plain
+    # prove of multiplier2 (domain 4) and poseidon (domain 256), and a three-party Rep3 prove of poseidon (in-process
+    # parties sharing this GPU). Wall ms per proof incl. zkey parse + key upload; these sizes are launch-latency bound.
+    gold = os.path.join(ROOT, "tests", "golden", "Groth16", "bn254")
+    small = {}
+    for circ in ("multiplier2", "poseidon"):
+        zk = open(os.path.join(gold, circ, "circuit.zkey"), "rb").read()
+        wt = open(os.path.join(gold, circ, "witness.wtns"), "rb").read()
+        g16.prove_plain(hip.BN254, zk, wt, 123456789, 987654321)
+        ts = []
+        for _ in range(10):
+            t0 = time.perf_counter()
+            g16.prove_plain(hip.BN254, zk, wt, 123456789, 987654321)
+            ts.append((time.perf_counter() - t0) * 1e3)
+        small[f"plain_{circ}_ms"] = sorted(ts)[len(ts) // 2]
+        if circ == "poseidon":
+            g16.prove_rep3(hip.BN254, zk, wt, 7, 123456789, 987654321)
+            ts = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                g16.prove_rep3(hip.BN254, zk, wt, 7, 123456789, 987654321)
+                ts.append((time.perf_counter() - t0) * 1e3)
+            small["rep3_poseidon_3_parties_ms"] = sorted(ts)[len(ts) // 2]
+    out["groth16_prove_reference_circuits"] = small
     return out
 
 
