@@ -16,6 +16,9 @@
 //
 // Replaces taceo_ark_algebra::msm::{msm_unchecked, msm_bigint} (see include/cosnarks_hip.h for the call
 // sites). The result is a group element; it is bit-identical to the reference after affine normalisation.
+#include <algorithm>
+#include <vector>
+
 #include "msm_impl.hpp"
 
 namespace csh {
@@ -171,6 +174,78 @@ int csh_msm_partial_dev(csh_bases_t bases, size_t offset, size_t n, const uint64
 int csh_msm_fold_partials(csh_curve_t curve, csh_group_t group, const void* partials_host, size_t nparts, void* out_jacobian) {
   CSH_REQUIRE(partials_host && out_jacobian, "NULL argument");
   CURVE_DISPATCH(curve, group, (fold_partials_t<Cfg>(partials_host, nparts, out_jacobian)));
+}
+
+// k MSMs over ONE scalar vector (the four aux-assignment MSMs of a Groth16 proof: A, B in G1, B in G2, L; groth16.rs:237-284):
+// the digit decomposition and the bucket sort depend on the scalars only and are done once; the bucket stage runs per set
+// of bases. All handles must belong to the same curve (same scalar field); every MSM uses n points from its offset.
+int csh_msm_multi_dev(const csh_bases_t* bases, const size_t* offsets, size_t k, size_t n, const uint64_t* scalars_dev, int mont,
+                      void* const* outs_host, void* stream) {
+  CSH_REQUIRE(bases && offsets && outs_host && k >= 1 && k <= 16, "msm_multi: bad arguments");
+  CSH_REQUIRE(scalars_dev || n == 0, "scalars is NULL");
+  CSH_REQUIRE(n < (size_t(1) << 31), "n too large");
+  CSH_TRY(ensure_device());
+  const Bases* B0 = reinterpret_cast<const Bases*>(bases[0]);
+  CSH_REQUIRE(B0, "bases[0] is NULL");
+  for (size_t i = 0; i < k; ++i) {
+    const Bases* B = reinterpret_cast<const Bases*>(bases[i]);
+    CSH_REQUIRE(B && outs_host[i], "msm_multi: NULL handle or output");
+    CSH_REQUIRE(B->curve == B0->curve, "msm_multi: all bases must belong to one curve");
+    CSH_REQUIRE(offsets[i] <= B->n && n <= B->n - offsets[i], "msm_multi: offset + n exceeds the number of bases");
+  }
+  hipStream_t st = resolve_stream(stream);
+  struct Ops {
+    size_t (*bytes)(const MsmParams*);
+    int (*bucket)(const Bases*, size_t, const MsmParams*, const SortOut*, hipStream_t, Arena*, void*, hipEvent_t*);
+    void (*fold)(const void*, int, int, void*);
+    size_t xyzz_bytes;
+  };
+  auto ops_of = [](const Bases* B, Ops* o) -> bool {
+#define CSH_OPS(CFG) *o = Ops{msm_bucket_bytes<CFG>, msm_bucket_stage<CFG>, fold_windows_erased<CFG>, sizeof(XYZZ<CFG::Fq>)}; return true
+    if (B->curve == CSH_BN254 && B->group == CSH_G1) { CSH_OPS(Bn254G1Cfg); }
+    if (B->curve == CSH_BN254 && B->group == CSH_G2) { CSH_OPS(Bn254G2Cfg); }
+    if (B->curve == CSH_BLS12_381 && B->group == CSH_G1) { CSH_OPS(Bls381G1Cfg); }
+    if (B->curve == CSH_BLS12_381 && B->group == CSH_G2) { CSH_OPS(Bls381G2Cfg); }
+    if (B->curve == CSH_GRUMPKIN && B->group == CSH_G1) { CSH_OPS(GrumpkinG1Cfg); }
+#undef CSH_OPS
+    return false;
+  };
+  std::vector<Ops> ops(k);
+  for (size_t i = 0; i < k; ++i) CSH_REQUIRE(ops_of(reinterpret_cast<const Bases*>(bases[i]), &ops[i]), "msm_multi: unknown curve/group");
+  if (n == 0) {
+    for (size_t i = 0; i < k; ++i) ops[i].fold(nullptr, 0, 2, outs_host[i]);
+    return CSH_OK;
+  }
+  const int bits = B0->curve == CSH_BLS12_381 ? Bls381FrParams::BITS : (B0->curve == CSH_GRUMPKIN ? Bn254FqParams::BITS : Bn254FrParams::BITS);
+  const MsmParams p = msm_plan(n, bits, mont);
+  size_t bucket_max = 0, win_bytes = 0;
+  for (auto& o : ops) {
+    bucket_max = std::max(bucket_max, o.bytes(&p));
+    win_bytes += Arena::padded(o.xyzz_bytes * MAX_WINDOWS);
+  }
+  Arena& ar = arena_for(st);
+  CSH_TRY(ar.reserve(msm_sort_bytes(p) + bucket_max));
+  Arena& wa = arena_for((hipStream_t)((uintptr_t)st ^ 0x2));
+  CSH_TRY(wa.reserve(win_bytes));
+  SortOut so;
+  if (B0->curve == CSH_BLS12_381) CSH_TRY(msm_sort_stage<Bls381Fr>(p, scalars_dev, st, ar, &so, nullptr));
+  else if (B0->curve == CSH_GRUMPKIN) CSH_TRY(msm_sort_stage<Bn254Fq>(p, scalars_dev, st, ar, &so, nullptr));
+  else CSH_TRY(msm_sort_stage<Bn254Fr>(p, scalars_dev, st, ar, &so, nullptr));
+  const size_t mark = ar.off;
+  std::vector<char*> win_dev(k);
+  for (size_t i = 0; i < k; ++i) {
+    ar.off = mark;  // the bucket-stage scratch is reused: the stages are stream-ordered
+    win_dev[i] = wa.take<char>(ops[i].xyzz_bytes * MAX_WINDOWS);
+    CSH_TRY(ops[i].bucket(reinterpret_cast<const Bases*>(bases[i]), offsets[i], &p, &so, st, &ar, win_dev[i], nullptr));
+  }
+  std::vector<std::vector<char>> wins(k);
+  for (size_t i = 0; i < k; ++i) {
+    wins[i].resize(ops[i].xyzz_bytes * p.W);
+    CSH_HIP(hipMemcpyAsync(wins[i].data(), win_dev[i], wins[i].size(), hipMemcpyDeviceToHost, st));
+  }
+  CSH_HIP(hipStreamSynchronize(st));
+  for (size_t i = 0; i < k; ++i) ops[i].fold(wins[i].data(), p.W, p.c, outs_host[i]);
+  return CSH_OK;
 }
 
 int csh_msm_last_params(uint32_t out[4]) {

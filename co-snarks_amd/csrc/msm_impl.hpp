@@ -299,15 +299,12 @@ struct PartialHeader {
 };
 constexpr uint32_t PARTIAL_MAGIC = 0x4d534d50u;  // "PMSM"
 
-template <class Cfg>
-int msm_windows_dev(const Bases* B, size_t offset, size_t n, const uint64_t* scalars_dev, int mont, hipStream_t st,
-                           XYZZ<typename Cfg::Fq>* win_out_dev /* W entries, device */, MsmParams* p_out) {
-  using Fq = typename Cfg::Fq;
-  using Fr = typename Cfg::Fr;
+// ---- the pipeline in three pieces: plan, sort stage (depends on the scalars only), bucket stage (per set of bases) ----
+inline MsmParams msm_plan(size_t n, int scalar_bits, int mont) {
   MsmParams p;
   p.n = (uint32_t)n;
-  p.c = choose_c(n, Fr::Params::BITS);
-  p.W = windows_for(Fr::Params::BITS, p.c);
+  p.c = choose_c(n, scalar_bits);
+  p.W = windows_for(scalar_bits, p.c);
   p.NB = 1u << (p.c - 1);
   // L = sorted entries per lane (power of two in [8, 1024]): as long as possible (fewer partial sums to merge) while
   // the W windows together still launch >= 2^19 lanes, ~8 waves per SIMD of the 256 CUs (measured optimum: 2^18 -> 16,
@@ -322,22 +319,25 @@ int msm_windows_dev(const Bases* B, size_t offset, size_t n, const uint64_t* sca
   p.S = 64;
   while (p.S < 8192 && (uint64_t)p.S * 8 < p.NB) p.S <<= 1;  // ~8 buckets per reduction segment
   p.mont = mont;
-  {
-    uint64_t ch = 512 / (uint64_t)p.W;
-    const uint64_t by_size = n / (2ull * p.NB);
-    if (ch > by_size) ch = by_size;
-    if (ch < 1) ch = 1;
-    p.CH = (uint32_t)ch;
-    p.chunk_len = (uint32_t)((n + ch - 1) / ch);
-  }
-  *p_out = p;
+  uint64_t ch = 512 / (uint64_t)p.W;
+  const uint64_t by_size = n / (2ull * p.NB);
+  if (ch > by_size) ch = by_size;
+  if (ch < 1) ch = 1;
+  p.CH = (uint32_t)ch;
+  p.chunk_len = (uint32_t)((n + ch - 1) / ch);
   tl_msm_params[0] = (uint32_t)p.c;
   tl_msm_params[1] = (uint32_t)p.W;
   tl_msm_params[2] = p.L;
   tl_msm_params[3] = p.S;
+  return p;
+}
 
-  const size_t len = (size_t)p.NB + 2;
-  Arena& ar = arena_for(st);
+struct SortOut {  // what the bucket stage consumes
+  uint32_t *start, *nlanes, *sorted;
+};
+
+inline size_t msm_sort_bytes(const MsmParams& p) {
+  const size_t len = (size_t)p.NB + 2, n = p.n;
   size_t need = 0;
   need += 2 * Arena::padded(sizeof(uint32_t) * len * p.W);       // hist/cursor, start
   need += Arena::padded(sizeof(uint32_t) * MAX_WINDOWS);          // lanes per window
@@ -345,14 +345,13 @@ int msm_windows_dev(const Bases* B, size_t offset, size_t n, const uint64_t* sca
   need += Arena::padded(sizeof(uint16_t) * n * p.W);              // digit codes
   need += Arena::padded(sizeof(uint32_t) * (size_t)p.NB * p.CH * p.W);  // per-chunk bucket counts / prefixes
   need += msm_sort_extra_bytes(p);  // level-1 records + partition offsets (two-level scatter, large n)
-  need += Arena::padded(sizeof(LazyPt<Cfg>) * (size_t)p.tmax * p.W); // partials
-  need += Arena::padded(sizeof(LazyPt<Cfg>) * (size_t)p.S * p.W);    // segment results
-  need += Arena::padded(sizeof(LazyPt<Cfg>) * (size_t)(p.NB + 1) * p.W);  // dense bucket sums
-  const uint32_t max_giant = (uint32_t)(((uint64_t)max_lanes * p.W) / MERGE_CAP + 1);
-  const uint32_t giant_blocks = max_giant < 1024 ? max_giant : 1024;
-  need += Arena::padded(sizeof(uint32_t) * (2 * (size_t)max_giant + 2));
-  need += Arena::padded(sizeof(LazyPt<Cfg>) * 256 * (size_t)giant_blocks);
-  CSH_TRY(ar.reserve(need));
+  return need;
+}
+
+// digits + counting sort; takes its buffers from `ar` (already reserved). ev (nullable): records ev[1..3].
+template <class Fr>
+int msm_sort_stage(const MsmParams& p, const uint64_t* scalars_dev, hipStream_t st, Arena& ar, SortOut* out, hipEvent_t* ev) {
+  const size_t len = (size_t)p.NB + 2, n = p.n;
   uint32_t* hist = ar.take<uint32_t>(len * p.W);
   uint32_t* start = ar.take<uint32_t>(len * p.W);
   uint32_t* nlanes = ar.take<uint32_t>(MAX_WINDOWS);
@@ -362,31 +361,47 @@ int msm_windows_dev(const Bases* B, size_t offset, size_t n, const uint64_t* sca
   const bool two_level = msm_sort_two_level(p);
   uint64_t* inter = two_level ? ar.take<uint64_t>(n * p.W) : nullptr;
   uint32_t* part_cnt = two_level ? ar.take<uint32_t>((size_t)(p.NB / 256) * p.CH * p.W) : nullptr;
+  CSH_HIP(hipMemsetAsync(hist, 0, sizeof(uint32_t) * len * p.W, st));
+  const int g1 = grid_for(n, MSM_BLK, 256 * 8);
+  hipLaunchKernelGGL(k_msm_digits<Fr>, dim3(g1), dim3(MSM_BLK), 0, st, reinterpret_cast<const Fr*>(scalars_dev), p, dig);
+  SortBuffers sb{hist, start, nlanes, sorted, dig, blkcnt, inter, part_cnt};
+  CSH_TRY(msm_sort_launch(p, sb, st, ev));
+  *out = SortOut{start, nlanes, sorted};
+  return CSH_OK;
+}
+
+template <class Cfg>
+size_t msm_bucket_bytes(const MsmParams* pp) {
+  const MsmParams& p = *pp;
+  const uint32_t max_lanes = (uint32_t)(((size_t)p.n + p.L - 1) / p.L);
+  const uint32_t max_giant = (uint32_t)(((uint64_t)max_lanes * p.W) / MERGE_CAP + 1);
+  const uint32_t giant_blocks = max_giant < 1024 ? max_giant : 1024;
+  size_t need = 0;
+  need += Arena::padded(sizeof(LazyPt<Cfg>) * (size_t)p.tmax * p.W);       // partials
+  need += Arena::padded(sizeof(LazyPt<Cfg>) * (size_t)p.S * p.W);          // segment results
+  need += Arena::padded(sizeof(LazyPt<Cfg>) * (size_t)(p.NB + 1) * p.W);   // dense bucket sums
+  need += Arena::padded(sizeof(uint32_t) * (2 * (size_t)max_giant + 2));
+  need += Arena::padded(sizeof(LazyPt<Cfg>) * 256 * (size_t)giant_blocks);
+  return need;
+}
+
+// accumulate -> merge -> reduce -> fold for one set of bases; win_out_dev: W x XYZZ<Fq> on the device. ev (nullable):
+// records ev[4] after the accumulation and ev[5] at the end.
+template <class Cfg>
+int msm_bucket_stage(const Bases* B, size_t offset, const MsmParams* pp, const SortOut* so, hipStream_t st, Arena* arp, void* win_out_dev,
+                     hipEvent_t* ev) {
+  using Fq = typename Cfg::Fq;
+  const MsmParams& p = *pp;
+  Arena& ar = *arp;
+  const uint32_t max_lanes = (uint32_t)(((size_t)p.n + p.L - 1) / p.L);
+  const uint32_t max_giant = (uint32_t)(((uint64_t)max_lanes * p.W) / MERGE_CAP + 1);
+  const uint32_t giant_blocks = max_giant < 1024 ? max_giant : 1024;
   LazyPt<Cfg>* partial = ar.take<LazyPt<Cfg>>((size_t)p.tmax * p.W);
   LazyPt<Cfg>* segres = ar.take<LazyPt<Cfg>>((size_t)p.S * p.W);
   LazyPt<Cfg>* dense = ar.take<LazyPt<Cfg>>((size_t)(p.NB + 1) * p.W);
   uint32_t* giant = ar.take<uint32_t>(2 * (size_t)max_giant + 2);  // [0] = count, list from [2]
   LazyPt<Cfg>* giant_tmp = ar.take<LazyPt<Cfg>>(256 * (size_t)giant_blocks);
-
-  const bool timing = getenv("CSH_MSM_TIMING") != nullptr;
-  hipEvent_t ev[7];
-  if (timing)
-    for (auto& e : ev) CSH_HIP(hipEventCreate(&e));
-  auto mark = [&](int i) -> int {
-    if (timing) CSH_HIP(hipEventRecord(ev[i], st));
-    return CSH_OK;
-  };
-
-  const Fr* sc = reinterpret_cast<const Fr*>(scalars_dev);
   const Affine<Fq>* bases = reinterpret_cast<const Affine<Fq>*>(B->points) + offset;
-  CSH_TRY(mark(0));
-  CSH_HIP(hipMemsetAsync(hist, 0, sizeof(uint32_t) * len * p.W, st));
-  const int g1 = grid_for(n, MSM_BLK, 256 * 8);
-  hipLaunchKernelGGL(k_msm_digits<Fr>, dim3(g1), dim3(MSM_BLK), 0, st, sc, p, dig);
-  {
-    SortBuffers sb{hist, start, nlanes, sorted, dig, blkcnt, inter, part_cnt};
-    CSH_TRY(msm_sort_launch(p, sb, st, timing ? ev : nullptr));
-  }
   {
     static const int blk = [] {
       const char* e = getenv("CSH_ACC_BLK");
@@ -394,19 +409,39 @@ int msm_windows_dev(const Bases* B, size_t offset, size_t n, const uint64_t* sca
       return (b == 64 || b == 128) ? b : ACC_BLK;
     }();
     const dim3 ag((max_lanes + blk - 1) / blk, p.W), ab(blk);
-    hipLaunchKernelGGL(k_msm_accum<Cfg>, ag, ab, 0, st, bases, p, start, nlanes, sorted, partial);
+    hipLaunchKernelGGL(k_msm_accum<Cfg>, ag, ab, 0, st, bases, p, so->start, so->nlanes, so->sorted, partial);
   }
-  CSH_TRY(mark(4));
+  if (ev) CSH_HIP(hipEventRecord(ev[4], st));
   CSH_HIP(hipMemsetAsync(giant, 0, 8, st));
-  hipLaunchKernelGGL(k_msm_merge<Cfg>, dim3((p.NB + 63) / 64, p.W), dim3(64), 0, st, p, start, partial, dense, giant, giant + 2);
+  hipLaunchKernelGGL(k_msm_merge<Cfg>, dim3((p.NB + 63) / 64, p.W), dim3(64), 0, st, p, so->start, partial, dense, giant, giant + 2);
   // buckets with > MERGE_CAP partials (heavily repeated scalars): block-wide tree, grid-stride over the queue
-  hipLaunchKernelGGL(k_msm_merge_giant<Cfg>, dim3(giant_blocks), dim3(256), 0, st, p, start, partial, dense, giant, giant + 2, giant_tmp);
+  hipLaunchKernelGGL(k_msm_merge_giant<Cfg>, dim3(giant_blocks), dim3(256), 0, st, p, so->start, partial, dense, giant, giant + 2, giant_tmp);
   hipLaunchKernelGGL(k_msm_reduce<Cfg>, dim3((p.S + 63) / 64, p.W), dim3(64), 0, st, p, dense, segres);
   for (uint32_t half = p.S / 2; half >= 1; half >>= 1)
     hipLaunchKernelGGL(k_msm_fold<Cfg>, dim3((half + 63) / 64, p.W), dim3(64), 0, st, segres, p.S, half);
-  hipLaunchKernelGGL(k_msm_gather_windows<Cfg>, dim3(1), dim3(MAX_WINDOWS), 0, st, segres, p.S, p.W, win_out_dev);
-  CSH_TRY(mark(5));
+  hipLaunchKernelGGL(k_msm_gather_windows<Cfg>, dim3(1), dim3(MAX_WINDOWS), 0, st, segres, p.S, p.W, reinterpret_cast<XYZZ<Fq>*>(win_out_dev));
+  if (ev) CSH_HIP(hipEventRecord(ev[5], st));
   CSH_HIP(hipGetLastError());
+  return CSH_OK;
+}
+
+template <class Cfg>
+int msm_windows_dev(const Bases* B, size_t offset, size_t n, const uint64_t* scalars_dev, int mont, hipStream_t st,
+                    XYZZ<typename Cfg::Fq>* win_out_dev /* W entries, device */, MsmParams* p_out) {
+  using Fr = typename Cfg::Fr;
+  const MsmParams p = msm_plan(n, Fr::Params::BITS, mont);
+  *p_out = p;
+  Arena& ar = arena_for(st);
+  CSH_TRY(ar.reserve(msm_sort_bytes(p) + msm_bucket_bytes<Cfg>(&p)));
+  const bool timing = getenv("CSH_MSM_TIMING") != nullptr;
+  hipEvent_t ev[7];
+  if (timing) {
+    for (auto& e : ev) CSH_HIP(hipEventCreate(&e));
+    CSH_HIP(hipEventRecord(ev[0], st));
+  }
+  SortOut so;
+  CSH_TRY(msm_sort_stage<Fr>(p, scalars_dev, st, ar, &so, timing ? ev : nullptr));
+  CSH_TRY(msm_bucket_stage<Cfg>(B, offset, &p, &so, st, &ar, win_out_dev, timing ? ev : nullptr));
   if (timing) {
     CSH_HIP(hipEventSynchronize(ev[5]));
     for (int i = 0; i < 5; ++i) CSH_HIP(hipEventElapsedTime(&tl_msm_timing[i], ev[i], ev[i + 1]));
@@ -415,6 +450,10 @@ int msm_windows_dev(const Bases* B, size_t offset, size_t n, const uint64_t* sca
   }
   return CSH_OK;
 }
+
+// type-erased host fold (the multi-MSM entry dispatches per set of bases at run time)
+template <class Cfg>
+void fold_windows_erased(const void* wins_host, int W, int c, void* out_jacobian);
 
 // Horner over window sums + affine normalisation -> arkworks Projective (x, y, 1) / (1, 1, 0). Runs on the host in
 // 64-bit limbs (host_fp64.hpp): W*c sequential doublings are latency, not throughput, and a CPU core does them faster.
@@ -429,6 +468,11 @@ void fold_windows_host(const XYZZ<Fq>* wins32, int W, int c, void* out_jacobian)
   Affine<F> a = xyzz_to_affine(horner_windows<F>(wins.data(), W, c));
   Jac<F> j = a.is_inf() ? Jac<F>::inf() : Jac<F>{a.x, a.y, F::one()};
   memcpy(out_jacobian, &j, sizeof(j));
+}
+
+template <class Cfg>
+void fold_windows_erased(const void* wins_host, int W, int c, void* out_jacobian) {
+  fold_windows_host<typename Cfg::Fq>(reinterpret_cast<const XYZZ<typename Cfg::Fq>*>(wins_host), W, c, out_jacobian);
 }
 
 template <class Cfg>
@@ -534,6 +578,9 @@ int repack_bases_t(Bases* B, hipStream_t st) {
   KW template int msm_t<CFG>(const Bases*, size_t, size_t, const uint64_t*, int, void*, hipStream_t);                           \
   KW template int msm_partial_t<CFG>(const Bases*, size_t, size_t, const uint64_t*, int, void*, hipStream_t);                   \
   KW template int fold_partials_t<CFG>(const void*, size_t, void*);                                                             \
-  KW template int repack_bases_t<CFG>(Bases*, hipStream_t);
+  KW template int repack_bases_t<CFG>(Bases*, hipStream_t);                                                                     \
+  KW template size_t msm_bucket_bytes<CFG>(const MsmParams*);                                                                   \
+  KW template int msm_bucket_stage<CFG>(const Bases*, size_t, const MsmParams*, const SortOut*, hipStream_t, Arena*, void*, hipEvent_t*); \
+  KW template void fold_windows_erased<CFG>(const void*, int, int, void*);
 
 }  // namespace csh

@@ -255,6 +255,20 @@ struct CoGroth16 {
     }
   }
 
+  // the part of calculate_coeff (groth16.rs:179-203) around the private-input MSM, given that MSM's result
+  template <class F>
+  static Proj<F> finish_coeff(int id, Proj<F> initial, const Query<F>& query, const AffineT<F>& vk_param, const std::vector<Fr>& input_assignment,
+                              const Proj<F>& priv_acc) {
+    const size_t pub_len = input_assignment.size();
+    Proj<F> pub_acc = Proj<F>::inf();  // msm_unchecked(&query[1..=pub_len], input_assignment): tiny, on the host (:194)
+    for (size_t i = 0; i < pub_len; ++i) pub_acc = point_add(pub_acc, point_mul(into_group(query.host[1 + i]), input_assignment[i]));
+    Proj<F> res = initial;
+    T::template add_assign_points_public_hs<F>(id, res, into_group(query.host[0]));
+    T::template add_assign_points_public_hs<F>(id, res, into_group(vk_param));
+    T::template add_assign_points_public_hs<F>(id, res, pub_acc);
+    return point_add(res, priv_acc);
+  }
+
   // groth16.rs:179-203
   template <class F>
   static Proj<F> calculate_coeff(int id, Proj<F> initial, const Query<F>& query, const AffineT<F>& vk_param,
@@ -292,14 +306,42 @@ struct CoGroth16 {
     std::vector<Fr> inputs(input_assignment.begin() + 1, input_assignment.end());  // &input_assignment[1..]
     Proj<Fq> r_g1, s_g1, l_acc, h_acc;
     Proj<Fq2> s_g2;
-    // rayon_join5 (:227-294): five independent MSM groups, issued from five host threads (the C ABI is re-entrant)
+    // rayon_join5 (:227-294): five independent MSM groups. The four that consume aux_assignment (A, B/G1, B/G2, L) share
+    // one digit decomposition + bucket sort on the device (csh_msm_multi_dev); h_query runs from a second host thread.
     Span* sp_msm = new Span("5 msm groups (compute A, B/G1, B/G2, msm l_query, msm h_query)");
-    std::thread t1([&] { r_g1 = calculate_coeff<Fq>(id, T::template scalar_mul_public_point_hs<Fq>(delta_g1, T::to_half_share(r)), pkey.a_query, pkey.alpha_g1, inputs, aux_dev); });
-    std::thread t2([&] { s_g1 = calculate_coeff<Fq>(id, T::template scalar_mul_public_point_hs<Fq>(delta_g1, T::to_half_share(s)), pkey.b_g1_query, pkey.beta_g1, inputs, aux_dev); });
-    std::thread t3([&] { s_g2 = calculate_coeff<Fq2>(id, T::template scalar_mul_public_point_hs<Fq2>(delta_g2, T::to_half_share(s)), pkey.b_g2_query, pkey.beta_g2, inputs, aux_dev); });
-    std::thread t4([&] { l_acc = T::template msm_public_points_hs<Fq>(BasesView{pkey.l_query.dev, 0, pkey.l_query.size()}, aux_dev); });
     std::thread t5([&] { h_acc = T::template msm_public_points_hs<Fq>(BasesView{pkey.h_query.dev, 0, pkey.h_query.size()}, h_dev); });
-    t1.join(); t2.join(); t3.join(); t4.join(); t5.join();
+    const size_t pub_len = inputs.size();
+    const size_t n_aux = aux_dev.n;
+    const bool same_len = pkey.a_query.size() == 1 + pub_len + n_aux && pkey.b_g1_query.size() == 1 + pub_len + n_aux &&
+                          pkey.b_g2_query.size() == 1 + pub_len + n_aux && pkey.l_query.size() == n_aux && n_aux > 0 &&
+                          !getenv("COG16_SEPARATE_MSMS");
+    if (same_len) {
+      csh::Jac<Fq> ja, jb1, jl;
+      csh::Jac<Fq2> jb2;
+      const csh_bases_t hs[4] = {pkey.a_query.dev, pkey.b_g1_query.dev, pkey.b_g2_query.dev, pkey.l_query.dev};
+      const size_t offs[4] = {1 + pub_len, 1 + pub_len, 1 + pub_len, 0};
+      void* const outs[4] = {&ja, &jb1, &jb2, &jl};
+      int rc = csh_msm_multi_dev(hs, offs, 4, n_aux, reinterpret_cast<const uint64_t*>(aux_dev.dev), 1, outs, nullptr);
+      if (rc != CSH_OK) {
+        t5.join();
+        check(rc, "csh_msm_multi_dev");
+      }
+      auto to_proj = [](const auto& j) {
+        using F = typename std::decay<decltype(j.x)>::type;
+        return j.is_inf() ? Proj<F>::inf() : Proj<F>::from_affine(AffineT<F>{j.x, j.y});
+      };
+      r_g1 = finish_coeff<Fq>(id, T::template scalar_mul_public_point_hs<Fq>(delta_g1, T::to_half_share(r)), pkey.a_query, pkey.alpha_g1, inputs, to_proj(ja));
+      s_g1 = finish_coeff<Fq>(id, T::template scalar_mul_public_point_hs<Fq>(delta_g1, T::to_half_share(s)), pkey.b_g1_query, pkey.beta_g1, inputs, to_proj(jb1));
+      s_g2 = finish_coeff<Fq2>(id, T::template scalar_mul_public_point_hs<Fq2>(delta_g2, T::to_half_share(s)), pkey.b_g2_query, pkey.beta_g2, inputs, to_proj(jb2));
+      l_acc = to_proj(jl);
+      t5.join();
+    } else {
+      std::thread t1([&] { r_g1 = calculate_coeff<Fq>(id, T::template scalar_mul_public_point_hs<Fq>(delta_g1, T::to_half_share(r)), pkey.a_query, pkey.alpha_g1, inputs, aux_dev); });
+      std::thread t2([&] { s_g1 = calculate_coeff<Fq>(id, T::template scalar_mul_public_point_hs<Fq>(delta_g1, T::to_half_share(s)), pkey.b_g1_query, pkey.beta_g1, inputs, aux_dev); });
+      std::thread t3([&] { s_g2 = calculate_coeff<Fq2>(id, T::template scalar_mul_public_point_hs<Fq2>(delta_g2, T::to_half_share(s)), pkey.b_g2_query, pkey.beta_g2, inputs, aux_dev); });
+      std::thread t4([&] { l_acc = T::template msm_public_points_hs<Fq>(BasesView{pkey.l_query.dev, 0, pkey.l_query.size()}, aux_dev); });
+      t1.join(); t2.join(); t3.join(); t4.join(); t5.join();
+    }
     delete sp_msm;
     Span sp_fin("finish - open two points and some adds");
 

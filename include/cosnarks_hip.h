@@ -100,6 +100,12 @@ int csh_msm_dev(csh_bases_t bases, size_t offset, size_t n, const uint64_t* scal
 int csh_msm_partial_dev(csh_bases_t bases, size_t offset, size_t n, const uint64_t* scalars_dev,
                         int scalars_are_montgomery, void* out_xyzz_dev /* csh_msm_partial_bytes */,
                         void* stream);
+/* k MSMs over ONE device scalar vector -- the four aux-assignment MSMs of a Groth16 proof (a_query, b_g1_query, b_g2_query,
+ * l_query: groth16.rs:237-284, calculate_coeff :179-203): the signed-digit decomposition and the bucket sort depend on the
+ * scalars only and are computed once. bases[i]: handles of one curve (G1 and G2 may be mixed), each MSM takes n points
+ * from offsets[i]; outs_host[i]: Jacobian as csh_msm. Synchronous. */
+int csh_msm_multi_dev(const csh_bases_t* bases, const size_t* offsets, size_t k, size_t n, const uint64_t* scalars_dev,
+                      int scalars_are_montgomery, void* const* outs_host, void* stream);
 int csh_msm_partial_bytes(csh_curve_t curve, csh_group_t group, size_t* bytes);
 int csh_msm_fold_partials(csh_curve_t curve, csh_group_t group, const void* partials_host, size_t nparts,
                           void* out_jacobian);
