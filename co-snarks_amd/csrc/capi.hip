@@ -137,6 +137,13 @@ int csh_device_count(int* count) {
   return CSH_OK;
 }
 
+int csh_current_device(int* device) {
+  CSH_REQUIRE(device, "device is NULL");
+  CSH_TRY(ensure_device());
+  *device = tl_device;
+  return CSH_OK;
+}
+
 int csh_malloc(void** dev_ptr, size_t bytes) {
   CSH_REQUIRE(dev_ptr, "dev_ptr is NULL");
   CSH_TRY(ensure_device());

@@ -136,6 +136,11 @@ static int msm_args(csh_bases_t bases, size_t offset, size_t n, const void* scal
   Bases* B = reinterpret_cast<Bases*>(bases);
   CSH_REQUIRE(offset <= B->n && n <= B->n - offset, "offset + n exceeds the uploaded bases");
   CSH_REQUIRE(scalars || n == 0, "scalars is NULL");
+  int cur = -1;
+  if (hipGetDevice(&cur) == hipSuccess && cur != B->device) {
+    set_error("bases were uploaded on device %d but the calling thread is bound to device %d (csh_init): upload a copy per device", B->device, cur);
+    return CSH_ERR_INVALID;
+  }
   return CSH_OK;
 }
 
@@ -192,6 +197,14 @@ int csh_msm_multi_dev(const csh_bases_t* bases, const size_t* offsets, size_t k,
     CSH_REQUIRE(B && outs_host[i], "msm_multi: NULL handle or output");
     CSH_REQUIRE(B->curve == B0->curve, "msm_multi: all bases must belong to one curve");
     CSH_REQUIRE(offsets[i] <= B->n && n <= B->n - offsets[i], "msm_multi: offset + n exceeds the number of bases");
+    CSH_REQUIRE(B->device == B0->device, "msm_multi: bases live on different devices");
+  }
+  {
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && cur != B0->device) {
+      set_error("bases were uploaded on device %d but the calling thread is bound to device %d (csh_init)", B0->device, cur);
+      return CSH_ERR_INVALID;
+    }
   }
   hipStream_t st = resolve_stream(stream);
   struct Ops {

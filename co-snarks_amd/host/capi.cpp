@@ -66,9 +66,15 @@ int prove_rep3_t(const uint8_t* zkey, size_t zlen, const uint8_t* wtns, size_t w
   using T = Rep3Groth16Driver<P>;
   using Fr = typename P::Fr;
   using Share = Rep3PrimeFieldShare<Fr>;
-  ProvingKey<P> pk;
-  ConstraintMatrices<P> m;
-  parse_zkey<P>(zkey, zlen, pk, m);
+  int ndev = 1;
+  csh_device_count(&ndev);
+  // One GPU per party when the node has them (BASELINE config 4): device memory is not shared between GPUs, so every
+  // party then holds its own copy of the proving key and matrices on its device; on one GPU a single copy serves all.
+  const bool per_party_keys = ndev > 1;
+  ProvingKey<P> pk_shared;
+  ConstraintMatrices<P> m_shared;
+  parse_zkey<P>(zkey, zlen, pk_shared, m_shared, /*upload=*/!per_party_keys);
+  const ConstraintMatrices<P>& m = m_shared;
   std::vector<Fr> w = parse_wtns<P>(wtns, wlen);
   // share_field_elements (mpc-core/src/protocols/rep3.rs:281-292, 375-389) with a seeded RNG
   std::mt19937_64 gen(seed);
@@ -103,12 +109,15 @@ int prove_rep3_t(const uint8_t* zkey, size_t zlen, const uint8_t* wtns, size_t w
   std::vector<Fr> hs[3];
   std::string errs[3];
   std::vector<std::thread> th;
-  int ndev = 1;
-  csh_device_count(&ndev);
   for (int p = 0; p < 3; ++p) {
     th.emplace_back([&, p] {
       try {
         check(csh_init(ndev > 0 ? p % ndev : 0), "csh_init");  // one GPU per party when the node has them (BASELINE config 4)
+        ProvingKey<P> pk_own;
+        ConstraintMatrices<P> m_own;
+        if (per_party_keys) parse_zkey<P>(zkey, zlen, pk_own, m_own);  // uploads onto this thread's device
+        const ProvingKey<P>& pk = per_party_keys ? pk_own : pk_shared;
+        const ConstraintMatrices<P>& m = per_party_keys ? m_own : m_shared;
         uint8_t my_seed[32];
         std::mt19937_64 g2(seed * 1000003ull + 17 * p + 1);
         for (int i = 0; i < 4; ++i) {

@@ -3,6 +3,7 @@
 // CircomReduction) above the C ABI. Same control flow, line-cited; the hot calls go to the device.
 #pragma once
 #include <map>
+#include <tuple>
 #include <type_traits>
 #include <mutex>
 #include <thread>
@@ -45,14 +46,16 @@ inline void groth16_roots_of_unity(size_t pow, Fr& group_gen, Fr& coset_shift) {
 // same circuit needs the same (curve, size, generator) every time.
 struct DomainCache {
   std::mutex mu;
-  std::map<std::pair<int, uint32_t>, csh_domain_t> doms;
+  std::map<std::tuple<int, int, uint32_t>, csh_domain_t> doms;  // (device, curve, log size): twiddle tables live on one GPU
   static DomainCache& get() {
     static DomainCache c;
     return c;
   }
   csh_domain_t lookup(csh_curve_t curve, uint32_t log_n, const uint64_t* gen, int* rc_out) {
     std::lock_guard<std::mutex> g(mu);
-    auto key = std::make_pair((int)curve, log_n);
+    int dev = 0;
+    (void)csh_current_device(&dev);
+    auto key = std::make_tuple(dev, (int)curve, log_n);
     auto it = doms.find(key);
     if (it != doms.end()) {
       *rc_out = CSH_OK;

@@ -100,19 +100,27 @@ inline void parallel_for(size_t n, size_t min_len, Fn fn) {
 // a prover asks for the same few sizes every time.
 struct DevicePool {
   std::mutex mu;
-  std::multimap<size_t, void*> free_;
+  std::map<int, std::multimap<size_t, void*>> free_;  // per device: a buffer is only valid on the GPU it was allocated on
   static DevicePool& get() {
     static DevicePool p;
     return p;
   }
-  void* take(size_t bytes, size_t* cap) {
+  static int device() {
+    int d = 0;
+    (void)csh_current_device(&d);
+    return d;
+  }
+  void* take(size_t bytes, size_t* cap, int* dev_out) {
+    const int dev = device();
+    *dev_out = dev;
     {
       std::lock_guard<std::mutex> g(mu);
-      auto it = free_.lower_bound(bytes);
-      if (it != free_.end() && it->first <= 2 * bytes + (size_t(1) << 20)) {
+      auto& fl = free_[dev];
+      auto it = fl.lower_bound(bytes);
+      if (it != fl.end() && it->first <= 2 * bytes + (size_t(1) << 20)) {
         void* p = it->second;
         *cap = it->first;
-        free_.erase(it);
+        fl.erase(it);
         return p;
       }
     }
@@ -121,13 +129,14 @@ struct DevicePool {
     *cap = bytes;
     return p;
   }
-  void give(void* p, size_t cap) {
+  void give(void* p, size_t cap, int dev) {
     std::lock_guard<std::mutex> g(mu);
-    free_.emplace(cap, p);
+    free_[dev].emplace(cap, p);
   }
   void trim() {
     std::lock_guard<std::mutex> g(mu);
-    for (auto& kv : free_) csh_free(kv.second);
+    for (auto& d : free_)
+      for (auto& kv : d.second) csh_free(kv.second);
     free_.clear();
   }
 };
@@ -138,16 +147,17 @@ struct DeviceScalars {
   void* dev = nullptr;
   size_t n = 0;
   size_t cap = 0;
+  int device = 0;
   DeviceScalars() = default;
-  explicit DeviceScalars(size_t count, size_t comps = 1) : n(count) { dev = DevicePool::get().take(count * comps * 32 + 32, &cap); }
+  explicit DeviceScalars(size_t count, size_t comps = 1) : n(count) { dev = DevicePool::get().take(count * comps * 32 + 32, &cap, &device); }
   DeviceScalars(const void* host, size_t count, size_t comps = 1) : DeviceScalars(count, comps) {
     if (count) check(csh_memcpy_h2d(dev, host, count * comps * 32), "csh_memcpy_h2d");
   }
   DeviceScalars(const DeviceScalars&) = delete;
   DeviceScalars& operator=(const DeviceScalars&) = delete;
-  DeviceScalars(DeviceScalars&& o) noexcept : dev(o.dev), n(o.n), cap(o.cap) { o.dev = nullptr; }
+  DeviceScalars(DeviceScalars&& o) noexcept : dev(o.dev), n(o.n), cap(o.cap), device(o.device) { o.dev = nullptr; }
   ~DeviceScalars() {
-    if (dev) DevicePool::get().give(dev, cap);
+    if (dev) DevicePool::get().give(dev, cap, device);
   }
 };
 

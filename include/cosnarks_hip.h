@@ -67,6 +67,8 @@ const char* csh_version(void);
 int csh_device_count(int* count);
 
 /* plain device-memory plumbing for harnesses without their own HIP binding (tests, the Rust shim) */
+/* the device the calling thread is bound to (csh_init, default 0): handles (bases, domains, matrices) are per device */
+int csh_current_device(int* device);
 int csh_malloc(void** dev_ptr, size_t bytes);
 int csh_free(void* dev_ptr);
 int csh_memcpy_h2d(void* dev_dst, const void* host_src, size_t bytes);
