@@ -493,6 +493,12 @@ using namespace csh;
 static int check_dom(csh_domain_t dom, uint32_t ncomp) {
   CSH_REQUIRE(dom, "domain is NULL");
   CSH_REQUIRE(ncomp == 1 || ncomp == 2, "ncomp must be 1 or 2");
+  int cur = -1;
+  const Domain* d = reinterpret_cast<const Domain*>(dom);
+  if (hipGetDevice(&cur) == hipSuccess && cur != d->device) {
+    set_error("the domain's twiddle tables live on device %d but the calling thread is bound to device %d (csh_init)", d->device, cur);
+    return CSH_ERR_INVALID;
+  }
   return CSH_OK;
 }
 
