@@ -98,7 +98,7 @@ def secondary_metrics(hip, B, L, C, np, torch, dev, stream):
     del a, b, m, o
     # Groth16 plain prove, synthetic 2^20-constraint circuit with a known-dlog key (closed-form checked), key resident
     from cosnarks_amd import groth16 as g16
-    out["groth16_prove_synthetic_2p20"] = g16.bench_synthetic(hip.BN254, 20, 3)
+    out["groth16_prove_synthetic_2p20"] = g16.bench_synthetic(hip.BN254, 20, 3, with_rep3=True)
     # BASELINE configs 1 and 4 on the reference's own circuits (tests/golden copies of test_vectors/Groth16/bn254): plain
     # prove of multiplier2 (domain 4) and poseidon (domain 256), and a three-party Rep3 prove of poseidon (in-process
     # parties sharing this GPU). Wall ms per proof incl. zkey parse + key upload; these sizes are launch-latency bound.

@@ -63,15 +63,20 @@ def prove_shamir(curve: int, zkey: bytes, wtns: bytes, num_parties: int, thresho
     return json.loads(out.value.decode())
 
 
-def bench_synthetic(curve: int, log_domain: int, iters: int = 3):
-    """Plain Groth16 prove on a synthetic 2^log_domain circuit with a known-dlog key (closed-form check)."""
-    ms = (C.c_double * 4)()
+def bench_synthetic(curve: int, log_domain: int, iters: int = 3, with_rep3: bool = False):
+    """Plain Groth16 prove on a synthetic 2^log_domain circuit with a known-dlog key (closed-form check); optionally
+    also three in-process Rep3 parties proving the same circuit (BASELINE config 4 at scale)."""
+    ms = (C.c_double * 6)()
     ok = C.c_int(0)
-    rc = glib().cog16_bench_synthetic(curve, log_domain, iters, ms, C.byref(ok))
+    rc = glib().cog16_bench_synthetic(curve, log_domain, iters, ms, C.byref(ok), int(with_rep3))
     if rc != 0:
         raise CoSnarksHipError(glib().cog16_last_error().decode())
-    return {"log_domain": log_domain, "witness_map_ms": ms[0], "create_proof_ms": ms[1], "prove_ms": ms[2],
-            "key_setup_ms": ms[3], "closed_form_check": bool(ok.value)}
+    out = {"log_domain": log_domain, "witness_map_ms": ms[0], "create_proof_ms": ms[1], "prove_ms": ms[2],
+           "key_setup_ms": ms[3], "closed_form_check": bool(ok.value)}
+    if with_rep3:
+        out["rep3_three_parties_prove_ms"] = ms[4]
+        out["rep3_proofs_equal_plain"] = bool(ms[5])
+    return out
 
 
 CIRCOM_REDUCTION, LIBSNARK_REDUCTION = 0, 1

@@ -259,8 +259,31 @@ void synth_query(csh_curve_t curve, csh_group_t group, uint64_t seed, size_t n, 
   csh_free(dev);
 }
 
+template <class Fr>
+struct Rep3Sharer {
+  std::mt19937_64 gen;
+  explicit Rep3Sharer(uint64_t seed) : gen(seed) {}
+  Fr rnd() {
+    uint8_t b[32];
+    for (int i = 0; i < 4; ++i) {
+      uint64_t v = gen();
+      memcpy(b + 8 * i, &v, 8);
+    }
+    return from_be_bytes_mod_order<Fr>(b);
+  }
+  void share(const std::vector<Fr>& vals, std::vector<Rep3PrimeFieldShare<Fr>> out[3]) {
+    for (auto& v : vals) {
+      Fr a = rnd(), b = rnd();
+      Fr c = Fr::sub(Fr::sub(v, a), b);
+      out[0].push_back({a, c});
+      out[1].push_back({b, a});
+      out[2].push_back({c, b});
+    }
+  }
+};
+
 template <class P>
-int bench_synth_t(int log_domain, int iters, double* out_ms, int* check_ok, const uint32_t* g1_words, const uint32_t* g2_words) {
+int bench_synth_t(int log_domain, int iters, double* out_ms, int* check_ok, const uint32_t* g1_words, const uint32_t* g2_words, bool with_rep3) {
   using T = PlainGroth16Driver<P>;
   using Fr = typename P::Fr;
   using Fq = typename P::Fq;
@@ -346,6 +369,68 @@ int bench_synth_t(int log_domain, int iters, double* out_ms, int* check_ok, cons
   AffineT<Fq> wa = into_affine(point_mul(into_group(g1), dA)), wc = into_affine(point_mul(into_group(g1), dC));
   AffineT<Fq2> wb = into_affine(point_mul(into_group(g2), dB2));
   *check_ok = eq1(wa, proof.a) && eq1(wc, proof.c) && wb.x == proof.b.x && wb.y == proof.b.y;
+
+  // BASELINE config 4 at scale: three in-process Rep3 parties (device ChaCha12 masks, two-component NTTs, half-share MSMs)
+  // prove the same circuit with the same r, s; they share this GPU (or take one GPU each when the node has several, with
+  // key copies per device). Wall time of the whole three-party run; the agreed proof must equal the plain one.
+  out_ms[4] = 0;
+  out_ms[5] = 0;
+  if (with_rep3) {
+    using T3 = Rep3Groth16Driver<P>;
+    using Share = Rep3PrimeFieldShare<Fr>;
+    Rep3Sharer<Fr> sharer(99);
+    std::vector<Share> wsh[3];
+    sharer.share(sw.witness, wsh);
+    Share r3[3], s3[3];
+    {
+      std::vector<Share> t[3];
+      sharer.share({r, s}, t);
+      for (int p = 0; p < 3; ++p) {
+        r3[p] = t[p][0];
+        s3[p] = t[p][1];
+      }
+    }
+    SharedWitness<P, Share> sw3[3];
+    for (int p = 0; p < 3; ++p) {
+      sw3[p].public_inputs = sw.public_inputs;
+      sw3[p].witness = std::move(wsh[p]);
+    }
+    double best3 = 1e30;
+    Proof<P> proofs[3];
+    for (int it = 0; it < iters; ++it) {
+      auto nets0 = LocalNetwork::new_parties(3), nets1 = LocalNetwork::new_parties(3);
+      std::string errs[3];
+      auto b0 = std::chrono::steady_clock::now();
+      std::vector<std::thread> th;
+      for (int p = 0; p < 3; ++p) {
+        th.emplace_back([&, p] {
+          try {
+            check(csh_init(0), "csh_init");
+            uint8_t my_seed[32];
+            std::mt19937_64 g2(4242ull * 1000003ull + 17 * p + 1 + it);
+            for (int i = 0; i < 4; ++i) {
+              uint64_t v = g2();
+              memcpy(my_seed + 8 * i, &v, 8);
+            }
+            Rep3State state0 = Rep3State::create(nets0[p], my_seed);
+            Rep3State state1 = state0.fork(0);
+            proofs[p] = CoGroth16<P, T3>::template prove_inner<CircomReduction>(&nets0[p], &nets1[p], state0, state1, pk, m, sw3[p], &r3[p], &s3[p]);
+          } catch (const std::exception& e) {
+            errs[p] = e.what();
+          }
+        });
+      }
+      for (auto& t : th) t.join();
+      best3 = std::min(best3, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - b0).count());
+      for (int p = 0; p < 3; ++p)
+        if (!errs[p].empty()) throw Error("rep3 party " + std::to_string(p) + ": " + errs[p]);
+    }
+    out_ms[4] = best3;
+    bool ok3 = true;
+    for (int p = 0; p < 3; ++p)
+      ok3 = ok3 && eq1(proofs[p].a, proof.a) && eq1(proofs[p].c, proof.c) && proofs[p].b.x == proof.b.x && proofs[p].b.y == proof.b.y;
+    out_ms[5] = ok3 ? 1.0 : 0.0;
+  }
   return 0;
 }
 
@@ -438,29 +523,6 @@ int witness_map_t(int reduction, int mode, const uint64_t* const row_ptr[3], con
 }
 
 // ---- PLONK / UltraHonk driver call sites (plonk_honk.hpp) on caller data: plain values in, shared inside for Rep3 --------
-template <class Fr>
-struct Rep3Sharer {
-  std::mt19937_64 gen;
-  explicit Rep3Sharer(uint64_t seed) : gen(seed) {}
-  Fr rnd() {
-    uint8_t b[32];
-    for (int i = 0; i < 4; ++i) {
-      uint64_t v = gen();
-      memcpy(b + 8 * i, &v, 8);
-    }
-    return from_be_bytes_mod_order<Fr>(b);
-  }
-  void share(const std::vector<Fr>& vals, std::vector<Rep3PrimeFieldShare<Fr>> out[3]) {
-    for (auto& v : vals) {
-      Fr a = rnd(), b = rnd();
-      Fr c = Fr::sub(Fr::sub(v, a), b);
-      out[0].push_back({a, c});
-      out[1].push_back({b, a});
-      out[2].push_back({c, b});
-    }
-  }
-};
-
 template <class Fn>
 void run_three_parties(uint64_t seed, Fn fn) {  // fn(party, Rep3State&)
   auto nets = LocalNetwork::new_parties(3);
@@ -722,11 +784,12 @@ int cog16_prove_shamir(int curve, const uint8_t* zkey, size_t zlen, const uint8_
   }
 }
 
-// out_ms[4] = {witness_map ms, create_proof ms, total prove ms, key generation+upload ms}; best of `iters`.
-int cog16_bench_synthetic(int curve, int log_domain, int iters, double* out_ms, int* check_ok) {
+// out_ms[6] = {witness_map ms, create_proof ms, total prove ms, key generation+upload ms, three-party Rep3 prove wall ms,
+// Rep3 proofs == plain proof (1/0)}; best of `iters`.
+int cog16_bench_synthetic(int curve, int log_domain, int iters, double* out_ms /* 6 entries */, int* check_ok, int with_rep3) {
   try {
-    if (curve == 0) return bench_synth_t<Bn254>(log_domain, iters, out_ms, check_ok, csh::Bn254G1Gen, csh::Bn254G2Gen);
-    if (curve == 1) return bench_synth_t<Bls12_381>(log_domain, iters, out_ms, check_ok, csh::Bls381G1Gen, csh::Bls381G2Gen);
+    if (curve == 0) return bench_synth_t<Bn254>(log_domain, iters, out_ms, check_ok, csh::Bn254G1Gen, csh::Bn254G2Gen, with_rep3 != 0);
+    if (curve == 1) return bench_synth_t<Bls12_381>(log_domain, iters, out_ms, check_ok, csh::Bls381G1Gen, csh::Bls381G2Gen, with_rep3 != 0);
     g_err = "unknown curve";
     return -1;
   } catch (const std::exception& e) {

@@ -106,7 +106,9 @@ def test_prove_rejects_wrong_witness_length(gpu):
 def test_synthetic_circuit_prove_closed_form(gpu, curve, logd):
     """SURVEY 8d config 1 (synthetic large circuit, known-dlog key): A, B, C equal their closed-form discrete logs."""
     from cosnarks_amd import groth16 as g
-    res = g.bench_synthetic(H.CURVE_IDS[curve], logd, iters=1)
+    res = g.bench_synthetic(H.CURVE_IDS[curve], logd, iters=1, with_rep3=(logd == 12))
+    if logd == 12:
+        assert res["rep3_proofs_equal_plain"]          # three Rep3 parties reproduce the plain proof of the synthetic circuit
     assert res["closed_form_check"], res
 
 
