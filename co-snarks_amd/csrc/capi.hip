@@ -165,6 +165,16 @@ int csh_memcpy_d2h(void* host_dst, const void* dev_src, size_t bytes) {
   CSH_HIP(hipMemcpy(host_dst, dev_src, bytes, hipMemcpyDeviceToHost));
   return CSH_OK;
 }
+int csh_extract_component_dev(const uint64_t* shares_dev, uint32_t ncomp, uint32_t comp, size_t n, uint64_t* out_dev, void* stream) {
+  CSH_REQUIRE(shares_dev && out_dev, "NULL argument");
+  CSH_REQUIRE(ncomp >= 1 && ncomp <= 4 && comp < ncomp, "bad component selector");
+  CSH_TRY(ensure_device());
+  if (n == 0) return CSH_OK;
+  CSH_HIP(hipMemcpy2DAsync(out_dev, 32, reinterpret_cast<const char*>(shares_dev) + 32 * (size_t)comp, 32 * (size_t)ncomp, 32, n,
+                           hipMemcpyDeviceToDevice, resolve_stream(stream)));
+  return CSH_OK;
+}
+
 int csh_sync(void* stream) {
   CSH_TRY(ensure_device());
   CSH_HIP(hipStreamSynchronize(resolve_stream(stream)));

@@ -400,9 +400,16 @@ struct CoGroth16 {
         if constexpr (std::is_same<Share, Half>::value) {
           return create_proof_device(net0, net1, state0, state1, pkey, r, s, h_dev, w.public_inputs, wit_dev);
         } else {
-          std::vector<Half> half(w.witness.size());
-          for (size_t i = 0; i < half.size(); ++i) half[i] = T::to_half_share(w.witness[i]);
-          const DeviceScalars aux_dev(half.data(), half.size());
+          // to_half_share over the witness (groth16.rs:159-163) on the device: a strided copy of the share component
+          // the driver's to_half_share keeps (Rep3: `.a`), instead of a host loop + a second 32 MB upload
+          static_assert(sizeof(Share) == COMPS * sizeof(Half), "share = COMPS field elements");
+          Share probe{};
+          reinterpret_cast<Fr*>(&probe)[0] = Fr::one();
+          const uint32_t keep = T::to_half_share(probe) == Fr::one() ? 0u : 1u;
+          const DeviceScalars aux_dev(w.witness.size());
+          check(csh_extract_component_dev((const uint64_t*)wit_dev.dev, (uint32_t)COMPS, keep, w.witness.size(), (uint64_t*)aux_dev.dev, nullptr),
+                "csh_extract_component_dev");
+          check(csh_sync(nullptr), "csh_sync");
           return create_proof_device(net0, net1, state0, state1, pkey, r, s, h_dev, w.public_inputs, aux_dev);
         }
       }

@@ -74,6 +74,9 @@ int csh_free(void* dev_ptr);
 int csh_memcpy_h2d(void* dev_dst, const void* host_src, size_t bytes);
 int csh_memcpy_d2h(void* host_dst, const void* dev_src, size_t bytes);
 int csh_sync(void* stream);
+/* out[i] = component `comp` of the i-th share (ncomp 32-byte field elements per share), device to device: the
+ * `to_half_share` map over the witness (groth16.rs:159-163; Rep3 = take `.a`, mpc/rep3.rs:120-122) without a host pass. */
+int csh_extract_component_dev(const uint64_t* shares_dev, uint32_t ncomp, uint32_t comp, size_t n, uint64_t* out_dev, void* stream);
 
 /* ---- MSM ------------------------------------------------------------------------------------
  * Replaces taceo_ark_algebra::msm::msm_unchecked(&[Affine<C>], &[F]) -> Projective<C> and
