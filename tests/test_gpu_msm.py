@@ -156,7 +156,8 @@ def test_generated_bases_have_known_dlog(gpu, curve, group):
         assert G.eq(P, G.mul(G.gen, int(k)))
 
 
-@pytest.mark.parametrize("curve,group,logn", [("bn254", 0, 20), ("bn254", 0, 22), ("bls12_381", 0, 18), ("bn254", 1, 17), ("bls12_381", 1, 16),
+@pytest.mark.parametrize("curve,group,logn", [("bn254", 0, 20), ("bn254", 0, 22), ("bn254", 0, 24), ("bls12_381", 0, 18), ("bls12_381", 0, 22),
+                                               ("bn254", 1, 17), ("bn254", 1, 20), ("bls12_381", 1, 16), ("bls12_381", 1, 20),
                                                ("grumpkin", 0, 18)])
 def test_msm_closed_form_full_size(gpu, curve, group, logn):
     """Known-dlog bases: MSM == (sum s_i k_i) G at BASELINE sizes, uniform scalars, Montgomery input."""
