@@ -128,19 +128,30 @@ __global__ __launch_bounds__(NTT_MAX_THREADS) void k_ntt_pass(F* __restrict__ da
 // the top limb absorbs the growth); in a decimation-in-frequency pass the sum output feeds the next sum and would double
 // per stage, so it is folded back below 2p each stage (fold_top: a top-limb quotient estimate, no multiplication). The
 // tile is brought back to [0, p) once per pass when it is stored (canonical_wide).
+// limb-major LDS tile: limbs (2i, 2i+1) of element e live in an 8-byte slot of pair-array i (ds_read/write_b64, lane
+// stride 8 bytes: conflict-free), the odd last limb in a 4-byte array behind them -- 5 LDS accesses per element instead of 9
 template <class LZ>
 struct LazyLds {
   int32_t* base;
   int E;
+  static constexpr int NP = LZ::NL / 2;
   __device__ __forceinline__ LZ get(int e) const {
     LZ r;
+    const int2* pairs = reinterpret_cast<const int2*>(base);
 #pragma unroll
-    for (int i = 0; i < LZ::NL; ++i) r.l[i] = base[i * E + e];
+    for (int i = 0; i < NP; ++i) {
+      const int2 v = pairs[i * E + e];
+      r.l[2 * i] = v.x;
+      r.l[2 * i + 1] = v.y;
+    }
+    if (LZ::NL & 1) r.l[LZ::NL - 1] = base[2 * NP * E + e];
     return r;
   }
   __device__ __forceinline__ void put(int e, const LZ& v) const {
+    int2* pairs = reinterpret_cast<int2*>(base);
 #pragma unroll
-    for (int i = 0; i < LZ::NL; ++i) base[i * E + e] = v.l[i];
+    for (int i = 0; i < NP; ++i) pairs[i * E + e] = make_int2(v.l[2 * i], v.l[2 * i + 1]);
+    if (LZ::NL & 1) base[2 * NP * E + e] = v.l[LZ::NL - 1];
   }
 };
 
