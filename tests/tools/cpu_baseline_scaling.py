@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Thread scaling of the oracle/c CPU MSM port on this host (context for bench.py's cpu_baseline)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from oracle import cbridge as cb
 
