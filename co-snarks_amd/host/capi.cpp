@@ -43,16 +43,26 @@ int prove_plain_t(const uint8_t* zkey, size_t zlen, const uint8_t* wtns, size_t 
   ProvingKey<P> pk;
   ConstraintMatrices<P> m;
   parse_zkey<P>(zkey, zlen, pk, m);
-  std::vector<Fr> w = parse_wtns<P>(wtns, wlen);
-  SharedWitness<P, Fr> sw;
-  sw.public_inputs.assign(w.begin(), w.begin() + m.num_instance_variables);
-  sw.witness.assign(w.begin() + m.num_instance_variables, w.end());
   UnitState st0, st1;
   Fr rr, ss;
   if (r) rr = fr_from_canonical<P>(r);
   if (s) ss = fr_from_canonical<P>(s);
   std::vector<Fr> h;
-  Proof<P> pr = CoGroth16<P, T>::template prove_inner<CircomReduction>(nullptr, nullptr, st0, st1, pk, m, sw, r ? &rr : nullptr, s ? &ss : nullptr, &h);
+  Proof<P> pr;
+  if (getenv("COG16_HOST_WTNS")) {  // witness values converted on the host, SharedWitness as in the reference's CLI
+    std::vector<Fr> w = parse_wtns<P>(wtns, wlen);
+    SharedWitness<P, Fr> sw;
+    sw.public_inputs.assign(w.begin(), w.begin() + m.num_instance_variables);
+    sw.witness.assign(w.begin() + m.num_instance_variables, w.end());
+    pr = CoGroth16<P, T>::template prove_inner<CircomReduction>(nullptr, nullptr, st0, st1, pk, m, sw, r ? &rr : nullptr, s ? &ss : nullptr, &h);
+  } else {
+    // zkey queries and the wtns values go to the device straight from the file images; only the public
+    // inputs (a handful of values) are decoded on the host
+    std::vector<Fr> pub = parse_wtns_prefix<P>(wtns, wlen, m.num_instance_variables);
+    const DeviceScalars wit_dev = parse_wtns_to_device<P>(wtns, wlen, m.num_instance_variables);
+    pr = CoGroth16<P, T>::template prove_inner_device_witness<CircomReduction>(nullptr, nullptr, st0, st1, pk, m, pub, wit_dev, r ? &rr : nullptr,
+                                                                               s ? &ss : nullptr, &h);
+  }
   if (h_out) {
     if (h.size() > h_cap) throw Error("h_out too small");
     memcpy(h_out, h.data(), h.size() * 32);

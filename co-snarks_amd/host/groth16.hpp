@@ -371,6 +371,31 @@ struct CoGroth16 {
     return Proof<P>{into_affine(g_a_opened), into_affine(g_c_opened), into_affine(g2_b_opened)};
   }
 
+  // prove_inner for a witness that is already a device vector of shares (e.g. ingested straight from a wtns image,
+  // zkey.hpp parse_wtns_to_device): same sequence as the device-resident branch of prove_inner below
+  template <class R>
+  static Proof<P> prove_inner_device_witness(const Net* net0, const Net* net1, State& state0, State& state1, const ProvingKey<P>& pkey,
+                                             const ConstraintMatrices<P>& matrices, const std::vector<Fr>& public_inputs,
+                                             const DeviceScalars& wit_dev, const Share* r_in, const Share* s_in, std::vector<Half>* h_out = nullptr) {
+    static_assert(std::is_same<Share, Half>::value, "device-ingested witnesses are single-component share vectors");
+    if (public_inputs.size() != matrices.num_instance_variables)
+      throw Error("amount of public inputs does not match with provided constraint system! Expected " +
+                  std::to_string(matrices.num_instance_variables) + ", but got " + std::to_string(public_inputs.size()));
+    if (wit_dev.n != matrices.num_witness_variables)
+      throw Error("amount of private witness variables does not match with provided constraint system! Expected " +
+                  std::to_string(matrices.num_witness_variables) + ", but got " + std::to_string(wit_dev.n));
+    if (!R::template device_map_available<P>(matrices)) throw Error("constraint matrices are not on the device");
+    const DeviceScalars h_dev = R::template witness_map_device<P, T>(state0, matrices, public_inputs, wit_dev);
+    Share r = T::rand(net0, state0), s = T::rand(net0, state0);
+    if (r_in) r = *r_in;
+    if (s_in) s = *s_in;
+    if (h_out) {
+      h_out->resize(h_dev.n);
+      check(csh_memcpy_d2h(h_out->data(), h_dev.dev, h_dev.n * sizeof(Half)), "csh_memcpy_d2h");
+    }
+    return create_proof_device(net0, net1, state0, state1, pkey, r, s, h_dev, public_inputs, wit_dev);
+  }
+
   // groth16.rs:125-177 with r, s optionally supplied (the reference always draws them with T::rand)
   template <class R>
   static Proof<P> prove_inner(const Net* net0, const Net* net1, State& state0, State& state1, const ProvingKey<P>& pkey,

@@ -202,6 +202,15 @@ struct Query {
     len = host.size();
     check(csh_bases_upload(curve, group, host.data(), host.size(), 0, &dev), "csh_bases_upload");
   }
+  // straight from a file image (zkey sections hold packed Montgomery little-endian points, the C ABI's own layout):
+  // the points go to the device from where they lie; the host keeps only the first `keep_host` entries it reads
+  void upload_from(csh_curve_t curve, csh_group_t group, const uint8_t* packed, size_t count, size_t keep_host, bool to_device) {
+    len = count;
+    const size_t k = to_device ? (keep_host < count ? keep_host : count) : count;
+    host.resize(k);
+    if (k) memcpy((void*)host.data(), packed, k * sizeof(AffineT<F>));
+    if (to_device) check(csh_bases_upload(curve, group, packed, count, 0, &dev), "csh_bases_upload");
+  }
   void release() {
     if (dev) csh_bases_free(dev);
     dev = nullptr;

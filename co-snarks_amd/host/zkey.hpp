@@ -79,20 +79,25 @@ void parse_zkey(const uint8_t* d, size_t n, ProvingKey<P>& pk, ConstraintMatrice
   pk.gamma_g2 = g2(off); off += 4 * n8q;
   pk.delta_g1 = g1(off); off += 2 * n8q;
   pk.delta_g2 = g2(off);
-  auto list1 = [&](uint32_t sec, std::vector<AffineT<Fq>>& out) {
+  // IC stays on the host; the five queries are uploaded from the file image itself ("zkey points are already
+  // Montgomery LE -- they can be DMA'd without conversion"). calculate_coeff reads query[0 ..= n_public] on the host.
+  {
+    auto [o, l] = s.at(3);
+    pk.ic.resize(l / (2 * n8q));
+    if (l) memcpy(pk.ic.data(), d + o, pk.ic.size() * 2 * n8q);
+  }
+  const size_t keep = (size_t)n_public + 1;
+  auto q1 = [&](uint32_t sec, Query<Fq>& q, size_t keep_host) {
     auto [o, l] = s.at(sec);
-    out.resize(l / (2 * n8q));
-    if (l) memcpy(out.data(), d + o, out.size() * 2 * n8q);
+    q.upload_from(P::ID, CSH_G1, d + o, l / (2 * n8q), keep_host, upload);
   };
-  list1(3, pk.ic);
-  list1(5, pk.a_query.host);
-  list1(6, pk.b_g1_query.host);
-  list1(8, pk.l_query.host);
-  list1(9, pk.h_query.host);
+  q1(5, pk.a_query, keep);
+  q1(6, pk.b_g1_query, keep);
+  q1(8, pk.l_query, 0);
+  q1(9, pk.h_query, 0);
   {
     auto [o, l] = s.at(7);
-    pk.b_g2_query.host.resize(l / (4 * n8q));
-    if (l) memcpy(pk.b_g2_query.host.data(), d + o, pk.b_g2_query.host.size() * 4 * n8q);
+    pk.b_g2_query.upload_from(P::ID, CSH_G2, d + o, l / (4 * n8q), keep, upload);
   }
   // coefficients -> ConstraintMatrices (public-input rows, constraint index >= num_constraints, are dropped:
   // the reference overwrites exactly those evaluation slots, groth16/reduction.rs:111-113)
@@ -122,14 +127,7 @@ void parse_zkey(const uint8_t* d, size_t n, ProvingKey<P>& pk, ConstraintMatrice
   for (auto& cf : coefs)
     if (cf.row < m.num_constraints) (cf.m == 0 ? m.a : m.b)[cf.row].push_back({cf.v, cf.sig});
   (void)domain;
-  if (upload) {
-    pk.a_query.upload(P::ID, CSH_G1);
-    pk.b_g1_query.upload(P::ID, CSH_G1);
-    pk.l_query.upload(P::ID, CSH_G1);
-    pk.h_query.upload(P::ID, CSH_G1);
-    pk.b_g2_query.upload(P::ID, CSH_G2);
-    m.upload();
-  }
+  if (upload) m.upload();
 }
 
 // witness values (canonical little-endian) -> Montgomery Fr
@@ -151,6 +149,52 @@ std::vector<typename P::Fr> parse_wtns(const uint8_t* d, size_t n) {
     memcpy(&raw, d + o + (size_t)i * n8, n8);
     out[i] = raw.to_mont();
   }
+  return out;
+}
+
+// the first `count` witness values only (the public inputs), Montgomery
+template <class P>
+std::vector<typename P::Fr> parse_wtns_prefix(const uint8_t* d, size_t n, size_t count) {
+  using Fr = typename P::Fr;
+  Sections s(d, n, "wtns");
+  auto [h, hl] = s.at(1);
+  (void)hl;
+  uint32_t n8, cnt;
+  memcpy(&n8, d + h, 4);
+  if (n8 != sizeof(Fr)) throw Error("wtns field size mismatch");
+  memcpy(&cnt, d + h + 4 + n8, 4);
+  auto [o, l] = s.at(2);
+  if (count > cnt || l < (size_t)cnt * n8) throw Error("truncated wtns");
+  std::vector<Fr> out(count);
+  for (size_t i = 0; i < count; ++i) {
+    Fr raw;
+    memcpy(&raw, d + o + i * n8, n8);
+    out[i] = raw.to_mont();
+  }
+  return out;
+}
+
+// The same witness values as a device vector: the canonical little-endian bytes are uploaded as they lie in the file
+// and converted to Montgomery form on the device (one multiplication by R^2 per element, csh_lincomb_dev with k = 1).
+template <class P>
+DeviceScalars parse_wtns_to_device(const uint8_t* d, size_t n, size_t skip_first = 0) {
+  using Fr = typename P::Fr;
+  Sections s(d, n, "wtns");
+  auto [h, hl] = s.at(1);
+  (void)hl;
+  uint32_t n8, cnt;
+  memcpy(&n8, d + h, 4);
+  if (n8 != sizeof(Fr)) throw Error("wtns field size mismatch");
+  memcpy(&cnt, d + h + 4 + n8, 4);
+  auto [o, l] = s.at(2);
+  if (l < (size_t)cnt * n8) throw Error("truncated wtns");
+  if (skip_first > cnt) throw Error("wtns shorter than the public inputs");
+  const size_t m = cnt - skip_first;
+  DeviceScalars out(d + o + skip_first * n8, m);  // raw canonical limbs
+  const Fr r2 = Fr::r2();
+  const uint64_t* ptrs[1] = {reinterpret_cast<const uint64_t*>(out.dev)};
+  check(csh_lincomb_dev(P::ID, ptrs, reinterpret_cast<const uint64_t*>(&r2), 1, reinterpret_cast<uint64_t*>(out.dev), m, nullptr), "csh_lincomb_dev");
+  check(csh_sync(nullptr), "csh_sync");
   return out;
 }
 
