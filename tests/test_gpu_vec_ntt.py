@@ -198,3 +198,26 @@ def test_sparse_constraint_evaluation_on_device(gpu, curve):
         want3 = [d3.eval_row(row, pub, shares[party]) for row in rows] + [(0, 0)] * (n_out - n_rows)
         got = H.unpack_shares(F, M.evaluate(1, party, H.pack(F, pub), H.pack_shares(F, shares[party]), n_out))
         assert got == want3
+
+
+def test_extract_component_and_current_device(gpu):
+    """csh_extract_component_dev (the to_half_share map over a Rep3 share vector, groth16.rs:159-163 / mpc/rep3.rs:120-122)
+    and csh_current_device."""
+    import ctypes as C
+    L = gpu.lib()
+    dev = C.c_int(-1)
+    gpu.bindings._check(L.csh_current_device(C.byref(dev)))
+    assert dev.value == 0
+    rs = np.random.RandomState(3)
+    n = 1000
+    shares = rs.randint(0, 1 << 62, size=(n, 2, 4), dtype=np.uint64)
+    src = gpu.DeviceBuffer.from_host(shares)
+    dst = gpu.DeviceBuffer(n * 32)
+    for comp in (0, 1):
+        gpu.bindings._check(L.csh_extract_component_dev(src.ptr, 2, comp, C.c_size_t(n), dst.ptr, None))
+        gpu.bindings.sync()
+        assert (dst.to_host(count=4 * n).reshape(n, 4) == shares[:, comp, :]).all()
+    assert L.csh_extract_component_dev(src.ptr, 2, 2, C.c_size_t(n), dst.ptr, None) != 0   # component out of range
+    src.free()
+    dst.free()
+
