@@ -90,3 +90,12 @@ def test_host_mirror_ark_wire_formats_match_the_oracle_serializer():
         assert n > 0, L.cog16_last_error()
         assert bytes(out[:n]) == b"".join(arkfmt.ser_g1(pt, G.F.p, nb) for pt in pts)
 
+
+def test_header_is_plain_c():
+    """The drop-in boundary must be bindable from cgo / bindgen / ctypes: the header parses as C11 and as C++17 on its own."""
+    import subprocess
+    from cosnarks_amd import bindings as B
+    for args in (["gcc", "-std=c11", "-x", "c"], ["g++", "-std=c++17", "-x", "c++"]):
+        r = subprocess.run(args + ["-fsyntax-only", "-Wall", "-Werror", B.header_path()], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+
