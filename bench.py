@@ -261,9 +261,21 @@ def main():
 
     # ---- correctness of the timed result: closed form (sum s_i k_i) * G via a second, tiny MSM
     check = None
-    if rank == 0 and not args.no_check and world == 1 and args.log_n <= 20:
-        from tests.check_closed_form import closed_form_ok
-        check = bool(closed_form_ok(hip, L, seed, n, sc.cpu().numpy(), res))
+    if not args.no_check and args.log_n <= 20:
+        if world == 1:
+            from tests.check_closed_form import closed_form_ok
+            check = bool(closed_form_ok(hip, L, seed, n, sc.cpu().numpy(), res))
+        else:
+            # every rank contributes sum_i s_i k_i of its own range (32-byte integer), rank 0 checks the folded MSM
+            from tests.check_closed_form import closed_form_ok_split, local_dlog_sum
+            mine = local_dlog_sum(seed, n, sc.cpu().numpy())
+            buf = torch.tensor(list(mine.to_bytes(32, "little")), dtype=torch.uint8, device=dev if backend == "nccl" else "cpu")
+            allb = torch.empty(32 * world, dtype=torch.uint8, device=buf.device)
+            dist.all_gather_into_tensor(allb, buf)
+            if rank == 0:
+                raw = bytes(allb.cpu().tolist())
+                sums = [int.from_bytes(raw[32 * i:32 * i + 32], "little") for i in range(world)]
+                check = bool(closed_form_ok_split(sums, res))
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

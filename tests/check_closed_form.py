@@ -53,3 +53,19 @@ def closed_form_ok(hip, L, seed, n, scalar_limbs_i64, jac_out) -> bool:
     G = cv.BN254_G1
     want = closed_form_point("bn254", 0, seed, n, np.asarray(scalar_limbs_i64).view(np.uint64), True)
     return G.eq(H.jac_to_affine(G, jac_out), want)
+
+
+def local_dlog_sum(seed, n, scalar_limbs_i64) -> int:
+    """sum_i s_i k_i mod r of one rank's share of a split MSM (scalars in Montgomery form, the factor R is removed by
+    closed_form_ok_split)."""
+    F = H.FR["bn254"]
+    return weighted_sum(np.asarray(scalar_limbs_i64).view(np.uint64), dlogs(seed, n)) % F.p
+
+
+def closed_form_ok_split(partial_sums, jac_out) -> bool:
+    """Split MSM over several ranks: the folded result must equal (sum over ranks of their local sums) * G."""
+    G = cv.BN254_G1
+    F = H.FR["bn254"]
+    S = sum(partial_sums) % F.p * F.Rinv % F.p
+    return G.eq(H.jac_to_affine(G, jac_out), G.mul(G.gen, S))
+
