@@ -306,10 +306,10 @@ inline MsmParams msm_plan(size_t n, int scalar_bits, int mont) {
   p.c = choose_c(n, scalar_bits);
   p.W = windows_for(scalar_bits, p.c);
   p.NB = 1u << (p.c - 1);
-  // L = sorted entries per lane (power of two in [8, 1024]): as long as possible (fewer partial sums to merge) while
+  // L = sorted entries per lane (power of two in [16, 1024]): as long as possible (fewer partial sums to merge) while
   // the W windows together still launch >= 2^19 lanes, ~8 waves per SIMD of the 256 CUs (measured optimum: 2^18 -> 16,
   // 2^20 -> 32, 2^22 -> 128, 2^24 -> 256..512). Every lane of a wave performs the same number of mixed additions.
-  uint64_t L = 8;
+  uint64_t L = 16;
   while (L < 1024 && 2 * L * (uint64_t(1) << 19) <= (uint64_t)n * p.W) L <<= 1;
   const char* envL = getenv("CSH_MSM_L");
   if (envL && atoi(envL) > 0) L = (uint64_t)atoi(envL);
