@@ -153,6 +153,11 @@ class Bases:
     def _out(self):
         return np.zeros(3 * point_bytes(self.curve, self.group) // 2 // 8, dtype=np.uint64)
 
+    def precompute(self, c: int = 0):
+        """csh_bases_precompute: fixed-base window tables (merged-window MSMs on this handle)."""
+        _check(lib().csh_bases_precompute(self.h, int(c)))
+        return self
+
     def msm(self, scalars, offset: int = 0, n: int | None = None, montgomery: bool = True):
         """-> Jacobian (X, Y, Z) limbs (Z in {0, 1}). scalars: (n, 4) u64 host array."""
         sc = _u64(scalars)

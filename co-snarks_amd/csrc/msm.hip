@@ -126,8 +126,36 @@ int csh_bases_free(csh_bases_t bases) {
   if (!bases) return CSH_OK;
   Bases* B = reinterpret_cast<Bases*>(bases);
   if (B->points) (void)hipFree(B->points);
+  if (B->table) (void)hipFree(B->table);
   delete B;
   return CSH_OK;
+}
+
+// Fixed-base window tables for a set of bases that is reused across MSMs (a proving key query): see msm_impl.hpp. c = 0
+// picks the window width (16 from 2^17 points on, narrower below); handles of fewer than 1024 points stay as they are.
+int csh_bases_precompute(csh_bases_t bases, int c) {
+  CSH_REQUIRE(bases, "bases is NULL");
+  CSH_TRY(ensure_device());
+  Bases* B = reinterpret_cast<Bases*>(bases);
+  CSH_REQUIRE(c == 0 || (c >= 4 && c <= 16), "window width must be 0 (auto) or in [4, 16]");
+  if (B->table) {
+    (void)hipFree(B->table);
+    B->table = nullptr;
+  }
+  if (B->n < 1024) return CSH_OK;
+  if (c == 0) {
+    c = 16;
+    while (c > 10 && (size_t(1) << (c + 1)) > B->n) --c;  // ~2 points per bucket and window at least
+  }
+  {
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && cur != B->device) {
+      set_error("bases were uploaded on device %d but the calling thread is bound to device %d (csh_init)", B->device, cur);
+      return CSH_ERR_INVALID;
+    }
+  }
+  hipStream_t st = resolve_stream(nullptr);
+  CURVE_DISPATCH(B->curve, B->group, (precompute_table_t<Cfg>(B, c, st)));
 }
 
 static int msm_args(csh_bases_t bases, size_t offset, size_t n, const void* scalars, const void* out) {
@@ -209,7 +237,7 @@ int csh_msm_multi_dev(const csh_bases_t* bases, const size_t* offsets, size_t k,
   hipStream_t st = resolve_stream(stream);
   struct Ops {
     size_t (*bytes)(const MsmParams*);
-    int (*bucket)(const Bases*, size_t, const MsmParams*, const SortOut*, hipStream_t, Arena*, void*, hipEvent_t*);
+    int (*bucket)(const void*, const MsmParams*, const SortOut*, hipStream_t, Arena*, void*, hipEvent_t*);
     void (*fold)(const void*, int, int, void*);
     size_t xyzz_bytes;
   };
@@ -230,26 +258,60 @@ int csh_msm_multi_dev(const csh_bases_t* bases, const size_t* offsets, size_t k,
     return CSH_OK;
   }
   const int bits = B0->curve == CSH_BLS12_381 ? Bls381FrParams::BITS : (B0->curve == CSH_GRUMPKIN ? Bn254FqParams::BITS : Bn254FrParams::BITS);
-  const MsmParams p = msm_plan(n, bits, mont);
+  // merged-window mode needs every handle to carry tables of one window width (the digit codes are shared)
+  bool merged = true;
+  for (size_t i = 0; i < k; ++i) {
+    const Bases* B = reinterpret_cast<const Bases*>(bases[i]);
+    merged = merged && msm_use_table(B, n) && B->table_c == B0->table_c;
+  }
+  const MsmParams pdig = merged ? msm_plan_merged(n, bits, mont, B0->table_c, B0->n, 0).dig : msm_plan(n, bits, mont);
+  MsmParams p = merged ? msm_plan_merged(n, bits, mont, B0->table_c, B0->n, 0).srt : pdig;
   size_t bucket_max = 0, win_bytes = 0;
   for (auto& o : ops) {
     bucket_max = std::max(bucket_max, o.bytes(&p));
     win_bytes += Arena::padded(o.xyzz_bytes * MAX_WINDOWS);
   }
   Arena& ar = arena_for(st);
+  // merged mode: the remap (table stride, offset) differs per handle, so the scatter runs per handle on shared digit
+  // codes; otherwise one sort serves all
   CSH_TRY(ar.reserve(msm_sort_bytes(p) + bucket_max));
   Arena& wa = arena_for((hipStream_t)((uintptr_t)st ^ 0x2));
   CSH_TRY(wa.reserve(win_bytes));
+  auto sort_stage = [&](const MsmParams& ps, SortOut* so) -> int {
+    if (B0->curve == CSH_BLS12_381) return msm_sort_stage<Bls381Fr>(ps, pdig, scalars_dev, st, ar, so, nullptr);
+    if (B0->curve == CSH_GRUMPKIN) return msm_sort_stage<Bn254Fq>(ps, pdig, scalars_dev, st, ar, so, nullptr);
+    return msm_sort_stage<Bn254Fr>(ps, pdig, scalars_dev, st, ar, so, nullptr);
+  };
   SortOut so;
-  if (B0->curve == CSH_BLS12_381) CSH_TRY(msm_sort_stage<Bls381Fr>(p, scalars_dev, st, ar, &so, nullptr));
-  else if (B0->curve == CSH_GRUMPKIN) CSH_TRY(msm_sort_stage<Bn254Fq>(p, scalars_dev, st, ar, &so, nullptr));
-  else CSH_TRY(msm_sort_stage<Bn254Fr>(p, scalars_dev, st, ar, &so, nullptr));
-  const size_t mark = ar.off;
   std::vector<char*> win_dev(k);
-  for (size_t i = 0; i < k; ++i) {
-    ar.off = mark;  // the bucket-stage scratch is reused: the stages are stream-ordered
-    win_dev[i] = wa.take<char>(ops[i].xyzz_bytes * MAX_WINDOWS);
-    CSH_TRY(ops[i].bucket(reinterpret_cast<const Bases*>(bases[i]), offsets[i], &p, &so, st, &ar, win_dev[i], nullptr));
+  if (!merged) {
+    CSH_TRY(sort_stage(p, &so));
+    const size_t mark = ar.off;
+    for (size_t i = 0; i < k; ++i) {
+      ar.off = mark;  // the bucket-stage scratch is reused: the stages are stream-ordered
+      const Bases* B = reinterpret_cast<const Bases*>(bases[i]);
+      win_dev[i] = wa.take<char>(ops[i].xyzz_bytes * MAX_WINDOWS);
+      CSH_TRY(ops[i].bucket(static_cast<const char*>(B->points) + offsets[i] * B->point_bytes, &p, &so, st, &ar, win_dev[i], nullptr));
+    }
+  } else {
+    // handles that share (table stride, offset) share the sorted index list; a different pair needs its own scatter
+    size_t last_stride = (size_t)-1, last_off = (size_t)-1;
+    size_t mark = 0;
+    for (size_t i = 0; i < k; ++i) {
+      const Bases* B = reinterpret_cast<const Bases*>(bases[i]);
+      if (B->n != last_stride || offsets[i] != last_off) {
+        ar.off = 0;
+        p.remap_stride = (uint32_t)B->n;
+        p.remap_off = (uint32_t)offsets[i];
+        CSH_TRY(sort_stage(p, &so));
+        mark = ar.off;
+        last_stride = B->n;
+        last_off = offsets[i];
+      }
+      ar.off = mark;
+      win_dev[i] = wa.take<char>(ops[i].xyzz_bytes * MAX_WINDOWS);
+      CSH_TRY(ops[i].bucket(B->table, &p, &so, st, &ar, win_dev[i], nullptr));
+    }
   }
   std::vector<std::vector<char>> wins(k);
   for (size_t i = 0; i < k; ++i) {

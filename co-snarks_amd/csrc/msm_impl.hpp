@@ -30,6 +30,10 @@ struct Bases {
   size_t n;
   size_t point_bytes;
   void* points;  // packed Affine<Fq>[n] on the device
+  // fixed-base window tables (csh_bases_precompute): table[w * n + i] = 2^(table_c * w) * points[i], w < table_W, same
+  // encoding as `points`. With them all windows of an MSM fall into ONE set of buckets (merged-window mode).
+  void* table = nullptr;
+  int table_c = 0, table_W = 0;
 };
 
 // MsmParams, the digit-code constants and the sort stage live in msm_sort.hpp / msm_sort.hip
@@ -325,11 +329,62 @@ inline MsmParams msm_plan(size_t n, int scalar_bits, int mont) {
   if (ch < 1) ch = 1;
   p.CH = (uint32_t)ch;
   p.chunk_len = (uint32_t)((n + ch - 1) / ch);
+  p.remap_n = p.remap_stride = p.remap_off = 0;
   tl_msm_params[0] = (uint32_t)p.c;
   tl_msm_params[1] = (uint32_t)p.W;
   tl_msm_params[2] = p.L;
   tl_msm_params[3] = p.S;
   return p;
+}
+
+// Merged-window mode (bases with fixed-base tables): the digit kernel still produces W windows of n codes (`dig`), but
+// the sort and bucket stages see them as ONE window of n * W entries over the 2^(c-1) buckets, every entry pointing at
+// the precomputed multiple 2^(c*w) * P_i -- one bucket reduction instead of W, no Horner over windows afterwards.
+struct MergedPlan {
+  MsmParams dig;  // n points, W windows: digit kernel
+  MsmParams srt;  // n * W entries, 1 window: sort + bucket stages
+};
+inline MergedPlan msm_plan_merged(size_t n, int scalar_bits, int mont, int c, size_t table_stride, size_t offset) {
+  MergedPlan m;
+  MsmParams& d = m.dig;
+  d.n = (uint32_t)n;
+  d.c = c;
+  d.W = windows_for(scalar_bits, c);
+  d.NB = 1u << (c - 1);
+  d.L = d.tmax = d.S = d.CH = d.chunk_len = 0;
+  d.mont = mont;
+  d.remap_n = d.remap_stride = d.remap_off = 0;
+  MsmParams& p = m.srt;
+  const uint64_t n2 = (uint64_t)n * d.W;
+  p.n = (uint32_t)n2;
+  p.c = c;
+  p.W = 1;
+  p.NB = d.NB;
+  uint64_t L = 16;  // one window only: 2^18 lanes fill the chip, longer runs mean fewer partials per bucket to merge
+  while (L < 1024 && 2 * L * (uint64_t(1) << 18) <= n2) L <<= 1;
+  if (const char* envL = getenv("CSH_MSM_L")) {
+    if (atoi(envL) > 0) L = (uint64_t)atoi(envL);
+  }
+  p.L = (uint32_t)L;
+  const uint32_t max_lanes = (uint32_t)((n2 + L - 1) / L);
+  p.tmax = p.NB + max_lanes + 2;
+  p.S = 64;
+  while (p.S < 8192 && (uint64_t)p.S * 4 < p.NB) p.S <<= 1;
+  p.mont = mont;
+  uint64_t ch = 512;
+  const uint64_t by_size = n2 / (2ull * p.NB);
+  if (ch > by_size) ch = by_size;
+  if (ch < 1) ch = 1;
+  p.CH = (uint32_t)ch;
+  p.chunk_len = (uint32_t)((n2 + ch - 1) / ch);
+  p.remap_n = (uint32_t)n;
+  p.remap_stride = (uint32_t)table_stride;
+  p.remap_off = (uint32_t)offset;
+  tl_msm_params[0] = (uint32_t)c;
+  tl_msm_params[1] = (uint32_t)d.W;
+  tl_msm_params[2] = p.L;
+  tl_msm_params[3] = p.S;
+  return m;
 }
 
 struct SortOut {  // what the bucket stage consumes
@@ -350,7 +405,7 @@ inline size_t msm_sort_bytes(const MsmParams& p) {
 
 // digits + counting sort; takes its buffers from `ar` (already reserved). ev (nullable): records ev[1..3].
 template <class Fr>
-int msm_sort_stage(const MsmParams& p, const uint64_t* scalars_dev, hipStream_t st, Arena& ar, SortOut* out, hipEvent_t* ev) {
+int msm_sort_stage(const MsmParams& p, const MsmParams& pdig, const uint64_t* scalars_dev, hipStream_t st, Arena& ar, SortOut* out, hipEvent_t* ev) {
   const size_t len = (size_t)p.NB + 2, n = p.n;
   uint32_t* hist = ar.take<uint32_t>(len * p.W);
   uint32_t* start = ar.take<uint32_t>(len * p.W);
@@ -362,8 +417,8 @@ int msm_sort_stage(const MsmParams& p, const uint64_t* scalars_dev, hipStream_t 
   uint64_t* inter = two_level ? ar.take<uint64_t>(n * p.W) : nullptr;
   uint32_t* part_cnt = two_level ? ar.take<uint32_t>((size_t)(p.NB / 256) * p.CH * p.W) : nullptr;
   CSH_HIP(hipMemsetAsync(hist, 0, sizeof(uint32_t) * len * p.W, st));
-  const int g1 = grid_for(n, MSM_BLK, 256 * 8);
-  hipLaunchKernelGGL(k_msm_digits<Fr>, dim3(g1), dim3(MSM_BLK), 0, st, reinterpret_cast<const Fr*>(scalars_dev), p, dig);
+  const int g1 = grid_for(pdig.n, MSM_BLK, 256 * 8);
+  hipLaunchKernelGGL(k_msm_digits<Fr>, dim3(g1), dim3(MSM_BLK), 0, st, reinterpret_cast<const Fr*>(scalars_dev), pdig, dig);  // dig[w * n + i]
   SortBuffers sb{hist, start, nlanes, sorted, dig, blkcnt, inter, part_cnt};
   CSH_TRY(msm_sort_launch(p, sb, st, ev));
   *out = SortOut{start, nlanes, sorted};
@@ -388,8 +443,7 @@ size_t msm_bucket_bytes(const MsmParams* pp) {
 // accumulate -> merge -> reduce -> fold for one set of bases; win_out_dev: W x XYZZ<Fq> on the device. ev (nullable):
 // records ev[4] after the accumulation and ev[5] at the end.
 template <class Cfg>
-int msm_bucket_stage(const Bases* B, size_t offset, const MsmParams* pp, const SortOut* so, hipStream_t st, Arena* arp, void* win_out_dev,
-                     hipEvent_t* ev) {
+int msm_bucket_stage(const void* points, const MsmParams* pp, const SortOut* so, hipStream_t st, Arena* arp, void* win_out_dev, hipEvent_t* ev) {
   using Fq = typename Cfg::Fq;
   const MsmParams& p = *pp;
   Arena& ar = *arp;
@@ -401,7 +455,7 @@ int msm_bucket_stage(const Bases* B, size_t offset, const MsmParams* pp, const S
   LazyPt<Cfg>* dense = ar.take<LazyPt<Cfg>>((size_t)(p.NB + 1) * p.W);
   uint32_t* giant = ar.take<uint32_t>(2 * (size_t)max_giant + 2);  // [0] = count, list from [2]
   LazyPt<Cfg>* giant_tmp = ar.take<LazyPt<Cfg>>(256 * (size_t)giant_blocks);
-  const Affine<Fq>* bases = reinterpret_cast<const Affine<Fq>*>(B->points) + offset;
+  const Affine<Fq>* bases = reinterpret_cast<const Affine<Fq>*>(points);
   {
     static const int blk = [] {
       const char* e = getenv("CSH_ACC_BLK");
@@ -425,12 +479,32 @@ int msm_bucket_stage(const Bases* B, size_t offset, const MsmParams* pp, const S
   return CSH_OK;
 }
 
+// merged-window mode applies when the handle carries tables, the call covers a good part of them (a tiny MSM against a
+// 2^15-bucket table would pay the bucket reduction for nothing) and the entry ids fit 31 bits
+inline bool msm_use_table(const Bases* B, size_t n) {
+  if (!B->table || n == 0 || getenv("CSH_MSM_NO_TABLE")) return false;
+  if ((uint64_t)n * (uint64_t)B->table_W >= (uint64_t(1) << 31) || (uint64_t)B->n * (uint64_t)B->table_W >= (uint64_t(1) << 31)) return false;
+  return n * 8 >= B->n;
+}
+
 template <class Cfg>
 int msm_windows_dev(const Bases* B, size_t offset, size_t n, const uint64_t* scalars_dev, int mont, hipStream_t st,
                     XYZZ<typename Cfg::Fq>* win_out_dev /* W entries, device */, MsmParams* p_out) {
   using Fr = typename Cfg::Fr;
-  const MsmParams p = msm_plan(n, Fr::Params::BITS, mont);
-  *p_out = p;
+  using Fq = typename Cfg::Fq;
+  const bool merged = msm_use_table(B, n);
+  MsmParams p, pdig;
+  const void* points;
+  if (merged) {
+    const MergedPlan m = msm_plan_merged(n, Fr::Params::BITS, mont, B->table_c, B->n, offset);
+    p = m.srt;
+    pdig = m.dig;
+    points = B->table;
+  } else {
+    p = pdig = msm_plan(n, Fr::Params::BITS, mont);
+    points = reinterpret_cast<const Affine<Fq>*>(B->points) + offset;
+  }
+  *p_out = p;  // merged: W = 1 (the single window sum is the result)
   Arena& ar = arena_for(st);
   CSH_TRY(ar.reserve(msm_sort_bytes(p) + msm_bucket_bytes<Cfg>(&p)));
   const bool timing = getenv("CSH_MSM_TIMING") != nullptr;
@@ -440,14 +514,70 @@ int msm_windows_dev(const Bases* B, size_t offset, size_t n, const uint64_t* sca
     CSH_HIP(hipEventRecord(ev[0], st));
   }
   SortOut so;
-  CSH_TRY(msm_sort_stage<Fr>(p, scalars_dev, st, ar, &so, timing ? ev : nullptr));
-  CSH_TRY(msm_bucket_stage<Cfg>(B, offset, &p, &so, st, &ar, win_out_dev, timing ? ev : nullptr));
+  CSH_TRY(msm_sort_stage<Fr>(p, pdig, scalars_dev, st, ar, &so, timing ? ev : nullptr));
+  CSH_TRY(msm_bucket_stage<Cfg>(points, &p, &so, st, &ar, win_out_dev, timing ? ev : nullptr));
   if (timing) {
     CSH_HIP(hipEventSynchronize(ev[5]));
     for (int i = 0; i < 5; ++i) CSH_HIP(hipEventElapsedTime(&tl_msm_timing[i], ev[i], ev[i + 1]));
     CSH_HIP(hipEventElapsedTime(&tl_msm_timing[5], ev[0], ev[5]));
     for (auto& e : ev) (void)hipEventDestroy(e);
   }
+  return CSH_OK;
+}
+
+// Fixed-base window tables: table[w * n + i] = 2^(c w) P_i for w < W = windows_for(scalar bits, c). One lane per point:
+// back to the arkworks encoding, c doublings per window in XYZZ, one inversion per window to return to affine, re-encoded
+// for storage. One-off per set of bases (a proving key): ~8.4 k field multiplications per G1 point.
+template <class Cfg>
+__global__ __launch_bounds__(128) void k_bases_precompute(const Affine<typename Cfg::Fq>* __restrict__ pts, size_t n, int c, int W,
+                                                          Affine<typename Cfg::Fq>* __restrict__ table) {
+  using Fq = typename Cfg::Fq;
+  using L = typename Cfg::L;
+  const size_t i = blockIdx.x * (size_t)128 + threadIdx.x;
+  if (i >= n) return;
+  const Affine<Fq> stored = pts[i];
+  table[i] = stored;
+  if (stored.is_inf()) {
+    for (int w = 1; w < W; ++w) table[(size_t)w * n + i] = stored;
+    return;
+  }
+  Affine<Fq> q{L::unpack(stored.x).to_fp(), L::unpack(stored.y).to_fp()};
+  for (int w = 1; w < W; ++w) {
+    XYZZ<Fq> acc = XYZZ<Fq>::from_affine(q);
+    for (int k = 0; k < c; ++k) acc = xyzz_dbl(acc);
+    q = xyzz_to_affine(acc);
+    Affine<Fq> out = q;
+    if (!q.is_inf()) {
+      out.x = L::repack_for_storage(q.x);
+      out.y = L::repack_for_storage(q.y);
+    }
+    table[(size_t)w * n + i] = out;
+  }
+}
+
+template <class Cfg>
+int precompute_table_t(Bases* B, int c, hipStream_t st) {
+  using Fq = typename Cfg::Fq;
+  using Fr = typename Cfg::Fr;
+  const int W = windows_for(Fr::Params::BITS, c);
+  void* t = nullptr;
+  hipError_t e = hipMalloc(&t, sizeof(Affine<Fq>) * B->n * (size_t)W);
+  if (e != hipSuccess) {
+    set_error("hipMalloc(%zu bytes) for the fixed-base tables failed: %s", sizeof(Affine<Fq>) * B->n * (size_t)W, hipGetErrorString(e));
+    return CSH_ERR_OOM;
+  }
+  hipLaunchKernelGGL(k_bases_precompute<Cfg>, dim3((unsigned)((B->n + 127) / 128)), dim3(128), 0, st, reinterpret_cast<const Affine<Fq>*>(B->points),
+                     B->n, c, W, reinterpret_cast<Affine<Fq>*>(t));
+  e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) {
+    (void)hipFree(t);
+    set_error("fixed-base table kernel failed: %s", hipGetErrorString(e));
+    return CSH_ERR_HIP;
+  }
+  B->table = t;
+  B->table_c = c;
+  B->table_W = W;
   return CSH_OK;
 }
 
@@ -580,7 +710,8 @@ int repack_bases_t(Bases* B, hipStream_t st) {
   KW template int fold_partials_t<CFG>(const void*, size_t, void*);                                                             \
   KW template int repack_bases_t<CFG>(Bases*, hipStream_t);                                                                     \
   KW template size_t msm_bucket_bytes<CFG>(const MsmParams*);                                                                   \
-  KW template int msm_bucket_stage<CFG>(const Bases*, size_t, const MsmParams*, const SortOut*, hipStream_t, Arena*, void*, hipEvent_t*); \
+  KW template int msm_bucket_stage<CFG>(const void*, const MsmParams*, const SortOut*, hipStream_t, Arena*, void*, hipEvent_t*);          \
+  KW template int precompute_table_t<CFG>(Bases*, int, hipStream_t);                                                            \
   KW template void fold_windows_erased<CFG>(const void*, int, int, void*);
 
 }  // namespace csh

@@ -7,6 +7,14 @@ namespace csh {
 
 constexpr int SORT_BLK = 1024;
 
+// index written into the sorted list for flat position i of the digit array (identity unless merged-window mode)
+__device__ __forceinline__ uint32_t entry_id(const MsmParams& p, size_t i) {
+  if (p.remap_n == 0) return (uint32_t)i;
+  const uint32_t f = (uint32_t)i;
+  const uint32_t w = f / p.remap_n;
+  return w * p.remap_stride + p.remap_off + (f - w * p.remap_n);
+}
+
 // Wave-aggregated LDS counter increment: returns this lane's slot in counter[b] (old value + rank).
 // Lanes that share the wave leader's bucket are peeled off with one atomic per group (up to 4 rounds), so a
 // skewed digit distribution (top window, 0/1-heavy witnesses) does not serialise on one LDS address.
@@ -135,7 +143,7 @@ __global__ __launch_bounds__(SORT_BLK) void k_msm_scatter_lds(MsmParams p, const
     if (i < hi) code = d[i];
     const bool valid = code != DIG_ZERO;
     const uint32_t pos = lds_slot(lds_cur, code & 0x7fffu, valid);
-    if (valid) so[pos] = (uint32_t)i | ((code >> 15) << 31);
+    if (valid) so[pos] = entry_id(p, i) | ((code >> 15) << 31);
   }
 }
 
@@ -234,7 +242,7 @@ __global__ __launch_bounds__(SORT_BLK) void k_msm_scatter_l1(MsmParams p, const 
       if (code[k] != DIG_ZERO) {
         const uint32_t b0 = code[k] & 0x7fffu;
         const uint32_t slot = toff[b0 / PART_BUCKETS] + rank[k];
-        pay[slot] = (uint32_t)(t0 + (size_t)k * SORT_BLK + tid) | ((code[k] >> 15) << 31);
+        pay[slot] = entry_id(p, t0 + (size_t)k * SORT_BLK + tid) | ((code[k] >> 15) << 31);
         slo[slot] = (uint8_t)(b0 % PART_BUCKETS);
         sbin[slot] = (uint8_t)(b0 / PART_BUCKETS);
       }

@@ -16,6 +16,9 @@ struct MsmParams {
   int mont;
   uint32_t CH;         // point chunks per window in the LDS counting sort
   uint32_t chunk_len;  // points per chunk
+  // merged-window mode (fixed-base tables, msm_impl.hpp): the sort sees ONE window of n = n_points * W codes; flat index f
+  // = w * remap_n + i is stored as the table index w * remap_stride + remap_off + i. remap_n = 0: identity.
+  uint32_t remap_n, remap_stride, remap_off;
 };
 
 // Digit code (one u16 per point and window): bits 0..14 = bucket-1, bit 15 = negative; 0xFFFF = zero digit.

@@ -252,3 +252,71 @@ def test_msm_multi_shares_one_sort(gpu, curve):
     for h in handles:
         h.free()
 
+
+@pytest.mark.parametrize("curve,group", GROUPS)
+def test_msm_fixed_base_tables(gpu, curve, group):
+    """csh_bases_precompute: with window tables on the handle every MSM (full, prefix, offset, skewed scalars, canonical
+    scalars) returns the same group element as the oracle; several table widths."""
+    G = cv.CURVES[curve][group]
+    F = H.FR[curve]
+    cid = H.CURVE_IDS[curve]
+    r = H.rng(555 + group)
+    n = 1100                                                   # >= 1024: tables are built
+    pts = H.rand_points(G, n, r, with_inf=True)
+    sc = H.rand_elems(F, n, r)
+    sk = [1] * 300 + [F.p - 1] * 300 + [0] * 100 + H.rand_elems(F, n - 700, r)
+    want_full, want_sk = G.msm(pts, sc), G.msm(pts, sk)
+    want_off = G.msm(pts[37:37 + 900], sc[:900])
+    for c in (0, 8, 13, 16):
+        bases = gpu.Bases(cid, group, cv.pack_points(G, pts)).precompute(c)
+        assert G.eq(H.jac_to_affine(G, bases.msm(H.pack(F, sc))), want_full), c
+        assert G.eq(H.jac_to_affine(G, bases.msm(H.pack(F, sk))), want_sk), c
+        assert G.eq(H.jac_to_affine(G, bases.msm(H.pack(F, sc[:900]), offset=37, n=900)), want_off), c
+        assert G.eq(H.jac_to_affine(G, bases.msm(H.pack(F, sc, mont=False), montgomery=False)), want_full), c
+        # a tiny MSM on the same handle takes the ordinary path
+        assert G.eq(H.jac_to_affine(G, bases.msm(H.pack(F, sc[:20]), n=20)), G.msm(pts[:20], sc[:20])), c
+        bases.free()
+
+
+def test_msm_fixed_base_tables_closed_form_and_multi(gpu):
+    """2^20 known-dlog bases with tables: closed form; the shared-sort multi-MSM over handles with tables (mixed G1 / G2,
+    different offsets) equals the oracle."""
+    import ctypes as C
+    from tests.check_closed_form import closed_form_point
+    G = cv.BN254_G1
+    n = 1 << 20
+    seed = 0xFEED
+    buf = _gen_bases(gpu, "bn254", 0, seed, n)
+    h = C.c_void_p()
+    L = gpu.lib()
+    gpu.bindings._check(L.csh_bases_upload_dev(0, 0, buf.ptr, C.c_size_t(n), C.c_size_t(0), None, C.byref(h)))
+    buf.free()
+    gpu.bindings._check(L.csh_bases_precompute(h, 0))
+    rs = np.random.RandomState(7)
+    limbs = rs.randint(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    limbs[:, 3] >>= np.uint64(3)
+    out = np.zeros(12, dtype=np.uint64)
+    gpu.bindings._check(L.csh_msm(h, C.c_size_t(0), C.c_size_t(n), limbs.ctypes.data_as(C.c_void_p), 1, out.ctypes.data_as(C.c_void_p)))
+    L.csh_bases_free(h)
+    assert G.eq(H.jac_to_affine(G, out), closed_form_point("bn254", 0, seed, n, limbs, True))
+    # multi over tables
+    G1, G2 = cv.CURVES["bn254"]
+    F = H.FR["bn254"]
+    r = H.rng(31337)
+    m = 1500
+    sets = [(G1, 0, H.rand_points(G1, m + 3, r), 3), (G1, 0, H.rand_points(G1, m + 3, r), 3), (G2, 1, H.rand_points(G2, m + 3, r), 3),
+            (G1, 0, H.rand_points(G1, m, r), 0)]
+    handles = [gpu.Bases(0, g, cv.pack_points(Gx, pts)).precompute(0) for Gx, g, pts, _ in sets]
+    sc = H.rand_elems(F, m, r)
+    dsc = gpu.DeviceBuffer.from_host(H.pack(F, sc))
+    outs = [np.zeros(3 * gpu.point_bytes(0, g) // 16, dtype=np.uint64) for _, g, _, _ in sets]
+    hs = (C.c_void_p * 4)(*[x.h.value for x in handles])
+    offs = (C.c_size_t * 4)(*[o for *_, o in sets])
+    po = (C.c_void_p * 4)(*[o.ctypes.data for o in outs])
+    gpu.bindings._check(L.csh_msm_multi_dev(hs, offs, C.c_size_t(4), C.c_size_t(m), dsc.ptr, 1, po, None))
+    for (Gx, g, pts, off), o in zip(sets, outs):
+        assert Gx.eq(H.jac_to_affine(Gx, o), Gx.msm(pts[off:off + m], sc)), (g, off)
+    dsc.free()
+    for x in handles:
+        x.free()
+

@@ -37,6 +37,11 @@ for logn in sizes:
     B.sync()
     h = C.c_void_p()
     B._check(L.csh_bases_upload_dev(CURVE, GROUP, buf.ptr, C.c_size_t(n), C.c_size_t(0), None, C.byref(h)))
+    if os.environ.get("PROBE_TABLE"):
+        import time as _t
+        _t0 = _t.perf_counter()
+        B._check(L.csh_bases_precompute(h, int(os.environ["PROBE_TABLE"]) if os.environ["PROBE_TABLE"].isdigit() else 0))
+        print(json.dumps({"precompute_ms": round((_t.perf_counter() - _t0) * 1e3, 1), "logn": logn}), flush=True)
     buf.free()
     rs = np.random.RandomState(1)
     limbs = rs.randint(0, 1 << 63, size=(n, 4), dtype=np.uint64)
