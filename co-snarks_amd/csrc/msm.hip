@@ -274,7 +274,9 @@ int csh_msm_multi_dev(const csh_bases_t* bases, const size_t* offsets, size_t k,
   Arena& ar = arena_for(st);
   // merged mode: the remap (table stride, offset) differs per handle, so the scatter runs per handle on shared digit
   // codes; otherwise one sort serves all
-  CSH_TRY(ar.reserve(msm_sort_bytes(p) + bucket_max));
+  // two bucket-stage scratch regions: consecutive bucket stages alternate between the caller's stream and a second one, so
+  // the latency-bound bucket reduction of MSM i overlaps the throughput-bound accumulation of MSM i + 1
+  CSH_TRY(ar.reserve(msm_sort_bytes(p) + 2 * Arena::padded(bucket_max)));
   Arena& wa = arena_for((hipStream_t)((uintptr_t)st ^ 0x2));
   CSH_TRY(wa.reserve(win_bytes));
   auto sort_stage = [&](const MsmParams& ps, SortOut* so) -> int {
@@ -284,15 +286,40 @@ int csh_msm_multi_dev(const csh_bases_t* bases, const size_t* offsets, size_t k,
   };
   SortOut so;
   std::vector<char*> win_dev(k);
+  static thread_local hipStream_t aux = nullptr;
+  static thread_local int aux_device = -1;
+  std::vector<hipStream_t> stage_stream(k, st);
   if (!merged) {
+    static const bool overlap = [] {
+      const char* e = getenv("CSH_MSM_MULTI_OVERLAP");
+      return !(e && atoi(e) == 0);
+    }();
+    if (overlap && k > 1) {
+      if (aux_device != B0->device) {
+        if (aux) (void)hipStreamDestroy(aux);
+        aux = nullptr;
+        if (hipStreamCreateWithFlags(&aux, hipStreamNonBlocking) == hipSuccess) aux_device = B0->device;
+        else aux_device = -1;
+      }
+    }
+    const bool two = overlap && k > 1 && aux != nullptr;
     CSH_TRY(sort_stage(p, &so));
     const size_t mark = ar.off;
+    hipEvent_t sorted_ev = nullptr;
+    if (two) {
+      CSH_HIP(hipEventCreateWithFlags(&sorted_ev, hipEventDisableTiming));
+      CSH_HIP(hipEventRecord(sorted_ev, st));
+      CSH_HIP(hipStreamWaitEvent(aux, sorted_ev, 0));
+    }
     for (size_t i = 0; i < k; ++i) {
-      ar.off = mark;  // the bucket-stage scratch is reused: the stages are stream-ordered
+      const bool on_aux = two && (i & 1);
+      stage_stream[i] = on_aux ? aux : st;
+      ar.off = mark + (on_aux ? Arena::padded(bucket_max) : 0);  // per-stream scratch region: stages on one stream are ordered
       const Bases* B = reinterpret_cast<const Bases*>(bases[i]);
       win_dev[i] = wa.take<char>(ops[i].xyzz_bytes * MAX_WINDOWS);
-      CSH_TRY(ops[i].bucket(static_cast<const char*>(B->points) + offsets[i] * B->point_bytes, &p, &so, st, &ar, win_dev[i], nullptr));
+      CSH_TRY(ops[i].bucket(static_cast<const char*>(B->points) + offsets[i] * B->point_bytes, &p, &so, stage_stream[i], &ar, win_dev[i], nullptr));
     }
+    if (sorted_ev) (void)hipEventDestroy(sorted_ev);
   } else {
     // handles that share (table stride, offset) share the sorted index list; a different pair needs its own scatter
     size_t last_stride = (size_t)-1, last_off = (size_t)-1;
@@ -316,9 +343,10 @@ int csh_msm_multi_dev(const csh_bases_t* bases, const size_t* offsets, size_t k,
   std::vector<std::vector<char>> wins(k);
   for (size_t i = 0; i < k; ++i) {
     wins[i].resize(ops[i].xyzz_bytes * p.W);
-    CSH_HIP(hipMemcpyAsync(wins[i].data(), win_dev[i], wins[i].size(), hipMemcpyDeviceToHost, st));
+    CSH_HIP(hipMemcpyAsync(wins[i].data(), win_dev[i], wins[i].size(), hipMemcpyDeviceToHost, stage_stream[i]));
   }
   CSH_HIP(hipStreamSynchronize(st));
+  if (aux) CSH_HIP(hipStreamSynchronize(aux));
   for (size_t i = 0; i < k; ++i) ops[i].fold(wins[i].data(), p.W, p.c, outs_host[i]);
   return CSH_OK;
 }
