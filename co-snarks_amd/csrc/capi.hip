@@ -22,9 +22,11 @@ static std::mutex g_lane_mu;
 static std::map<int, std::vector<Lane*>> g_free_lanes;
 
 struct LaneHolder {
-  std::map<int, Lane*> by_device;
-  Lane* get(int device) {
-    auto it = by_device.find(device);
+  std::map<int, Lane*> by_device;  // key: device, or device + AUX_KEY for the thread's second (overlap) lane
+  static constexpr int AUX_KEY = 1 << 20;
+  Lane* get(int key) {
+    const int device = key >= AUX_KEY ? key - AUX_KEY : key;
+    auto it = by_device.find(key);
     if (it != by_device.end()) return it->second;
     Lane* l = nullptr;
     {
@@ -40,12 +42,12 @@ struct LaneHolder {
       l->device = device;
       if (hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking) != hipSuccess) l->stream = nullptr;  // fall back to the null stream
     }
-    by_device[device] = l;
+    by_device[key] = l;
     return l;
   }
   ~LaneHolder() {  // thread exit: hand the lanes back (work on them has been synchronised by the API contract)
     std::lock_guard<std::mutex> g(g_lane_mu);
-    for (auto& kv : by_device) g_free_lanes[kv.first].push_back(kv.second);
+    for (auto& kv : by_device) g_free_lanes[kv.first >= AUX_KEY ? kv.first - AUX_KEY : kv.first].push_back(kv.second);
   }
 };
 static thread_local LaneHolder tl_lanes;
@@ -86,6 +88,9 @@ int Arena::reserve(size_t bytes) {
 }
 
 Arena& arena_for(hipStream_t s) { return tl_lanes.get(tl_device)->arenas[s]; }
+
+// a second pooled stream for the calling thread (overlapping two stages of one call); nullptr if none could be created
+hipStream_t resolve_aux_stream() { return tl_lanes.get(tl_device + LaneHolder::AUX_KEY)->stream; }
 
 }  // namespace csh
 

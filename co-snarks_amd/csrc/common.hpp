@@ -57,6 +57,7 @@ struct Arena {
   static size_t padded(size_t bytes) { return (bytes + 255) & ~size_t(255); }
 };
 Arena& arena_for(hipStream_t s);
+hipStream_t resolve_aux_stream();  // second pooled stream of the calling thread (may be nullptr)
 
 // Host-pointer convenience path: stage inputs into a per-thread arena, run on the thread's stream, copy back.
 struct HostStage {

@@ -286,22 +286,14 @@ int csh_msm_multi_dev(const csh_bases_t* bases, const size_t* offsets, size_t k,
   };
   SortOut so;
   std::vector<char*> win_dev(k);
-  static thread_local hipStream_t aux = nullptr;
-  static thread_local int aux_device = -1;
+  hipStream_t aux = nullptr;
   std::vector<hipStream_t> stage_stream(k, st);
   if (!merged) {
     static const bool overlap = [] {
       const char* e = getenv("CSH_MSM_MULTI_OVERLAP");
       return !(e && atoi(e) == 0);
     }();
-    if (overlap && k > 1) {
-      if (aux_device != B0->device) {
-        if (aux) (void)hipStreamDestroy(aux);
-        aux = nullptr;
-        if (hipStreamCreateWithFlags(&aux, hipStreamNonBlocking) == hipSuccess) aux_device = B0->device;
-        else aux_device = -1;
-      }
-    }
+    if (overlap && k > 1) aux = resolve_aux_stream();  // pooled with the thread's lane: no stream creation per call
     const bool two = overlap && k > 1 && aux != nullptr;
     CSH_TRY(sort_stage(p, &so));
     const size_t mark = ar.off;
