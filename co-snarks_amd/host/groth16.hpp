@@ -312,7 +312,17 @@ struct CoGroth16 {
     // rayon_join5 (:227-294): five independent MSM groups. The four that consume aux_assignment (A, B/G1, B/G2, L) share
     // one digit decomposition + bucket sort on the device (csh_msm_multi_dev); h_query runs from a second host thread.
     Span* sp_msm = new Span("5 msm groups (compute A, B/G1, B/G2, msm l_query, msm h_query)");
-    std::thread t5([&] { h_acc = T::template msm_public_points_hs<Fq>(BasesView{pkey.h_query.dev, 0, pkey.h_query.size()}, h_dev); });
+    int cur_dev = 0;
+    (void)csh_current_device(&cur_dev);
+    std::string h_err;
+    std::thread t5([&] {
+      try {
+        check(csh_init(cur_dev), "csh_init");  // a new host thread is not bound to the parent's GPU
+        h_acc = T::template msm_public_points_hs<Fq>(BasesView{pkey.h_query.dev, 0, pkey.h_query.size()}, h_dev);
+      } catch (const std::exception& e) {
+        h_err = e.what();
+      }
+    });
     const size_t pub_len = inputs.size();
     const size_t n_aux = aux_dev.n;
     const bool same_len = pkey.a_query.size() == 1 + pub_len + n_aux && pkey.b_g1_query.size() == 1 + pub_len + n_aux &&
@@ -338,12 +348,16 @@ struct CoGroth16 {
       s_g2 = finish_coeff<Fq2>(id, T::template scalar_mul_public_point_hs<Fq2>(delta_g2, T::to_half_share(s)), pkey.b_g2_query, pkey.beta_g2, inputs, to_proj(jb2));
       l_acc = to_proj(jl);
       t5.join();
+      if (!h_err.empty()) throw Error(h_err);
     } else {
-      std::thread t1([&] { r_g1 = calculate_coeff<Fq>(id, T::template scalar_mul_public_point_hs<Fq>(delta_g1, T::to_half_share(r)), pkey.a_query, pkey.alpha_g1, inputs, aux_dev); });
-      std::thread t2([&] { s_g1 = calculate_coeff<Fq>(id, T::template scalar_mul_public_point_hs<Fq>(delta_g1, T::to_half_share(s)), pkey.b_g1_query, pkey.beta_g1, inputs, aux_dev); });
-      std::thread t3([&] { s_g2 = calculate_coeff<Fq2>(id, T::template scalar_mul_public_point_hs<Fq2>(delta_g2, T::to_half_share(s)), pkey.b_g2_query, pkey.beta_g2, inputs, aux_dev); });
-      std::thread t4([&] { l_acc = T::template msm_public_points_hs<Fq>(BasesView{pkey.l_query.dev, 0, pkey.l_query.size()}, aux_dev); });
+      // (fallback: separate MSMs from separate host threads, each bound to the parent's GPU)
+      auto bind = [cur_dev] { check(csh_init(cur_dev), "csh_init"); };
+      std::thread t1([&] { bind(); r_g1 = calculate_coeff<Fq>(id, T::template scalar_mul_public_point_hs<Fq>(delta_g1, T::to_half_share(r)), pkey.a_query, pkey.alpha_g1, inputs, aux_dev); });
+      std::thread t2([&] { bind(); s_g1 = calculate_coeff<Fq>(id, T::template scalar_mul_public_point_hs<Fq>(delta_g1, T::to_half_share(s)), pkey.b_g1_query, pkey.beta_g1, inputs, aux_dev); });
+      std::thread t3([&] { bind(); s_g2 = calculate_coeff<Fq2>(id, T::template scalar_mul_public_point_hs<Fq2>(delta_g2, T::to_half_share(s)), pkey.b_g2_query, pkey.beta_g2, inputs, aux_dev); });
+      std::thread t4([&] { bind(); l_acc = T::template msm_public_points_hs<Fq>(BasesView{pkey.l_query.dev, 0, pkey.l_query.size()}, aux_dev); });
       t1.join(); t2.join(); t3.join(); t4.join(); t5.join();
+      if (!h_err.empty()) throw Error(h_err);
     }
     delete sp_msm;
     Span sp_fin("finish - open two points and some adds");
