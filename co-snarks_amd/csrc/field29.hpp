@@ -379,6 +379,23 @@ struct FpS {
     return r;
   }
 
+  // 32 * x with carries propagated (limbs 0..NL-2 back in [0, 2^B), the top limb takes the growth). R' = 2^(NL*B) is
+  // 2^5 * 2^256 for the 9 x 29-bit scalar fields, so  mul(a, b.times32()) = a b 2^5 / R' = a b / 2^256  is the arkworks
+  // Montgomery product of two arkworks-encoded operands with no table or domain change (share-vector kernels).
+  CSH_HD FpS times32() const {
+    static_assert(NL * B - 32 * F32::N == 5, "R' / R must be 2^5");
+    FpS r;
+    int64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < NL - 1; ++i) {
+      const int64_t t = ((int64_t)l[i] << 5) + c;
+      r.l[i] = (int32_t)((uint32_t)t & LP::MASK);
+      c = t >> B;
+    }
+    r.l[NL - 1] = (int32_t)(((int64_t)l[NL - 1] << 5) + c);
+    return r;
+  }
+
   // Partial reduction of a sum: full signed carry propagation, then subtract k*p with k estimated from the top limb
   // (float reciprocal of T + 1, T = top limb of p; exact to +-1 for |k| <= 64). Result: value in (-p - eps, 2p + eps), limbs
   // 0..NL-2 in [0, 2^B), small signed top limb -- a valid product operand. ~45 simple instructions, no multiplication by
@@ -474,6 +491,16 @@ using Fq28s = FpS<Bls381Fq28Params, Bls381Fq>;
 using Fr29s = FpS<Bn254Fr29Params, Bn254Fr>;  // Grumpkin base field; BN254 NTT butterflies
 using Bls381Fr29s = FpS<Bls381Fr29Params, Bls381Fr>;
 using Bls377Fr29s = FpS<Bls377Fr29Params, Bls377Fr>;
+
+// scalar field -> its lazy representation (NTT butterflies, share-vector kernels)
+template <class F>
+struct LazyOf;
+template <>
+struct LazyOf<Bn254Fr> { using type = Fr29s; };
+template <>
+struct LazyOf<Bls381Fr> { using type = Bls381Fr29s; };
+template <>
+struct LazyOf<Bls377Fr> { using type = Bls377Fr29s; };
 
 // ---- Fp2 = Fp[i]/(i^2+1) over the signed lazy field: schoolbook products accumulated double-width with ONE
 // reduction per output component (2 NL^2 + NL^2 mads per component, cheaper than Karatsuba's three full

@@ -223,15 +223,6 @@ __global__ __launch_bounds__(256) void k_to_lazy_table(const F* __restrict__ in,
   for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = LZ::repack_for_storage(in[i]);
 }
 
-template <class F>
-struct LazyOf;
-template <>
-struct LazyOf<Bn254Fr> { using type = Fr29s; };
-template <>
-struct LazyOf<Bls381Fr> { using type = Bls381Fr29s; };
-template <>
-struct LazyOf<Bls377Fr> { using type = Bls377Fr29s; };
-
 __device__ __forceinline__ uint32_t bitrev_n(uint32_t i, int log_n) { return log_n == 0 ? 0 : (__brev(i) >> (32 - log_n)); }
 
 // in-place bit-reversal permutation of entries (ncomp elements each)

@@ -220,6 +220,29 @@ static int lazy_fr_chain_t(const uint64_t a[4], const uint64_t b[4], const uint6
   return CSH_OK;
 }
 
+// Host run of the share-vector kernels' lazy products (vec_ops.hip): op 0: a*b; op 1: a*(c+d) + b*c + m (Rep3 local
+// multiplication with la = a, lb = b, ra = c, rb = d, mask m). All arkworks-Montgomery in and out.
+template <class LZ, class F>
+static int lazy_vec_t(int op, const uint64_t* a, const uint64_t* b, const uint64_t* c, const uint64_t* d, const uint64_t* m, uint64_t* out) {
+  F fa, fb, fc, fd, fm;
+  memcpy(&fa, a, 32);
+  memcpy(&fb, b, 32);
+  memcpy(&fc, c, 32);
+  memcpy(&fd, d, 32);
+  memcpy(&fm, m, 32);
+  F r;
+  if (op == 0) {
+    r = LZ::mul(LZ::unpack(fa), LZ::unpack(fb).times32()).canonical_wide().pack();
+  } else {
+    const LZ xa = LZ::unpack(fa), xb = LZ::unpack(fb), ya = LZ::unpack(fc), yb = LZ::unpack(fd);
+    LZ t = LZ::reduce(LZ::mul_add_wide(xa, LZ::add(ya, yb).times32(), xb, ya.times32()));
+    t = LZ::add(t, LZ::unpack(fm));
+    r = t.canonical_wide().pack();
+  }
+  memcpy(out, &r, 32);
+  return CSH_OK;
+}
+
 extern "C" {
 
 int csh_selftest_lazy_chain_dev(int curve, int group, const void* affine_pts, size_t n, size_t len, size_t nthreads, size_t host_samples,
@@ -284,6 +307,14 @@ int csh_selftest_lazy_fr_chain(int field_of, const uint64_t a[4], const uint64_t
   if (field_of == CSH_BN254) return lazy_fr_chain_t<Fr29s, Bn254Fr>(a, b, w, k, negative, out);
   if (field_of == CSH_BLS12_381) return lazy_fr_chain_t<Bls381Fr29s, Bls381Fr>(a, b, w, k, negative, out);
   if (field_of == CSH_BLS12_377) return lazy_fr_chain_t<Bls377Fr29s, Bls377Fr>(a, b, w, k, negative, out);
+  return CSH_ERR_INVALID;
+}
+
+int csh_selftest_lazy_vec(int field_of, int op, const uint64_t* a, const uint64_t* b, const uint64_t* c, const uint64_t* d, const uint64_t* m,
+                          uint64_t* out) {
+  if (field_of == CSH_BN254) return lazy_vec_t<Fr29s, Bn254Fr>(op, a, b, c, d, m, out);
+  if (field_of == CSH_BLS12_381) return lazy_vec_t<Bls381Fr29s, Bls381Fr>(op, a, b, c, d, m, out);
+  if (field_of == CSH_BLS12_377) return lazy_vec_t<Bls377Fr29s, Bls377Fr>(op, a, b, c, d, m, out);
   return CSH_ERR_INVALID;
 }
 

@@ -1,8 +1,12 @@
 // Element-wise secret-shared field arithmetic (Rep3 / Shamir / plain) on gfx950.
 // HBM-bound streaming kernels: one 32-byte field element per lane per step, 2 x 16-byte accesses,
 // grid-stride over <= 4096 workgroups of 256 threads. See DESIGN.md section "share-vector kernels".
+// Products run in the signed lazy 9 x 29-bit field (field29.hpp): operands are re-sliced as they are, one of them is
+// scaled by 2^5 = R'/2^256 so the lazy Montgomery product is the arkworks one; 162 multiply-adds instead of a 32-bit CIOS
+// product with its carry chains, which keeps these kernels on the HBM side of the roofline.
 #include "common.hpp"
 #include "field.hpp"
+#include "field29.hpp"
 #include "chacha.hpp"
 #include <string.h>
 
@@ -13,7 +17,8 @@ constexpr int VB = 256;
 template <class F>
 __global__ __launch_bounds__(VB) void k_vec_mul(const F* __restrict__ a, const F* __restrict__ b, F* out, size_t n) {
   for (size_t i = blockIdx.x * (size_t)VB + threadIdx.x; i < n; i += (size_t)gridDim.x * VB) {
-    out[i] = F::mul(a[i], b[i]);
+    using LZ = typename LazyOf<F>::type;
+    out[i] = LZ::mul(LZ::unpack(a[i]), LZ::unpack(b[i]).times32()).canonical_wide().pack();
   }
 }
 
@@ -29,7 +34,8 @@ template <class F>
 __global__ __launch_bounds__(VB) void k_vec_mul_table(F* v, const F* __restrict__ table, size_t n_elems, uint32_t ncomp) {
   for (size_t e = blockIdx.x * (size_t)VB + threadIdx.x; e < n_elems; e += (size_t)gridDim.x * VB) {
     size_t i = ncomp == 1 ? e : e / ncomp;
-    v[e] = F::mul(v[e], table[i]);
+    using LZ = typename LazyOf<F>::type;
+    v[e] = LZ::mul(LZ::unpack(v[e]), LZ::unpack(table[i]).times32()).canonical_wide().pack();
   }
 }
 
@@ -41,16 +47,21 @@ __global__ __launch_bounds__(VB) void k_rep3_local_mul(const F* __restrict__ lhs
     F la = lhs[2 * i], lb = lhs[2 * i + 1];
     F ra = rhs[2 * i], rb = rhs[2 * i + 1];
     // a*a' + a*b' + b*a' = la*(ra+rb) + lb*ra  (2 multiplications instead of 3; same field element)
-    F r = F::add(F::mul(la, F::add(ra, rb)), F::mul(lb, ra));
-    if (mask) r = F::add(r, mask[i]);
-    out[i] = r;
+    //   both products accumulate double-width before ONE reduction
+    using LZ = typename LazyOf<F>::type;
+    const LZ xa = LZ::unpack(la), xb = LZ::unpack(lb), ya = LZ::unpack(ra), yb = LZ::unpack(rb);
+    LZ r = LZ::reduce(LZ::mul_add_wide(xa, LZ::add(ya, yb).times32(), xb, ya.times32()));
+    if (mask) r = LZ::add(r, LZ::unpack(mask[i]));
+    out[i] = r.canonical_wide().pack();
   }
 }
 
 template <class F>
 __global__ __launch_bounds__(VB) void k_rep3_to_shamir(const F* __restrict__ in, F x, F y, F* out, size_t n) {
   for (size_t i = blockIdx.x * (size_t)VB + threadIdx.x; i < n; i += (size_t)gridDim.x * VB) {
-    out[i] = F::add(F::mul(in[2 * i], x), F::mul(in[2 * i + 1], y));
+    using LZ = typename LazyOf<F>::type;
+    const LZ lx = LZ::unpack(x).times32(), ly = LZ::unpack(y).times32();
+    out[i] = LZ::reduce(LZ::mul_add_wide(LZ::unpack(in[2 * i]), lx, LZ::unpack(in[2 * i + 1]), ly)).canonical_wide().pack();
   }
 }
 

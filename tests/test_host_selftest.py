@@ -331,3 +331,23 @@ def test_lazy_ntt_butterfly_arithmetic(hip, curve):
                 want = (a - k * b * w) % F.p if neg else (a + k * b * w) % F.p
                 assert H.unpack(F, out) == [want], (a, b, w, k, neg)
 
+
+@pytest.mark.parametrize("curve", ["bn254", "bls12_381", "bls12_377"])
+def test_lazy_share_vector_products(hip, curve):
+    """The lazy-field products of the share-vector kernels (vec_ops.hip; operands re-sliced as they are, one scaled by
+    2^5 = R'/2^256) run on the host with limb-bound assertions: a*b and the Rep3 local multiplication, edge values included."""
+    F = H.FR[curve]
+    cid = H.CURVE_IDS[curve]
+    r = H.rng(4321)
+    vals = [0, 1, 2, F.p - 1, F.p - 2, (F.p - 1) // 2, (F.p + 1) // 2] + H.rand_elems(F, 10, r)
+    L = hip.lib()
+    pk = lambda v: H.pack(F, [v]).ctypes.data_as(C.c_void_p)
+    for i, a in enumerate(vals):
+        for j, b in enumerate(vals):
+            c, d, m = vals[(i + 2 * j + 1) % len(vals)], vals[(3 * i + j + 2) % len(vals)], vals[(i * j + 3) % len(vals)]
+            out = np.zeros(4, dtype=np.uint64)
+            assert L.csh_selftest_lazy_vec(cid, 0, pk(a), pk(b), pk(c), pk(d), pk(m), out.ctypes.data_as(C.c_void_p)) == 0
+            assert H.unpack(F, out) == [a * b % F.p]
+            assert L.csh_selftest_lazy_vec(cid, 1, pk(a), pk(b), pk(c), pk(d), pk(m), out.ctypes.data_as(C.c_void_p)) == 0
+            assert H.unpack(F, out) == [(a * (c + d) + b * c + m) % F.p]
+
