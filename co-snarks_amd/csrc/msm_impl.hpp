@@ -417,7 +417,7 @@ int msm_sort_stage(const MsmParams& p, const MsmParams& pdig, const uint64_t* sc
   uint64_t* inter = two_level ? ar.take<uint64_t>(n * p.W) : nullptr;
   uint32_t* part_cnt = two_level ? ar.take<uint32_t>((size_t)(p.NB / 256) * p.CH * p.W) : nullptr;
   CSH_HIP(hipMemsetAsync(hist, 0, sizeof(uint32_t) * len * p.W, st));
-  const int g1 = grid_for(pdig.n, MSM_BLK, 256 * 8);
+  const int g1 = grid_for(pdig.n, MSM_BLK, 65536);
   hipLaunchKernelGGL(k_msm_digits<Fr>, dim3(g1), dim3(MSM_BLK), 0, st, reinterpret_cast<const Fr*>(scalars_dev), pdig, dig);  // dig[w * n + i]
   SortBuffers sb{hist, start, nlanes, sorted, dig, blkcnt, inter, part_cnt};
   CSH_TRY(msm_sort_launch(p, sb, st, ev));
