@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 # The kernel gathers every 64-byte base once per window (W = 17 at 2^20): 1.14 GB is inherent to Pippenger; the rest is
 # the x2 FETCH_SIZE correction applied to 64-byte gathers (raw counter: 1.44 GB), the sorted-index reads and the
 # partial-sum writes (0.14 GB).
-PMC_TRAFFIC_BYTES = {20: 3030954499}
+PMC_TRAFFIC_BYTES = {20: 3026656721}
 MADS_PER_MADD = 1467   # 10 products (6 mul 81 + 2 sqr 45 + fused 2x81) + 9 Montgomery reductions x 81, 9-limb 29-bit field
 MAD_PEAK_T = 31.0      # measured v_mad_u64_u32 issue rate, T lane-ops/s
 
