@@ -63,6 +63,50 @@ def prove_shamir(curve: int, zkey: bytes, wtns: bytes, num_parties: int, thresho
     return json.loads(out.value.decode())
 
 
+def split_witness(curve: int, protocol: str, wtns: bytes, num_inputs: int, seed: int, compression: int = 0, threshold: int = 1,
+                  num_parties: int = 3):
+    """`co-circom split-witness`: the parties' `.shared` files (bincode) as a list of bytes. protocol "rep3" | "shamir";
+    num_inputs counts the public inputs and the constant 1. Host-only."""
+    proto = {"rep3": 0, "shamir": 1}[protocol]
+    n_files = 3 if proto == 0 else num_parties
+    cap = n_files * (2 * len(wtns) + 4096)
+    out = (C.c_uint8 * cap)()
+    sizes = (C.c_size_t * n_files)()
+    rc = glib().cog16_split_witness(curve, proto, wtns, C.c_size_t(len(wtns)), C.c_size_t(num_inputs), compression, threshold, num_parties,
+                                    C.c_uint64(seed), out, C.c_size_t(cap), sizes)
+    if rc < 0:
+        raise CoSnarksHipError(glib().cog16_last_error().decode())
+    raw, files, at = bytes(out), [], 0
+    for i in range(rc):
+        files.append(raw[at:at + sizes[i]])
+        at += sizes[i]
+    return files
+
+
+def share_file_roundtrip(curve: int, protocol: str, data: bytes):
+    """Parse a `.shared` file with the host mirror and serialize it again -> (bytes, variant, n_public, n_witness)."""
+    out = (C.c_uint8 * (len(data) + 64))()
+    variant, npub, nwit = C.c_uint32(0), C.c_size_t(0), C.c_size_t(0)
+    rc = glib().cog16_share_file_roundtrip(curve, {"rep3": 0, "shamir": 1}[protocol], data, C.c_size_t(len(data)), out, C.c_size_t(len(out)),
+                                           C.byref(variant), C.byref(npub), C.byref(nwit))
+    if rc < 0:
+        raise CoSnarksHipError(glib().cog16_last_error().decode())
+    return bytes(out)[:rc], variant.value, npub.value, nwit.value
+
+
+def prove_from_shares(curve: int, protocol: str, zkey: bytes, files, threshold: int = 1, seed: int = 1, r=None, s=None):
+    """`co-circom generate-proof` from the parties' `.shared` files with in-process parties -> proof dict."""
+    n = len(files)
+    arr = (C.c_char_p * n)(*files)
+    lens = (C.c_size_t * n)(*[len(f) for f in files])
+    out = C.create_string_buffer(8192)
+    rc = glib().cog16_prove_from_shares(curve, {"rep3": 0, "shamir": 1}[protocol], zkey, C.c_size_t(len(zkey)), arr, lens, n, threshold,
+                                        C.c_uint64(seed), _scalar(r), _scalar(s), out, C.c_size_t(len(out)))
+    if rc != 0:
+        raise CoSnarksHipError(glib().cog16_last_error().decode())
+    return json.loads(out.value.decode())
+
+
 def bench_synthetic(curve: int, log_domain: int, iters: int = 3, with_rep3: bool = False):
     """Plain Groth16 prove on a synthetic 2^log_domain circuit with a known-dlog key (closed-form check); optionally
     also three in-process Rep3 parties proving the same circuit (BASELINE config 4 at scale)."""

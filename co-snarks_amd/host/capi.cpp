@@ -10,6 +10,7 @@
 
 #include "groth16.hpp"
 #include "arkwire.hpp"
+#include "sharefile.hpp"
 #include "plonk_honk.hpp"
 #include "zkey.hpp"
 
@@ -70,9 +71,55 @@ int prove_plain_t(const uint8_t* zkey, size_t zlen, const uint8_t* wtns, size_t 
   return write_out(proof_to_json(pr), out, cap);
 }
 
+// share_field_elements (mpc-core/src/protocols/rep3.rs:281-292, 375-389) with a seeded RNG
+template <class Fr>
+struct SeededSharer {
+  std::mt19937_64 gen;
+  explicit SeededSharer(uint64_t seed) : gen(seed) {}
+  Fr rnd() {
+    uint8_t b[32];
+    for (int i = 0; i < 4; ++i) {
+      uint64_t v = gen();
+      memcpy(b + 8 * i, &v, 8);
+    }
+    return from_be_bytes_mod_order<Fr>(b);
+  }
+  void share(const Fr& val, Rep3PrimeFieldShare<Fr> out3[3]) {
+    Fr a = rnd(), b = rnd();
+    Fr c = Fr::sub(Fr::sub(val, a), b);
+    out3[0] = {a, c};
+    out3[1] = {b, a};
+    out3[2] = {c, b};
+  }
+};
+
+// CompressedRep3SharedWitness::share_rep3 (co-circom-types/src/lib.rs:279-333) for Compression::None / HalfShares
 template <class P>
-int prove_rep3_t(const uint8_t* zkey, size_t zlen, const uint8_t* wtns, size_t wlen, uint64_t seed, const uint64_t* r, const uint64_t* s,
-                 char* out, size_t cap, uint64_t* h_shares_out, size_t h_cap) {
+void split_witness_rep3(const std::vector<typename P::Fr>& w, size_t npub, int compression, uint64_t seed,
+                        sharefile::CompressedRep3SharedWitness<P> out[3]) {
+  using Fr = typename P::Fr;
+  if (npub > w.size()) throw Error("num_inputs exceeds the witness length");
+  if (compression != 0 && compression != 1) throw Error("compression must be 0 (none: replicated shares) or 1 (half shares: additive)");
+  SeededSharer<Fr> sh(seed);
+  for (int p = 0; p < 3; ++p) {
+    out[p].public_inputs.assign(w.begin(), w.begin() + npub);
+    out[p].kind = compression == 0 ? sharefile::REPLICATED : sharefile::ADDITIVE;
+  }
+  for (size_t i = npub; i < w.size(); ++i) {
+    Rep3PrimeFieldShare<Fr> t[3];
+    sh.share(w[i], t);
+    for (int p = 0; p < 3; ++p) {
+      if (compression == 0) out[p].replicated.push_back(t[p]);
+      else out[p].additive.push_back(t[p].a);
+    }
+  }
+}
+
+// Rep3CoGroth16::prove (groth16.rs:360-379) with three in-process parties. `shares[p]` is what party p read from its
+// `.shared` file (co-circom.rs:1014-1016); additive half shares are completed inside the party's thread.
+template <class P>
+int prove_rep3_core(const uint8_t* zkey, size_t zlen, sharefile::CompressedRep3SharedWitness<P> shares[3], uint64_t seed, const uint64_t* r,
+                    const uint64_t* s, char* out, size_t cap, uint64_t* h_shares_out, size_t h_cap) {
   using T = Rep3Groth16Driver<P>;
   using Fr = typename P::Fr;
   using Share = Rep3PrimeFieldShare<Fr>;
@@ -84,36 +131,16 @@ int prove_rep3_t(const uint8_t* zkey, size_t zlen, const uint8_t* wtns, size_t w
   ProvingKey<P> pk_shared;
   ConstraintMatrices<P> m_shared;
   parse_zkey<P>(zkey, zlen, pk_shared, m_shared, /*upload=*/!per_party_keys);
-  const ConstraintMatrices<P>& m = m_shared;
-  std::vector<Fr> w = parse_wtns<P>(wtns, wlen);
-  // share_field_elements (mpc-core/src/protocols/rep3.rs:281-292, 375-389) with a seeded RNG
-  std::mt19937_64 gen(seed);
-  auto rnd = [&] {
-    uint8_t b[32];
-    for (int i = 0; i < 4; ++i) {
-      uint64_t v = gen();
-      memcpy(b + 8 * i, &v, 8);
-    }
-    return from_be_bytes_mod_order<Fr>(b);
-  };
-  auto share = [&](const Fr& val, Share out3[3]) {
-    Fr a = rnd(), b = rnd();
-    Fr c = Fr::sub(Fr::sub(val, a), b);
-    out3[0] = {a, c};
-    out3[1] = {b, a};
-    out3[2] = {c, b};
-  };
-  SharedWitness<P, Share> sw[3];
-  const size_t npub = m.num_instance_variables;
-  for (int p = 0; p < 3; ++p) sw[p].public_inputs.assign(w.begin(), w.begin() + npub);
-  for (size_t i = npub; i < w.size(); ++i) {
-    Share t[3];
-    share(w[i], t);
-    for (int p = 0; p < 3; ++p) sw[p].witness.push_back(t[p]);
+  // checked up front for all parties: a party that bails out alone would leave the other two waiting on the network
+  for (int p = 0; p < 3; ++p) {
+    if (shares[p].public_inputs.size() != m_shared.num_instance_variables) throw Error("witness share: public input count does not match the proving key");
+    const size_t len = shares[p].kind == sharefile::REPLICATED ? shares[p].replicated.size() : shares[p].additive.size();
+    if (len != m_shared.num_witness_variables) throw Error("witness share: the amount of private witness variables does not match the proving key");
   }
+  SeededSharer<Fr> rs_sharer(seed ^ 0x9e3779b97f4a7c15ull);
   Share r3[3], s3[3];
-  if (r) share(fr_from_canonical<P>(r), r3);
-  if (s) share(fr_from_canonical<P>(s), s3);
+  if (r) rs_sharer.share(fr_from_canonical<P>(r), r3);
+  if (s) rs_sharer.share(fr_from_canonical<P>(s), s3);
   auto nets0 = LocalNetwork::new_parties(3), nets1 = LocalNetwork::new_parties(3);
   Proof<P> proofs[3];
   std::vector<Fr> hs[3];
@@ -136,7 +163,8 @@ int prove_rep3_t(const uint8_t* zkey, size_t zlen, const uint8_t* wtns, size_t w
         }
         Rep3State state0 = Rep3State::create(nets0[p], my_seed);  // groth16.rs:371
         Rep3State state1 = state0.fork(0);                         // :372
-        proofs[p] = CoGroth16<P, T>::template prove_inner<CircomReduction>(&nets0[p], &nets1[p], state0, state1, pk, m, sw[p],
+        SharedWitness<P, Share> sw = sharefile::uncompress<P>(std::move(shares[p]), nets0[p]);  // co-circom.rs:1016
+        proofs[p] = CoGroth16<P, T>::template prove_inner<CircomReduction>(&nets0[p], &nets1[p], state0, state1, pk, m, sw,
                                                                             r ? &r3[p] : nullptr, s ? &s3[p] : nullptr, &hs[p]);
       } catch (const std::exception& e) {
         errs[p] = e.what();
@@ -156,31 +184,30 @@ int prove_rep3_t(const uint8_t* zkey, size_t zlen, const uint8_t* wtns, size_t w
   return write_out(j0, out, cap);
 }
 
-// ShamirCoGroth16::prove (groth16.rs:439-463) and Rep3CoGroth16::prove_with_shamir_bridge (groth16.rs:394-417) with
-// n in-process parties. Preprocessing (ShamirPreprocessing::new, DN07 double sharings) is replaced by a dealer that
-// hands every party its (degree-t, degree-2t) share pairs; with r/s given, the first two pairs share exactly r and s.
 template <class P>
-int prove_shamir_t(const uint8_t* zkey, size_t zlen, const uint8_t* wtns, size_t wlen, int n, int t, uint64_t seed, const uint64_t* r,
-                   const uint64_t* s, int bridge, char* out, size_t cap) {
-  using T = ShamirGroth16Driver<P>;
-  using Fr = typename P::Fr;
-  if (n < 2 * t + 1 || t < 1) throw Error("num_parties must be at least 2 * threshold + 1");
-  if (bridge && (n != 3 || t != 1)) throw Error("the Rep3 -> Shamir bridge is the 3-party, threshold-1 case");
-  ProvingKey<P> pk;
-  ConstraintMatrices<P> m;
-  parse_zkey<P>(zkey, zlen, pk, m);
-  std::vector<Fr> w = parse_wtns<P>(wtns, wlen);
-  std::mt19937_64 gen(seed);
-  auto rnd = [&] {
+int prove_rep3_t(const uint8_t* zkey, size_t zlen, const uint8_t* wtns, size_t wlen, uint64_t seed, const uint64_t* r, const uint64_t* s,
+                 char* out, size_t cap, uint64_t* h_shares_out, size_t h_cap) {
+  std::vector<typename P::Fr> w = parse_wtns<P>(wtns, wlen);
+  sharefile::CompressedRep3SharedWitness<P> shares[3];
+  split_witness_rep3<P>(w, zkey_num_instance_variables<P>(zkey, zlen), 0, seed, shares);
+  return prove_rep3_core<P>(zkey, zlen, shares, seed, r, s, out, cap, h_shares_out, h_cap);
+}
+
+// shamir::share (shamir.rs:359-376): random degree-`deg` polynomial, shares = evaluations at 1..n
+template <class Fr>
+struct SeededShamirSharer {
+  std::mt19937_64 gen;
+  int n;
+  SeededShamirSharer(uint64_t seed, int parties) : gen(seed), n(parties) {}
+  Fr rnd() {
     uint8_t b[32];
     for (int i = 0; i < 4; ++i) {
       uint64_t v = gen();
       memcpy(b + 8 * i, &v, 8);
     }
     return from_be_bytes_mod_order<Fr>(b);
-  };
-  // shamir::share (shamir.rs:359-376): random degree-`deg` polynomial, shares = evaluations at 1..n
-  auto share = [&](const Fr& secret, int deg) {
+  }
+  std::vector<Fr> share(const Fr& secret, int deg) {
     std::vector<Fr> coeffs{secret};
     for (int i = 0; i < deg; ++i) coeffs.push_back(rnd());
     std::vector<Fr> out(n);
@@ -190,40 +217,51 @@ int prove_shamir_t(const uint8_t* zkey, size_t zlen, const uint8_t* wtns, size_t
       out[p] = e;
     }
     return out;
-  };
-  const size_t npub = m.num_instance_variables;
+  }
+};
+
+// SharedWitness::share_shamir (co-circom-types/src/lib.rs:362-381)
+template <class P>
+std::vector<SharedWitness<P, typename P::Fr>> split_witness_shamir(const std::vector<typename P::Fr>& w, size_t npub, int t, int n, uint64_t seed) {
+  using Fr = typename P::Fr;
+  if (npub > w.size()) throw Error("num_inputs exceeds the witness length");
+  if (n < 2 * t + 1 || t < 1) throw Error("num_parties must be at least 2 * threshold + 1");
+  SeededShamirSharer<Fr> sh(seed, n);
   std::vector<SharedWitness<P, Fr>> sw(n);
   for (int p = 0; p < n; ++p) sw[p].public_inputs.assign(w.begin(), w.begin() + npub);
-  if (!bridge) {
-    for (size_t i = npub; i < w.size(); ++i) {
-      auto sh = share(w[i], t);
-      for (int p = 0; p < n; ++p) sw[p].witness.push_back(sh[p]);
-    }
-  } else {
-    // Rep3 shares first (rep3.rs:281-292), then translate_primefield_repshare_vec on the device (bridges/rep3_to_shamir.rs:43-62)
-    std::vector<Rep3PrimeFieldShare<Fr>> rs[3];
-    for (size_t i = npub; i < w.size(); ++i) {
-      Fr a = rnd(), b = rnd(), c = Fr::sub(Fr::sub(w[i], a), b);
-      rs[0].push_back({a, c});
-      rs[1].push_back({b, a});
-      rs[2].push_back({c, b});
-    }
-    for (int p = 0; p < 3; ++p) {
-      const uint64_t e = p + 1, z1 = p == 0 ? 3 : p, z2 = p == 2 ? 1 : p + 2;  // get_translation_points (:14-28): f(X) = 1 - X/z
-      Fr x = Fr::sub(Fr::one(), Fr::mul(Fr::from_u64(e), Fr::inv(Fr::from_u64(z1))));
-      Fr y = Fr::sub(Fr::one(), Fr::mul(Fr::from_u64(e), Fr::inv(Fr::from_u64(z2))));
-      sw[p].witness.resize(rs[p].size());
-      check(csh_rep3_to_shamir_vec(P::ID, (const uint64_t*)rs[p].data(), (const uint64_t*)&x, (const uint64_t*)&y, (uint64_t*)sw[p].witness.data(),
-                                   rs[p].size()), "csh_rep3_to_shamir_vec");
-    }
+  for (size_t i = npub; i < w.size(); ++i) {
+    auto v = sh.share(w[i], t);
+    for (int p = 0; p < n; ++p) sw[p].witness.push_back(v[p]);
   }
+  return sw;
+}
+
+// ShamirCoGroth16::prove (groth16.rs:439-463) with n in-process parties, each holding the share it read from its
+// `.shared` file (co-circom.rs:1031-1035). Preprocessing (ShamirPreprocessing::new, DN07 double sharings) is replaced by a
+// dealer that hands every party its (degree-t, degree-2t) share pairs; with r/s given, the first two pairs share exactly
+// r and s.
+template <class P>
+int prove_shamir_core(const uint8_t* zkey, size_t zlen, std::vector<SharedWitness<P, typename P::Fr>>& sw, int t, uint64_t seed, const uint64_t* r,
+                      const uint64_t* s, char* out, size_t cap) {
+  using T = ShamirGroth16Driver<P>;
+  using Fr = typename P::Fr;
+  const int n = (int)sw.size();
+  if (n < 2 * t + 1 || t < 1) throw Error("num_parties must be at least 2 * threshold + 1");
+  ProvingKey<P> pk;
+  ConstraintMatrices<P> m;
+  parse_zkey<P>(zkey, zlen, pk, m);
+  for (auto& w : sw) {
+    if (w.public_inputs.size() != m.num_instance_variables) throw Error("witness share: public input count does not match the proving key");
+    if (w.witness.size() != m.num_witness_variables) throw Error("witness share: the amount of private witness variables does not match the proving key");
+  }
+  SeededShamirSharer<Fr> dealer(seed ^ 0x9e3779b97f4a7c15ull, n);
   // dealer: three double sharings per party (two rand calls + one scalar_mul: groth16.rs:448-449)
   std::vector<std::deque<std::pair<Fr, Fr>>> pairs(n);
   for (int k = 0; k < 3; ++k) {
-    Fr v = rnd();
+    Fr v = dealer.rnd();
     if (k == 0 && r) v = fr_from_canonical<P>(r);
     if (k == 1 && s) v = fr_from_canonical<P>(s);
-    auto st = share(v, t), s2t = share(v, 2 * t);
+    auto st = dealer.share(v, t), s2t = dealer.share(v, 2 * t);
     for (int p = 0; p < n; ++p) pairs[p].push_back({st[p], s2t[p]});
   }
   auto nets0 = LocalNetwork::new_parties(n), nets1 = LocalNetwork::new_parties(n);
@@ -251,6 +289,42 @@ int prove_shamir_t(const uint8_t* zkey, size_t zlen, const uint8_t* wtns, size_t
   for (int p = 1; p < n; ++p)
     if (j0 != proof_to_json(proofs[p])) throw Error("the parties disagree on the proof");
   return write_out(j0, out, cap);
+}
+
+// From a plain witness: ShamirCoGroth16::prove after share_shamir, or Rep3CoGroth16::prove_with_shamir_bridge
+// (groth16.rs:394-417) when `bridge` is set.
+template <class P>
+int prove_shamir_t(const uint8_t* zkey, size_t zlen, const uint8_t* wtns, size_t wlen, int n, int t, uint64_t seed, const uint64_t* r,
+                   const uint64_t* s, int bridge, char* out, size_t cap) {
+  using Fr = typename P::Fr;
+  if (n < 2 * t + 1 || t < 1) throw Error("num_parties must be at least 2 * threshold + 1");
+  if (bridge && (n != 3 || t != 1)) throw Error("the Rep3 -> Shamir bridge is the 3-party, threshold-1 case");
+  std::vector<Fr> w = parse_wtns<P>(wtns, wlen);
+  const size_t npub = zkey_num_instance_variables<P>(zkey, zlen);
+  if (!bridge) {
+    auto sw = split_witness_shamir<P>(w, npub, t, n, seed);
+    return prove_shamir_core<P>(zkey, zlen, sw, t, seed, r, s, out, cap);
+  }
+  if (npub > w.size()) throw Error("num_inputs exceeds the witness length");
+  // Rep3 shares first (rep3.rs:281-292), then translate_primefield_repshare_vec on the device (bridges/rep3_to_shamir.rs:43-62)
+  SeededSharer<Fr> sh(seed);
+  std::vector<SharedWitness<P, Fr>> sw(3);
+  std::vector<Rep3PrimeFieldShare<Fr>> rs[3];
+  for (size_t i = npub; i < w.size(); ++i) {
+    Rep3PrimeFieldShare<Fr> t3[3];
+    sh.share(w[i], t3);
+    for (int p = 0; p < 3; ++p) rs[p].push_back(t3[p]);
+  }
+  for (int p = 0; p < 3; ++p) {
+    sw[p].public_inputs.assign(w.begin(), w.begin() + npub);
+    const uint64_t e = p + 1, z1 = p == 0 ? 3 : p, z2 = p == 2 ? 1 : p + 2;  // get_translation_points (:14-28): f(X) = 1 - X/z
+    Fr x = Fr::sub(Fr::one(), Fr::mul(Fr::from_u64(e), Fr::inv(Fr::from_u64(z1))));
+    Fr y = Fr::sub(Fr::one(), Fr::mul(Fr::from_u64(e), Fr::inv(Fr::from_u64(z2))));
+    sw[p].witness.resize(rs[p].size());
+    check(csh_rep3_to_shamir_vec(P::ID, (const uint64_t*)rs[p].data(), (const uint64_t*)&x, (const uint64_t*)&y, (uint64_t*)sw[p].witness.data(),
+                                 rs[p].size()), "csh_rep3_to_shamir_vec");
+  }
+  return prove_shamir_core<P>(zkey, zlen, sw, t, seed, r, s, out, cap);
 }
 
 // ---- synthetic large circuit with a known-trapdoor-style key: every query point is
@@ -775,6 +849,108 @@ int cog16_witness_map(int curve, int reduction, int mode, const uint64_t* const 
     if (curve == 3) return witness_map_t<Bls12_377>(reduction, mode, row_ptr, col, coef, n_rows, n_instance, witness_full, n_vars, seed, h_out, h_cap_elems);
     g_err = "unknown curve";
     return -1;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+
+// `co-circom split-witness` (co-circom.rs:660-740): protocol 0 = Rep3 (three files; compression 0 none, 1 half shares),
+// 1 = Shamir (num_parties files of threshold `threshold`). The files are written back to back into `out`; sizes[i] is
+// the length of party i's file. num_inputs counts the public inputs and the constant 1 (r1cs.num_inputs). Host-only
+// (no device call). Returns the number of files or -1.
+int cog16_split_witness(int curve, int protocol, const uint8_t* wtns, size_t wlen, size_t num_inputs, int compression, int threshold,
+                        int num_parties, uint64_t seed, uint8_t* out, size_t cap, size_t* sizes) {
+  try {
+    std::vector<std::vector<uint8_t>> files;
+    auto run = [&](auto tag) {
+      using P = decltype(tag);
+      std::vector<typename P::Fr> w = parse_wtns<P>(wtns, wlen);
+      if (protocol == 0) {
+        sharefile::CompressedRep3SharedWitness<P> sh[3];
+        split_witness_rep3<P>(w, num_inputs, compression, seed, sh);
+        for (int p = 0; p < 3; ++p) files.push_back(sharefile::write_rep3<P>(sh[p]));
+      } else if (protocol == 1) {
+        for (auto& sw : split_witness_shamir<P>(w, num_inputs, threshold, num_parties, seed)) files.push_back(sharefile::write_shamir<P>(sw));
+      } else {
+        throw Error("protocol must be 0 (Rep3) or 1 (Shamir)");
+      }
+    };
+    if (curve == 0) run(Bn254{});
+    else if (curve == 1) run(Bls12_381{});
+    else throw Error("unknown curve");
+    size_t at = 0;
+    for (size_t i = 0; i < files.size(); ++i) {
+      if (at + files[i].size() > cap) throw Error("output buffer too small");
+      memcpy(out + at, files[i].data(), files[i].size());
+      sizes[i] = files[i].size();
+      at += files[i].size();
+    }
+    return (int)files.size();
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+
+// Parse one witness-share file and write it again (must reproduce the input byte for byte); reports the variant
+// (Rep3: 0 replicated, 2 additive; Shamir: 0) and the element counts. Host-only. Returns bytes written or -1.
+int cog16_share_file_roundtrip(int curve, int protocol, const uint8_t* file, size_t len, uint8_t* out, size_t cap, uint32_t* variant,
+                               size_t* n_public, size_t* n_witness) {
+  try {
+    std::vector<uint8_t> buf;
+    auto run = [&](auto tag) {
+      using P = decltype(tag);
+      if (protocol == 0) {
+        auto w = sharefile::read_rep3<P>(file, len);
+        *variant = w.kind;
+        *n_public = w.public_inputs.size();
+        *n_witness = w.kind == sharefile::REPLICATED ? w.replicated.size() : w.additive.size();
+        buf = sharefile::write_rep3<P>(w);
+      } else if (protocol == 1) {
+        auto w = sharefile::read_shamir<P>(file, len);
+        *variant = 0;
+        *n_public = w.public_inputs.size();
+        *n_witness = w.witness.size();
+        buf = sharefile::write_shamir<P>(w);
+      } else {
+        throw Error("protocol must be 0 (Rep3) or 1 (Shamir)");
+      }
+    };
+    if (curve == 0) run(Bn254{});
+    else if (curve == 1) run(Bls12_381{});
+    else throw Error("unknown curve");
+    if (buf.size() > cap) throw Error("output buffer too small");
+    memcpy(out, buf.data(), buf.size());
+    return (int)buf.size();
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+
+// `co-circom generate-proof` from the parties' `.shared` files (co-circom.rs:1008-1050) with in-process parties:
+// protocol 0 = Rep3 (exactly three files), 1 = Shamir (n files, threshold t).
+int cog16_prove_from_shares(int curve, int protocol, const uint8_t* zkey, size_t zlen, const uint8_t* const* files, const size_t* lens,
+                            int num_parties, int threshold, uint64_t seed, const uint64_t* r, const uint64_t* s, char* out_json, size_t cap) {
+  try {
+    auto run = [&](auto tag) -> int {
+      using P = decltype(tag);
+      if (protocol == 0) {
+        if (num_parties != 3 || threshold != 1) throw Error("REP3 only allows three parties and the threshold to be 1");
+        sharefile::CompressedRep3SharedWitness<P> sh[3];
+        for (int p = 0; p < 3; ++p) sh[p] = sharefile::read_rep3<P>(files[p], lens[p]);
+        if (sh[0].kind != sh[1].kind || sh[0].kind != sh[2].kind) throw Error("the parties' share files use different compression");
+        return prove_rep3_core<P>(zkey, zlen, sh, seed, r, s, out_json, cap, nullptr, 0);
+      }
+      if (protocol != 1) throw Error("protocol must be 0 (Rep3) or 1 (Shamir)");
+      std::vector<SharedWitness<P, typename P::Fr>> sw;
+      for (int p = 0; p < num_parties; ++p) sw.push_back(sharefile::read_shamir<P>(files[p], lens[p]));
+      return prove_shamir_core<P>(zkey, zlen, sw, threshold, seed, r, s, out_json, cap);
+    };
+    if (curve == 0) return run(Bn254{});
+    if (curve == 1) return run(Bls12_381{});
+    throw Error("unknown curve");
   } catch (const std::exception& e) {
     g_err = e.what();
     return -1;

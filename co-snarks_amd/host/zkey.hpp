@@ -36,6 +36,18 @@ struct Sections {
   }
 };
 
+// num_instance_variables (public inputs + the constant 1) from the zkey header alone
+template <class P>
+size_t zkey_num_instance_variables(const uint8_t* d, size_t n) {
+  Sections s(d, n, "zkey");
+  auto [h, hl] = s.at(2);
+  const size_t need = 4 + sizeof(typename P::Fq) + 4 + sizeof(typename P::Fr) + 12;
+  if (hl < need) throw Error("truncated zkey header");
+  uint32_t n_public;
+  memcpy(&n_public, d + h + need - 8, 4);
+  return (size_t)n_public + 1;
+}
+
 template <class P>
 void parse_zkey(const uint8_t* d, size_t n, ProvingKey<P>& pk, ConstraintMatrices<P>& m, bool upload = true) {
   using Fq = typename P::Fq;

@@ -97,3 +97,68 @@ def parse_g1(data: bytes, off: int, p: int, nbytes: int):
         raise ValueError("y-sign flag does not match y")
     return (x, y), off + 2 * nbytes
 
+
+
+# ---- bincode witness-share files (co-circom split-witness / generate-proof) ----------------------------------------
+# Restated from the published bincode 1.3 defaults (u64 little-endian lengths, u32 enum variant index) and the
+# reference's serde glue: `ark_se` (mpc-core/src/serde_compat.rs:7-15) emits ONE byte string per annotated field, holding
+# the ark-serialize encoding of the value. Types: CompressedRep3SharedWitness (co-circom-types/src/lib.rs:163-173),
+# Rep3ShareVecType (mpc-core/src/protocols/rep3.rs:135-150; Replicated = 0, SeededReplicated = 1, Additive = 2,
+# SeededAdditive = 3), SharedWitness (co-circom-types/src/lib.rs:204-218).
+REP3_REPLICATED, REP3_ADDITIVE = 0, 2
+
+
+def _bincode_bytes(b: bytes) -> bytes:
+    return struct.pack("<Q", len(b)) + b
+
+
+def _read_bincode_bytes(data: bytes, off: int):
+    (n,) = struct.unpack_from("<Q", data, off)
+    off += 8
+    if off + n > len(data):
+        raise ValueError("byte string exceeds the input")
+    return data[off : off + n], off + n
+
+
+def _parse_vec(blob: bytes, nbytes: int, items: int):
+    (cnt,) = struct.unpack_from("<Q", blob, 0)
+    if 8 + cnt * items * nbytes != len(blob):
+        raise ValueError("Vec length does not match its byte string")
+    flat = [int.from_bytes(blob[8 + i * nbytes : 8 + (i + 1) * nbytes], "little") for i in range(cnt * items)]
+    return flat if items == 1 else [tuple(flat[i * items : (i + 1) * items]) for i in range(cnt)]
+
+
+def ser_rep3_share_file(public_inputs, kind: int, shares, nbytes: int = 32) -> bytes:
+    """shares: [(a, b)] for REP3_REPLICATED (Rep3PrimeFieldShare serializes a then b), [a] for REP3_ADDITIVE."""
+    out = _bincode_bytes(ser_vec(public_inputs, nbytes)) + struct.pack("<I", kind)
+    if kind == REP3_REPLICATED:
+        body = struct.pack("<Q", len(shares)) + b"".join(ser_field(a, nbytes) + ser_field(b, nbytes) for a, b in shares)
+    elif kind == REP3_ADDITIVE:
+        body = ser_vec(shares, nbytes)
+    else:
+        raise ValueError("seeded variants are not restated")
+    return out + _bincode_bytes(body)
+
+
+def parse_rep3_share_file(data: bytes, nbytes: int = 32):
+    """-> (public_inputs, kind, shares)"""
+    pub, off = _read_bincode_bytes(data, 0)
+    (kind,) = struct.unpack_from("<I", data, off)
+    body, off = _read_bincode_bytes(data, off + 4)
+    if off != len(data):
+        raise ValueError("trailing bytes")
+    if kind not in (REP3_REPLICATED, REP3_ADDITIVE):
+        raise ValueError("unsupported Rep3ShareVecType variant %d" % kind)
+    return _parse_vec(pub, nbytes, 1), kind, _parse_vec(body, nbytes, 2 if kind == REP3_REPLICATED else 1)
+
+
+def ser_shamir_share_file(public_inputs, shares, nbytes: int = 32) -> bytes:
+    return _bincode_bytes(ser_vec(public_inputs, nbytes)) + _bincode_bytes(ser_vec(shares, nbytes))
+
+
+def parse_shamir_share_file(data: bytes, nbytes: int = 32):
+    pub, off = _read_bincode_bytes(data, 0)
+    body, off = _read_bincode_bytes(data, off)
+    if off != len(data):
+        raise ValueError("trailing bytes")
+    return _parse_vec(pub, nbytes, 1), _parse_vec(body, nbytes, 1)

@@ -92,6 +92,35 @@ def test_shamir_parties_agree_and_match_plain(gpu, curve, circ, n, t, bridge):
         g.prove_shamir(H.CURVE_IDS[curve], zk, wt, 2 * t, t, seed=1)
 
 
+@pytest.mark.parametrize("curve,circ,protocol,compression,n,t", [
+    ("bn254", "multiplier2", "rep3", 0, 3, 1), ("bn254", "poseidon", "rep3", 1, 3, 1), ("bls12_381", "poseidon", "rep3", 0, 3, 1),
+    ("bls12_381", "multiplier2", "rep3", 1, 3, 1), ("bn254", "poseidon", "shamir", 0, 3, 1), ("bls12_381", "multiplier2", "shamir", 0, 5, 2)])
+def test_prove_from_witness_share_files(gpu, curve, circ, protocol, compression, n, t):
+    """`co-circom split-witness` then `generate-proof` (co-circom.rs:660-740, 1008-1050): every party reads its bincode
+    `.shared` file (additive half shares are completed with one reshare_vec round) and the parties' proof is
+    the plain proof for the same r, s."""
+    from cosnarks_amd import groth16 as g
+    zk, wt, vk, pub = _load(curve, circ)
+    zko = oz.parse_zkey(zk)
+    cid = H.CURVE_IDS[curve]
+    files = g.split_witness(cid, protocol, wt, zko.n_public + 1, seed=21, compression=compression, threshold=t, num_parties=n)
+    proof = g.prove_from_shares(cid, protocol, zk, files, threshold=t, seed=5, r=R, s=S)
+    gold = json.load(open(os.path.join(GOLD, "groth16_golden.json")))[f"{curve}/{circ}"]
+    assert proof["pi_a"][:2] == gold["a"] and proof["pi_b"][:2] == gold["b"] and proof["pi_c"][:2] == gold["c"]
+    fresh = g.prove_from_shares(cid, protocol, zk, files, threshold=t, seed=6)
+    assert og.verify(curve, zko.G1, vk, _as_points(fresh), pub)
+    # files of another circuit / a wrong party count are refused before any device work
+    other = g.split_witness(cid, protocol, wt, zko.n_public + 2, seed=1, compression=compression, threshold=t, num_parties=n)
+    with pytest.raises(gpu.CoSnarksHipError, match="public input count"):
+        g.prove_from_shares(cid, protocol, zk, other, threshold=t)
+    if protocol == "rep3":
+        with pytest.raises(gpu.CoSnarksHipError, match="three parties"):
+            g.prove_from_shares(cid, protocol, zk, files[:2], threshold=t)
+        mixed = [files[0]] + g.split_witness(cid, "rep3", wt, zko.n_public + 1, seed=21, compression=1 - compression)[1:]
+        with pytest.raises(gpu.CoSnarksHipError, match="different compression"):
+            g.prove_from_shares(cid, protocol, zk, mixed)
+
+
 def test_prove_rejects_wrong_witness_length(gpu):
     from cosnarks_amd import groth16 as g
     zk, wt, _, _ = _load("bn254", "multiplier2")
