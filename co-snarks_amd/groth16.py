@@ -107,6 +107,23 @@ def prove_from_shares(curve: int, protocol: str, zkey: bytes, files, threshold: 
     return json.loads(out.value.decode())
 
 
+def translate_witness(curve: int, files):
+    """`co-circom translate-witness`: three Rep3 `.shared` files -> three Shamir (n = 3, t = 1) `.shared` files."""
+    arr = (C.c_char_p * 3)(*files)
+    lens = (C.c_size_t * 3)(*[len(f) for f in files])
+    cap = sum(len(f) for f in files) + 4096
+    out = (C.c_uint8 * cap)()
+    sizes = (C.c_size_t * 3)()
+    rc = glib().cog16_translate_witness(curve, arr, lens, out, C.c_size_t(cap), sizes)
+    if rc < 0:
+        raise CoSnarksHipError(glib().cog16_last_error().decode())
+    raw, res, at = bytes(out), [], 0
+    for i in range(3):
+        res.append(raw[at:at + sizes[i]])
+        at += sizes[i]
+    return res
+
+
 def bench_synthetic(curve: int, log_domain: int, iters: int = 3, with_rep3: bool = False):
     """Plain Groth16 prove on a synthetic 2^log_domain circuit with a known-dlog key (closed-form check); optionally
     also three in-process Rep3 parties proving the same circuit (BASELINE config 4 at scale)."""

@@ -957,6 +957,70 @@ int cog16_prove_from_shares(int curve, int protocol, const uint8_t* zkey, size_t
   }
 }
 
+// `co-circom translate-witness` (co-circom.rs:925-962, co_circom::translate_witness lib.rs:93-135): the three parties'
+// Rep3 `.shared` files -> their 3-party, threshold-1 Shamir `.shared` files. Replicated shares are translated locally
+// by translate_primefield_repshare_vec on the device (bridges/rep3_to_shamir.rs:43-62). Additive half shares are first
+// completed with one reshare_vec round and then translated the same way -- the reference instead runs a degree
+// reduction with fresh Shamir preprocessing (rep3_to_shamir.rs:79-95); both yield valid degree-1 sharings of the same
+// witness, the share values are random in either case. Files written back to back into `out`; returns 3 or -1.
+int cog16_translate_witness(int curve, const uint8_t* const* files, const size_t* lens, uint8_t* out, size_t cap, size_t* sizes) {
+  try {
+    std::vector<std::vector<uint8_t>> outs(3);
+    auto run = [&](auto tag) {
+      using P = decltype(tag);
+      using Fr = typename P::Fr;
+      sharefile::CompressedRep3SharedWitness<P> sh[3];
+      for (int p = 0; p < 3; ++p) sh[p] = sharefile::read_rep3<P>(files[p], lens[p]);
+      size_t len[3];
+      for (int p = 0; p < 3; ++p) len[p] = sh[p].kind == sharefile::REPLICATED ? sh[p].replicated.size() : sh[p].additive.size();
+      if (sh[0].kind != sh[1].kind || sh[0].kind != sh[2].kind) throw Error("the parties' share files use different compression");
+      if (len[0] != len[1] || len[0] != len[2]) throw Error("the parties' share files differ in length");
+      auto nets = LocalNetwork::new_parties(3);
+      std::string errs[3];
+      std::vector<std::thread> th;
+      int dev = 0;
+      check(csh_current_device(&dev), "csh_current_device");
+      for (int p = 0; p < 3; ++p) {
+        th.emplace_back([&, p] {
+          try {
+            check(csh_init(dev), "csh_init");
+            auto rep = sharefile::uncompress<P>(std::move(sh[p]), nets[p]);
+            SharedWitness<P, Fr> sw;
+            sw.public_inputs = rep.public_inputs;
+            sw.witness.resize(rep.witness.size());
+            const uint64_t e = p + 1, z1 = p == 0 ? 3 : p, z2 = p == 2 ? 1 : p + 2;  // get_translation_points (:14-28): f(X) = 1 - X/z
+            Fr x = Fr::sub(Fr::one(), Fr::mul(Fr::from_u64(e), Fr::inv(Fr::from_u64(z1))));
+            Fr y = Fr::sub(Fr::one(), Fr::mul(Fr::from_u64(e), Fr::inv(Fr::from_u64(z2))));
+            if (!rep.witness.empty())
+              check(csh_rep3_to_shamir_vec(P::ID, (const uint64_t*)rep.witness.data(), (const uint64_t*)&x, (const uint64_t*)&y,
+                                           (uint64_t*)sw.witness.data(), rep.witness.size()), "csh_rep3_to_shamir_vec");
+            outs[p] = sharefile::write_shamir<P>(sw);
+          } catch (const std::exception& ex) {
+            errs[p] = ex.what();
+          }
+        });
+      }
+      for (auto& t : th) t.join();
+      for (int p = 0; p < 3; ++p)
+        if (!errs[p].empty()) throw Error("party " + std::to_string(p) + ": " + errs[p]);
+    };
+    if (curve == 0) run(Bn254{});
+    else if (curve == 1) run(Bls12_381{});
+    else throw Error("unknown curve");
+    size_t at = 0;
+    for (int p = 0; p < 3; ++p) {
+      if (at + outs[p].size() > cap) throw Error("output buffer too small");
+      memcpy(out + at, outs[p].data(), outs[p].size());
+      sizes[p] = outs[p].size();
+      at += outs[p].size();
+    }
+    return 3;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+
 int cog16_prove_shamir(int curve, const uint8_t* zkey, size_t zlen, const uint8_t* wtns, size_t wlen, int num_parties, int threshold,
                        uint64_t seed, const uint64_t* r, const uint64_t* s, int bridge, char* out_json, size_t cap) {
   try {

@@ -121,6 +121,36 @@ def test_prove_from_witness_share_files(gpu, curve, circ, protocol, compression,
             g.prove_from_shares(cid, protocol, zk, mixed)
 
 
+@pytest.mark.parametrize("curve,circ,compression", [("bn254", "poseidon", 0), ("bn254", "multiplier2", 1), ("bls12_381", "multiplier2", 0)])
+def test_translate_witness_share_files(gpu, curve, circ, compression):
+    """`co-circom translate-witness` (lib.rs:93-135): Rep3 `.shared` files -> Shamir `.shared` files on the device
+    (translate_primefield_repshare_vec); the translated shares reconstruct the witness (any two parties, degree 1), match
+    the oracle's translation share for share, and the Shamir parties' proof from them is the plain proof."""
+    from cosnarks_amd import groth16 as g
+    from oracle import arkfmt, mpc
+    zk, wt, vk, pub = _load(curve, circ)
+    zko = oz.parse_zkey(zk)
+    F = zko.Fr
+    cid = H.CURVE_IDS[curve]
+    npub = zko.n_public + 1
+    w = oz.parse_wtns(wt)
+    rep = g.split_witness(cid, "rep3", wt, npub, seed=33, compression=compression)
+    sham = g.translate_witness(cid, rep)
+    parsed = [arkfmt.parse_shamir_share_file(f) for f in sham]
+    for p in range(3):
+        assert parsed[p][0] == w[:npub]
+    for ids in ([0, 1], [1, 2], [0, 2]):
+        lag = mpc.lagrange_from_coeff(F, [i + 1 for i in ids])
+        assert [mpc.shamir_reconstruct(F, [parsed[i][1][k] for i in ids], lag) for k in range(len(w) - npub)] == w[npub:]
+    if compression == 0:
+        for p in range(3):
+            _, _, shares = arkfmt.parse_rep3_share_file(rep[p])
+            assert parsed[p][1] == mpc.rep3_to_shamir_vec(F, shares, p)         # bridges/rep3_to_shamir.rs:43-62
+    proof = g.prove_from_shares(cid, "shamir", zk, sham, threshold=1, seed=5, r=R, s=S)
+    gold = json.load(open(os.path.join(GOLD, "groth16_golden.json")))[f"{curve}/{circ}"]
+    assert proof["pi_a"][:2] == gold["a"] and proof["pi_b"][:2] == gold["b"] and proof["pi_c"][:2] == gold["c"]
+
+
 def test_prove_rejects_wrong_witness_length(gpu):
     from cosnarks_amd import groth16 as g
     zk, wt, _, _ = _load("bn254", "multiplier2")
