@@ -12,7 +12,8 @@ namespace csh {
 constexpr int UB_BLK = 256;
 constexpr int UB_CHAINS = 8;
 
-// kind: 0 mad_u64_u32, 1 add_u64, 2 addc pair, 3 mul_lo_u32, 4 add_u32, 5 mul_hi_u32
+// kind: 0 v_mad_u64_u32, 1 v_lshl_add_u64, 2 v_add_co_u32 + v_addc_co_u32 (2 instructions), 3 v_mul_lo_u32, 4 v_add_u32,
+// 5 v_mul_hi_u32, 6 v_ashrrev_i64, 7 v_alignbit_b32 + v_ashrrev_i32 (2 instructions), 8 v_mad_i64_i32, 9 v_lshl_add_u64
 template <int KIND>
 __global__ __launch_bounds__(UB_BLK) void k_ub(uint32_t* out, int iters, uint32_t seed) {
   uint32_t a = threadIdx.x * 2654435761u + seed, b = blockIdx.x * 40503u + seed * 3u + 1u;
@@ -24,21 +25,38 @@ __global__ __launch_bounds__(UB_BLK) void k_ub(uint32_t* out, int iters, uint32_
     for (int u = 0; u < 4; ++u) {
 #pragma unroll
       for (int k = 0; k < UB_CHAINS; ++k) {
+        // every instruction is forced with inline asm: left to itself the compiler collapses unrolled chains of constant
+        // adds / multiplies / shifts into fewer instructions and the "rate" comes out several times too high
         if (KIND == 0) {
-          acc[k] = (uint64_t)(uint32_t)acc[k] * b + acc[k];
+          asm volatile("v_mad_u64_u32 %0, s[4:5], %1, %2, %0" : "+v"(acc[k]) : "v"((uint32_t)acc[(k + 1) % UB_CHAINS]), "s"(b) : "s4", "s5");
         } else if (KIND == 1) {
-          acc[k] = acc[k] + (acc[(k + 1) % UB_CHAINS] | 1);
-        } else if (KIND == 2) {
-          unsigned c1, c2;
-          uint32_t lo = __builtin_addc((uint32_t)acc[k], a, 0u, &c1);
-          uint32_t hi = __builtin_addc((uint32_t)(acc[k] >> 32), b, c1, &c2);
+          asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(acc[k]) : "v"(acc[(k + 1) % UB_CHAINS]));
+        } else if (KIND == 2) {  // 64-bit add as a carry pair (counted as 2 instructions)
+          uint32_t lo = (uint32_t)acc[k], hi = (uint32_t)(acc[k] >> 32);
+          asm volatile("v_add_co_u32 %0, vcc, %0, %2\n\tv_addc_co_u32 %1, vcc, %1, %3, vcc" : "+v"(lo), "+v"(hi) : "v"(a), "v"(b) : "vcc");
           acc[k] = ((uint64_t)hi << 32) | lo;
         } else if (KIND == 3) {
-          acc[k] = (uint32_t)acc[k] * (b | 1u);
+          uint32_t lo = (uint32_t)acc[k];
+          asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(lo) : "v"(b | 1u));
+          acc[k] = lo;
         } else if (KIND == 4) {
-          acc[k] = (uint32_t)acc[k] + b;
-        } else {
-          acc[k] = __umulhi((uint32_t)acc[k], b | 0x80000001u) + 3u;
+          uint32_t lo = (uint32_t)acc[k];
+          asm volatile("v_add_u32 %0, %0, %1" : "+v"(lo) : "v"(b));
+          acc[k] = lo;
+        } else if (KIND == 5) {
+          uint32_t lo = (uint32_t)acc[k];
+          asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(lo) : "v"(b | 0x80000001u));
+          acc[k] = lo;
+        } else if (KIND == 6) {  // v_ashrrev_i64 (forced: the compiler would merge a chain of constant shifts)
+          asm volatile("v_ashrrev_i64 %0, 3, %0" : "+v"(acc[k]));
+        } else if (KIND == 7) {  // the same shift from 32-bit halves: v_alignbit_b32 + v_ashrrev_i32
+          uint32_t lo = (uint32_t)acc[k], hi = (uint32_t)(acc[k] >> 32);
+          asm volatile("v_alignbit_b32 %0, %1, %0, 3\n\tv_ashrrev_i32 %1, 3, %1" : "+v"(lo), "+v"(hi));
+          acc[k] = ((uint64_t)hi << 32) | lo;
+        } else if (KIND == 8) {  // 64-bit += sign-extended 32-bit value through v_mad_i64_i32 (multiplier in an SGPR)
+          asm volatile("v_mad_i64_i32 %0, s[4:5], %1, %2, %0" : "+v"(acc[k]) : "v"((uint32_t)acc[(k + 1) % UB_CHAINS]), "s"(b) : "s4", "s5");
+        } else {  // 9: v_lshl_add_u64 (forced)
+          asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(acc[k]) : "v"(acc[(k + 1) % UB_CHAINS]));
         }
       }
     }
@@ -111,11 +129,15 @@ int csh_microbench(int kind, int iters, double* ops_per_s) {
       case 2: rc = time_kernel(k_ub<2>, dim3(blocks), dim3(UB_BLK), &ms, out, iters, 7u); break;
       case 3: rc = time_kernel(k_ub<3>, dim3(blocks), dim3(UB_BLK), &ms, out, iters, 7u); break;
       case 4: rc = time_kernel(k_ub<4>, dim3(blocks), dim3(UB_BLK), &ms, out, iters, 7u); break;
-      default: rc = time_kernel(k_ub<5>, dim3(blocks), dim3(UB_BLK), &ms, out, iters, 7u); break;
+      case 5: rc = time_kernel(k_ub<5>, dim3(blocks), dim3(UB_BLK), &ms, out, iters, 7u); break;
+      case 6: rc = time_kernel(k_ub<6>, dim3(blocks), dim3(UB_BLK), &ms, out, iters, 7u); break;
+      case 7: rc = time_kernel(k_ub<7>, dim3(blocks), dim3(UB_BLK), &ms, out, iters, 7u); break;
+      case 8: rc = time_kernel(k_ub<8>, dim3(blocks), dim3(UB_BLK), &ms, out, iters, 7u); break;
+      default: rc = time_kernel(k_ub<9>, dim3(blocks), dim3(UB_BLK), &ms, out, iters, 7u); break;
     }
     (void)hipFree(out);
     if (rc != CSH_OK) return rc;
-    double per_lane = (double)iters * 4 * UB_CHAINS * (kind == 2 ? 2 : 1);
+    double per_lane = (double)iters * 4 * UB_CHAINS * ((kind == 2 || kind == 7) ? 2 : 1);  // instructions per lane
     *ops_per_s = per_lane * threads / (ms * 1e-3);
     return CSH_OK;
   }
