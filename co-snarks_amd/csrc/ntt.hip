@@ -13,6 +13,7 @@
 // CSH_NTT_LAZY=0 for A/B measurements.
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 
 #include "common.hpp"
 #include "field.hpp"
@@ -156,7 +157,7 @@ struct LazyLds {
 };
 
 template <class F, class LZ, bool DIF>
-__global__ __launch_bounds__(NTT_MAX_THREADS) void k_ntt_pass_lazy(F* __restrict__ data, const F* __restrict__ twl, int L, int s0, int k, int cb,
+__global__ __launch_bounds__(NTT_MAX_THREADS) __attribute__((amdgpu_waves_per_eu(8))) void k_ntt_pass_lazy(F* __restrict__ data, const F* __restrict__ twl, int L, int s0, int k, int cb,
                                                                     int ncomp_log, F scale_lazy, int do_scale) {
   extern __shared__ uint4 lds_raw[];
   const int cc_log = cb + ncomp_log;
@@ -179,8 +180,12 @@ __global__ __launch_bounds__(NTT_MAX_THREADS) void k_ntt_pass_lazy(F* __restrict
   __syncthreads();
 
   const int half_E = E >> 1;
-  for (int qq = 0; qq < k; ++qq) {
-    const int q = DIF ? (k - 1 - qq) : qq;
+  // One butterfly stage over the tile. NORM: run the parallel carry step on the decimation-in-time outputs. x is a fresh
+  // product (limbs < 2^B) and u +- x of a normalised u is a two-term sum, still an admissible `a` operand of the next
+  // stage's product, so the carry step is only needed every second stage (and not after the last one: the tile leaves
+  // through mul / canonical_wide, which take two-term limbs).
+  auto stage = [&](int q, auto norm_tag) {
+    constexpr bool NORM = decltype(norm_tag)::value;
     const int half = 1 << q;
     const int tw_shift = L - 1 - (s0 + q);
     for (int bidx = tid; bidx < half_E; bidx += NT) {
@@ -199,11 +204,23 @@ __global__ __launch_bounds__(NTT_MAX_THREADS) void k_ntt_pass_lazy(F* __restrict
         lds.put(e1, LZ::mul(LZ::sub(u, v), w));  // the two-term difference is an admissible product operand as is
       } else {
         const LZ x = LZ::mul(v, w);
-        lds.put(e0, LZ::add(u, x).normalized());
-        lds.put(e1, LZ::sub(u, x).normalized());
+        if (NORM) {
+          lds.put(e0, LZ::add(u, x).normalized());
+          lds.put(e1, LZ::sub(u, x).normalized());
+        } else {
+          lds.put(e0, LZ::add(u, x));
+          lds.put(e1, LZ::sub(u, x));
+        }
       }
     }
     __syncthreads();
+  };
+  for (int qq = 0; qq < k; ++qq) {
+    const int q = DIF ? (k - 1 - qq) : qq;
+    if (DIF || (qq & 1))
+      stage(q, std::true_type{});
+    else
+      stage(q, std::false_type{});
   }
 
   const LZ sc = LZ::unpack(scale_lazy);

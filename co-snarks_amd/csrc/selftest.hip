@@ -199,9 +199,12 @@ static int lazy_fr_chain_t(const uint64_t a[4], const uint64_t b[4], const uint6
   LZ acc = LZ::unpack(fa);
   const LZ lb = LZ::unpack(fb);
   const LZ lw = LZ::unpack(LZ::repack_for_storage(fw));
-  for (int i = 0; i < k; ++i) {
+  for (int i = 0; i < k; ++i) {  // as the decimation-in-time stages do: the carry step only every second stage
     const LZ x = LZ::mul(lb, lw);
-    acc = negative ? LZ::sub(acc, x).normalized() : LZ::add(acc, x).normalized();
+    acc = negative ? LZ::sub(acc, x) : LZ::add(acc, x);
+    if (i & 1) acc = acc.normalized();
+    const LZ as_operand = LZ::mul(acc, lw);  // the other role of a stage output: `v` of the next product (limb-bound asserted)
+    (void)as_operand;
   }
   {  // sums feeding sums (decimation in frequency): doubling with fold_top must stay exact and in range
     LZ d = acc;
