@@ -111,7 +111,8 @@ def translate_witness(curve: int, files):
     """`co-circom translate-witness`: three Rep3 `.shared` files -> three Shamir (n = 3, t = 1) `.shared` files."""
     arr = (C.c_char_p * 3)(*files)
     lens = (C.c_size_t * 3)(*[len(f) for f in files])
-    cap = sum(len(f) for f in files) + 4096
+    _, _, n_pub, n_wit = share_file_roundtrip(curve, "rep3", files[0])   # seeded files are tiny, the Shamir files are not
+    cap = 3 * (64 + 32 * (n_pub + n_wit))
     out = (C.c_uint8 * cap)()
     sizes = (C.c_size_t * 3)()
     rc = glib().cog16_translate_witness(curve, arr, lens, out, C.c_size_t(cap), sizes)

@@ -93,17 +93,42 @@ struct SeededSharer {
   }
 };
 
-// CompressedRep3SharedWitness::share_rep3 (co-circom-types/src/lib.rs:279-333) for Compression::None / HalfShares
+// CompressedRep3SharedWitness::share_rep3 (co-circom-types/src/lib.rs:279-333). compression as the reference's enum
+// (lib.rs:150-161): 0 None (replicated), 1 HalfShares (additive), 2 SeededShares, 3 SeededHalfShares -- the seeded
+// levels keep one explicit share vector and two ChaCha12 seeds (rep3.rs:455-533).
 template <class P>
 void split_witness_rep3(const std::vector<typename P::Fr>& w, size_t npub, int compression, uint64_t seed,
                         sharefile::CompressedRep3SharedWitness<P> out[3]) {
   using Fr = typename P::Fr;
   if (npub > w.size()) throw Error("num_inputs exceeds the witness length");
-  if (compression != 0 && compression != 1) throw Error("compression must be 0 (none: replicated shares) or 1 (half shares: additive)");
+  if (compression < 0 || compression > 3) throw Error("compression must be 0 (none), 1 (half shares), 2 (seeded shares) or 3 (seeded half shares)");
   SeededSharer<Fr> sh(seed);
+  static const sharefile::Rep3Variant kinds[4] = {sharefile::REPLICATED, sharefile::ADDITIVE, sharefile::SEEDED_REPLICATED, sharefile::SEEDED_ADDITIVE};
   for (int p = 0; p < 3; ++p) {
     out[p].public_inputs.assign(w.begin(), w.begin() + npub);
-    out[p].kind = compression == 0 ? sharefile::REPLICATED : sharefile::ADDITIVE;
+    out[p].kind = kinds[compression];
+  }
+  if (compression >= 2) {
+    sharefile::SeededShare<Fr> a, b, c;
+    b.is_seed = c.is_seed = true;
+    b.len = c.len = w.size() - npub;
+    for (int i = 0; i < 4; ++i) {
+      uint64_t v = sh.gen(), u = sh.gen();
+      memcpy(b.seed + 8 * i, &v, 8);
+      memcpy(c.seed + 8 * i, &u, 8);
+    }
+    const std::vector<Fr> bv = b.expand(), cv = c.expand();
+    for (size_t i = npub; i < w.size(); ++i) a.shares.push_back(Fr::sub(Fr::sub(w[i], bv[i - npub]), cv[i - npub]));
+    if (compression == 3) {  // share_field_elements_additive_seeded: [a, b, c]
+      out[0].sa = a;
+      out[1].sa = b;
+      out[2].sa = c;
+    } else {  // share_field_elements_seeded: {a, c}, {b, a}, {c, b}
+      out[0].sa = a; out[0].sb = c;
+      out[1].sa = b; out[1].sb = a;
+      out[2].sa = c; out[2].sb = b;
+    }
+    return;
   }
   for (size_t i = npub; i < w.size(); ++i) {
     Rep3PrimeFieldShare<Fr> t[3];
@@ -134,8 +159,7 @@ int prove_rep3_core(const uint8_t* zkey, size_t zlen, sharefile::CompressedRep3S
   // checked up front for all parties: a party that bails out alone would leave the other two waiting on the network
   for (int p = 0; p < 3; ++p) {
     if (shares[p].public_inputs.size() != m_shared.num_instance_variables) throw Error("witness share: public input count does not match the proving key");
-    const size_t len = shares[p].kind == sharefile::REPLICATED ? shares[p].replicated.size() : shares[p].additive.size();
-    if (len != m_shared.num_witness_variables) throw Error("witness share: the amount of private witness variables does not match the proving key");
+    if (shares[p].length() != m_shared.num_witness_variables) throw Error("witness share: the amount of private witness variables does not match the proving key");
   }
   SeededSharer<Fr> rs_sharer(seed ^ 0x9e3779b97f4a7c15ull);
   Share r3[3], s3[3];
@@ -856,7 +880,7 @@ int cog16_witness_map(int curve, int reduction, int mode, const uint64_t* const 
 }
 
 // `co-circom split-witness` (co-circom.rs:660-740): protocol 0 = Rep3 (three files; compression 0 none, 1 half shares),
-// 1 = Shamir (num_parties files of threshold `threshold`). The files are written back to back into `out`; sizes[i] is
+// 2 seeded shares, 3 seeded half shares = what the reference's CLI writes), 1 = Shamir (num_parties files of threshold `threshold`). The files are written back to back into `out`; sizes[i] is
 // the length of party i's file. num_inputs counts the public inputs and the constant 1 (r1cs.num_inputs). Host-only
 // (no device call). Returns the number of files or -1.
 int cog16_split_witness(int curve, int protocol, const uint8_t* wtns, size_t wlen, size_t num_inputs, int compression, int threshold,
@@ -894,7 +918,7 @@ int cog16_split_witness(int curve, int protocol, const uint8_t* wtns, size_t wle
 }
 
 // Parse one witness-share file and write it again (must reproduce the input byte for byte); reports the variant
-// (Rep3: 0 replicated, 2 additive; Shamir: 0) and the element counts. Host-only. Returns bytes written or -1.
+// (Rep3: 0 replicated, 1 seeded replicated, 2 additive, 3 seeded additive; Shamir: 0) and the element counts. Host-only. Returns bytes written or -1.
 int cog16_share_file_roundtrip(int curve, int protocol, const uint8_t* file, size_t len, uint8_t* out, size_t cap, uint32_t* variant,
                                size_t* n_public, size_t* n_witness) {
   try {
@@ -905,7 +929,7 @@ int cog16_share_file_roundtrip(int curve, int protocol, const uint8_t* file, siz
         auto w = sharefile::read_rep3<P>(file, len);
         *variant = w.kind;
         *n_public = w.public_inputs.size();
-        *n_witness = w.kind == sharefile::REPLICATED ? w.replicated.size() : w.additive.size();
+        *n_witness = w.length();
         buf = sharefile::write_rep3<P>(w);
       } else if (protocol == 1) {
         auto w = sharefile::read_shamir<P>(file, len);
@@ -972,7 +996,7 @@ int cog16_translate_witness(int curve, const uint8_t* const* files, const size_t
       sharefile::CompressedRep3SharedWitness<P> sh[3];
       for (int p = 0; p < 3; ++p) sh[p] = sharefile::read_rep3<P>(files[p], lens[p]);
       size_t len[3];
-      for (int p = 0; p < 3; ++p) len[p] = sh[p].kind == sharefile::REPLICATED ? sh[p].replicated.size() : sh[p].additive.size();
+      for (int p = 0; p < 3; ++p) len[p] = sh[p].length();
       if (sh[0].kind != sh[1].kind || sh[0].kind != sh[2].kind) throw Error("the parties' share files use different compression");
       if (len[0] != len[1] || len[0] != len[2]) throw Error("the parties' share files differ in length");
       auto nets = LocalNetwork::new_parties(3);

@@ -105,7 +105,7 @@ def parse_g1(data: bytes, off: int, p: int, nbytes: int):
 # the ark-serialize encoding of the value. Types: CompressedRep3SharedWitness (co-circom-types/src/lib.rs:163-173),
 # Rep3ShareVecType (mpc-core/src/protocols/rep3.rs:135-150; Replicated = 0, SeededReplicated = 1, Additive = 2,
 # SeededAdditive = 3), SharedWitness (co-circom-types/src/lib.rs:204-218).
-REP3_REPLICATED, REP3_ADDITIVE = 0, 2
+REP3_REPLICATED, REP3_SEEDED_REPLICATED, REP3_ADDITIVE, REP3_SEEDED_ADDITIVE = 0, 1, 2, 3
 
 
 def _bincode_bytes(b: bytes) -> bytes:
@@ -128,28 +128,84 @@ def _parse_vec(blob: bytes, nbytes: int, items: int):
     return flat if items == 1 else [tuple(flat[i * items : (i + 1) * items]) for i in range(cnt)]
 
 
+def _ser_seeded(x, nbytes: int) -> bytes:
+    """SeededType (mpc-core/src/protocols/rep3.rs:152-165): ("shares", [a]) -> variant 0 + bytes(Vec<F>);
+    ("seed", seed32, len) -> variant 1 + 32 raw bytes ([u8; 32] is a serde tuple) + u64 (usize); PhantomData is empty."""
+    if x[0] == "shares":
+        return struct.pack("<I", 0) + _bincode_bytes(ser_vec(x[1], nbytes))
+    return struct.pack("<I", 1) + bytes(x[1]) + struct.pack("<Q", x[2])
+
+
+def _parse_seeded(data: bytes, off: int, nbytes: int):
+    (v,) = struct.unpack_from("<I", data, off)
+    off += 4
+    if v == 0:
+        blob, off = _read_bincode_bytes(data, off)
+        return ("shares", _parse_vec(blob, nbytes, 1)), off
+    if v != 1:
+        raise ValueError("unknown SeededType variant %d" % v)
+    seed = data[off : off + 32]
+    (n,) = struct.unpack_from("<Q", data, off + 32)
+    return ("seed", seed, n), off + 40
+
+
+def expand_seeded(x, p: int, nbits: int, mont_r: int):
+    """SeededType::expand_vec (rep3.rs:185-196): F::rand over ChaCha12Rng::from_seed(seed). ark-ff 0.6.0 (not vendored;
+    restated from the published source, fields/models/fp/mod.rs `Distribution<Fp> for Standard`): four next_u64 words =
+    32 keystream bytes as little-endian limbs, top limb masked to the modulus bit size, redrawn while >= p; the limbs are
+    the Montgomery representation, so the canonical value is limbs * R^-1. PARITY UNPINNED (no reference vector)."""
+    if x[0] == "shares":
+        return list(x[1])
+    from . import chacha
+    seed, n = x[1], x[2]
+    out, pos, rinv = [], 0, pow(mont_r, -1, p)
+    stream = chacha.keystream(seed, 32 * (n + 8) + 64)
+    mask = (1 << nbits) - 1
+    while len(out) < n:
+        if pos + 32 > len(stream):
+            stream += chacha.keystream(seed, 32 * 64, start_byte=len(stream))
+        v = int.from_bytes(stream[pos : pos + 32], "little") & mask
+        pos += 32
+        if v < p:
+            out.append(v * rinv % p)
+    return out
+
+
 def ser_rep3_share_file(public_inputs, kind: int, shares, nbytes: int = 32) -> bytes:
-    """shares: [(a, b)] for REP3_REPLICATED (Rep3PrimeFieldShare serializes a then b), [a] for REP3_ADDITIVE."""
+    """shares: [(a, b)] for REP3_REPLICATED (Rep3PrimeFieldShare serializes a then b), [a] for REP3_ADDITIVE, a SeededType
+    tuple for REP3_SEEDED_ADDITIVE, a pair of them (ReplicatedSeedType {a, b}, rep3.rs:225-238) for REP3_SEEDED_REPLICATED."""
     out = _bincode_bytes(ser_vec(public_inputs, nbytes)) + struct.pack("<I", kind)
     if kind == REP3_REPLICATED:
         body = struct.pack("<Q", len(shares)) + b"".join(ser_field(a, nbytes) + ser_field(b, nbytes) for a, b in shares)
-    elif kind == REP3_ADDITIVE:
-        body = ser_vec(shares, nbytes)
-    else:
-        raise ValueError("seeded variants are not restated")
-    return out + _bincode_bytes(body)
+        return out + _bincode_bytes(body)
+    if kind == REP3_ADDITIVE:
+        return out + _bincode_bytes(ser_vec(shares, nbytes))
+    if kind == REP3_SEEDED_ADDITIVE:
+        return out + _ser_seeded(shares, nbytes)
+    if kind == REP3_SEEDED_REPLICATED:
+        return out + _ser_seeded(shares[0], nbytes) + _ser_seeded(shares[1], nbytes)
+    raise ValueError("unknown Rep3ShareVecType variant")
 
 
 def parse_rep3_share_file(data: bytes, nbytes: int = 32):
-    """-> (public_inputs, kind, shares)"""
+    """-> (public_inputs, kind, shares) with shares as ser_rep3_share_file takes them"""
     pub, off = _read_bincode_bytes(data, 0)
     (kind,) = struct.unpack_from("<I", data, off)
-    body, off = _read_bincode_bytes(data, off + 4)
+    off += 4
+    if kind in (REP3_REPLICATED, REP3_ADDITIVE):
+        body, off = _read_bincode_bytes(data, off)
+        shares = _parse_vec(body, nbytes, 2 if kind == REP3_REPLICATED else 1)
+    elif kind == REP3_SEEDED_ADDITIVE:
+        shares, off = _parse_seeded(data, off, nbytes)
+    elif kind == REP3_SEEDED_REPLICATED:
+        a, off = _parse_seeded(data, off, nbytes)
+        b, off = _parse_seeded(data, off, nbytes)
+        shares = (a, b)
+    else:
+        raise ValueError("unsupported Rep3ShareVecType variant %d" % kind)
     if off != len(data):
         raise ValueError("trailing bytes")
-    if kind not in (REP3_REPLICATED, REP3_ADDITIVE):
-        raise ValueError("unsupported Rep3ShareVecType variant %d" % kind)
-    return _parse_vec(pub, nbytes, 1), kind, _parse_vec(body, nbytes, 2 if kind == REP3_REPLICATED else 1)
+    return _parse_vec(pub, nbytes, 1), kind, shares
 
 
 def ser_shamir_share_file(public_inputs, shares, nbytes: int = 32) -> bytes:

@@ -94,11 +94,13 @@ def test_shamir_parties_agree_and_match_plain(gpu, curve, circ, n, t, bridge):
 
 @pytest.mark.parametrize("curve,circ,protocol,compression,n,t", [
     ("bn254", "multiplier2", "rep3", 0, 3, 1), ("bn254", "poseidon", "rep3", 1, 3, 1), ("bls12_381", "poseidon", "rep3", 0, 3, 1),
-    ("bls12_381", "multiplier2", "rep3", 1, 3, 1), ("bn254", "poseidon", "shamir", 0, 3, 1), ("bls12_381", "multiplier2", "shamir", 0, 5, 2)])
+    ("bls12_381", "multiplier2", "rep3", 1, 3, 1), ("bn254", "poseidon", "rep3", 3, 3, 1), ("bls12_381", "poseidon", "rep3", 3, 3, 1),
+    ("bn254", "multiplier2", "rep3", 2, 3, 1), ("bn254", "poseidon", "shamir", 0, 3, 1), ("bls12_381", "multiplier2", "shamir", 0, 5, 2)])
 def test_prove_from_witness_share_files(gpu, curve, circ, protocol, compression, n, t):
     """`co-circom split-witness` then `generate-proof` (co-circom.rs:660-740, 1008-1050): every party reads its bincode
-    `.shared` file (additive half shares are completed with one reshare_vec round) and the parties' proof is
-    the plain proof for the same r, s."""
+    `.shared` file (compression 0 replicated, 1 additive half shares completed with one reshare_vec round,
+    2 / 3 their seeded forms -- 3 is what the reference's CLI writes) and the parties' proof is the plain proof for the
+    same r, s."""
     from cosnarks_amd import groth16 as g
     zk, wt, vk, pub = _load(curve, circ)
     zko = oz.parse_zkey(zk)
@@ -116,12 +118,13 @@ def test_prove_from_witness_share_files(gpu, curve, circ, protocol, compression,
     if protocol == "rep3":
         with pytest.raises(gpu.CoSnarksHipError, match="three parties"):
             g.prove_from_shares(cid, protocol, zk, files[:2], threshold=t)
-        mixed = [files[0]] + g.split_witness(cid, "rep3", wt, zko.n_public + 1, seed=21, compression=1 - compression)[1:]
+        mixed = [files[0]] + g.split_witness(cid, "rep3", wt, zko.n_public + 1, seed=21, compression=(compression + 1) % 4)[1:]
         with pytest.raises(gpu.CoSnarksHipError, match="different compression"):
             g.prove_from_shares(cid, protocol, zk, mixed)
 
 
-@pytest.mark.parametrize("curve,circ,compression", [("bn254", "poseidon", 0), ("bn254", "multiplier2", 1), ("bls12_381", "multiplier2", 0)])
+@pytest.mark.parametrize("curve,circ,compression", [("bn254", "poseidon", 0), ("bn254", "multiplier2", 1), ("bls12_381", "multiplier2", 0),
+                                                    ("bls12_381", "poseidon", 3), ("bn254", "multiplier2", 2)])
 def test_translate_witness_share_files(gpu, curve, circ, compression):
     """`co-circom translate-witness` (lib.rs:93-135): Rep3 `.shared` files -> Shamir `.shared` files on the device
     (translate_primefield_repshare_vec); the translated shares reconstruct the witness (any two parties, degree 1), match

@@ -24,31 +24,72 @@ def _load(curve, circ):
     return zk, wt, oz.parse_zkey(zk).n_public + 1, oz.parse_wtns(wt)
 
 
+def _expand(F, x):
+    return arkfmt.expand_seeded(x, F.p, F.p.bit_length(), 1 << 256)
+
+
 @pytest.mark.parametrize("curve,circ", CIRCUITS)
-@pytest.mark.parametrize("compression", [0, 1])
+@pytest.mark.parametrize("compression", [0, 1, 2, 3])
 def test_rep3_split_witness_files(curve, circ, compression):
+    """All four Compression levels of co-circom-types/src/lib.rs:150-161; 3 (SeededHalfShares) is what the reference's
+    `split-witness` command writes (co-circom.rs:693-697)."""
     _, wt, npub, w = _load(curve, circ)
     F = H.FR[curve]
     files = g.split_witness(H.CURVE_IDS[curve], "rep3", wt, npub, seed=7, compression=compression)
     assert len(files) == 3
     parsed = [arkfmt.parse_rep3_share_file(f) for f in files]
+    want_kind = [arkfmt.REP3_REPLICATED, arkfmt.REP3_ADDITIVE, arkfmt.REP3_SEEDED_REPLICATED, arkfmt.REP3_SEEDED_ADDITIVE][compression]
+    nw = len(w) - npub
     for f, (pub, kind, shares) in zip(files, parsed):
         assert pub == w[:npub]                                              # lib.rs:285, 320-322
-        assert kind == (arkfmt.REP3_REPLICATED if compression == 0 else arkfmt.REP3_ADDITIVE)
-        assert len(shares) == len(w) - npub
+        assert kind == want_kind
         assert arkfmt.ser_rep3_share_file(pub, kind, shares) == f           # the oracle's writer gives the same bytes
         back, variant, n_pub, n_wit = g.share_file_roundtrip(H.CURVE_IDS[curve], "rep3", f)
-        assert back == f and variant == kind and n_pub == npub and n_wit == len(w) - npub
+        assert back == f and variant == kind and n_pub == npub and n_wit == nw
     if compression == 0:
         a = [[s[0] for s in p[2]] for p in parsed]
         b = [[s[1] for s in p[2]] for p in parsed]
+    elif compression == 1:
+        a, b = [p[2] for p in parsed], None
+    elif compression == 2:                                                   # rep3.rs:455-497: {a, c}, {b, a}, {c, b}
+        assert [p[2][0][0] for p in parsed] == ["shares", "seed", "seed"] and [p[2][1][0] for p in parsed] == ["seed", "shares", "seed"]
+        a = [_expand(F, p[2][0]) for p in parsed]
+        b = [_expand(F, p[2][1]) for p in parsed]
+    else:                                                                    # rep3.rs:500-533: [Shares(a), Seed(b), Seed(c)]
+        assert [p[2][0] for p in parsed] == ["shares", "seed", "seed"]
+        assert len(files[1]) == len(files[2]) == 8 + 8 + 32 * npub + 4 + 4 + 32 + 8
+        a, b = [_expand(F, p[2]) for p in parsed], None
+    assert all(len(x) == nw for x in a)
+    if b is not None:
         for i in range(3):
             assert b[i] == a[(i + 2) % 3]                                   # replicated: my b is the previous party's a
-    else:
-        a = [p[2] for p in parsed]
     assert [(x + y + z) % F.p for x, y, z in zip(*a)] == w[npub:]           # rep3.rs:281-292
-    if len(w) - npub > 1:
+    if nw > 1:
         assert a[0] != w[npub:] and len(set(a[0])) > 1                      # actually masked
+
+
+def test_seed_expansion_is_the_restated_field_sampler():
+    """F::rand over ChaCha12Rng (ark-ff 0.6.0 `Distribution<Fp> for Standard`, restated): 32 keystream bytes per draw as
+    little-endian limbs, top bits masked, rejected while >= p, taken as the Montgomery representation. Checked here
+    independently of the oracle helper, straight from the ChaCha12 keystream (itself pinned on RFC 7539 in test_oracle)."""
+    from oracle import chacha
+    _, wt, npub, w = _load("bls12_381", "multiplier2")
+    F = H.FR["bls12_381"]
+    files = g.split_witness(1, "rep3", wt, npub, seed=99, compression=3)
+    _, _, (tag, seed, n) = arkfmt.parse_rep3_share_file(files[1])
+    assert tag == "seed" and n == len(w) - npub
+    ks = chacha.keystream(seed, 32 * 64)
+    draws, pos = [], 0
+    while len(draws) < n:
+        v = int.from_bytes(ks[pos:pos + 32], "little") & ((1 << 255) - 1)
+        pos += 32
+        if v < F.p:
+            draws.append(v * pow(1 << 256, -1, F.p) % F.p)
+    assert draws == _expand(F, ("seed", seed, n))
+    # the explicit party's share is witness - b - c with those draws
+    _, _, (_, a) = arkfmt.parse_rep3_share_file(files[0])
+    c = _expand(F, arkfmt.parse_rep3_share_file(files[2])[2])
+    assert [(x + y + z) % F.p for x, y, z in zip(a, draws, c)] == w[npub:]
 
 
 @pytest.mark.parametrize("curve,circ", CIRCUITS[:1] + CIRCUITS[3:])
@@ -84,11 +125,19 @@ def test_share_file_reader_rejects_malformed_input():
     ]:
         with pytest.raises(CoSnarksHipError):
             rt(bad)
-    # seeded variants (SeededReplicated = 1, SeededAdditive = 3) carry RNG seeds, not shares: refused with a clear message
+    # an unknown Rep3ShareVecType / SeededType variant index, or a seeded body cut short, is refused
     pub_len = 8 + struct.unpack_from("<Q", good, 0)[0]
-    for variant in (1, 3, 9):
-        with pytest.raises(CoSnarksHipError, match="variant"):
-            rt(good[:pub_len] + struct.pack("<I", variant) + good[pub_len + 4:])
+    with pytest.raises(CoSnarksHipError, match="variant"):
+        rt(good[:pub_len] + struct.pack("<I", 9) + good[pub_len + 4:])
+    seeded = g.split_witness(0, "rep3", wt, npub, seed=3, compression=3)[1]
+    assert rt(seeded)[0] == seeded
+    with pytest.raises(CoSnarksHipError, match="variant"):
+        rt(seeded[:pub_len + 4] + struct.pack("<I", 2) + seeded[pub_len + 8:])
+    for cut in (1, 8, 20, 41):
+        with pytest.raises(CoSnarksHipError):
+            rt(seeded[:-cut])
+    with pytest.raises(CoSnarksHipError, match="implausible"):
+        rt(seeded[:-8] + struct.pack("<Q", 1 << 40))
     # a non-canonical field element (>= r) is refused as ark-serialize does
     F = H.FR["bn254"]
     blob = bytearray(good)
@@ -98,7 +147,7 @@ def test_share_file_reader_rejects_malformed_input():
     with pytest.raises(CoSnarksHipError):
         g.split_witness(0, "rep3", wt, len(w) + 1, seed=1)
     with pytest.raises(CoSnarksHipError):
-        g.split_witness(0, "rep3", wt, npub, seed=1, compression=2)       # seeded compression levels are not produced
+        g.split_witness(0, "rep3", wt, npub, seed=1, compression=4)
     with pytest.raises(CoSnarksHipError):
         g.split_witness(0, "shamir", wt, npub, seed=1, threshold=2, num_parties=4)
 
