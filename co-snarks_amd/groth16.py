@@ -94,6 +94,15 @@ def share_file_roundtrip(curve: int, protocol: str, data: bytes):
     return bytes(out)[:rc], variant.value, npub.value, nwit.value
 
 
+def public_inputs_json(curve: int, protocol: str, share_file: bytes) -> str:
+    """The public-input JSON `generate-proof` writes (decimal strings, constant 1 skipped), from a `.shared` file."""
+    out = C.create_string_buffer(64 + 80 * 4096)
+    rc = glib().cog16_public_inputs_json(curve, {"rep3": 0, "shamir": 1}[protocol], share_file, C.c_size_t(len(share_file)), out, C.c_size_t(len(out)))
+    if rc != 0:
+        raise CoSnarksHipError(glib().cog16_last_error().decode())
+    return out.value.decode()
+
+
 def prove_from_shares(curve: int, protocol: str, zkey: bytes, files, threshold: int = 1, seed: int = 1, r=None, s=None):
     """`co-circom generate-proof` from the parties' `.shared` files with in-process parties -> proof dict."""
     n = len(files)

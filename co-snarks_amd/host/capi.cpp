@@ -953,6 +953,33 @@ int cog16_share_file_roundtrip(int curve, int protocol, const uint8_t* file, siz
   }
 }
 
+// The public-input file `generate-proof` writes next to the proof (co-circom.rs:1120-1140): the share file's public
+// inputs without the leading constant 1, as a compact JSON array of decimal strings. Host-only. Returns 0 or -1.
+int cog16_public_inputs_json(int curve, int protocol, const uint8_t* file, size_t len, char* out_json, size_t cap) {
+  try {
+    std::string j = "[";
+    auto run = [&](auto tag) {
+      using P = decltype(tag);
+      std::vector<typename P::Fr> pub;
+      if (protocol == 0) pub = sharefile::read_rep3<P>(file, len).public_inputs;
+      else if (protocol == 1) pub = sharefile::read_shamir<P>(file, len).public_inputs;
+      else throw Error("protocol must be 0 (Rep3) or 1 (Shamir)");
+      for (size_t i = 1; i < pub.size(); ++i) {
+        if (i > 1) j += ",";
+        j += "\"" + to_decimal(pub[i]) + "\"";
+      }
+    };
+    if (curve == 0) run(Bn254{});
+    else if (curve == 1) run(Bls12_381{});
+    else throw Error("unknown curve");
+    j += "]";
+    return write_out(j, out_json, cap);
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+
 // `co-circom generate-proof` from the parties' `.shared` files (co-circom.rs:1008-1050) with in-process parties:
 // protocol 0 = Rep3 (exactly three files), 1 = Shamir (n files, threshold t).
 int cog16_prove_from_shares(int curve, int protocol, const uint8_t* zkey, size_t zlen, const uint8_t* const* files, const size_t* lens,

@@ -160,3 +160,29 @@ def test_empty_private_witness_share_files():
     assert pub == w and shares == [] and kind == arkfmt.REP3_REPLICATED
     assert len(files[0]) == 8 + 8 + 32 * len(w) + 4 + 8 + 8
     assert g.share_file_roundtrip(0, "rep3", files[0])[0] == files[0]
+
+
+@pytest.mark.parametrize("curve,circ", CIRCUITS)
+def test_public_input_file_matches_the_reference_fixture(curve, circ):
+    """generate-proof writes the share file's public inputs (constant 1 skipped) as decimal strings (co-circom.rs:1120-1140):
+    equal to the reference's committed public.json for every circuit, from a Rep3 and from a Shamir share file."""
+    import json
+    _, wt, npub, w = _load(curve, circ)
+    want = json.load(open(os.path.join(GOLD, "Groth16", curve, circ, "public.json")))
+    cid = H.CURVE_IDS[curve]
+    rep = g.split_witness(cid, "rep3", wt, npub, seed=1, compression=3)
+    sham = g.split_witness(cid, "shamir", wt, npub, seed=1, threshold=1, num_parties=3)
+    for proto, f in (("rep3", rep[0]), ("rep3", rep[2]), ("shamir", sham[1])):
+        txt = g.public_inputs_json(cid, proto, f)
+        assert json.loads(txt) == want
+        assert " " not in txt and "\n" not in txt                      # serde_json::to_writer is compact
+
+
+def test_public_input_file_decimal_edge_values():
+    """Zero prints as "0" (co-circom.rs:1126-1130), limb-boundary values and r - 1 print exactly."""
+    import json
+    F = H.FR["bn254"]
+    vals = [1, 0, 5, 10**9, 10**9 - 1, 10**18 + 7, 2**64, 2**128 - 1, F.p - 1]
+    txt = g.public_inputs_json(0, "shamir", arkfmt.ser_shamir_share_file(vals, []))
+    assert json.loads(txt) == [str(v) for v in vals[1:]]
+    assert g.public_inputs_json(0, "rep3", arkfmt.ser_rep3_share_file([1], arkfmt.REP3_ADDITIVE, [])) == "[]"
