@@ -154,6 +154,21 @@ def test_translate_witness_share_files(gpu, curve, circ, compression):
     assert proof["pi_a"][:2] == gold["a"] and proof["pi_b"][:2] == gold["b"] and proof["pi_c"][:2] == gold["c"]
 
 
+@pytest.mark.parametrize("family,proto", [("rep3_replicated", "rep3"), ("rep3_seeded_replicated", "rep3"), ("rep3_additive", "rep3"),
+                                          ("rep3_seeded_additive", "rep3"), ("shamir_t1", "shamir")])
+def test_prove_from_committed_share_files(gpu, family, proto):
+    """The committed `.shared` fixtures (tests/golden/share_files, written by the oracle's restatement) prove to the golden
+    plain proof of the reference's multiplier2 circuit."""
+    from cosnarks_amd import groth16 as g
+    zk, wt, vk, pub = _load("bn254", "multiplier2")
+    d = os.path.join(GOLD, "share_files")
+    files = [open(os.path.join(d, f"{family}.{p}.shared"), "rb").read() for p in range(3)]
+    proof = g.prove_from_shares(0, proto, zk, files, threshold=1, seed=9, r=R, s=S)
+    gold = json.load(open(os.path.join(GOLD, "groth16_golden.json")))["bn254/multiplier2"]
+    assert proof["pi_a"][:2] == gold["a"] and proof["pi_b"][:2] == gold["b"] and proof["pi_c"][:2] == gold["c"]
+    assert json.loads(g.public_inputs_json(0, proto, files[1])) == json.load(open(os.path.join(GOLD, "Groth16", "bn254", "multiplier2", "public.json")))
+
+
 def test_prove_rejects_wrong_witness_length(gpu):
     from cosnarks_amd import groth16 as g
     zk, wt, _, _ = _load("bn254", "multiplier2")

@@ -186,3 +186,52 @@ def test_public_input_file_decimal_edge_values():
     txt = g.public_inputs_json(0, "shamir", arkfmt.ser_shamir_share_file(vals, []))
     assert json.loads(txt) == [str(v) for v in vals[1:]]
     assert g.public_inputs_json(0, "rep3", arkfmt.ser_rep3_share_file([1], arkfmt.REP3_ADDITIVE, [])) == "[]"
+
+
+SHARE_FIXTURES = os.path.join(GOLD, "share_files")
+
+
+@pytest.mark.parametrize("family,proto,kind", [("rep3_replicated", "rep3", 0), ("rep3_seeded_replicated", "rep3", 1), ("rep3_additive", "rep3", 2),
+                                               ("rep3_seeded_additive", "rep3", 3), ("shamir_t1", "shamir", 0)])
+def test_committed_share_file_fixtures(family, proto, kind):
+    """tests/golden/share_files (written by the oracle's restatement with fixed randomness,
+    tests/golden/make_golden_share_files.py -- regression fixtures, not reference output): the host mirror parses every
+    file, re-serializes it byte for byte, and the three parties' shares reconstruct the reference's committed witness."""
+    _, _, npub, w = _load("bn254", "multiplier2")
+    F = H.FR["bn254"]
+    files = [open(os.path.join(SHARE_FIXTURES, f"{family}.{p}.shared"), "rb").read() for p in range(3)]
+    for f in files:
+        back, variant, n_pub, n_wit = g.share_file_roundtrip(0, proto, f)
+        assert back == f and variant == kind and n_pub == npub and n_wit == len(w) - npub
+    if proto == "shamir":
+        parsed = [arkfmt.parse_shamir_share_file(f) for f in files]
+        lag = mpc.lagrange_from_coeff(F, [1, 3])
+        assert [mpc.shamir_reconstruct(F, [parsed[0][1][k], parsed[2][1][k]], lag) for k in range(len(w) - npub)] == w[npub:]
+        return
+    parsed = [arkfmt.parse_rep3_share_file(f) for f in files]
+    assert all(p[0] == w[:npub] and p[1] == kind for p in parsed)
+    if kind == 0:
+        a = [[s[0] for s in p[2]] for p in parsed]
+    elif kind == 1:
+        a = [_expand(F, p[2][0]) for p in parsed]
+    elif kind == 2:
+        a = [p[2] for p in parsed]
+    else:
+        a = [_expand(F, p[2]) for p in parsed]
+    assert [(x + y + z) % F.p for x, y, z in zip(*a)] == w[npub:]
+
+
+def test_share_file_fixtures_are_reproducible(tmp_path):
+    """The committed fixtures are exactly what the generating script writes today."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    before = {f: open(os.path.join(SHARE_FIXTURES, f), "rb").read() for f in sorted(os.listdir(SHARE_FIXTURES))}
+    assert len(before) == 15
+    src = open(os.path.join(GOLD, "make_golden_share_files.py")).read().replace('OUT = os.path.join(HERE, "share_files")', f'OUT = {str(tmp_path)!r}')
+    script = tmp_path / "gen.py"
+    script.write_text(src.replace("HERE = os.path.dirname(os.path.abspath(__file__))", f"HERE = {GOLD!r}").replace(
+        "sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))", f"sys.path.insert(0, {root!r})"))
+    subprocess.run([sys.executable, str(script)], check=True, capture_output=True)
+    for f, data in before.items():
+        assert open(tmp_path / f, "rb").read() == data, f
