@@ -99,3 +99,27 @@ def test_header_is_plain_c():
         r = subprocess.run(args + ["-fsyntax-only", "-Wall", "-Werror", B.header_path()], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
 
+
+
+def _build_c_example(tmp_path):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "msm_ntt_from_c")
+    libdir = os.path.join(root, "co-snarks_amd", "lib")
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(root, "include"),
+                    os.path.join(root, "examples", "msm_ntt_from_c.c"), "-L" + libdir, "-lcosnarks_hip", "-Wl,-rpath," + libdir, "-o", exe],
+                   check=True, capture_output=True)
+    return exe
+
+
+def test_plain_c_caller_links_and_fails_loudly_without_a_gpu(hip, tmp_path):
+    """examples/msm_ntt_from_c.c -- the boundary used from C11 with gcc, no C++ and no Python in between -- compiles
+    warning-free, links against the library, and on a box without a GPU exits with the library's no-device error."""
+    import subprocess
+    import torch
+    exe = _build_c_example(tmp_path)
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu-marked test")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3, (r.returncode, r.stderr)
+    assert "no CPU fallback" in r.stderr

@@ -320,3 +320,13 @@ def test_msm_fixed_base_tables_closed_form_and_multi(gpu):
     for x in handles:
         x.free()
 
+
+
+def test_plain_c_caller_of_the_boundary(gpu, tmp_path):
+    """examples/msm_ntt_from_c.c: MSM and NTT through the C ABI from a C11 program built with gcc."""
+    import subprocess
+    from tests.test_abi_cpu import _build_c_example
+    exe = _build_c_example(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert "ok: NTT round trip" in r.stdout
