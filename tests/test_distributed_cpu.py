@@ -1,4 +1,4 @@
-"""world_size-2 gloo test of the split-MSM exchange (the N > 1 path of bench.py): each rank builds the partial
+"""world_size-2/3/4 gloo tests of the split-MSM exchange (the N > 1 path of bench.py): each rank builds the partial
 buffer of its point range (here from the oracle, standing in for csh_msm_partial_dev), the partials are
 all-gathered and folded by the product's host fold; the result equals the full MSM."""
 import os
@@ -19,7 +19,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, n=24):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch
@@ -31,7 +31,7 @@ def _worker(rank, world, port, q):
     from tests import helpers as H
     G, F = cv.BN254_G1, H.FR["bn254"]
     r = H.rng(5)                                    # same seed on every rank: identical global inputs
-    n, c = 24, 7
+    c = 7
     pts = H.rand_points(G, n, r, with_inf=True)
     sc = H.rand_elems(F, n, r)
     lo, hi = rank * n // world, (rank + 1) * n // world
@@ -59,13 +59,15 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2])
-def test_split_msm_allgather_fold_gloo(world):
+@pytest.mark.parametrize("world,n", [(2, 24), (3, 25), (4, 3)])
+def test_split_msm_allgather_fold_gloo(world, n):
+    """(2, 24): even halves; (3, 25): uneven contiguous ranges 8/8/9; (4, 3): more ranks than points -- one rank holds an
+    empty range and contributes the all-infinity partial."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, n)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in range(world)]
