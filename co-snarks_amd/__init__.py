@@ -12,6 +12,7 @@ every compute call raises ``CoSnarksHipError`` if the library is missing or no H
 The directory name contains a hyphen; import it as ``import cosnarks_amd`` (alias module at the repo root)
 or ``importlib.import_module("co-snarks_amd")``.
 """
+from . import bindings  # noqa: F401
 from .bindings import (  # noqa: F401
     BLS12_381,
     BN254,
@@ -20,6 +21,7 @@ from .bindings import (  # noqa: F401
     G2,
     Bases,
     CoSnarksHipError,
+    Comm,
     DeviceBuffer,
     Domain,
     device_count,
@@ -31,9 +33,13 @@ from .bindings import (  # noqa: F401
     lincomb,
     msm_fold_partials,
     msm_partial_bytes,
+    msm_split,
     point_bytes,
     rep3_local_mul_vec,
     rep3_to_shamir_vec,
+    tune_get,
+    tune_set,
+    tuned,
     vec_add,
     vec_mul,
     vec_mul_table,

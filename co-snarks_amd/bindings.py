@@ -200,6 +200,104 @@ def msm_fold_partials(curve: int, group: int, partials: np.ndarray, nparts: int)
     return out
 
 
+def tune_set(key: str, value: int):
+    """csh_tune_set: process-wide tuning knob (tests / A-B runs)."""
+    _check(lib().csh_tune_set(key.encode(), int(value)))
+
+
+def tune_get(key: str) -> int:
+    v = C.c_int(0)
+    _check(lib().csh_tune_get(key.encode(), C.byref(v)))
+    return v.value
+
+
+class tuned:
+    """with tuned(msm_c=11, sort_two_level=1): ...  -- sets knobs, restores the previous values on exit."""
+
+    def __init__(self, **kv):
+        self.kv = kv
+        self.old = {}
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            self.old[k] = tune_get(k)
+            tune_set(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            tune_set(k, v)
+        return False
+
+
+SPLIT_PEER, SPLIT_HOST, SPLIT_RCCL = 0, 1, 2
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id() -> bytes:
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    _check(lib().csh_comm_unique_id(buf))
+    return bytes(buf)
+
+
+class Comm:
+    """csh_comm_t: one rank of a split-MSM communicator (RCCL behind the C ABI; no torch)."""
+
+    def __init__(self, handle):
+        self.h = handle
+
+    @classmethod
+    def init_rank(cls, uid, nranks: int, rank: int):
+        h = C.c_void_p()
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(uid) if uid is not None else None
+        _check(lib().csh_comm_init_rank(buf, int(nranks), int(rank), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def init_all(cls, devices):
+        k = len(devices)
+        arr = (C.c_int * k)(*devices)
+        hs = (C.c_void_p * k)()
+        _check(lib().csh_comm_init_all(arr, k, hs))
+        return [cls(C.c_void_p(hs[i])) for i in range(k)]
+
+    def info(self):
+        r, n, d = C.c_int(0), C.c_int(0), C.c_int(0)
+        _check(lib().csh_comm_info(self.h, C.byref(r), C.byref(n), C.byref(d)))
+        return r.value, n.value, d.value
+
+    def msm_split_rank_dev(self, bases: "Bases", scalars_dev, n: int, offset: int = 0, montgomery: bool = True, stream=None):
+        out = bases._out()
+        _check(lib().csh_msm_split_rank_dev(self.h, bases.h, C.c_size_t(offset), C.c_size_t(n), _devptr(scalars_dev), int(montgomery),
+                                            _p(out), _stream(stream)))
+        return out
+
+    def destroy(self):
+        if self.h:
+            lib().csh_comm_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+def msm_split(bases, offsets, counts, scalars_dev, montgomery: bool = True, mode: int = SPLIT_PEER, comms=None):
+    """csh_msm_split: one MSM over k ranges (one thread drives every device). bases: list of Bases; scalars_dev: list of
+    device pointers / DeviceBuffers."""
+    k = len(bases)
+    hs = (C.c_void_p * k)(*[b.h.value for b in bases])
+    offs = (C.c_size_t * k)(*offsets)
+    cnts = (C.c_size_t * k)(*counts)
+    ptrs = (C.c_void_p * k)(*[(_devptr(s).value if s is not None else None) for s in scalars_dev])
+    cm = (C.c_void_p * k)(*[c.h.value for c in comms]) if comms else None
+    out = bases[0]._out()
+    _check(lib().csh_msm_split(hs, offs, cnts, ptrs, C.c_size_t(k), int(montgomery), int(mode), cm, _p(out)))
+    return out
+
+
 def msm_last_timing():
     out = (C.c_float * 6)()
     _check(lib().csh_msm_last_timing(out))

@@ -52,6 +52,34 @@ struct LaneHolder {
 };
 static thread_local LaneHolder tl_lanes;
 
+static int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return (e && *e) ? atoi(e) : dflt;
+}
+struct TuneEntry { const char* key; const char* env; std::atomic<int> Tune::*field; };
+static const TuneEntry kTune[] = {
+    {"msm_c", "CSH_MSM_C", &Tune::msm_c},
+    {"msm_l", "CSH_MSM_L", &Tune::msm_l},
+    {"msm_timing", "CSH_MSM_TIMING", &Tune::msm_timing},
+    {"msm_no_table", "CSH_MSM_NO_TABLE", &Tune::msm_no_table},
+    {"msm_multi_overlap", "CSH_MSM_MULTI_OVERLAP", &Tune::msm_multi_overlap},
+    {"acc_blk", "CSH_ACC_BLK", &Tune::acc_blk},
+    {"sort_two_level", "CSH_SORT_TWO_LEVEL", &Tune::sort_two_level},
+    {"vec_max_blocks", "CSH_VEC_MAX_BLOCKS", &Tune::vec_max_blocks},
+    {"ntt_lazy", "CSH_NTT_LAZY", &Tune::ntt_lazy},
+    {"ntt_threads", "CSH_NTT_THREADS", &Tune::ntt_threads},
+    {"msm_variant", "CSH_MSM_VARIANT", &Tune::msm_variant},
+    {"ntt_variant", "CSH_NTT_VARIANT", &Tune::ntt_variant},
+};
+Tune& tune() {
+  static Tune* t = [] {
+    Tune* x = new Tune();
+    for (const TuneEntry& e : kTune) (x->*(e.field)).store(env_int(e.env, (x->*(e.field)).load()));
+    return x;
+  }();
+  return *t;
+}
+
 void set_error(const char* fmt, ...) {
   char buf[1024];
   va_list ap;
@@ -130,6 +158,27 @@ int csh_shutdown(void) {
 
 const char* csh_last_error(void) { return tl_error.c_str(); }
 const char* csh_version(void) { return "cosnarks-hip 0.1.0 (gfx950)"; }
+
+int csh_tune_set(const char* key, int value) {
+  CSH_REQUIRE(key, "key is NULL");
+  for (const TuneEntry& e : kTune)
+    if (!strcmp(e.key, key)) {
+      (tune().*(e.field)).store(value);
+      return CSH_OK;
+    }
+  set_error("csh_tune_set: unknown key '%s'", key);
+  return CSH_ERR_INVALID;
+}
+int csh_tune_get(const char* key, int* value) {
+  CSH_REQUIRE(key && value, "NULL argument");
+  for (const TuneEntry& e : kTune)
+    if (!strcmp(e.key, key)) {
+      *value = (tune().*(e.field)).load();
+      return CSH_OK;
+    }
+  set_error("csh_tune_get: unknown key '%s'", key);
+  return CSH_ERR_INVALID;
+}
 
 int csh_device_count(int* count) {
   CSH_REQUIRE(count, "count is NULL");

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <string>
@@ -89,6 +90,24 @@ int ntt_coset_table(const Domain* d, const uint64_t* shift, uint64_t* out_dev, h
 int ntt_bit_reverse(csh_curve_t c, uint64_t* data, uint32_t log_n, uint32_t ncomp, hipStream_t st);
 size_t domain_size_of(const Domain* d);
 csh_curve_t domain_curve_of(const Domain* d);
+
+// Process-wide tuning knobs (csh_tune_set / csh_tune_get): read once from the environment at load (CSH_MSM_C, ...),
+// changed at run time through the C ABI -- no getenv on any call path.
+struct Tune {
+  std::atomic<int> msm_c{0};             // forced window width (0 = cost model)
+  std::atomic<int> msm_l{0};             // forced entries per accumulate lane (0 = from the launch width)
+  std::atomic<int> msm_timing{0};        // record per-stage HIP events (csh_msm_last_timing)
+  std::atomic<int> msm_no_table{0};      // ignore fixed-base tables
+  std::atomic<int> msm_multi_overlap{1}; // alternate bucket stages of csh_msm_multi_dev between two streams
+  std::atomic<int> acc_blk{0};           // accumulate workgroup size (0 = default)
+  std::atomic<int> sort_two_level{-1};   // -1 auto, 0 / 1 forced
+  std::atomic<int> vec_max_blocks{65536};
+  std::atomic<int> ntt_lazy{1};
+  std::atomic<int> ntt_threads{1024};
+  std::atomic<int> msm_variant{0};       // experimental kernel variants (A/B runs)
+  std::atomic<int> ntt_variant{0};
+};
+Tune& tune();
 
 inline int grid_for(size_t n, int block, int max_blocks = 256 * 16) {
   size_t g = (n + block - 1) / block;

@@ -34,25 +34,9 @@ CSH_MSM_INSTANTIATE(extern, GrumpkinG1Cfg)
 
 static int repack_bases(Bases* B, hipStream_t st);
 
-static size_t point_bytes_of(csh_curve_t c, csh_group_t g) {
-  const size_t fq = c == CSH_BLS12_381 ? 48 : 32;
-  return 2 * fq * (g == CSH_G2 ? 2 : 1);
-}
-
 }  // namespace csh
 
 using namespace csh;
-
-#define CURVE_DISPATCH(curve, group, CALL)                                                      \
-  do {                                                                                          \
-    if ((curve) == CSH_BN254 && (group) == CSH_G1) { using Cfg = Bn254G1Cfg; return CALL; }     \
-    if ((curve) == CSH_BN254 && (group) == CSH_G2) { using Cfg = Bn254G2Cfg; return CALL; }     \
-    if ((curve) == CSH_BLS12_381 && (group) == CSH_G1) { using Cfg = Bls381G1Cfg; return CALL; } \
-    if ((curve) == CSH_BLS12_381 && (group) == CSH_G2) { using Cfg = Bls381G2Cfg; return CALL; } \
-    if ((curve) == CSH_GRUMPKIN && (group) == CSH_G1) { using Cfg = GrumpkinG1Cfg; return CALL; }  \
-    set_error("unknown curve/group %d/%d", (int)(curve), (int)(group));                          \
-    return CSH_ERR_INVALID;                                                                     \
-  } while (0)
 
 static int csh::repack_bases(Bases* B, hipStream_t st) {
   CURVE_DISPATCH(B->curve, B->group, (repack_bases_t<Cfg>(B, st)));
@@ -192,7 +176,7 @@ int csh_msm(csh_bases_t bases, size_t offset, size_t n, const uint64_t* scalars,
 int csh_msm_partial_bytes(csh_curve_t curve, csh_group_t group, size_t* bytes) {
   CSH_REQUIRE(bytes, "bytes is NULL");
   CSH_TRY(valid_cg(curve, group));
-  *bytes = sizeof(PartialHeader) + 2 * point_bytes_of(curve, group) * MAX_WINDOWS;
+  *bytes = partial_bytes_of(curve, group);
   return CSH_OK;
 }
 
@@ -201,7 +185,7 @@ int csh_msm_partial_dev(csh_bases_t bases, size_t offset, size_t n, const uint64
   CSH_TRY(ensure_device());
   Bases* B = reinterpret_cast<Bases*>(bases);
   hipStream_t st = resolve_stream(stream);
-  CURVE_DISPATCH(B->curve, B->group, (msm_partial_t<Cfg>(B, offset, n, scalars_dev, mont, out_dev, st)));
+  CURVE_DISPATCH(B->curve, B->group, (msm_partial_t<Cfg>(B, offset, n, scalars_dev, mont, out_dev, st, true)));
 }
 
 int csh_msm_fold_partials(csh_curve_t curve, csh_group_t group, const void* partials_host, size_t nparts, void* out_jacobian) {
@@ -289,10 +273,7 @@ int csh_msm_multi_dev(const csh_bases_t* bases, const size_t* offsets, size_t k,
   hipStream_t aux = nullptr;
   std::vector<hipStream_t> stage_stream(k, st);
   if (!merged) {
-    static const bool overlap = [] {
-      const char* e = getenv("CSH_MSM_MULTI_OVERLAP");
-      return !(e && atoi(e) == 0);
-    }();
+    const bool overlap = tune().msm_multi_overlap.load(std::memory_order_relaxed) != 0;
     if (overlap && k > 1) aux = resolve_aux_stream();  // pooled with the thread's lane: no stream creation per call
     const bool two = overlap && k > 1 && aux != nullptr;
     CSH_TRY(sort_stage(p, &so));

@@ -279,9 +279,8 @@ extern thread_local uint32_t tl_msm_params[4];  // c, W, L, S of the last MSM
 
 
 inline int choose_c(size_t n, int bits) {
-  const char* env = getenv("CSH_MSM_C");
-  if (env) {
-    int c = atoi(env);
+  {
+    const int c = tune().msm_c.load(std::memory_order_relaxed);
     if (c >= 2 && c <= 16) return c;
   }
   double best = 1e300;
@@ -315,8 +314,7 @@ inline MsmParams msm_plan(size_t n, int scalar_bits, int mont) {
   // 2^20 -> 32, 2^22 -> 128, 2^24 -> 256..512). Every lane of a wave performs the same number of mixed additions.
   uint64_t L = 16;
   while (L < 1024 && 2 * L * (uint64_t(1) << 19) <= (uint64_t)n * p.W) L <<= 1;
-  const char* envL = getenv("CSH_MSM_L");
-  if (envL && atoi(envL) > 0) L = (uint64_t)atoi(envL);
+  if (const int fl = tune().msm_l.load(std::memory_order_relaxed); fl > 0) L = (uint64_t)fl;
   p.L = (uint32_t)L;
   const uint32_t max_lanes = (uint32_t)((n + L - 1) / L);
   p.tmax = p.NB + max_lanes + 2;  // partial slots per window: slot = bucket + lane
@@ -362,9 +360,7 @@ inline MergedPlan msm_plan_merged(size_t n, int scalar_bits, int mont, int c, si
   p.NB = d.NB;
   uint64_t L = 16;  // one window only: 2^18 lanes fill the chip, longer runs mean fewer partials per bucket to merge
   while (L < 1024 && 2 * L * (uint64_t(1) << 18) <= n2) L <<= 1;
-  if (const char* envL = getenv("CSH_MSM_L")) {
-    if (atoi(envL) > 0) L = (uint64_t)atoi(envL);
-  }
+  if (const int fl = tune().msm_l.load(std::memory_order_relaxed); fl > 0) L = (uint64_t)fl;
   p.L = (uint32_t)L;
   const uint32_t max_lanes = (uint32_t)((n2 + L - 1) / L);
   p.tmax = p.NB + max_lanes + 2;
@@ -457,11 +453,8 @@ int msm_bucket_stage(const void* points, const MsmParams* pp, const SortOut* so,
   LazyPt<Cfg>* giant_tmp = ar.take<LazyPt<Cfg>>(256 * (size_t)giant_blocks);
   const Affine<Fq>* bases = reinterpret_cast<const Affine<Fq>*>(points);
   {
-    static const int blk = [] {
-      const char* e = getenv("CSH_ACC_BLK");
-      const int b = e ? atoi(e) : ACC_BLK;
-      return (b == 64 || b == 128) ? b : ACC_BLK;
-    }();
+    const int tb = tune().acc_blk.load(std::memory_order_relaxed);
+    const int blk = (tb == 64 || tb == 128) ? tb : ACC_BLK;
     const dim3 ag((max_lanes + blk - 1) / blk, p.W), ab(blk);
     hipLaunchKernelGGL(k_msm_accum<Cfg>, ag, ab, 0, st, bases, p, so->start, so->nlanes, so->sorted, partial);
   }
@@ -482,7 +475,7 @@ int msm_bucket_stage(const void* points, const MsmParams* pp, const SortOut* so,
 // merged-window mode applies when the handle carries tables, the call covers a good part of them (a tiny MSM against a
 // 2^15-bucket table would pay the bucket reduction for nothing) and the entry ids fit 31 bits
 inline bool msm_use_table(const Bases* B, size_t n) {
-  if (!B->table || n == 0 || getenv("CSH_MSM_NO_TABLE")) return false;
+  if (!B->table || n == 0 || tune().msm_no_table.load(std::memory_order_relaxed)) return false;
   if ((uint64_t)n * (uint64_t)B->table_W >= (uint64_t(1) << 31) || (uint64_t)B->n * (uint64_t)B->table_W >= (uint64_t(1) << 31)) return false;
   return n * 8 >= B->n;
 }
@@ -507,7 +500,7 @@ int msm_windows_dev(const Bases* B, size_t offset, size_t n, const uint64_t* sca
   *p_out = p;  // merged: W = 1 (the single window sum is the result)
   Arena& ar = arena_for(st);
   CSH_TRY(ar.reserve(msm_sort_bytes(p) + msm_bucket_bytes<Cfg>(&p)));
-  const bool timing = getenv("CSH_MSM_TIMING") != nullptr;
+  const bool timing = tune().msm_timing.load(std::memory_order_relaxed) != 0;
   hipEvent_t ev[7];
   if (timing) {
     for (auto& e : ev) CSH_HIP(hipEventCreate(&e));
@@ -625,22 +618,35 @@ int msm_t(const Bases* B, size_t offset, size_t n, const uint64_t* scalars_dev, 
   return CSH_OK;
 }
 
-template <class Cfg>
-int msm_partial_t(const Bases* B, size_t offset, size_t n, const uint64_t* scalars_dev, int mont, void* out_dev, hipStream_t st) {
-  using Fq = typename Cfg::Fq;
+// header of a partial buffer, written on the stream (no host round trip: the partial stays asynchronous)
+template <int UNUSED = 0>
+__global__ void k_msm_partial_header(PartialHeader* out, uint32_t c, uint32_t W) {
   PartialHeader h;
-  memset(&h, 0, sizeof h);
   h.magic = PARTIAL_MAGIC;
+  h.c = c;
+  h.W = W;
+  h.reserved = 0;
+  for (int i = 0; i < 4; ++i) h.pad[i] = 0;
+  *out = h;
+}
+
+// One range of a split MSM: PartialHeader + W window sums (XYZZ, arkworks encoding) left on the device. Asynchronous on
+// `st` unless `sync`.
+template <class Cfg>
+int msm_partial_t(const Bases* B, size_t offset, size_t n, const uint64_t* scalars_dev, int mont, void* out_dev, hipStream_t st, bool sync) {
+  using Fq = typename Cfg::Fq;
   XYZZ<Fq>* wins = reinterpret_cast<XYZZ<Fq>*>(static_cast<char*>(out_dev) + sizeof(PartialHeader));
   CSH_HIP(hipMemsetAsync(out_dev, 0, sizeof(PartialHeader) + sizeof(XYZZ<Fq>) * MAX_WINDOWS, st));
+  uint32_t c = 0, W = 0;
   if (n > 0) {
     MsmParams p;
     CSH_TRY((msm_windows_dev<Cfg>(B, offset, n, scalars_dev, mont, st, wins, &p)));
-    h.c = p.c;
-    h.W = p.W;
+    c = (uint32_t)p.c;
+    W = (uint32_t)p.W;
   }
-  CSH_HIP(hipMemcpyAsync(out_dev, &h, sizeof h, hipMemcpyHostToDevice, st));
-  CSH_HIP(hipStreamSynchronize(st));  // h is on the stack
+  hipLaunchKernelGGL(k_msm_partial_header<0>, dim3(1), dim3(1), 0, st, reinterpret_cast<PartialHeader*>(out_dev), c, W);
+  CSH_HIP(hipGetLastError());
+  if (sync) CSH_HIP(hipStreamSynchronize(st));
   return CSH_OK;
 }
 
@@ -706,12 +712,30 @@ int repack_bases_t(Bases* B, hipStream_t st) {
 // one explicit instantiation set per configuration (msm_inst_*.hip); everyone else only sees the declarations
 #define CSH_MSM_INSTANTIATE(KW, CFG)                                                                                            \
   KW template int msm_t<CFG>(const Bases*, size_t, size_t, const uint64_t*, int, void*, hipStream_t);                           \
-  KW template int msm_partial_t<CFG>(const Bases*, size_t, size_t, const uint64_t*, int, void*, hipStream_t);                   \
+  KW template int msm_partial_t<CFG>(const Bases*, size_t, size_t, const uint64_t*, int, void*, hipStream_t, bool);                 \
   KW template int fold_partials_t<CFG>(const void*, size_t, void*);                                                             \
   KW template int repack_bases_t<CFG>(Bases*, hipStream_t);                                                                     \
   KW template size_t msm_bucket_bytes<CFG>(const MsmParams*);                                                                   \
   KW template int msm_bucket_stage<CFG>(const void*, const MsmParams*, const SortOut*, hipStream_t, Arena*, void*, hipEvent_t*);          \
   KW template int precompute_table_t<CFG>(Bases*, int, hipStream_t);                                                            \
   KW template void fold_windows_erased<CFG>(const void*, int, int, void*);
+
+// the five group configurations, by run-time (curve, group)
+#define CURVE_DISPATCH(curve, group, CALL)                                                      \
+  do {                                                                                          \
+    if ((curve) == CSH_BN254 && (group) == CSH_G1) { using Cfg = csh::Bn254G1Cfg; return CALL; }     \
+    if ((curve) == CSH_BN254 && (group) == CSH_G2) { using Cfg = csh::Bn254G2Cfg; return CALL; }     \
+    if ((curve) == CSH_BLS12_381 && (group) == CSH_G1) { using Cfg = csh::Bls381G1Cfg; return CALL; } \
+    if ((curve) == CSH_BLS12_381 && (group) == CSH_G2) { using Cfg = csh::Bls381G2Cfg; return CALL; } \
+    if ((curve) == CSH_GRUMPKIN && (group) == CSH_G1) { using Cfg = csh::GrumpkinG1Cfg; return CALL; }  \
+    csh::set_error("unknown curve/group %d/%d", (int)(curve), (int)(group));                     \
+    return CSH_ERR_INVALID;                                                                     \
+  } while (0)
+
+inline size_t point_bytes_of(csh_curve_t c, csh_group_t g) {
+  const size_t fq = c == CSH_BLS12_381 ? 48 : 32;
+  return 2 * fq * (g == CSH_G2 ? 2 : 1);
+}
+inline size_t partial_bytes_of(csh_curve_t c, csh_group_t g) { return sizeof(PartialHeader) + 2 * point_bytes_of(c, g) * MAX_WINDOWS; }
 
 }  // namespace csh

@@ -348,11 +348,10 @@ __global__ __launch_bounds__(SORT_BLK) void k_msm_scatter_l2(MsmParams p, const 
 }
 
 // Two-level mode pays off once a (partition, window) block has enough records to fill its tiles: n >= 2^20
-// (measured: 2^20 0.22 -> 0.12 ms, 2^24 6.2 -> 2.1 ms; slower at 2^18). CSH_SORT_TWO_LEVEL=0/1 forces a mode (tests).
+// (measured: 2^20 0.22 -> 0.12 ms, 2^24 6.2 -> 2.1 ms; slower at 2^18). csh_tune_set("sort_two_level", 0/1) forces a mode (tests).
 bool msm_sort_two_level(const MsmParams& p) {
   if (p.NB < 4 * PART_BUCKETS) return false;
-  const char* e = getenv("CSH_SORT_TWO_LEVEL");
-  if (e && *e) return atoi(e) != 0;
+  if (const int f = tune().sort_two_level.load(std::memory_order_relaxed); f >= 0) return f != 0;
   return p.n >= (1u << 20);
 }
 

@@ -320,16 +320,12 @@ static int run_ntt(const Domain* d, F* data, uint32_t ncomp, bool dif, hipStream
   const int ncomp_log = ncomp == 2 ? 1 : 0;
   Pass passes[8];
   const int np = plan_passes(L, ncomp_log, passes);
-  static const bool use_lazy = [] {
-    const char* e = getenv("CSH_NTT_LAZY");
-    return !(e && atoi(e) == 0);
-  }();
+  const bool use_lazy = tune().ntt_lazy.load(std::memory_order_relaxed) != 0;
   using LZ = typename LazyOf<F>::type;
   const F* tw = reinterpret_cast<const F*>(use_lazy ? (dif ? d->tw_inv_lazy : d->tw_fwd_lazy) : (dif ? d->tw_inv : d->tw_fwd));
   F scale = f_from_words<F>(use_lazy ? d->n_inv_lazy : d->n_inv);
-  static const int NTT_THREADS = [] {
-    const char* e = getenv("CSH_NTT_THREADS");
-    const int v = e ? atoi(e) : 1024;  // 16 waves per tile: measured best for both field representations
+  const int NTT_THREADS = [] {
+    const int v = tune().ntt_threads.load(std::memory_order_relaxed);  // 16 waves per tile: measured best for both field representations
     return (v == 256 || v == 512 || v == 1024) ? v : 1024;
   }();
   for (int pi = 0; pi < np; ++pi) {

@@ -15,10 +15,8 @@ namespace csh {
 
 constexpr int VB = 256;
 static int vec_grid(size_t n) {
-  static const int mb = [] {
-    const char* e = getenv("CSH_VEC_MAX_BLOCKS");
-    return e && atoi(e) > 0 ? atoi(e) : 65536;  // up to one element per lane at 2^24: measured 8-10 % faster than 4096 blocks + grid stride
-  }();
+  int mb = tune().vec_max_blocks.load(std::memory_order_relaxed);  // default 65536: up to one element per lane at 2^24, measured 8-10 % faster than 4096 blocks + grid stride
+  if (mb <= 0) mb = 65536;
   return grid_for(n, VB, mb);
 }
 

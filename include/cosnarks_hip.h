@@ -65,6 +65,12 @@ int csh_shutdown(void);              /* free all cached workspaces/streams of ev
 const char* csh_last_error(void);
 const char* csh_version(void);
 int csh_device_count(int* count);
+/* Process-wide tuning knobs for A/B runs and tests (initial values come from the environment once, at load: CSH_MSM_C ...;
+ * no entry point reads the environment afterwards). Keys: "msm_c" (forced window width, 0 = cost model), "msm_l" (entries per
+ * accumulate lane), "msm_timing" (record csh_msm_last_timing), "msm_no_table", "msm_multi_overlap", "acc_blk",
+ * "sort_two_level" (-1 auto), "vec_max_blocks", "ntt_lazy", "ntt_threads", "msm_variant", "ntt_variant". */
+int csh_tune_set(const char* key, int value);
+int csh_tune_get(const char* key, int* value);
 
 /* plain device-memory plumbing for harnesses without their own HIP binding (tests, the Rust shim) */
 /* the device the calling thread is bound to (csh_init, default 0): handles (bases, domains, matrices) are per device */
@@ -106,12 +112,44 @@ int csh_msm(csh_bases_t bases, size_t offset, size_t n, const uint64_t* scalars,
             int scalars_are_montgomery, void* out_jacobian);
 int csh_msm_dev(csh_bases_t bases, size_t offset, size_t n, const uint64_t* scalars_dev,
                 int scalars_are_montgomery, void* out_jacobian_host, void* stream);
-/* Split-MSM support (one MSM over several GPUs): the un-normalised partial result as
- * `nwindows` XYZZ points (4 base-field elements each) left ON THE DEVICE for an RCCL all-gather, and the
- * host-side fold of gathered partials. */
+/* Split-MSM building blocks (the entry points below compose them): the un-normalised partial result of one range -- a
+ * 32-byte header {magic, c, W} + up to 128 window sums as XYZZ points (4 base-field elements each, arkworks encoding) --
+ * left ON THE DEVICE (synchronous: the buffer is complete when the call returns), and the host-side fold of gathered
+ * partials. Ranges may use different window widths; an empty range (n = 0) folds as the identity. */
 int csh_msm_partial_dev(csh_bases_t bases, size_t offset, size_t n, const uint64_t* scalars_dev,
                         int scalars_are_montgomery, void* out_xyzz_dev /* csh_msm_partial_bytes */,
                         void* stream);
+/* ---- one MSM split over the GPUs of a node (BASELINE config 5) ---------------------------------------------
+ * Same seam as csh_msm_dev -- the MSM closures of groth16.rs:227-294 -- for a query too large or too urgent for one GPU:
+ * the points are cut into contiguous ranges (one csh_bases_t per GPU, uploaded once), every GPU reduces its range to window
+ * sums, ONE exchange moves those partial buffers (csh_msm_partial_bytes each, <= 48 KiB) and the host folds them. The
+ * exchange is RCCL ncclAllGather over xGMI (bound with dlopen: no link-time dependency, no torch), hipMemcpyPeer to a root
+ * device, or one device-to-host copy per GPU. RCCL has no elliptic-curve reduction operator, so this is an all-gather. */
+#define CSH_COMM_ID_BYTES 128
+typedef struct csh_comm_s* csh_comm_t;
+/* One process (or thread) per GPU: rank 0 draws an id (ncclGetUniqueId), ships the 128 bytes to the other ranks by whatever
+ * channel the host has, every rank calls csh_comm_init_rank on the thread bound (csh_init) to its GPU. nranks == 1 with
+ * id == NULL makes a local communicator without loading RCCL. A communicator is used by one thread at a time. */
+int csh_comm_unique_id(uint8_t id[CSH_COMM_ID_BYTES]);
+int csh_comm_init_rank(const uint8_t id[CSH_COMM_ID_BYTES], int nranks, int rank, csh_comm_t* out);
+/* One process driving `ndev` distinct GPUs (ncclCommInitAll): out[i] = rank i on devices[i]. */
+int csh_comm_init_all(const int* devices, int ndev, csh_comm_t* out);
+int csh_comm_info(csh_comm_t comm, int* rank, int* nranks, int* device); /* any out pointer may be NULL */
+int csh_comm_destroy(csh_comm_t comm);
+/* This rank's share of one split MSM: sum_{i<n} scalars[i] * bases[offset+i] over its own range -> window sums -> all-gather
+ * over the communicator -> fold. Every rank receives the full result in out_jacobian (host, as csh_msm). Synchronous;
+ * collective: every rank of the communicator must call it (n may be 0 on a rank). */
+int csh_msm_split_rank_dev(csh_comm_t comm, csh_bases_t bases, size_t offset, size_t n, const uint64_t* scalars_dev,
+                           int scalars_are_montgomery, void* out_jacobian, void* stream);
+/* One thread driving all GPUs: part i = counts[i] points from offsets[i] of bases[i] (a handle on any device; several parts
+ * may share a device) with device scalars scalars_dev[i] on that device. The ranges run concurrently on their devices'
+ * streams; `mode` picks the exchange. CSH_SPLIT_RCCL needs comms[i] = rank i of csh_comm_init_all over the parts' (distinct)
+ * devices; `comms` is ignored otherwise. The calling thread's device binding is restored on return. Synchronous. */
+typedef enum { CSH_SPLIT_PEER = 0 /* hipMemcpyPeerAsync to the first part's device */, CSH_SPLIT_HOST = 1 /* one D2H per part */,
+               CSH_SPLIT_RCCL = 2 /* grouped ncclAllGather */ } csh_split_mode_t;
+int csh_msm_split(const csh_bases_t* bases, const size_t* offsets, const size_t* counts, const uint64_t* const* scalars_dev,
+                  size_t k, int scalars_are_montgomery, int mode, const csh_comm_t* comms, void* out_jacobian);
+
 /* k MSMs over ONE device scalar vector -- the four aux-assignment MSMs of a Groth16 proof (a_query, b_g1_query, b_g2_query,
  * l_query: groth16.rs:237-284, calculate_coeff :179-203): the signed-digit decomposition and the bucket sort depend on the
  * scalars only and are computed once. bases[i]: handles of one curve (G1 and G2 may be mixed), each MSM takes n points
@@ -265,7 +303,7 @@ int csh_event_record(void* ev, void* stream);
 int csh_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);
 int csh_event_destroy(void* ev);
 /* Per-MSM stage timings (ms) of the last csh_msm*_dev call on this thread: [digits+histogram, scan,
- * scatter, bucket accumulate, bucket reduce, total]; valid only when CSH_MSM_TIMING=1 in the env. */
+ * scatter, bucket accumulate, bucket reduce, total]; valid only while csh_tune_set("msm_timing", 1) is in effect. */
 int csh_msm_last_timing(float out_ms[6]);
 /* Pipeline parameters of the last csh_msm*_dev call on this thread: [window bits c, windows W, entries per lane L,
  * reduction segments S]. */

@@ -60,8 +60,8 @@ def test_msm_edge_cases(gpu, curve, group):
     assert G.eq(_run(gpu, curve, group, pts, sc[:20], offset=7, n=20), G.msm(pts[7:27], sc[:20]))
 
 
-def test_msm_window_sizes(gpu, monkeypatch):
-    """Every window width the heuristic can choose gives the same element (CSH_MSM_C forces c)."""
+def test_msm_window_sizes(gpu):
+    """Every window width the heuristic can choose gives the same element (csh_tune_set("msm_c") forces c)."""
     G = cv.BN254_G1
     F = H.FR["bn254"]
     r = H.rng(8)
@@ -69,24 +69,21 @@ def test_msm_window_sizes(gpu, monkeypatch):
     pts = H.rand_points(G, n, r, with_inf=True)
     sc = H.rand_elems(F, n, r)
     want = G.msm(pts, sc)
-    for c in [2, 3, 5, 8, 11, 13, 16, 17, 20]:
-        monkeypatch.setenv("CSH_MSM_C", str(c))
-        assert G.eq(_run(gpu, "bn254", 0, pts, sc), want), c
+    for c in [2, 3, 5, 8, 11, 13, 16]:
+        with gpu.tuned(msm_c=c):
+            assert G.eq(_run(gpu, "bn254", 0, pts, sc), want), c
     # both scatter variants (single-level LDS cursors / two-level tile sort), uniform and skewed digits
     sk2 = [1] * 120 + [F.p - 1] * 80 + [5 << 200] * 60 + sc[:40]
     want2 = G.msm(pts, sk2)
-    for mode in ["0", "1"]:
-        monkeypatch.setenv("CSH_SORT_TWO_LEVEL", mode)
+    for mode in [0, 1]:
         for c in [11, 14, 16]:
-            monkeypatch.setenv("CSH_MSM_C", str(c))
-            assert G.eq(_run(gpu, "bn254", 0, pts, sc), want), (mode, c)
-            assert G.eq(_run(gpu, "bn254", 0, pts, sk2), want2), (mode, c)
-    monkeypatch.delenv("CSH_SORT_TWO_LEVEL")
-    monkeypatch.delenv("CSH_MSM_C")
+            with gpu.tuned(sort_two_level=mode, msm_c=c):
+                assert G.eq(_run(gpu, "bn254", 0, pts, sc), want), (mode, c)
+                assert G.eq(_run(gpu, "bn254", 0, pts, sk2), want2), (mode, c)
     # tiny task length: forces many tasks per bucket (the skew path) on a skewed scalar set
-    monkeypatch.setenv("CSH_MSM_L", "3")
-    sk = [1] * 150 + [F.p - 1] * 100 + sc[:50]
-    assert G.eq(_run(gpu, "bn254", 0, pts, sk), G.msm(pts, sk))
+    with gpu.tuned(msm_l=3):
+        sk = [1] * 150 + [F.p - 1] * 100 + sc[:50]
+        assert G.eq(_run(gpu, "bn254", 0, pts, sk), G.msm(pts, sk))
 
 
 def test_msm_arkworks_affine_stride(gpu):

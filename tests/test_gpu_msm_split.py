@@ -1,0 +1,180 @@
+"""GPU parity of the split MSM (BASELINE config 5) through the C ABI: contiguous point ranges reduced per range
+(`csh_msm_partial_dev`), folded (`csh_msm_fold_partials`), and the composed entry points `csh_msm_split` (one thread, PEER /
+HOST / RCCL exchange) and `csh_comm_init_rank` + `csh_msm_split_rank_dev` (one rank per GPU). On a one-GPU box the ranges
+share device 0 (the exchange code is the same; RCCL runs with one rank); the multi-rank exchange is covered on CPU by
+tests/test_distributed_cpu.py and measured by the driver's 1/2/4/8-GPU bench."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import curves as cv
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+GROUPS = [("bn254", 0), ("bn254", 1), ("bls12_381", 0), ("bls12_381", 1), ("grumpkin", 0)]
+
+
+def _cuts(n, k, empty_at=None):
+    """k contiguous ranges covering [0, n): uneven on purpose; range `empty_at` is empty."""
+    if k == 1:
+        return [(0, n)]
+    w = [(i % 3) + 1 for i in range(k)]
+    if empty_at is not None:
+        w[empty_at] = 0
+    tot = sum(w)
+    edges = [0]
+    for x in w:
+        edges.append(edges[-1] + n * x // tot)
+    edges[-1] = n
+    return [(edges[i], edges[i + 1] - edges[i]) for i in range(k)]
+
+
+def _partials(gpu, bases, dsc, cuts, curve_id, group, c_per_range=None):
+    pb = gpu.msm_partial_bytes(curve_id, group)
+    host = np.zeros(pb * len(cuts), dtype=np.uint8)
+    for i, (off, cnt) in enumerate(cuts):
+        out = gpu.DeviceBuffer(pb)
+        ptr = C.c_void_p(dsc.ptr.value + 32 * off)
+        if c_per_range:
+            with gpu.tuned(msm_c=c_per_range[i % len(c_per_range)]):
+                bases.msm_partial_dev(ptr, cnt, out, offset=off)
+        else:
+            bases.msm_partial_dev(ptr, cnt, out, offset=off)
+        host[pb * i:pb * (i + 1)] = out.to_host(np.uint8)
+        out.free()
+    return host
+
+
+@pytest.mark.parametrize("curve,group", GROUPS)
+@pytest.mark.parametrize("k", [2, 3, 8])
+def test_partial_ranges_fold_to_the_oracle_msm(gpu, curve, group, k):
+    G = cv.CURVES[curve][group]
+    F = H.FR[curve]
+    cid = H.CURVE_IDS[curve]
+    r = H.rng(500 + 10 * k + group)
+    n = 700
+    pts = H.rand_points(G, n, r, with_inf=True)
+    sc = H.rand_elems(F, n, r)
+    sc[5], sc[6], sc[7] = 0, 1, F.p - 1
+    want = G.msm(pts, sc)
+    bases = gpu.Bases(cid, group, cv.pack_points(G, pts))
+    dsc = gpu.DeviceBuffer.from_host(H.pack(F, sc))
+    # (a) uneven ranges, (b) one empty range, (c) a different window width per range
+    for cuts, cs in ((_cuts(n, k), None), (_cuts(n, k, empty_at=1), None), (_cuts(n, k), [5, 9, 12])):
+        host = _partials(gpu, bases, dsc, cuts, cid, group, cs)
+        got = gpu.msm_fold_partials(cid, group, host, len(cuts))
+        assert G.eq(H.jac_to_affine(G, got), want), (cuts, cs)
+    # the composed entry point, both torch-free single-thread exchanges, ranges sharing device 0
+    for mode in (gpu.bindings.SPLIT_PEER, gpu.bindings.SPLIT_HOST):
+        cuts = _cuts(n, k, empty_at=0 if k == 3 else None)
+        got = gpu.msm_split([bases] * k, [o for o, _ in cuts], [c for _, c in cuts],
+                            [C.c_void_p(dsc.ptr.value + 32 * o) for o, _ in cuts], mode=mode)
+        assert G.eq(H.jac_to_affine(G, got), want), (mode, cuts)
+    bases.free()
+    dsc.free()
+
+
+def test_split_all_ranges_empty_or_cancelling(gpu):
+    G = cv.BN254_G1
+    F = H.FR["bn254"]
+    r = H.rng(9)
+    pts = H.rand_points(G, 40, r)
+    pts[20:] = [G.neg(p) for p in pts[:20]]
+    sc = H.rand_elems(F, 20, r) * 2                      # second half cancels the first
+    bases = gpu.Bases(0, 0, cv.pack_points(G, pts))
+    dsc = gpu.DeviceBuffer.from_host(H.pack(F, sc))
+    got = gpu.msm_split([bases, bases], [0, 20], [20, 20], [dsc.ptr, C.c_void_p(dsc.ptr.value + 32 * 20)])
+    assert H.jac_to_affine(G, got) is None
+    got = gpu.msm_split([bases, bases, bases], [0, 5, 9], [0, 0, 0], [dsc.ptr] * 3, mode=gpu.bindings.SPLIT_HOST)
+    assert H.jac_to_affine(G, got) is None
+
+
+def test_split_rejects_bad_arguments(gpu):
+    G = cv.BN254_G1
+    r = H.rng(3)
+    b1 = gpu.Bases(0, 0, cv.pack_points(G, H.rand_points(G, 8, r)))
+    G2 = cv.CURVES["bn254"][1]
+    b2 = gpu.Bases(0, 1, cv.pack_points(G2, H.rand_points(G2, 8, r)))
+    dsc = gpu.DeviceBuffer.from_host(np.zeros(32, dtype=np.uint64))
+    with pytest.raises(gpu.CoSnarksHipError):
+        gpu.msm_split([b1, b2], [0, 0], [4, 4], [dsc.ptr, dsc.ptr])                   # mixed groups
+    with pytest.raises(gpu.CoSnarksHipError):
+        gpu.msm_split([b1], [6], [4], [dsc.ptr])                                       # range past the handle
+    with pytest.raises(gpu.CoSnarksHipError):
+        gpu.msm_split([b1, b1], [0, 4], [4, 4], [dsc.ptr, dsc.ptr], mode=gpu.bindings.SPLIT_RCCL)  # RCCL mode without comms
+    with pytest.raises(gpu.CoSnarksHipError):
+        gpu.Comm.init_all([0, 0])                                                      # a device twice
+
+
+@pytest.mark.parametrize("curve,group", [("bn254", 0), ("bls12_381", 1)])
+def test_rccl_rank_path_with_one_rank(gpu, curve, group):
+    """csh_comm_unique_id -> csh_comm_init_rank -> csh_msm_split_rank_dev: RCCL is dlopen'ed and a real communicator is built
+    (one rank here; N ranks under the driver's multi-GPU bench). Also the RCCL-free local communicator (id = NULL) and the
+    single-thread RCCL mode over csh_comm_init_all([0])."""
+    G = cv.CURVES[curve][group]
+    F = H.FR[curve]
+    cid = H.CURVE_IDS[curve]
+    r = H.rng(77 + group)
+    n = 500
+    pts = H.rand_points(G, n, r, with_inf=True)
+    sc = H.rand_elems(F, n, r)
+    want = G.msm(pts, sc)
+    bases = gpu.Bases(cid, group, cv.pack_points(G, pts))
+    dsc = gpu.DeviceBuffer.from_host(H.pack(F, sc))
+    uid = gpu.bindings.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    comm = gpu.Comm.init_rank(uid, 1, 0)
+    assert comm.info() == (0, 1, 0)
+    for _ in range(2):                                     # communicator buffers are reused across calls
+        assert G.eq(H.jac_to_affine(G, comm.msm_split_rank_dev(bases, dsc, n)), want)
+    assert G.eq(H.jac_to_affine(G, comm.msm_split_rank_dev(bases, C.c_void_p(dsc.ptr.value + 32 * 100), 300, offset=100)),
+                G.msm(pts[100:400], sc[100:400]))
+    comm.destroy()
+    local = gpu.Comm.init_rank(None, 1, 0)
+    assert G.eq(H.jac_to_affine(G, local.msm_split_rank_dev(bases, dsc, n)), want)
+    local.destroy()
+    comms = gpu.Comm.init_all([0])
+    got = gpu.msm_split([bases], [0], [n], [dsc.ptr], mode=gpu.bindings.SPLIT_RCCL, comms=comms)
+    assert G.eq(H.jac_to_affine(G, got), want)
+    for c in comms:
+        c.destroy()
+    bases.free()
+    dsc.free()
+
+
+def _gen_bases_handle(gpu, cid, group, seed, n):
+    buf = gpu.DeviceBuffer(n * gpu.point_bytes(cid, group))
+    gpu.bindings._check(gpu.lib().csh_util_generate_bases_dev(cid, group, C.c_uint64(seed), C.c_size_t(n), buf.ptr, None))
+    gpu.bindings.sync()
+    h = C.c_void_p()
+    gpu.bindings._check(gpu.lib().csh_bases_upload_dev(cid, group, buf.ptr, C.c_size_t(n), C.c_size_t(0), None, C.byref(h)))
+    buf.free()
+    b = gpu.Bases.__new__(gpu.Bases)
+    b.curve, b.group, b.n, b.h = cid, group, n, h
+    return b
+
+
+@pytest.mark.parametrize("curve,group,logn,k", [("bn254", 0, 22, 3), ("bn254", 0, 24, 8), ("bls12_381", 0, 24, 8), ("bls12_381", 1, 22, 8),
+                                                 ("bls12_381", 1, 24, 8)])
+def test_split_closed_form_at_config5_sizes(gpu, curve, group, logn, k):
+    """BASELINE config 5 sizes (BLS12-381 G1 / G2 at 2^24, cut into 8 ranges as on an 8-GPU node) and BN254 G1: known-dlog
+    bases, uniform Montgomery scalars; the folded split result equals (sum s_i k_i) G and the single-launch csh_msm_dev."""
+    from tests.check_closed_form import closed_form_point
+    G = cv.CURVES[curve][group]
+    cid = H.CURVE_IDS[curve]
+    n = 1 << logn
+    seed = 0x5EED0000 + logn
+    bases = _gen_bases_handle(gpu, cid, group, seed, n)
+    rs = np.random.RandomState(logn + group)
+    limbs = rs.randint(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    limbs[:, 3] >>= np.uint64(3)
+    dsc = gpu.DeviceBuffer.from_host(limbs)
+    cuts = _cuts(n, k)
+    got = gpu.msm_split([bases] * k, [o for o, _ in cuts], [c for _, c in cuts], [C.c_void_p(dsc.ptr.value + 32 * o) for o, _ in cuts])
+    want = closed_form_point(curve, group, seed, n, limbs, True)
+    assert G.eq(H.jac_to_affine(G, got), want)
+    if logn <= 22:
+        assert G.eq(H.jac_to_affine(G, bases.msm_dev(dsc, n)), want)
+    bases.free()
+    dsc.free()
