@@ -1,18 +1,24 @@
 #!/usr/bin/env python3
-"""bench.py -- BN254 G1 MSM points/s on MI355X (BASELINE.json metric), one process per GPU.
+"""bench.py -- MSM points/s on MI355X (BASELINE.json metric), one process per GPU, everything through the C ABI.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--log-n 20]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload bn254_g1] [--log-n 20] [--scaling weak|strong]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
-A "step" = one pass of the hot path over one batch: one Pippenger MSM of 2^log_n BN254 G1 bases per rank
-(BASELINE config 2: 2^20 uniform 254-bit scalars, the reference's `msm_unchecked` call, scalars in
-Montgomery form) through the C ABI (`csh_msm_dev`), with bases and scalars already resident in HBM.
-N > 1: ONE MSM of N*2^log_n points split by contiguous point ranges: every rank reduces its
-range to per-window partial sums (`csh_msm_partial_dev`), the partials (a few KiB) are exchanged with an
-RCCL all-gather over xGMI, and every rank folds them -- weak scaling, value = total points / time.
+A "step" = one pass of the hot path over one batch: one Pippenger MSM (the reference's `msm_unchecked` call: uniform scalars
+in Montgomery form, bases and scalars already resident in HBM).
+  N = 1   `csh_msm_dev` on 2^log_n points (default: BN254 G1, 2^20 = BASELINE config 2).
+  N > 1   ONE MSM split by contiguous point ranges over the N ranks: every rank reduces its range to window sums,
+          ONE RCCL all-gather over xGMI moves the partial buffers, every rank folds them -- all inside
+          `csh_msm_split_rank_dev` (RCCL bound by the library itself; torch.distributed/gloo is only this harness's control
+          plane: rendezvous, barriers, max-over-ranks timing).
+          --scaling weak (default): 2^log_n points per rank;  --scaling strong: 2^log_n points in total (BASELINE config 5 is
+          `--workload bls12_381_g1|bls12_381_g2 --log-n 24 --scaling strong`).
+`value` = points of the whole job per second. The timed result is checked against the closed form (sum s_i k_i) G at every N.
 
-Extra objects on the JSON line: "roofline" (dominant kernel k_msm_accum, HIP-event timed on the launch
-stream) and "cpu_baseline" (the oracle's C restatement timed on this box's host cores; rank 0, N=1 only).
+Extra objects on the JSON line: "roofline" (dominant kernel k_msm_accum, HIP-event timed on the launch stream; constants
+and PMC traffic read from profiles/roofline_inputs.json), "cpu_baseline" (oracle/c `oc_msm_fast` on this box's host cores on
+the step's own inputs; rank 0, N = 1 only) and "secondary" (MSM 2^24, NTT 2^22, Rep3 local_mul_vec, Groth16 prove ms, and the
+config-5 workloads at this N).
 """
 import argparse
 import json
@@ -22,42 +28,259 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("OMP_PROC_BIND", "spread")   # cpu_baseline leg: one pinned OpenMP thread per core
+os.environ.setdefault("OMP_PLACES", "cores")
 
-# k_msm_accum HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; see tools/pmc_summary.py).
-# The kernel gathers every 64-byte base once per window (W = 17 at 2^20): 1.14 GB is inherent to Pippenger; the rest is
-# the x2 FETCH_SIZE correction applied to 64-byte gathers (raw counter: 1.44 GB), the sorted-index reads and the
-# partial-sum writes (0.14 GB).
-PMC_TRAFFIC_BYTES = {20: 3026656721}
-MADS_PER_MADD = 1467   # 10 products (6 mul 81 + 2 sqr 45 + fused 2x81) + 9 Montgomery reductions x 81, 9-limb 29-bit field
-MAD_PEAK_T = 31.0      # measured v_mad_u64_u32 issue rate, T lane-ops/s
+WORKLOADS = {
+    # name: (curve id, group id, bytes per affine point, label, arithmetic type)
+    "bn254_g1": (0, 0, 64, "BN254 G1", "i32x9 29-bit-limb lazy Montgomery, i64 accumulate (BN254 Fq 254-bit)"),
+    "bn254_g2": (0, 1, 128, "BN254 G2", "Fp2 over i32x9 29-bit-limb lazy Montgomery, i64 accumulate (BN254 Fq2)"),
+    "bls12_381_g1": (1, 0, 96, "BLS12-381 G1", "i32x14 28-bit-limb lazy Montgomery, i64 accumulate (BLS12-381 Fq 381-bit)"),
+    "bls12_381_g2": (1, 1, 192, "BLS12-381 G2", "Fp2 over i32x14 28-bit-limb lazy Montgomery, i64 accumulate (BLS12-381 Fq2)"),
+    "grumpkin_g1": (2, 0, 64, "Grumpkin G1", "i32x9 29-bit-limb lazy Montgomery, i64 accumulate (BN254 Fr 254-bit)"),
+}
+CURVE_NAMES = {0: "bn254", 1: "bls12_381", 2: "grumpkin"}
+SEED = 0x00C0FFEE5EED
 
 
-def secondary_metrics(hip, B, L, C, np, torch, dev, stream):
-    """MSM at 2^24, NTT/iNTT at 2^22 (BASELINE config 3), Rep3 local_mul_vec, Groth16 prove on a synthetic 2^20 circuit."""
+def load_roofline_inputs():
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "roofline_inputs.json")))
+    except Exception:
+        return {}
+
+
+class Ctx:
+    """Everything a workload needs: the library, the device, the stream, the harness's process group."""
+
+    def __init__(self, args):
+        import torch  # FIRST: torch bundles its own libamdhip64.so.7; our library must bind to the same runtime
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        assert self.world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={self.world}"
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # BENCH_FOLD_RANKS=1 folds the ranks onto the GPUs that exist (debugging the N > 1 code path on a smaller box; the
+        # exchange then falls back to the harness all-gather because RCCL cannot put two ranks on one device).
+        self.folded = bool(os.environ.get("BENCH_FOLD_RANKS"))
+        self.dev_index = local_rank % max(1, torch.cuda.device_count()) if self.folded else local_rank
+        torch.cuda.set_device(self.dev_index)
+        self.dev = torch.device("cuda", self.dev_index)
+        if self.world > 1:
+            dist.init_process_group("gloo", rank=self.rank, world_size=self.world)   # control plane only
+        import ctypes as C
+
+        import numpy as np
+
+        import cosnarks_amd as hip
+        from cosnarks_amd import bindings as B
+        self.C, self.np, self.hip, self.B = C, np, hip, B
+        self.L = hip.lib()
+        B._check(self.L.csh_init(self.dev_index))
+        self.stream = torch.cuda.current_stream().cuda_stream
+        self.comm = None
+        self.exchange = "single GPU"
+        if self.world > 1:
+            self._make_comm(args)
+
+    def _make_comm(self, args):
+        """RCCL communicator behind the C ABI: rank 0 draws the id, gloo ships the 128 bytes."""
+        torch, dist, B = self.torch, self.dist, self.B
+        ok, err = 1, ""
+        want_rccl = args.exchange == "rccl" and not self.folded
+        if want_rccl:
+            try:
+                uid = torch.zeros(B.COMM_ID_BYTES, dtype=torch.uint8)
+                if self.rank == 0:
+                    uid = torch.tensor(list(B.comm_unique_id()), dtype=torch.uint8)
+                dist.broadcast(uid, 0)
+                self.comm = B.Comm.init_rank(bytes(uid.tolist()), self.world, self.rank)
+            except Exception as e:  # noqa: BLE001
+                ok, err = 0, repr(e)
+        flag = torch.tensor([ok if want_rccl else 0], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            self.exchange = "csh_msm_split_rank_dev: RCCL ncclAllGather of window partials over xGMI, behind the C ABI"
+        else:
+            if self.comm is not None:
+                self.comm.destroy()
+                self.comm = None
+            self.exchange = "csh_msm_partial_dev + harness all-gather (gloo) + csh_msm_fold_partials" + (f" [RCCL path unavailable: {err}]" if err else "")
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+        self.B.sync()
+
+    def max_over_ranks(self, x: float) -> float:
+        if self.world == 1:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+
+class MsmJob:
+    """One rank's share of one MSM: known-dlog bases [start, start + n) of the global family k_i = splitmix64(SEED + i) | 1,
+    uniform 253-bit scalars (valid Montgomery encodings of uniform field elements), both resident in HBM."""
+
+    def __init__(self, cx: Ctx, workload: str, start: int, n: int, scalar_seed: int):
+        C, torch, B, L = cx.C, cx.torch, cx.B, cx.L
+        self.cx, self.workload, self.start, self.n = cx, workload, start, n
+        self.curve, self.group, self.pbytes, self.label, self.dtype = WORKLOADS[workload]
+        pts = torch.empty(n * self.pbytes, dtype=torch.uint8, device=cx.dev)
+        B._check(L.csh_util_generate_bases_dev(self.curve, self.group, C.c_uint64((SEED + start) & (2**64 - 1)), C.c_size_t(n), C.c_void_p(pts.data_ptr()), C.c_void_p(cx.stream)))
+        torch.cuda.synchronize()
+        B.sync()
+        self.h = C.c_void_p()
+        B._check(L.csh_bases_upload_dev(self.curve, self.group, C.c_void_p(pts.data_ptr()), C.c_size_t(n), C.c_size_t(0), C.c_void_p(cx.stream), C.byref(self.h)))
+        self.pts_host = None
+        self._pts_dev = pts          # kept only until the caller asks for a host copy (cpu_baseline) or drops it
+        g = torch.Generator(device=cx.dev)
+        g.manual_seed(scalar_seed)
+        sc = torch.randint(0, 1 << 62, (n, 4), dtype=torch.int64, device=cx.dev, generator=g)
+        sc = sc * 2 + torch.randint(0, 2, (n, 4), dtype=torch.int64, device=cx.dev, generator=g)   # 63 random bits per limb
+        sc[:, 3] >>= 2                                                                              # < 2^253 < r on every curve here
+        self.sc = sc
+        torch.cuda.synchronize()
+        self.out = cx.np.zeros(3 * self.pbytes // 16, dtype=cx.np.uint64)
+        self.part = None
+
+    def drop_point_copy(self):
+        self._pts_dev = None
+
+    def points_to_host(self):
+        p = self._pts_dev.cpu().numpy().view(self.cx.np.uint64).reshape(self.n, -1)
+        self._pts_dev = None
+        return p
+
+    def step(self):
+        cx, C, B, L = self.cx, self.cx.C, self.cx.B, self.cx.L
+        if cx.world == 1:
+            B._check(L.csh_msm_dev(self.h, C.c_size_t(0), C.c_size_t(self.n), C.c_void_p(self.sc.data_ptr()), 1, self.out.ctypes.data_as(C.c_void_p), C.c_void_p(cx.stream)))
+        elif cx.comm is not None:
+            B._check(L.csh_msm_split_rank_dev(cx.comm.h, self.h, C.c_size_t(0), C.c_size_t(self.n), C.c_void_p(self.sc.data_ptr()), 1,
+                                              self.out.ctypes.data_as(C.c_void_p), C.c_void_p(cx.stream)))
+        else:
+            from cosnarks_amd.distributed import allgather_and_fold
+            if self.part is None:
+                self.part = cx.torch.zeros(cx.hip.msm_partial_bytes(self.curve, self.group), dtype=cx.torch.uint8, device=cx.dev)
+            self.local()
+            self.out = allgather_and_fold(self.part.cpu(), self.curve, self.group, cx.world, cx.dist)
+        return self.out
+
+    def local(self):
+        """The device part of a step on this rank, no exchange (what the roofline object describes)."""
+        cx, C, B, L = self.cx, self.cx.C, self.cx.B, self.cx.L
+        if cx.world == 1:
+            return self.step()
+        if self.part is None:
+            self.part = cx.torch.zeros(cx.hip.msm_partial_bytes(self.curve, self.group), dtype=cx.torch.uint8, device=cx.dev)
+        B._check(L.csh_msm_partial_dev(self.h, C.c_size_t(0), C.c_size_t(self.n), C.c_void_p(self.sc.data_ptr()), 1, C.c_void_p(self.part.data_ptr()), C.c_void_p(cx.stream)))
+
+    def timed(self, steps: int, warmup: int):
+        cx = self.cx
+        for _ in range(warmup):
+            self.step()
+        cx.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            res = self.step()
+        cx.barrier()
+        dt = cx.max_over_ranks(time.perf_counter() - t0)
+        return dt, res
+
+    def check(self, res) -> bool:
+        """Closed form: the folded MSM must equal (sum over ranks of sum_i s_i k_i) * G. Checker only (uses the oracle)."""
+        from oracle import curves as cv
+        from tests import helpers as H
+        from tests.check_closed_form import dlogs, weighted_sum
+        cx, np = self.cx, self.cx.np
+        name = CURVE_NAMES[self.curve]
+        F = H.FR[name]
+        mine = weighted_sum(self.sc.cpu().numpy().view(np.uint64), dlogs(SEED, self.n, self.start)) % F.p
+        sums = [mine]
+        if cx.world > 1:
+            buf = cx.torch.tensor(list(mine.to_bytes(32, "little")), dtype=cx.torch.uint8)
+            allb = [cx.torch.empty(32, dtype=cx.torch.uint8) for _ in range(cx.world)]
+            cx.dist.all_gather(allb, buf)
+            sums = [int.from_bytes(bytes(t.tolist()), "little") for t in allb]
+        if cx.rank != 0:
+            return True
+        G = cv.CURVES[name][self.group]
+        S = sum(sums) % F.p * F.Rinv % F.p
+        return bool(G.eq(H.jac_to_affine(G, res), G.mul(G.gen, S)))
+
+    def affine_words(self, res):
+        """Jacobian (X, Y, Z in {0, 1}) -> packed affine words (all-zero = infinity), for the bit-exact CPU comparison."""
+        np = self.cx.np
+        w = res.size // 3
+        return np.zeros(2 * w, dtype=np.uint64) if not res[2 * w:].any() else np.ascontiguousarray(res[:2 * w])
+
+    def stage_timing(self, reps=5):
+        cx, B, np = self.cx, self.cx.B, self.cx.np
+        B.tune_set("msm_timing", 1)
+        acc = []
+        for _ in range(reps):
+            self.local()
+            acc.append(B.msm_last_timing())
+        B.tune_set("msm_timing", 0)
+        return [float(np.mean([a[i] for a in acc])) for i in range(6)], B.msm_last_params()
+
+    def free(self):
+        self.cx.L.csh_bases_free(self.h)
+        self.sc = None
+        self._pts_dev = None
+
+
+def msm_roofline(job: MsmJob, rin: dict, log_n_local: int):
+    stage_ms, (c_bits, n_win, lane_len, n_seg) = job.stage_timing()
+    t_acc = stage_ms[3] * 1e-3
+    kname = {"bn254_g1": "Bn254G1", "bn254_g2": "Bn254G2", "bls12_381_g1": "Bls381G1", "bls12_381_g2": "Bls381G2", "grumpkin_g1": "GrumpkinG1"}[job.workload]
+    alg_bytes = job.n * (32.0 + job.pbytes)                  # SURVEY 8d: scalar + affine base per point
+    achieved = alg_bytes / t_acc / 1e9
+    kin = rin.get("kernels", {}).get(f"k_msm_accum<{kname}> 2^{log_n_local}", {})
+    mads = rin.get("mads_per_madd", {}).get(kname)
+    mad_peak = rin.get("mad_peak_T")
+    roof = {"bound": "hbm", "kernel": f"k_msm_accum<{kname}Cfg>", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
+            "frac": round(achieved / 8000.0, 5), "traffic": kin.get("traffic_bytes"), "traffic_source": kin.get("file"),
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "note": "the MSM is integer-ALU bound (v_mad_i64_i32 issue), not HBM bound, by construction (W mixed additions ~ 160 modmuls per 96 B); "
+                    "see `alu` and DESIGN.md 3.1",
+            "msm_params": {"c": c_bits, "windows": n_win, "lane_len": lane_len, "segments": n_seg},
+            "stage_ms": {"digits+hist": stage_ms[0], "scan": stage_ms[1], "scatter": stage_ms[2], "accum": stage_ms[3], "merge+reduce+fold": stage_ms[4],
+                         "total_device": stage_ms[5]}}
+    if mads and mad_peak:
+        a = job.n * n_win * mads / t_acc / 1e12
+        roof["alu"] = {"unit": "Tmad/s", "achieved": round(a, 2), "peak": mad_peak, "frac": round(a / mad_peak, 3), "mads_per_madd": mads,
+                       "madds_per_s": round(job.n * n_win / t_acc), "peak_source": rin.get("mad_peak_source")}
+    return roof
+
+
+def secondary_single_gpu(cx: Ctx, rin: dict, args):
+    """N = 1 extras: MSM 2^24 (BN254 G1 + the config-5 groups, closed-form checked), NTT 2^22 (config 3), Rep3 local_mul_vec,
+    Groth16 prove ms (configs 1, 4 and the synthetic 2^20 circuit)."""
+    hip, B, L, C, np, torch, dev, stream = cx.hip, cx.B, cx.L, cx.C, cx.np, cx.torch, cx.dev, cx.stream
     out = {}
     torch.cuda.synchronize()
-    # MSM 2^24
-    n = 1 << 24
-    pts = torch.empty(n * 64, dtype=torch.uint8, device=dev)
-    B._check(L.csh_util_generate_bases_dev(hip.BN254, hip.G1, C.c_uint64(77), C.c_size_t(n), C.c_void_p(pts.data_ptr()), C.c_void_p(stream)))
-    h = C.c_void_p()
-    B._check(L.csh_bases_upload_dev(hip.BN254, hip.G1, C.c_void_p(pts.data_ptr()), C.c_size_t(n), C.c_size_t(0), C.c_void_p(stream), C.byref(h)))
-    del pts
-    sc = torch.randint(0, 1 << 62, (n, 4), dtype=torch.int64, device=dev)
-    sc[:, 3] >>= 1
-    res = np.zeros(12, dtype=np.uint64)
-    run = lambda: B._check(L.csh_msm_dev(h, C.c_size_t(0), C.c_size_t(n), C.c_void_p(sc.data_ptr()), 1, res.ctypes.data_as(C.c_void_p), C.c_void_p(stream)))
-    run()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(5):
-        run()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / 5
-    out["msm_bn254_g1_2p24"] = {"points_per_s": n / dt, "ms": dt * 1e3}
-    L.csh_bases_free(h)
-    del sc
-    # NTT 2^22 (snarkjs root), data resident
+    cpu_inputs = None
+    for wl, logn, steps in (("bn254_g1", 24, 5), ("bls12_381_g1", 24, 3), ("bls12_381_g2", 24, 2)):
+        job = MsmJob(cx, wl, 0, 1 << logn, 4321 + logn)
+        keep = wl == "bn254_g1" and not args.no_cpu_baseline
+        pts_host = job.points_to_host() if keep else None
+        job.drop_point_copy()
+        dt, res = job.timed(steps, 1)
+        roof = msm_roofline(job, rin, logn)
+        out[f"msm_{wl}_2p{logn}"] = {"points_per_s": job.n * steps / dt, "ms": dt / steps * 1e3, "result_check": job.check(res),
+                                     "roofline": {k: roof[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "traffic", "alu", "stage_ms") if k in roof}}
+        if keep:
+            cpu_inputs = (pts_host, job.sc.cpu().numpy().view(np.uint64), job.affine_words(res))
+        job.free()
+        del job
+    # NTT 2^22 (snarkjs root), data resident; HIP events on the launch stream
     logn = 22
     r = 21888242871839275222246405745257275088548364400416034343698204186575808495617
     g = pow(pow(5, (r - 1) >> 28, r), 1 << (28 - logn), r) * ((1 << 256) % r) % r
@@ -65,8 +288,6 @@ def secondary_metrics(hip, B, L, C, np, torch, dev, stream):
     dom = hip.Domain(hip.BN254, logn, gen)
     data = torch.randint(0, 1 << 62, (1 << logn, 4), dtype=torch.int64, device=dev)
     data[:, 3] >>= 1   # canonical (< r)
-    # HIP events recorded on the stream the kernels run on (torch's default stream handle is 0 = the library's own
-    # per-thread stream here, which torch.cuda.Event would not observe)
     e0, e1 = B.Event(), B.Event()
     dom.ifft_in_to_out_dev(data.data_ptr(), 1, stream)
     e0.record(stream)
@@ -76,11 +297,14 @@ def secondary_metrics(hip, B, L, C, np, torch, dev, stream):
     e1.record(stream)
     ms = e0.elapsed_ms(e1) / 20
     modmuls = (1 << logn) // 2 * logn                      # one twiddle multiplication per butterfly
-    out["ntt_bn254_2p22"] = {"elements_per_s": (1 << logn) / ms * 1e3, "ms": ms, "alg_GBps": 64.0 * (1 << logn) / ms / 1e6,
-                             "hbm_peak_frac": 64.0 * (1 << logn) / ms / 1e6 / 8000.0,
-                             # integer roofline: lazy-field modular multiplications/s against the measured 156 G/s of that
-                             # multiplier; the NTT is ALU-bound, not HBM-bound
-                             "modmul_per_s": modmuls / ms * 1e3, "modmul_peak_frac": modmuls / ms * 1e3 / 156e9}
+    mm_peak = rin.get("modmul_peak_G")
+    kin = rin.get("kernels", {}).get("k_ntt_pass_lazy 2^22", {})
+    out["ntt_bn254_2p22"] = {"elements_per_s": (1 << logn) / ms * 1e3, "ms": ms,
+                             "roofline": {"bound": "hbm", "kernel": "k_ntt_pass_lazy (all passes of one transform)", "achieved": round(64.0 * (1 << logn) / ms / 1e6, 1),
+                                          "peak": 8000.0, "unit": "GB/s", "frac": round(64.0 * (1 << logn) / ms / 1e6 / 8000.0, 4), "traffic": kin.get("traffic_bytes"),
+                                          "traffic_source": kin.get("file"),
+                                          "alu": {"unit": "G modmul/s", "achieved": round(modmuls / ms / 1e6, 1), "peak": mm_peak,
+                                                  "frac": round(modmuls / ms / 1e6 / mm_peak, 3) if mm_peak else None, "peak_source": rin.get("modmul_peak_source")}}}
     dom.free()
     del data
     # Rep3 local_mul_vec 2^24 (192 B/element)
@@ -93,13 +317,17 @@ def secondary_metrics(hip, B, L, C, np, torch, dev, stream):
         x[:, 3] >>= 1
     f = lambda: B._check(L.csh_rep3_local_mul_vec_dev(hip.BN254, C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(m.data_ptr()),
                                                        C.c_void_p(o.data_ptr()), C.c_size_t(n), C.c_void_p(stream)))
-    f()
+    for _ in range(3):
+        f()
     e0.record(stream)
-    for _ in range(10):
+    for _ in range(20):
         f()
     e1.record(stream)
-    ms = e0.elapsed_ms(e1) / 10
-    out["rep3_local_mul_vec_2p24"] = {"elements_per_s": n / ms * 1e3, "ms": ms, "alg_GBps": 192.0 * n / ms / 1e6, "hbm_peak_frac": 192.0 * n / ms / 1e6 / 8000.0}
+    ms = e0.elapsed_ms(e1) / 20
+    kin = rin.get("kernels", {}).get("k_rep3_local_mul 2^24", {})
+    out["rep3_local_mul_vec_2p24"] = {"elements_per_s": n / ms * 1e3, "ms": ms,
+                                      "roofline": {"bound": "hbm", "kernel": "k_rep3_local_mul<Bn254Fr>", "achieved": round(192.0 * n / ms / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
+                                                   "frac": round(192.0 * n / ms / 1e6 / 8000.0, 4), "traffic": kin.get("traffic_bytes"), "traffic_source": kin.get("file")}}
     del a, b, m, o
     # Groth16 plain prove, synthetic 2^20-constraint circuit with a known-dlog key (closed-form checked), key resident
     from cosnarks_amd import groth16 as g16
@@ -128,7 +356,90 @@ def secondary_metrics(hip, B, L, C, np, torch, dev, stream):
                 ts.append((time.perf_counter() - t0) * 1e3)
             small["rep3_poseidon_3_parties_ms"] = sorted(ts)[len(ts) // 2]
     out["groth16_prove_reference_circuits"] = small
+    return out, cpu_inputs
+
+
+def secondary_multi_gpu(cx: Ctx, args):
+    """N > 1 extras: the strong-scaling workloads of BASELINE config 5 (ONE MSM of 2^24 points split over the N ranks) on
+    BLS12-381 G1 / G2 and BN254 G1, closed-form checked; then, on rank 0 alone, the single-thread `csh_msm_split` over all N
+    devices with its three exchanges (hipMemcpyPeer / host copies / grouped RCCL) so both exchanges are measured."""
+    out = {}
+    logn = 24
+    total = 1 << logn
+    per = total // cx.world
+    for wl, steps in (("bn254_g1", 5), ("bls12_381_g1", 3), ("bls12_381_g2", 2)):
+        start = cx.rank * per
+        cnt = per if cx.rank < cx.world - 1 else total - start
+        job = MsmJob(cx, wl, start, cnt, 777 + cx.rank)
+        job.drop_point_copy()
+        dt, res = job.timed(steps, 1)
+        ok = job.check(res)
+        out[f"msm_{wl}_2p{logn}_strong"] = {"points_per_s": total * steps / dt, "ms": dt / steps * 1e3, "result_check": ok, "ranks": cx.world,
+                                            "points_per_rank": per}
+        job.free()
+        del job
+    cx.barrier()
+    if cx.rank == 0 and not cx.folded:
+        try:
+            out["single_process_split_bn254_g1_2p24"] = single_process_split(cx, 0, 0, 64, logn)
+        except Exception as e:  # noqa: BLE001
+            out["single_process_split_bn254_g1_2p24"] = {"error": repr(e)}
+    cx.barrier()
     return out
+
+
+def single_process_split(cx: Ctx, curve, group, pbytes, logn):
+    """Rank 0 drives every GPU of the node from one thread: csh_msm_split with PEER / HOST / RCCL exchange, ms per MSM."""
+    C, B, L, torch, np = cx.C, cx.B, cx.L, cx.torch, cx.np
+    k = cx.world
+    total = 1 << logn
+    per = total // k
+    bases, scal = [], []
+    for d in range(k):
+        B._check(L.csh_init(d))
+        with torch.cuda.device(d):
+            dev = torch.device("cuda", d)
+            pts = torch.empty(per * pbytes, dtype=torch.uint8, device=dev)
+            B._check(L.csh_util_generate_bases_dev(curve, group, C.c_uint64(SEED + d * per), C.c_size_t(per), C.c_void_p(pts.data_ptr()), None))
+            B.sync()
+            h = C.c_void_p()
+            B._check(L.csh_bases_upload_dev(curve, group, C.c_void_p(pts.data_ptr()), C.c_size_t(per), C.c_size_t(0), None, C.byref(h)))
+            del pts
+            sc = torch.randint(0, 1 << 61, (per, 4), dtype=torch.int64, device=dev)
+            torch.cuda.synchronize(d)
+            bases.append(h)
+            scal.append(sc)
+    B._check(L.csh_init(cx.dev_index))
+    hs = (C.c_void_p * k)(*[h.value for h in bases])
+    offs = (C.c_size_t * k)(*([0] * k))
+    cnts = (C.c_size_t * k)(*([per] * k))
+    ptrs = (C.c_void_p * k)(*[s.data_ptr() for s in scal])
+    res = {}
+    comms = None
+    outs = {}
+    for name, mode in (("hipMemcpyPeer", B.SPLIT_PEER), ("host_copies", B.SPLIT_HOST), ("rccl_grouped", B.SPLIT_RCCL)):
+        cm = None
+        if mode == B.SPLIT_RCCL:
+            comms = B.Comm.init_all(list(range(k)))
+            cm = (C.c_void_p * k)(*[c.h.value for c in comms])
+        o = np.zeros(3 * pbytes // 16, dtype=np.uint64)
+        run = lambda: B._check(L.csh_msm_split(hs, offs, cnts, ptrs, C.c_size_t(k), 1, mode, cm, o.ctypes.data_as(C.c_void_p)))
+        run()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            run()
+        res[name + "_ms"] = (time.perf_counter() - t0) / 5 * 1e3
+        outs[name] = o.copy()
+    res["exchanges_agree"] = bool(all((v == outs["hipMemcpyPeer"]).all() for v in outs.values()))
+    res["points_per_s_best"] = total / (min(v for kk, v in res.items() if kk.endswith("_ms")) * 1e-3)
+    if comms:
+        for c in comms:
+            c.destroy()
+    for d, h in enumerate(bases):
+        B._check(L.csh_init(d))
+        L.csh_bases_free(h)
+    B._check(L.csh_init(cx.dev_index))
+    return res
 
 
 def main():
@@ -137,175 +448,81 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log-n", type=int, default=20)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="bn254_g1")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--exchange", choices=["rccl", "harness"], default="rccl", help="N > 1: RCCL behind the C ABI (default) or the gloo harness all-gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the secondary metrics (MSM 2^24, NTT 2^22, Groth16 prove ms)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary metrics")
     args = ap.parse_args()
 
-    import torch  # FIRST: torch bundles its own libamdhip64.so.7; our library must bind to the same runtime
-    import torch.distributed as dist
+    cx = Ctx(args)
+    rin = load_roofline_inputs()
+    world, rank = cx.world, cx.rank
+    if args.scaling == "weak":
+        n_local = 1 << args.log_n
+        start = rank * n_local
+        total = world * n_local
+    else:
+        total = 1 << args.log_n
+        per = total // world
+        start = rank * per
+        n_local = per if rank < world - 1 else total - start
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    # One rank per GPU over RCCL is the real configuration. BENCH_DIST_BACKEND=gloo (with ranks folded onto the GPUs
-    # that exist) is a debugging aid to exercise the N > 1 code path on a box with fewer GPUs than ranks.
-    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
-    dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    if world > 1:
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-
-    import ctypes as C
-
-    import numpy as np
-
-    import cosnarks_amd as hip
-    from cosnarks_amd import bindings as B
-    L = hip.lib()
-    B._check(L.csh_init(dev_index))
-
-    n = 1 << args.log_n
-    stream = torch.cuda.current_stream().cuda_stream
-
-    # ---- synthetic inputs, generated on the device (known-dlog bases, uniform 253-bit Montgomery scalars)
-    seed = 0x00C0FFEE5EED + rank * (1 << 32)
-    pts = torch.empty(n * 64, dtype=torch.uint8, device=dev)
-    B._check(L.csh_util_generate_bases_dev(hip.BN254, hip.G1, C.c_uint64(seed), C.c_size_t(n), C.c_void_p(pts.data_ptr()), C.c_void_p(stream)))
-    torch.cuda.synchronize()
-    bases_h = C.c_void_p()
-    B._check(L.csh_bases_upload_dev(hip.BN254, hip.G1, C.c_void_p(pts.data_ptr()), C.c_size_t(n), C.c_size_t(0), C.c_void_p(stream), C.byref(bases_h)))
-    del pts
-    g = torch.Generator(device=dev)
-    g.manual_seed(1234 + rank)
-    sc = torch.randint(0, 1 << 62, (n, 4), dtype=torch.int64, device=dev, generator=g)
-    sc = sc * 2 + torch.randint(0, 2, (n, 4), dtype=torch.int64, device=dev, generator=g)   # 63 random bits/limb
-    sc[:, 3] >>= 2                                                                           # < 2^253 < r
-    torch.cuda.synchronize()
-
-    out = np.zeros(12, dtype=np.uint64)
-    pbytes = hip.msm_partial_bytes(hip.BN254, hip.G1)
-    part = torch.zeros(pbytes, dtype=torch.uint8, device=dev)
-    from cosnarks_amd.distributed import allgather_and_fold
-
-    def step():
-        if world == 1:
-            B._check(L.csh_msm_dev(bases_h, C.c_size_t(0), C.c_size_t(n), C.c_void_p(sc.data_ptr()), 1, out.ctypes.data_as(C.c_void_p), C.c_void_p(stream)))
-            return out
-        B._check(L.csh_msm_partial_dev(bases_h, C.c_size_t(0), C.c_size_t(n), C.c_void_p(sc.data_ptr()), 1, C.c_void_p(part.data_ptr()), C.c_void_p(stream)))
-        return allgather_and_fold(part if backend == "nccl" else part.cpu(), hip.BN254, hip.G1, world, dist)   # RCCL all-gather over xGMI + host fold
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        B.sync()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    job = MsmJob(cx, args.workload, start, n_local, 1234 + rank)
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "bn254_g1"
+    pts_host = job.points_to_host() if want_cpu else None
+    job.drop_point_copy()
+    dt, res = job.timed(args.steps, args.warmup)
     ms_per_step = dt / args.steps * 1e3
-    value = world * n * args.steps / dt
+    value = total * args.steps / dt
 
-    # ---- per-kernel timing for the roofline object (separate untimed passes, HIP events on `stream`)
-    roofline = None
-    stage_ms = None
-    def local_msm():  # the device part of a step on this rank (no collective): what the roofline object describes
-        if world == 1:
-            return step()
-        B._check(L.csh_msm_partial_dev(bases_h, C.c_size_t(0), C.c_size_t(n), C.c_void_p(sc.data_ptr()), 1, C.c_void_p(part.data_ptr()), C.c_void_p(stream)))
+    log_local = max(0, n_local.bit_length() - 1)
+    roofline = msm_roofline(job, rin, log_local)          # every rank runs the same untimed passes (keeps the ranks in step)
+    check = None if args.no_check else job.check(res)
 
-    if True:  # every rank runs the same untimed passes (keeps the ranks in step); rank 0 reports
-        os.environ["CSH_MSM_TIMING"] = "1"
-        acc = []
-        for _ in range(5):
-            local_msm()
-            acc.append(B.msm_last_timing())
-        del os.environ["CSH_MSM_TIMING"]
-        stage_ms = [float(np.mean([a[i] for a in acc])) for i in range(6)]
-        c_bits, n_win, lane_len, n_seg = B.msm_last_params()
-        t_acc = stage_ms[3] * 1e-3
-        alg_bytes = n * 96.0                                 # 32 B scalar + 64 B affine base per point
-        achieved = alg_bytes / t_acc / 1e9
-        # HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/ (FETCH_SIZE x2
-        # per the gfx950 correction + WRITE_SIZE, KiB -> bytes); measured for the default 2^20 workload only.
-        traffic = PMC_TRAFFIC_BYTES.get(args.log_n)
-        roofline = {"bound": "hbm", "kernel": "k_msm_accum<Bn254G1>", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
-                    "frac": round(achieved / 8000.0, 5), "traffic": traffic,
-                    "traffic_source": "profiles/r01_f_msm_bn254g1_2p20_pmc_hbm_bytes.csv" if traffic else None,
-                    "note": "MSM is integer-ALU (v_mad_u64_u32 / v_mad_i64_i32) bound, not HBM bound; see DESIGN.md 3.1",
-                    # integer roofline of the same kernel: mixed additions x 64-bit multiply-adds per addition (ISA count of
-                    # the k_msm_accum<Bn254G1> loop body) over the measured issue peak of those instructions
-                    # (tools/gpu_probe.py microbench, profiles/*probe*: 31e12 lane-ops/s)
-                    "alu": {"unit": "Tmad/s", "achieved": round(n * n_win * MADS_PER_MADD / t_acc / 1e12, 2), "peak": MAD_PEAK_T,
-                            "frac": round(n * n_win * MADS_PER_MADD / t_acc / 1e12 / MAD_PEAK_T, 3), "mads_per_madd": MADS_PER_MADD,
-                            "madds_per_s": round(n * n_win / t_acc, 0)},
-                    "msm_params": {"c": c_bits, "windows": n_win, "lane_len": lane_len, "segments": n_seg},
-                    "stage_ms": {"hist": stage_ms[0], "scan": stage_ms[1], "scatter": stage_ms[2], "accum": stage_ms[3],
-                                 "reduce": stage_ms[4], "total_device": stage_ms[5]}}
-
-    # ---- correctness of the timed result: closed form (sum s_i k_i) * G via a second, tiny MSM
-    check = None
-    if not args.no_check and args.log_n <= 20:
-        if world == 1:
-            from tests.check_closed_form import closed_form_ok
-            check = bool(closed_form_ok(hip, L, seed, n, sc.cpu().numpy(), res))
-        else:
-            # every rank contributes sum_i s_i k_i of its own range (32-byte integer), rank 0 checks the folded MSM
-            from tests.check_closed_form import closed_form_ok_split, local_dlog_sum
-            mine = local_dlog_sum(seed, n, sc.cpu().numpy())
-            buf = torch.tensor(list(mine.to_bytes(32, "little")), dtype=torch.uint8, device=dev if backend == "nccl" else "cpu")
-            allb = torch.empty(32 * world, dtype=torch.uint8, device=buf.device)
-            dist.all_gather_into_tensor(allb, buf)
-            if rank == 0:
-                raw = bytes(allb.cpu().tolist())
-                sums = [int.from_bytes(raw[32 * i:32 * i + 32], "little") for i in range(world)]
-                check = bool(closed_form_ok_split(sums, res))
+    extras, cpu_inputs24 = None, None
+    if not args.no_extras:
+        try:
+            if world == 1:
+                keep = (job, pts_host)
+                extras, cpu_inputs24 = secondary_single_gpu(cx, rin, args)
+            else:
+                extras = secondary_multi_gpu(cx, args)
+        except Exception as e:  # noqa: BLE001 -- extras never break the headline
+            extras = {"error": repr(e)}
 
     cpu_baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if want_cpu:
         try:
-            from oracle.cbridge import cpu_msm_baseline
-            cpu_baseline = cpu_msm_baseline(target_seconds=12.0)
+            from oracle.cbridge import cpu_baseline_suite
+            sc_host = job.sc.cpu().numpy().view(cx.np.uint64)
+            p24, s24, a24 = cpu_inputs24 if cpu_inputs24 else (None, None, None)
+            cpu_baseline = cpu_baseline_suite(pts_host, sc_host, job.affine_words(res), p24, s24, a24)
+            cpu_baseline["gpu_over_cpu_2p20"] = round(value / cpu_baseline["value"], 1)
+            if extras and "msm_2p24" in cpu_baseline and "msm_bn254_g1_2p24" in extras:
+                cpu_baseline["gpu_over_cpu_2p24"] = round(extras["msm_bn254_g1_2p24"]["points_per_s"] / cpu_baseline["msm_2p24"]["points_per_s"], 1)
         except Exception as e:  # the baseline is a reported extra, never part of the measured path
             cpu_baseline = {"error": repr(e)}
 
-    # ---- secondary metrics of BASELINE.json (untimed extras, N = 1 only): MSM 2^24, NTT 2^22, Groth16 prove ms
-    extras = None
-    if rank == 0 and world == 1 and not args.no_extras:
-        extras = {}
-        try:
-            extras.update(secondary_metrics(hip, B, L, C, np, torch, dev, stream))
-        except Exception as e:
-            extras["error"] = repr(e)
-
     if rank == 0:
+        label = WORKLOADS[args.workload][3]
+        per_rank = f"2^{args.log_n} points per GPU" if args.scaling == "weak" else f"2^{args.log_n} points in total, {total // world} per GPU"
         line = {
-            "metric": "BN254 G1 MSM points/sec", "value": value, "unit": "points/s", "n_gpus": world,
+            "metric": f"{label} MSM points/sec", "value": value, "unit": "points/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "i32x9 29-bit-limb Montgomery, i64 accumulate (BN254 Fq 254-bit)", "data": "synthetic",
-            "config": {"workload": f"BN254 G1 Pippenger MSM, 2^{args.log_n} uniform scalars/points per GPU (BASELINE config 2)",
-                       "points_per_gpu": n, "split": "contiguous point ranges + RCCL all-gather of window partials" if world > 1 else "single GPU"},
+            "scaling": args.scaling, "vs_baseline": None, "dtype": WORKLOADS[args.workload][4], "data": "synthetic",
+            "config": {"workload": f"{label} Pippenger MSM, uniform scalars / known-dlog points, {per_rank}"
+                                   + (" (BASELINE config 2)" if args.workload == "bn254_g1" and args.log_n == 20 else "")
+                                   + (" (BASELINE config 5)" if args.workload.startswith("bls12_381") and args.log_n == 24 and args.scaling == "strong" else ""),
+                       "points_total": total, "points_per_gpu": n_local, "split": cx.exchange},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "result_check": check, "secondary": extras,
         }
         print(json.dumps(line))
+    if cx.comm is not None:
+        cx.comm.destroy()
     if world > 1:
-        dist.destroy_process_group()
+        cx.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -89,6 +89,28 @@ __global__ __launch_bounds__(UB_BLK) void k_modmul29(const Bn254Fq* in, Bn254Fq*
   out[i] = Fq29::add(x, y).to_fp();
 }
 
+// FETCH_SIZE / WRITE_SIZE calibration (tools/gpu_calib.py under rocprofv3 --pmc): every lane reads ONE record of REC bytes
+// from a table far larger than the 256 MiB Infinity Cache -- at a hashed index (the access pattern of k_msm_accum's base
+// gather: REC = 64 / 96 / 128 / 192 for the four groups) or at its own index (SEQ: the coalesced streaming pattern the
+// guide's x2 correction was calibrated on) -- and writes 4 bytes. Known traffic: n * REC read, n * 4 written.
+template <int REC, bool SEQ>
+__global__ __launch_bounds__(256) void k_gather_calib(const uint4* __restrict__ table, uint32_t rec_mask, uint32_t* __restrict__ out, uint32_t n) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  uint64_t x = (uint64_t)i + 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  const uint32_t r = SEQ ? (i & rec_mask) : ((uint32_t)(x ^ (x >> 31)) & rec_mask);
+  const uint4* p = table + (size_t)r * (REC / 16);
+  uint4 acc = p[0];
+#pragma unroll
+  for (int k = 1; k < REC / 16; ++k) {
+    const uint4 v = p[k];
+    acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w;
+  }
+  out[i] = acc.x ^ acc.y ^ acc.z ^ acc.w;
+}
+
 template <class K, class... Args>
 static int time_kernel(K kern, dim3 grid, dim3 blk, float* ms, Args... args) {
   hipStream_t st = resolve_stream(nullptr);
@@ -159,6 +181,37 @@ int csh_microbench(int kind, int iters, double* ops_per_s) {
   if (rc != CSH_OK) return rc;
   *ops_per_s = 2.0 * iters * threads / (ms * 1e-3);
   return CSH_OK;
+}
+
+// One calibration launch (+ a warm-up): n = 2^log_n lanes, each reading one rec_bytes record out of 2^log_records.
+// ms: duration of the timed launch. bytes_read / bytes_written: the known traffic of that launch.
+int csh_microbench_gather(int rec_bytes, int log_records, int log_n, int sequential, float* ms, double* bytes_read, double* bytes_written) {
+  CSH_REQUIRE(ms && bytes_read && bytes_written, "NULL argument");
+  CSH_REQUIRE(rec_bytes == 64 || rec_bytes == 96 || rec_bytes == 128 || rec_bytes == 192, "record size must be 64, 96, 128 or 192");
+  CSH_REQUIRE(log_records >= 10 && log_records <= 27 && log_n >= 10 && log_n <= 27, "bad sizes");
+  CSH_TRY(ensure_device());
+  const size_t recs = size_t(1) << log_records, n = size_t(1) << log_n;
+  void* table;
+  uint32_t* out;
+  CSH_HIP(hipMalloc(&table, recs * rec_bytes));
+  CSH_HIP(hipMalloc((void**)&out, n * 4));
+  CSH_HIP(hipMemset(table, 0x5a, recs * rec_bytes));
+  const dim3 grid((unsigned)((n + 255) / 256)), blk(256);
+  const uint32_t mask = (uint32_t)(recs - 1);
+  int rc = CSH_OK;
+#define CSH_CALIB(REC)                                                                                                             \
+  rc = sequential ? time_kernel(k_gather_calib<REC, true>, grid, blk, ms, (const uint4*)table, mask, out, (uint32_t)n)              \
+                  : time_kernel(k_gather_calib<REC, false>, grid, blk, ms, (const uint4*)table, mask, out, (uint32_t)n)
+  if (rec_bytes == 64) { CSH_CALIB(64); }
+  else if (rec_bytes == 96) { CSH_CALIB(96); }
+  else if (rec_bytes == 128) { CSH_CALIB(128); }
+  else { CSH_CALIB(192); }
+#undef CSH_CALIB
+  (void)hipFree(table);
+  (void)hipFree(out);
+  *bytes_read = (double)n * rec_bytes;
+  *bytes_written = (double)n * 4;
+  return rc;
 }
 
 // Host-side self-check hook for the 29-bit representation: out = to_fp(mul29(from_fp(a), from_fp(b)))

@@ -172,6 +172,151 @@ static void EC(msm)(EC(aff)* out, const EC(aff)* points, const uint64_t* scalars
   free(all_buckets); free(wsum); free(sc);
 }
 
+/* ---- second, faster restatement: the CPU baseline ("port") and the full-size checker ---------------------------------
+ * Same function (msm_unchecked / msm_bigint), built the way a tuned CPU Pippenger is: Booth-recoded signed c-bit digits
+ * (2^(c-1) buckets per window, no carry chain between windows), XYZZ bucket accumulators with mixed additions (8M + 2S,
+ * EFD madd-2008-s), thread-private bucket arrays allocated and first-touched by the thread that uses them, dynamic
+ * (window, point-chunk) tasks, software prefetch of the next bucket / point. Deliberately different from both the
+ * product (sort-based, lane runs, lazy 29-bit limbs, carry-propagating recoding) and EC(msm) above (Jacobian, unsigned
+ * digits), so the three agree only if all three are right. Not arkworks: a restatement of the published algorithm shape. */
+typedef struct { FE(t) x, y, zz, zzz; } EC(xyzz); /* infinity: zz = 0 */
+static inline void EC(xyzz_set_inf)(EC(xyzz)* p) { FE(set_zero)(&p->x); FE(set_zero)(&p->y); FE(set_zero)(&p->zz); FE(set_zero)(&p->zzz); }
+static inline int EC(xyzz_is_inf)(const EC(xyzz)* p) { return FE(is_zero)(&p->zz); }
+
+static void EC(xyzz_dbl_aff)(EC(xyzz)* r, const FE(t)* x, const FE(t)* y) { /* mdbl-2008-s-1, a = 0 */
+  FE(t) u, v, w, s, m, t;
+  FE(dbl)(&u, y); FE(sqr)(&v, &u); FE(mul)(&w, &u, &v); FE(mul)(&s, x, &v);
+  FE(sqr)(&m, x); FE(dbl)(&t, &m); FE(add)(&m, &t, &m);
+  FE(sqr)(&r->x, &m); FE(dbl)(&t, &s); FE(sub)(&r->x, &r->x, &t);
+  FE(sub)(&t, &s, &r->x); FE(mul)(&t, &m, &t); FE(mul)(&u, &w, y); FE(sub)(&r->y, &t, &u);
+  r->zz = v; r->zzz = w;
+}
+/* a += (qx, +-qy) */
+static inline void EC(xyzz_madd)(EC(xyzz)* a, const EC(aff)* q, int negate) {
+  if (EC(aff_is_inf)(q)) return;
+  FE(t) qy = q->y;
+  if (negate) FE(neg)(&qy, &qy);
+  if (EC(xyzz_is_inf)(a)) { a->x = q->x; a->y = qy; FE(set_one)(&a->zz); FE(set_one)(&a->zzz); return; }
+  FE(t) u2, s2, p, r, pp, ppp, qq, t;
+  FE(mul)(&u2, &q->x, &a->zz); FE(mul)(&s2, &qy, &a->zzz);
+  FE(sub)(&p, &u2, &a->x); FE(sub)(&r, &s2, &a->y);
+  if (FE(is_zero)(&p)) {
+    if (FE(is_zero)(&r)) EC(xyzz_dbl_aff)(a, &q->x, &qy); else EC(xyzz_set_inf)(a);
+    return;
+  }
+  FE(sqr)(&pp, &p); FE(mul)(&ppp, &p, &pp); FE(mul)(&qq, &a->x, &pp);
+  FE(sqr)(&t, &r); FE(sub)(&t, &t, &ppp); FE(sub)(&t, &t, &qq); FE(sub)(&t, &t, &qq);
+  FE(t) y3; FE(sub)(&y3, &qq, &t); FE(mul)(&y3, &r, &y3); FE(mul)(&u2, &a->y, &ppp); FE(sub)(&a->y, &y3, &u2);
+  a->x = t;
+  FE(mul)(&a->zz, &a->zz, &pp); FE(mul)(&a->zzz, &a->zzz, &ppp);
+}
+static void EC(xyzz_to_jac)(EC(jac)* r, const EC(xyzz)* p) { /* (X, Y, ZZ, ZZZ) -> Jacobian (X ZZZ^2 ZZ, Y ZZZ^3 ZZ^3 ... ) via z = ZZZ/ZZ */
+  if (EC(xyzz_is_inf)(p)) { EC(jac_set_inf)(r); return; }
+  /* z = zzz / zz satisfies z^2 = zz, z^3 = zzz. Avoid the inversion: scale to z' = zz * zzz (z'^2 = zz^2 zzz^2 = zz * zz^3... ) --
+   * simpler and exact: x/zz, y/zzz are the affine coordinates; Jacobian with Z = zz*zzz: X = x * zz * zzz^2, Y = y * zz^3 * zzz^2 */
+  FE(t) z, z2, t;
+  FE(mul)(&z, &p->zz, &p->zzz);            /* Z = zz zzz, Z^2 = zz^2 zzz^2, Z^3 = zz^3 zzz^3 */
+  FE(sqr)(&z2, &p->zzz);                   /* zzz^2 */
+  FE(mul)(&t, &p->x, &p->zz); FE(mul)(&r->x, &t, &z2);                 /* x/zz * Z^2 = x zz zzz^2 */
+  FE(sqr)(&t, &p->zz); FE(mul)(&t, &t, &p->zz); FE(mul)(&t, &t, &z2); /* zz^3 zzz^2 */
+  FE(mul)(&r->y, &p->y, &t);                                          /* y/zzz * Z^3 */
+  r->z = z;
+}
+
+/* Booth digit of window w (c bits): d in [-2^(c-1), 2^(c-1)]; sum_w d_w 2^(wc) = s when W*c > bit length of s */
+static inline int32_t EC(booth)(const uint64_t* s, int w, int c) {
+  const int bit = w * c - 1; /* window [bit, bit + c] */
+  uint64_t v;
+  if (bit < 0) {
+    v = (s[0] << 1) & ((1ull << (c + 1)) - 1);
+  } else {
+    const int limb = bit >> 6, off = bit & 63;
+    unsigned __int128 two = limb < SF_N ? s[limb] : 0;
+    if (limb + 1 < SF_N) two |= (unsigned __int128)s[limb + 1] << 64;
+    v = (uint64_t)(two >> off) & ((1ull << (c + 1)) - 1);
+  }
+  const int32_t d = (int32_t)((v + 1) >> 1);
+  return (v >> c) ? d - (int32_t)(1u << c) : d;
+}
+
+static void EC(msm_fast)(EC(aff)* out, const EC(aff)* points, const uint64_t* scalars, size_t n, int mont, int nthreads, int force_c, double* stage_s) {
+  EC(jac) total; EC(jac_set_inf)(&total);
+  if (n == 0) { EC(jac_to_aff)(out, &total); return; }
+  const double t_0 = omp_get_wtime();
+  uint64_t* sc = (uint64_t*)scalars;
+  uint64_t* sc_own = NULL;
+  if (mont) {
+    sc_own = (uint64_t*)malloc(n * SF_N * 8);
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+    for (size_t i = 0; i < n; i++) {
+      SF(t) v; memcpy(&v, scalars + i * SF_N, SF_N * 8);
+      SF(from_mont)(&v, &v);
+      memcpy(sc_own + i * SF_N, &v, SF_N * 8);
+    }
+    sc = sc_own;
+  }
+  /* window width: minimise per-thread work  W * (n + reduce(c)) / T  with the bucket array (2^(c-1) XYZZ) preferably
+   * inside a core's L2 (<= 1 MiB); tasks = W x chunks >= 4 T for balance under dynamic scheduling */
+  int c = force_c;
+  if (c < 2 || c > 20) {
+    double best = 1e300; c = 8;
+    for (int cc = 4; cc <= 18; cc++) {
+      const int ww = (SF_BITS + cc) / cc;                   /* W*c > bits: Booth needs the spare top bit */
+      const double nb = (double)((size_t)1 << (cc - 1));
+      const int ch = nthreads == 1 ? 1 : (4 * nthreads + ww - 1) / ww;
+      double cost = (double)ww * ((double)n + 3.0 * nb * ch);       /* bucket reduction: 2 full additions ~ 3 mixed per bucket */
+      if (nb * sizeof(EC(xyzz)) > (1 << 20)) cost *= 1.25;          /* L2 misses on every bucket touch */
+      if (cost < best) { best = cost; c = cc; }
+    }
+    if (n < 32) c = 3;
+  }
+  const int W = (SF_BITS + c) / c;
+  int chunks = nthreads == 1 ? 1 : (4 * nthreads + W - 1) / W;
+  if ((size_t)chunks * 256 > n) chunks = (int)(n / 256);
+  if (chunks < 1) chunks = 1;
+  const size_t per = (n + chunks - 1) / chunks;
+  const size_t nb = (size_t)1 << (c - 1);
+  EC(jac)* wsum = (EC(jac)*)malloc(sizeof(EC(jac)) * (size_t)W * chunks);
+  const int ntasks = W * chunks;
+  const double t_1 = omp_get_wtime();
+#pragma omp parallel num_threads(nthreads)
+  {
+    EC(xyzz)* buckets = (EC(xyzz)*)malloc(sizeof(EC(xyzz)) * nb); /* private, first-touched here */
+#pragma omp for schedule(dynamic, 1)
+    for (int task = 0; task < ntasks; task++) {
+      const int w = task / chunks, ch = task % chunks;
+      size_t lo = (size_t)ch * per, hi = lo + per; if (hi > n) hi = n; if (lo > hi) lo = hi;
+      for (size_t b = 0; b < nb; b++) FE(set_zero)(&buckets[b].zz);
+      const size_t PF = 8;
+      for (size_t i = lo; i < hi; i++) {
+        if (i + PF < hi) {
+          const int32_t dn = EC(booth)(sc + (i + PF) * SF_N, w, c);
+          if (dn) __builtin_prefetch(&buckets[(dn < 0 ? -dn : dn) - 1], 1, 1);
+          __builtin_prefetch(&points[i + PF], 0, 0);
+        }
+        const int32_t d = EC(booth)(sc + i * SF_N, w, c);
+        if (d > 0) EC(xyzz_madd)(&buckets[d - 1], &points[i], 0);
+        else if (d < 0) EC(xyzz_madd)(&buckets[-d - 1], &points[i], 1);
+      }
+      EC(jac) running, acc, bj; EC(jac_set_inf)(&running); EC(jac_set_inf)(&acc);
+      for (size_t b = nb; b-- > 0;) {
+        if (!EC(xyzz_is_inf)(&buckets[b])) { EC(xyzz_to_jac)(&bj, &buckets[b]); EC(jac_add)(&running, &running, &bj); }
+        EC(jac_add)(&acc, &acc, &running);
+      }
+      wsum[task] = acc;
+    }
+    free(buckets);
+  }
+  const double t_2 = omp_get_wtime();
+  for (int w = W - 1; w >= 0; w--) {
+    for (int k = 0; k < c; k++) EC(jac_dbl)(&total, &total);
+    for (int ch = 0; ch < chunks; ch++) EC(jac_add)(&total, &total, &wsum[w * chunks + ch]);
+  }
+  EC(jac_to_aff)(out, &total);
+  if (stage_s) { stage_s[0] = t_1 - t_0; stage_s[1] = t_2 - t_1; stage_s[2] = omp_get_wtime() - t_2; stage_s[3] = (double)c; stage_s[4] = (double)W; stage_s[5] = (double)chunks; }
+  free(wsum); free(sc_own);
+}
+
 /* bases[i] = (splitmix64(seed+i)|1) * G (the product's csh_util_generate_bases_dev family) */
 static void EC(gen_bases)(EC(aff)* out, const EC(aff)* gen, uint64_t seed, size_t n, int nthreads) {
 #pragma omp parallel for schedule(static) num_threads(nthreads)

@@ -142,6 +142,17 @@ int oc_msm(int curve, int group, const uint64_t* points, const uint64_t* scalars
   return -1;
 }
 
+/* The tuned restatement (Booth digits, XYZZ buckets, thread-private bucket arrays): cpu_baseline "port" + full-size checker.
+ * force_c = 0: cost model. stage_s (nullable, 6 doubles): [scalar conversion s, bucket tasks s, fold s, c, W, chunks]. */
+int oc_msm_fast(int curve, int group, const uint64_t* points, const uint64_t* scalars, size_t n, int mont, int nthreads, int force_c, double* stage_s, uint64_t* out) {
+  nthreads = threads_or_default(nthreads);
+  if (curve == 0 && group == 0) { bn_g1_msm_fast((bn_g1_aff*)out, (const bn_g1_aff*)points, scalars, n, mont, nthreads, force_c, stage_s); return 0; }
+  if (curve == 0 && group == 1) { bn_g2_msm_fast((bn_g2_aff*)out, (const bn_g2_aff*)points, scalars, n, mont, nthreads, force_c, stage_s); return 0; }
+  if (curve == 1 && group == 0) { bl_g1_msm_fast((bl_g1_aff*)out, (const bl_g1_aff*)points, scalars, n, mont, nthreads, force_c, stage_s); return 0; }
+  if (curve == 1 && group == 1) { bl_g2_msm_fast((bl_g2_aff*)out, (const bl_g2_aff*)points, scalars, n, mont, nthreads, force_c, stage_s); return 0; }
+  return -1;
+}
+
 int oc_generate_bases(int curve, int group, uint64_t seed, size_t n, int nthreads, uint64_t* out) {
   nthreads = threads_or_default(nthreads);
   if (curve == 0 && group == 0) { bn_g1_gen_bases((bn_g1_aff*)out, (const bn_g1_aff*)BN254_G1_GEN, seed, n, nthreads); return 0; }

@@ -126,6 +126,18 @@ def test_c_msm_matches_python(curve, group):
         for mont in (True, False):
             got = cbridge.msm(H.CURVE_IDS[curve], group, cv.pack_points(G, pts), H.pack(F, sc, mont=mont), montgomery=mont)
             assert G.eq(cv.unpack_points(G, got)[0], want)
+            # the tuned restatement (Booth digits, XYZZ buckets; cpu_baseline "port" + full-size checker), several widths/threads
+            for c, th in ((0, 0), (2, 1), (5, 3), (11, 2), (16, 1)):
+                got = cbridge.msm_fast(H.CURVE_IDS[curve], group, cv.pack_points(G, pts), H.pack(F, sc, mont=mont), montgomery=mont, threads=th, c=c)
+                assert G.eq(cv.unpack_points(G, got)[0], want), (n, mont, c, th)
+    # doubling / cancellation inside one bucket, all-equal scalars, all-infinity bases
+    pts = H.rand_points(G, 12, r)
+    pts[1], pts[2], pts[5] = pts[0], pts[0], G.neg(pts[4])
+    for sc in ([7] * 12, [F.p - 1] * 12, [0] * 12, [3, 3, 3, 9, 5, 5] * 2):
+        got = cbridge.msm_fast(H.CURVE_IDS[curve], group, cv.pack_points(G, pts), H.pack(F, sc), c=4)
+        assert G.eq(cv.unpack_points(G, got)[0], G.msm(pts, sc)), sc
+    got = cbridge.msm_fast(H.CURVE_IDS[curve], group, cv.pack_points(G, [None] * 5), H.pack(F, [5] * 5))
+    assert cv.unpack_points(G, got)[0] is None
     # naive double-and-add cross-check of the Python Pippenger itself
     pts = H.rand_points(G, 6, r)
     sc = H.rand_elems(F, 6, r)
@@ -166,6 +178,7 @@ def test_c_generated_bases_closed_form():
     sc[:, 3] >>= np.uint64(3)
     got = cv.unpack_points(G, cbridge.msm(0, 0, pts, sc, True))[0]
     assert G.eq(got, closed_form_point("bn254", 0, 77, n, sc, True))
+    assert (cbridge.msm_fast(0, 0, pts, sc, True) == cbridge.msm(0, 0, pts, sc, True)).all()
 
 
 @pytest.mark.parametrize("curve,generator", [("bn254", 5), ("bls12_381", 7)])

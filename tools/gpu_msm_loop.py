@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Lean MSM loop for profiling (no torch): known-dlog bases + uniform scalars resident in HBM, `reps` csh_msm_dev calls per
+(curve, group, log n) job. Prints stage timings (HIP events) per job. Usage: gpu_msm_loop.py [--reps 5] curve:group:logn ..."""
+import ctypes as C
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+import cosnarks_amd as hip
+from cosnarks_amd import bindings as B
+
+L = hip.lib()
+args = sys.argv[1:]
+reps = 5
+if args and args[0] == "--reps":
+    reps = int(args[1])
+    args = args[2:]
+timing = not os.environ.get("LOOP_NO_TIMING")
+for job in args:
+    curve, group, logn = (int(x) for x in job.split(":"))
+    n = 1 << logn
+    pb = hip.point_bytes(curve, group)
+    buf = hip.DeviceBuffer(n * pb)
+    B._check(L.csh_util_generate_bases_dev(curve, group, C.c_uint64(1), C.c_size_t(n), buf.ptr, None))
+    B.sync()
+    h = C.c_void_p()
+    B._check(L.csh_bases_upload_dev(curve, group, buf.ptr, C.c_size_t(n), C.c_size_t(0), None, C.byref(h)))
+    buf.free()
+    rs = np.random.RandomState(1)
+    limbs = rs.randint(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    limbs[:, 3] >>= np.uint64(3)
+    sc = hip.DeviceBuffer.from_host(limbs)
+    out = np.zeros(3 * pb // 16, dtype=np.uint64)
+    if timing:
+        B.tune_set("msm_timing", 1)
+    best = None
+    for _ in range(reps):
+        B._check(L.csh_msm_dev(h, C.c_size_t(0), C.c_size_t(n), sc.ptr, 1, out.ctypes.data_as(C.c_void_p), None))
+        t = B.msm_last_timing()
+        if best is None or t[5] < best[5]:
+            best = t
+    B.tune_set("msm_timing", 0)
+    print(json.dumps({"curve": curve, "group": group, "logn": logn, "params_c_W_L_S": B.msm_last_params(),
+                      "ms_digits_scan_scatter_accum_reduce_total": [round(x, 3) for x in best], "Mpts_s": round(n / best[5] / 1e3, 1) if timing else None}), flush=True)
+    L.csh_bases_free(h)
+    sc.free()

@@ -30,7 +30,7 @@ if os.environ.get("PROBE_SKIP_UB"):
     pass
 sizes = [int(x) for x in os.environ.get("PROBE_LOGN", "20,24").split(",")]
 cs = [int(x) for x in os.environ.get("PROBE_C", "0,13,14,15,16,17,18").split(",")]
-os.environ["CSH_MSM_TIMING"] = "1"
+B.tune_set("msm_timing", 1)
 for logn in sizes:
     n = 1 << logn
     buf = hip.DeviceBuffer(n * PB)
@@ -50,10 +50,7 @@ for logn in sizes:
     sc = hip.DeviceBuffer.from_host(limbs)
     out = np.zeros(3 * PB // 16, dtype=np.uint64)
     for c in cs:
-        if c:
-            os.environ["CSH_MSM_C"] = str(c)
-        elif "CSH_MSM_C" in os.environ:
-            del os.environ["CSH_MSM_C"]
+        B.tune_set("msm_c", c)
         best = None
         for rep in range(3):
             B._check(L.csh_msm_dev(h, C.c_size_t(0), C.c_size_t(n), sc.ptr, 1, out.ctypes.data_as(C.c_void_p), None))

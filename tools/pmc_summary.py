@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
-"""rocprofv3 --pmc DBs (one counter per pass) -> per-kernel average HBM bytes per launch.
+"""rocprofv3 --pmc DBs (FETCH_SIZE and WRITE_SIZE in separate passes) -> per-kernel average RAW counter bytes per launch.
 
-Correction per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE reports half the bytes of
-wide coalesced reads -> doubled; WRITE_SIZE taken as is; both counters are in KiB. Calibration visible in the same
-run: __amd_rocclr_copyBuffer of 64 MiB reads FETCH_SIZE = 32 MiB, WRITE_SIZE = 64 MiB."""
+Units: both counters are in KiB (raw * 1024 = bytes as the counter sees them). No blanket correction is applied here: the
+gfx950 read-side factor depends on the access pattern (/opt/skills/guides/MI355X_MICROARCH.md, HBM section: x2 was calibrated
+for wide coalesced streaming reads only), so the factor for each kernel comes from the known-bytes launches of
+tools/gpu_calib.py profiled in the same way (k_gather_calib<REC, SEQ> rows; tools/make_roofline_inputs.py applies them)."""
 import csv
 import sqlite3
 import sys
@@ -24,14 +25,13 @@ def main(fetch_db, write_db, out_csv, note=""):
         if note:
             fh.write("# " + note + "\n")
         cw = csv.writer(fh)
-        cw.writerow(["kernel", "launches", "FETCH_SIZE_KiB_raw_avg", "fetch_bytes_corrected_x2", "WRITE_SIZE_KiB_avg", "write_bytes", "hbm_bytes_per_launch"])
-        for k in sorted(set(f) | set(w), key=lambda k: -(f.get(k, (0, 0))[1] * 2 + w.get(k, (0, 0))[1])):
+        cw.writerow(["kernel", "launches", "FETCH_SIZE_KiB_raw_avg", "fetch_bytes_raw", "WRITE_SIZE_KiB_raw_avg", "write_bytes_raw"])
+        for k in sorted(set(f) | set(w), key=lambda k: -(f.get(k, (0, 0))[1] + w.get(k, (0, 0))[1])):
             if not k.startswith("csh::"):
                 continue
             fc, fa = f.get(k, (0, 0.0))
             wc, wa = w.get(k, (0, 0.0))
-            fb, wb = 2 * fa * 1024, wa * 1024
-            cw.writerow([k[:90], fc or wc, round(fa, 1), int(fb), round(wa, 1), int(wb), int(fb + wb)])
+            cw.writerow([k[:110], fc or wc, round(fa, 1), int(fa * 1024), round(wa, 1), int(wa * 1024)])
 
 
 if __name__ == "__main__":

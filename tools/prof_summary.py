@@ -15,8 +15,8 @@ def main(db_path, out_csv, note=""):
         w.writerow(["kernel", "calls", "total_us", "avg_us", "pct"])
         for name, calls, tot, avg, pct in rows:
             short = name.split("(")[0].replace("void ", "")
-            if len(short) > 90:
-                short = short[:87] + "..."
+            if len(short) > 110:
+                short = short[:107] + "..."
             w.writerow([short, calls, round(tot, 1), round(avg, 1), round(pct, 2)])
 
 
