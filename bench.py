@@ -28,6 +28,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+try:
+    HOST_CPUS = len(os.sched_getaffinity(0))        # before any OpenMP runtime pins this thread
+except Exception:
+    HOST_CPUS = os.cpu_count() or 1
 os.environ.setdefault("OMP_PROC_BIND", "spread")   # cpu_baseline leg: one pinned OpenMP thread per core
 os.environ.setdefault("OMP_PLACES", "cores")
 
@@ -485,7 +489,6 @@ def main():
     if not args.no_extras:
         try:
             if world == 1:
-                keep = (job, pts_host)
                 extras, cpu_inputs24 = secondary_single_gpu(cx, rin, args)
             else:
                 extras = secondary_multi_gpu(cx, args)
@@ -498,7 +501,7 @@ def main():
             from oracle.cbridge import cpu_baseline_suite
             sc_host = job.sc.cpu().numpy().view(cx.np.uint64)
             p24, s24, a24 = cpu_inputs24 if cpu_inputs24 else (None, None, None)
-            cpu_baseline = cpu_baseline_suite(pts_host, sc_host, job.affine_words(res), p24, s24, a24)
+            cpu_baseline = cpu_baseline_suite(pts_host, sc_host, job.affine_words(res), p24, s24, a24, host_cpus=HOST_CPUS)
             cpu_baseline["gpu_over_cpu_2p20"] = round(value / cpu_baseline["value"], 1)
             if extras and "msm_2p24" in cpu_baseline and "msm_bn254_g1_2p24" in extras:
                 cpu_baseline["gpu_over_cpu_2p24"] = round(extras["msm_bn254_g1_2p24"]["points_per_s"] / cpu_baseline["msm_2p24"]["points_per_s"], 1)

@@ -130,6 +130,8 @@ def _devptr(x):
         return x.ptr
     if x is None:
         return None
+    if isinstance(x, C.c_void_p):
+        return x
     return C.c_void_p(int(x))  # raw address, e.g. torch.Tensor.data_ptr()
 
 

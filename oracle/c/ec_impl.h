@@ -317,6 +317,36 @@ static void EC(msm_fast)(EC(aff)* out, const EC(aff)* points, const uint64_t* sc
   free(wsum); free(sc_own);
 }
 
+/* k * P for a 256-bit k (4 little-endian limbs) */
+static void EC(mul_u256)(EC(jac)* r, const EC(aff)* p, const uint64_t k[4]) {
+  EC(jac) acc; EC(jac_set_inf)(&acc);
+  for (int l = 3; l >= 0; l--)
+    for (int b = 63; b >= 0; b--) {
+      EC(jac_dbl)(&acc, &acc);
+      if ((k[l] >> b) & 1) EC(jac_add_mixed)(&acc, &acc, p);
+    }
+  *r = acc;
+}
+/* Full-range bases for direct (non closed-form) parity at BASELINE sizes: bases[i] = k_i * G with a 253-bit k_i drawn from
+ * four splitmix64 outputs -- generic points with full-width coordinates, every fourth-thousandth one the point at infinity
+ * (the zkey queries contain such points). SURVEY 8d config 2, family (i) in spirit: no structure the MSM could exploit. */
+static void EC(gen_bases_wide)(EC(aff)* out, const EC(aff)* gen, uint64_t seed, size_t n, int nthreads) {
+#pragma omp parallel for schedule(dynamic, 256) num_threads(nthreads)
+  for (size_t i = 0; i < n; i++) {
+    uint64_t k[4];
+    for (int l = 0; l < 4; l++) {
+      uint64_t x = seed + 4 * i + l + 0x9E3779B97F4A7C15ull;
+      x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+      x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+      k[l] = x ^ (x >> 31);
+    }
+    k[3] >>= 3;
+    if ((k[0] & 4095) == 0) { FE(set_zero)(&out[i].x); FE(set_zero)(&out[i].y); continue; }
+    EC(jac) j; EC(mul_u256)(&j, gen, k);
+    EC(jac_to_aff)(&out[i], &j);
+  }
+}
+
 /* bases[i] = (splitmix64(seed+i)|1) * G (the product's csh_util_generate_bases_dev family) */
 static void EC(gen_bases)(EC(aff)* out, const EC(aff)* gen, uint64_t seed, size_t n, int nthreads) {
 #pragma omp parallel for schedule(static) num_threads(nthreads)

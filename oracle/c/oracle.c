@@ -162,6 +162,54 @@ int oc_generate_bases(int curve, int group, uint64_t seed, size_t n, int nthread
   return -1;
 }
 
+int oc_generate_bases_wide(int curve, int group, uint64_t seed, size_t n, int nthreads, uint64_t* out) {
+  nthreads = threads_or_default(nthreads);
+  if (curve == 0 && group == 0) { bn_g1_gen_bases_wide((bn_g1_aff*)out, (const bn_g1_aff*)BN254_G1_GEN, seed, n, nthreads); return 0; }
+  if (curve == 0 && group == 1) { bn_g2_gen_bases_wide((bn_g2_aff*)out, (const bn_g2_aff*)BN254_G2_GEN, seed, n, nthreads); return 0; }
+  if (curve == 1 && group == 0) { bl_g1_gen_bases_wide((bl_g1_aff*)out, (const bl_g1_aff*)BLS381_G1_GEN, seed, n, nthreads); return 0; }
+  if (curve == 1 && group == 1) { bl_g2_gen_bases_wide((bl_g2_aff*)out, (const bl_g2_aff*)BLS381_G2_GEN, seed, n, nthreads); return 0; }
+  return -1;
+}
+
+/* BN254 G1 "hashed" points (family i): x = splitmix-derived field element, incremented until x^3 + 3 is
+ * a square; y = rhs^((q+1)/4) (q = 3 mod 4), sign from a PRNG bit. Cofactor 1: every curve point is in the group. No
+ * relation to the generator whatsoever. */
+int oc_hash_points_bn254_g1(uint64_t seed, size_t n, int nthreads, uint64_t* out) {
+  nthreads = threads_or_default(nthreads);
+  uint64_t e[4];
+  { /* (q + 1) / 4 */
+    unsigned __int128 c = 1;
+    uint64_t t[4];
+    for (int i = 0; i < 4; i++) { c += BN254_FQ_P[i]; t[i] = (uint64_t)c; c >>= 64; }
+    for (int i = 0; i < 4; i++) e[i] = (t[i] >> 2) | (i < 3 ? t[i + 1] << 62 : (uint64_t)c << 62);
+  }
+  bnq_t three; bnq_from_u64(&three, 3);
+  bn_g1_aff* o = (bn_g1_aff*)out;
+#pragma omp parallel for schedule(dynamic, 256) num_threads(nthreads)
+  for (size_t i = 0; i < n; i++) {
+    uint64_t k[4];
+    for (int l = 0; l < 4; l++) {
+      uint64_t x = seed + 4 * i + l + 0x9E3779B97F4A7C15ull;
+      x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+      x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+      k[l] = x ^ (x >> 31);
+    }
+    const int sign = (int)(k[3] >> 63);
+    k[3] &= (1ull << 61) - 1;                       /* < 2^253 < q: a canonical value; to_mont makes it a field element */
+    bnq_t x, rhs, y, chk, one; memcpy(&x, k, 32); bnq_to_mont(&x, &x); bnq_set_one(&one);
+    for (;;) {
+      bnq_sqr(&rhs, &x); bnq_mul(&rhs, &rhs, &x); bnq_add(&rhs, &rhs, &three);
+      bnq_pow(&y, &rhs, e, 4);
+      bnq_sqr(&chk, &y);
+      if (bnq_eq(&chk, &rhs)) break;
+      bnq_add(&x, &x, &one);
+    }
+    if (sign) bnq_neg(&y, &y);
+    o[i].x = x; o[i].y = y;
+  }
+  return 0;
+}
+
 /* ---- NTT / vector ops over Fr (both scalar fields are 4 limbs) ------------------------------------------- */
 typedef struct { uint64_t l[4]; } fr_t;
 typedef void (*fr_bin)(fr_t*, const fr_t*, const fr_t*);
@@ -289,6 +337,36 @@ int oc_vec_sub(int curve, const uint64_t* a, const uint64_t* b, uint64_t* out, s
   fr_ops o = ops_for(curve);
 #pragma omp parallel for schedule(static) num_threads(nthreads)
   for (size_t i = 0; i < n_elems; i++) o.sub((fr_t*)out + i, (const fr_t*)a + i, (const fr_t*)b + i);
+  return 0;
+}
+
+/* Horner: out = sum_i coeffs[i * stride] * x^i (i < n), no NTT code involved (spot checks of full-size transforms) */
+int oc_eval_poly(int curve, const uint64_t* coeffs, size_t n, size_t stride, const uint64_t* x, uint64_t* out) {
+  fr_ops o = ops_for(curve);
+  fr_t acc; memset(&acc, 0, sizeof acc);
+  for (size_t i = n; i-- > 0;) { o.mul(&acc, &acc, (const fr_t*)x); o.add(&acc, &acc, (const fr_t*)coeffs + i * stride); }
+  *(fr_t*)out = acc;
+  return 0;
+}
+
+int oc_vec_add(int curve, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n_elems, int nthreads) {
+  nthreads = threads_or_default(nthreads);
+  fr_ops o = ops_for(curve);
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+  for (size_t i = 0; i < n_elems; i++) o.add((fr_t*)out + i, (const fr_t*)a + i, (const fr_t*)b + i);
+  return 0;
+}
+
+/* out[i] = sum_k coeffs[k] * shares[k][i] (Shamir reconstruct / open_vec, shamir.rs:483-491; Rep3 combine with coeffs = 1) */
+int oc_lincomb(int curve, const uint64_t* const* shares, const uint64_t* coeffs, size_t k, uint64_t* out, size_t n, int nthreads) {
+  nthreads = threads_or_default(nthreads);
+  fr_ops o = ops_for(curve);
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+  for (size_t i = 0; i < n; i++) {
+    fr_t acc, t; memset(&acc, 0, sizeof acc);
+    for (size_t j = 0; j < k; j++) { o.mul(&t, (const fr_t*)shares[j] + i, (const fr_t*)coeffs + j); o.add(&acc, &acc, &t); }
+    ((fr_t*)out)[i] = acc;
+  }
   return 0;
 }
 

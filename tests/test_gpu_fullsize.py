@@ -1,0 +1,141 @@
+"""GPU parity at the BASELINE sizes by DIRECT comparison with the CPU restatement (oracle/c), not only through properties:
+NTT 2^20 / 2^22 (config 3) full-vector equality + 16 Horner indices, MSM 2^20 (config 2) on full-range random points on
+three groups, the share-vector kernels at 2^24 + 5 elements (the grid-stride branch), and the reference's BN254 Fr products
+(tests/tests/mpc/rep3.rs:286-345) through the device kernels. Everything through the C ABI; bit-exact."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import cbridge, ntt
+from oracle import curves as cv
+from oracle import fields as fl
+from oracle import mpc
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _uniform_limbs(rs, n):
+    """n canonical values < 2^253 (< r on every curve here), used as Montgomery encodings of uniform field elements."""
+    v = rs.randint(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    v[:, 3] >>= np.uint64(3)
+    return v
+
+
+@pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
+@pytest.mark.parametrize("logn,ncomp", [(20, 1), (20, 2), (22, 1), (22, 2)])
+def test_ntt_full_size_equals_cpu_restatement(gpu, curve, logn, ncomp):
+    """BASELINE config 3 (BN254, 2^22) and the Rep3 two-component form: both directions bit-identical to oracle/c's radix-2
+    NTT over the whole vector, the round trip, and 16 output indices re-derived by Horner (no NTT code involved)."""
+    if curve == "bls12_381" and (logn, ncomp) != (22, 1):
+        pytest.skip("one full-size BLS12-381 case is enough")
+    F = H.FR[curve]
+    cid = H.CURVE_IDS[curve]
+    n = 1 << logn
+    gen = ntt.roots_of_unity(F)[1][logn]                      # snarkjs root (reduction.rs:38-43 via groth16 roots)
+    pg = H.pack(F, [gen])
+    dom = gpu.Domain(cid, logn, pg)
+    x = _uniform_limbs(np.random.RandomState(1000 + logn + ncomp), n * ncomp)
+    coeffs = dom.ifft_in_to_out(x, ncomp=ncomp)
+    want = cbridge.ntt(cid, x, logn, pg, ncomp=ncomp, dif=True)
+    assert np.array_equal(coeffs.reshape(-1), want.reshape(-1))
+    evals = dom.fft_out_to_in(coeffs, ncomp=ncomp)
+    assert np.array_equal(evals.reshape(-1), x.reshape(-1))                                     # bit-exact round trip
+    assert np.array_equal(cbridge.ntt(cid, want, logn, pg, ncomp=ncomp, dif=False).reshape(-1), x.reshape(-1))
+    # Horner: x[k] (component comp) = sum_i c[bitrev(i)] w^(ik); natural-order coefficients through the CPU bit reversal
+    nat = cbridge.bit_reverse(coeffs, logn, ncomp=ncomp)
+    r = H.rng(logn)
+    for _ in range(16):
+        k, comp = r.randrange(n), r.randrange(ncomp)
+        wk = H.pack(F, [pow(gen, k, F.p)])
+        got = cbridge.eval_poly(cid, nat, wk, stride=ncomp, offset=comp)
+        assert np.array_equal(got, x.reshape(n, ncomp, 4)[k, comp]), (k, comp)
+    dom.free()
+
+
+@pytest.mark.parametrize("curve,group,family", [("bn254", 0, "hashed"), ("bn254", 0, "wide"), ("bn254", 1, "wide"), ("bls12_381", 0, "wide"),
+                                                 ("bls12_381", 1, "wide")])
+def test_msm_2p20_random_points_equals_cpu_restatement(gpu, curve, group, family):
+    """BASELINE config 2 size on full-range points with no exploitable structure: BN254 G1 points hashed to the curve
+    (SURVEY 8d family i), and k G with 253-bit k on every group (incl. points at infinity); uniform scalars in Montgomery form
+    and canonical (msm_bigint). The affine result is bit-identical to oracle/c's independent Pippenger (Booth / XYZZ)."""
+    cid = H.CURVE_IDS[curve]
+    logn = 20 if group == 0 else 18
+    n = 1 << logn
+    pts = cbridge.hash_points_bn254_g1(0xA11CE, n) if family == "hashed" else cbridge.generate_bases_wide(cid, group, 0xB0B + group, n)
+    sc = _uniform_limbs(np.random.RandomState(7 + group), n)
+    sc[:64] = 0                                                # zero scalars
+    sc[64:128] = sc[128:192]                                   # repeated scalars
+    bases = gpu.Bases(cid, group, pts)
+    for mont in (True, False):
+        got = bases.msm(sc, montgomery=mont)
+        w = got.size // 3
+        got_aff = np.zeros(2 * w, dtype=np.uint64) if not got[2 * w:].any() else got[:2 * w]
+        want = cbridge.msm_fast(cid, group, pts, sc, montgomery=mont)
+        assert np.array_equal(got_aff, want), (curve, group, family, mont)
+    bases.free()
+
+
+@pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
+def test_share_vector_kernels_beyond_one_launch_width(gpu, curve):
+    """2^24 + 5 elements: more than 65536 workgroups x 256 lanes, so every kernel takes its grid-stride branch; each result is
+    compared element for element with oracle/c."""
+    F = H.FR[curve]
+    cid = H.CURVE_IDS[curve]
+    n = (1 << 24) + 5
+    rs = np.random.RandomState(99)
+    a2, b2 = _uniform_limbs(rs, 2 * n), _uniform_limbs(rs, 2 * n)
+    m = _uniform_limbs(rs, n)
+    eq = lambda x, y: np.array_equal(np.asarray(x).reshape(-1), np.asarray(y).reshape(-1))
+    assert eq(gpu.rep3_local_mul_vec(cid, a2, b2, m), cbridge.rep3_local_mul_vec(cid, a2, b2, m))
+    a1, b1 = a2[:n], b2[:n]
+    assert eq(gpu.vec_mul(cid, a1, b1), cbridge.vec_mul(cid, a1, b1))
+    assert eq(gpu.vec_sub(cid, a1, b1), cbridge.vec_sub(cid, a1, b1))
+    assert eq(gpu.vec_add(cid, a1, b1), cbridge.vec_add(cid, a1, b1))
+    if curve == "bn254":
+        assert eq(gpu.vec_sub(cid, a2, b2, ncomp=2), cbridge.vec_sub(cid, a2, b2))
+        assert eq(gpu.vec_mul_table(cid, a1, m), cbridge.vec_mul_table(cid, a1, m))
+        assert eq(gpu.vec_mul_table(cid, a2, m, ncomp=2), cbridge.vec_mul_table(cid, a2, m, ncomp=2))
+        x, y = mpc.rep3_to_shamir_points(F, 1)
+        px, py = H.pack(F, [x]), H.pack(F, [y])
+        assert eq(gpu.rep3_to_shamir_vec(cid, a2, px, py), cbridge.rep3_to_shamir_vec(cid, a2, px, py))
+        co = H.pack(F, [3, F.p - 2, 12345])
+        assert eq(gpu.lincomb(cid, [a1, b1, m], co), cbridge.lincomb(cid, [a1, b1, m], co))
+
+
+KAT_X = [13839525561076761625780930844889299788193703994911163378019280196128582690055,
+         19302971480864839163158232064620707211435225928426123775531639309944891593977,
+         8048717310762513532550620831072439583505607813129662608591015555880153427210,
+         2585271390974436123003027749932103593962191064365118925254473311197989280023]
+KAT_Y = [2688648969035332064113669477511029957484512453056743431884706385750388613065,
+         13632770404954969699480437686769008635735921498648460325387842712839596176806,
+         19199593902803943133889170931116903997086625101975591190159463567024116566625,
+         8255472466884305547009533395117607586789669747151273739964395707537515634749]
+KAT_Z = [14012338922664984944451142760937475581748095944353358534203030914664561190462,
+         4297594441150501195973997511775989720904927516253689527653694984160382713321,
+         7875903949174289914141782934879682497141865775307179984684659764891697566272,
+         6646526994769136778802685410292764833027657364709823469005920616147071273574]
+
+
+def test_reference_bn254_fr_products_through_the_device_kernels(gpu):
+    """The four products hard-coded by the reference (tests/tests/mpc/rep3.rs:286-345, the same in shamir.rs): through
+    csh_vec_mul (plain / Shamir local_mul_vec), and through three Rep3 parties -- share_field_elements semantics, each party's
+    csh_rep3_local_mul_vec with correlated masks, opened with csh_lincomb -- exactly the flow of that test (mul_vec then open)."""
+    F = fl.BN254_FR
+    cid = H.CURVE_IDS["bn254"]
+    px, py = H.pack(F, KAT_X), H.pack(F, KAT_Y)
+    assert H.unpack(F, gpu.vec_mul(cid, px, py)) == KAT_Z
+    r = H.rng(2024)
+    rnd = lambda: r.randrange(F.p)
+    xs = [mpc.rep3_share(F, v, rnd(), rnd()) for v in KAT_X]   # per value: three (a, b) shares
+    ys = [mpc.rep3_share(F, v, rnd(), rnd()) for v in KAT_Y]
+    keys = [rnd() for _ in range(12)]                          # masks m_p = k_p - k_{p-1} per element: they cancel
+    prods = []
+    for p in range(3):
+        lhs = H.pack_shares(F, [xs[i][p] for i in range(4)])
+        rhs = H.pack_shares(F, [ys[i][p] for i in range(4)])
+        mask = H.pack(F, [(keys[4 * p + i] - keys[4 * ((p + 2) % 3) + i]) % F.p for i in range(4)])
+        prods.append(gpu.rep3_local_mul_vec(cid, lhs, rhs, mask))
+    opened = gpu.lincomb(cid, prods, H.pack(F, [1, 1, 1]))
+    assert H.unpack(F, opened) == KAT_Z
