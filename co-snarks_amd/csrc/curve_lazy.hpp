@@ -3,6 +3,8 @@
 // explicit `empty` flag replaces the ZZ == 0 test, and the P == 0 (doubling / cancellation) case is detected
 // with a 3-instruction filter on the low limb before the exact check.
 #pragma once
+#include <type_traits>
+
 #include "curve.hpp"
 #include "field29.hpp"
 
@@ -43,11 +45,25 @@ CSH_HD_NOINLINE XYZZLazy<L> lazy_mdbl_v(L x, L y) {  // by value: fine (and fast
   return lazy_mdbl_inl<L>(x, y);
 }
 
+// Rare-path helper of the accumulate kernel for the wide fields: 2 * (the affine point at `src`, negated if asked), re-read
+// from memory INSIDE the out-of-line routine. (The former version took private stack copies of x2 / y2 in the caller's rare
+// branch; the compiler hoisted those stores to the top of the loop body, so every mixed addition wrote 2 field elements of
+// scratch -- 2.5 GB per 2^20 BN254 G2 MSM, 4.2 GB on BLS12-381 G2 by WRITE_SIZE, profiles/r02_a_msm_*_pmc_hbm_bytes.csv.)
+template <class L, class AffT>
+CSH_HD_NOINLINE void lazy_mdbl_mem(const AffT* src, uint32_t negate, XYZZLazy<L>* out) {
+  const AffT pt = *src;
+  const L x = L::unpack(pt.x);
+  L y = L::unpack(pt.y);
+  if (negate) y = L::neg(y).normalized();
+  *out = lazy_mdbl_inl<L>(x, y);
+}
+
 // acc += (x2, y2); the caller has already excluded the point at infinity. Contract: x2, y2 have limbs in
 // [-2, 2^B + 2] (unpack() output, or neg(..).normalized() for a negated point) -- acc.x / acc.y inherit that bound
-// and are subtracted limb-wise from fresh products below.
-template <class L>
-CSH_HD void lazy_madd(XYZZLazy<L>& acc, const L& x2, const L& y2) {
+// and are subtracted limb-wise from fresh products below. src (nullable) / negate: where (x2, y2) came from, for the rare
+// doubling path of the wide fields.
+template <class L, class AffT = void>
+CSH_HD void lazy_madd(XYZZLazy<L>& acc, const L& x2, const L& y2, const AffT* src = nullptr, uint32_t negate = 0) {
   if (acc.empty) {
     acc.x = x2;
     acc.y = y2;
@@ -66,6 +82,10 @@ CSH_HD void lazy_madd(XYZZLazy<L>& acc, const L& x2, const L& y2) {
         if (y2.is_zero()) acc.empty = true;  // 2-torsion cannot occur on these curves; kept for completeness
         else if constexpr (sizeof(L) <= 40) {
           acc = lazy_mdbl_v<L>(x2, y2);
+        } else if constexpr (!std::is_void<AffT>::value) {
+          XYZZLazy<L> d;
+          lazy_mdbl_mem<L, AffT>(src, negate, &d);
+          acc = d;
         } else {
           const L tx = x2, ty = y2;  // private copies: the call takes addresses
           XYZZLazy<L> d;

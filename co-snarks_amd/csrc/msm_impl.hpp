@@ -123,7 +123,7 @@ __global__ __launch_bounds__(ACC_BLK) void k_msm_accum(const Affine<typename Cfg
       const L x = L::unpack(pt.x);
       L y = L::unpack(pt.y);
       if (e >> 31) y = L::neg(y).normalized();  // keep |limb| <= 2^B + 1: lazy_madd subtracts acc.y limb-wise
-      lazy_madd(acc, x, y);
+      lazy_madd<L, Affine<Fq>>(acc, x, y, bases + (e & 0x7fffffffu), e >> 31);
     }
     pw[b + k] = acc;
   }

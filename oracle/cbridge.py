@@ -187,6 +187,23 @@ def _available_cpus() -> int:
         return os.cpu_count() or 1
 
 
+def _cgroup_cpu_quota():
+    """CPUs' worth of time the container may use (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited / unknown. A box can
+    expose 256 CPUs in its affinity mask and still be throttled to a few CPUs of time: more threads than that only adds
+    contention (measured on the GPU boxes: linear to 16 threads, flat total throughput beyond)."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if q == "max" else float(q) / float(per)
+    except Exception:
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except Exception:
+        return None
+
+
 def _best_of(f, reps=2):
     best = None
     for _ in range(reps):
@@ -209,7 +226,8 @@ def cpu_baseline_suite(pts20, sc20, gpu_affine20=None, pts24=None, sc24=None, gp
     n20 = np.ascontiguousarray(sc20).size // 4
     spent = time.perf_counter()
     table = []
-    cands = sorted({t for t in (8, 16, 32, 64, 128, 192, 256, hw) if t <= hw})
+    quota = _cgroup_cpu_quota()
+    cands = sorted({t for t in (2, 4, 8, 16, 32, 64, 128, 256, hw) if t <= hw})
     best_t, best_v, res20 = 1, 0.0, None
     for t in cands:
         st = []
@@ -221,13 +239,15 @@ def cpu_baseline_suite(pts20, sc20, gpu_affine20=None, pts24=None, sc24=None, gp
             best_t, best_v, res20 = t, n20 / dt, r
         if time.perf_counter() - spent > budget_s * 0.4:
             break
+        if len(table) >= 2 and table[-1]["points_per_s"] < 0.9 * max(r["points_per_s"] for r in table[:-1]) and t >= 32:
+            break   # past the plateau (CPU-time quota of the container / shared host): more threads only add contention
     # single-thread row on a 2^17 prefix (bounded): the per-thread mixed-addition rate without any sharing effects
     m = min(n20, 1 << 17)
     st = []
     dt1, _ = _best_of(lambda: msm_fast(curve, group, np.ascontiguousarray(pts20).reshape(n20, -1)[:m], np.ascontiguousarray(sc20).reshape(n20, 4)[:m], True, threads=1, stages=st), reps=1)
     table.insert(0, {"threads": 1, "points_per_s": round(m / dt1), "ms": round(dt1 * 1e3, 2), "mixed_adds_per_s_per_thread": round(m * st[4] / max(st[1], 1e-9)),
                      "c": int(st[3]), "windows": int(st[4]), "sample": f"first 2^{m.bit_length() - 1} points"})
-    out = {"value": best_v, "unit": "points/s", "cores": best_t, "kind": "port", "host_cpus_available": hw, "build": flags,
+    out = {"value": best_v, "unit": "points/s", "cores": best_t, "kind": "port", "host_cpus_available": hw, "cgroup_cpu_quota": quota, "build": flags,
            "sample": f"BN254 G1 MSM, the bench step's own 2^{n20.bit_length() - 1} bases and scalars copied back from the GPU; oracle/c oc_msm_fast "
                      f"(Booth signed digits, XYZZ mixed additions, thread-private buckets, __int128 Montgomery; OpenMP x{best_t}), best of 2; "
                      "a restatement of the published Pippenger shape, NOT arkworks (no Rust toolchain / un-vendored crates here)",
