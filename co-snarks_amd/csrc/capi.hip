@@ -69,6 +69,7 @@ static const TuneEntry kTune[] = {
     {"ntt_lazy", "CSH_NTT_LAZY", &Tune::ntt_lazy},
     {"ntt_threads", "CSH_NTT_THREADS", &Tune::ntt_threads},
     {"msm_variant", "CSH_MSM_VARIANT", &Tune::msm_variant},
+    {"msm_seg_buckets", "CSH_MSM_SEG_BUCKETS", &Tune::msm_seg_buckets},
     {"ntt_variant", "CSH_NTT_VARIANT", &Tune::ntt_variant},
 };
 Tune& tune() {

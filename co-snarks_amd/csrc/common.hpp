@@ -105,6 +105,7 @@ struct Tune {
   std::atomic<int> ntt_lazy{1};
   std::atomic<int> ntt_threads{1024};
   std::atomic<int> msm_variant{0};       // experimental kernel variants (A/B runs)
+  std::atomic<int> msm_seg_buckets{8};   // buckets per window-reduction segment
   std::atomic<int> ntt_variant{0};
 };
 Tune& tune();

@@ -7,6 +7,7 @@
 #include "common.hpp"
 #include "curve.hpp"
 #include "curve_lazy.hpp"
+#include "curve_quad.hpp"
 #include "host_fp64.hpp"
 #include "msm_digits.hpp"
 #include "msm_sort.hpp"
@@ -129,87 +130,129 @@ __global__ __launch_bounds__(ACC_BLK) void k_msm_accum(const Affine<typename Cfg
   }
 }
 
-// Point addition used by the merge / reduction kernels: inlined for the 9-limb base field, out of line (operands
-// through memory) for the wide fields (code size, and see the note on lazy_mdbl).
-template <class Cfg>
-__device__ __forceinline__ void padd(LazyPt<Cfg>& a, const LazyPt<Cfg>& b) {
-  if constexpr (Cfg::INLINE_ADD) {
-    lazy_add_inl<typename Cfg::L>(a, b);
-  } else {
-    const LazyPt<Cfg> t = b;
-    lazy_add_p<typename Cfg::L>(&a, &t);
-  }
-}
+// ---- the latency-bound tail: merge -> reduce -> fold, four lanes per point (curve_quad.hpp) ---------------------------
+// A "logical lane" (one bucket / one segment / one tree node) is a DPP quad; blocks of TAIL_BLK threads hold TAIL_BLK / 4 of
+// them. Control flow depends on the logical index and on quad-broadcast flags only, so the four lanes stay converged.
+constexpr int TAIL_BLK = 64;
+constexpr int TAIL_Q = TAIL_BLK / 4;
 
 // Bucket merge: the partials of bucket b sit in consecutive slots b + k0 .. b + k1 (k0, k1 = first / last lane that
-// touched it). One lane per bucket folds them into the dense array dense[w][b]; buckets with more than MERGE_CAP
+// touched it). One quad per bucket folds them into the dense array dense[w][b]; buckets with more than MERGE_CAP
 // partials (heavily repeated scalars) are queued for the block-wide tree kernel below.
 constexpr uint32_t MERGE_CAP = 16;
 template <class Cfg>
-__global__ __launch_bounds__(64) void k_msm_merge(MsmParams p, const uint32_t* __restrict__ start,
-                                                  const LazyPt<Cfg>* __restrict__ partial, LazyPt<Cfg>* dense,
-                                                  uint32_t* giant_count, uint32_t* giant_list) {
+__global__ __launch_bounds__(TAIL_BLK) void k_msm_merge(MsmParams p, const uint32_t* __restrict__ start,
+                                                        const LazyPt<Cfg>* __restrict__ partial, LazyPt<Cfg>* dense,
+                                                        uint32_t* giant_count, uint32_t* giant_list) {
+  using L = typename Cfg::L;
   const int w = blockIdx.y;
-  const uint32_t b = blockIdx.x * 64 + threadIdx.x + 1;
+  const int role = threadIdx.x & 3;
+  const uint32_t b = blockIdx.x * TAIL_Q + (threadIdx.x >> 2) + 1;
   if (b > p.NB) return;
   const uint32_t* st = start + (size_t)w * (p.NB + 2);
   const uint32_t lo = st[b], hi = st[b + 1];
-  LazyPt<Cfg> acc = LazyPt<Cfg>::inf();
+  QPt<L> acc = qpt_inf<L>();
   if (hi > lo) {
     const uint32_t k0 = lo / p.L, k1 = (hi - 1) / p.L;
     const LazyPt<Cfg>* pw = partial + (size_t)w * p.tmax + b;
     if (k1 - k0 >= MERGE_CAP) {
-      const uint32_t g = atomicAdd(giant_count, 1u);
-      giant_list[2 * g] = (uint32_t)w;
-      giant_list[2 * g + 1] = b;
+      if (role == 0) {
+        const uint32_t g = atomicAdd(giant_count, 1u);
+        giant_list[2 * g] = (uint32_t)w;
+        giant_list[2 * g + 1] = b;
+      }
     } else {
-      acc = pw[k0];
-      for (uint32_t k = k0 + 1; k <= k1; ++k) padd<Cfg>(acc, pw[k]);
+      acc = qpt_load<L>(&pw[k0], role);
+      for (uint32_t k = k0 + 1; k <= k1; ++k) qadd<L>(acc, qpt_load<L>(&pw[k], role), role);
     }
   }
-  dense[(size_t)w * (p.NB + 1) + b] = acc;
+  qpt_store<L>(&dense[(size_t)w * (p.NB + 1) + b], role, acc);
 }
 
-// One 256-thread block per queued bucket: strided private sums, then a tree over global scratch-free LDS-less
-// exchange through the dense array's own slot list (pairwise passes over `tmp`).
+// Tree over the quads of one block through LDS: on return quad 0 holds the sum of all nq quad values (nq a power of two).
+template <class L>
+__device__ __forceinline__ void quad_block_tree(QPt<L>& x, XYZZLazy<L>* sh, int q, int nq, int role) {
+  for (int half = nq >> 1; half >= 1; half >>= 1) {
+    if (q >= half && q < 2 * half) qpt_store<L>(&sh[q - half], role, x);
+    __syncthreads();
+    if (q < half) qadd<L>(x, qpt_load<L>(&sh[q], role), role);
+    __syncthreads();
+  }
+}
+
+// One 256-thread block (64 quads) per queued bucket: strided private sums, then the LDS tree.
 template <class Cfg>
 __global__ __launch_bounds__(256) void k_msm_merge_giant(MsmParams p, const uint32_t* __restrict__ start,
                                                          const LazyPt<Cfg>* __restrict__ partial, LazyPt<Cfg>* dense,
-                                                         const uint32_t* __restrict__ giant_count, const uint32_t* __restrict__ giant_list,
-                                                         LazyPt<Cfg>* tmp) {
+                                                         const uint32_t* __restrict__ giant_count, const uint32_t* __restrict__ giant_list) {
+  using L = typename Cfg::L;
+  __shared__ XYZZLazy<L> sh[32];
   const uint32_t count = *giant_count;
-  LazyPt<Cfg>* t = tmp + (size_t)blockIdx.x * 256;
+  const int role = threadIdx.x & 3, q = threadIdx.x >> 2;
   for (uint32_t g = blockIdx.x; g < count; g += gridDim.x) {
     const uint32_t w = giant_list[2 * g], b = giant_list[2 * g + 1];
     const uint32_t* st = start + (size_t)w * (p.NB + 2);
     const uint32_t k0 = st[b] / p.L, k1 = (st[b + 1] - 1) / p.L;
     const LazyPt<Cfg>* pw = partial + (size_t)w * p.tmax + b;
-    LazyPt<Cfg> acc = LazyPt<Cfg>::inf();
-    for (uint32_t k = k0 + threadIdx.x; k <= k1; k += 256) padd<Cfg>(acc, pw[k]);
-    t[threadIdx.x] = acc;
-    __syncthreads();
-    for (uint32_t half = 128; half >= 1; half >>= 1) {
-      if (threadIdx.x < half) {
-        LazyPt<Cfg> x = t[threadIdx.x];
-        padd<Cfg>(x, t[threadIdx.x + half]);
-        t[threadIdx.x] = x;
-      }
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) dense[(size_t)w * (p.NB + 1) + b] = t[0];
-    __syncthreads();
+    QPt<L> acc = qpt_inf<L>();
+    for (uint32_t k = k0 + q; k <= k1; k += 64) qadd<L>(acc, qpt_load<L>(&pw[k], role), role);
+    quad_block_tree<L>(acc, sh, q, 64, role);
+    if (q == 0) qpt_store<L>(&dense[(size_t)w * (p.NB + 1) + b], role, acc);
   }
 }
 
-// Segment k of window w folds slots [t0, t1) of the (bucket-sorted) partial array: returns sum_t bucket(t) * partial(t)
-// by the running-sum trick with explicit gaps; slots whose bucket id is 0 were never written and are skipped.
+// Segment k of window w folds dense buckets [t0, t1): returns sum_t t * B_t by the running-sum trick with explicit gaps
+// (empty buckets are skipped; a gap of more than 4 empty buckets is bridged by one small scalar multiple).
 template <class Cfg>
-__global__ __launch_bounds__(64) void k_msm_reduce(MsmParams p, const LazyPt<Cfg>* __restrict__ dense,
-                                                   LazyPt<Cfg>* segres) {
+__global__ __launch_bounds__(TAIL_BLK) void k_msm_reduce(MsmParams p, const LazyPt<Cfg>* __restrict__ dense,
+                                                         LazyPt<Cfg>* segres) {
+  using L = typename Cfg::L;
+  const int w = blockIdx.y;
+  const int role = threadIdx.x & 3;
+  const uint32_t k = blockIdx.x * TAIL_Q + (threadIdx.x >> 2);
+  if (k >= p.S) return;
+  const uint32_t per = (p.NB + p.S - 1) / p.S;  // dense[w][b], b = 1..NB (index 0 unused)
+  const uint32_t t0 = 1 + k * per;
+  uint32_t t1 = t0 + per;
+  if (t1 > p.NB + 1) t1 = p.NB + 1;
+  QPt<L> running = qpt_inf<L>(), acc = qpt_inf<L>();
+  uint32_t prev_b = 0;
+  if (t0 < t1) {
+    const LazyPt<Cfg>* dw = dense + (size_t)w * (p.NB + 1);
+    for (uint32_t t = t1; t-- > t0;) {
+      const QPt<L> pt = qpt_load<L>(&dw[t], role);
+      if (pt.empty) continue;
+      uint32_t gap = prev_b ? prev_b - t : 0;
+      if (gap) {
+        if (gap <= 4) {
+          while (gap--) qadd<L>(acc, running, role);
+        } else {
+          const QPt<L> m = qmul_small<L>(running, gap, role);
+          qadd<L>(acc, m, role);
+        }
+      }
+      qadd<L>(running, pt, role);
+      prev_b = t;
+    }
+    if (prev_b) {  // acc = sum (b - bmin) B_b ; add bmin * R
+      const QPt<L> m = qmul_small<L>(running, prev_b, role);
+      qadd<L>(acc, m, role);
+    }
+  }
+  qpt_store<L>(&segres[(size_t)w * p.S + k], role, acc);
+}
+
+// Lane-serial form of the same reduction (one lane per segment, whole points in registers): 1.75x less total work than the
+// quad form. With one wave per SIMD in flight (S x W / 64 waves ~ 1024 SIMDs) the stage is bound by work, not by the latency
+// of one addition, and this form wins (measured, BN254 G1 2^20: 263 us against 293 us); the quad form wins when few points
+// are left (merge of few partials per bucket, fold tree). tune "msm_variant" bit 0 selects the quad form for A/B runs.
+template <class Cfg>
+__global__ __launch_bounds__(64) void k_msm_reduce_serial(MsmParams p, const LazyPt<Cfg>* __restrict__ dense, LazyPt<Cfg>* segres) {
+  using L = typename Cfg::L;
   const int w = blockIdx.y;
   const uint32_t k = blockIdx.x * 64 + threadIdx.x;
   if (k >= p.S) return;
-  const uint32_t per = (p.NB + p.S - 1) / p.S;  // dense[w][b], b = 1..NB (index 0 unused)
+  const uint32_t per = (p.NB + p.S - 1) / p.S;
   const uint32_t t0 = 1 + k * per;
   uint32_t t1 = t0 + per;
   if (t1 > p.NB + 1) t1 = p.NB + 1;
@@ -223,33 +266,38 @@ __global__ __launch_bounds__(64) void k_msm_reduce(MsmParams p, const LazyPt<Cfg
       uint32_t gap = prev_b ? prev_b - t : 0;
       if (gap) {
         if (gap <= 4) {
-          while (gap--) padd<Cfg>(acc, running);
+          while (gap--) lazy_add_inl<L>(acc, running);
         } else {
-          LazyPt<Cfg> m = lazy_mul_small<typename Cfg::L, Cfg::INLINE_ADD>(running, gap);
-          padd<Cfg>(acc, m);
+          const LazyPt<Cfg> m = lazy_mul_small<L, true>(running, gap);
+          lazy_add_inl<L>(acc, m);
         }
       }
-      padd<Cfg>(running, pt);
+      lazy_add_inl<L>(running, pt);
       prev_b = t;
     }
     if (prev_b) {  // acc = sum (b - bmin) B_b ; add bmin * R
-      LazyPt<Cfg> m = lazy_mul_small<typename Cfg::L, Cfg::INLINE_ADD>(running, prev_b);
-      padd<Cfg>(acc, m);
+      const LazyPt<Cfg> m = lazy_mul_small<L, true>(running, prev_b);
+      lazy_add_inl<L>(acc, m);
     }
   }
   segres[(size_t)w * p.S + k] = acc;
 }
 
-// arr[w][i] += arr[w][i + half], i < half
+// Fold tree: block (j, w) sums in[w][j * 128 .. j * 128 + 127] (entries >= count are skipped) into out[w][j]; 256 threads =
+// 64 quads, two loads per quad, then the LDS tree. Two launches take 2048 segment sums to one window sum.
 template <class Cfg>
-__global__ __launch_bounds__(64) void k_msm_fold(LazyPt<Cfg>* arr, uint32_t stride, uint32_t half) {
+__global__ __launch_bounds__(256) void k_msm_fold_tree(const LazyPt<Cfg>* __restrict__ in, uint32_t stride_in, uint32_t count,
+                                                       LazyPt<Cfg>* out, uint32_t stride_out) {
+  using L = typename Cfg::L;
+  __shared__ XYZZLazy<L> sh[32];
   const int w = blockIdx.y;
-  const uint32_t i = blockIdx.x * 64 + threadIdx.x;
-  if (i >= half) return;
-  LazyPt<Cfg>* a = arr + (size_t)w * stride;
-  LazyPt<Cfg> x = a[i];
-  padd<Cfg>(x, a[i + half]);
-  a[i] = x;
+  const int role = threadIdx.x & 3, q = threadIdx.x >> 2;
+  const LazyPt<Cfg>* a = in + (size_t)w * stride_in;
+  const uint32_t i0 = blockIdx.x * 128 + q, i1 = i0 + 64;
+  QPt<L> x = i0 < count ? qpt_load<L>(&a[i0], role) : qpt_inf<L>();
+  if (i1 < count) qadd<L>(x, qpt_load<L>(&a[i1], role), role);
+  quad_block_tree<L>(x, sh, q, 64, role);
+  if (q == 0) qpt_store<L>(&out[(size_t)w * stride_out + blockIdx.x], role, x);
 }
 
 // In-place re-encoding of uploaded bases for LAZY curves: x*2^(32N) -> canonical x*R' (infinity stays 0,0)
@@ -318,8 +366,12 @@ inline MsmParams msm_plan(size_t n, int scalar_bits, int mont) {
   p.L = (uint32_t)L;
   const uint32_t max_lanes = (uint32_t)((n + L - 1) / L);
   p.tmax = p.NB + max_lanes + 2;  // partial slots per window: slot = bucket + lane
-  p.S = 64;
-  while (p.S < 8192 && (uint64_t)p.S * 8 < p.NB) p.S <<= 1;  // ~8 buckets per reduction segment
+  {
+    int per = tune().msm_seg_buckets.load(std::memory_order_relaxed);  // buckets per reduction segment
+    if (per != 2 && per != 4 && per != 8 && per != 16) per = 8;
+    p.S = 64;
+    while (p.S < 16384 && (uint64_t)p.S * per < p.NB) p.S <<= 1;
+  }
   p.mont = mont;
   uint64_t ch = 512 / (uint64_t)p.W;
   const uint64_t by_size = n / (2ull * p.NB);
@@ -432,7 +484,8 @@ size_t msm_bucket_bytes(const MsmParams* pp) {
   need += Arena::padded(sizeof(LazyPt<Cfg>) * (size_t)p.S * p.W);          // segment results
   need += Arena::padded(sizeof(LazyPt<Cfg>) * (size_t)(p.NB + 1) * p.W);   // dense bucket sums
   need += Arena::padded(sizeof(uint32_t) * (2 * (size_t)max_giant + 2));
-  need += Arena::padded(sizeof(LazyPt<Cfg>) * 256 * (size_t)giant_blocks);
+  need += 2 * Arena::padded(sizeof(LazyPt<Cfg>) * (size_t)((p.S + 127) / 128) * p.W);  // fold-tree ping / pong
+  (void)giant_blocks;
   return need;
 }
 
@@ -450,7 +503,9 @@ int msm_bucket_stage(const void* points, const MsmParams* pp, const SortOut* so,
   LazyPt<Cfg>* segres = ar.take<LazyPt<Cfg>>((size_t)p.S * p.W);
   LazyPt<Cfg>* dense = ar.take<LazyPt<Cfg>>((size_t)(p.NB + 1) * p.W);
   uint32_t* giant = ar.take<uint32_t>(2 * (size_t)max_giant + 2);  // [0] = count, list from [2]
-  LazyPt<Cfg>* giant_tmp = ar.take<LazyPt<Cfg>>(256 * (size_t)giant_blocks);
+  const uint32_t fold_n1 = (p.S + 127) / 128;
+  LazyPt<Cfg>* fold_a = ar.take<LazyPt<Cfg>>((size_t)fold_n1 * p.W);
+  LazyPt<Cfg>* fold_b = ar.take<LazyPt<Cfg>>((size_t)fold_n1 * p.W);
   const Affine<Fq>* bases = reinterpret_cast<const Affine<Fq>*>(points);
   {
     const int tb = tune().acc_blk.load(std::memory_order_relaxed);
@@ -460,13 +515,26 @@ int msm_bucket_stage(const void* points, const MsmParams* pp, const SortOut* so,
   }
   if (ev) CSH_HIP(hipEventRecord(ev[4], st));
   CSH_HIP(hipMemsetAsync(giant, 0, 8, st));
-  hipLaunchKernelGGL(k_msm_merge<Cfg>, dim3((p.NB + 63) / 64, p.W), dim3(64), 0, st, p, so->start, partial, dense, giant, giant + 2);
+  hipLaunchKernelGGL(k_msm_merge<Cfg>, dim3((p.NB + TAIL_Q - 1) / TAIL_Q, p.W), dim3(TAIL_BLK), 0, st, p, so->start, partial, dense, giant, giant + 2);
   // buckets with > MERGE_CAP partials (heavily repeated scalars): block-wide tree, grid-stride over the queue
-  hipLaunchKernelGGL(k_msm_merge_giant<Cfg>, dim3(giant_blocks), dim3(256), 0, st, p, so->start, partial, dense, giant, giant + 2, giant_tmp);
-  hipLaunchKernelGGL(k_msm_reduce<Cfg>, dim3((p.S + 63) / 64, p.W), dim3(64), 0, st, p, dense, segres);
-  for (uint32_t half = p.S / 2; half >= 1; half >>= 1)
-    hipLaunchKernelGGL(k_msm_fold<Cfg>, dim3((half + 63) / 64, p.W), dim3(64), 0, st, segres, p.S, half);
-  hipLaunchKernelGGL(k_msm_gather_windows<Cfg>, dim3(1), dim3(MAX_WINDOWS), 0, st, segres, p.S, p.W, reinterpret_cast<XYZZ<Fq>*>(win_out_dev));
+  hipLaunchKernelGGL(k_msm_merge_giant<Cfg>, dim3(giant_blocks), dim3(256), 0, st, p, so->start, partial, dense, giant, giant + 2);
+  if (tune().msm_variant.load(std::memory_order_relaxed) & 1)
+    hipLaunchKernelGGL(k_msm_reduce<Cfg>, dim3((p.S + TAIL_Q - 1) / TAIL_Q, p.W), dim3(TAIL_BLK), 0, st, p, dense, segres);
+  else
+    hipLaunchKernelGGL(k_msm_reduce_serial<Cfg>, dim3((p.S + 63) / 64, p.W), dim3(64), 0, st, p, dense, segres);
+  // fold tree: S segment sums per window -> one, 128 per block and launch
+  const LazyPt<Cfg>* cur = segres;
+  uint32_t cur_n = p.S, cur_stride = p.S;
+  LazyPt<Cfg>* nxt = fold_a;
+  while (cur_n > 1) {
+    const uint32_t out_n = (cur_n + 127) / 128;
+    hipLaunchKernelGGL(k_msm_fold_tree<Cfg>, dim3(out_n, p.W), dim3(256), 0, st, cur, cur_stride, cur_n, nxt, fold_n1);
+    cur = nxt;
+    cur_n = out_n;
+    cur_stride = fold_n1;
+    nxt = nxt == fold_a ? fold_b : fold_a;
+  }
+  hipLaunchKernelGGL(k_msm_gather_windows<Cfg>, dim3(1), dim3(MAX_WINDOWS), 0, st, cur, cur_stride, p.W, reinterpret_cast<XYZZ<Fq>*>(win_out_dev));
   if (ev) CSH_HIP(hipEventRecord(ev[5], st));
   CSH_HIP(hipGetLastError());
   return CSH_OK;
