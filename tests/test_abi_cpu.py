@@ -123,3 +123,21 @@ def test_plain_c_caller_links_and_fails_loudly_without_a_gpu(hip, tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 3, (r.returncode, r.stderr)
     assert "no CPU fallback" in r.stderr
+
+
+def test_rust_sys_crate_covers_every_header_symbol():
+    """rust/cosnarks-hip-sys/src/lib.rs is generated from include/cosnarks_hip.h (tools/gen_rust_sys.py): regenerating must be a
+    no-op and every declared entry point must appear in the extern block (the crate cannot be compiled here: no rustc)."""
+    import re
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(ROOT, "rust", "cosnarks-hip-sys", "src", "lib.rs")
+    before = open(path).read()
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_rust_sys.py")], check=True, capture_output=True)
+    assert open(path).read() == before, "rust/cosnarks-hip-sys/src/lib.rs is stale: run tools/gen_rust_sys.py"
+    have = set(re.findall(r"pub fn (csh_\w+)\(", before))
+    from cosnarks_amd import bindings
+    assert have == set(bindings.declared_symbols())
+    for f in ("lib.rs", "drivers.rs", "hip_reduction.rs", "layout.rs", "bases.rs", "domain.rs", "split.rs", "error.rs"):
+        assert os.path.exists(os.path.join(ROOT, "rust", "co-groth16-hip", "src", f)), f

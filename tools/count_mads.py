@@ -34,6 +34,6 @@ out = {"Bn254G1": fp_madd(9), "GrumpkinG1": fp_madd(9), "Bls381G1": fp_madd(14),
 if len(sys.argv) > 2 and sys.argv[1] == "--isa":
     s = open(sys.argv[2]).read()
     for m in re.finditer(r"^(_ZN3csh11k_msm_accum\w+):.*?\n(.*?)s_endpgm", s, re.S | re.M):
-        print("ISA static v_mad_i64_i32 in", m.group(1)[:48], "=", m.group(2).count("v_mad_i64_i32"))
+        print("ISA static 64-bit mads (v_mad_i64_i32 + v_mad_u64_u32) in", m.group(1)[:48], "=", m.group(2).count("v_mad_i64_i32") + m.group(2).count("v_mad_u64_u32"))
 json.dump(out, open(os.path.join(ROOT, "profiles", "mads_per_madd.json"), "w"), indent=1)
 print(json.dumps(out))
