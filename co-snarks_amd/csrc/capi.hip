@@ -70,6 +70,7 @@ static const TuneEntry kTune[] = {
     {"ntt_threads", "CSH_NTT_THREADS", &Tune::ntt_threads},
     {"msm_variant", "CSH_MSM_VARIANT", &Tune::msm_variant},
     {"msm_seg_buckets", "CSH_MSM_SEG_BUCKETS", &Tune::msm_seg_buckets},
+    {"allow_unmasked_rep3", "CSH_ALLOW_UNMASKED_REP3", &Tune::allow_unmasked_rep3},
     {"ntt_variant", "CSH_NTT_VARIANT", &Tune::ntt_variant},
 };
 Tune& tune() {

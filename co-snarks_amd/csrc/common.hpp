@@ -106,9 +106,20 @@ struct Tune {
   std::atomic<int> ntt_threads{1024};
   std::atomic<int> msm_variant{0};       // experimental kernel variants (A/B runs)
   std::atomic<int> msm_seg_buckets{8};   // buckets per window-reduction segment
+  std::atomic<int> allow_unmasked_rep3{0};  // Rep3 products without the re-randomising masks: refused unless set (tests)
   std::atomic<int> ntt_variant{0};
 };
 Tune& tune();
+
+// A Rep3 local multiplication without its correlated mask is not a valid sharing step: once opened, the products leak
+// cross terms (rep3/arithmetic.rs:132-146 always adds masking_field_elements_vec). NULL masks / seeds are therefore an
+// error unless the caller has opted in explicitly with csh_tune_set("allow_unmasked_rep3", 1) (unit tests of the arithmetic).
+inline int require_rep3_masks(bool have_masks, const char* what) {
+  if (have_masks || tune().allow_unmasked_rep3.load(std::memory_order_relaxed)) return CSH_OK;
+  set_error("%s: Rep3 (protocol 1) needs its masks / ChaCha12 seeds; unmasked products leak cross terms when opened "
+            "(csh_tune_set(\"allow_unmasked_rep3\", 1) overrides this for tests)", what);
+  return CSH_ERR_INVALID;
+}
 
 inline int grid_for(size_t n, int block, int max_blocks = 256 * 16) {
   size_t g = (n + block - 1) / block;

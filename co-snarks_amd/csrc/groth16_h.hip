@@ -31,6 +31,7 @@ int csh_groth16_h_dev(csh_domain_t dom, const uint64_t shift[4], int protocol, u
                       const uint64_t* mask_ab, uint64_t* h_out, void* stream) {
   CSH_REQUIRE(dom && shift && a && b && h_out, "NULL argument");
   CSH_REQUIRE(protocol == 0 || protocol == 1, "protocol must be 0 (plain/Shamir) or 1 (Rep3)");
+  if (protocol == 1) CSH_TRY(require_rep3_masks(mask_c && mask_ab, "groth16_h"));
   CSH_TRY(ensure_device());
   const Domain* d = reinterpret_cast<const Domain*>(dom);
   const size_t n = domain_size_of(d);
@@ -115,6 +116,7 @@ int csh_groth16_h_libsnark_dev(csh_domain_t dom, const uint64_t generator[4], in
                                const uint64_t* mask, uint64_t* h_out, void* stream) {
   CSH_REQUIRE(dom && generator && a && b && c && h_out, "NULL argument");
   CSH_REQUIRE(protocol == 0 || protocol == 1, "protocol must be 0 (plain/Shamir) or 1 (Rep3)");
+  if (protocol == 1) CSH_TRY(require_rep3_masks(mask != nullptr, "groth16_h_libsnark"));
   CSH_TRY(ensure_device());
   const Domain* d = reinterpret_cast<const Domain*>(dom);
   const size_t n = domain_size_of(d);

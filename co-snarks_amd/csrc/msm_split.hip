@@ -311,7 +311,7 @@ int csh_msm_split(const csh_bases_t* bases, const size_t* offsets, const size_t*
       hipStream_t st = resolve_stream(nullptr);
       size_t cnt = 0;
       for (size_t i = 0; i < k; ++i) cnt += parts[i].dev == d;
-      Arena& pa = arena_for((hipStream_t)((uintptr_t)st ^ 0x4));
+      Arena& pa = arena_for((hipStream_t)((uintptr_t)st ^ 0x8));
       CSH_TRY(pa.reserve(Arena::padded(pb) * (cnt + (d == devs[0] ? k : 0))));  // + the gather region on the root device
       for (size_t i = 0; i < k; ++i)
         if (parts[i].dev == d) {
@@ -351,7 +351,7 @@ int csh_msm_split(const csh_bases_t* bases, const size_t* offsets, const size_t*
       }
       CSH_TRY(csh_init(root));
       hipStream_t rs = resolve_stream(nullptr);
-      Arena& pa = arena_for((hipStream_t)((uintptr_t)rs ^ 0x4));
+      Arena& pa = arena_for((hipStream_t)((uintptr_t)rs ^ 0x8));
       char* gather = pa.take<char>(pb * k);
       size_t ei = 0;
       for (size_t i = 0; i < k; ++i) {

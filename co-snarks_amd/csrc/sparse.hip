@@ -10,6 +10,8 @@ namespace csh {
 
 struct Matrix {
   csh_curve_t curve;
+  int device;        // handles are per device (checked on use, like bases and domains)
+  uint32_t max_col;  // largest column index (validated against n_public + n_witness where the caller states them)
   size_t n_rows, nnz;
   uint64_t* row_ptr;  // device, n_rows + 1
   uint32_t* col_idx;  // device, nnz
@@ -103,9 +105,15 @@ int csh_matrix_upload(csh_curve_t field_of, const uint64_t* row_ptr, const uint3
   CSH_REQUIRE(out && row_ptr && (nnz == 0 || (col_idx && coeffs)), "matrix_upload: NULL argument");
   CSH_REQUIRE(field_of == CSH_BN254 || field_of == CSH_BLS12_381 || field_of == CSH_BLS12_377, "unknown curve");
   CSH_REQUIRE(row_ptr[n_rows] == nnz, "matrix_upload: row_ptr[n_rows] != nnz");
+  CSH_REQUIRE(row_ptr[0] == 0, "matrix_upload: row_ptr[0] != 0");
+  for (size_t i = 0; i < n_rows; ++i) CSH_REQUIRE(row_ptr[i] <= row_ptr[i + 1], "matrix_upload: row_ptr is not monotone");
+  uint32_t max_col = 0;
+  for (size_t i = 0; i < nnz; ++i) max_col = col_idx[i] > max_col ? col_idx[i] : max_col;
   CSH_TRY(ensure_device());
   Matrix* m = new Matrix();
   m->curve = field_of;
+  m->max_col = max_col;
+  if (hipGetDevice(&m->device) != hipSuccess) m->device = 0;
   m->n_rows = n_rows;
   m->nnz = nnz;
   m->row_ptr = nullptr;
@@ -138,12 +146,33 @@ int csh_matrix_free(csh_matrix_t mm) {
   return CSH_OK;
 }
 
+// a matrix handle used from a thread bound to another GPU would hand the kernels pointers of the wrong device
+static int check_matrix_device(const Matrix* m) {
+  int cur = -1;
+  if (hipGetDevice(&cur) == hipSuccess && cur != m->device) {
+    set_error("constraint matrix was uploaded on device %d but the calling thread is bound to device %d (csh_init): upload a copy per device", m->device, cur);
+    return CSH_ERR_INVALID;
+  }
+  return CSH_OK;
+}
+
+int csh_matrix_info(csh_matrix_t mm, size_t* n_rows, size_t* nnz, uint32_t* max_column, int* device) {
+  CSH_REQUIRE(mm, "matrix is NULL");
+  const Matrix* m = reinterpret_cast<const Matrix*>(mm);
+  if (n_rows) *n_rows = m->n_rows;
+  if (nnz) *nnz = m->nnz;
+  if (max_column) *max_column = m->max_col;
+  if (device) *device = m->device;
+  return CSH_OK;
+}
+
 int csh_evaluate_constraints_dev(csh_matrix_t mm, int protocol, int party_id, const uint64_t* public_dev, size_t n_public,
                                  const uint64_t* witness_dev, uint64_t* out_dev, size_t n_out, void* stream) {
   CSH_REQUIRE(mm && out_dev, "evaluate_constraints: NULL argument");
   CSH_REQUIRE(protocol == 0 || protocol == 1, "protocol must be 0 (plain/Shamir) or 1 (Rep3)");
   CSH_TRY(ensure_device());
   Matrix* m = reinterpret_cast<Matrix*>(mm);
+  CSH_TRY(check_matrix_device(m));
   hipStream_t st = resolve_stream(stream);
   if (m->curve == CSH_BN254) return eval_t<Bn254Fr>(m, protocol, party_id, public_dev, n_public, witness_dev, out_dev, n_out, st);
   if (m->curve == CSH_BLS12_377) return eval_t<Bls377Fr>(m, protocol, party_id, public_dev, n_public, witness_dev, out_dev, n_out, st);
@@ -156,6 +185,7 @@ int csh_groth16_witness_map_dev(csh_domain_t dom, const uint64_t shift[4], int p
                                 const uint8_t seed1[32], uint64_t off1, const uint8_t seed2[32], uint64_t off2, uint64_t* h_out_dev, void* stream) {
   CSH_REQUIRE(dom && shift && ma && mb && h_out_dev && (public_inputs || n_public == 0) && witness_dev, "witness_map_dev: NULL argument");
   CSH_REQUIRE(protocol == 0 || protocol == 1, "protocol must be 0 (plain/Shamir) or 1 (Rep3)");
+  if (protocol == 1) CSH_TRY(require_rep3_masks(seed1 && seed2, "groth16_witness_map"));
   CSH_TRY(ensure_device());
   const Domain* d = reinterpret_cast<const Domain*>(dom);
   const size_t n = domain_size_of(d);
@@ -190,8 +220,14 @@ int csh_groth16_witness_map_dev(csh_domain_t dom, const uint64_t shift[4], int p
 int csh_groth16_witness_map(csh_domain_t dom, const uint64_t shift[4], int protocol, int party_id, csh_matrix_t ma, csh_matrix_t mb,
                             size_t num_constraints, const uint64_t* public_inputs, size_t n_public, const uint64_t* witness, size_t n_witness,
                             const uint8_t seed1[32], uint64_t off1, const uint8_t seed2[32], uint64_t off2, uint64_t* h_out) {
-  CSH_REQUIRE(dom && h_out && (witness || n_witness == 0), "witness_map: NULL argument");
+  CSH_REQUIRE(dom && ma && mb && h_out && (witness || n_witness == 0), "witness_map: NULL argument");
   CSH_REQUIRE(protocol == 0 || protocol == 1, "protocol must be 0 (plain/Shamir) or 1 (Rep3)");
+  {  // a column index beyond public || witness would be an out-of-bounds device read in the row kernel
+    const Matrix* A = reinterpret_cast<const Matrix*>(ma);
+    const Matrix* B = reinterpret_cast<const Matrix*>(mb);
+    const uint32_t mc = A->max_col > B->max_col ? A->max_col : B->max_col;
+    CSH_REQUIRE((A->nnz == 0 && B->nnz == 0) || (size_t)mc < n_public + n_witness, "witness_map: a matrix column index exceeds n_public + n_witness");
+  }
   const size_t n = domain_size_of(reinterpret_cast<const Domain*>(dom));
   const size_t comp = protocol == 1 ? 2 : 1;
   CSH_TRY(ensure_device());
@@ -218,6 +254,11 @@ int csh_groth16_witness_map_libsnark(csh_domain_t dom, const uint64_t generator[
   CSH_REQUIRE(dom && generator && ma && mb && mc && h_out && (public_inputs || n_public == 0) && (witness || n_witness == 0),
               "witness_map_libsnark: NULL argument");
   CSH_REQUIRE(protocol == 0 || protocol == 1, "protocol must be 0 (plain/Shamir) or 1 (Rep3)");
+  if (protocol == 1) CSH_TRY(require_rep3_masks(seed1 && seed2, "groth16_witness_map_libsnark"));
+  for (csh_matrix_t mm : {ma, mb, mc}) {
+    const Matrix* M = reinterpret_cast<const Matrix*>(mm);
+    CSH_REQUIRE(M->nnz == 0 || (size_t)M->max_col < n_public + n_witness, "witness_map_libsnark: a matrix column index exceeds n_public + n_witness");
+  }
   const Domain* d = reinterpret_cast<const Domain*>(dom);
   const size_t n = domain_size_of(d);
   const csh_curve_t f = domain_curve_of(d);

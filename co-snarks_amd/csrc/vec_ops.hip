@@ -209,6 +209,7 @@ int csh_vec_mul_table_dev(csh_curve_t f, uint64_t* v, const uint64_t* table, siz
   FR_DISPATCH(f, vec_mul_table_t<F>(v, table, n, ncomp, st));
 }
 int csh_rep3_local_mul_vec_dev(csh_curve_t f, const uint64_t* l, const uint64_t* r, const uint64_t* m, uint64_t* out, size_t n, void* stream) {
+  CSH_TRY(require_rep3_masks(m != nullptr || n == 0, "rep3_local_mul_vec"));
   CSH_TRY(ensure_device());
   hipStream_t st = resolve_stream(stream);
   FR_DISPATCH(f, rep3_local_mul_t<F>(l, r, m, out, n, st));

@@ -14,6 +14,31 @@
 #include "plonk_honk.hpp"
 #include "zkey.hpp"
 
+#include <sys/random.h>
+
+namespace cosnarks {
+void secure_random_bytes(void* out, size_t n) {
+  uint8_t* p = static_cast<uint8_t*>(out);
+  size_t got = 0;
+  while (got < n) {
+    const ssize_t r = getrandom(p + got, n - got, 0);
+    if (r > 0) {
+      got += (size_t)r;
+      continue;
+    }
+    break;
+  }
+  if (got < n) {  // pre-3.17 kernels / seccomp without getrandom
+    FILE* f = fopen("/dev/urandom", "rb");
+    if (f) {
+      got += fread(p + got, 1, n - got, f);
+      fclose(f);
+    }
+  }
+  if (got < n) throw Error("no OS entropy source (getrandom and /dev/urandom both failed)");
+}
+}  // namespace cosnarks
+
 using namespace cosnarks;
 
 namespace {
@@ -25,6 +50,14 @@ typename P::Fr fr_from_canonical(const uint64_t v[4]) {
   typename P::Fr f;
   memcpy(&f, v, 32);
   return f.to_mont();
+}
+
+// the root cause first: parties that merely saw the abort of a failing peer report "network aborted"
+void throw_first_party_error(const std::string* errs, int n) {
+  for (int pass = 0; pass < 2; ++pass)
+    for (int p = 0; p < n; ++p)
+      if (!errs[p].empty() && (pass == 1 || errs[p].find("network aborted") == std::string::npos))
+        throw Error("party " + std::to_string(p) + ": " + errs[p]);
 }
 
 int write_out(const std::string& json, char* out, size_t cap) {
@@ -74,8 +107,8 @@ int prove_plain_t(const uint8_t* zkey, size_t zlen, const uint8_t* wtns, size_t 
 // share_field_elements (mpc-core/src/protocols/rep3.rs:281-292, 375-389) with a seeded RNG
 template <class Fr>
 struct SeededSharer {
-  std::mt19937_64 gen;
-  explicit SeededSharer(uint64_t seed) : gen(seed) {}
+  ShareRng gen;  // seed 0 = OS entropy; a non-zero seed is for reproducible tests only
+  explicit SeededSharer(uint64_t seed, uint64_t domain = 1) : gen(seed, domain) {}
   Fr rnd() {
     uint8_t b[32];
     for (int i = 0; i < 4; ++i) {
@@ -161,7 +194,7 @@ int prove_rep3_core(const uint8_t* zkey, size_t zlen, sharefile::CompressedRep3S
     if (shares[p].public_inputs.size() != m_shared.num_instance_variables) throw Error("witness share: public input count does not match the proving key");
     if (shares[p].length() != m_shared.num_witness_variables) throw Error("witness share: the amount of private witness variables does not match the proving key");
   }
-  SeededSharer<Fr> rs_sharer(seed ^ 0x9e3779b97f4a7c15ull);
+  SeededSharer<Fr> rs_sharer(seed, /*domain=*/11);
   Share r3[3], s3[3];
   if (r) rs_sharer.share(fr_from_canonical<P>(r), r3);
   if (s) rs_sharer.share(fr_from_canonical<P>(s), s3);
@@ -180,11 +213,7 @@ int prove_rep3_core(const uint8_t* zkey, size_t zlen, sharefile::CompressedRep3S
         const ProvingKey<P>& pk = per_party_keys ? pk_own : pk_shared;
         const ConstraintMatrices<P>& m = per_party_keys ? m_own : m_shared;
         uint8_t my_seed[32];
-        std::mt19937_64 g2(seed * 1000003ull + 17 * p + 1);
-        for (int i = 0; i < 4; ++i) {
-          uint64_t v = g2();
-          memcpy(my_seed + 8 * i, &v, 8);
-        }
+        ShareRng(seed, 100 + p).fill(my_seed, 32);  // Rep3State::new draws it from the OS rng (rep3.rs:56-76); seed != 0: tests
         Rep3State state0 = Rep3State::create(nets0[p], my_seed);  // groth16.rs:371
         Rep3State state1 = state0.fork(0);                         // :372
         SharedWitness<P, Share> sw = sharefile::uncompress<P>(std::move(shares[p]), nets0[p]);  // co-circom.rs:1016
@@ -192,12 +221,13 @@ int prove_rep3_core(const uint8_t* zkey, size_t zlen, sharefile::CompressedRep3S
                                                                             r ? &r3[p] : nullptr, s ? &s3[p] : nullptr, &hs[p]);
       } catch (const std::exception& e) {
         errs[p] = e.what();
+        nets0[p].abort();  // let the other parties unwind instead of waiting on this one
+        nets1[p].abort();  // let the other parties unwind instead of waiting on this one
       }
     });
   }
   for (auto& t : th) t.join();
-  for (int p = 0; p < 3; ++p)
-    if (!errs[p].empty()) throw Error("party " + std::to_string(p) + ": " + errs[p]);
+  throw_first_party_error(errs, 3);
   std::string j0 = proof_to_json(proofs[0]);
   if (j0 != proof_to_json(proofs[1]) || j0 != proof_to_json(proofs[2])) throw Error("the three parties disagree on the proof");
   if (h_shares_out) {
@@ -220,9 +250,9 @@ int prove_rep3_t(const uint8_t* zkey, size_t zlen, const uint8_t* wtns, size_t w
 // shamir::share (shamir.rs:359-376): random degree-`deg` polynomial, shares = evaluations at 1..n
 template <class Fr>
 struct SeededShamirSharer {
-  std::mt19937_64 gen;
+  ShareRng gen;  // seed 0 = OS entropy; a non-zero seed is for reproducible tests only
   int n;
-  SeededShamirSharer(uint64_t seed, int parties) : gen(seed), n(parties) {}
+  SeededShamirSharer(uint64_t seed, int parties, uint64_t domain = 2) : gen(seed, domain), n(parties) {}
   Fr rnd() {
     uint8_t b[32];
     for (int i = 0; i < 4; ++i) {
@@ -271,14 +301,19 @@ int prove_shamir_core(const uint8_t* zkey, size_t zlen, std::vector<SharedWitnes
   using Fr = typename P::Fr;
   const int n = (int)sw.size();
   if (n < 2 * t + 1 || t < 1) throw Error("num_parties must be at least 2 * threshold + 1");
-  ProvingKey<P> pk;
-  ConstraintMatrices<P> m;
-  parse_zkey<P>(zkey, zlen, pk, m);
+  int ndev = 1;
+  csh_device_count(&ndev);
+  // device memory is not shared between GPUs: with one GPU per party every party uploads its own copy of the proving key
+  // and matrices onto its device (as prove_rep3_core does); on one GPU a single copy serves all
+  const bool per_party_keys = ndev > 1;
+  ProvingKey<P> pk_shared;
+  ConstraintMatrices<P> m_shared;
+  parse_zkey<P>(zkey, zlen, pk_shared, m_shared, /*upload=*/!per_party_keys);
   for (auto& w : sw) {
-    if (w.public_inputs.size() != m.num_instance_variables) throw Error("witness share: public input count does not match the proving key");
-    if (w.witness.size() != m.num_witness_variables) throw Error("witness share: the amount of private witness variables does not match the proving key");
+    if (w.public_inputs.size() != m_shared.num_instance_variables) throw Error("witness share: public input count does not match the proving key");
+    if (w.witness.size() != m_shared.num_witness_variables) throw Error("witness share: the amount of private witness variables does not match the proving key");
   }
-  SeededShamirSharer<Fr> dealer(seed ^ 0x9e3779b97f4a7c15ull, n);
+  SeededShamirSharer<Fr> dealer(seed, n, /*domain=*/12);
   // dealer: three double sharings per party (two rand calls + one scalar_mul: groth16.rs:448-449)
   std::vector<std::deque<std::pair<Fr, Fr>>> pairs(n);
   for (int k = 0; k < 3; ++k) {
@@ -292,23 +327,27 @@ int prove_shamir_core(const uint8_t* zkey, size_t zlen, std::vector<SharedWitnes
   std::vector<Proof<P>> proofs(n);
   std::vector<std::string> errs(n);
   std::vector<std::thread> th;
-  int ndev = 1;
-  csh_device_count(&ndev);
   for (int p = 0; p < n; ++p) {
     th.emplace_back([&, p] {
       try {
         check(csh_init(ndev > 0 ? p % ndev : 0), "csh_init");
+        ProvingKey<P> pk_own;
+        ConstraintMatrices<P> m_own;
+        if (per_party_keys) parse_zkey<P>(zkey, zlen, pk_own, m_own);  // uploads onto this thread's device
+        const ProvingKey<P>& pk = per_party_keys ? pk_own : pk_shared;
+        const ConstraintMatrices<P>& m = per_party_keys ? m_own : m_shared;
         auto state0 = ShamirState<Fr>::create(p, n, t, pairs[p]);
         auto state1 = state0.fork(1);
         proofs[p] = CoGroth16<P, T>::template prove_inner<CircomReduction>(&nets0[p], &nets1[p], state0, state1, pk, m, sw[p], nullptr, nullptr);
       } catch (const std::exception& e) {
         errs[p] = e.what();
+        nets0[p].abort();  // let the other parties unwind instead of waiting on this one
+        nets1[p].abort();  // let the other parties unwind instead of waiting on this one
       }
     });
   }
   for (auto& x : th) x.join();
-  for (int p = 0; p < n; ++p)
-    if (!errs[p].empty()) throw Error("party " + std::to_string(p) + ": " + errs[p]);
+  throw_first_party_error(errs.data(), n);
   std::string j0 = proof_to_json(proofs[0]);
   for (int p = 1; p < n; ++p)
     if (j0 != proof_to_json(proofs[p])) throw Error("the parties disagree on the proof");
@@ -369,8 +408,8 @@ void synth_query(csh_curve_t curve, csh_group_t group, uint64_t seed, size_t n, 
 
 template <class Fr>
 struct Rep3Sharer {
-  std::mt19937_64 gen;
-  explicit Rep3Sharer(uint64_t seed) : gen(seed) {}
+  ShareRng gen;
+  explicit Rep3Sharer(uint64_t seed) : gen(seed, 3) {}
   Fr rnd() {
     uint8_t b[32];
     for (int i = 0; i < 4; ++i) {
@@ -515,16 +554,14 @@ int bench_synth_t(int log_domain, int iters, double* out_ms, int* check_ok, cons
           try {
             check(csh_init(0), "csh_init");
             uint8_t my_seed[32];
-            std::mt19937_64 g2(4242ull * 1000003ull + 17 * p + 1 + it);
-            for (int i = 0; i < 4; ++i) {
-              uint64_t v = g2();
-              memcpy(my_seed + 8 * i, &v, 8);
-            }
+            ShareRng(4242ull + it, 100 + p).fill(my_seed, 32);
             Rep3State state0 = Rep3State::create(nets0[p], my_seed);
             Rep3State state1 = state0.fork(0);
             proofs[p] = CoGroth16<P, T3>::template prove_inner<CircomReduction>(&nets0[p], &nets1[p], state0, state1, pk, m, sw3[p], &r3[p], &s3[p]);
           } catch (const std::exception& e) {
             errs[p] = e.what();
+        nets0[p].abort();  // let the other parties unwind instead of waiting on this one
+        nets1[p].abort();  // let the other parties unwind instead of waiting on this one
           }
         });
       }
@@ -583,7 +620,7 @@ int witness_map_t(int reduction, int mode, const uint64_t* const row_ptr[3], con
     return (int)h.size();
   }
   using Share = Rep3PrimeFieldShare<Fr>;
-  std::mt19937_64 gen(seed);
+  ShareRng gen(seed, 4);
   auto rnd = [&] {
     uint8_t b[32];
     for (int i = 0; i < 4; ++i) {
@@ -609,21 +646,17 @@ int witness_map_t(int reduction, int mode, const uint64_t* const row_ptr[3], con
       try {
         check(csh_init(0), "csh_init");
         uint8_t my_seed[32];
-        std::mt19937_64 g2(seed * 1000003ull + 17 * p + 1);
-        for (int i = 0; i < 4; ++i) {
-          uint64_t v = g2();
-          memcpy(my_seed + 8 * i, &v, 8);
-        }
+        ShareRng(seed, 100 + p).fill(my_seed, 32);  // Rep3State::new draws it from the OS rng (rep3.rs:56-76); seed != 0: tests
         Rep3State state = Rep3State::create(nets[p], my_seed);
         hs[p] = run(Rep3Groth16Driver<P>{}, state, wit[p]);
       } catch (const std::exception& e) {
         errs[p] = e.what();
+        nets[p].abort();  // let the other parties unwind instead of waiting on this one
       }
     });
   }
   for (auto& t : th) t.join();
-  for (int p = 0; p < 3; ++p)
-    if (!errs[p].empty()) throw Error("party " + std::to_string(p) + ": " + errs[p]);
+  throw_first_party_error(errs, 3);
   const size_t n = hs[0].size();
   if (3 * n > h_cap) throw Error("h_out too small");
   for (int p = 0; p < 3; ++p) memcpy(h_out + 4 * n * p, hs[p].data(), 32 * n);
@@ -641,21 +674,17 @@ void run_three_parties(uint64_t seed, Fn fn) {  // fn(party, Rep3State&)
       try {
         check(csh_init(0), "csh_init");
         uint8_t my_seed[32];
-        std::mt19937_64 g2(seed * 1000003ull + 17 * p + 1);
-        for (int i = 0; i < 4; ++i) {
-          uint64_t v = g2();
-          memcpy(my_seed + 8 * i, &v, 8);
-        }
+        ShareRng(seed, 100 + p).fill(my_seed, 32);  // Rep3State::new draws it from the OS rng (rep3.rs:56-76); seed != 0: tests
         Rep3State state = Rep3State::create(nets[p], my_seed);
         fn(p, state);
       } catch (const std::exception& e) {
         errs[p] = e.what();
+        nets[p].abort();  // let the other parties unwind instead of waiting on this one
       }
     });
   }
   for (auto& t : th) t.join();
-  for (int p = 0; p < 3; ++p)
-    if (!errs[p].empty()) throw Error("party " + std::to_string(p) + ": " + errs[p]);
+  throw_first_party_error(errs, 3);
 }
 
 template <class P>

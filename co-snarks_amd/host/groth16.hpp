@@ -258,6 +258,17 @@ struct CoGroth16 {
     }
   }
 
+  template <class Fn>
+  static void net_leg(const Net* net0, const Net* net1, Fn fn) {
+    try {
+      fn();
+    } catch (...) {
+      if (net0) net0->abort();
+      if (net1) net1->abort();
+      throw;
+    }
+  }
+
   // the part of calculate_coeff (groth16.rs:179-203) around the private-input MSM, given that MSM's result
   template <class F>
   static Proj<F> finish_coeff(int id, Proj<F> initial, const Query<F>& query, const AffineT<F>& vk_param, const std::vector<Fr>& input_assignment,
@@ -314,14 +325,10 @@ struct CoGroth16 {
     Span* sp_msm = new Span("5 msm groups (compute A, B/G1, B/G2, msm l_query, msm h_query)");
     int cur_dev = 0;
     (void)csh_current_device(&cur_dev);
-    std::string h_err;
-    std::thread t5([&] {
-      try {
-        check(csh_init(cur_dev), "csh_init");  // a new host thread is not bound to the parent's GPU
-        h_acc = T::template msm_public_points_hs<Fq>(BasesView{pkey.h_query.dev, 0, pkey.h_query.size()}, h_dev);
-      } catch (const std::exception& e) {
-        h_err = e.what();
-      }
+    // workers carry their exception back to join() (a plain std::thread would std::terminate on a HIP OOM in an MSM)
+    Joined t5([&] {
+      check(csh_init(cur_dev), "csh_init");  // a new host thread is not bound to the parent's GPU
+      h_acc = T::template msm_public_points_hs<Fq>(BasesView{pkey.h_query.dev, 0, pkey.h_query.size()}, h_dev);
     });
     const size_t pub_len = inputs.size();
     const size_t n_aux = aux_dev.n;
@@ -336,7 +343,7 @@ struct CoGroth16 {
       void* const outs[4] = {&ja, &jb1, &jb2, &jl};
       int rc = csh_msm_multi_dev(hs, offs, 4, n_aux, reinterpret_cast<const uint64_t*>(aux_dev.dev), 1, outs, nullptr);
       if (rc != CSH_OK) {
-        t5.join();
+        t5.join_quiet();
         check(rc, "csh_msm_multi_dev");
       }
       auto to_proj = [](const auto& j) {
@@ -348,16 +355,14 @@ struct CoGroth16 {
       s_g2 = finish_coeff<Fq2>(id, T::template scalar_mul_public_point_hs<Fq2>(delta_g2, T::to_half_share(s)), pkey.b_g2_query, pkey.beta_g2, inputs, to_proj(jb2));
       l_acc = to_proj(jl);
       t5.join();
-      if (!h_err.empty()) throw Error(h_err);
     } else {
       // (fallback: separate MSMs from separate host threads, each bound to the parent's GPU)
       auto bind = [cur_dev] { check(csh_init(cur_dev), "csh_init"); };
-      std::thread t1([&] { bind(); r_g1 = calculate_coeff<Fq>(id, T::template scalar_mul_public_point_hs<Fq>(delta_g1, T::to_half_share(r)), pkey.a_query, pkey.alpha_g1, inputs, aux_dev); });
-      std::thread t2([&] { bind(); s_g1 = calculate_coeff<Fq>(id, T::template scalar_mul_public_point_hs<Fq>(delta_g1, T::to_half_share(s)), pkey.b_g1_query, pkey.beta_g1, inputs, aux_dev); });
-      std::thread t3([&] { bind(); s_g2 = calculate_coeff<Fq2>(id, T::template scalar_mul_public_point_hs<Fq2>(delta_g2, T::to_half_share(s)), pkey.b_g2_query, pkey.beta_g2, inputs, aux_dev); });
-      std::thread t4([&] { bind(); l_acc = T::template msm_public_points_hs<Fq>(BasesView{pkey.l_query.dev, 0, pkey.l_query.size()}, aux_dev); });
-      t1.join(); t2.join(); t3.join(); t4.join(); t5.join();
-      if (!h_err.empty()) throw Error(h_err);
+      Joined t1([&] { bind(); r_g1 = calculate_coeff<Fq>(id, T::template scalar_mul_public_point_hs<Fq>(delta_g1, T::to_half_share(r)), pkey.a_query, pkey.alpha_g1, inputs, aux_dev); });
+      Joined t2([&] { bind(); s_g1 = calculate_coeff<Fq>(id, T::template scalar_mul_public_point_hs<Fq>(delta_g1, T::to_half_share(s)), pkey.b_g1_query, pkey.beta_g1, inputs, aux_dev); });
+      Joined t3([&] { bind(); s_g2 = calculate_coeff<Fq2>(id, T::template scalar_mul_public_point_hs<Fq2>(delta_g2, T::to_half_share(s)), pkey.b_g2_query, pkey.beta_g2, inputs, aux_dev); });
+      Joined t4([&] { bind(); l_acc = T::template msm_public_points_hs<Fq>(BasesView{pkey.l_query.dev, 0, pkey.l_query.size()}, aux_dev); });
+      t1.join(); t2.join(); t3.join(); t4.join(); t5.join();  // the first failure is rethrown; ~Joined reaps the rest
     }
     delete sp_msm;
     Span sp_fin("finish - open two points and some adds");
@@ -366,8 +371,9 @@ struct CoGroth16 {
     Proj<Fq> r_s_delta_g1 = T::template scalar_mul_public_point_hs<Fq>(delta_g1, rs);        // :298
     Proj<Fq> g_a_opened, r_g1_b;
     {  // mpc_net::join (:305-308): two network legs
-      std::thread n1([&] { r_g1_b = scalar_mul_dispatch(s_g1, r, net1, state1); });
-      g_a_opened = T::template open_half_point<Fq>(r_g1, net0, state0);
+      // a leg that throws aborts both networks first, so that the other leg (and the peers) unwind instead of waiting
+      Joined n1([&] { net_leg(net0, net1, [&] { r_g1_b = scalar_mul_dispatch(s_g1, r, net1, state1); }); });
+      net_leg(net0, net1, [&] { g_a_opened = T::template open_half_point<Fq>(r_g1, net0, state0); });
       n1.join();
     }
     Proj<Fq> g_c = T::template scalar_mul_public_point_hs<Fq>(g_a_opened, T::to_half_share(s));  // :313-314
@@ -378,8 +384,8 @@ struct CoGroth16 {
     Proj<Fq> g_c_opened;
     Proj<Fq2> g2_b_opened;
     {  // :325-328
-      std::thread n1([&] { g2_b_opened = T::template open_half_point<Fq2>(s_g2, net1, state1); });
-      g_c_opened = T::template open_half_point<Fq>(g_c, net0, state0);
+      Joined n1([&] { net_leg(net0, net1, [&] { g2_b_opened = T::template open_half_point<Fq2>(s_g2, net1, state1); }); });
+      net_leg(net0, net1, [&] { g_c_opened = T::template open_half_point<Fq>(g_c, net0, state0); });
       n1.join();
     }
     return Proof<P>{into_affine(g_a_opened), into_affine(g_c_opened), into_affine(g2_b_opened)};

@@ -120,9 +120,8 @@ struct PlainGroth16Driver {
   static constexpr bool DEVICE_MASKS = false;
 
   static ArithmeticShare rand(const Net*, State&) {  // mpc/plain.rs:23-26
-    std::random_device rd;
     uint8_t b[32];
-    for (auto& x : b) x = (uint8_t)rd();
+    secure_random_bytes(b, 32);  // thread_rng() in the reference: a CSPRNG
     return from_be_bytes_mod_order<Fr>(b);
   }
   static ArithmeticShare evaluate_constraint(int, const std::vector<std::pair<Fr, size_t>>& lhs, const std::vector<Fr>& pub,
@@ -239,10 +238,14 @@ struct Rep3Groth16Driver {
     Proj<F> a_hs = into_group(net->reshare(mine));
     // b * point: rhs.a*self.a + rhs.b*self.a + rhs.a*self.b (rep3/pointshare/ops.rs:95-102) + masking_ec_element
     Proj<F> r = point_add(point_add(point_mul(a, b.a), point_mul(a_hs, b.a)), point_mul(a, b.b));
-    // masking_ec_element = C::rand(rng1) - C::rand(rng2) (rngs.rs:177-187): a random multiple of the generator per stream
+    // + masking_ec_element = C::rand(rng1) - C::rand(rng2) (rngs.rs:177-187, pointshare.rs:124): re-randomises the half share
+    // before it is opened. A uniform group element per stream = a uniform multiple of the generator: (m1 - m2) * G, the three
+    // parties' masks summing to the identity exactly as the reference's do.
     auto [m1, m2] = st.rand.template random_fes<Fr>();
-    (void)m1; (void)m2;  // zero-sum across parties; generator-free mirror: omitted (documented in DESIGN.md)
-    return r;
+    AffineT<F> gen;
+    static_assert(sizeof(gen) == sizeof(AffineT<typename P::Fq>), "scalar_mul is only used on G1 (mpc.rs:131-137)");
+    memcpy(&gen, P::g1_generator_words(), sizeof gen);
+    return point_add(r, point_mul(into_group(gen), Fr::sub(m1, m2)));
   }
 };
 

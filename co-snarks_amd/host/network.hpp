@@ -5,8 +5,11 @@
 // tests run three parties in one process (tests/tests/circom/e2e_tests/rep3.rs:57-69). The real inter-party
 // transport (TCP/TLS/QUIC) is out of scope: it carries ~1 KB per proof and stays in the Rust host.
 #pragma once
+#include <atomic>
 #include <condition_variable>
 #include <deque>
+#include <exception>
+#include <thread>
 #include <memory>
 #include <mutex>
 #include <vector>
@@ -17,10 +20,16 @@ namespace cosnarks {
 
 using Bytes = std::vector<uint8_t>;
 
+// thrown out of recv() in every party once one party has given up (LocalNetwork::abort): nobody blocks forever on a peer that died
+struct NetworkAborted : Error {
+  NetworkAborted() : Error("network aborted: another party failed") {}
+};
+
 struct Channel {
   std::mutex mu;
   std::condition_variable cv;
   std::deque<Bytes> q;
+  const std::atomic<bool>* aborted = nullptr;
   void push(Bytes b) {
     {
       std::lock_guard<std::mutex> g(mu);
@@ -30,25 +39,68 @@ struct Channel {
   }
   Bytes pop() {
     std::unique_lock<std::mutex> g(mu);
-    cv.wait(g, [&] { return !q.empty(); });
+    cv.wait(g, [&] { return !q.empty() || (aborted && aborted->load()); });
+    if (q.empty()) throw NetworkAborted();
     Bytes b = std::move(q.front());
     q.pop_front();
     return b;
+  }
+  void wake() {
+    std::lock_guard<std::mutex> g(mu);
+    cv.notify_all();
   }
 };
 
 struct LocalFabric {
   int n;
+  std::atomic<bool> aborted{false};
   std::vector<std::unique_ptr<Channel>> ch;  // [from * n + to]
   explicit LocalFabric(int parties) : n(parties) {
-    for (int i = 0; i < n * n; ++i) ch.emplace_back(new Channel());
+    for (int i = 0; i < n * n; ++i) {
+      ch.emplace_back(new Channel());
+      ch.back()->aborted = &aborted;
+    }
   }
+  void abort() {
+    aborted.store(true);
+    for (auto& c : ch) c->wake();
+  }
+};
+
+// A worker thread whose exception is carried back to the joiner (std::thread would call std::terminate): the two network
+// legs of mpc_net::join (mpc-net/src/lib.rs:139-148) and the MSM closures of rayon_join5 (groth16.rs:227-294).
+struct Joined {
+  std::thread th;
+  std::exception_ptr err;
+  template <class Fn>
+  explicit Joined(Fn fn) : th([this, fn]() mutable {
+    try {
+      fn();
+    } catch (...) {
+      err = std::current_exception();
+    }
+  }) {}
+  Joined(const Joined&) = delete;
+  void join() {
+    if (th.joinable()) th.join();
+    if (err) {
+      std::exception_ptr e = err;
+      err = nullptr;
+      std::rethrow_exception(e);
+    }
+  }
+  void join_quiet() noexcept {  // on an error path that is already propagating another exception
+    if (th.joinable()) th.join();
+    err = nullptr;
+  }
+  ~Joined() { join_quiet(); }
 };
 
 struct LocalNetwork {
   std::shared_ptr<LocalFabric> fab;
   int my_id;
   int id() const { return my_id; }
+  void abort() const { fab->abort(); }  // a failing party calls this so that its peers unwind instead of waiting on it
   void send(int to, Bytes b) const { fab->ch[my_id * fab->n + to]->push(std::move(b)); }
   Bytes recv(int from) const { return fab->ch[from * fab->n + my_id]->pop(); }
   static std::vector<LocalNetwork> new_parties(int n) {
@@ -135,6 +187,41 @@ struct ChaCha12 {
       n -= k;
     }
   }
+};
+
+// ---- randomness for shares, seeds and PRF keys --------------------------------------------------------------------
+// OS CSPRNG (getrandom(2), /dev/urandom as a fallback); throws if neither works.
+void secure_random_bytes(void* out, size_t n);
+
+// seed == 0 (production): a ChaCha12 stream keyed with 32 bytes of OS entropy. seed != 0 (TEST ONLY: reproducible fixtures
+// and golden proofs): the key is expanded from (seed, domain) -- 64 bits of entropy at most, never for shares handed to
+// real parties. `domain` separates the streams drawn for different purposes / parties from one seed.
+struct ShareRng {
+  ChaCha12 stream;
+  static ChaCha12 make(uint64_t seed, uint64_t domain) {
+    uint8_t key[32];
+    if (seed == 0) {
+      secure_random_bytes(key, 32);
+    } else {
+      uint64_t x = seed ^ (domain * 0x9E3779B97F4A7C15ull);
+      for (int i = 0; i < 4; ++i) {
+        x += 0x9E3779B97F4A7C15ull;
+        uint64_t z = x;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        memcpy(key + 8 * i, &z, 8);
+      }
+    }
+    return ChaCha12(key);
+  }
+  ShareRng(uint64_t seed, uint64_t domain) : stream(make(seed, domain)) {}
+  uint64_t operator()() {
+    uint64_t v;
+    stream.fill_bytes(reinterpret_cast<uint8_t*>(&v), 8);
+    return v;
+  }
+  void fill(uint8_t* out, size_t n) { stream.fill_bytes(out, n); }
 };
 
 // F::from_be_bytes_mod_order over a MODULUS_BIT_SIZE.div_ceil(8) = 32-byte chunk (rngs.rs:137-156).

@@ -184,7 +184,7 @@ struct Rep3PlonkDriver {
     check(csh_bases_upload(P::ID, CSH_G1, points.data(), cnt, 0, &h), "csh_bases_upload");  // uploaded once for both MSMs
     const BasesView v{h, 0, cnt};
     try {
-      std::thread t([&] { out.b = msm_device<Fq>(v, b.data(), cnt); });  // rayon::join
+      Joined t([&] { out.b = msm_device<Fq>(v, b.data(), cnt); });  // rayon::join; an exception is rethrown by join()
       out.a = msm_device<Fq>(v, a.data(), cnt);
       t.join();
     } catch (...) {

@@ -18,13 +18,13 @@ struct Sections {
     memcpy(&nsec, d + 8, 4);
     size_t off = 12;
     for (uint32_t i = 0; i < nsec; ++i) {
-      if (off + 12 > n) throw Error("truncated section table");
+      if (n - off < 12) throw Error("truncated section table");
       uint32_t typ;
       uint64_t len;
       memcpy(&typ, d + off, 4);
       memcpy(&len, d + off + 4, 8);
       off += 12;
-      if (off + len > n) throw Error("truncated section");
+      if (len > n - off) throw Error("truncated section");  // overflow-safe: len is an attacker-controlled u64
       if (!pos.count(typ)) pos[typ] = {off, (size_t)len};
       off += len;
     }
@@ -55,13 +55,15 @@ void parse_zkey(const uint8_t* d, size_t n, ProvingKey<P>& pk, ConstraintMatrice
   Sections s(d, n, "zkey");
   {
     auto [off, len] = s.at(1);
-    (void)len;
+    if (len < 4) throw Error("truncated zkey protocol section");
     uint32_t proto;
     memcpy(&proto, d + off, 4);
     if (proto != 1) throw Error("not a groth16 zkey");
   }
   auto [h, hl] = s.at(2);
-  (void)hl;
+  // header = n8q, q, n8r, r, nVars, nPublic, domainSize, alpha1, beta1, beta2, gamma2, delta1, delta2
+  const size_t header_need = 4 + sizeof(Fq) + 4 + sizeof(Fr) + 12 + 3 * 2 * sizeof(Fq) + 3 * 4 * sizeof(Fq);
+  if (hl < header_need) throw Error("truncated zkey header");
   uint32_t n8q, n8r, n_vars, n_public, domain;
   memcpy(&n8q, d + h, 4);
   if (n8q != sizeof(Fq)) throw Error("zkey base field size does not match the selected curve");
@@ -75,6 +77,8 @@ void parse_zkey(const uint8_t* d, size_t n, ProvingKey<P>& pk, ConstraintMatrice
   memcpy(&n_public, d + off + 4, 4);
   memcpy(&domain, d + off + 8, 4);
   off += 12;
+  if ((uint64_t)n_public + 1 > n_vars) throw Error("zkey header: more public inputs than variables");
+  if (domain == 0 || (domain & (domain - 1)) != 0) throw Error("zkey header: domain size is not a power of two");
   auto g1 = [&](size_t o) {
     AffineT<Fq> p;
     memcpy(&p, d + o, 2 * n8q);
@@ -93,30 +97,41 @@ void parse_zkey(const uint8_t* d, size_t n, ProvingKey<P>& pk, ConstraintMatrice
   pk.delta_g2 = g2(off);
   // IC stays on the host; the five queries are uploaded from the file image itself ("zkey points are already
   // Montgomery LE -- they can be DMA'd without conversion"). calculate_coeff reads query[0 ..= n_public] on the host.
+  // every point section must hold exactly the number of points the header implies (a short section would make the MSMs
+  // read past the uploaded bases, a ragged one would shift every point after it)
+  auto expect = [&](uint32_t sec, size_t l, size_t point_bytes, size_t count) {
+    if (l != point_bytes * count)
+      throw Error("zkey section " + std::to_string(sec) + ": " + std::to_string(l) + " bytes, expected " + std::to_string(count) + " points of " +
+                  std::to_string(point_bytes) + " bytes");
+  };
+  const size_t keep = (size_t)n_public + 1;
   {
     auto [o, l] = s.at(3);
-    pk.ic.resize(l / (2 * n8q));
-    if (l) memcpy(pk.ic.data(), d + o, pk.ic.size() * 2 * n8q);
+    expect(3, l, 2 * n8q, keep);
+    pk.ic.resize(keep);
+    memcpy(pk.ic.data(), d + o, l);
   }
-  const size_t keep = (size_t)n_public + 1;
-  auto q1 = [&](uint32_t sec, Query<Fq>& q, size_t keep_host) {
+  auto q1 = [&](uint32_t sec, Query<Fq>& q, size_t keep_host, size_t count) {
     auto [o, l] = s.at(sec);
-    q.upload_from(P::ID, CSH_G1, d + o, l / (2 * n8q), keep_host, upload);
+    expect(sec, l, 2 * n8q, count);
+    q.upload_from(P::ID, CSH_G1, d + o, count, keep_host, upload);
   };
-  q1(5, pk.a_query, keep);
-  q1(6, pk.b_g1_query, keep);
-  q1(8, pk.l_query, 0);
-  q1(9, pk.h_query, 0);
+  q1(5, pk.a_query, keep, n_vars);
+  q1(6, pk.b_g1_query, keep, n_vars);
+  q1(8, pk.l_query, 0, (size_t)n_vars - keep);
+  q1(9, pk.h_query, 0, domain);
   {
     auto [o, l] = s.at(7);
-    pk.b_g2_query.upload_from(P::ID, CSH_G2, d + o, l / (4 * n8q), keep, upload);
+    expect(7, l, 4 * n8q, n_vars);
+    pk.b_g2_query.upload_from(P::ID, CSH_G2, d + o, n_vars, keep, upload);
   }
   // coefficients -> ConstraintMatrices (public-input rows, constraint index >= num_constraints, are dropped:
   // the reference overwrites exactly those evaluation slots, groth16/reduction.rs:111-113)
   auto [c, cl] = s.at(4);
-  (void)cl;
+  if (cl < 4) throw Error("truncated zkey coefficient section");
   uint32_t ncoef;
   memcpy(&ncoef, d + c, 4);
+  if ((cl - 4) / (12 + (size_t)n8r) < ncoef) throw Error("zkey coefficient section shorter than its coefficient count");
   size_t o = c + 4;
   uint32_t max_constraint = 0;
   struct Coef { uint32_t m, row, sig; Fr v; };
@@ -129,8 +144,12 @@ void parse_zkey(const uint8_t* d, size_t n, ProvingKey<P>& pk, ConstraintMatrice
     memcpy(&raw, d + o + 12, n8r);
     coefs[i].v = raw.from_mont();  // v R^2 -> v R
     o += 12 + n8r;
+    if (coefs[i].m > 1) throw Error("zkey coefficient: matrix index must be 0 (A) or 1 (B)");
+    if (coefs[i].sig >= n_vars) throw Error("zkey coefficient: signal index " + std::to_string(coefs[i].sig) + " >= nVars");  // an out-of-range column would be an out-of-bounds device read in k_eval_rows
+    if (coefs[i].row >= domain) throw Error("zkey coefficient: constraint index beyond the domain");
     if (coefs[i].row > max_constraint) max_constraint = coefs[i].row;
   }
+  if (max_constraint < n_public) throw Error("zkey coefficients: fewer rows than public inputs");
   m.num_instance_variables = n_public + 1;
   m.num_witness_variables = n_vars - n_public - 1;
   m.num_constraints = max_constraint - n_public;
@@ -148,10 +167,11 @@ std::vector<typename P::Fr> parse_wtns(const uint8_t* d, size_t n) {
   using Fr = typename P::Fr;
   Sections s(d, n, "wtns");
   auto [h, hl] = s.at(1);
-  (void)hl;
+  if (hl < 4 + sizeof(Fr) + 4) throw Error("truncated wtns header");
   uint32_t n8, cnt;
   memcpy(&n8, d + h, 4);
   if (n8 != sizeof(Fr)) throw Error("wtns field size mismatch");
+  if (memcmp(d + h + 4, Fr::Params::MOD, n8) != 0) throw Error("wtns field modulus does not match the selected curve");
   memcpy(&cnt, d + h + 4 + n8, 4);
   auto [o, l] = s.at(2);
   if (l < (size_t)cnt * n8) throw Error("truncated wtns");
@@ -170,10 +190,11 @@ std::vector<typename P::Fr> parse_wtns_prefix(const uint8_t* d, size_t n, size_t
   using Fr = typename P::Fr;
   Sections s(d, n, "wtns");
   auto [h, hl] = s.at(1);
-  (void)hl;
+  if (hl < 4 + sizeof(Fr) + 4) throw Error("truncated wtns header");
   uint32_t n8, cnt;
   memcpy(&n8, d + h, 4);
   if (n8 != sizeof(Fr)) throw Error("wtns field size mismatch");
+  if (memcmp(d + h + 4, Fr::Params::MOD, n8) != 0) throw Error("wtns field modulus does not match the selected curve");
   memcpy(&cnt, d + h + 4 + n8, 4);
   auto [o, l] = s.at(2);
   if (count > cnt || l < (size_t)cnt * n8) throw Error("truncated wtns");
@@ -193,10 +214,11 @@ DeviceScalars parse_wtns_to_device(const uint8_t* d, size_t n, size_t skip_first
   using Fr = typename P::Fr;
   Sections s(d, n, "wtns");
   auto [h, hl] = s.at(1);
-  (void)hl;
+  if (hl < 4 + sizeof(Fr) + 4) throw Error("truncated wtns header");
   uint32_t n8, cnt;
   memcpy(&n8, d + h, 4);
   if (n8 != sizeof(Fr)) throw Error("wtns field size mismatch");
+  if (memcmp(d + h + 4, Fr::Params::MOD, n8) != 0) throw Error("wtns field modulus does not match the selected curve");
   memcpy(&cnt, d + h + 4 + n8, 4);
   auto [o, l] = s.at(2);
   if (l < (size_t)cnt * n8) throw Error("truncated wtns");

@@ -68,7 +68,8 @@ int csh_device_count(int* count);
 /* Process-wide tuning knobs for A/B runs and tests (initial values come from the environment once, at load: CSH_MSM_C ...;
  * no entry point reads the environment afterwards). Keys: "msm_c" (forced window width, 0 = cost model), "msm_l" (entries per
  * accumulate lane), "msm_timing" (record csh_msm_last_timing), "msm_no_table", "msm_multi_overlap", "acc_blk",
- * "sort_two_level" (-1 auto), "vec_max_blocks", "ntt_lazy", "ntt_threads", "msm_variant", "ntt_variant". */
+ * "sort_two_level" (-1 auto), "vec_max_blocks", "ntt_lazy", "ntt_threads", "msm_variant", "ntt_variant", "msm_seg_buckets",
+ * "allow_unmasked_rep3" (see csh_rep3_local_mul_vec). */
 int csh_tune_set(const char* key, int value);
 int csh_tune_get(const char* key, int* value);
 
@@ -198,7 +199,9 @@ int csh_vec_sub(csh_curve_t field_of, const uint64_t* a, const uint64_t* b, uint
  * mpc/rep3.rs:95-106, mpc/shamir.rs:85-96, mpc/plain.rs:91-98; half-share form reduction.rs:166-171) */
 int csh_vec_mul_table(csh_curve_t field_of, uint64_t* v, const uint64_t* table, size_t n, uint32_t ncomp);
 /* out[i] = l.a*r.a + l.a*r.b + l.b*r.a + mask[i]: Rep3 local_mul_vec (rep3/arithmetic.rs:132-146,
- * arithmetic/ops.rs:69-76); mask = Rep3Rand::masking_field_elements_vec (rngs.rs:137-156), NULL = 0 */
+ * arithmetic/ops.rs:69-76); mask = Rep3Rand::masking_field_elements_vec (rngs.rs:137-156). The reference always adds the
+ * mask: an unmasked product leaks cross terms once opened, so mask == NULL (and NULL masks / seeds of every protocol-1 entry
+ * point below) is refused with CSH_ERR_INVALID unless csh_tune_set("allow_unmasked_rep3", 1) was called (arithmetic unit tests). */
 int csh_rep3_local_mul_vec(csh_curve_t field_of, const uint64_t* lhs_ab, const uint64_t* rhs_ab,
                            const uint64_t* mask, uint64_t* out, size_t n);
 /* out[i] = in[i].a*x + in[i].b*y: translate_primefield_repshare_vec (bridges/rep3_to_shamir.rs:43-62) */
@@ -236,7 +239,7 @@ int csh_lincomb_dev(csh_curve_t field_of, const uint64_t* const* shares_dev /* h
  * h[i] = (A*B - C)(shift * w^i) entirely on the device: 6 NTTs + 2 local_mul_vec + 3 table muls + 1 sub.
  * protocol: 0 plain / Shamir (ncomp 1, out = a*b), 1 Rep3 (ncomp 2, local mul with masks).
  * mask_c / mask_ab: the two mask vectors drawn (in this order) by the two local_mul_vec calls
- * (reduction.rs:160 then :182); NULL for protocol 0 or zero masks.  a and b are clobbered. */
+ * (reduction.rs:160 then :182); NULL for protocol 0.  a and b are clobbered. */
 int csh_groth16_h(csh_domain_t dom, const uint64_t shift[4], int protocol, uint64_t* a, uint64_t* b,
                   const uint64_t* mask_c, const uint64_t* mask_ab, uint64_t* h_out);
 int csh_groth16_h_dev(csh_domain_t dom, const uint64_t shift[4], int protocol, uint64_t* a_dev, uint64_t* b_dev,
@@ -271,12 +274,15 @@ typedef struct csh_matrix_s* csh_matrix_t;
 int csh_matrix_upload(csh_curve_t field_of, const uint64_t* row_ptr, const uint32_t* col_idx, const uint64_t* coeffs,
                       size_t n_rows, size_t nnz, csh_matrix_t* out);
 int csh_matrix_free(csh_matrix_t m);
+/* rows, non-zeros, the largest column index (a caller that passes device witness pointers validates it against n_public +
+ * n_witness itself; the host-pointer entry points below check it) and the device the handle lives on; any pointer may be NULL */
+int csh_matrix_info(csh_matrix_t m, size_t* n_rows, size_t* nnz, uint32_t* max_column, int* device);
 int csh_evaluate_constraints_dev(csh_matrix_t m, int protocol, int party_id, const uint64_t* public_dev, size_t n_public,
                                  const uint64_t* witness_dev, uint64_t* out_dev, size_t n_out, void* stream);
 /* witness_map_from_matrices of CircomReduction (reduction.rs:77-193) entirely on the device: evaluate A and B rows,
  * overwrite the public-input slots a[num_constraints .. +n_public] with the promoted public inputs (:111-113), then the
  * fused pipeline of csh_groth16_h. Host pointers; witness = n_witness entries (1 or 2 components). For protocol 1 the
- * masks come from the ChaCha12 seeds as in csh_groth16_h_rep3_seeded (seed pointers may be NULL for zero masks). */
+ * masks come from the ChaCha12 seeds as in csh_groth16_h_rep3_seeded (required for protocol 1; NULL for protocol 0). */
 int csh_groth16_witness_map(csh_domain_t dom, const uint64_t shift[4], int protocol, int party_id, csh_matrix_t a, csh_matrix_t b,
                             size_t num_constraints, const uint64_t* public_inputs, size_t n_public, const uint64_t* witness,
                             size_t n_witness, const uint8_t seed1[32], uint64_t elem_offset1, const uint8_t seed2[32],
@@ -290,7 +296,7 @@ int csh_groth16_witness_map_dev(csh_domain_t dom, const uint64_t shift[4], int p
 /* LibSnarkReduction::witness_map_from_matrices (reduction.rs:241-342) on the device: rows of a, b through
  * evaluate_constraint, rows of c through evaluate_constraint_half_share (mpc/rep3.rs:51-74, mpc/shamir.rs:51-68,
  * mpc/plain.rs:45-60), then csh_groth16_h_libsnark. dom = Domain::new (NULL generator at csh_domain_create),
- * generator = F::GENERATOR. Host pointers; one mask vector from the seeds (NULL seeds = zero mask). */
+ * generator = F::GENERATOR. Host pointers; one mask vector from the seeds (required for protocol 1). */
 int csh_groth16_witness_map_libsnark(csh_domain_t dom, const uint64_t generator[4], int protocol, int party_id, csh_matrix_t a,
                                      csh_matrix_t b, csh_matrix_t c, size_t num_constraints, const uint64_t* public_inputs,
                                      size_t n_public, const uint64_t* witness, size_t n_witness, const uint8_t seed1[32],

@@ -37,7 +37,11 @@ def test_rep3_ops(gpu, curve, n):
     masks = H.rand_elems(F, n, r)
     pl, pr, pm = H.pack_shares(F, lhs), H.pack_shares(F, rhs), H.pack(F, masks)
     assert H.unpack(F, gpu.rep3_local_mul_vec(cid, pl, pr, pm)) == mpc.rep3_local_mul_vec(F, lhs, rhs, masks)
-    assert H.unpack(F, gpu.rep3_local_mul_vec(cid, pl, pr, None)) == mpc.rep3_local_mul_vec(F, lhs, rhs, [0] * n)
+    if n:   # an unmasked Rep3 product is refused (it leaks cross terms once opened) unless explicitly allowed
+        with pytest.raises(gpu.CoSnarksHipError, match="needs its masks"):
+            gpu.rep3_local_mul_vec(cid, pl, pr, None)
+    with gpu.tuned(allow_unmasked_rep3=1):
+        assert H.unpack(F, gpu.rep3_local_mul_vec(cid, pl, pr, None)) == mpc.rep3_local_mul_vec(F, lhs, rhs, [0] * n)
     tbl = H.rand_elems(F, n, r)
     got = H.unpack_shares(F, gpu.vec_mul_table(cid, pl, H.pack(F, tbl), ncomp=2))
     assert got == [mpc.rep3_mul_public(F, s, t) for s, t in zip(lhs, tbl)]
