@@ -385,65 +385,24 @@ def secondary_multi_gpu(cx: Ctx, args):
     cx.barrier()
     if cx.rank == 0 and not cx.folded:
         try:
-            out["single_process_split_bn254_g1_2p24"] = single_process_split(cx, 0, 0, 64, logn)
+            out["single_process_split_bn254_g1_2p24"] = single_process_split(cx, 0, 0, logn)
         except Exception as e:  # noqa: BLE001
             out["single_process_split_bn254_g1_2p24"] = {"error": repr(e)}
     cx.barrier()
     return out
 
 
-def single_process_split(cx: Ctx, curve, group, pbytes, logn):
-    """Rank 0 drives every GPU of the node from one thread: csh_msm_split with PEER / HOST / RCCL exchange, ms per MSM."""
-    C, B, L, torch, np = cx.C, cx.B, cx.L, cx.torch, cx.np
-    k = cx.world
-    total = 1 << logn
-    per = total // k
-    bases, scal = [], []
-    for d in range(k):
-        B._check(L.csh_init(d))
-        with torch.cuda.device(d):
-            dev = torch.device("cuda", d)
-            pts = torch.empty(per * pbytes, dtype=torch.uint8, device=dev)
-            B._check(L.csh_util_generate_bases_dev(curve, group, C.c_uint64(SEED + d * per), C.c_size_t(per), C.c_void_p(pts.data_ptr()), None))
-            B.sync()
-            h = C.c_void_p()
-            B._check(L.csh_bases_upload_dev(curve, group, C.c_void_p(pts.data_ptr()), C.c_size_t(per), C.c_size_t(0), None, C.byref(h)))
-            del pts
-            sc = torch.randint(0, 1 << 61, (per, 4), dtype=torch.int64, device=dev)
-            torch.cuda.synchronize(d)
-            bases.append(h)
-            scal.append(sc)
-    B._check(L.csh_init(cx.dev_index))
-    hs = (C.c_void_p * k)(*[h.value for h in bases])
-    offs = (C.c_size_t * k)(*([0] * k))
-    cnts = (C.c_size_t * k)(*([per] * k))
-    ptrs = (C.c_void_p * k)(*[s.data_ptr() for s in scal])
-    res = {}
-    comms = None
-    outs = {}
-    for name, mode in (("hipMemcpyPeer", B.SPLIT_PEER), ("host_copies", B.SPLIT_HOST), ("rccl_grouped", B.SPLIT_RCCL)):
-        cm = None
-        if mode == B.SPLIT_RCCL:
-            comms = B.Comm.init_all(list(range(k)))
-            cm = (C.c_void_p * k)(*[c.h.value for c in comms])
-        o = np.zeros(3 * pbytes // 16, dtype=np.uint64)
-        run = lambda: B._check(L.csh_msm_split(hs, offs, cnts, ptrs, C.c_size_t(k), 1, mode, cm, o.ctypes.data_as(C.c_void_p)))
-        run()
-        t0 = time.perf_counter()
-        for _ in range(5):
-            run()
-        res[name + "_ms"] = (time.perf_counter() - t0) / 5 * 1e3
-        outs[name] = o.copy()
-    res["exchanges_agree"] = bool(all((v == outs["hipMemcpyPeer"]).all() for v in outs.values()))
-    res["points_per_s_best"] = total / (min(v for kk, v in res.items() if kk.endswith("_ms")) * 1e-3)
-    if comms:
-        for c in comms:
-            c.destroy()
-    for d, h in enumerate(bases):
-        B._check(L.csh_init(d))
-        L.csh_bases_free(h)
-    B._check(L.csh_init(cx.dev_index))
-    return res
+def single_process_split(cx: Ctx, curve, group, logn):
+    """Rank 0 drives every GPU of the node from one thread (csh_msm_split: PEER / HOST / RCCL exchange). Runs in a subprocess with
+    a timeout so that nothing it does can stall the ranks waiting at the barrier."""
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_single_process_split.py"), "--devices", str(cx.world), "--curve", str(curve),
+           "--group", str(group), "--log-n", str(logn)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": (r.stderr or r.stdout)[-400:]}
+    return json.loads(lines[-1])
 
 
 def main():

@@ -67,6 +67,27 @@ __global__ __launch_bounds__(UB_BLK) void k_ub(uint32_t* out, int iters, uint32_
   out[blockIdx.x * UB_BLK + threadIdx.x] = (uint32_t)s ^ (uint32_t)(s >> 32);
 }
 
+// v_fma_f64 issue rate (kind 13): the building block of the double-precision "split product" multiplier (two FMAs give the
+// exact high and low halves of a 52 x 52-bit limb product). Measured to price that alternative against the 29-bit integer
+// scheme: each limb product there costs 2 FMA + 1 subtraction + 2 64-bit integer additions.
+__global__ __launch_bounds__(UB_BLK) void k_ub_fma64(double* out, int iters, double seed) {
+  double acc[UB_CHAINS];
+  const double b = 1.0 + seed * 1e-9, c = 1e-3 * (threadIdx.x + 1);
+#pragma unroll
+  for (int k = 0; k < UB_CHAINS; ++k) acc[k] = seed + k * 0.5 + blockIdx.x;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int k = 0; k < UB_CHAINS; ++k) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(acc[k]) : "v"(b), "v"(c));
+    }
+  }
+  double s = 0;
+#pragma unroll
+  for (int k = 0; k < UB_CHAINS; ++k) s += acc[k];
+  out[blockIdx.x * UB_BLK + threadIdx.x] = s;
+}
+
 // modmul chains: kind 10 = Fp<Bn254Fq>::mul (8 x 32-bit CIOS), 11 = Fp29 (9 x 29-bit lazy), 12 = Bls381Fq
 template <class F>
 __global__ __launch_bounds__(UB_BLK) void k_modmul(const F* in, F* out, int iters) {
@@ -141,6 +162,15 @@ int csh_microbench(int kind, int iters, double* ops_per_s) {
   const int blocks = 256 * 8;
   const size_t threads = (size_t)blocks * UB_BLK;
   float ms = 0;
+  if (kind == 13) {
+    double* out;
+    CSH_HIP(hipMalloc((void**)&out, threads * 8));
+    const int rc = time_kernel(k_ub_fma64, dim3(blocks), dim3(UB_BLK), &ms, out, iters, 1.5);
+    (void)hipFree(out);
+    if (rc != CSH_OK) return rc;
+    *ops_per_s = (double)iters * 4 * UB_CHAINS * threads / (ms * 1e-3);
+    return CSH_OK;
+  }
   if (kind < 10) {
     uint32_t* out;
     CSH_HIP(hipMalloc((void**)&out, threads * 4));

@@ -452,8 +452,26 @@ inline size_t msm_sort_bytes(const MsmParams& p) {
 }
 
 // digits + counting sort; takes its buffers from `ar` (already reserved). ev (nullable): records ev[1..3].
+struct SortStageBufs {
+  SortBuffers sb;
+  bool two_level;
+};
+// window group [w0, w0 + nw) of the sort buffers: every array has a per-window stride
+inline SortBuffers sort_group_view(const MsmParams& p, const SortBuffers& b, int w0) {
+  const size_t len = (size_t)p.NB + 2, n = p.n;
+  SortBuffers g = b;
+  g.hist += len * w0;
+  g.start += len * w0;
+  g.nlanes += w0;
+  g.sorted += n * w0;
+  g.dig += n * w0;
+  g.blkcnt += (size_t)p.NB * p.CH * w0;
+  if (g.inter) g.inter += n * w0;
+  if (g.part_cnt) g.part_cnt += (size_t)(p.NB / 256) * p.CH * w0;
+  return g;
+}
 template <class Fr>
-int msm_sort_stage(const MsmParams& p, const MsmParams& pdig, const uint64_t* scalars_dev, hipStream_t st, Arena& ar, SortOut* out, hipEvent_t* ev) {
+int msm_sort_prepare(const MsmParams& p, const MsmParams& pdig, const uint64_t* scalars_dev, hipStream_t st, Arena& ar, SortStageBufs* out) {
   const size_t len = (size_t)p.NB + 2, n = p.n;
   uint32_t* hist = ar.take<uint32_t>(len * p.W);
   uint32_t* start = ar.take<uint32_t>(len * p.W);
@@ -467,9 +485,16 @@ int msm_sort_stage(const MsmParams& p, const MsmParams& pdig, const uint64_t* sc
   CSH_HIP(hipMemsetAsync(hist, 0, sizeof(uint32_t) * len * p.W, st));
   const int g1 = grid_for(pdig.n, MSM_BLK, 65536);
   hipLaunchKernelGGL(k_msm_digits<Fr>, dim3(g1), dim3(MSM_BLK), 0, st, reinterpret_cast<const Fr*>(scalars_dev), pdig, dig);  // dig[w * n + i]
-  SortBuffers sb{hist, start, nlanes, sorted, dig, blkcnt, inter, part_cnt};
-  CSH_TRY(msm_sort_launch(p, sb, st, ev));
-  *out = SortOut{start, nlanes, sorted};
+  out->sb = SortBuffers{hist, start, nlanes, sorted, dig, blkcnt, inter, part_cnt};
+  out->two_level = two_level;
+  return CSH_OK;
+}
+template <class Fr>
+int msm_sort_stage(const MsmParams& p, const MsmParams& pdig, const uint64_t* scalars_dev, hipStream_t st, Arena& ar, SortOut* out, hipEvent_t* ev) {
+  SortStageBufs ss;
+  CSH_TRY(msm_sort_prepare<Fr>(p, pdig, scalars_dev, st, ar, &ss));
+  CSH_TRY(msm_sort_launch(p, ss.sb, st, ev));
+  *out = SortOut{ss.sb.start, ss.sb.nlanes, ss.sb.sorted};
   return CSH_OK;
 }
 
@@ -483,62 +508,102 @@ size_t msm_bucket_bytes(const MsmParams* pp) {
   need += Arena::padded(sizeof(LazyPt<Cfg>) * (size_t)p.tmax * p.W);       // partials
   need += Arena::padded(sizeof(LazyPt<Cfg>) * (size_t)p.S * p.W);          // segment results
   need += Arena::padded(sizeof(LazyPt<Cfg>) * (size_t)(p.NB + 1) * p.W);   // dense bucket sums
-  need += Arena::padded(sizeof(uint32_t) * (2 * (size_t)max_giant + 2));
+  need += Arena::padded(sizeof(uint32_t) * (2 * (size_t)max_giant + 2) * 8 /* MAX_GROUPS */);
   need += 2 * Arena::padded(sizeof(LazyPt<Cfg>) * (size_t)((p.S + 127) / 128) * p.W);  // fold-tree ping / pong
   (void)giant_blocks;
   return need;
 }
 
-// accumulate -> merge -> reduce -> fold for one set of bases; win_out_dev: W x XYZZ<Fq> on the device. ev (nullable):
-// records ev[4] after the accumulation and ev[5] at the end.
+// Scratch of the bucket stage, every array with a per-window stride (window groups run on offset views of it)
 template <class Cfg>
-int msm_bucket_stage(const void* points, const MsmParams* pp, const SortOut* so, hipStream_t st, Arena* arp, void* win_out_dev, hipEvent_t* ev) {
+struct BucketBufs {
+  LazyPt<Cfg>*partial, *segres, *dense, *fold_a, *fold_b;
+  uint32_t* giant;  // MAX_GROUPS x ([0] = count, list from [2])
+  uint32_t fold_n1, max_lanes, max_giant, giant_blocks;
+};
+constexpr int MAX_GROUPS = 8;
+template <class Cfg>
+BucketBufs<Cfg> bucket_take(const MsmParams& p, Arena& ar) {
+  BucketBufs<Cfg> b;
+  b.max_lanes = (uint32_t)(((size_t)p.n + p.L - 1) / p.L);
+  b.max_giant = (uint32_t)(((uint64_t)b.max_lanes * p.W) / MERGE_CAP + 1);
+  b.giant_blocks = b.max_giant < 1024 ? b.max_giant : 1024;
+  b.partial = ar.take<LazyPt<Cfg>>((size_t)p.tmax * p.W);
+  b.segres = ar.take<LazyPt<Cfg>>((size_t)p.S * p.W);
+  b.dense = ar.take<LazyPt<Cfg>>((size_t)(p.NB + 1) * p.W);
+  b.giant = ar.take<uint32_t>((2 * (size_t)b.max_giant + 2) * MAX_GROUPS);
+  b.fold_n1 = (p.S + 127) / 128;
+  b.fold_a = ar.take<LazyPt<Cfg>>((size_t)b.fold_n1 * p.W);
+  b.fold_b = ar.take<LazyPt<Cfg>>((size_t)b.fold_n1 * p.W);
+  return b;
+}
+
+// accumulate -> merge -> reduce -> fold tree -> window sums for windows [w0, w0 + nw) on `st`; `group` picks the giant queue.
+// ev (nullable): records ev[4] after the accumulation.
+template <class Cfg>
+int bucket_group(const void* points, const MsmParams& p, const SortOut& so, const BucketBufs<Cfg>& bb, int w0, int nw, int group, hipStream_t st,
+                 void* win_out_dev, hipEvent_t* ev) {
   using Fq = typename Cfg::Fq;
-  const MsmParams& p = *pp;
-  Arena& ar = *arp;
-  const uint32_t max_lanes = (uint32_t)(((size_t)p.n + p.L - 1) / p.L);
-  const uint32_t max_giant = (uint32_t)(((uint64_t)max_lanes * p.W) / MERGE_CAP + 1);
-  const uint32_t giant_blocks = max_giant < 1024 ? max_giant : 1024;
-  LazyPt<Cfg>* partial = ar.take<LazyPt<Cfg>>((size_t)p.tmax * p.W);
-  LazyPt<Cfg>* segres = ar.take<LazyPt<Cfg>>((size_t)p.S * p.W);
-  LazyPt<Cfg>* dense = ar.take<LazyPt<Cfg>>((size_t)(p.NB + 1) * p.W);
-  uint32_t* giant = ar.take<uint32_t>(2 * (size_t)max_giant + 2);  // [0] = count, list from [2]
-  const uint32_t fold_n1 = (p.S + 127) / 128;
-  LazyPt<Cfg>* fold_a = ar.take<LazyPt<Cfg>>((size_t)fold_n1 * p.W);
-  LazyPt<Cfg>* fold_b = ar.take<LazyPt<Cfg>>((size_t)fold_n1 * p.W);
+  const size_t len = (size_t)p.NB + 2;
+  const uint32_t* start = so.start + len * w0;
+  const uint32_t* nlanes = so.nlanes + w0;
+  const uint32_t* sorted = so.sorted + (size_t)p.n * w0;
+  LazyPt<Cfg>* partial = bb.partial + (size_t)p.tmax * w0;
+  LazyPt<Cfg>* segres = bb.segres + (size_t)p.S * w0;
+  LazyPt<Cfg>* dense = bb.dense + (size_t)(p.NB + 1) * w0;
+  LazyPt<Cfg>* fold_a = bb.fold_a + (size_t)bb.fold_n1 * w0;
+  LazyPt<Cfg>* fold_b = bb.fold_b + (size_t)bb.fold_n1 * w0;
+  uint32_t* giant = bb.giant + (2 * (size_t)bb.max_giant + 2) * group;
   const Affine<Fq>* bases = reinterpret_cast<const Affine<Fq>*>(points);
   {
     const int tb = tune().acc_blk.load(std::memory_order_relaxed);
     const int blk = (tb == 64 || tb == 128) ? tb : ACC_BLK;
-    const dim3 ag((max_lanes + blk - 1) / blk, p.W), ab(blk);
-    hipLaunchKernelGGL(k_msm_accum<Cfg>, ag, ab, 0, st, bases, p, so->start, so->nlanes, so->sorted, partial);
+    const dim3 ag((bb.max_lanes + blk - 1) / blk, nw), ab(blk);
+    hipLaunchKernelGGL(k_msm_accum<Cfg>, ag, ab, 0, st, bases, p, start, nlanes, sorted, partial);
   }
   if (ev) CSH_HIP(hipEventRecord(ev[4], st));
   CSH_HIP(hipMemsetAsync(giant, 0, 8, st));
-  hipLaunchKernelGGL(k_msm_merge<Cfg>, dim3((p.NB + TAIL_Q - 1) / TAIL_Q, p.W), dim3(TAIL_BLK), 0, st, p, so->start, partial, dense, giant, giant + 2);
+  hipLaunchKernelGGL(k_msm_merge<Cfg>, dim3((p.NB + TAIL_Q - 1) / TAIL_Q, nw), dim3(TAIL_BLK), 0, st, p, start, partial, dense, giant, giant + 2);
   // buckets with > MERGE_CAP partials (heavily repeated scalars): block-wide tree, grid-stride over the queue
-  hipLaunchKernelGGL(k_msm_merge_giant<Cfg>, dim3(giant_blocks), dim3(256), 0, st, p, so->start, partial, dense, giant, giant + 2);
+  hipLaunchKernelGGL(k_msm_merge_giant<Cfg>, dim3(bb.giant_blocks), dim3(256), 0, st, p, start, partial, dense, giant, giant + 2);
   if (tune().msm_variant.load(std::memory_order_relaxed) & 1)
-    hipLaunchKernelGGL(k_msm_reduce<Cfg>, dim3((p.S + TAIL_Q - 1) / TAIL_Q, p.W), dim3(TAIL_BLK), 0, st, p, dense, segres);
+    hipLaunchKernelGGL(k_msm_reduce<Cfg>, dim3((p.S + TAIL_Q - 1) / TAIL_Q, nw), dim3(TAIL_BLK), 0, st, p, dense, segres);
   else
-    hipLaunchKernelGGL(k_msm_reduce_serial<Cfg>, dim3((p.S + 63) / 64, p.W), dim3(64), 0, st, p, dense, segres);
+    hipLaunchKernelGGL(k_msm_reduce_serial<Cfg>, dim3((p.S + 63) / 64, nw), dim3(64), 0, st, p, dense, segres);
   // fold tree: S segment sums per window -> one, 128 per block and launch
   const LazyPt<Cfg>* cur = segres;
   uint32_t cur_n = p.S, cur_stride = p.S;
   LazyPt<Cfg>* nxt = fold_a;
   while (cur_n > 1) {
     const uint32_t out_n = (cur_n + 127) / 128;
-    hipLaunchKernelGGL(k_msm_fold_tree<Cfg>, dim3(out_n, p.W), dim3(256), 0, st, cur, cur_stride, cur_n, nxt, fold_n1);
+    hipLaunchKernelGGL(k_msm_fold_tree<Cfg>, dim3(out_n, nw), dim3(256), 0, st, cur, cur_stride, cur_n, nxt, bb.fold_n1);
     cur = nxt;
     cur_n = out_n;
-    cur_stride = fold_n1;
+    cur_stride = bb.fold_n1;
     nxt = nxt == fold_a ? fold_b : fold_a;
   }
-  hipLaunchKernelGGL(k_msm_gather_windows<Cfg>, dim3(1), dim3(MAX_WINDOWS), 0, st, cur, cur_stride, p.W, reinterpret_cast<XYZZ<Fq>*>(win_out_dev));
-  if (ev) CSH_HIP(hipEventRecord(ev[5], st));
+  hipLaunchKernelGGL(k_msm_gather_windows<Cfg>, dim3(1), dim3(MAX_WINDOWS), 0, st, cur, cur_stride, nw,
+                     reinterpret_cast<XYZZ<Fq>*>(win_out_dev) + w0);
   CSH_HIP(hipGetLastError());
   return CSH_OK;
 }
+
+// accumulate -> merge -> reduce -> fold for one set of bases; win_out_dev: W x XYZZ<Fq> on the device. ev (nullable):
+// records ev[4] after the accumulation and ev[5] at the end.
+template <class Cfg>
+int msm_bucket_stage(const void* points, const MsmParams* pp, const SortOut* so, hipStream_t st, Arena* arp, void* win_out_dev, hipEvent_t* ev) {
+  const MsmParams& p = *pp;
+  const BucketBufs<Cfg> bb = bucket_take<Cfg>(p, *arp);
+  CSH_TRY((bucket_group<Cfg>(points, p, *so, bb, 0, p.W, 0, st, win_out_dev, ev)));
+  if (ev) CSH_HIP(hipEventRecord(ev[5], st));
+  return CSH_OK;
+}
+
+// (A software pipeline over window groups on two streams -- group g's sort and tail under the accumulation of its
+// neighbours -- was built and measured: BN254 G1 2^20 2.07 -> 2.19 / 2.49 / 2.61 ms with 2 / 3 / 4 groups, 2^24 23.4 -> 25.2 /
+// 23.9 / 24.8 ms, worse on every group and size, profiles/r02_c5_pipeline.log. The accumulate workgroups hold every SIMD's
+// register file, so the other stream's kernels wait for them to retire: the stages serialise anyway and each group adds its
+// own ramp-up / ramp-down. Not kept; bucket_group() keeps the window-offset form it needed.)
 
 // merged-window mode applies when the handle carries tables, the call covers a good part of them (a tiny MSM against a
 // 2^15-bucket table would pay the bucket reduction for nothing) and the entry ids fit 31 bits

@@ -63,10 +63,11 @@ void parse_zkey(const uint8_t* d, size_t n, ProvingKey<P>& pk, ConstraintMatrice
   auto [h, hl] = s.at(2);
   // header = n8q, q, n8r, r, nVars, nPublic, domainSize, alpha1, beta1, beta2, gamma2, delta1, delta2
   const size_t header_need = 4 + sizeof(Fq) + 4 + sizeof(Fr) + 12 + 3 * 2 * sizeof(Fq) + 3 * 4 * sizeof(Fq);
-  if (hl < header_need) throw Error("truncated zkey header");
+  if (hl < 4) throw Error("truncated zkey header");
   uint32_t n8q, n8r, n_vars, n_public, domain;
   memcpy(&n8q, d + h, 4);
-  if (n8q != sizeof(Fq)) throw Error("zkey base field size does not match the selected curve");
+  if (n8q != sizeof(Fq)) throw Error("zkey base field size does not match the selected curve");  // before the length check: a key of the other curve has another header size
+  if (hl < header_need) throw Error("truncated zkey header");
   if (memcmp(d + h + 4, Fq::Params::MOD, n8q) != 0) throw Error("zkey base field modulus does not match the selected curve");
   size_t off = h + 4 + n8q;
   memcpy(&n8r, d + off, 4);
