@@ -48,6 +48,40 @@ def test_no_cpu_fallback_without_device(hip):
         g.prove_plain(0, open(os.path.join(gold, "circuit.zkey"), "rb").read(), open(os.path.join(gold, "witness.wtns"), "rb").read(), 1, 2)
 
 
+def test_split_msm_entry_points_without_device(hip):
+    """The split-MSM / communicator / tuning entry points on a machine without a GPU: the argument checks work, the host-side
+    fold works (it is pure host code: identity for empty partials), everything that needs a device fails loudly."""
+    import ctypes as C
+    from cosnarks_amd import bindings as B
+    L = hip.lib()
+    # tuning knobs are host state
+    B.tune_set("msm_c", 13)
+    assert B.tune_get("msm_c") == 13
+    B.tune_set("msm_c", 0)
+    with pytest.raises(hip.CoSnarksHipError, match="unknown key"):
+        B.tune_set("no_such_knob", 1)
+    # fold of well-formed empty partials = the identity (1, 1, 0) in Montgomery form; a bad header is refused
+    for curve, group in ((0, 0), (1, 1), (2, 0)):
+        pb = hip.msm_partial_bytes(curve, group)
+        assert pb == 32 + 128 * 2 * hip.point_bytes(curve, group)
+        parts = np.zeros(3 * pb, dtype=np.uint8)
+        for k in range(3):
+            parts[k * pb:k * pb + 4] = np.frombuffer((0x4d534d50).to_bytes(4, "little"), dtype=np.uint8)
+        out = hip.msm_fold_partials(curve, group, parts, 3)
+        w = out.size // 3
+        assert not out[2 * w:].any() and out[:w].any()                 # Z = 0, X = Montgomery one
+        with pytest.raises(hip.CoSnarksHipError, match="bad partial header"):
+            hip.msm_fold_partials(curve, group, np.zeros(pb, dtype=np.uint8), 1)
+    if hip.have_device():
+        return
+    with pytest.raises(hip.CoSnarksHipError, match="no HIP device|no CPU fallback"):
+        hip.Comm.init_rank(None, 1, 0)
+    with pytest.raises(hip.CoSnarksHipError):
+        hip.Comm.init_rank(None, 2, 0)                                  # nranks > 1 needs an id
+    with pytest.raises(hip.CoSnarksHipError):
+        hip.Comm.init_all([0, 0])
+
+
 def test_product_does_not_import_the_oracle():
     """Static check: nothing under co-snarks_amd/ references oracle/ (the oracle is test infrastructure only)."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
