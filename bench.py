@@ -85,6 +85,7 @@ class Ctx:
         B._check(self.L.csh_init(self.dev_index))
         self.stream = torch.cuda.current_stream().cuda_stream
         self.comm = None
+        self.hard_exit = False
         self.exchange = "single GPU"
         if self.world > 1:
             self._make_comm(args)
@@ -93,14 +94,37 @@ class Ctx:
         """RCCL communicator behind the C ABI: rank 0 draws the id, gloo ships the 128 bytes."""
         torch, dist, B = self.torch, self.dist, self.B
         ok, err = 1, ""
-        want_rccl = args.exchange == "rccl" and not self.folded
+        want_rccl = args.exchange == "rccl" and (not self.folded or bool(os.environ.get("BENCH_FORCE_RCCL")))   # forced + folded: exercises the fallback
         if want_rccl:
             try:
                 uid = torch.zeros(B.COMM_ID_BYTES, dtype=torch.uint8)
                 if self.rank == 0:
                     uid = torch.tensor(list(B.comm_unique_id()), dtype=torch.uint8)
                 dist.broadcast(uid, 0)
-                self.comm = B.Comm.init_rank(bytes(uid.tolist()), self.world, self.rank)
+                # ncclCommInitRank is collective: if the fabric bootstrap wedges on one rank it wedges on all, and nothing can
+                # interrupt it. Run it on a daemon thread with a deadline; past it every rank falls back to the harness
+                # exchange (the flag is agreed below) and the process leaves through os._exit once the line is printed.
+                import threading
+                box = {}
+
+                def init():
+                    try:
+                        L = self.L
+                        B._check(L.csh_init(self.dev_index))        # the thread needs its own device binding
+                        box["comm"] = B.Comm.init_rank(bytes(uid.tolist()), self.world, self.rank)
+                    except Exception as e:  # noqa: BLE001
+                        box["err"] = repr(e)
+
+                th = threading.Thread(target=init, daemon=True)
+                th.start()
+                th.join(timeout=float(os.environ.get("BENCH_RCCL_INIT_TIMEOUT", "120")))
+                if th.is_alive():
+                    ok, err = 0, "ncclCommInitRank did not return within the deadline"
+                    self.hard_exit = True
+                elif "err" in box:
+                    ok, err = 0, box["err"]
+                else:
+                    self.comm = box["comm"]
             except Exception as e:  # noqa: BLE001
                 ok, err = 0, repr(e)
         flag = torch.tensor([ok if want_rccl else 0], dtype=torch.int32)
@@ -481,6 +505,9 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu_baseline, "result_check": check, "secondary": extras,
         }
         print(json.dumps(line))
+    sys.stdout.flush()
+    if cx.hard_exit:          # a wedged RCCL bootstrap thread is still alive: skip interpreter teardown
+        os._exit(0)
     if cx.comm is not None:
         cx.comm.destroy()
     if world > 1:
