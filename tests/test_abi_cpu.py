@@ -135,13 +135,13 @@ def test_header_is_plain_c():
 
 
 
-def _build_c_example(tmp_path):
+def _build_c_example(tmp_path, name="msm_ntt_from_c"):
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = str(tmp_path / "msm_ntt_from_c")
+    exe = str(tmp_path / name)
     libdir = os.path.join(root, "co-snarks_amd", "lib")
     subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(root, "include"),
-                    os.path.join(root, "examples", "msm_ntt_from_c.c"), "-L" + libdir, "-lcosnarks_hip", "-Wl,-rpath," + libdir, "-o", exe],
+                    os.path.join(root, "examples", name + ".c"), "-L" + libdir, "-lcosnarks_hip", "-Wl,-rpath," + libdir, "-o", exe],
                    check=True, capture_output=True)
     return exe
 
@@ -157,6 +157,18 @@ def test_plain_c_caller_links_and_fails_loudly_without_a_gpu(hip, tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 3, (r.returncode, r.stderr)
     assert "no CPU fallback" in r.stderr
+
+
+def test_plain_c_split_msm_caller_links_and_fails_loudly_without_a_gpu(hip, tmp_path):
+    """examples/msm_split_from_c.c (one MSM over every GPU of the node from a single C thread) builds warning-free and, with no
+    GPU, exits with status 3."""
+    import subprocess
+    import torch
+    exe = _build_c_example(tmp_path, "msm_split_from_c")
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu-marked test")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3, (r.returncode, r.stderr)
 
 
 def test_rust_sys_crate_covers_every_header_symbol():

@@ -178,3 +178,14 @@ def test_split_closed_form_at_config5_sizes(gpu, curve, group, logn, k):
         assert G.eq(H.jac_to_affine(G, bases.msm_dev(dsc, n)), want)
     bases.free()
     dsc.free()
+
+
+def test_plain_c_split_msm_caller(gpu, tmp_path):
+    """examples/msm_split_from_c.c: csh_msm_split from a C11 program (ranges over every visible GPU; three ranges on device 0 on
+    a one-GPU box), every exchange equal to the unsplit MSM."""
+    import subprocess
+    from tests.test_abi_cpu import _build_c_example
+    exe = _build_c_example(tmp_path, "msm_split_from_c")
+    r = subprocess.run([exe, "17"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert "hipMemcpyPeer" in r.stdout and "MISMATCH" not in r.stdout
