@@ -33,6 +33,26 @@ def num_threads() -> int:
     return lib().oc_num_threads()
 
 
+_DEFAULT_THREADS = None
+
+
+def default_threads() -> int:
+    """Threads for a call that did not ask for a count: the CPUs this process may actually use -- the affinity mask capped by the
+    container's CPU-time quota (the GPU boxes show 256 CPUs and grant 16: 256 OpenMP threads there are 10-100x slower)."""
+    global _DEFAULT_THREADS
+    if _DEFAULT_THREADS is None:
+        n = _available_cpus()
+        q = _cgroup_cpu_quota()
+        if q:
+            n = max(1, min(n, int(q + 0.5)))
+        _DEFAULT_THREADS = n
+    return _DEFAULT_THREADS
+
+
+def _t(threads: int) -> int:
+    return int(threads) if threads and threads > 0 else default_threads()
+
+
 def point_words(curve: int, group: int) -> int:
     return (4 if curve == 0 else 6) * 2 * (2 if group else 1)
 
@@ -42,7 +62,7 @@ def msm(curve: int, group: int, points, scalars, montgomery=True, threads=0):
     sc = np.ascontiguousarray(scalars, dtype=np.uint64)
     n = sc.size // 4
     out = np.zeros(point_words(curve, group), dtype=np.uint64)
-    assert lib().oc_msm(curve, group, _p(pts), _p(sc), C.c_size_t(n), int(montgomery), threads, _p(out)) == 0
+    assert lib().oc_msm(curve, group, _p(pts), _p(sc), C.c_size_t(n), int(montgomery), _t(threads), _p(out)) == 0
     return out
 
 
@@ -54,7 +74,7 @@ def msm_fast(curve: int, group: int, points, scalars, montgomery=True, threads=0
     n = sc.size // 4
     out = np.zeros(point_words(curve, group), dtype=np.uint64)
     st = (C.c_double * 6)()
-    assert lib().oc_msm_fast(curve, group, _p(pts), _p(sc), C.c_size_t(n), int(montgomery), int(threads), int(c), st, _p(out)) == 0
+    assert lib().oc_msm_fast(curve, group, _p(pts), _p(sc), C.c_size_t(n), int(montgomery), _t(threads), int(c), st, _p(out)) == 0
     if stages is not None:
         stages[:] = list(st)
     return out
@@ -62,21 +82,21 @@ def msm_fast(curve: int, group: int, points, scalars, montgomery=True, threads=0
 
 def generate_bases(curve: int, group: int, seed: int, n: int, threads=0):
     out = np.zeros((n, point_words(curve, group)), dtype=np.uint64)
-    assert lib().oc_generate_bases(curve, group, C.c_uint64(seed), C.c_size_t(n), threads, _p(out)) == 0
+    assert lib().oc_generate_bases(curve, group, C.c_uint64(seed), C.c_size_t(n), _t(threads), _p(out)) == 0
     return out
 
 
 def generate_bases_wide(curve: int, group: int, seed: int, n: int, threads=0):
     """bases[i] = k_i * G with 253-bit k_i (four splitmix64 outputs); ~1 in 4096 is the point at infinity."""
     out = np.zeros((n, point_words(curve, group)), dtype=np.uint64)
-    assert lib().oc_generate_bases_wide(curve, group, C.c_uint64(seed), C.c_size_t(n), threads, _p(out)) == 0
+    assert lib().oc_generate_bases_wide(curve, group, C.c_uint64(seed), C.c_size_t(n), _t(threads), _p(out)) == 0
     return out
 
 
 def hash_points_bn254_g1(seed: int, n: int, threads=0):
     """SURVEY 8d family (i): x hashed, incremented until x^3 + 3 is a square; y = sqrt, sign from a PRNG bit."""
     out = np.zeros((n, 8), dtype=np.uint64)
-    assert lib().oc_hash_points_bn254_g1(C.c_uint64(seed), C.c_size_t(n), threads, _p(out)) == 0
+    assert lib().oc_hash_points_bn254_g1(C.c_uint64(seed), C.c_size_t(n), _t(threads), _p(out)) == 0
     return out
 
 
@@ -93,7 +113,7 @@ def eval_poly(curve, coeffs, x, stride=1, offset=0):
 def vec_add(curve, a, b, threads=0):
     a, b = np.ascontiguousarray(a, dtype=np.uint64), np.ascontiguousarray(b, dtype=np.uint64)
     out = np.empty_like(a)
-    lib().oc_vec_add(curve, _p(a), _p(b), _p(out), C.c_size_t(a.size // 4), threads)
+    lib().oc_vec_add(curve, _p(a), _p(b), _p(out), C.c_size_t(a.size // 4), _t(threads))
     return out
 
 
@@ -103,14 +123,14 @@ def lincomb(curve, shares, coeffs, threads=0):
     arr = (C.c_void_p * k)(*[s.ctypes.data for s in sh])
     co = np.ascontiguousarray(coeffs, dtype=np.uint64)
     out = np.empty(n * 4, dtype=np.uint64)
-    lib().oc_lincomb(curve, arr, _p(co), C.c_size_t(k), _p(out), C.c_size_t(n), threads)
+    lib().oc_lincomb(curve, arr, _p(co), C.c_size_t(k), _p(out), C.c_size_t(n), _t(threads))
     return out
 
 
 def ntt(curve: int, data, logn: int, gen, ncomp=1, dif=False, threads=0):
     d = np.ascontiguousarray(data, dtype=np.uint64).copy()
     g = np.ascontiguousarray(gen, dtype=np.uint64)
-    assert lib().oc_ntt(curve, _p(d), logn, _p(g), ncomp, int(dif), threads) == 0
+    assert lib().oc_ntt(curve, _p(d), logn, _p(g), ncomp, int(dif), _t(threads)) == 0
     return d
 
 
@@ -130,7 +150,7 @@ def coset_table(curve: int, shift, logn: int):
 def vec_mul(curve, a, b, threads=0):
     a, b = np.ascontiguousarray(a, dtype=np.uint64), np.ascontiguousarray(b, dtype=np.uint64)
     out = np.empty_like(a)
-    lib().oc_vec_mul(curve, _p(a), _p(b), _p(out), C.c_size_t(a.size // 4), threads)
+    lib().oc_vec_mul(curve, _p(a), _p(b), _p(out), C.c_size_t(a.size // 4), _t(threads))
     return out
 
 
@@ -139,21 +159,21 @@ def rep3_local_mul_vec(curve, l, r, mask=None, threads=0):
     m = np.ascontiguousarray(mask, dtype=np.uint64) if mask is not None else None
     n = l.size // 8
     out = np.empty(n * 4, dtype=np.uint64)
-    lib().oc_rep3_local_mul_vec(curve, _p(l), _p(r), _p(m), _p(out), C.c_size_t(n), threads)
+    lib().oc_rep3_local_mul_vec(curve, _p(l), _p(r), _p(m), _p(out), C.c_size_t(n), _t(threads))
     return out
 
 
 def vec_mul_table(curve, v, table, ncomp=1, threads=0):
     v = np.ascontiguousarray(v, dtype=np.uint64).copy()
     t = np.ascontiguousarray(table, dtype=np.uint64)
-    lib().oc_vec_mul_table(curve, _p(v), _p(t), C.c_size_t(t.size // 4), ncomp, threads)
+    lib().oc_vec_mul_table(curve, _p(v), _p(t), C.c_size_t(t.size // 4), ncomp, _t(threads))
     return v
 
 
 def vec_sub(curve, a, b, threads=0):
     a, b = np.ascontiguousarray(a, dtype=np.uint64), np.ascontiguousarray(b, dtype=np.uint64)
     out = np.empty_like(a)
-    lib().oc_vec_sub(curve, _p(a), _p(b), _p(out), C.c_size_t(a.size // 4), threads)
+    lib().oc_vec_sub(curve, _p(a), _p(b), _p(out), C.c_size_t(a.size // 4), _t(threads))
     return out
 
 
@@ -162,7 +182,7 @@ def rep3_to_shamir_vec(curve, in_ab, x, y, threads=0):
     n = a.size // 8
     out = np.empty(n * 4, dtype=np.uint64)
     lib().oc_rep3_to_shamir_vec(curve, _p(a), _p(np.ascontiguousarray(x, dtype=np.uint64)), _p(np.ascontiguousarray(y, dtype=np.uint64)),
-                                _p(out), C.c_size_t(n), threads)
+                                _p(out), C.c_size_t(n), _t(threads))
     return out
 
 

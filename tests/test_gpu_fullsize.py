@@ -139,3 +139,59 @@ def test_reference_bn254_fr_products_through_the_device_kernels(gpu):
         prods.append(gpu.rep3_local_mul_vec(cid, lhs, rhs, mask))
     opened = gpu.lincomb(cid, prods, H.pack(F, [1, 1, 1]))
     assert H.unpack(F, opened) == KAT_Z
+
+
+@pytest.mark.parametrize("curve,group,rounds", [("bn254", 0, 28), ("bn254", 1, 6), ("bls12_381", 0, 8), ("bls12_381", 1, 4)])
+def test_msm_fuzz_sizes_and_plans_vs_cpu_restatement(gpu, curve, group, rounds):
+    """Random sizes around the plan boundaries (single- / two-level sort, chunk counts, lane lengths) with random forced window
+    widths and lane lengths, zero / repeated / extreme scalars and points at infinity mixed in: every result bit-identical to
+    oracle/c's independent Pippenger."""
+    cid = H.CURVE_IDS[curve]
+    F = H.FR[curve]
+    r = H.rng(4242 + group + 10 * cid)
+    nmax = 40000 if group == 0 else 9000
+    pts_all = cbridge.generate_bases_wide(cid, group, 0xF00D + group, nmax)
+    rs = np.random.RandomState(11 + group)
+    for it in range(rounds):
+        n = r.choice([1, 2, 63, 64, 65, 255, 256, 257, 1023, 1025, 4095, 4097, r.randrange(1, nmax), r.randrange(1, nmax)])
+        off = r.randrange(0, nmax - n + 1)
+        sc = _uniform_limbs(rs, n)
+        k = r.randrange(0, 4)
+        if k == 0 and n > 8:
+            sc[: n // 3] = sc[0]                          # one giant bucket per window
+        elif k == 1 and n > 8:
+            sc[::2] = 0
+            sc[1::4] = np.array([1, 0, 0, 0], dtype=np.uint64)
+        elif k == 2:
+            pm1 = np.array([((F.p - 1) >> (64 * i)) & (2**64 - 1) for i in range(4)], dtype=np.uint64)
+            sc[: max(1, n // 5)] = pm1                    # canonical r - 1
+        knobs = {"msm_c": r.choice([0, 0, 3, 7, 10, 12, 13, 14, 15, 16]), "msm_l": r.choice([0, 0, 1, 5, 16, 64]),
+                 "sort_two_level": r.choice([-1, -1, 0, 1])}
+        bases = gpu.Bases(cid, group, pts_all[off:off + n])
+        with gpu.tuned(**knobs):
+            got = bases.msm(sc, montgomery=False)
+        bases.free()
+        w = got.size // 3
+        got_aff = np.zeros(2 * w, dtype=np.uint64) if not got[2 * w:].any() else got[:2 * w]
+        want = cbridge.msm_fast(cid, group, pts_all[off:off + n], sc, montgomery=False)
+        assert np.array_equal(got_aff, want), (curve, group, it, n, off, k, knobs)
+
+
+@pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
+def test_ntt_every_size_up_to_2p19_vs_cpu_restatement(gpu, curve):
+    """Every domain size 2^1 .. 2^19 (all pass plans: one, two and three sweeps), both directions, ncomp 1 and 2, against
+    oracle/c's radix-2 NTT over the whole vector."""
+    F = H.FR[curve]
+    cid = H.CURVE_IDS[curve]
+    rs = np.random.RandomState(77)
+    roots = ntt.roots_of_unity(F)[1]
+    for logn in range(1, 20):
+        n = 1 << logn
+        gen = roots[logn]
+        pg = H.pack(F, [gen])
+        dom = gpu.Domain(cid, logn, pg)
+        for ncomp in ((1, 2) if logn % 3 == 0 or logn >= 14 else (1,)):
+            x = _uniform_limbs(rs, n * ncomp)
+            assert np.array_equal(dom.ifft_in_to_out(x, ncomp=ncomp).reshape(-1), cbridge.ntt(cid, x, logn, pg, ncomp=ncomp, dif=True, threads=8).reshape(-1)), (logn, ncomp, "ifft")
+            assert np.array_equal(dom.fft_out_to_in(x, ncomp=ncomp).reshape(-1), cbridge.ntt(cid, x, logn, pg, ncomp=ncomp, dif=False, threads=8).reshape(-1)), (logn, ncomp, "fft")
+        dom.free()
