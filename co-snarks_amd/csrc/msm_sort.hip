@@ -43,7 +43,8 @@ __device__ __forceinline__ uint32_t lds_slot(uint32_t* counter, uint32_t b, bool
 }
 
 // Block (chunk ch, window w): LDS histogram of the chunk's digits -> blkcnt[w][ch][0..NB)
-__global__ __launch_bounds__(SORT_BLK) void k_msm_hist_lds(MsmParams p, const uint16_t* __restrict__ dig, uint32_t* __restrict__ blkcnt) {
+__global__ __launch_bounds__(SORT_BLK) void k_msm_hist_lds(MsmParams p, const uint16_t* __restrict__ dig, uint32_t* __restrict__ blkcnt,
+                                                            uint32_t* __restrict__ part_cnt /* two-level mode: [w][ch][NB/256], else NULL */) {
   extern __shared__ uint32_t lds_cnt[];
   const uint32_t ch = blockIdx.x, w = blockIdx.y;
   for (uint32_t b = threadIdx.x; b < p.NB; b += SORT_BLK) lds_cnt[b] = 0;
@@ -65,6 +66,17 @@ __global__ __launch_bounds__(SORT_BLK) void k_msm_hist_lds(MsmParams p, const ui
   __syncthreads();
   uint32_t* out = blkcnt + ((size_t)w * p.CH + ch) * p.NB;
   for (uint32_t b = threadIdx.x; b < p.NB; b += SORT_BLK) out[b] = lds_cnt[b];
+  if (part_cnt) {  // entries of this chunk per partition of 256 adjacent buckets, straight from the LDS histogram (one wave each)
+    const uint32_t P = p.NB / 256;
+    const int lane = threadIdx.x & 63;
+    for (uint32_t part = threadIdx.x >> 6; part < P; part += SORT_BLK / 64) {
+      const uint32_t* c = lds_cnt + part * 256;
+      uint32_t v = c[lane] + c[lane + 64] + c[lane + 128] + c[lane + 192];
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d);
+      if (lane == 0) part_cnt[((size_t)w * p.CH + ch) * P + part] = v;
+    }
+  }
 }
 
 // Per (window, bucket): exclusive prefix over chunks (in place) and the bucket total -> hist[w][b+1]
@@ -86,39 +98,57 @@ __global__ __launch_bounds__(256) void k_msm_colscan(MsmParams p, uint32_t* __re
 // Out: start[w][b] = first sorted slot of bucket b (start[w][NB+1] = total entries of the window) and
 // nlanes[w] = ceil(total / L): the accumulate kernel cuts the sorted array into equal runs of L entries, one lane
 // each, so every lane of a wave does the same number of mixed additions whatever the bucket sizes are.
+// The counts are staged in LDS (coalesced loads / stores; each thread then walks its own contiguous run of counters in LDS, where
+// the odd run length keeps the lanes on different banks) and the 1024 per-thread totals are scanned with wave shuffles + one
+// LDS hop: 52 us -> ~10 us per launch at NB = 2^14 against the former strided global walk + 20-barrier Hillis-Steele scan.
 __global__ __launch_bounds__(1024) void k_msm_scan(MsmParams p, uint32_t* hist, uint32_t* start, uint32_t* nlanes) {
-  __shared__ uint32_t sh_cnt[1024];
+  extern __shared__ uint32_t sc_lds[];  // len counters, then 16 wave totals
   const int w = blockIdx.x;
   const uint32_t len = p.NB + 2;
   uint32_t* h = hist + (size_t)w * len;
   uint32_t* st = start + (size_t)w * len;
+  uint32_t* wave_tot = sc_lds + len;
+  for (uint32_t b = threadIdx.x; b < len; b += 1024) {
+    sc_lds[b] = h[b];
+    h[b] = 0;  // ready for the next MSM on this arena
+  }
+  __syncthreads();
   const uint32_t per = (len + 1023) / 1024;
   const uint32_t b0 = threadIdx.x * per;
   uint32_t cnt = 0;
   for (uint32_t k = 0; k < per; ++k) {
     const uint32_t b = b0 + k;
-    if (b < len) cnt += h[b];
+    if (b < len) cnt += sc_lds[b];
   }
-  sh_cnt[threadIdx.x] = cnt;
+  // inclusive scan of cnt over the block: within the wave by shuffles, across the 16 waves through LDS
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint32_t incl = cnt;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+    if (lane >= d) incl += up;
+  }
+  if (lane == 63) wave_tot[wv] = incl;
   __syncthreads();
-  for (int d = 1; d < 1024; d <<= 1) {  // Hillis-Steele inclusive scan over 1024 partials
-    uint32_t a = 0;
-    if ((int)threadIdx.x >= d) a = sh_cnt[threadIdx.x - d];
-    __syncthreads();
-    sh_cnt[threadIdx.x] += a;
-    __syncthreads();
+  uint32_t base = 0, total = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const uint32_t t = wave_tot[i];
+    if (i < wv) base += t;
+    total += t;
   }
-  uint32_t run_c = sh_cnt[threadIdx.x] - cnt;
+  uint32_t run_c = base + incl - cnt;  // exclusive prefix of this thread's run
   for (uint32_t k = 0; k < per; ++k) {
     const uint32_t b = b0 + k;
     if (b < len) {
-      const uint32_t cv = h[b];
-      st[b] = run_c;
+      const uint32_t cv = sc_lds[b];
+      sc_lds[b] = run_c;
       run_c += cv;
-      h[b] = 0;
     }
   }
-  if (threadIdx.x == 1023) nlanes[w] = (sh_cnt[1023] + p.L - 1) / p.L;
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < len; b += 1024) st[b] = sc_lds[b];
+  if (threadIdx.x == 0) nlanes[w] = (total + p.L - 1) / p.L;
 }
 
 // Block (chunk ch, window w): LDS cursors = bucket start + this chunk's prefix; scatter (index | sign) into
@@ -155,20 +185,6 @@ __global__ __launch_bounds__(SORT_BLK) void k_msm_scatter_lds(MsmParams p, const
 // byte with 256 open streams inside one contiguous output slice. All offsets come from the histogram already built.
 constexpr uint32_t PART_BUCKETS = 256;
 constexpr int SORT_UNROLL = 4;
-
-// part_cnt[w][ch][p] = entries of chunk ch whose bucket lies in partition p (from the RAW per-chunk counts)
-__global__ __launch_bounds__(256) void k_msm_part_count(MsmParams p, const uint32_t* __restrict__ blkcnt, uint32_t* __restrict__ part_cnt) {
-  __shared__ uint32_t red[256];
-  const uint32_t part = blockIdx.x, ch = blockIdx.y, w = blockIdx.z;
-  const uint32_t P = p.NB / PART_BUCKETS;
-  red[threadIdx.x] = blkcnt[((size_t)w * p.CH + ch) * p.NB + (size_t)part * PART_BUCKETS + threadIdx.x];
-  __syncthreads();
-  for (int d = 128; d >= 1; d >>= 1) {
-    if ((int)threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) part_cnt[((size_t)w * p.CH + ch) * P + part] = red[0];
-}
 
 // in place: part_cnt[w][ch][p] -> first intermediate slot of (chunk ch, partition p) = start of the partition's first
 // bucket + entries of earlier chunks
@@ -372,11 +388,20 @@ int msm_sort_launch(const MsmParams& p, const SortBuffers& b, hipStream_t st, hi
       raised = true;
     }
   }
-  hipLaunchKernelGGL(k_msm_hist_lds, dim3(p.CH, p.W), dim3(SORT_BLK), sort_lds, st, p, b.dig, b.blkcnt);
-  if (two_level) hipLaunchKernelGGL(k_msm_part_count, dim3(nparts, p.CH, p.W), dim3(256), 0, st, p, b.blkcnt, b.part_cnt);
+  hipLaunchKernelGGL(k_msm_hist_lds, dim3(p.CH, p.W), dim3(SORT_BLK), sort_lds, st, p, b.dig, b.blkcnt, two_level ? b.part_cnt : nullptr);
   hipLaunchKernelGGL(k_msm_colscan, dim3((p.NB + 255) / 256, p.W), dim3(256), 0, st, p, b.blkcnt, b.hist);
   if (ev) CSH_HIP(hipEventRecord(ev[1], st));
-  hipLaunchKernelGGL(k_msm_scan, dim3(p.W), dim3(1024), 0, st, p, b.hist, b.start, b.nlanes);
+  {
+    const size_t scan_lds = sizeof(uint32_t) * ((size_t)p.NB + 2 + 16);
+    if (scan_lds > 48 * 1024) {
+      static thread_local bool raised_scan = false;
+      if (!raised_scan) {
+        CSH_HIP(hipFuncSetAttribute((const void*)k_msm_scan, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
+        raised_scan = true;
+      }
+    }
+    hipLaunchKernelGGL(k_msm_scan, dim3(p.W), dim3(1024), scan_lds, st, p, b.hist, b.start, b.nlanes);
+  }
   if (ev) CSH_HIP(hipEventRecord(ev[2], st));
   if (two_level) {
     hipLaunchKernelGGL(k_msm_part_offsets, dim3((nparts + 255) / 256, p.W), dim3(256), 0, st, p, b.start, b.part_cnt);
