@@ -23,7 +23,8 @@ class CoSnarksHipError(RuntimeError):
 
 
 def lib_path() -> str:
-    return os.path.join(_HERE, "lib", "libcosnarks_hip.so")
+    """The in-tree build; COSNARKS_HIP_LIB points A/B runs of kernel variants at another build of the same sources."""
+    return os.environ.get("COSNARKS_HIP_LIB") or os.path.join(_HERE, "lib", "libcosnarks_hip.so")
 
 
 def header_path() -> str:

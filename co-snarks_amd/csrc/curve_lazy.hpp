@@ -29,7 +29,7 @@ CSH_HD XYZZLazy<L> lazy_mdbl_inl(const L& x, const L& y) {
   L xx = L::sqr(x);
   L m = L::add(L::add(xx, xx), xx).normalized();
   XYZZLazy<L> r;
-  r.x = L::sub(L::sqr(m), L::add(s, s)).normalized();
+  r.x = L::sqr_sub(m, L::add(s, s));
   r.y = L::mul_sub(m, L::sub(s, r.x), w, y);
   r.zz = v;
   r.zzz = w;
@@ -45,21 +45,36 @@ CSH_HD_NOINLINE XYZZLazy<L> lazy_mdbl_v(L x, L y) {  // by value: fine (and fast
   return lazy_mdbl_inl<L>(x, y);
 }
 
+// Fp2 values split over a lane pair (curve_pair.hpp): the lane's half of an affine point comes from memory by role
+template <class LF>
+struct Fp2Pair;
+template <class L>
+struct IsPair { static constexpr bool value = false; };
+template <class LF>
+struct IsPair<Fp2Pair<LF>> { static constexpr bool value = true; };
+template <class L, class AffT>
+__device__ void pair_unpack_affine(const AffT* src, L* x, L* y);
+
 // Rare-path helper of the accumulate kernel for the wide fields: 2 * (the affine point at `src`, negated if asked), re-read
 // from memory INSIDE the out-of-line routine. (The former version took private stack copies of x2 / y2 in the caller's rare
 // branch; the compiler hoisted those stores to the top of the loop body, so every mixed addition wrote 2 field elements of
 // scratch -- 2.5 GB per 2^20 BN254 G2 MSM, 4.2 GB on BLS12-381 G2 by WRITE_SIZE, profiles/r02_a_msm_*_pmc_hbm_bytes.csv.)
 template <class L, class AffT>
 CSH_HD_NOINLINE void lazy_mdbl_mem(const AffT* src, uint32_t negate, XYZZLazy<L>* out) {
-  const AffT pt = *src;
-  const L x = L::unpack(pt.x);
-  L y = L::unpack(pt.y);
-  if (negate) y = L::neg(y).normalized();
+  L x, y;
+  if constexpr (IsPair<L>::value) {
+    pair_unpack_affine<L, AffT>(src, &x, &y);
+  } else {
+    const AffT pt = *src;
+    x = L::unpack(pt.x);
+    y = L::unpack(pt.y);
+  }
+  if (negate) y = y.neg_unpacked();
   *out = lazy_mdbl_inl<L>(x, y);
 }
 
-// acc += (x2, y2); the caller has already excluded the point at infinity. Contract: x2, y2 have limbs in
-// [-2, 2^B + 2] (unpack() output, or neg(..).normalized() for a negated point) -- acc.x / acc.y inherit that bound
+// acc += (x2, y2); the caller has already excluded the point at infinity. Contract: x2, y2 have limbs 0..NL-2 in
+// [-2, 2^B + 2] and a small signed top limb (unpack() output, or .neg_unpacked() of it for a negated point) -- acc.x / acc.y inherit that bound
 // and are subtracted limb-wise from fresh products below. src (nullable) / negate: where (x2, y2) came from, for the rare
 // doubling path of the wide fields.
 template <class L, class AffT = void>
@@ -101,7 +116,7 @@ CSH_HD void lazy_madd(XYZZLazy<L>& acc, const L& x2, const L& y2, const AffT* sr
   const L pp = L::sqr(p);
   const L ppp = L::mul(p, pp);
   const L q = L::mul(acc.x, pp);
-  const L x3 = L::sub(L::sub(L::sqr(r), ppp), L::add(q, q)).normalized();
+  const L x3 = L::sqr_sub(r, L::add(ppp, L::add(q, q)));   // r^2 - ppp - 2q, normalised by the reduction's own carry chain
   const L y3 = L::mul_sub(r, L::sub(q, x3), acc.y, ppp);   // r*(q - x3) - y1*ppp, one reduction
   acc.x = x3;
   acc.y = y3;
@@ -126,7 +141,7 @@ CSH_HD XYZZLazy<L> lazy_dbl_inl(const XYZZLazy<L>& p) {
   const L xx = L::sqr(p.x);
   const L m = L::add(L::add(xx, xx), xx).normalized();
   XYZZLazy<L> r;
-  r.x = L::sub(L::sqr(m), L::add(s, s)).normalized();
+  r.x = L::sqr_sub(m, L::add(s, s));
   r.y = L::mul_sub(m, L::sub(s, r.x), w, p.y);
   r.zz = L::mul(v, p.zz);
   r.zzz = L::mul(w, p.zzz);
@@ -166,7 +181,7 @@ CSH_HD void lazy_add_inl(XYZZLazy<L>& acc, const XYZZLazy<L>& p) {
   const L pp = L::sqr(pd);
   const L ppp = L::mul(pd, pp);
   const L q = L::mul(u1, pp);
-  const L x3 = L::sub(L::sub(L::sqr(r), ppp), L::add(q, q)).normalized();
+  const L x3 = L::sqr_sub(r, L::add(ppp, L::add(q, q)));
   const L y3 = L::mul_sub(r, L::sub(q, x3), s1, ppp);
   acc.x = x3;
   acc.y = y3;

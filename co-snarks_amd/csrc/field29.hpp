@@ -221,6 +221,28 @@ struct FpS {
     for (int i = 0; i < NL; ++i) r.l[i] = -a.l[i];
     return r;
   }
+  // -a for an unpack() output (limbs 0..NL-2 in [0, 2^B), small non-negative top limb) by limb-wise complement:
+  // sum (MASK - l_i) 2^(B i) + 1 - (l_top + 1) 2^(B (NL-1)) = -a. One instruction per limb, no carry step: limbs 0..NL-2 stay in
+  // [0, 2^B], the top limb turns negative (it carries the sign, as after a reduction). Replaces neg().normalized() where a
+  // stored base point is negated (4 instructions per limb).
+  CSH_HD FpS neg_unpacked() const {
+    FpS r;
+    r.l[0] = (int32_t)(LP::MASK + 1u) - l[0];
+#pragma unroll
+    for (int i = 1; i < NL - 1; ++i) r.l[i] = (int32_t)LP::MASK - l[i];
+    r.l[NL - 1] = -1 - l[NL - 1];
+    return r;
+  }
+  // neg01 ? neg_unpacked() : *this, branch-free (x ^ MASK = MASK - x on B-bit limbs, x ^ -1 = -1 - x on the top limb)
+  CSH_HD FpS cneg_unpacked(uint32_t neg01) const {
+    const uint32_t all = 0u - neg01, low = all & LP::MASK;
+    FpS r;
+    r.l[0] = (int32_t)(((uint32_t)l[0] ^ low) + neg01);
+#pragma unroll
+    for (int i = 1; i < NL - 1; ++i) r.l[i] = (int32_t)((uint32_t)l[i] ^ low);
+    r.l[NL - 1] = (int32_t)((uint32_t)l[NL - 1] ^ all);
+    return r;
+  }
   CSH_HD FpS normalized() const {
     FpS r;
     r.l[0] = (int32_t)((uint32_t)l[0] & LP::MASK);
@@ -337,8 +359,23 @@ struct FpS {
     r.l[NL - 1] = (int32_t)w.t[2 * NL - 1];
     return r;
   }
+  // reduce(w) - s for a subtrahend with |limb| < 2^31 (a sum of a few reduced values): s enters the upper columns before the
+  // output carry chain, one multiply-add per limb, so the difference comes out with limbs 0..NL-2 in [0, 2^B) -- instead of a
+  // limb-wise subtraction per term plus a carry step afterwards (x3 = r^2 - ppp - 2q in every point addition).
+  CSH_HD static FpS reduce_sub(Wide w, const FpS& s) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int32_t m1;  // -1 the compiler cannot see through: keeps "s * -1 + t" ONE v_mad_i64_i32 (it would otherwise be rewritten
+    asm("s_mov_b32 %0, -1" : "=s"(m1));  // as sign extension + a two-instruction 64-bit subtraction)
+#else
+    const int32_t m1 = -1;
+#endif
+#pragma unroll
+    for (int k = 0; k < NL; ++k) w.t[NL + k] = (int64_t)s.l[k] * (int64_t)m1 + w.t[NL + k];
+    return reduce(w);
+  }
   CSH_HD static FpS mul(const FpS& a, const FpS& b) { return reduce(mul_wide(a, b)); }
   CSH_HD static FpS sqr(const FpS& a) { return reduce(sqr_wide(a)); }
+  CSH_HD static FpS sqr_sub(const FpS& a, const FpS& s) { return reduce_sub(sqr_wide(a), s); }  // a^2 - s
   CSH_HD static FpS mul_sub(const FpS& a, const FpS& b, const FpS& c, const FpS& d) { return reduce(mul_sub_wide(a, b, c, d)); }
 
   // exact value in [0, p) with limbs in [0, 2^B); input value must lie within (-2p, 4p)
@@ -514,11 +551,17 @@ struct Fp2S {
   CSH_HD static Fp2S sub(const Fp2S& a, const Fp2S& b) { return {LF::sub(a.c0, b.c0), LF::sub(a.c1, b.c1)}; }
   CSH_HD static Fp2S neg(const Fp2S& a) { return {LF::neg(a.c0), LF::neg(a.c1)}; }
   CSH_HD Fp2S normalized() const { return {c0.normalized(), c1.normalized()}; }
+  CSH_HD Fp2S neg_unpacked() const { return {c0.neg_unpacked(), c1.neg_unpacked()}; }
+  CSH_HD Fp2S cneg_unpacked(uint32_t neg01) const { return {c0.cneg_unpacked(neg01), c1.cneg_unpacked(neg01)}; }
   CSH_HD static Fp2S mul(const Fp2S& a, const Fp2S& b) {
     return {LF::reduce(LF::mul_sub_wide(a.c0, b.c0, a.c1, b.c1)), LF::reduce(LF::mul_add_wide(a.c0, b.c1, a.c1, b.c0))};
   }
   CSH_HD static Fp2S sqr(const Fp2S& a) {
     return {LF::reduce(LF::sqr_sub_wide(a.c0, a.c1)), LF::mul(LF::add(a.c0, a.c0), a.c1)};
+  }
+  // a^2 - s (s: |limb| < 2^31)
+  CSH_HD static Fp2S sqr_sub(const Fp2S& a, const Fp2S& s) {
+    return {LF::reduce_sub(LF::sqr_sub_wide(a.c0, a.c1), s.c0), LF::reduce_sub(LF::mul_wide(LF::add(a.c0, a.c0), a.c1), s.c1)};
   }
   // a*b - c*d
   CSH_HD static Fp2S mul_sub(const Fp2S& a, const Fp2S& b, const Fp2S& c, const Fp2S& d) {

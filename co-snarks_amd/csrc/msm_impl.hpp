@@ -8,6 +8,7 @@
 #include "curve.hpp"
 #include "curve_lazy.hpp"
 #include "curve_quad.hpp"
+#include "curve_pair.hpp"
 #include "host_fp64.hpp"
 #include "msm_digits.hpp"
 #include "msm_sort.hpp"
@@ -17,12 +18,13 @@ namespace csh {
 
 // LAZY: bucket accumulation runs in the signed lazy field (field29.hpp); Bases then stores the coordinates
 // re-encoded as canonical x*R' (same 32 bytes per coordinate), converted once at upload.
-struct Bn254G1Cfg { using Fq = Bn254Fq;   using Fr = Bn254Fr; static constexpr bool LAZY = true;  using L = Fq29s; static constexpr bool INLINE_ADD = true; };
-struct Bn254G2Cfg { using Fq = Bn254Fq2;  using Fr = Bn254Fr; static constexpr bool LAZY = true;  using L = Fq29s2; static constexpr bool INLINE_ADD = true; };
-struct Bls381G1Cfg { using Fq = Bls381Fq;  using Fr = Bls381Fr; static constexpr bool LAZY = true;  using L = Fq28s; static constexpr bool INLINE_ADD = true; };
+// PAIR (the G2 groups): accumulate and window reduction run with two lanes per point, one Fp2 component each (curve_pair.hpp)
+struct Bn254G1Cfg { using Fq = Bn254Fq;   using Fr = Bn254Fr; static constexpr bool LAZY = true;  using L = Fq29s; static constexpr bool INLINE_ADD = true; static constexpr bool PAIR = false; };
+struct Bn254G2Cfg { using Fq = Bn254Fq2;  using Fr = Bn254Fr; static constexpr bool LAZY = true;  using L = Fq29s2; static constexpr bool INLINE_ADD = true; static constexpr bool PAIR = true; using LP = Fp2Pair<Fq29s>; };
+struct Bls381G1Cfg { using Fq = Bls381Fq;  using Fr = Bls381Fr; static constexpr bool LAZY = true;  using L = Fq28s; static constexpr bool INLINE_ADD = true; static constexpr bool PAIR = false; };
 // Grumpkin: base field = BN254 Fr, scalars = BN254 Fq (the 2-cycle partner of BN254)
-struct GrumpkinG1Cfg { using Fq = Bn254Fr;   using Fr = Bn254Fq; static constexpr bool LAZY = true;  using L = Fr29s; static constexpr bool INLINE_ADD = true; };
-struct Bls381G2Cfg { using Fq = Bls381Fq2; using Fr = Bls381Fr; static constexpr bool LAZY = true;  using L = Fq28s2; static constexpr bool INLINE_ADD = true; };
+struct GrumpkinG1Cfg { using Fq = Bn254Fr;   using Fr = Bn254Fq; static constexpr bool LAZY = true;  using L = Fr29s; static constexpr bool INLINE_ADD = true; static constexpr bool PAIR = false; };
+struct Bls381G2Cfg { using Fq = Bls381Fq2; using Fr = Bls381Fr; static constexpr bool LAZY = true;  using L = Fq28s2; static constexpr bool INLINE_ADD = true; static constexpr bool PAIR = true; using LP = Fp2Pair<Fq28s>; };
 
 struct Bases {
   csh_curve_t curve;
@@ -65,6 +67,16 @@ __global__ __launch_bounds__(MSM_BLK) void k_msm_digits(const Fr* __restrict__ s
     });
     for (; next < p.W; ++next) dig[(size_t)next * p.n + i] = (uint16_t)DIG_ZERO;
   }
+}
+
+// one-word necessary condition for the stored point at infinity (0, 0): the full 16..48-word test only runs behind it
+template <class P>
+__device__ __forceinline__ uint32_t top_word(const Fp<P>& f) { return f.l[Fp<P>::N - 1]; }
+template <class F>
+__device__ __forceinline__ uint32_t top_word(const Fp2T<F>& f) { return top_word(f.c0) | top_word(f.c1); }
+template <class Fq>
+__device__ __forceinline__ bool stored_is_inf(const Affine<Fq>& pt) {
+  return (top_word(pt.x) | top_word(pt.y)) == 0 && pt.is_inf();
 }
 
 // first index in [lo, hi) with a[idx] > v
@@ -115,19 +127,79 @@ __global__ __launch_bounds__(ACC_BLK) void k_msm_accum(const Affine<typename Cfg
         e_next = so[pos + 1];
         pt_next = bases[e_next & 0x7fffffffu];
       }
-      if (pos == next) {                            // crossed into the next non-empty bucket: flush
-        pw[b + k] = acc;
-        acc = XYZZLazy<L>::inf();
-        do { ++b; next = st[b + 1]; } while (next <= pos);
-      }
-      if (pt.is_inf()) continue;
+      const bool inf = stored_is_inf(pt);
       const L x = L::unpack(pt.x);
-      L y = L::unpack(pt.y);
-      if (e >> 31) y = L::neg(y).normalized();  // keep |limb| <= 2^B + 1: lazy_madd subtracts acc.y limb-wise
+      const L y = L::unpack(pt.y).cneg_unpacked(e >> 31);  // limbs stay in [0, 2^B]: lazy_madd subtracts acc.y limb-wise
+      if (pos == next) {                            // crossed into the next non-empty bucket: flush, and the entry that
+        pw[b + k] = acc;                            // opens the bucket becomes the accumulator (the coordinates of an
+        do { ++b; next = st[b + 1]; } while (next <= pos);  // empty accumulator are never read)
+        acc.x = x;
+        acc.y = y;
+        acc.zz = L::one();
+        acc.zzz = L::one();
+        acc.empty = inf;
+        continue;
+      }
+      if (inf) continue;
       lazy_madd<L, Affine<Fq>>(acc, x, y, bases + (e & 0x7fffffffu), e >> 31);
     }
     pw[b + k] = acc;
   }
+}
+
+// The same accumulation with two lanes per run (G2: lane 2k holds the c0 components of the point, lane 2k+1 the c1 components,
+// curve_pair.hpp). Everything that steers control flow (run bounds, bucket boundaries, the empty flag, the point-at-infinity and
+// doubling tests) is identical on the two lanes of a pair.
+template <class Cfg>
+__global__ __launch_bounds__(ACC_BLK) void k_msm_accum_pair(const Affine<typename Cfg::Fq>* __restrict__ bases, MsmParams p,
+                                                            const uint32_t* __restrict__ start, const uint32_t* __restrict__ nlanes,
+                                                            const uint32_t* __restrict__ sorted, LazyPt<Cfg>* partial) {
+  using Fq = typename Cfg::Fq;
+  using L = typename Cfg::LP;
+  using LF = typename L::Base;
+  using F32 = decltype(bases->x.c0);
+  const int w = blockIdx.y;
+  const int role = pair_role();
+  const uint32_t k = (blockIdx.x * blockDim.x + threadIdx.x) >> 1;
+  if (k >= nlanes[w]) return;
+  const uint32_t* st = start + (size_t)w * (p.NB + 2);
+  const uint32_t total = st[p.NB + 1];
+  const uint32_t lo = k * p.L;
+  uint32_t hi = lo + p.L;
+  if (hi > total) hi = total;
+  uint32_t b = upper_bound_u32(st, 1, p.NB + 1, lo) - 1;  // bucket containing sorted position lo
+  uint32_t next = st[b + 1];
+  const uint32_t* so = sorted + (size_t)w * p.n;
+  LazyPt<Cfg>* pw = partial + (size_t)w * p.tmax;
+  const F32* half = reinterpret_cast<const F32*>(bases) + role;  // component `role` of x at [4 i], of y at [4 i + 2]
+  XYZZLazy<L> acc = XYZZLazy<L>::inf();
+  uint32_t e_next = so[lo];
+  F32 x_next = half[4 * (size_t)(e_next & 0x7fffffffu)], y_next = half[4 * (size_t)(e_next & 0x7fffffffu) + 2];
+  for (uint32_t pos = lo; pos < hi; ++pos) {
+    const uint32_t e = e_next;
+    const F32 xs = x_next, ys = y_next;
+    if (pos + 1 < hi) {                           // software prefetch of the next gather
+      e_next = so[pos + 1];
+      x_next = half[4 * (size_t)(e_next & 0x7fffffffu)];
+      y_next = half[4 * (size_t)(e_next & 0x7fffffffu) + 2];
+    }
+    const bool inf = pair_all((top_word(xs) | top_word(ys)) == 0 && xs.is_zero() && ys.is_zero());  // infinity is stored as (0, 0)
+    const L x{LF::unpack(xs)};
+    const L y{LF::unpack(ys).cneg_unpacked(e >> 31)};
+    if (pos == next) {                            // crossed into the next non-empty bucket: flush; this entry opens the next sum
+      pair_store(&pw[b + k], role, acc);
+      do { ++b; next = st[b + 1]; } while (next <= pos);
+      acc.x = x;
+      acc.y = y;
+      acc.zz = L::one();
+      acc.zzz = L::one();
+      acc.empty = inf;
+      continue;
+    }
+    if (inf) continue;
+    lazy_madd<L, Affine<Fq>>(acc, x, y, bases + (e & 0x7fffffffu), e >> 31);
+  }
+  pair_store(&pw[b + k], role, acc);
 }
 
 // ---- the latency-bound tail: merge -> reduce -> fold, four lanes per point (curve_quad.hpp) ---------------------------
@@ -281,6 +353,46 @@ __global__ __launch_bounds__(64) void k_msm_reduce_serial(MsmParams p, const Laz
     }
   }
   segres[(size_t)w * p.S + k] = acc;
+}
+
+// The lane-serial reduction with two lanes per segment (G2, curve_pair.hpp): half the registers per lane (no scratch) and half
+// the instructions on the dependent chain of every point operation.
+template <class Cfg>
+__global__ __launch_bounds__(64) void k_msm_reduce_pair(MsmParams p, const LazyPt<Cfg>* __restrict__ dense, LazyPt<Cfg>* segres) {
+  using L = typename Cfg::LP;
+  const int w = blockIdx.y;
+  const int role = pair_role();
+  const uint32_t k = blockIdx.x * 32 + (threadIdx.x >> 1);
+  if (k >= p.S) return;
+  const uint32_t per = (p.NB + p.S - 1) / p.S;
+  const uint32_t t0 = 1 + k * per;
+  uint32_t t1 = t0 + per;
+  if (t1 > p.NB + 1) t1 = p.NB + 1;
+  XYZZLazy<L> running = XYZZLazy<L>::inf(), acc = XYZZLazy<L>::inf();
+  uint32_t prev_b = 0;
+  if (t0 < t1) {
+    const LazyPt<Cfg>* dw = dense + (size_t)w * (p.NB + 1);
+    for (uint32_t t = t1; t-- > t0;) {
+      if (dw[t].empty) continue;
+      const XYZZLazy<L> pt = pair_load(&dw[t], role);
+      uint32_t gap = prev_b ? prev_b - t : 0;
+      if (gap) {
+        if (gap <= 4) {
+          while (gap--) lazy_add_inl<L>(acc, running);
+        } else {
+          const XYZZLazy<L> m = lazy_mul_small<L, true>(running, gap);
+          lazy_add_inl<L>(acc, m);
+        }
+      }
+      lazy_add_inl<L>(running, pt);
+      prev_b = t;
+    }
+    if (prev_b) {  // acc = sum (b - bmin) B_b ; add bmin * R
+      const XYZZLazy<L> m = lazy_mul_small<L, true>(running, prev_b);
+      lazy_add_inl<L>(acc, m);
+    }
+  }
+  pair_store(&segres[(size_t)w * p.S + k], role, acc);
 }
 
 // Fold tree: block (j, w) sums in[w][j * 128 .. j * 128 + 127] (entries >= count are skipped) into out[w][j]; 256 threads =
@@ -558,18 +670,36 @@ int bucket_group(const void* points, const MsmParams& p, const SortOut& so, cons
   {
     const int tb = tune().acc_blk.load(std::memory_order_relaxed);
     const int blk = (tb == 64 || tb == 128) ? tb : ACC_BLK;
-    const dim3 ag((bb.max_lanes + blk - 1) / blk, nw), ab(blk);
-    hipLaunchKernelGGL(k_msm_accum<Cfg>, ag, ab, 0, st, bases, p, start, nlanes, sorted, partial);
+    // tune "msm_variant" bit 1: two lanes per point on the G2 groups (curve_pair.hpp). Measured a wash against whole points
+    // per lane (profiles/r02_g_pair_stages.log): one wave of multiply-add code already saturates the SIMD's integer pipe, so
+    // the second wave the smaller footprint buys has nothing to fill. Kept for A/B runs and covered by the GPU parity suite.
+    bool pair = false;
+    if constexpr (Cfg::PAIR) pair = (tune().msm_variant.load(std::memory_order_relaxed) & 2) != 0;
+    if constexpr (Cfg::PAIR) {
+      if (pair) {
+        const dim3 ag((2 * bb.max_lanes + blk - 1) / blk, nw), ab(blk);
+        hipLaunchKernelGGL(k_msm_accum_pair<Cfg>, ag, ab, 0, st, bases, p, start, nlanes, sorted, partial);
+      }
+    }
+    if (!pair) {
+      const dim3 ag((bb.max_lanes + blk - 1) / blk, nw), ab(blk);
+      hipLaunchKernelGGL(k_msm_accum<Cfg>, ag, ab, 0, st, bases, p, start, nlanes, sorted, partial);
+    }
   }
   if (ev) CSH_HIP(hipEventRecord(ev[4], st));
   CSH_HIP(hipMemsetAsync(giant, 0, 8, st));
   hipLaunchKernelGGL(k_msm_merge<Cfg>, dim3((p.NB + TAIL_Q - 1) / TAIL_Q, nw), dim3(TAIL_BLK), 0, st, p, start, partial, dense, giant, giant + 2);
   // buckets with > MERGE_CAP partials (heavily repeated scalars): block-wide tree, grid-stride over the queue
   hipLaunchKernelGGL(k_msm_merge_giant<Cfg>, dim3(bb.giant_blocks), dim3(256), 0, st, p, start, partial, dense, giant, giant + 2);
-  if (tune().msm_variant.load(std::memory_order_relaxed) & 1)
+  bool pair_red = false;
+  if constexpr (Cfg::PAIR) pair_red = (tune().msm_variant.load(std::memory_order_relaxed) & 4) != 0;  // bit 2: two-lane reduction
+  if (tune().msm_variant.load(std::memory_order_relaxed) & 1) {
     hipLaunchKernelGGL(k_msm_reduce<Cfg>, dim3((p.S + TAIL_Q - 1) / TAIL_Q, nw), dim3(TAIL_BLK), 0, st, p, dense, segres);
-  else
+  } else if (pair_red) {
+    if constexpr (Cfg::PAIR) hipLaunchKernelGGL(k_msm_reduce_pair<Cfg>, dim3((p.S + 31) / 32, nw), dim3(64), 0, st, p, dense, segres);
+  } else {
     hipLaunchKernelGGL(k_msm_reduce_serial<Cfg>, dim3((p.S + 63) / 64, nw), dim3(64), 0, st, p, dense, segres);
+  }
   // fold tree: S segment sums per window -> one, 128 per block and launch
   const LazyPt<Cfg>* cur = segres;
   uint32_t cur_n = p.S, cur_stride = p.S;

@@ -93,7 +93,7 @@ int lazy_accumulate_t(const void* affine_pts, const uint8_t* neg, size_t npts, v
     if (p.is_inf()) continue;
     Fq sx = L::repack_for_storage(p.x), sy = L::repack_for_storage(p.y);  // what Bases stores
     L x = L::unpack(sx), y = L::unpack(sy);
-    if (neg && neg[i]) y = L::neg(y).normalized();
+    if (neg && neg[i]) y = y.neg_unpacked();
     lazy_madd(acc, x, y);
   }
   XYZZ<Fq> r = lazy_to_xyzz<L, Fq>(acc);
@@ -114,7 +114,7 @@ int lazy_tree_t(const void* affine_pts, const uint8_t* neg, size_t npts, size_t 
       memcpy(&p, pts + i, sizeof p);
       if (p.is_inf()) continue;
       L x = L::unpack(L::repack_for_storage(p.x)), y = L::unpack(L::repack_for_storage(p.y));
-      if (neg && neg[i]) y = L::neg(y).normalized();
+      if (neg && neg[i]) y = y.neg_unpacked();
       lazy_madd(acc, x, y);
     }
     parts.push_back(acc);
@@ -147,7 +147,7 @@ __host__ __device__ inline XYZZ<Fq> lazy_chain(const Affine<Fq>* pts, size_t n, 
     Affine<Fq> p = pts[(t + i) % n];
     if (p.is_inf()) continue;
     L x = L::unpack(p.x), y = L::unpack(p.y);
-    if (((t * 2654435761u + i * 40503u) >> 7) & 1) y = L::neg(y).normalized();
+    if (((t * 2654435761u + i * 40503u) >> 7) & 1) y = y.neg_unpacked();
     lazy_madd(acc, x, y);
   }
   return lazy_to_xyzz<L, Fq>(acc);

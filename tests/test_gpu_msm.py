@@ -86,6 +86,28 @@ def test_msm_window_sizes(gpu):
         assert G.eq(_run(gpu, "bn254", 0, pts, sk), G.msm(pts, sk))
 
 
+@pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
+@pytest.mark.parametrize("variant", [2, 4, 6])
+def test_msm_g2_lane_pair_variants(gpu, curve, variant):
+    """The two-lanes-per-point G2 kernels (csrc/curve_pair.hpp; msm_variant bit 1 = accumulate, bit 2 = window reduction): same
+    group element as the oracle on random points with duplicates, P / -P, points at infinity and the edge scalars, at several
+    window widths (the doubling and cancellation paths run through the DPP exchange too)."""
+    G = cv.CURVES[curve][1]
+    F = H.FR[curve]
+    r = H.rng(700 + variant)
+    n = 300
+    pts = H.rand_points(G, n, r, with_inf=True)
+    pts[10] = pts[11]
+    pts[20] = G.neg(pts[21])
+    pts[30:40] = [pts[30]] * 10            # a run of equal points: doublings inside one bucket
+    for name, sc in {"random": H.rand_elems(F, n, r), "ones": [1] * n, "r-1": [F.p - 1] * n,
+                     "mixed": ([0, 1, F.p - 1, 2, (F.p - 1) // 2, 7] * 50)}.items():
+        want = G.msm(pts, sc)
+        for c in (0, 4, 11):
+            with gpu.tuned(msm_variant=variant, msm_c=c):
+                assert G.eq(_run(gpu, curve, 1, pts, sc), want), (name, c)
+
+
 def test_msm_arkworks_affine_stride(gpu):
     """Bases passed with a stride (arkworks Affine = x, y, infinity flag + padding) need no repacking."""
     G = cv.BN254_G1
