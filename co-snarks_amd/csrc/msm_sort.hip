@@ -205,14 +205,14 @@ __global__ __launch_bounds__(256) void k_msm_part_offsets(MsmParams p, const uin
 
 // Level 1: block (chunk, window); tiles of L1_TILE digit codes are counting-sorted by partition inside LDS and
 // written out as 8-byte records (index | sign << 31 | low bucket byte << 32) in runs of neighbouring addresses.
-// COMPACT (entry ids < 2^23, i.e. n <= 2^23 and no table remap): 4-byte records (index | sign << 23 | low bucket byte << 24)
-// -- 14 instead of 22 bytes of HBM traffic per entry over the two levels.
+// REC = 1 (entry ids < 2^23, i.e. n <= 2^23 and no table remap): 4-byte records (index | sign << 23 | low bucket byte << 24)
+// -- 14 instead of 22 bytes of HBM traffic per entry over the two levels. REC = 0: the 8-byte records.
 constexpr int L1_EPT = 8;
 constexpr int L1_TILE = L1_EPT * SORT_BLK;
-template <bool COMPACT>
+template <int REC>
 __global__ __launch_bounds__(SORT_BLK) void k_msm_scatter_l1(MsmParams p, const uint16_t* __restrict__ dig, const uint32_t* __restrict__ part_off,
                                                              void* __restrict__ inter) {
-  using Rec = typename std::conditional<COMPACT, uint32_t, uint64_t>::type;
+  using Rec = typename std::conditional<REC != 0, uint32_t, uint64_t>::type;
   constexpr uint32_t MAXP = 128;  // NB <= 2^15
   __shared__ uint32_t gcur[MAXP];
   __shared__ uint32_t cnt[MAXP];
@@ -275,10 +275,12 @@ __global__ __launch_bounds__(SORT_BLK) void k_msm_scatter_l1(MsmParams p, const 
       const uint32_t sl = k * SORT_BLK + tid;
       if (sl < tile_n) {
         const uint32_t bin = sbin[sl];
-        if constexpr (COMPACT)
-          out[gcur[bin] + (sl - toff[bin])] = (pay[sl] & 0x7fffffu) | ((pay[sl] >> 31) << 23) | ((uint32_t)slo[sl] << 24);
-        else
-          out[gcur[bin] + (sl - toff[bin])] = (uint64_t)pay[sl] | ((uint64_t)slo[sl] << 32);
+        const uint32_t dst = gcur[bin] + (sl - toff[bin]);
+        if constexpr (REC == 1) {
+          out[dst] = (pay[sl] & 0x7fffffu) | ((pay[sl] >> 31) << 23) | ((uint32_t)slo[sl] << 24);
+        } else {
+          out[dst] = (uint64_t)pay[sl] | ((uint64_t)slo[sl] << 32);
+        }
       }
     }
     __syncthreads();
@@ -295,11 +297,11 @@ __global__ __launch_bounds__(SORT_BLK) void k_msm_scatter_l1(MsmParams p, const 
 // neighbouring addresses (runs of ~L2_TILE/256 entries per bucket) instead of 64 unrelated 4-byte stores per wave.
 constexpr int L2_EPT = 8;
 constexpr int L2_TILE = L2_EPT * SORT_BLK;
-template <bool COMPACT>
+template <int REC>
 __global__ __launch_bounds__(SORT_BLK) void k_msm_scatter_l2(MsmParams p, const uint32_t* __restrict__ start, const void* __restrict__ inter,
                                                              uint32_t* __restrict__ sorted) {
-  using Rec = typename std::conditional<COMPACT, uint32_t, uint64_t>::type;
-  constexpr int BIN_SHIFT = COMPACT ? 24 : 32;
+  using Rec = typename std::conditional<REC != 0, uint32_t, uint64_t>::type;
+  constexpr int BIN_SHIFT = REC != 0 ? 24 : 32;
   __shared__ uint32_t gcur[PART_BUCKETS];  // next free sorted slot per bucket
   __shared__ uint32_t cnt[PART_BUCKETS];   // tile histogram
   __shared__ uint32_t toff[PART_BUCKETS];  // tile-local exclusive offsets
@@ -352,7 +354,7 @@ __global__ __launch_bounds__(SORT_BLK) void k_msm_scatter_l2(MsmParams p, const 
       if (t0 + k * SORT_BLK + tid < hi) {
         const uint32_t bin = (uint32_t)(e[k] >> BIN_SHIFT);
         const uint32_t slot = toff[bin] + rank[k];
-        if constexpr (COMPACT) pay[slot] = ((uint32_t)e[k] & 0x7fffffu) | ((((uint32_t)e[k] >> 23) & 1u) << 31);
+        if constexpr (REC == 1) pay[slot] = ((uint32_t)e[k] & 0x7fffffu) | ((((uint32_t)e[k] >> 23) & 1u) << 31);
         else pay[slot] = (uint32_t)e[k];
         sbin[slot] = (uint8_t)bin;
       }
@@ -418,14 +420,17 @@ int msm_sort_launch(const MsmParams& p, const SortBuffers& b, hipStream_t st, hi
   if (ev) CSH_HIP(hipEventRecord(ev[2], st));
   if (two_level) {
     hipLaunchKernelGGL(k_msm_part_offsets, dim3((nparts + 255) / 256, p.W), dim3(256), 0, st, p, b.start, b.part_cnt);
-    // 4-byte intermediate records when every entry id fits 23 bits (n <= 2^23, no fixed-base table remap)
-    const bool compact = p.remap_n == 0 && p.n <= (1u << 23) && tune().msm_variant.load(std::memory_order_relaxed) != 2;
-    if (compact) {
-      hipLaunchKernelGGL(k_msm_scatter_l1<true>, dim3(p.CH, p.W), dim3(SORT_BLK), 0, st, p, b.dig, b.part_cnt, (void*)b.inter);
-      hipLaunchKernelGGL(k_msm_scatter_l2<true>, dim3(nparts, p.W), dim3(SORT_BLK), 0, st, p, b.start, (const void*)b.inter, b.sorted);
+    // 4-byte intermediate records when every entry id fits 23 bits (n <= 2^23, no fixed-base table remap); tune "msm_variant"
+    // bit 3 forces the 8-byte records (A/B runs, tests). (4-byte records + a separate sign byte for ids up to 2^24 were
+    // measured and lose to the 8-byte records: scatter 2.29 against 2.10 ms on BN254 G1 2^24 -- byte-granular scattered
+    // writes cost more than the 3 bytes per entry they save, profiles/r02_g_rec_stages.log.)
+    const bool wide_only = p.remap_n != 0 || (tune().msm_variant.load(std::memory_order_relaxed) & 8) != 0;
+    if (!wide_only && p.n <= (1u << 23)) {
+      hipLaunchKernelGGL(k_msm_scatter_l1<1>, dim3(p.CH, p.W), dim3(SORT_BLK), 0, st, p, b.dig, b.part_cnt, (void*)b.inter);
+      hipLaunchKernelGGL(k_msm_scatter_l2<1>, dim3(nparts, p.W), dim3(SORT_BLK), 0, st, p, b.start, (const void*)b.inter, b.sorted);
     } else {
-      hipLaunchKernelGGL(k_msm_scatter_l1<false>, dim3(p.CH, p.W), dim3(SORT_BLK), 0, st, p, b.dig, b.part_cnt, (void*)b.inter);
-      hipLaunchKernelGGL(k_msm_scatter_l2<false>, dim3(nparts, p.W), dim3(SORT_BLK), 0, st, p, b.start, (const void*)b.inter, b.sorted);
+      hipLaunchKernelGGL(k_msm_scatter_l1<0>, dim3(p.CH, p.W), dim3(SORT_BLK), 0, st, p, b.dig, b.part_cnt, (void*)b.inter);
+      hipLaunchKernelGGL(k_msm_scatter_l2<0>, dim3(nparts, p.W), dim3(SORT_BLK), 0, st, p, b.start, (const void*)b.inter, b.sorted);
     }
   } else {
     hipLaunchKernelGGL(k_msm_scatter_lds, dim3(p.CH, p.W), dim3(SORT_BLK), sort_lds, st, p, b.dig, b.start, b.blkcnt, b.sorted);
