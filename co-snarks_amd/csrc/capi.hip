@@ -96,6 +96,21 @@ int ensure_device() {
   return csh_init(0);
 }
 
+int device_simds() {
+  static std::atomic<int> cache[64];
+  int dev = tl_device;
+  if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return 1024;
+  if (dev < 0 || dev >= 64) return 1024;
+  int v = cache[dev].load(std::memory_order_relaxed);
+  if (v == 0) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    v = 4 * cus;
+    cache[dev].store(v, std::memory_order_relaxed);
+  }
+  return v;
+}
+
 hipStream_t resolve_stream(void* s) {
   if (s) return reinterpret_cast<hipStream_t>(s);
   return tl_lanes.get(tl_device)->stream;

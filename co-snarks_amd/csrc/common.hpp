@@ -16,6 +16,7 @@ namespace csh {
 
 void set_error(const char* fmt, ...);
 int ensure_device();                    // lazy csh_init(0) for the calling thread; returns csh_status
+int device_simds();                     // SIMDs of the calling thread's device (4 per CU; 1024 on MI355X), cached per device
 hipStream_t resolve_stream(void* s);    // NULL -> the calling thread's stream on its current device
 
 #define CSH_HIP(call)                                                                 \

@@ -18,13 +18,13 @@ namespace csh {
 
 // LAZY: bucket accumulation runs in the signed lazy field (field29.hpp); Bases then stores the coordinates
 // re-encoded as canonical x*R' (same 32 bytes per coordinate), converted once at upload.
-// PAIR (the G2 groups): accumulate and window reduction run with two lanes per point, one Fp2 component each (curve_pair.hpp)
+// PAIR (the G2 groups): accumulate and window reduction can run with two lanes per point, one Fp2 component each (curve_pair.hpp)
 struct Bn254G1Cfg { using Fq = Bn254Fq;   using Fr = Bn254Fr; static constexpr bool LAZY = true;  using L = Fq29s; static constexpr bool INLINE_ADD = true; static constexpr bool PAIR = false; };
-struct Bn254G2Cfg { using Fq = Bn254Fq2;  using Fr = Bn254Fr; static constexpr bool LAZY = true;  using L = Fq29s2; static constexpr bool INLINE_ADD = true; static constexpr bool PAIR = true; using LP = Fp2Pair<Fq29s>; };
+struct Bn254G2Cfg { using Fq = Bn254Fq2;  using Fr = Bn254Fr; static constexpr bool LAZY = true;  using L = Fq29s2; static constexpr bool INLINE_ADD = true; static constexpr bool PAIR = true; using LP = Fp2Pair<Fq29s>; static constexpr bool PAIR_REDUCE = false; };
 struct Bls381G1Cfg { using Fq = Bls381Fq;  using Fr = Bls381Fr; static constexpr bool LAZY = true;  using L = Fq28s; static constexpr bool INLINE_ADD = true; static constexpr bool PAIR = false; };
 // Grumpkin: base field = BN254 Fr, scalars = BN254 Fq (the 2-cycle partner of BN254)
 struct GrumpkinG1Cfg { using Fq = Bn254Fr;   using Fr = Bn254Fq; static constexpr bool LAZY = true;  using L = Fr29s; static constexpr bool INLINE_ADD = true; static constexpr bool PAIR = false; };
-struct Bls381G2Cfg { using Fq = Bls381Fq2; using Fr = Bls381Fr; static constexpr bool LAZY = true;  using L = Fq28s2; static constexpr bool INLINE_ADD = true; static constexpr bool PAIR = true; using LP = Fp2Pair<Fq28s>; };
+struct Bls381G2Cfg { using Fq = Bls381Fq2; using Fr = Bls381Fr; static constexpr bool LAZY = true;  using L = Fq28s2; static constexpr bool INLINE_ADD = true; static constexpr bool PAIR = true; using LP = Fp2Pair<Fq28s>; static constexpr bool PAIR_REDUCE = true; };
 
 struct Bases {
   csh_curve_t curve;
@@ -456,6 +456,37 @@ inline int choose_c(size_t n, int bits) {
   return best_c;
 }
 
+// L = sorted entries per accumulate lane. Every lane of every wave performs exactly L mixed additions and one wave of
+// multiply-add code already saturates its SIMD's integer pipe, so the accumulate kernel takes ceil(waves / SIMDs) rounds of L
+// additions: a sawtooth in L (measured, BN254 G1 2^22, 16 windows: L = 128 -> 8192 waves = 8.00 per SIMD, 4.82 ms; L = 112 ->
+// 9.16 per SIMD = 10 rounds, 5.28 ms; L = 144 -> 5.36 ms; profiles/r02_g_lsweep*.log). Longer lanes leave fewer partial sums
+// to merge (n W / L of them, ~4.6e-5 addition rounds each); with few long rounds the last one is balanced less well (+~0.2 round).
+// The plan takes the L in [16, 1024] with the smallest
+//   (rounds(L) + 0.2) * L + 4.6e-5 * n * W / L.
+// With 16 windows at the power-of-two sizes this lands on the former table (2^22 -> 128, 2^24 -> 256); it matters whenever
+// n W / 64 is not a multiple of the SIMD count: 17 windows (BN254 at 2^20: L = 32 meant 8.5 waves per SIMD, 9 rounds of 32
+// where 5 of 55 do, accumulate + merge 1.78 -> 1.73 ms; BN254 G2 5.48 -> 5.2 ms; 2^19: 1.33 -> 1.25 ms) and the arbitrary sizes of
+// real proving keys.
+inline uint32_t choose_lane_length(size_t n, int W) {
+  if (const int fl = tune().msm_l.load(std::memory_order_relaxed); fl > 0) return (uint32_t)fl;
+  const double simds = (double)device_simds();
+  const int wpb = ACC_BLK / 64;
+  double best = 1e300;
+  uint32_t best_L = 16;
+  for (uint32_t L = 16; L <= 1024; ++L) {
+    const uint64_t lanes = (n + L - 1) / L;
+    const uint64_t waves = (uint64_t)W * ((lanes + ACC_BLK - 1) / ACC_BLK) * wpb;
+    const double rounds = ceil((double)waves / simds);
+    const double cost = (rounds + 0.2) * L + 4.6e-5 * (double)n * W / L;
+    if (cost < best) {
+      best = cost;
+      best_L = L;
+    }
+    if (rounds <= 1) break;  // one round already: longer lanes only cost
+  }
+  return best_L;
+}
+
 struct PartialHeader {
   uint32_t magic, c, W, reserved;
   uint32_t pad[4];
@@ -469,14 +500,8 @@ inline MsmParams msm_plan(size_t n, int scalar_bits, int mont) {
   p.c = choose_c(n, scalar_bits);
   p.W = windows_for(scalar_bits, p.c);
   p.NB = 1u << (p.c - 1);
-  // L = sorted entries per lane (power of two in [16, 1024]): as long as possible (fewer partial sums to merge) while
-  // the W windows together still launch >= 2^19 lanes, ~8 waves per SIMD of the 256 CUs (measured optimum: 2^18 -> 16,
-  // 2^20 -> 32, 2^22 -> 128, 2^24 -> 256..512). Every lane of a wave performs the same number of mixed additions.
-  uint64_t L = 16;
-  while (L < 1024 && 2 * L * (uint64_t(1) << 19) <= (uint64_t)n * p.W) L <<= 1;
-  if (const int fl = tune().msm_l.load(std::memory_order_relaxed); fl > 0) L = (uint64_t)fl;
-  p.L = (uint32_t)L;
-  const uint32_t max_lanes = (uint32_t)((n + L - 1) / L);
+  p.L = choose_lane_length(n, p.W);
+  const uint32_t max_lanes = (uint32_t)((n + p.L - 1) / p.L);
   p.tmax = p.NB + max_lanes + 2;  // partial slots per window: slot = bucket + lane
   {
     int per = tune().msm_seg_buckets.load(std::memory_order_relaxed);  // buckets per reduction segment
@@ -692,7 +717,9 @@ int bucket_group(const void* points, const MsmParams& p, const SortOut& so, cons
   // buckets with > MERGE_CAP partials (heavily repeated scalars): block-wide tree, grid-stride over the queue
   hipLaunchKernelGGL(k_msm_merge_giant<Cfg>, dim3(bb.giant_blocks), dim3(256), 0, st, p, start, partial, dense, giant, giant + 2);
   bool pair_red = false;
-  if constexpr (Cfg::PAIR) pair_red = (tune().msm_variant.load(std::memory_order_relaxed) & 4) != 0;  // bit 2: two-lane reduction
+  // two-lane window reduction: the default on BLS12-381 G2, where the whole-point form needs 512 VGPRs + 131 spilled registers
+  // (3.5 against 3.0 ms at 2^20); tune "msm_variant" bit 2 flips the choice (A/B runs, tests)
+  if constexpr (Cfg::PAIR) pair_red = Cfg::PAIR_REDUCE != ((tune().msm_variant.load(std::memory_order_relaxed) & 4) != 0);
   if (tune().msm_variant.load(std::memory_order_relaxed) & 1) {
     hipLaunchKernelGGL(k_msm_reduce<Cfg>, dim3((p.S + TAIL_Q - 1) / TAIL_Q, nw), dim3(TAIL_BLK), 0, st, p, dense, segres);
   } else if (pair_red) {
