@@ -106,7 +106,7 @@ struct Tune {
   std::atomic<int> ntt_lazy{1};
   std::atomic<int> ntt_threads{1024};
   std::atomic<int> msm_variant{0};       // experimental kernel variants (A/B runs)
-  std::atomic<int> msm_seg_buckets{8};   // buckets per window-reduction segment
+  std::atomic<int> msm_seg_buckets{0};   // buckets per window-reduction segment (0 = as many segments as fit one round)
   std::atomic<int> allow_unmasked_rep3{0};  // Rep3 products without the re-randomising masks: refused unless set (tests)
   std::atomic<int> ntt_variant{0};
 };

@@ -4,6 +4,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+
 #include "common.hpp"
 #include "curve.hpp"
 #include "curve_lazy.hpp"
@@ -20,11 +22,11 @@ namespace csh {
 // re-encoded as canonical x*R' (same 32 bytes per coordinate), converted once at upload.
 // PAIR (the G2 groups): accumulate and window reduction can run with two lanes per point, one Fp2 component each (curve_pair.hpp)
 struct Bn254G1Cfg { using Fq = Bn254Fq;   using Fr = Bn254Fr; static constexpr bool LAZY = true;  using L = Fq29s; static constexpr bool INLINE_ADD = true; static constexpr bool PAIR = false; };
-struct Bn254G2Cfg { using Fq = Bn254Fq2;  using Fr = Bn254Fr; static constexpr bool LAZY = true;  using L = Fq29s2; static constexpr bool INLINE_ADD = true; static constexpr bool PAIR = true; using LP = Fp2Pair<Fq29s>; static constexpr bool PAIR_REDUCE = false; };
+struct Bn254G2Cfg { using Fq = Bn254Fq2;  using Fr = Bn254Fr; static constexpr bool LAZY = true;  using L = Fq29s2; static constexpr bool INLINE_ADD = true; static constexpr bool PAIR = true; using LP = Fp2Pair<Fq29s>; };
 struct Bls381G1Cfg { using Fq = Bls381Fq;  using Fr = Bls381Fr; static constexpr bool LAZY = true;  using L = Fq28s; static constexpr bool INLINE_ADD = true; static constexpr bool PAIR = false; };
 // Grumpkin: base field = BN254 Fr, scalars = BN254 Fq (the 2-cycle partner of BN254)
 struct GrumpkinG1Cfg { using Fq = Bn254Fr;   using Fr = Bn254Fq; static constexpr bool LAZY = true;  using L = Fr29s; static constexpr bool INLINE_ADD = true; static constexpr bool PAIR = false; };
-struct Bls381G2Cfg { using Fq = Bls381Fq2; using Fr = Bls381Fr; static constexpr bool LAZY = true;  using L = Fq28s2; static constexpr bool INLINE_ADD = true; static constexpr bool PAIR = true; using LP = Fp2Pair<Fq28s>; static constexpr bool PAIR_REDUCE = true; };
+struct Bls381G2Cfg { using Fq = Bls381Fq2; using Fr = Bls381Fr; static constexpr bool LAZY = true;  using L = Fq28s2; static constexpr bool INLINE_ADD = true; static constexpr bool PAIR = true; using LP = Fp2Pair<Fq28s>; };
 
 struct Bases {
   csh_curve_t curve;
@@ -42,7 +44,10 @@ struct Bases {
 // MsmParams, the digit-code constants and the sort stage live in msm_sort.hpp / msm_sort.hip
 
 constexpr int MSM_BLK = 256;
-constexpr int ACC_BLK = 128;
+#ifndef CSH_ACC_BLK
+#define CSH_ACC_BLK 128
+#endif
+constexpr int ACC_BLK = CSH_ACC_BLK;
 
 // canonical little-endian limbs of scalar i
 template <class Fr>
@@ -276,12 +281,12 @@ __global__ __launch_bounds__(256) void k_msm_merge_giant(MsmParams p, const uint
 // Segment k of window w folds dense buckets [t0, t1): returns sum_t t * B_t by the running-sum trick with explicit gaps
 // (empty buckets are skipped; a gap of more than 4 empty buckets is bridged by one small scalar multiple).
 template <class Cfg>
-__global__ __launch_bounds__(TAIL_BLK) void k_msm_reduce(MsmParams p, const LazyPt<Cfg>* __restrict__ dense,
-                                                         LazyPt<Cfg>* segres) {
+__global__ __launch_bounds__(256) void k_msm_reduce(MsmParams p, const LazyPt<Cfg>* __restrict__ dense,
+                                                    LazyPt<Cfg>* segres) {
   using L = typename Cfg::L;
   const int w = blockIdx.y;
   const int role = threadIdx.x & 3;
-  const uint32_t k = blockIdx.x * TAIL_Q + (threadIdx.x >> 2);
+  const uint32_t k = blockIdx.x * 64 + (threadIdx.x >> 2);
   if (k >= p.S) return;
   const uint32_t per = (p.NB + p.S - 1) / p.S;  // dense[w][b], b = 1..NB (index 0 unused)
   const uint32_t t0 = 1 + k * per;
@@ -314,15 +319,20 @@ __global__ __launch_bounds__(TAIL_BLK) void k_msm_reduce(MsmParams p, const Lazy
   qpt_store<L>(&segres[(size_t)w * p.S + k], role, acc);
 }
 
+// The lane-serial reductions run in workgroups of four waves: a workgroup's waves spread over the four SIMDs of one CU and the
+// <= 256 workgroups of a one-round launch over the CUs, so every SIMD gets exactly one wave (single-wave workgroups are packed
+// unevenly: 870 of them took 0.38 ms where 544 took 0.26 ms, profiles/r02_g_seg_stages.log).
+constexpr int RED_BLK = 256;
+
 // Lane-serial form of the same reduction (one lane per segment, whole points in registers): 1.75x less total work than the
-// quad form. With one wave per SIMD in flight (S x W / 64 waves ~ 1024 SIMDs) the stage is bound by work, not by the latency
-// of one addition, and this form wins (measured, BN254 G1 2^20: 263 us against 293 us); the quad form wins when few points
-// are left (merge of few partials per bucket, fold tree). tune "msm_variant" bit 0 selects the quad form for A/B runs.
+// quad form but a 2-3x longer dependent chain per point operation. Round 2 first measured both at the SAME segment count
+// (2048 segments: quad = 2176 waves = three rounds, 293 us against 263 us) and kept this one; sized to one round each
+// (reduce_segments) and launched in four-wave workgroups the quad form wins by 17-25 %. Kept for A/B runs (msm_variant).
 template <class Cfg>
-__global__ __launch_bounds__(64) void k_msm_reduce_serial(MsmParams p, const LazyPt<Cfg>* __restrict__ dense, LazyPt<Cfg>* segres) {
+__global__ __launch_bounds__(RED_BLK) void k_msm_reduce_serial(MsmParams p, const LazyPt<Cfg>* __restrict__ dense, LazyPt<Cfg>* segres) {
   using L = typename Cfg::L;
   const int w = blockIdx.y;
-  const uint32_t k = blockIdx.x * 64 + threadIdx.x;
+  const uint32_t k = blockIdx.x * RED_BLK + threadIdx.x;
   if (k >= p.S) return;
   const uint32_t per = (p.NB + p.S - 1) / p.S;
   const uint32_t t0 = 1 + k * per;
@@ -358,11 +368,11 @@ __global__ __launch_bounds__(64) void k_msm_reduce_serial(MsmParams p, const Laz
 // The lane-serial reduction with two lanes per segment (G2, curve_pair.hpp): half the registers per lane (no scratch) and half
 // the instructions on the dependent chain of every point operation.
 template <class Cfg>
-__global__ __launch_bounds__(64) void k_msm_reduce_pair(MsmParams p, const LazyPt<Cfg>* __restrict__ dense, LazyPt<Cfg>* segres) {
+__global__ __launch_bounds__(RED_BLK) void k_msm_reduce_pair(MsmParams p, const LazyPt<Cfg>* __restrict__ dense, LazyPt<Cfg>* segres) {
   using L = typename Cfg::LP;
   const int w = blockIdx.y;
   const int role = pair_role();
-  const uint32_t k = blockIdx.x * 32 + (threadIdx.x >> 1);
+  const uint32_t k = blockIdx.x * (RED_BLK / 2) + (threadIdx.x >> 1);
   if (k >= p.S) return;
   const uint32_t per = (p.NB + p.S - 1) / p.S;
   const uint32_t t0 = 1 + k * per;
@@ -487,6 +497,22 @@ inline uint32_t choose_lane_length(size_t n, int W) {
   return best_L;
 }
 
+// Window reduction: S segments of `per` consecutive buckets per window, `lanes_per_segment` lanes each (1, or 2 for the lane-pair
+// form), a dependent chain of 2 per + ~21 point operations. One wave saturates its SIMD, so the stage takes
+// ceil(W S lanes / 64 / SIMDs) rounds of that chain: as many segments as still fit ONE round (BN254 2^20: 17 windows x 3277
+// segments of 5 buckets = 870 waves, chain 31 instead of 37 with the former 2048 x 8; a finer 4096 x 4 would need two rounds).
+// tune "msm_seg_buckets" forces `per`.
+inline uint32_t reduce_segments(uint32_t NB, int W, int lanes_per_segment) {
+  int per = tune().msm_seg_buckets.load(std::memory_order_relaxed);
+  if (per < 1 || per > 64) {
+    const uint64_t s_max = (uint64_t)device_simds() * 64 / ((uint64_t)W * lanes_per_segment);
+    per = (int)((NB + s_max - 1) / s_max);
+    if (per < 2) per = 2;
+  }
+  const uint32_t S = (NB + per - 1) / per;
+  return S < 1 ? 1 : S;
+}
+
 struct PartialHeader {
   uint32_t magic, c, W, reserved;
   uint32_t pad[4];
@@ -503,12 +529,7 @@ inline MsmParams msm_plan(size_t n, int scalar_bits, int mont) {
   p.L = choose_lane_length(n, p.W);
   const uint32_t max_lanes = (uint32_t)((n + p.L - 1) / p.L);
   p.tmax = p.NB + max_lanes + 2;  // partial slots per window: slot = bucket + lane
-  {
-    int per = tune().msm_seg_buckets.load(std::memory_order_relaxed);  // buckets per reduction segment
-    if (per != 2 && per != 4 && per != 8 && per != 16) per = 8;
-    p.S = 64;
-    while (p.S < 16384 && (uint64_t)p.S * per < p.NB) p.S <<= 1;
-  }
+  p.S = reduce_segments(p.NB, p.W, 1);
   p.mont = mont;
   uint64_t ch = 512 / (uint64_t)p.W;
   const uint64_t by_size = n / (2ull * p.NB);
@@ -716,20 +737,30 @@ int bucket_group(const void* points, const MsmParams& p, const SortOut& so, cons
   hipLaunchKernelGGL(k_msm_merge<Cfg>, dim3((p.NB + TAIL_Q - 1) / TAIL_Q, nw), dim3(TAIL_BLK), 0, st, p, start, partial, dense, giant, giant + 2);
   // buckets with > MERGE_CAP partials (heavily repeated scalars): block-wide tree, grid-stride over the queue
   hipLaunchKernelGGL(k_msm_merge_giant<Cfg>, dim3(bb.giant_blocks), dim3(256), 0, st, p, start, partial, dense, giant, giant + 2);
-  bool pair_red = false;
-  // two-lane window reduction: the default on BLS12-381 G2, where the whole-point form needs 512 VGPRs + 131 spilled registers
-  // (3.5 against 3.0 ms at 2^20); tune "msm_variant" bit 2 flips the choice (A/B runs, tests)
-  if constexpr (Cfg::PAIR) pair_red = Cfg::PAIR_REDUCE != ((tune().msm_variant.load(std::memory_order_relaxed) & 4) != 0);
-  if (tune().msm_variant.load(std::memory_order_relaxed) & 1) {
-    hipLaunchKernelGGL(k_msm_reduce<Cfg>, dim3((p.S + TAIL_Q - 1) / TAIL_Q, nw), dim3(TAIL_BLK), 0, st, p, dense, segres);
-  } else if (pair_red) {
-    if constexpr (Cfg::PAIR) hipLaunchKernelGGL(k_msm_reduce_pair<Cfg>, dim3((p.S + 31) / 32, nw), dim3(64), 0, st, p, dense, segres);
+  // Window reduction, three forms of the same segment walk, each with as many segments as fit one round of its waves
+  // (reduce_segments): four lanes per point (curve_quad.hpp; the default on the G1 groups: BN254 G1 2^20 tail 0.41 -> 0.33 ms,
+  // BLS12-381 G1 0.96 -> 0.80 ms against the lane-serial form at equal launch width, profiles/r02_g_seg_stages3.log), two lanes
+  // per Fp2 point (curve_pair.hpp; the default on the G2 groups: half the registers per lane -- no spills where the whole-point
+  // form needs 437-512 VGPRs + scratch -- and half the dependent chain per point operation; BN254 G2 2^20 tail 1.05 -> 0.81 ms,
+  // BLS12-381 G2 3.2 -> 2.1 ms, profiles/r02_g_seg_stages2.log), or one lane per segment. tune "msm_variant" picks another
+  // form for A/B runs and tests: G1: bit 0 -> lane-serial; G2: bit 0 -> four lanes, bit 2 -> lane-serial.
+  const int variant = tune().msm_variant.load(std::memory_order_relaxed);
+  int form;  // 0 lane-serial, 1 quad, 2 pair
+  if constexpr (Cfg::PAIR) form = (variant & 1) ? 1 : ((variant & 4) ? 0 : 2);
+  else form = (variant & 1) ? 0 : 1;
+  MsmParams pr = p;  // the reduction's own segmentation (never more segments than the plan sized the buffers for)
+  if (form == 1) {
+    pr.S = std::min(p.S, reduce_segments(p.NB, p.W, 4));
+    hipLaunchKernelGGL(k_msm_reduce<Cfg>, dim3((pr.S + 63) / 64, nw), dim3(256), 0, st, pr, dense, segres);
+  } else if (form == 2) {
+    pr.S = std::min(p.S, reduce_segments(p.NB, p.W, 2));
+    if constexpr (Cfg::PAIR) hipLaunchKernelGGL(k_msm_reduce_pair<Cfg>, dim3((pr.S + RED_BLK / 2 - 1) / (RED_BLK / 2), nw), dim3(RED_BLK), 0, st, pr, dense, segres);
   } else {
-    hipLaunchKernelGGL(k_msm_reduce_serial<Cfg>, dim3((p.S + 63) / 64, nw), dim3(64), 0, st, p, dense, segres);
+    hipLaunchKernelGGL(k_msm_reduce_serial<Cfg>, dim3((pr.S + RED_BLK - 1) / RED_BLK, nw), dim3(RED_BLK), 0, st, pr, dense, segres);
   }
   // fold tree: S segment sums per window -> one, 128 per block and launch
   const LazyPt<Cfg>* cur = segres;
-  uint32_t cur_n = p.S, cur_stride = p.S;
+  uint32_t cur_n = pr.S, cur_stride = pr.S;
   LazyPt<Cfg>* nxt = fold_a;
   while (cur_n > 1) {
     const uint32_t out_n = (cur_n + 127) / 128;

@@ -86,13 +86,17 @@ def test_msm_window_sizes(gpu):
         assert G.eq(_run(gpu, "bn254", 0, pts, sk), G.msm(pts, sk))
 
 
-@pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
-@pytest.mark.parametrize("variant", [2, 4, 6])
-def test_msm_g2_lane_pair_variants(gpu, curve, variant):
-    """The two-lanes-per-point G2 kernels (csrc/curve_pair.hpp; msm_variant bit 1 = accumulate, bit 2 = window reduction): same
-    group element as the oracle on random points with duplicates, P / -P, points at infinity and the edge scalars, at several
-    window widths (the doubling and cancellation paths run through the DPP exchange too)."""
-    G = cv.CURVES[curve][1]
+@pytest.mark.parametrize("curve,group", [("bn254", 1), ("bls12_381", 1), ("bn254", 0), ("bls12_381", 0)])
+@pytest.mark.parametrize("variant", [1, 2, 4, 6])
+def test_msm_kernel_form_variants(gpu, curve, group, variant):
+    """Every form of the bucket kernels that is not the default of its group (tune "msm_variant"): G2: bit 1 = two lanes per point in
+    the accumulate kernel (csrc/curve_pair.hpp), bit 0 / bit 2 = four-lane / lane-serial window reduction instead of the two-lane
+    one; G1: bit 0 = lane-serial window reduction instead of the four-lane one. Same group element as the oracle on random points
+    with duplicates, P / -P, points at infinity and the edge scalars, at several window widths (the doubling and cancellation
+    paths run through the DPP exchanges too)."""
+    if group == 0 and variant != 1:
+        pytest.skip("bits 1 and 2 only select G2 kernels")
+    G = cv.CURVES[curve][group]
     F = H.FR[curve]
     r = H.rng(700 + variant)
     n = 300
@@ -105,7 +109,7 @@ def test_msm_g2_lane_pair_variants(gpu, curve, variant):
         want = G.msm(pts, sc)
         for c in (0, 4, 11):
             with gpu.tuned(msm_variant=variant, msm_c=c):
-                assert G.eq(_run(gpu, curve, 1, pts, sc), want), (name, c)
+                assert G.eq(_run(gpu, curve, group, pts, sc), want), (name, c)
 
 
 def test_msm_arkworks_affine_stride(gpu):
