@@ -13,10 +13,16 @@ static thread_local int tl_device = -1;
 // A "lane" = one HIP stream plus the scratch arenas used on it. Lanes are pooled per device and leased to host
 // threads: short-lived callers (the reference spawns rayon tasks / scoped threads per proof) reuse warm streams and
 // already-grown arenas instead of paying hipStreamCreate + hipMalloc on every call.
+struct PinnedSlot {
+  void* host = nullptr;  // hipHostMalloc: page-locked, mapped into the device's address space
+  void* dev = nullptr;   // the device-side alias of `host`
+  size_t cap = 0;
+};
 struct Lane {
   int device = 0;
   hipStream_t stream = nullptr;
   std::map<hipStream_t, Arena> arenas;
+  std::map<hipStream_t, PinnedSlot> pinned;
 };
 static std::mutex g_lane_mu;
 static std::map<int, std::vector<Lane*>> g_free_lanes;
@@ -135,6 +141,30 @@ int Arena::reserve(size_t bytes) {
 Arena& arena_for(hipStream_t s) { return tl_lanes.get(tl_device)->arenas[s]; }
 
 // a second pooled stream for the calling thread (overlapping two stages of one call); nullptr if none could be created
+// Small page-locked result buffer bound to (calling thread's lane, stream): kernels write a call's few hundred bytes of results
+// straight into host memory, so the synchronous entry points end with a stream synchronisation instead of a staged copy.
+bool pinned_for(hipStream_t s, size_t bytes, void** host, void** dev) {
+  PinnedSlot& slot = tl_lanes.get(tl_device)->pinned[s];
+  if (!slot.host || slot.cap < bytes) {
+    if (slot.host) (void)hipHostFree(slot.host);
+    slot = PinnedSlot{};
+    const size_t cap = bytes < 16384 ? 16384 : bytes;
+    void* h = nullptr;
+    void* d = nullptr;
+    if (hipHostMalloc(&h, cap, hipHostMallocDefault) != hipSuccess) return false;
+    if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+      (void)hipHostFree(h);
+      return false;
+    }
+    slot.host = h;
+    slot.dev = d;
+    slot.cap = cap;
+  }
+  *host = slot.host;
+  *dev = slot.dev;
+  return true;
+}
+
 hipStream_t resolve_aux_stream() { return tl_lanes.get(tl_device + LaneHolder::AUX_KEY)->stream; }
 
 }  // namespace csh
@@ -165,6 +195,9 @@ int csh_shutdown(void) {
     for (auto& kv : l->arenas)
       if (kv.second.base) (void)hipFree(kv.second.base);
     l->arenas.clear();
+    for (auto& kv : l->pinned)
+      if (kv.second.host) (void)hipHostFree(kv.second.host);
+    l->pinned.clear();
   };
   for (auto& kv : tl_lanes.by_device) drop(kv.second);
   std::lock_guard<std::mutex> g(g_lane_mu);

@@ -60,6 +60,7 @@ struct Arena {
 };
 Arena& arena_for(hipStream_t s);
 hipStream_t resolve_aux_stream();  // second pooled stream of the calling thread (may be nullptr)
+bool pinned_for(hipStream_t s, size_t bytes, void** host, void** dev);  // page-locked result buffer of (thread lane, stream)
 
 // Host-pointer convenience path: stage inputs into a per-thread arena, run on the thread's stream, copy back.
 struct HostStage {

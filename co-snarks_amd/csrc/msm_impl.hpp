@@ -105,11 +105,12 @@ using LazyPt = XYZZLazy<typename Cfg::L>;
 template <class Cfg>
 __global__ __launch_bounds__(ACC_BLK) void k_msm_accum(const Affine<typename Cfg::Fq>* __restrict__ bases, MsmParams p,
                                                        const uint32_t* __restrict__ start, const uint32_t* __restrict__ nlanes,
-                                                       const uint32_t* __restrict__ sorted, LazyPt<Cfg>* partial) {
+                                                       const uint32_t* __restrict__ sorted, LazyPt<Cfg>* partial, uint32_t* giant_count) {
   using Fq = typename Cfg::Fq;
   static_assert(Cfg::LAZY, "the bucket pipeline runs in the signed lazy field");
   const int w = blockIdx.y;
   const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k == 0 && w == 0) *giant_count = 0;  // the merge kernel's queue of oversized buckets (stream-ordered after this kernel)
   if (k >= nlanes[w]) return;
   const uint32_t* st = start + (size_t)w * (p.NB + 2);
   const uint32_t total = st[p.NB + 1];
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(ACC_BLK) void k_msm_accum(const Affine<typename Cfg
 template <class Cfg>
 __global__ __launch_bounds__(ACC_BLK) void k_msm_accum_pair(const Affine<typename Cfg::Fq>* __restrict__ bases, MsmParams p,
                                                             const uint32_t* __restrict__ start, const uint32_t* __restrict__ nlanes,
-                                                            const uint32_t* __restrict__ sorted, LazyPt<Cfg>* partial) {
+                                                            const uint32_t* __restrict__ sorted, LazyPt<Cfg>* partial, uint32_t* giant_count) {
   using Fq = typename Cfg::Fq;
   using L = typename Cfg::LP;
   using LF = typename L::Base;
@@ -166,6 +167,7 @@ __global__ __launch_bounds__(ACC_BLK) void k_msm_accum_pair(const Affine<typenam
   const int w = blockIdx.y;
   const int role = pair_role();
   const uint32_t k = (blockIdx.x * blockDim.x + threadIdx.x) >> 1;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && w == 0) *giant_count = 0;
   if (k >= nlanes[w]) return;
   const uint32_t* st = start + (size_t)w * (p.NB + 2);
   const uint32_t total = st[p.NB + 1];
@@ -640,7 +642,6 @@ int msm_sort_prepare(const MsmParams& p, const MsmParams& pdig, const uint64_t* 
   const bool two_level = msm_sort_two_level(p);
   uint64_t* inter = two_level ? ar.take<uint64_t>(n * p.W) : nullptr;
   uint32_t* part_cnt = two_level ? ar.take<uint32_t>((size_t)(p.NB / 256) * p.CH * p.W) : nullptr;
-  CSH_HIP(hipMemsetAsync(hist, 0, sizeof(uint32_t) * len * p.W, st));
   const int g1 = grid_for(pdig.n, MSM_BLK, 65536);
   hipLaunchKernelGGL(k_msm_digits<Fr>, dim3(g1), dim3(MSM_BLK), 0, st, reinterpret_cast<const Fr*>(scalars_dev), pdig, dig);  // dig[w * n + i]
   out->sb = SortBuffers{hist, start, nlanes, sorted, dig, blkcnt, inter, part_cnt};
@@ -724,16 +725,15 @@ int bucket_group(const void* points, const MsmParams& p, const SortOut& so, cons
     if constexpr (Cfg::PAIR) {
       if (pair) {
         const dim3 ag((2 * bb.max_lanes + blk - 1) / blk, nw), ab(blk);
-        hipLaunchKernelGGL(k_msm_accum_pair<Cfg>, ag, ab, 0, st, bases, p, start, nlanes, sorted, partial);
+        hipLaunchKernelGGL(k_msm_accum_pair<Cfg>, ag, ab, 0, st, bases, p, start, nlanes, sorted, partial, giant);
       }
     }
     if (!pair) {
       const dim3 ag((bb.max_lanes + blk - 1) / blk, nw), ab(blk);
-      hipLaunchKernelGGL(k_msm_accum<Cfg>, ag, ab, 0, st, bases, p, start, nlanes, sorted, partial);
+      hipLaunchKernelGGL(k_msm_accum<Cfg>, ag, ab, 0, st, bases, p, start, nlanes, sorted, partial, giant);
     }
   }
   if (ev) CSH_HIP(hipEventRecord(ev[4], st));
-  CSH_HIP(hipMemsetAsync(giant, 0, 8, st));
   hipLaunchKernelGGL(k_msm_merge<Cfg>, dim3((p.NB + TAIL_Q - 1) / TAIL_Q, nw), dim3(TAIL_BLK), 0, st, p, start, partial, dense, giant, giant + 2);
   // buckets with > MERGE_CAP partials (heavily repeated scalars): block-wide tree, grid-stride over the queue
   hipLaunchKernelGGL(k_msm_merge_giant<Cfg>, dim3(bb.giant_blocks), dim3(256), 0, st, p, start, partial, dense, giant, giant + 2);
@@ -932,10 +932,21 @@ int msm_t(const Bases* B, size_t offset, size_t n, const uint64_t* scalars_dev, 
   XYZZ<Fq>* win_dev = wa.take<XYZZ<Fq>>(MAX_WINDOWS);
   MsmParams p;
   CSH_TRY((msm_windows_dev<Cfg>(B, offset, n, scalars_dev, mont, st, win_dev, &p)));
-  std::vector<XYZZ<Fq>> wins(p.W);
-  CSH_HIP(hipMemcpyAsync(wins.data(), win_dev, sizeof(XYZZ<Fq>) * p.W, hipMemcpyDeviceToHost, st));
+  // the W window sums come back through a page-locked buffer of the calling thread's lane (a DMA copy straight into it; a
+  // pageable destination is staged: 26 us per call. Letting the export kernel write host memory itself was measured and is far
+  // worse: its dword stores cross PCIe one by one, +0.1 ms on G1, +0.8 ms on G2)
+  void *pin_host = nullptr, *pin_dev = nullptr;
+  std::vector<XYZZ<Fq>> pageable;
+  XYZZ<Fq>* wins = nullptr;
+  if (pinned_for(st, sizeof(XYZZ<Fq>) * MAX_WINDOWS, &pin_host, &pin_dev)) {
+    wins = reinterpret_cast<XYZZ<Fq>*>(pin_host);
+  } else {
+    pageable.resize(p.W);
+    wins = pageable.data();
+  }
+  CSH_HIP(hipMemcpyAsync(wins, win_dev, sizeof(XYZZ<Fq>) * p.W, hipMemcpyDeviceToHost, st));
   CSH_HIP(hipStreamSynchronize(st));
-  fold_windows_host<Fq>(wins.data(), p.W, p.c, out_host);
+  fold_windows_host<Fq>(wins, p.W, p.c, out_host);
   return CSH_OK;
 }
 

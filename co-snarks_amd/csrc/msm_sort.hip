@@ -94,6 +94,10 @@ __global__ __launch_bounds__(256) void k_msm_colscan(MsmParams p, uint32_t* __re
     acc += t;
   }
   hist[(size_t)w * (p.NB + 2) + b + 1] = acc;
+  if (b == 0) {  // the two border entries the scan reads as zero (no memset of the histogram per call)
+    hist[(size_t)w * (p.NB + 2)] = 0;
+    hist[(size_t)w * (p.NB + 2) + p.NB + 1] = 0;
+  }
 }
 
 // One 1024-thread block per window. In: hist[w][0..NB+1] counts (index 0 and NB+1 unused = 0).
@@ -189,7 +193,8 @@ constexpr uint32_t PART_BUCKETS = 256;
 constexpr int SORT_UNROLL = 4;
 
 // in place: part_cnt[w][ch][p] -> first intermediate slot of (chunk ch, partition p) = start of the partition's first
-// bucket + entries of earlier chunks
+// bucket + entries of earlier chunks. (Folding this into k_msm_scan, 64 threads per window walking the chunks, was measured:
+// 24 us against 7 + 10 us as two launches.)
 __global__ __launch_bounds__(256) void k_msm_part_offsets(MsmParams p, const uint32_t* __restrict__ start, uint32_t* part_cnt) {
   const uint32_t P = p.NB / PART_BUCKETS;
   const uint32_t part = blockIdx.x * 256 + threadIdx.x, w = blockIdx.y;
