@@ -313,14 +313,23 @@ int csh_msm_multi_dev(const csh_bases_t* bases, const size_t* offsets, size_t k,
       CSH_TRY(ops[i].bucket(B->table, &p, &so, st, &ar, win_dev[i], nullptr));
     }
   }
-  std::vector<std::vector<char>> wins(k);
-  for (size_t i = 0; i < k; ++i) {
-    wins[i].resize(ops[i].xyzz_bytes * p.W);
-    CSH_HIP(hipMemcpyAsync(wins[i].data(), win_dev[i], wins[i].size(), hipMemcpyDeviceToHost, stage_stream[i]));
+  // window sums of all k results through one page-locked buffer of the lane (DMA copies, no staging), pageable fallback
+  size_t slice = 0;
+  for (size_t i = 0; i < k; ++i) slice = std::max(slice, Arena::padded(ops[i].xyzz_bytes * MAX_WINDOWS));
+  void *pin_host = nullptr, *pin_dev = nullptr;
+  std::vector<char> pageable;
+  char* wins = nullptr;
+  if (pinned_for((hipStream_t)((uintptr_t)st ^ 0x4), slice * k, &pin_host, &pin_dev)) {
+    wins = static_cast<char*>(pin_host);
+  } else {
+    pageable.resize(slice * k);
+    wins = pageable.data();
   }
+  for (size_t i = 0; i < k; ++i)
+    CSH_HIP(hipMemcpyAsync(wins + slice * i, win_dev[i], ops[i].xyzz_bytes * p.W, hipMemcpyDeviceToHost, stage_stream[i]));
   CSH_HIP(hipStreamSynchronize(st));
   if (aux) CSH_HIP(hipStreamSynchronize(aux));
-  for (size_t i = 0; i < k; ++i) ops[i].fold(wins[i].data(), p.W, p.c, outs_host[i]);
+  for (size_t i = 0; i < k; ++i) ops[i].fold(wins + slice * i, p.W, p.c, outs_host[i]);
   return CSH_OK;
 }
 

@@ -459,6 +459,9 @@ inline int choose_c(size_t n, int bits) {
   int best_c = 4;
   for (int c = 3; c <= 16; ++c) {  // digit codes are 15 bits + sign
     const double nb = double(size_t(1) << (c - 1));
+    // per window: n mixed additions + the bucket stages, ~5 additions' worth per bucket (merge, running sums, segment multiple).
+    // Re-checked after the one-round window reduction (profiles/r02_g_csweep.log, r02_g_c1516.log): at 2^20 c = 15 and 16 tie
+    // within 1-2 % (G1: 15 ahead, G2: 16 ahead), 2^17-2^19: 13 / 13 / 13-15, >= 2^21: 16.
     const double cost = windows_for(bits, c) * (double(n) + 5.0 * nb);
     if (cost < best) {
       best = cost;
