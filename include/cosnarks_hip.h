@@ -67,9 +67,12 @@ const char* csh_version(void);
 int csh_device_count(int* count);
 /* Process-wide tuning knobs for A/B runs and tests (initial values come from the environment once, at load: CSH_MSM_C ...;
  * no entry point reads the environment afterwards). Keys: "msm_c" (forced window width, 0 = cost model), "msm_l" (entries per
- * accumulate lane), "msm_timing" (record csh_msm_last_timing), "msm_no_table", "msm_multi_overlap", "acc_blk",
- * "sort_two_level" (-1 auto), "vec_max_blocks", "ntt_lazy", "ntt_threads", "msm_variant", "ntt_variant", "msm_seg_buckets",
- * "allow_unmasked_rep3" (see csh_rep3_local_mul_vec). */
+ * accumulate lane, 0 = round-count cost model), "msm_seg_buckets" (buckets per window-reduction segment, 0 = as many segments
+ * as fit one round of waves), "msm_timing" (record csh_msm_last_timing), "msm_no_table", "msm_multi_overlap", "acc_blk",
+ * "sort_two_level" (-1 auto), "vec_max_blocks", "ntt_lazy", "ntt_threads", "ntt_variant", "allow_unmasked_rep3" (see
+ * csh_rep3_local_mul_vec), "msm_variant" (bit mask of non-default kernel forms, same results: bit 0 = window reduction
+ * lane-serial on G1 / four-lane on G2, bit 1 = two lanes per point in the G2 accumulate kernel, bit 2 = lane-serial window
+ * reduction on G2, bit 3 = 8-byte sort records at every size). */
 int csh_tune_set(const char* key, int value);
 int csh_tune_get(const char* key, int* value);
 
