@@ -411,8 +411,9 @@ __global__ __launch_bounds__(RED_BLK) void k_msm_reduce_pair(MsmParams p, const 
 // 64 quads, two loads per quad, then the LDS tree. Two launches take 2048 segment sums to one window sum.
 template <class Cfg>
 __global__ __launch_bounds__(256) void k_msm_fold_tree(const LazyPt<Cfg>* __restrict__ in, uint32_t stride_in, uint32_t count,
-                                                       LazyPt<Cfg>* out, uint32_t stride_out) {
+                                                       LazyPt<Cfg>* out, uint32_t stride_out, XYZZ<typename Cfg::Fq>* win_out) {
   using L = typename Cfg::L;
+  using Fq = typename Cfg::Fq;
   __shared__ XYZZLazy<L> sh[32];
   const int w = blockIdx.y;
   const int role = threadIdx.x & 3, q = threadIdx.x >> 2;
@@ -421,7 +422,14 @@ __global__ __launch_bounds__(256) void k_msm_fold_tree(const LazyPt<Cfg>* __rest
   QPt<L> x = i0 < count ? qpt_load<L>(&a[i0], role) : qpt_inf<L>();
   if (i1 < count) qadd<L>(x, qpt_load<L>(&a[i1], role), role);
   quad_block_tree<L>(x, sh, q, 64, role);
-  if (q == 0) qpt_store<L>(&out[(size_t)w * stride_out + blockIdx.x], role, x);
+  if (q == 0) {
+    if (win_out) {  // last level: the window sum leaves in the arkworks encoding (lane r converts member r; no export launch)
+      static_assert(sizeof(XYZZ<Fq>) == 4 * sizeof(Fq), "XYZZ members must be contiguous");
+      (&win_out[w].x)[role] = x.empty ? Fq::zero() : x.v.to_fp();
+    } else {
+      qpt_store<L>(&out[(size_t)w * stride_out + blockIdx.x], role, x);
+    }
+  }
 }
 
 // In-place re-encoding of uploaded bases for LAZY curves: x*2^(32N) -> canonical x*R' (infinity stays 0,0)
@@ -765,16 +773,20 @@ int bucket_group(const void* points, const MsmParams& p, const SortOut& so, cons
   const LazyPt<Cfg>* cur = segres;
   uint32_t cur_n = pr.S, cur_stride = pr.S;
   LazyPt<Cfg>* nxt = fold_a;
+  XYZZ<Fq>* win_out = reinterpret_cast<XYZZ<Fq>*>(win_out_dev) + w0;
+  bool exported = false;
   while (cur_n > 1) {
     const uint32_t out_n = (cur_n + 127) / 128;
-    hipLaunchKernelGGL(k_msm_fold_tree<Cfg>, dim3(out_n, nw), dim3(256), 0, st, cur, cur_stride, cur_n, nxt, bb.fold_n1);
+    exported = out_n == 1;  // the last level writes the window sums in the arkworks encoding itself
+    hipLaunchKernelGGL(k_msm_fold_tree<Cfg>, dim3(out_n, nw), dim3(256), 0, st, cur, cur_stride, cur_n, nxt, bb.fold_n1,
+                       exported ? win_out : (XYZZ<Fq>*)nullptr);
     cur = nxt;
     cur_n = out_n;
     cur_stride = bb.fold_n1;
     nxt = nxt == fold_a ? fold_b : fold_a;
   }
-  hipLaunchKernelGGL(k_msm_gather_windows<Cfg>, dim3(1), dim3(MAX_WINDOWS), 0, st, cur, cur_stride, nw,
-                     reinterpret_cast<XYZZ<Fq>*>(win_out_dev) + w0);
+  if (!exported)  // a single segment per window: nothing to fold
+    hipLaunchKernelGGL(k_msm_gather_windows<Cfg>, dim3(1), dim3(MAX_WINDOWS), 0, st, cur, cur_stride, nw, win_out);
   CSH_HIP(hipGetLastError());
   return CSH_OK;
 }

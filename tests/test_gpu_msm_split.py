@@ -143,6 +143,41 @@ def test_rccl_rank_path_with_one_rank(gpu, curve, group):
     dsc.free()
 
 
+def test_comm_created_on_a_helper_thread(gpu):
+    """bench.py builds the RCCL communicator on a daemon thread (so that a wedged fabric bootstrap cannot hang the rank) and
+    uses it from the main thread: the communicator and its buffers must not depend on the creating thread's stream lane."""
+    import threading
+    G = cv.BN254_G1
+    F = H.FR["bn254"]
+    r = H.rng(321)
+    n = 400
+    pts = H.rand_points(G, n, r, with_inf=True)
+    sc = H.rand_elems(F, n, r)
+    want = G.msm(pts, sc)
+    bases = gpu.Bases(0, 0, cv.pack_points(G, pts))
+    dsc = gpu.DeviceBuffer.from_host(H.pack(F, sc))
+    uid = gpu.bindings.comm_unique_id()
+    box = {}
+
+    def make():
+        try:
+            gpu.bindings._check(gpu.lib().csh_init(0))
+            box["comm"] = gpu.Comm.init_rank(uid, 1, 0)
+        except Exception as e:  # noqa: BLE001
+            box["err"] = repr(e)
+
+    th = threading.Thread(target=make, daemon=True)
+    th.start()
+    th.join(timeout=120)
+    assert not th.is_alive() and "err" not in box, box
+    comm = box["comm"]
+    for _ in range(3):
+        assert G.eq(H.jac_to_affine(G, comm.msm_split_rank_dev(bases, dsc, n)), want)
+    comm.destroy()
+    bases.free()
+    dsc.free()
+
+
 def _gen_bases_handle(gpu, cid, group, seed, n):
     buf = gpu.DeviceBuffer(n * gpu.point_bytes(cid, group))
     gpu.bindings._check(gpu.lib().csh_util_generate_bases_dev(cid, group, C.c_uint64(seed), C.c_size_t(n), buf.ptr, None))
