@@ -75,7 +75,12 @@ struct Fp2Pair {
       LF::mac_wide(w, hi_signed(c.v), quad_perm<PairSwap::value>(d.v), true);
       return {LF::reduce(w)};
     } else {
-      return sub(mul(a, b), mul(c, d)).normalized();
+      typename LF::Wide w = mul_wide(a, b);  // two products, then a carry sweep so that the next two fit the same columns
+      LF::compress_wide(w);
+      typename LF::Wide v = LF::mul_wide(LF::neg(quad_perm<PairLo::value>(c.v)), d.v);
+      LF::mac_wide(v, hi_signed(c.v), quad_perm<PairSwap::value>(d.v), true);
+      LF::add_wide(w, v);
+      return {LF::reduce(w)};
     }
   }
   __device__ __forceinline__ bool maybe_zero() const { return pair_all(v.maybe_zero()); }

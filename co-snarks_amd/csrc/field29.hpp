@@ -338,6 +338,20 @@ struct FpS {
       for (int j = 0; j < NL; ++j) w.t[i + j] = (int64_t)aa.l[i] * (int64_t)b.l[j] + w.t[i + j];
     }
   }
+  // One signed carry sweep over a double-width value: columns 0..2NL-2 come back into [0, 2^B), the top column takes the rest.
+  // Lets a second pair of NL-term product sums share the accumulator where four would overflow a 63-bit column (9 x 29 bits):
+  // ~4 simple instructions per column instead of a whole extra Montgomery reduction (NL^2 mads + carries).
+  CSH_HD static void compress_wide(Wide& w) {
+#pragma unroll
+    for (int k = 0; k < 2 * NL - 1; ++k) {
+      w.t[k + 1] += w.t[k] >> B;
+      w.t[k] = (int64_t)((uint64_t)w.t[k] & (uint64_t)LP::MASK);
+    }
+  }
+  CSH_HD static void add_wide(Wide& a, const Wide& b) {
+#pragma unroll
+    for (int k = 0; k < 2 * NL; ++k) a.t[k] += b.t[k];
+  }
   // can four NL-term product sums (+ the reduction's NL terms) share one 63-bit column?
   static constexpr bool FOUR_PRODUCTS_FIT = (5.0 * NL) * (double)(1ull << (2 * B - 40)) < (double)(1ull << 23);
 
@@ -574,7 +588,17 @@ struct Fp2S {
       LF::mac_wide(w1, c.c1, d.c0, true);
       return {LF::reduce(w0), LF::reduce(w1)};
     } else {
-      return sub(mul(a, b), mul(c, d)).normalized();
+      // two products per accumulator, a carry sweep between the pairs, ONE reduction per component (instead of two full Fp2
+      // products = four reductions, a limb-wise subtraction and a carry step)
+      typename LF::Wide w0 = LF::mul_sub_wide(a.c0, b.c0, a.c1, b.c1);   //   a0 b0 - a1 b1
+      LF::compress_wide(w0);
+      LF::add_wide(w0, LF::mul_sub_wide(c.c1, d.c1, c.c0, d.c0));        // + c1 d1 - c0 d0
+      typename LF::Wide w1 = LF::mul_add_wide(a.c0, b.c1, a.c1, b.c0);   //   a0 b1 + a1 b0
+      LF::compress_wide(w1);
+      typename LF::Wide v1 = LF::mul_wide(LF::neg(c.c0), d.c1);          // - c0 d1 - c1 d0
+      LF::mac_wide(v1, c.c1, d.c0, true);
+      LF::add_wide(w1, v1);
+      return {LF::reduce(w0), LF::reduce(w1)};
     }
   }
   CSH_HD bool maybe_zero() const { return c0.maybe_zero() && c1.maybe_zero(); }
