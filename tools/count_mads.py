@@ -6,7 +6,8 @@ Derived from the formulas in csrc/curve_lazy.hpp::lazy_madd and csrc/field29.hpp
 NL(NL+1)/2, a Montgomery reduction NL^2): EFD madd-2008-s = u2, s2, ppp, q, zz', zzz' (6 products), pp, r^2 (2 squares), y3 =
 r (q - x3) - y1 ppp (two products fused under ONE reduction) -> 9 reductions. Over Fp2 a product is 4 base products + 2
 reductions, a square is (a0^2 - a1^2: 2 squares) + (2 a0 a1: 1 product) + 2 reductions, and the fused y3 is 8 products + 2
-reductions where four 2NL-term sums fit a 63-bit column (BLS12-381: 14 x 28 bits) and two full Fp2 products otherwise (BN254).
+reductions: four 2NL-term sums fit a 63-bit column on BLS12-381 (14 x 28 bits); on BN254 (9 x 29 bits) the accumulator takes a
+carry sweep (FpS::compress_wide, no mads) between the first and the second pair of products.
 x3 = r^2 - ppp - 2q takes its subtrahend into the reduction of r^2 (FpS::reduce_sub): NL more mads per base-field reduction.
 With --isa FILE.s (hipcc -S --offload-device-only of csrc/msm_inst_<group>.hip) the static count of v_mad_i64_i32 in the kernel
 body is printed next to it (it additionally contains the exact zero test behind the low-limb filter: 2 NL^2 per inlined copy)."""
@@ -27,7 +28,7 @@ def fp2_madd(nl, four_fit):
     prod, sq, red = nl * nl, nl * (nl + 1) // 2, nl * nl
     mul2 = 4 * prod + 2 * red
     sqr2 = 2 * sq + prod + 2 * red
-    y3 = (8 * prod + 2 * red) if four_fit else 2 * mul2
+    y3 = 8 * prod + 2 * red                      # four_fit: one column holds all four sums; otherwise a carry sweep between the pairs
     return 6 * mul2 + 2 * sqr2 + y3 + 2 * nl    # + x3's subtrahend entering both components' reductions (reduce_sub)
 
 
