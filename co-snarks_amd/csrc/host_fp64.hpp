@@ -125,6 +125,8 @@ struct Fp64 {
   static Fp64 sqr(const Fp64& a) { return mul(a, a); }
   static Fp64 mul2(const Fp64& a) { return add(a, a); }
   static Fp64 mul3(const Fp64& a) { return add(add(a, a), a); }
+  static Fp64 mul4(const Fp64& a) { return mul2(mul2(a)); }
+  static Fp64 mul8(const Fp64& a) { return mul2(mul4(a)); }
   static Fp64 inv(const Fp64& a) {  // a^(p-2)
     Fp64 r = one();
     for (int i = P::N * 32 - 1; i >= 0; --i) {

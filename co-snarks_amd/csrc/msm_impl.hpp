@@ -997,12 +997,36 @@ int msm_partial_t(const Bases* B, size_t offset, size_t n, const uint64_t* scala
   return CSH_OK;
 }
 
+// c doublings of an XYZZ point on the host, run in Jacobian coordinates: dbl-2009-l for a = 0 costs 2M + 5S against 6M + 3S for
+// the XYZZ doubling, and the round trip is 4 + 2 multiplications: (X, Y, ZZ, ZZZ) = (X ZZ^2 : Y ZZ^3 : ZZZ) because ZZZ^2 = ZZ^3,
+// back with (X : Y : Z) = (X, Y, Z^2, Z^3). ~16 % fewer field multiplications over the c (W - 1) sequential doublings of the fold.
+template <class F>
+XYZZ<F> xyzz_dbl_many_host(const XYZZ<F>& p, int c) {
+  if (p.is_inf() || c <= 0) return p;
+  const F zz2 = F::sqr(p.zz);
+  F X = F::mul(p.x, zz2), Y = F::mul(p.y, F::mul(zz2, p.zz)), Z = p.zzz;
+  for (int k = 0; k < c; ++k) {
+    if (Y.is_zero()) return XYZZ<F>::inf();  // 2-torsion: not on these prime-order groups, kept for completeness
+    const F A = F::sqr(X), B = F::sqr(Y), C = F::sqr(B);
+    const F t = F::add(X, B);
+    const F D = F::mul2(F::sub(F::sub(F::sqr(t), A), C));
+    const F E = F::mul3(A);
+    const F X3 = F::sub(F::sqr(E), F::mul2(D));
+    const F Y3 = F::sub(F::mul(E, F::sub(D, X3)), F::mul8(C));
+    Z = F::mul2(F::mul(Y, Z));
+    X = X3;
+    Y = Y3;
+  }
+  const F ZZ = F::sqr(Z);
+  return {X, Y, ZZ, F::mul(Z, ZZ)};
+}
+
 // Horner value (not yet normalised) of one set of window sums, 64-bit host limbs
 template <class F>
 XYZZ<F> horner_windows(const XYZZ<F>* wins, int W, int c) {
   XYZZ<F> acc = XYZZ<F>::inf();
   for (int w = W - 1; w >= 0; --w) {
-    for (int k = 0; k < c; ++k) acc = xyzz_dbl_inl(acc);
+    acc = xyzz_dbl_many_host(acc, c);
     acc = xyzz_add_inl(acc, wins[w]);
   }
   return acc;
