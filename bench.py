@@ -438,6 +438,8 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="bn254_g1")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--exchange", choices=["rccl", "harness"], default="rccl", help="N > 1: RCCL behind the C ABI (default) or the gloo harness all-gather")
+    ap.add_argument("--spinup", type=int, default=int(os.environ.get("BENCH_SPINUP", "0")),
+                    help="untimed steps issued during setup, before the W warmup steps (brings the GPU out of its idle clocks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary metrics")
@@ -460,6 +462,8 @@ def main():
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "bn254_g1"
     pts_host = job.points_to_host() if want_cpu else None
     job.drop_point_copy()
+    for _ in range(args.spinup):
+        job.step()
     dt, res = job.timed(args.steps, args.warmup)
     ms_per_step = dt / args.steps * 1e3
     value = total * args.steps / dt
@@ -501,7 +505,7 @@ def main():
             "config": {"workload": f"{label} Pippenger MSM, uniform scalars / known-dlog points, {per_rank}"
                                    + (" (BASELINE config 2)" if args.workload == "bn254_g1" and args.log_n == 20 else "")
                                    + (" (BASELINE config 5)" if args.workload.startswith("bls12_381") and args.log_n == 24 and args.scaling == "strong" else ""),
-                       "points_total": total, "points_per_gpu": n_local, "split": cx.exchange},
+                       "points_total": total, "points_per_gpu": n_local, "split": cx.exchange, "spinup_steps": args.spinup},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "result_check": check, "secondary": extras,
         }
         print(json.dumps(line))
