@@ -29,6 +29,8 @@ for job in args:
     h = C.c_void_p()
     B._check(L.csh_bases_upload_dev(curve, group, buf.ptr, C.c_size_t(n), C.c_size_t(0), None, C.byref(h)))
     buf.free()
+    if os.environ.get("LOOP_PRECOMPUTE"):   # fixed-base window tables on the handle (merged-window mode), c from the env (0 = auto)
+        B._check(L.csh_bases_precompute(h, int(os.environ["LOOP_PRECOMPUTE"]) if os.environ["LOOP_PRECOMPUTE"] != "auto" else 0))
     rs = np.random.RandomState(1)
     limbs = rs.randint(0, 1 << 63, size=(n, 4), dtype=np.uint64)
     limbs[:, 3] >>= np.uint64(3)
