@@ -156,9 +156,12 @@ class Bases:
     def _out(self):
         return np.zeros(3 * point_bytes(self.curve, self.group) // 2 // 8, dtype=np.uint64)
 
-    def precompute(self, c: int = 0):
-        """csh_bases_precompute: fixed-base window tables (merged-window MSMs on this handle)."""
-        _check(lib().csh_bases_precompute(self.h, int(c)))
+    def precompute(self, c: int = 0, groups: int = 0):
+        """csh_bases_precompute[_grouped]: fixed-base tables (merged-window MSMs on this handle); groups = 0: one row per window."""
+        if groups:
+            _check(lib().csh_bases_precompute_grouped(self.h, int(c), int(groups)))
+        else:
+            _check(lib().csh_bases_precompute(self.h, int(c)))
         return self
 
     def msm(self, scalars, offset: int = 0, n: int | None = None, montgomery: bool = True):

@@ -117,7 +117,13 @@ int csh_bases_free(csh_bases_t bases) {
 
 // Fixed-base window tables for a set of bases that is reused across MSMs (a proving key query): see msm_impl.hpp. c = 0
 // picks the window width (16 from 2^17 points on, narrower below); handles of fewer than 1024 points stay as they are.
-int csh_bases_precompute(csh_bases_t bases, int c) {
+static int bases_precompute(csh_bases_t bases, int c, int groups);
+int csh_bases_precompute(csh_bases_t bases, int c) { return bases_precompute(bases, c, 0); }
+int csh_bases_precompute_grouped(csh_bases_t bases, int c, int groups) {
+  CSH_REQUIRE(groups >= 2 && groups <= MAX_WINDOWS, "groups must be in [2, 128]");
+  return bases_precompute(bases, c, groups);
+}
+static int bases_precompute(csh_bases_t bases, int c, int groups) {
   CSH_REQUIRE(bases, "bases is NULL");
   CSH_TRY(ensure_device());
   Bases* B = reinterpret_cast<Bases*>(bases);
@@ -139,7 +145,7 @@ int csh_bases_precompute(csh_bases_t bases, int c) {
     }
   }
   hipStream_t st = resolve_stream(nullptr);
-  CURVE_DISPATCH(B->curve, B->group, (precompute_table_t<Cfg>(B, c, st)));
+  CURVE_DISPATCH(B->curve, B->group, (precompute_table_t<Cfg>(B, c, groups, st)));
 }
 
 static int msm_args(csh_bases_t bases, size_t offset, size_t n, const void* scalars, const void* out) {
@@ -246,10 +252,10 @@ int csh_msm_multi_dev(const csh_bases_t* bases, const size_t* offsets, size_t k,
   bool merged = true;
   for (size_t i = 0; i < k; ++i) {
     const Bases* B = reinterpret_cast<const Bases*>(bases[i]);
-    merged = merged && msm_use_table(B, n) && B->table_c == B0->table_c;
+    merged = merged && msm_use_table(B, n) && B->table_c == B0->table_c && B->table_W == B0->table_W;
   }
-  const MsmParams pdig = merged ? msm_plan_merged(n, bits, mont, B0->table_c, B0->n, 0).dig : msm_plan(n, bits, mont);
-  MsmParams p = merged ? msm_plan_merged(n, bits, mont, B0->table_c, B0->n, 0).srt : pdig;
+  const MsmParams pdig = merged ? msm_plan_merged(n, bits, mont, B0->table_c, B0->table_W, B0->n, 0).dig : msm_plan(n, bits, mont);
+  MsmParams p = merged ? msm_plan_merged(n, bits, mont, B0->table_c, B0->table_W, B0->n, 0).srt : pdig;
   size_t bucket_max = 0, win_bytes = 0;
   for (auto& o : ops) {
     bucket_max = std::max(bucket_max, o.bytes(&p));

@@ -35,8 +35,9 @@ struct Bases {
   size_t n;
   size_t point_bytes;
   void* points;  // packed Affine<Fq>[n] on the device
-  // fixed-base window tables (csh_bases_precompute): table[w * n + i] = 2^(table_c * w) * points[i], w < table_W, same
-  // encoding as `points`. With them all windows of an MSM fall into ONE set of buckets (merged-window mode).
+  // fixed-base tables (csh_bases_precompute[_grouped]): table[k * n + i] = 2^(table_c * W' * k) * points[i], k < table_W rows
+  // (W' = ceil(windows / table_W)), same encoding as `points`. Windows w and w + W' k of an MSM share one set of buckets
+  // (merged-window mode); table_W = windows is the full merge (one bucket set, W' = 1).
   void* table = nullptr;
   int table_c = 0, table_W = 0;
 };
@@ -64,13 +65,16 @@ __global__ __launch_bounds__(MSM_BLK) void k_msm_digits(const Fr* __restrict__ s
   for (size_t i = blockIdx.x * (size_t)MSM_BLK + threadIdx.x; i < p.n; i += (size_t)gridDim.x * MSM_BLK) {
     uint32_t s[Fr::N];
     load_scalar<Fr>(scalars, i, p.mont, s);
+    const uint32_t g = p.dig_g > 1 ? p.dig_g : 1u, wp = p.dig_g > 1 ? p.dig_wp : (uint32_t)p.W;
+    const int rows = (int)(g * wp);  // >= W: the windows past W (grouped tables, g * W' > W) hold no digits
+    auto row = [&](int w) -> size_t { return g > 1 ? (size_t)((uint32_t)w % wp) * g + (uint32_t)w / wp : (size_t)w; };
     int next = 0;
     for_each_digit<Fr::N>(s, p.c, p.W, [&](int w, uint32_t b, uint32_t neg) {
-      for (; next < w; ++next) dig[(size_t)next * p.n + i] = (uint16_t)DIG_ZERO;
-      dig[(size_t)w * p.n + i] = (uint16_t)((b - 1) | (neg << 15));
+      for (; next < w; ++next) dig[row(next) * p.n + i] = (uint16_t)DIG_ZERO;
+      dig[row(w) * p.n + i] = (uint16_t)((b - 1) | (neg << 15));
       next = w + 1;
     });
-    for (; next < p.W; ++next) dig[(size_t)next * p.n + i] = (uint16_t)DIG_ZERO;
+    for (; next < rows; ++next) dig[row(next) * p.n + i] = (uint16_t)DIG_ZERO;
   }
 }
 
@@ -551,6 +555,7 @@ inline MsmParams msm_plan(size_t n, int scalar_bits, int mont) {
   p.CH = (uint32_t)ch;
   p.chunk_len = (uint32_t)((n + ch - 1) / ch);
   p.remap_n = p.remap_stride = p.remap_off = 0;
+  p.dig_g = p.dig_wp = 0;
   tl_msm_params[0] = (uint32_t)p.c;
   tl_msm_params[1] = (uint32_t)p.W;
   tl_msm_params[2] = p.L;
@@ -558,14 +563,16 @@ inline MsmParams msm_plan(size_t n, int scalar_bits, int mont) {
   return p;
 }
 
-// Merged-window mode (bases with fixed-base tables): the digit kernel still produces W windows of n codes (`dig`), but
-// the sort and bucket stages see them as ONE window of n * W entries over the 2^(c-1) buckets, every entry pointing at
-// the precomputed multiple 2^(c*w) * P_i -- one bucket reduction instead of W, no Horner over windows afterwards.
+// Merged-window mode (bases with fixed-base tables of g rows, table[k] = 2^(c W' k) P with W' = ceil(W / g)): the digit kernel
+// still produces W windows of n codes, but window w is filed as row k = w / W' of sort window w' = w % W', every entry pointing
+// at the precomputed multiple 2^(c W' k) P_i: the sort and bucket stages see W' windows of n g entries. g = W (one window, no
+// Horner over windows afterwards) is the full merge; g = 2..4 keeps the sort in its efficient regime and halves / quarters the
+// window reductions and the host Horner for g times the key memory.
 struct MergedPlan {
   MsmParams dig;  // n points, W windows: digit kernel
-  MsmParams srt;  // n * W entries, 1 window: sort + bucket stages
+  MsmParams srt;  // n g entries per window, W' windows: sort + bucket stages
 };
-inline MergedPlan msm_plan_merged(size_t n, int scalar_bits, int mont, int c, size_t table_stride, size_t offset) {
+inline MergedPlan msm_plan_merged(size_t n, int scalar_bits, int mont, int c, int groups, size_t table_stride, size_t offset) {
   MergedPlan m;
   MsmParams& d = m.dig;
   d.n = (uint32_t)n;
@@ -575,22 +582,22 @@ inline MergedPlan msm_plan_merged(size_t n, int scalar_bits, int mont, int c, si
   d.L = d.tmax = d.S = d.CH = d.chunk_len = 0;
   d.mont = mont;
   d.remap_n = d.remap_stride = d.remap_off = 0;
+  const int g = groups < 1 ? 1 : (groups > d.W ? d.W : groups);
+  const int wp = (d.W + g - 1) / g;
+  d.dig_g = (uint32_t)g;
+  d.dig_wp = (uint32_t)wp;
   MsmParams& p = m.srt;
-  const uint64_t n2 = (uint64_t)n * d.W;
+  const uint64_t n2 = (uint64_t)n * g;
   p.n = (uint32_t)n2;
   p.c = c;
-  p.W = 1;
+  p.W = wp;
   p.NB = d.NB;
-  uint64_t L = 16;  // one window only: 2^18 lanes fill the chip, longer runs mean fewer partials per bucket to merge
-  while (L < 1024 && 2 * L * (uint64_t(1) << 18) <= n2) L <<= 1;
-  if (const int fl = tune().msm_l.load(std::memory_order_relaxed); fl > 0) L = (uint64_t)fl;
-  p.L = (uint32_t)L;
-  const uint32_t max_lanes = (uint32_t)((n2 + L - 1) / L);
+  p.L = choose_lane_length((size_t)n2, p.W);
+  const uint32_t max_lanes = (uint32_t)((n2 + p.L - 1) / p.L);
   p.tmax = p.NB + max_lanes + 2;
-  p.S = 64;
-  while (p.S < 8192 && (uint64_t)p.S * 4 < p.NB) p.S <<= 1;
+  p.S = reduce_segments(p.NB, p.W, 1);
   p.mont = mont;
-  uint64_t ch = 512;
+  uint64_t ch = 512 / (uint64_t)p.W;
   const uint64_t by_size = n2 / (2ull * p.NB);
   if (ch > by_size) ch = by_size;
   if (ch < 1) ch = 1;
@@ -599,8 +606,9 @@ inline MergedPlan msm_plan_merged(size_t n, int scalar_bits, int mont, int c, si
   p.remap_n = (uint32_t)n;
   p.remap_stride = (uint32_t)table_stride;
   p.remap_off = (uint32_t)offset;
+  p.dig_g = p.dig_wp = 0;
   tl_msm_params[0] = (uint32_t)c;
-  tl_msm_params[1] = (uint32_t)d.W;
+  tl_msm_params[1] = (uint32_t)p.W;
   tl_msm_params[2] = p.L;
   tl_msm_params[3] = p.S;
   return m;
@@ -825,7 +833,7 @@ int msm_windows_dev(const Bases* B, size_t offset, size_t n, const uint64_t* sca
   MsmParams p, pdig;
   const void* points;
   if (merged) {
-    const MergedPlan m = msm_plan_merged(n, Fr::Params::BITS, mont, B->table_c, B->n, offset);
+    const MergedPlan m = msm_plan_merged(n, Fr::Params::BITS, mont, B->table_c, B->table_W, B->n, offset);
     p = m.srt;
     pdig = m.dig;
     points = B->table;
@@ -854,7 +862,7 @@ int msm_windows_dev(const Bases* B, size_t offset, size_t n, const uint64_t* sca
   return CSH_OK;
 }
 
-// Fixed-base window tables: table[w * n + i] = 2^(c w) P_i for w < W = windows_for(scalar bits, c). One lane per point:
+// Fixed-base tables: table[k * n + i] = 2^(step k) P_i for k < W rows (step = c W' doublings; `c` below is that step). One lane per point:
 // back to the arkworks encoding, c doublings per window in XYZZ, one inversion per window to return to affine, re-encoded
 // for storage. One-off per set of bases (a proving key): ~8.4 k field multiplications per G1 point.
 template <class Cfg>
@@ -885,10 +893,12 @@ __global__ __launch_bounds__(128) void k_bases_precompute(const Affine<typename 
 }
 
 template <class Cfg>
-int precompute_table_t(Bases* B, int c, hipStream_t st) {
+int precompute_table_t(Bases* B, int c, int groups, hipStream_t st) {
   using Fq = typename Cfg::Fq;
   using Fr = typename Cfg::Fr;
-  const int W = windows_for(Fr::Params::BITS, c);
+  const int windows = windows_for(Fr::Params::BITS, c);
+  const int W = groups <= 0 || groups > windows ? windows : groups;  // table rows
+  const int step = c * ((windows + W - 1) / W);                    // doublings between rows: c * W'
   void* t = nullptr;
   hipError_t e = hipMalloc(&t, sizeof(Affine<Fq>) * B->n * (size_t)W);
   if (e != hipSuccess) {
@@ -896,7 +906,7 @@ int precompute_table_t(Bases* B, int c, hipStream_t st) {
     return CSH_ERR_OOM;
   }
   hipLaunchKernelGGL(k_bases_precompute<Cfg>, dim3((unsigned)((B->n + 127) / 128)), dim3(128), 0, st, reinterpret_cast<const Affine<Fq>*>(B->points),
-                     B->n, c, W, reinterpret_cast<Affine<Fq>*>(t));
+                     B->n, step, W, reinterpret_cast<Affine<Fq>*>(t));
   e = hipGetLastError();
   if (e == hipSuccess) e = hipStreamSynchronize(st);
   if (e != hipSuccess) {
@@ -1088,7 +1098,7 @@ int repack_bases_t(Bases* B, hipStream_t st) {
   KW template int repack_bases_t<CFG>(Bases*, hipStream_t);                                                                     \
   KW template size_t msm_bucket_bytes<CFG>(const MsmParams*);                                                                   \
   KW template int msm_bucket_stage<CFG>(const void*, const MsmParams*, const SortOut*, hipStream_t, Arena*, void*, hipEvent_t*);          \
-  KW template int precompute_table_t<CFG>(Bases*, int, hipStream_t);                                                            \
+  KW template int precompute_table_t<CFG>(Bases*, int, int, hipStream_t);                                                            \
   KW template void fold_windows_erased<CFG>(const void*, int, int, void*);
 
 // the five group configurations, by run-time (curve, group)

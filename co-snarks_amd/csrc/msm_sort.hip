@@ -425,12 +425,13 @@ int msm_sort_launch(const MsmParams& p, const SortBuffers& b, hipStream_t st, hi
   if (ev) CSH_HIP(hipEventRecord(ev[2], st));
   if (two_level) {
     hipLaunchKernelGGL(k_msm_part_offsets, dim3((nparts + 255) / 256, p.W), dim3(256), 0, st, p, b.start, b.part_cnt);
-    // 4-byte intermediate records when every entry id fits 23 bits (n <= 2^23, no fixed-base table remap); tune "msm_variant"
+    // 4-byte intermediate records when every stored entry id fits 23 bits (n, or rows x bases with tables, <= 2^23); tune "msm_variant"
     // bit 3 forces the 8-byte records (A/B runs, tests). (4-byte records + a separate sign byte for ids up to 2^24 were
     // measured and lose to the 8-byte records: scatter 2.29 against 2.10 ms on BN254 G1 2^24 -- byte-granular scattered
     // writes cost more than the 3 bytes per entry they save, profiles/r02_g_rec_stages.log.)
-    const bool wide_only = p.remap_n != 0 || (tune().msm_variant.load(std::memory_order_relaxed) & 8) != 0;
-    if (!wide_only && p.n <= (1u << 23)) {
+    const uint64_t max_id = p.remap_n ? (uint64_t)(p.n / p.remap_n) * p.remap_stride : (uint64_t)p.n;  // stored ids: table indices
+    const bool wide_only = (tune().msm_variant.load(std::memory_order_relaxed) & 8) != 0;
+    if (!wide_only && max_id <= (1u << 23)) {
       hipLaunchKernelGGL(k_msm_scatter_l1<1>, dim3(p.CH, p.W), dim3(SORT_BLK), 0, st, p, b.dig, b.part_cnt, (void*)b.inter);
       hipLaunchKernelGGL(k_msm_scatter_l2<1>, dim3(nparts, p.W), dim3(SORT_BLK), 0, st, p, b.start, (const void*)b.inter, b.sorted);
     } else {

@@ -16,9 +16,13 @@ struct MsmParams {
   int mont;
   uint32_t CH;         // point chunks per window in the LDS counting sort
   uint32_t chunk_len;  // points per chunk
-  // merged-window mode (fixed-base tables, msm_impl.hpp): the sort sees ONE window of n = n_points * W codes; flat index f
-  // = w * remap_n + i is stored as the table index w * remap_stride + remap_off + i. remap_n = 0: identity.
+  // merged-window mode (fixed-base tables, msm_impl.hpp): a sort window holds n = n_points * g codes (g table rows); flat index
+  // f = k * remap_n + i is stored as the table index k * remap_stride + remap_off + i. remap_n = 0: identity.
   uint32_t remap_n, remap_stride, remap_off;
+  // digit kernel only (grouped tables): digit window w is written to row (w % dig_wp) * dig_g + w / dig_wp, so that the dig_g
+  // rows of sort window w' = w % dig_wp are contiguous; rows up to dig_g * dig_wp that no digit window maps to are zero-filled.
+  // dig_g <= 1: identity.
+  uint32_t dig_g, dig_wp;
 };
 
 // Digit code (one u16 per point and window): bits 0..14 = bucket-1, bit 15 = negative; 0xFFFF = zero digit.

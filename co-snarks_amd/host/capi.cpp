@@ -449,6 +449,7 @@ int bench_synth_t(int log_domain, int iters, double* out_ms, int* check_ok, cons
   synth_query<Fq2>(P::ID, CSH_G2, SB2, n_vars, pk.b_g2_query);
   synth_query<Fq>(P::ID, CSH_G1, SL, n_vars - 2, pk.l_query);
   synth_query<Fq>(P::ID, CSH_G1, SH, domain, pk.h_query);
+  pk.build_tables();
   const uint64_t d_alpha = 0x1111, d_beta = 0x2222, d_delta = 0x3333;
   auto kG1 = [&](uint64_t k) { return into_affine(point_mul(into_group(g1), Fr::from_u64(k))); };
   auto kG2 = [&](uint64_t k) { return into_affine(point_mul(into_group(g2), Fr::from_u64(k))); };

@@ -107,6 +107,11 @@ int csh_bases_len(csh_bases_t bases, size_t* n);
  * saves 7 % on a BN254 G2 MSM of 2^20 points and ~1 % on G1 (the bucket reduction it removes is latency-bound, and the
  * gathers lose the cache reuse of the 64-byte points), and costs 6 % at 2^22; the host mirror does not use it. */
 int csh_bases_precompute(csh_bases_t bases, int c);
+/* The same with `groups` (2..128) table rows instead of one per window: row k holds 2^(c W' k) P_i, W' = ceil(windows / groups),
+ * so that windows w and w + W' k share a bucket set: W' bucket reductions instead of W and a host Horner over W' windows, for
+ * groups x the memory of the points. groups = 2 or 4 keeps the sort stage in its efficient regime (the full merge above runs it
+ * on a single window). Same results; replaces any tables already on the handle. */
+int csh_bases_precompute_grouped(csh_bases_t bases, int c, int groups);
 int csh_bases_free(csh_bases_t bases);
 
 /* sum_{i<n} scalars[i] * bases[offset+i].  "unchecked": the caller passes the shorter length

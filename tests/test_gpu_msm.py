@@ -286,8 +286,9 @@ def test_msm_multi_shares_one_sort(gpu, curve):
 
 @pytest.mark.parametrize("curve,group", GROUPS)
 def test_msm_fixed_base_tables(gpu, curve, group):
-    """csh_bases_precompute: with window tables on the handle every MSM (full, prefix, offset, skewed scalars, canonical
-    scalars) returns the same group element as the oracle; several table widths."""
+    """csh_bases_precompute / csh_bases_precompute_grouped: with tables on the handle every MSM (full, prefix, offset, skewed
+    scalars, canonical scalars) returns the same group element as the oracle; several table widths and row counts (2, 3, 4, 5
+    rows: windows w and w + W' k share a bucket set; the last group is ragged when rows x W' > windows)."""
     G = cv.CURVES[curve][group]
     F = H.FR[curve]
     cid = H.CURVE_IDS[curve]
@@ -298,8 +299,8 @@ def test_msm_fixed_base_tables(gpu, curve, group):
     sk = [1] * 300 + [F.p - 1] * 300 + [0] * 100 + H.rand_elems(F, n - 700, r)
     want_full, want_sk = G.msm(pts, sc), G.msm(pts, sk)
     want_off = G.msm(pts[37:37 + 900], sc[:900])
-    for c in (0, 8, 13, 16):
-        bases = gpu.Bases(cid, group, cv.pack_points(G, pts)).precompute(c)
+    for c, groups in ((0, 0), (8, 0), (13, 0), (16, 0), (15, 2), (16, 2), (13, 4), (9, 3), (11, 5)):   # groups = 0: one row per window
+        bases = gpu.Bases(cid, group, cv.pack_points(G, pts)).precompute(c, groups)
         assert G.eq(H.jac_to_affine(G, bases.msm(H.pack(F, sc))), want_full), c
         assert G.eq(H.jac_to_affine(G, bases.msm(H.pack(F, sk))), want_sk), c
         assert G.eq(H.jac_to_affine(G, bases.msm(H.pack(F, sc[:900]), offset=37, n=900)), want_off), c
@@ -322,14 +323,19 @@ def test_msm_fixed_base_tables_closed_form_and_multi(gpu):
     L = gpu.lib()
     gpu.bindings._check(L.csh_bases_upload_dev(0, 0, buf.ptr, C.c_size_t(n), C.c_size_t(0), None, C.byref(h)))
     buf.free()
-    gpu.bindings._check(L.csh_bases_precompute(h, 0))
     rs = np.random.RandomState(7)
     limbs = rs.randint(0, 1 << 63, size=(n, 4), dtype=np.uint64)
     limbs[:, 3] >>= np.uint64(3)
-    out = np.zeros(12, dtype=np.uint64)
-    gpu.bindings._check(L.csh_msm(h, C.c_size_t(0), C.c_size_t(n), limbs.ctypes.data_as(C.c_void_p), 1, out.ctypes.data_as(C.c_void_p)))
+    want = closed_form_point("bn254", 0, seed, n, limbs, True)
+    for c, groups in ((0, 0), (15, 2), (16, 4)):
+        if groups:
+            gpu.bindings._check(L.csh_bases_precompute_grouped(h, c, groups))
+        else:
+            gpu.bindings._check(L.csh_bases_precompute(h, c))
+        out = np.zeros(12, dtype=np.uint64)
+        gpu.bindings._check(L.csh_msm(h, C.c_size_t(0), C.c_size_t(n), limbs.ctypes.data_as(C.c_void_p), 1, out.ctypes.data_as(C.c_void_p)))
+        assert G.eq(H.jac_to_affine(G, out), want), (c, groups)
     L.csh_bases_free(h)
-    assert G.eq(H.jac_to_affine(G, out), closed_form_point("bn254", 0, seed, n, limbs, True))
     # multi over tables
     G1, G2 = cv.CURVES["bn254"]
     F = H.FR["bn254"]
@@ -337,8 +343,18 @@ def test_msm_fixed_base_tables_closed_form_and_multi(gpu):
     m = 1500
     sets = [(G1, 0, H.rand_points(G1, m + 3, r), 3), (G1, 0, H.rand_points(G1, m + 3, r), 3), (G2, 1, H.rand_points(G2, m + 3, r), 3),
             (G1, 0, H.rand_points(G1, m, r), 0)]
-    handles = [gpu.Bases(0, g, cv.pack_points(Gx, pts)).precompute(0) for Gx, g, pts, _ in sets]
     sc = H.rand_elems(F, m, r)
+    for groups in (2, 0):
+        handles = [gpu.Bases(0, g, cv.pack_points(Gx, pts)).precompute(0, groups) for Gx, g, pts, _ in sets]
+        _multi_over_tables(gpu, sets, handles, sc, m)
+        for x in handles:
+            x.free()
+
+
+def _multi_over_tables(gpu, sets, handles, sc, m):
+    import ctypes as C
+    L = gpu.lib()
+    F = H.FR["bn254"]
     dsc = gpu.DeviceBuffer.from_host(H.pack(F, sc))
     outs = [np.zeros(3 * gpu.point_bytes(0, g) // 16, dtype=np.uint64) for _, g, _, _ in sets]
     hs = (C.c_void_p * 4)(*[x.h.value for x in handles])
@@ -348,9 +364,6 @@ def test_msm_fixed_base_tables_closed_form_and_multi(gpu):
     for (Gx, g, pts, off), o in zip(sets, outs):
         assert Gx.eq(H.jac_to_affine(Gx, o), Gx.msm(pts[off:off + m], sc)), (g, off)
     dsc.free()
-    for x in handles:
-        x.free()
-
 
 
 def test_plain_c_caller_of_the_boundary(gpu, tmp_path):

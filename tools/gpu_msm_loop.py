@@ -29,8 +29,12 @@ for job in args:
     h = C.c_void_p()
     B._check(L.csh_bases_upload_dev(curve, group, buf.ptr, C.c_size_t(n), C.c_size_t(0), None, C.byref(h)))
     buf.free()
-    if os.environ.get("LOOP_PRECOMPUTE"):   # fixed-base window tables on the handle (merged-window mode), c from the env (0 = auto)
-        B._check(L.csh_bases_precompute(h, int(os.environ["LOOP_PRECOMPUTE"]) if os.environ["LOOP_PRECOMPUTE"] != "auto" else 0))
+    if os.environ.get("LOOP_PRECOMPUTE"):   # fixed-base tables on the handle: "c" or "c:rows" (c = 0 / auto: automatic width)
+        spec = os.environ["LOOP_PRECOMPUTE"].replace("auto", "0").split(":")
+        if len(spec) > 1 and int(spec[1]) > 1:
+            B._check(L.csh_bases_precompute_grouped(h, int(spec[0]), int(spec[1])))
+        else:
+            B._check(L.csh_bases_precompute(h, int(spec[0])))
     rs = np.random.RandomState(1)
     limbs = rs.randint(0, 1 << 63, size=(n, 4), dtype=np.uint64)
     limbs[:, 3] >>= np.uint64(3)
