@@ -308,6 +308,19 @@ def secondary_single_gpu(cx: Ctx, rin: dict, args):
             cpu_inputs = (pts_host, job.sc.cpu().numpy().view(np.uint64), job.affine_words(res))
         job.free()
         del job
+    # the headline workload again with fixed-base tables on the handle (opt-in key-load precomputation, csh_bases_precompute_grouped:
+    # 2 rows = 2 x the bases in HBM; the headline itself runs on the plain handle, as the reference's msm_unchecked does)
+    try:
+        job = MsmJob(cx, "bn254_g1", 0, 1 << 20, 1234)
+        job.drop_point_copy()
+        B._check(L.csh_bases_precompute_grouped(job.h, 16, 2))
+        dt, res = job.timed(20, 5)
+        out["msm_bn254_g1_2p20_fixed_base_tables"] = {"points_per_s": job.n * 20 / dt, "ms": dt / 20 * 1e3, "result_check": job.check(res),
+                                                      "table_rows": 2, "window_bits": 16}
+        job.free()
+        del job
+    except Exception as e:  # noqa: BLE001
+        out["msm_bn254_g1_2p20_fixed_base_tables"] = {"error": repr(e)}
     # NTT 2^22 (snarkjs root), data resident; HIP events on the launch stream
     logn = 22
     r = 21888242871839275222246405745257275088548364400416034343698204186575808495617

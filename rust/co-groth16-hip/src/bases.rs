@@ -53,6 +53,16 @@ pub fn get_or_upload<P: Pairing, C: SWCurveConfig>(points: &[Affine<C>]) -> (Arc
     hip_ok(unsafe {
         sys::csh_bases_upload(curve_id::<P>(), group_id::<C>(), points.as_ptr().cast(), points.len(), stride, &mut handle)
     });
+    // Proving-key queries are reused across proofs: four-row fixed-base tables (4x the key memory on the device, built once)
+    // let windows w, w + W', w + 2W', w + 3W' share a bucket set. Same policy as ProvingKey::build_tables of the C++ mirror:
+    // only for 2^14..2^21 points, one window width for every query of a key so that csh_msm_multi_dev can share its digit pass.
+    if (1usize << 14..=1usize << 21).contains(&points.len()) {
+        let mut c = 16i32;
+        while c > 10 && (1usize << (c + 1)) > points.len() {
+            c -= 1;
+        }
+        hip_ok(unsafe { sys::csh_bases_precompute_grouped(handle, c, 4) });
+    }
     let b = Arc::new(DeviceBases { handle, host_base: points.as_ptr() as usize, len: points.len(), stride });
     map.insert((dev, points.as_ptr() as usize, points.len()), b.clone());
     (b, 0)
