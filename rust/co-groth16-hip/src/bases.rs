@@ -55,7 +55,8 @@ pub fn get_or_upload<P: Pairing, C: SWCurveConfig>(points: &[Affine<C>]) -> (Arc
     });
     // Proving-key queries are reused across proofs: four-row fixed-base tables (4x the key memory on the device, built once)
     // let windows w, w + W', w + 2W', w + 3W' share a bucket set. Same policy as ProvingKey::build_tables of the C++ mirror:
-    // only for 2^14..2^21 points, one window width for every query of a key so that csh_msm_multi_dev can share its digit pass.
+    // only for 2^14..2^21 points. The width follows the slice length (the cache sees slices, not keys): queries of one key whose
+    // lengths straddle a power of two get different widths and csh_msm_multi_dev then runs that call on the plain points.
     if (1usize << 14..=1usize << 21).contains(&points.len()) {
         let mut c = 16i32;
         while c > 10 && (1usize << (c + 1)) > points.len() {
