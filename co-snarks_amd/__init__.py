@@ -38,6 +38,7 @@ from .bindings import (  # noqa: F401
     rep3_local_mul_vec,
     rep3_to_shamir_vec,
     tune_get,
+    msm_plan,
     tune_set,
     tuned,
     vec_add,

@@ -206,6 +206,13 @@ def msm_fold_partials(curve: int, group: int, partials: np.ndarray, nparts: int)
     return out
 
 
+def msm_plan(curve: int, n: int):
+    """csh_msm_plan: (c, W, L, S, accumulate waves, SIMDs) an n-point MSM would run with; host-only."""
+    out = (C.c_uint32 * 6)()
+    _check(lib().csh_msm_plan(curve, C.c_size_t(n), out))
+    return tuple(int(x) for x in out)
+
+
 def tune_set(key: str, value: int):
     """csh_tune_set: process-wide tuning knob (tests / A-B runs)."""
     _check(lib().csh_tune_set(key.encode(), int(value)))

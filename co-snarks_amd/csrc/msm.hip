@@ -365,6 +365,25 @@ int csh_msm_multi_dev(const csh_bases_t* bases, const size_t* offsets, size_t k,
   return CSH_OK;
 }
 
+int csh_msm_plan(csh_curve_t curve, size_t n, uint32_t out[6]) {
+  CSH_REQUIRE(out, "out is NULL");
+  CSH_REQUIRE(curve == CSH_BN254 || curve == CSH_BLS12_381 || curve == CSH_GRUMPKIN, "unknown curve");
+  CSH_REQUIRE(n >= 1 && n < (size_t(1) << 31), "n out of range");
+  const int bits = curve == CSH_BLS12_381 ? Bls381FrParams::BITS : (curve == CSH_GRUMPKIN ? Bn254FqParams::BITS : Bn254FrParams::BITS);
+  uint32_t keep[4];
+  for (int i = 0; i < 4; ++i) keep[i] = tl_msm_params[i];  // planning must not disturb csh_msm_last_params
+  const MsmParams p = msm_plan(n, bits, 1);
+  for (int i = 0; i < 4; ++i) tl_msm_params[i] = keep[i];
+  const uint64_t lanes = (n + p.L - 1) / p.L;
+  out[0] = (uint32_t)p.c;
+  out[1] = (uint32_t)p.W;
+  out[2] = p.L;
+  out[3] = p.S;
+  out[4] = (uint32_t)((uint64_t)p.W * ((lanes + ACC_BLK - 1) / ACC_BLK) * (ACC_BLK / 64));
+  out[5] = (uint32_t)device_simds();
+  return CSH_OK;
+}
+
 int csh_msm_last_params(uint32_t out[4]) {
   CSH_REQUIRE(out, "out is NULL");
   for (int i = 0; i < 4; ++i) out[i] = tl_msm_params[i];

@@ -322,6 +322,11 @@ int csh_msm_last_timing(float out_ms[6]);
 /* Pipeline parameters of the last csh_msm*_dev call on this thread: [window bits c, windows W, entries per lane L,
  * reduction segments S]. */
 int csh_msm_last_params(uint32_t out[4]);
+/* The plan an n-point MSM on `curve` would run with on the calling thread's device (no device: a 256-CU part is assumed), without
+ * running it: [window bits c, windows W, entries per accumulate lane L, window-reduction segments S, accumulate waves, SIMDs].
+ * The accumulate kernel takes ceil(waves / SIMDs) rounds of L mixed additions; L and S are chosen so that every SIMD runs a
+ * whole number of equal rounds. Host-only: for capacity planning and for tests of the planner. */
+int csh_msm_plan(csh_curve_t curve, size_t n, uint32_t out[6]);
 
 /* ---- synthetic inputs (bench / full-size parity) -------------------------------------------------------
  * out[i] = k_i * G (affine, packed), k_i = csh_util_splitmix64(seed + i) | 1: known discrete logs, so an MSM

@@ -82,6 +82,40 @@ def test_split_msm_entry_points_without_device(hip):
         hip.Comm.init_all([0, 0])
 
 
+def test_msm_planner_invariants(hip):
+    """csh_msm_plan (host-only): the launch geometry the MSM would use. Lane length within [16, 1024]; the plan's round-count
+    cost is never worse than the former power-of-two rule under the same model; the window reduction's segments cover every
+    bucket and fit one round of waves; where n W / 64 is a multiple of the SIMD count the plan lands on a whole number of
+    rounds (2^22 -> 128, 2^24 -> 256 on a 256-CU part); planning does not disturb csh_msm_last_params."""
+    import math
+    B = hip.bindings
+    before = B.msm_last_params()
+
+    def cost(n, W, L, simds):
+        lanes = -(-n // L)
+        waves = W * -(-lanes // 128) * 2
+        return (math.ceil(waves / simds) + 0.2) * L + 4.6e-5 * n * W / L
+
+    for curve in (0, 1, 2):
+        for n in (1, 700, 5000, 1 << 14, 70001, 1 << 17, 1 << 18, 300007, 1 << 19, 1 << 20, 1200000, 1 << 21, 3000000, 1 << 22, 1 << 24, 20000003):
+            c, W, L, S, waves, simds = B.msm_plan(curve, n)
+            assert 2 <= c <= 16 and W * c >= 254 and 16 <= L <= 1024 and simds >= 4, (curve, n, c, W, L)
+            assert waves == W * -(-(-(-n // L)) // 128) * 2
+            old_L = 16
+            while old_L < 1024 and 2 * old_L * (1 << 19) <= n * W:
+                old_L <<= 1
+            assert cost(n, W, L, simds) <= cost(n, W, old_L, simds) + 1e-9, (curve, n, L, old_L)
+            NB = 1 << (c - 1)
+            per = -(-NB // S)
+            assert S >= 1 and S * per >= NB and -(-S // 64) * W <= max(simds, W), (curve, n, S, per)
+    if B.msm_plan(0, 1 << 22)[5] == 1024:
+        assert B.msm_plan(0, 1 << 22)[2] == 128 and B.msm_plan(0, 1 << 24)[2] == 256
+        assert B.msm_plan(0, 1 << 22)[4] % 1024 == 0
+    assert B.msm_last_params() == before
+    with pytest.raises(hip.CoSnarksHipError):
+        B.msm_plan(7, 100)
+
+
 def test_product_does_not_import_the_oracle():
     """Static check: nothing under co-snarks_amd/ references oracle/ (the oracle is test infrastructure only)."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
