@@ -227,15 +227,17 @@ struct ProvingKey {
   Query<typename P::Fq2> b_g2_query;
   std::vector<G1> ic;
   // Fixed-base tables on the five queries (csh_bases_precompute_grouped): rows x the key memory on the device, built once per
-  // key. Four rows: windows w, w + W', w + 2W', w + 3W' share a bucket set, so an MSM reduces W' = ceil(W / 4) windows and the
-  // host folds W' window sums (BN254 2^20: G2 query 4.7 -> 4.3 ms, G1 queries -1..3 %). Only for keys of 2^14..2^21 points:
+  // key. With g rows, windows w, w + W', ..., w + (g - 1) W' share a bucket set, so an MSM reduces W' = ceil(W / g) windows and
+  // the host folds W' window sums (BN254 2^20, 4 rows: G2 query 4.7 -> 4.3 ms, G1 queries -1..3 %). Only for keys of 2^14..2^21 points:
   // below, the MSM is launch-bound either way; above, the tables fall out of the caches and lose. COG16_TABLES=0 disables,
   // COG16_TABLES=g sets the row count. All queries get the same (c, rows): csh_msm_multi_dev shares one digit pass over them.
   void build_tables() {
-    int rows = 4;
-    if (const char* e = getenv("COG16_TABLES")) rows = atoi(e);
     size_t big = 0;
     for (size_t n : {a_query.size(), b_g1_query.size(), l_query.size(), h_query.size(), b_g2_query.size()}) big = n > big ? n : big;
+    // up to 2^18 points one row per window pays (every window into one bucket set: 2^16 3.4 -> 3.2 ms, 2^18 5.4 -> 5.0 ms per
+    // proof, profiles/r02_g_prove_table_rows.log); above, 4 / 8 / 16 rows measure the same and 4 cost the least memory
+    int rows = big <= (size_t(3) << 17) ? 16 : 4;  // (a 2^18-constraint key has 2^18 + a few wires)
+    if (const char* e = getenv("COG16_TABLES")) rows = atoi(e);
     if (rows < 2 || big < (size_t(1) << 14) || big > (size_t(1) << 21)) return;
     int c = 16;
     while (c > 10 && (size_t(1) << (c + 1)) > big) --c;
