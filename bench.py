@@ -47,6 +47,48 @@ CURVE_NAMES = {0: "bn254", 1: "bls12_381", 2: "grumpkin"}
 SEED = 0x00C0FFEE5EED
 
 
+# scalar-field moduli (BN254 Fr, BLS12-381 Fr, Grumpkin Fr = BN254 Fq)
+SCALAR_MODULUS = {
+    0: 21888242871839275222246405745257275088548364400416034343698204186575808495617,
+    1: 52435875175126190479447740508185965837690552500527637822603658699938581184513,
+    2: 21888242871839275222246405745257275088696311157297823662689037894645226208583,
+}
+
+
+def uniform_scalars(torch, dev, n, modulus, seed):
+    """n x 4 little-endian u64 limbs (as int64 bit patterns), uniform in [0, modulus) by rejection sampling (SURVEY 8d config 2:
+    "random scalars"): every limb carries 64 random bits, the top limb as many as the modulus has, draws >= modulus are redrawn.
+    Taken as Montgomery encodings they decode to uniform field elements."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    top_bits = modulus.bit_length() - 192
+    m = [(modulus >> (64 * i)) & (2**64 - 1) for i in range(4)]
+    flip = -(1 << 63)                     # x ^ flip maps unsigned order onto signed order
+    ms = [((x ^ (1 << 63)) - (1 << 63)) if i < 3 else x for i, x in enumerate(m)]   # flipped signed images of the modulus limbs (top limb < 2^63 as is)
+
+    def draw(k):
+        lo = torch.randint(0, 1 << 32, (k, 4), dtype=torch.int64, device=dev, generator=g)
+        hi = torch.randint(-(1 << 31), 1 << 31, (k, 4), dtype=torch.int64, device=dev, generator=g)
+        v = (hi << 32) | lo
+        v[:, 3] = (v[:, 3] >> (64 - top_bits)) & ((1 << top_bits) - 1)     # logical shift: top_bits random bits
+        return v
+
+    def ge_modulus(v):
+        ge = torch.ones(v.shape[0], dtype=torch.bool, device=dev)      # equal so far => (v >= m) holds on the empty suffix
+        for i in range(4):                                             # from the least significant limb up
+            x = v[:, i] ^ flip if i < 3 else v[:, i]
+            ge = (x > ms[i]) | ((x == ms[i]) & ge)
+        return ge
+
+    sc = draw(n)
+    bad = ge_modulus(sc)
+    while bool(bad.any()):
+        idx = bad.nonzero().flatten()
+        sc[idx] = draw(idx.numel())
+        bad = ge_modulus(sc)
+    return sc
+
+
 def load_roofline_inputs():
     try:
         return json.load(open(os.path.join(ROOT, "profiles", "roofline_inputs.json")))
@@ -167,12 +209,7 @@ class MsmJob:
         B._check(L.csh_bases_upload_dev(self.curve, self.group, C.c_void_p(pts.data_ptr()), C.c_size_t(n), C.c_size_t(0), C.c_void_p(cx.stream), C.byref(self.h)))
         self.pts_host = None
         self._pts_dev = pts          # kept only until the caller asks for a host copy (cpu_baseline) or drops it
-        g = torch.Generator(device=cx.dev)
-        g.manual_seed(scalar_seed)
-        sc = torch.randint(0, 1 << 62, (n, 4), dtype=torch.int64, device=cx.dev, generator=g)
-        sc = sc * 2 + torch.randint(0, 2, (n, 4), dtype=torch.int64, device=cx.dev, generator=g)   # 63 random bits per limb
-        sc[:, 3] >>= 2                                                                              # < 2^253 < r on every curve here
-        self.sc = sc
+        self.sc = uniform_scalars(torch, cx.dev, n, SCALAR_MODULUS[self.curve], scalar_seed)
         torch.cuda.synchronize()
         self.out = cx.np.zeros(3 * self.pbytes // 16, dtype=cx.np.uint64)
         self.part = None
@@ -426,7 +463,84 @@ def secondary_multi_gpu(cx: Ctx, args):
         except Exception as e:  # noqa: BLE001
             out["single_process_split_bn254_g1_2p24"] = {"error": repr(e)}
     cx.barrier()
+    # the metric's second half at this N: ONE plain prover with its five query MSMs placed on the N GPUs (rank 0, subprocess)
+    if cx.rank == 0:
+        try:
+            devs = [0] * cx.world if cx.folded else list(range(cx.world))
+            out["groth16_prove_synthetic_2p20_placed"] = prove_over_devices(devs)
+        except Exception as e:  # noqa: BLE001
+            out["groth16_prove_synthetic_2p20_placed"] = {"error": repr(e)}
+    cx.barrier()
     return out
+
+
+def prove_over_devices(devices, logn=20, steps=5, warmup=2, timeout=300):
+    """Plain Groth16 prove of the synthetic 2^logn circuit with the five query MSMs placed on `devices` (one process, one host
+    thread per GPU): tools/bench_prove_devices.py in a subprocess with a timeout, so nothing it does can stall the caller."""
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_prove_devices.py"), "--devices", ",".join(str(d) for d in devices),
+           "--log-n", str(logn), "--steps", str(steps), "--warmup", str(warmup)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": (r.stderr or r.stdout)[-400:]}
+    return json.loads(lines[-1])
+
+
+def run_groth16_prove(cx: Ctx, args):
+    """--workload groth16_prove: a step = one plain Groth16 prove (prove_inner: witness upload, device witness map, five MSM
+    groups, finish) of the synthetic 2^log_n-constraint BN254 circuit, key resident. ONE prover: at N > 1 rank 0 drives all N
+    GPUs (its five independent query MSMs -- rayon_join5, groth16.rs:227-294 -- placed on them, scalars by peer copy); the other
+    ranks only keep the barriers. value = ms per proof (lower is better), scaling = strong."""
+    from cosnarks_amd import groth16 as g16
+    world, rank = cx.world, cx.rank
+    if world == 1:
+        devices = [cx.dev_index]
+    elif cx.folded:                      # BENCH_FOLD_RANKS: logical slots on the GPUs that exist
+        devices = [cx.dev_index] * world
+    else:
+        devices = [cx.dev_index] + [d for d in range(world) if d != cx.dev_index]
+    circ, err = None, None
+    if rank == 0:
+        try:
+            g16.set_prover_devices(devices if len(devices) > 1 else None)
+            circ = g16.SynthCircuit(cx.hip.BN254, args.log_n)
+            for _ in range(args.warmup):
+                circ.prove()
+        except Exception as e:  # noqa: BLE001
+            err = repr(e)
+    cx.barrier()
+    t0 = time.perf_counter()
+    phases = []
+    if rank == 0 and err is None:
+        try:
+            for _ in range(args.steps):
+                phases.append(circ.prove())
+        except Exception as e:  # noqa: BLE001
+            err = repr(e)
+    cx.barrier()
+    dt = cx.max_over_ranks(time.perf_counter() - t0)
+    if rank == 0:
+        ok = None
+        if err is None and not args.no_check:
+            ok = circ.check()
+        ms = dt / args.steps * 1e3
+        med = lambda k: sorted(p[k] for p in phases)[len(phases) // 2] if phases else None
+        line = {"metric": "Groth16 prove ms", "value": ms if err is None else None, "unit": "ms", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": ms, "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
+                "dtype": "BN254: i32x9 29-bit-limb lazy Montgomery (MSM, NTT butterflies), Fp2 for the G2 query", "data": "synthetic",
+                "config": {"workload": f"plain Groth16 prove (CircomReduction), synthetic 2^{args.log_n}-constraint BN254 circuit with a known-dlog key, key resident; "
+                                       "one prover, its five query MSMs placed on the GPUs", "devices": devices,
+                           "placement": "LPT over the queries (G2 = 2.5 x G1), csh_bases_clone + csh_memcpy_peer, one host thread per GPU"},
+                "phases_ms_median": {k: med(k) for k in ("witness_upload_and_map", "msm_groups", "finish")}, "result_check": ok, "error": err,
+                "roofline": None, "cpu_baseline": None}
+        print(json.dumps(line))
+        if circ is not None:
+            circ.close()
+        g16.set_prover_devices(None)
+    sys.stdout.flush()
+    if world > 1:
+        cx.dist.destroy_process_group()
 
 
 def single_process_split(cx: Ctx, curve, group, logn):
@@ -448,7 +562,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log-n", type=int, default=20)
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="bn254_g1")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS) + ["groth16_prove"], default="bn254_g1")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--exchange", choices=["rccl", "harness"], default="rccl", help="N > 1: RCCL behind the C ABI (default) or the gloo harness all-gather")
     ap.add_argument("--spinup", type=int, default=int(os.environ.get("BENCH_SPINUP", "0")),
@@ -458,7 +572,11 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary metrics")
     args = ap.parse_args()
 
+    if args.workload == "groth16_prove":
+        args.exchange = "harness"      # no split MSM in this workload: no RCCL communicator to build
     cx = Ctx(args)
+    if args.workload == "groth16_prove":
+        return run_groth16_prove(cx, args)
     rin = load_roofline_inputs()
     world, rank = cx.world, cx.rank
     if args.scaling == "weak":
@@ -501,7 +619,18 @@ def main():
             from oracle.cbridge import cpu_baseline_suite
             sc_host = job.sc.cpu().numpy().view(cx.np.uint64)
             p24, s24, a24 = cpu_inputs24 if cpu_inputs24 else (None, None, None)
-            cpu_baseline = cpu_baseline_suite(pts_host, sc_host, job.affine_words(res), p24, s24, a24, host_cpus=HOST_CPUS)
+            # G2 bases of the same known-dlog family for the CPU prove composition (generated on the GPU, copied back; untimed)
+            g2_host = None
+            try:
+                g2 = cx.torch.empty(job.n * 128, dtype=cx.torch.uint8, device=cx.dev)
+                cx.B._check(cx.L.csh_util_generate_bases_dev(0, 1, cx.C.c_uint64(SEED), cx.C.c_size_t(job.n), cx.C.c_void_p(g2.data_ptr()), cx.C.c_void_p(cx.stream)))
+                cx.torch.cuda.synchronize()
+                cx.B.sync()
+                g2_host = g2.cpu().numpy().view(cx.np.uint64).reshape(job.n, -1)
+                del g2
+            except Exception:  # noqa: BLE001
+                g2_host = None
+            cpu_baseline = cpu_baseline_suite(pts_host, sc_host, job.affine_words(res), p24, s24, a24, host_cpus=HOST_CPUS, pts20_g2=g2_host)
             cpu_baseline["gpu_over_cpu_2p20"] = round(value / cpu_baseline["value"], 1)
             if extras and "msm_2p24" in cpu_baseline and "msm_bn254_g1_2p24" in extras:
                 cpu_baseline["gpu_over_cpu_2p24"] = round(extras["msm_bn254_g1_2p24"]["points_per_s"] / cpu_baseline["msm_2p24"]["points_per_s"], 1)

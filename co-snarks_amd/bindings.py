@@ -502,9 +502,10 @@ class Matrix:
     def evaluate(self, protocol: int, party: int, public, witness, n_out: int):
         pub, wit = _u64(public), _u64(witness)
         comp = 2 if protocol == 1 else 1
+        n_wit = wit.size // (4 * comp)
         dp, dw = DeviceBuffer.from_host(pub), DeviceBuffer.from_host(wit if wit.size else np.zeros(4, dtype=np.uint64))
         out = DeviceBuffer(n_out * comp * 32)
-        _check(lib().csh_evaluate_constraints_dev(self.h, protocol, party, dp.ptr, C.c_size_t(pub.size // 4), dw.ptr, out.ptr, C.c_size_t(n_out), None))
+        _check(lib().csh_evaluate_constraints_dev(self.h, protocol, party, dp.ptr, C.c_size_t(pub.size // 4), dw.ptr, C.c_size_t(n_wit), out.ptr, C.c_size_t(n_out), None))
         sync()
         return out.to_host()
 

@@ -269,6 +269,16 @@ int csh_memcpy_d2h(void* host_dst, const void* dev_src, size_t bytes) {
   CSH_HIP(hipMemcpy(host_dst, dev_src, bytes, hipMemcpyDeviceToHost));
   return CSH_OK;
 }
+// device-to-device copy between (possibly different) GPUs; stream = NULL: synchronous, otherwise asynchronous on a stream of the
+// CALLING thread's device
+int csh_memcpy_peer(void* dst, int dst_device, const void* src, int src_device, size_t bytes, void* stream) {
+  CSH_REQUIRE((dst && src) || bytes == 0, "NULL argument");
+  CSH_TRY(ensure_device());
+  if (bytes == 0) return CSH_OK;
+  if (stream) CSH_HIP(hipMemcpyPeerAsync(dst, dst_device, src, src_device, bytes, resolve_stream(stream)));
+  else CSH_HIP(hipMemcpyPeer(dst, dst_device, src, src_device, bytes));
+  return CSH_OK;
+}
 int csh_extract_component_dev(const uint64_t* shares_dev, uint32_t ncomp, uint32_t comp, size_t n, uint64_t* out_dev, void* stream) {
   CSH_REQUIRE(shares_dev && out_dev, "NULL argument");
   CSH_REQUIRE(ncomp >= 1 && ncomp <= 4 && comp < ncomp, "bad component selector");

@@ -64,12 +64,32 @@ struct Fp2Pair {
     LF::mac_wide(w, hi_signed(a.v), quad_perm<PairSwap::value>(b.v), false);
     return w;
   }
+#if CSH_REDUCE_SCAN
+  __device__ __forceinline__ static Fp2Pair mul(const Fp2Pair& a, const Fp2Pair& b) {
+    const LF alo = quad_perm<PairLo::value>(a.v), ahi = hi_signed(a.v), bsw = quad_perm<PairSwap::value>(b.v);
+    return {LF::reduce_scan([&](int k, int64_t acc) CSH_LAMBDA_INLINE { return LF::col_mul(ahi, bsw, k, LF::col_mul(alo, b.v, k, acc)); })};
+  }
+  __device__ __forceinline__ static Fp2Pair sqr(const Fp2Pair& a) { return mul(a, a); }
+  __device__ __forceinline__ static Fp2Pair sqr_sub(const Fp2Pair& a, const Fp2Pair& s) {
+    const LF alo = quad_perm<PairLo::value>(a.v), ahi = hi_signed(a.v), bsw = quad_perm<PairSwap::value>(a.v);
+    const int32_t m1 = LF::opaque_minus_one();
+    return {LF::reduce_scan([&](int k, int64_t acc) CSH_LAMBDA_INLINE { return LF::col_sub_hi(s.v, m1, k, LF::col_mul(ahi, bsw, k, LF::col_mul(alo, a.v, k, acc))); })};
+  }
+#else
   __device__ __forceinline__ static Fp2Pair mul(const Fp2Pair& a, const Fp2Pair& b) { return {LF::reduce(mul_wide(a, b))}; }
   __device__ __forceinline__ static Fp2Pair sqr(const Fp2Pair& a) { return mul(a, a); }
   __device__ __forceinline__ static Fp2Pair sqr_sub(const Fp2Pair& a, const Fp2Pair& s) { return {LF::reduce_sub(mul_wide(a, a), s.v)}; }
+#endif
   // a*b - c*d
   __device__ __forceinline__ static Fp2Pair mul_sub(const Fp2Pair& a, const Fp2Pair& b, const Fp2Pair& c, const Fp2Pair& d) {
     if constexpr (LF::FOUR_PRODUCTS_FIT) {
+#if CSH_REDUCE_SCAN
+      const LF alo = quad_perm<PairLo::value>(a.v), ahi = hi_signed(a.v), bsw = quad_perm<PairSwap::value>(b.v);
+      const LF nclo = LF::neg(quad_perm<PairLo::value>(c.v)), nchi = LF::neg(hi_signed(c.v)), dsw = quad_perm<PairSwap::value>(d.v);
+      return {LF::reduce_scan([&](int k, int64_t acc) CSH_LAMBDA_INLINE {
+        return LF::col_mul(nchi, dsw, k, LF::col_mul(nclo, d.v, k, LF::col_mul(ahi, bsw, k, LF::col_mul(alo, b.v, k, acc))));
+      })};
+#endif
       typename LF::Wide w = mul_wide(a, b);
       LF::mac_wide(w, quad_perm<PairLo::value>(c.v), d.v, true);
       LF::mac_wide(w, hi_signed(c.v), quad_perm<PairSwap::value>(d.v), true);

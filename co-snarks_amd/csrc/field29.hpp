@@ -185,6 +185,42 @@ using Fq29 = FpLazy<Bn254Fq29Params, Bn254Fq>;
 #define CSH_LIMB_BOUND(x, bound, what) do { } while (0)
 #endif
 
+// the column-term lambdas of reduce_scan must be inlined whatever their size (the column index has to be a constant)
+#define CSH_LAMBDA_INLINE __attribute__((always_inline))
+#ifndef CSH_REDUCE_SCAN
+#define CSH_REDUCE_SCAN 1
+#endif
+#ifndef CSH_PIN_MADS
+#define CSH_PIN_MADS (CSH_REDUCE_SCAN ? 3 : 0)
+#endif
+// acc = x * y + acc as ONE v_mad_i64_i32 in the order written: the empty asm makes every partial sum opaque to the compiler's
+// reassociation pass, which otherwise sorts a column's terms by rank, moves the incoming carry (the latest value) to the end of
+// the chain and pays a separate 64-bit addition for it.
+CSH_HD inline int64_t mad_pinned(int32_t x, int32_t y, int64_t acc) {
+#if defined(__HIP_DEVICE_COMPILE__) && CSH_PIN_MADS == 2
+  uint64_t sd;
+  asm("v_mad_i64_i32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(sd) : "v"(x), "v"(y));
+#else
+  acc = (int64_t)x * (int64_t)y + acc;
+#if defined(__HIP_DEVICE_COMPILE__) && CSH_PIN_MADS == 1
+  asm("" : "+v"(acc));
+#elif defined(__HIP_DEVICE_COMPILE__) && CSH_PIN_MADS == 3
+  asm volatile("" ::"v"(acc));  // a second use of the partial sum: the reassociation pass only linearises single-use chains
+#endif
+#endif
+  return acc;
+}
+// the same with a wave-uniform second factor (a modulus limb) in a scalar register
+CSH_HD inline int64_t mad_pinned_s(int32_t x, int32_t y, int64_t acc) {
+#if defined(__HIP_DEVICE_COMPILE__) && CSH_PIN_MADS == 2
+  uint64_t sd;
+  asm("v_mad_i64_i32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(sd) : "v"(x), "s"(y));
+  return acc;
+#else
+  return mad_pinned(x, y, acc);
+#endif
+}
+
 template <class LP, class F32>
 struct FpS {
   static constexpr int NL = LP::NL;
@@ -357,6 +393,9 @@ struct FpS {
 
   // Montgomery reduction of a double-width value: (w + m p) / R', result in (-p/16, p + p/16) for |w| < 2^6 p R'/64
   CSH_HD static FpS reduce(Wide w) {
+#if CSH_REDUCE_SCAN
+    return reduce_scan([&](int k, int64_t acc) CSH_LAMBDA_INLINE { return acc + w.t[k]; });
+#endif
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
       const int32_t m = (int32_t)(((uint32_t)w.t[i] * LP::INV) & LP::MASK);
@@ -387,10 +426,118 @@ struct FpS {
     for (int k = 0; k < NL; ++k) w.t[NL + k] = (int64_t)s.l[k] * (int64_t)m1 + w.t[NL + k];
     return reduce(w);
   }
+  // ---- product-scanning Montgomery multiplication -----------------------------------------------------------------------
+  // The same sums as mul_wide() + reduce(), taken column by column: column k starts from the carry of column k - 1 (the
+  // addend of its first multiply-add), collects its operand products and the m_i p_(k-i) terms, and hands acc >> B on. A carry
+  // is then ONE shift instead of shift + 64-bit addition (16 instructions less per reduction), and only one 64-bit accumulator
+  // is live instead of 2 NL columns. `col(k, acc)` adds the operand products of column k. Bit-identical to the row-wise form.
+  // (column K as a template parameter: a #pragma unroll over the 2 NL columns exceeds the compiler's pragma-unroll size
+  // threshold at NL = 14 and silently stays a loop, with the column index -- and every limb index derived from it -- dynamic)
+  template <int K, class ColFn>
+  CSH_HD static void scan_column(ColFn& col, int32_t* m, FpS& r, int64_t& acc) {
+    acc = col(K, acc);
+    if constexpr (K < NL) {
+#pragma unroll
+      for (int i = 0; i < NL; ++i)
+        if (i < K) acc = mad_pinned_s(m[i], (int32_t)LP::MOD[K - i], acc);
+      m[K] = (int32_t)(((uint32_t)acc * LP::INV) & LP::MASK);
+      acc = mad_pinned_s(m[K], (int32_t)LP::MOD[0], acc);  // the low B bits are zero now
+      acc >>= B;
+    } else if constexpr (K < 2 * NL - 1) {
+#pragma unroll
+      for (int i = 0; i < NL; ++i)
+        if (i > K - NL) acc = mad_pinned_s(m[i], (int32_t)LP::MOD[K - i], acc);
+      r.l[K - NL] = (int32_t)((uint32_t)acc & LP::MASK);
+      acc >>= B;
+    } else {
+      r.l[NL - 1] = (int32_t)acc;
+    }
+    if constexpr (K + 1 < 2 * NL) scan_column<K + 1>(col, m, r, acc);
+  }
+  template <class ColFn>
+  CSH_HD static FpS reduce_scan(ColFn&& col) {
+    int32_t m[NL];
+    FpS r;
+    int64_t acc = 0;
+    scan_column<0>(col, m, r, acc);
+    return r;
+  }
+  // operand products of column k
+  CSH_HD static int64_t col_mul(const FpS& a, const FpS& b, int k, int64_t acc) {
+    CSH_LIMB_BOUND(a, LIM2, "col_mul(a)");
+    CSH_LIMB_BOUND(b, LIM1, "col_mul(b)");
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+      if (k - i >= 0 && k - i < NL) acc = mad_pinned(a.l[i], b.l[k - i], acc);
+    return acc;
+  }
+  // a^2: squares + doubled cross terms (a2 = 2 a)
+  CSH_HD static int64_t col_sqr(const FpS& a, const FpS& a2, int k, int64_t acc) {
+    CSH_LIMB_BOUND(a, LIM1, "col_sqr");
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int j = k - i;
+      if (j == i) acc = mad_pinned(a.l[i], a.l[i], acc);
+      else if (j > i && j < NL) acc = mad_pinned(a2.l[i], a.l[j], acc);
+    }
+    return acc;
+  }
+  // - b^2 (nb = -b, nb2 = -2 b)
+  CSH_HD static int64_t col_nsqr(const FpS& b, const FpS& nb, const FpS& nb2, int k, int64_t acc) {
+    CSH_LIMB_BOUND(b, LIM1, "col_nsqr");
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int j = k - i;
+      if (j == i) acc = mad_pinned(nb.l[i], b.l[i], acc);
+      else if (j > i && j < NL) acc = mad_pinned(nb2.l[i], b.l[j], acc);
+    }
+    return acc;
+  }
+  // - s_(k - NL) in the upper columns (reduce_sub's subtrahend), one multiply-add by a -1 the compiler cannot fold
+  CSH_HD static int64_t col_sub_hi(const FpS& s, int32_t m1, int k, int64_t acc) {
+    if (k >= NL) acc = mad_pinned_s(s.l[k - NL], m1, acc);
+    return acc;
+  }
+  CSH_HD static int32_t opaque_minus_one() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int32_t m1;
+    asm("s_mov_b32 %0, -1" : "=s"(m1));
+    return m1;
+#else
+    return -1;
+#endif
+  }
+#if CSH_REDUCE_SCAN
+  CSH_HD static FpS mul(const FpS& a, const FpS& b) {
+    CSH_LIMB_BOUND(a, LIM2, "mul(a)");
+    CSH_LIMB_BOUND(b, LIM1, "mul(b)");
+    return reduce_scan([&](int k, int64_t acc) CSH_LAMBDA_INLINE { return col_mul(a, b, k, acc); });
+  }
+  CSH_HD static FpS sqr(const FpS& a) {
+    CSH_LIMB_BOUND(a, LIM1, "sqr");
+    const FpS a2 = add(a, a);
+    return reduce_scan([&](int k, int64_t acc) CSH_LAMBDA_INLINE { return col_sqr(a, a2, k, acc); });
+  }
+  CSH_HD static FpS sqr_sub(const FpS& a, const FpS& s) {  // a^2 - s
+    CSH_LIMB_BOUND(a, LIM1, "sqr_sub");
+    const FpS a2 = add(a, a);
+    const int32_t m1 = opaque_minus_one();
+    return reduce_scan([&](int k, int64_t acc) CSH_LAMBDA_INLINE { return col_sub_hi(s, m1, k, col_sqr(a, a2, k, acc)); });
+  }
+  CSH_HD static FpS mul_sub(const FpS& a, const FpS& b, const FpS& c, const FpS& d) {  // a b - c d
+    CSH_LIMB_BOUND(a, LIM1, "mul_sub(a)");
+    CSH_LIMB_BOUND(b, LIM1, "mul_sub(b)");
+    CSH_LIMB_BOUND(c, LIM1, "mul_sub(c)");
+    CSH_LIMB_BOUND(d, LIM1, "mul_sub(d)");
+    const FpS nc = neg(c);
+    return reduce_scan([&](int k, int64_t acc) CSH_LAMBDA_INLINE { return col_mul(nc, d, k, col_mul(a, b, k, acc)); });
+  }
+#else
   CSH_HD static FpS mul(const FpS& a, const FpS& b) { return reduce(mul_wide(a, b)); }
   CSH_HD static FpS sqr(const FpS& a) { return reduce(sqr_wide(a)); }
   CSH_HD static FpS sqr_sub(const FpS& a, const FpS& s) { return reduce_sub(sqr_wide(a), s); }  // a^2 - s
   CSH_HD static FpS mul_sub(const FpS& a, const FpS& b, const FpS& c, const FpS& d) { return reduce(mul_sub_wide(a, b, c, d)); }
+#endif
 
   // exact value in [0, p) with limbs in [0, 2^B); input value must lie within (-2p, 4p)
   CSH_HD FpS canonical() const {
@@ -567,6 +714,25 @@ struct Fp2S {
   CSH_HD Fp2S normalized() const { return {c0.normalized(), c1.normalized()}; }
   CSH_HD Fp2S neg_unpacked() const { return {c0.neg_unpacked(), c1.neg_unpacked()}; }
   CSH_HD Fp2S cneg_unpacked(uint32_t neg01) const { return {c0.cneg_unpacked(neg01), c1.cneg_unpacked(neg01)}; }
+#if CSH_REDUCE_SCAN
+  CSH_HD static Fp2S mul(const Fp2S& a, const Fp2S& b) {
+    const LF na1 = LF::neg(a.c1);
+    return {LF::reduce_scan([&](int k, int64_t acc) CSH_LAMBDA_INLINE { return LF::col_mul(na1, b.c1, k, LF::col_mul(a.c0, b.c0, k, acc)); }),
+            LF::reduce_scan([&](int k, int64_t acc) CSH_LAMBDA_INLINE { return LF::col_mul(a.c1, b.c0, k, LF::col_mul(a.c0, b.c1, k, acc)); })};
+  }
+  CSH_HD static Fp2S sqr(const Fp2S& a) {
+    const LF a2 = LF::add(a.c0, a.c0), nb = LF::neg(a.c1), nb2 = LF::add(nb, nb);
+    return {LF::reduce_scan([&](int k, int64_t acc) CSH_LAMBDA_INLINE { return LF::col_nsqr(a.c1, nb, nb2, k, LF::col_sqr(a.c0, a2, k, acc)); }),
+            LF::mul(a2, a.c1)};
+  }
+  // a^2 - s (s: |limb| < 2^31)
+  CSH_HD static Fp2S sqr_sub(const Fp2S& a, const Fp2S& s) {
+    const LF a2 = LF::add(a.c0, a.c0), nb = LF::neg(a.c1), nb2 = LF::add(nb, nb);
+    const int32_t m1 = LF::opaque_minus_one();
+    return {LF::reduce_scan([&](int k, int64_t acc) CSH_LAMBDA_INLINE { return LF::col_sub_hi(s.c0, m1, k, LF::col_nsqr(a.c1, nb, nb2, k, LF::col_sqr(a.c0, a2, k, acc))); }),
+            LF::reduce_scan([&](int k, int64_t acc) CSH_LAMBDA_INLINE { return LF::col_sub_hi(s.c1, m1, k, LF::col_mul(a2, a.c1, k, acc)); })};
+  }
+#else
   CSH_HD static Fp2S mul(const Fp2S& a, const Fp2S& b) {
     return {LF::reduce(LF::mul_sub_wide(a.c0, b.c0, a.c1, b.c1)), LF::reduce(LF::mul_add_wide(a.c0, b.c1, a.c1, b.c0))};
   }
@@ -577,9 +743,19 @@ struct Fp2S {
   CSH_HD static Fp2S sqr_sub(const Fp2S& a, const Fp2S& s) {
     return {LF::reduce_sub(LF::sqr_sub_wide(a.c0, a.c1), s.c0), LF::reduce_sub(LF::mul_wide(LF::add(a.c0, a.c0), a.c1), s.c1)};
   }
+#endif
   // a*b - c*d
   CSH_HD static Fp2S mul_sub(const Fp2S& a, const Fp2S& b, const Fp2S& c, const Fp2S& d) {
     if constexpr (LF::FOUR_PRODUCTS_FIT) {
+#if CSH_REDUCE_SCAN
+      const LF na1 = LF::neg(a.c1), nc0 = LF::neg(c.c0), nc1 = LF::neg(c.c1);
+      return {LF::reduce_scan([&](int k, int64_t acc) CSH_LAMBDA_INLINE {
+                return LF::col_mul(c.c1, d.c1, k, LF::col_mul(nc0, d.c0, k, LF::col_mul(na1, b.c1, k, LF::col_mul(a.c0, b.c0, k, acc))));
+              }),
+              LF::reduce_scan([&](int k, int64_t acc) CSH_LAMBDA_INLINE {
+                return LF::col_mul(nc1, d.c0, k, LF::col_mul(nc0, d.c1, k, LF::col_mul(a.c1, b.c0, k, LF::col_mul(a.c0, b.c1, k, acc))));
+              })};
+#else
       typename LF::Wide w0 = LF::mul_sub_wide(a.c0, b.c0, a.c1, b.c1);
       LF::mac_wide(w0, c.c0, d.c0, true);
       LF::mac_wide(w0, c.c1, d.c1, false);
@@ -587,6 +763,7 @@ struct Fp2S {
       LF::mac_wide(w1, c.c0, d.c1, true);
       LF::mac_wide(w1, c.c1, d.c0, true);
       return {LF::reduce(w0), LF::reduce(w1)};
+#endif
     } else {
       // two products per accumulator, a carry sweep between the pairs, ONE reduction per component (instead of two full Fp2
       // products = four reductions, a limb-wise subtraction and a carry step)

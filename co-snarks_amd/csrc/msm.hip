@@ -106,6 +106,38 @@ int csh_bases_len(csh_bases_t bases, size_t* n) {
   *n = reinterpret_cast<Bases*>(bases)->n;
   return CSH_OK;
 }
+// A copy of a handle (points and fixed-base tables, already in the stored encoding) on another GPU: device-to-device, no host
+// staging and no re-encoding. The calling thread's device binding is restored.
+int csh_bases_clone(csh_bases_t src, int device, csh_bases_t* out) {
+  CSH_REQUIRE(src && out, "NULL argument");
+  const Bases* S = reinterpret_cast<const Bases*>(src);
+  int ndev = 0, cur = 0;
+  CSH_HIP(hipGetDeviceCount(&ndev));
+  CSH_REQUIRE(device >= 0 && device < ndev, "device out of range");
+  CSH_HIP(hipGetDevice(&cur));
+  Bases* B = new Bases(*S);
+  B->device = device;
+  B->points = nullptr;
+  B->table = nullptr;
+  const size_t pbytes = S->n * S->point_bytes, tbytes = S->table ? pbytes * (size_t)S->table_W : 0;
+  hipError_t e = hipSetDevice(device);
+  if (e == hipSuccess && pbytes) e = hipMalloc(&B->points, pbytes);
+  if (e == hipSuccess && tbytes) e = hipMalloc(&B->table, tbytes);
+  if (e == hipSuccess && pbytes) e = hipMemcpyPeer(B->points, device, S->points, S->device, pbytes);
+  if (e == hipSuccess && tbytes) e = hipMemcpyPeer(B->table, device, S->table, S->device, tbytes);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  (void)hipSetDevice(cur);
+  if (e != hipSuccess) {
+    const bool oom = e == hipErrorOutOfMemory;
+    if (B->points) (void)hipFree(B->points);
+    if (B->table) (void)hipFree(B->table);
+    delete B;
+    set_error("csh_bases_clone to device %d failed: %s", device, hipGetErrorString(e));
+    return oom ? CSH_ERR_OOM : CSH_ERR_HIP;
+  }
+  *out = reinterpret_cast<csh_bases_t>(B);
+  return CSH_OK;
+}
 int csh_bases_free(csh_bases_t bases) {
   if (!bases) return CSH_OK;
   Bases* B = reinterpret_cast<Bases*>(bases);
@@ -118,6 +150,30 @@ int csh_bases_free(csh_bases_t bases) {
 // Fixed-base window tables for a set of bases that is reused across MSMs (a proving key query): see msm_impl.hpp. c = 0
 // picks the window width (16 from 2^17 points on, narrower below); handles of fewer than 1024 points stay as they are.
 static int bases_precompute(csh_bases_t bases, int c, int groups);
+int csh_bases_table_policy(size_t key_points, int* c_out, int* rows_out) {
+  CSH_REQUIRE(c_out && rows_out, "c_out / rows_out is NULL");
+  *c_out = 0;
+  *rows_out = 0;
+  if (key_points < (size_t(1) << 14) || key_points > (size_t(1) << 21)) return CSH_OK;
+  int c = 16;
+  while (c > 10 && (size_t(1) << (c + 1)) > key_points) --c;
+  // up to 2^18 points one row per window pays (2^16 3.4 -> 3.2 ms, 2^18 5.4 -> 5.0 ms per proof, profiles/r02_g_prove_table_rows.log);
+  // above, 4 / 8 / 16 rows measure the same and 4 cost the least memory. (A 2^18-constraint key has 2^18 + a few wires.)
+  // (16 = "one row per window" at c = 16; with more windows the precompute clamps to the rows its W' = ceil(W / 16) references)
+  *c_out = c;
+  *rows_out = key_points <= (size_t(3) << 17) ? 16 : 4;
+  return CSH_OK;
+}
+int csh_bases_drop_tables(csh_bases_t bases) {
+  CSH_REQUIRE(bases, "bases is NULL");
+  Bases* B = reinterpret_cast<Bases*>(bases);
+  if (B->table) {
+    (void)hipFree(B->table);
+    B->table = nullptr;
+    B->table_c = B->table_W = 0;
+  }
+  return CSH_OK;
+}
 int csh_bases_precompute(csh_bases_t bases, int c) { return bases_precompute(bases, c, 0); }
 int csh_bases_precompute_grouped(csh_bases_t bases, int c, int groups) {
   CSH_REQUIRE(groups >= 2 && groups <= MAX_WINDOWS, "groups must be in [2, 128]");

@@ -897,8 +897,10 @@ int precompute_table_t(Bases* B, int c, int groups, hipStream_t st) {
   using Fq = typename Cfg::Fq;
   using Fr = typename Cfg::Fr;
   const int windows = windows_for(Fr::Params::BITS, c);
-  const int W = groups <= 0 || groups > windows ? windows : groups;  // table rows
-  const int step = c * ((windows + W - 1) / W);                    // doublings between rows: c * W'
+  const int asked = groups <= 0 || groups > windows ? windows : groups;
+  const int wp = (windows + asked - 1) / asked;                    // W': windows per bucket set
+  const int W = (windows + wp - 1) / wp;                           // table rows actually referenced (rows >= this would never be read)
+  const int step = c * wp;                                         // doublings between rows: c * W'
   void* t = nullptr;
   hipError_t e = hipMalloc(&t, sizeof(Affine<Fq>) * B->n * (size_t)W);
   if (e != hipSuccess) {

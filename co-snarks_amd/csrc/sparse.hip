@@ -167,12 +167,14 @@ int csh_matrix_info(csh_matrix_t mm, size_t* n_rows, size_t* nnz, uint32_t* max_
 }
 
 int csh_evaluate_constraints_dev(csh_matrix_t mm, int protocol, int party_id, const uint64_t* public_dev, size_t n_public,
-                                 const uint64_t* witness_dev, uint64_t* out_dev, size_t n_out, void* stream) {
+                                 const uint64_t* witness_dev, size_t n_witness, uint64_t* out_dev, size_t n_out, void* stream) {
   CSH_REQUIRE(mm && out_dev, "evaluate_constraints: NULL argument");
   CSH_REQUIRE(protocol == 0 || protocol == 1, "protocol must be 0 (plain/Shamir) or 1 (Rep3)");
   CSH_TRY(ensure_device());
   Matrix* m = reinterpret_cast<Matrix*>(mm);
   CSH_TRY(check_matrix_device(m));
+  // a matrix from an untrusted circuit must not index past the vectors the caller handed over (the kernel gathers by column)
+  CSH_REQUIRE(m->nnz == 0 || (size_t)m->max_col < n_public + n_witness, "evaluate_constraints: a matrix column index exceeds n_public + n_witness");
   hipStream_t st = resolve_stream(stream);
   if (m->curve == CSH_BN254) return eval_t<Bn254Fr>(m, protocol, party_id, public_dev, n_public, witness_dev, out_dev, n_out, st);
   if (m->curve == CSH_BLS12_377) return eval_t<Bls377Fr>(m, protocol, party_id, public_dev, n_public, witness_dev, out_dev, n_out, st);
@@ -181,7 +183,7 @@ int csh_evaluate_constraints_dev(csh_matrix_t mm, int protocol, int party_id, co
 
 // Device-resident core: witness already on the device, h stays on the device (scratch from the stream's arena)
 int csh_groth16_witness_map_dev(csh_domain_t dom, const uint64_t shift[4], int protocol, int party_id, csh_matrix_t ma, csh_matrix_t mb,
-                                size_t num_constraints, const uint64_t* public_inputs, size_t n_public, const uint64_t* witness_dev,
+                                size_t num_constraints, const uint64_t* public_inputs, size_t n_public, const uint64_t* witness_dev, size_t n_witness,
                                 const uint8_t seed1[32], uint64_t off1, const uint8_t seed2[32], uint64_t off2, uint64_t* h_out_dev, void* stream) {
   CSH_REQUIRE(dom && shift && ma && mb && h_out_dev && (public_inputs || n_public == 0) && witness_dev, "witness_map_dev: NULL argument");
   CSH_REQUIRE(protocol == 0 || protocol == 1, "protocol must be 0 (plain/Shamir) or 1 (Rep3)");
@@ -201,8 +203,8 @@ int csh_groth16_witness_map_dev(csh_domain_t dom, const uint64_t shift[4], int p
   uint64_t* dpub = reinterpret_cast<uint64_t*>(ar.take<char>(32 * n_public + 32));
   uint64_t *dmc = nullptr, *dmab = nullptr;
   if (n_public) CSH_HIP(hipMemcpyAsync(dpub, public_inputs, 32 * n_public, hipMemcpyHostToDevice, st));
-  CSH_TRY(csh_evaluate_constraints_dev(ma, protocol, party_id, dpub, n_public, witness_dev, da, n, st));   // reduction.rs:102-110
-  CSH_TRY(csh_evaluate_constraints_dev(mb, protocol, party_id, dpub, n_public, witness_dev, db, n, st));   // :118-127
+  CSH_TRY(csh_evaluate_constraints_dev(ma, protocol, party_id, dpub, n_public, witness_dev, n_witness, da, n, st));   // reduction.rs:102-110
+  CSH_TRY(csh_evaluate_constraints_dev(mb, protocol, party_id, dpub, n_public, witness_dev, n_witness, db, n, st));   // :118-127
   if (f == CSH_BN254) CSH_TRY(promote_t<Bn254Fr>(protocol, da, num_constraints, dpub, n_public, party_id, st));  // :111-113
   else if (f == CSH_BLS12_377) CSH_TRY(promote_t<Bls377Fr>(protocol, da, num_constraints, dpub, n_public, party_id, st));
   else CSH_TRY(promote_t<Bls381Fr>(protocol, da, num_constraints, dpub, n_public, party_id, st));
@@ -237,7 +239,7 @@ int csh_groth16_witness_map(csh_domain_t dom, const uint64_t shift[4], int proto
   uint64_t* dwit = reinterpret_cast<uint64_t*>(ar.take<char>(32 * comp * n_witness + 32));
   uint64_t* dh = reinterpret_cast<uint64_t*>(ar.take<char>(32 * n));
   if (n_witness) CSH_HIP(hipMemcpyAsync(dwit, witness, 32 * comp * n_witness, hipMemcpyHostToDevice, st));
-  CSH_TRY(csh_groth16_witness_map_dev(dom, shift, protocol, party_id, ma, mb, num_constraints, public_inputs, n_public, dwit, seed1, off1, seed2, off2,
+  CSH_TRY(csh_groth16_witness_map_dev(dom, shift, protocol, party_id, ma, mb, num_constraints, public_inputs, n_public, dwit, n_witness, seed1, off1, seed2, off2,
                                       dh, st));
   CSH_HIP(hipMemcpyAsync(h_out, dh, 32 * n, hipMemcpyDeviceToHost, st));
   CSH_HIP(hipStreamSynchronize(st));
@@ -274,12 +276,12 @@ int csh_groth16_witness_map_libsnark(csh_domain_t dom, const uint64_t generator[
   CSH_TRY(h.up(dh, nullptr, eb));
   CSH_TRY(h.up(dpub, public_inputs, 32 * n_public));
   CSH_TRY(h.up(dwit, witness, 32 * comp * n_witness));
-  CSH_TRY(csh_evaluate_constraints_dev(ma, protocol, party_id, dpub, n_public, dwit, da, n, h.st));    // reduction.rs:260-266
+  CSH_TRY(csh_evaluate_constraints_dev(ma, protocol, party_id, dpub, n_public, dwit, n_witness, da, n, h.st));    // reduction.rs:260-266
   if (f == CSH_BN254) CSH_TRY(promote_t<Bn254Fr>(protocol, da, num_constraints, dpub, n_public, party_id, h.st));  // :267-269
   else if (f == CSH_BLS12_377) CSH_TRY(promote_t<Bls377Fr>(protocol, da, num_constraints, dpub, n_public, party_id, h.st));
   else CSH_TRY(promote_t<Bls381Fr>(protocol, da, num_constraints, dpub, n_public, party_id, h.st));
-  CSH_TRY(csh_evaluate_constraints_dev(mb, protocol, party_id, dpub, n_public, dwit, db, n, h.st));    // :276-282
-  CSH_TRY(csh_evaluate_constraints_dev(mc, protocol, party_id, dpub, n_public, dwit, dcf, n, h.st));   // :292-298
+  CSH_TRY(csh_evaluate_constraints_dev(mb, protocol, party_id, dpub, n_public, dwit, n_witness, db, n, h.st));    // :276-282
+  CSH_TRY(csh_evaluate_constraints_dev(mc, protocol, party_id, dpub, n_public, dwit, n_witness, dcf, n, h.st));   // :292-298
   if (protocol == 1) {  // half share = component a
     CSH_TRY(h.up(dc, nullptr, eb));
     CSH_HIP(hipMemcpy2DAsync(dc, 32, dcf, 64, 32, n, hipMemcpyDeviceToDevice, h.st));

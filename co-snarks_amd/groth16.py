@@ -134,20 +134,63 @@ def translate_witness(curve: int, files):
     return res
 
 
+def set_prover_devices(devices):
+    """One prover's five query MSMs (rayon_join5, groth16.rs:227-294) over several GPUs: keys built afterwards clone their queries
+    onto `devices` (entry 0 = the key's home GPU; a GPU may be listed more than once). None / one entry switches it off."""
+    d = list(devices or [])
+    arr = (C.c_int * max(1, len(d)))(*d) if d else None
+    if glib().cog16_set_prover_devices(arr, len(d)) != 0:
+        raise CoSnarksHipError(glib().cog16_last_error().decode())
+
+
 def bench_synthetic(curve: int, log_domain: int, iters: int = 3, with_rep3: bool = False):
     """Plain Groth16 prove on a synthetic 2^log_domain circuit with a known-dlog key (closed-form check); optionally
-    also three in-process Rep3 parties proving the same circuit (BASELINE config 4 at scale)."""
+    also three in-process Rep3 parties proving the same circuit (BASELINE config 4 at scale). `prove_ms` = prove_inner with the
+    key resident; `prove_phases_ms` = host-clock phases INSIDE that prove (witness upload + device witness map, the five MSM groups
+    = create_proof_with_assignment up to the join, the finish); `witness_map_ms` = the standalone host-facing
+    witness_map_from_matrices (h returned to the host), a different code path."""
     ms = (C.c_double * 6)()
+    ph = (C.c_double * 3)()
     ok = C.c_int(0)
-    rc = glib().cog16_bench_synthetic(curve, log_domain, iters, ms, C.byref(ok), int(with_rep3))
+    rc = glib().cog16_bench_synthetic2(curve, log_domain, iters, ms, C.byref(ok), int(with_rep3), ph)
     if rc != 0:
         raise CoSnarksHipError(glib().cog16_last_error().decode())
-    out = {"log_domain": log_domain, "witness_map_ms": ms[0], "create_proof_ms": ms[1], "prove_ms": ms[2],
+    out = {"log_domain": log_domain, "witness_map_ms": ms[0], "prove_ms": ms[2],
+           "prove_phases_ms": {"witness_upload_and_map": ph[0], "msm_groups": ph[1], "finish": ph[2]},
            "key_setup_ms": ms[3], "closed_form_check": bool(ok.value)}
     if with_rep3:
         out["rep3_three_parties_prove_ms"] = ms[4]
         out["rep3_proofs_equal_plain"] = bool(ms[5])
     return out
+
+
+class SynthCircuit:
+    """The synthetic 2^log_domain-constraint circuit with its known-dlog proving key resident on the device (queries placed on
+    the GPUs of `set_prover_devices`, if any): `prove()` = one plain `prove_inner`, `check()` = closed-form check of a proof."""
+
+    def __init__(self, curve: int, log_domain: int):
+        self.h = C.c_void_p()
+        self.log_domain = log_domain
+        if glib().cog16_synth_open(curve, log_domain, C.byref(self.h)) != 0:
+            raise CoSnarksHipError(glib().cog16_last_error().decode())
+
+    def prove(self):
+        ph = (C.c_double * 3)()
+        key = C.c_double(0)
+        if glib().cog16_synth_prove(self.h, ph, C.byref(key)) != 0:
+            raise CoSnarksHipError(glib().cog16_last_error().decode())
+        return {"witness_upload_and_map": ph[0], "msm_groups": ph[1], "finish": ph[2], "key_setup_ms": key.value}
+
+    def check(self) -> bool:
+        ok = C.c_int(0)
+        if glib().cog16_synth_check(self.h, C.byref(ok)) != 0:
+            raise CoSnarksHipError(glib().cog16_last_error().decode())
+        return bool(ok.value)
+
+    def close(self):
+        if self.h:
+            glib().cog16_synth_close(self.h)
+            self.h = C.c_void_p()
 
 
 CIRCOM_REDUCTION, LIBSNARK_REDUCTION = 0, 1

@@ -429,94 +429,141 @@ struct Rep3Sharer {
   }
 };
 
+// The synthetic circuit with its known-dlog proving key resident on the device: built once, proved many times (bench.py times
+// K calls of prove() between barriers), checked against the closed form.
+struct SynthBase {
+  virtual ~SynthBase() = default;
+  virtual void prove(bool want_h) = 0;
+  virtual bool closed_form() = 0;
+  ProveTimes phases;
+  double key_ms = 0;
+};
 template <class P>
-int bench_synth_t(int log_domain, int iters, double* out_ms, int* check_ok, const uint32_t* g1_words, const uint32_t* g2_words, bool with_rep3) {
+struct SynthCircuit : SynthBase {
   using T = PlainGroth16Driver<P>;
   using Fr = typename P::Fr;
   using Fq = typename P::Fq;
   using Fq2 = typename P::Fq2;
-  const size_t domain = size_t(1) << log_domain;
-  const size_t nc = domain - 2, n_vars = nc + 3;
+  static constexpr uint64_t SA = 0x1000000000ull, SB1 = 0x2000000000ull, SB2 = 0x3000000000ull, SL = 0x4000000000ull, SH = 0x5000000000ull;
+  static constexpr uint64_t d_alpha = 0x1111, d_beta = 0x2222, d_delta = 0x3333;
+  size_t domain, nc, n_vars;
   AffineT<Fq> g1;
   AffineT<Fq2> g2;
-  memcpy(&g1, g1_words, sizeof g1);
-  memcpy(&g2, g2_words, sizeof g2);
-  auto t0 = std::chrono::steady_clock::now();
   ProvingKey<P> pk;
-  const uint64_t SA = 0x1000000000ull, SB1 = 0x2000000000ull, SB2 = 0x3000000000ull, SL = 0x4000000000ull, SH = 0x5000000000ull;
-  synth_query<Fq>(P::ID, CSH_G1, SA, n_vars, pk.a_query);
-  synth_query<Fq>(P::ID, CSH_G1, SB1, n_vars, pk.b_g1_query);
-  synth_query<Fq2>(P::ID, CSH_G2, SB2, n_vars, pk.b_g2_query);
-  synth_query<Fq>(P::ID, CSH_G1, SL, n_vars - 2, pk.l_query);
-  synth_query<Fq>(P::ID, CSH_G1, SH, domain, pk.h_query);
-  pk.build_tables();
-  const uint64_t d_alpha = 0x1111, d_beta = 0x2222, d_delta = 0x3333;
-  auto kG1 = [&](uint64_t k) { return into_affine(point_mul(into_group(g1), Fr::from_u64(k))); };
-  auto kG2 = [&](uint64_t k) { return into_affine(point_mul(into_group(g2), Fr::from_u64(k))); };
-  pk.alpha_g1 = kG1(d_alpha);
-  pk.beta_g1 = kG1(d_beta);
-  pk.beta_g2 = kG2(d_beta);
-  pk.delta_g1 = kG1(d_delta);
-  pk.delta_g2 = kG2(d_delta);
-  out_ms[3] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   ConstraintMatrices<P> m;
-  m.num_instance_variables = 2;
-  m.num_witness_variables = n_vars - 2;
-  m.num_constraints = nc;
-  m.a.resize(nc);
-  m.b.resize(nc);
-  const Fr one = Fr::one();
-  for (size_t j = 0; j < nc; ++j) {
-    m.a[j].push_back({one, j + 1});
-    m.b[j].push_back({one, j + 2});
-  }
-  m.upload();
-  std::vector<Fr> w(n_vars);
-  w[0] = one;
-  w[1] = Fr::from_u64(3);
-  w[2] = Fr::from_u64(5);
-  for (size_t j = 0; j < nc; ++j) w[j + 3] = Fr::mul(w[j + 1], w[j + 2]);
+  std::vector<Fr> w, h;
   SharedWitness<P, Fr> sw;
-  sw.public_inputs.assign(w.begin(), w.begin() + 2);
-  sw.witness.assign(w.begin() + 2, w.end());
-  const Fr r = Fr::from_u64(123456789), s = Fr::from_u64(987654321);
+  Fr r, s;
   UnitState st0, st1;
-  double best_h = 1e30, best_total = 1e30;
   Proof<P> proof;
-  std::vector<Fr> h;
+  SynthCircuit(int log_domain, const uint32_t* g1_words, const uint32_t* g2_words) {
+    domain = size_t(1) << log_domain;
+    nc = domain - 2;
+    n_vars = nc + 3;
+    memcpy(&g1, g1_words, sizeof g1);
+    memcpy(&g2, g2_words, sizeof g2);
+    auto t0 = std::chrono::steady_clock::now();
+    synth_query<Fq>(P::ID, CSH_G1, SA, n_vars, pk.a_query);
+    synth_query<Fq>(P::ID, CSH_G1, SB1, n_vars, pk.b_g1_query);
+    synth_query<Fq2>(P::ID, CSH_G2, SB2, n_vars, pk.b_g2_query);
+    synth_query<Fq>(P::ID, CSH_G1, SL, n_vars - 2, pk.l_query);
+    synth_query<Fq>(P::ID, CSH_G1, SH, domain, pk.h_query);
+    pk.build_tables();
+    pk.place_default();
+    auto kG1 = [&](uint64_t k) { return into_affine(point_mul(into_group(g1), Fr::from_u64(k))); };
+    auto kG2 = [&](uint64_t k) { return into_affine(point_mul(into_group(g2), Fr::from_u64(k))); };
+    pk.alpha_g1 = kG1(d_alpha);
+    pk.beta_g1 = kG1(d_beta);
+    pk.beta_g2 = kG2(d_beta);
+    pk.delta_g1 = kG1(d_delta);
+    pk.delta_g2 = kG2(d_delta);
+    key_ms = ms_since(t0);
+    m.num_instance_variables = 2;
+    m.num_witness_variables = n_vars - 2;
+    m.num_constraints = nc;
+    m.a.resize(nc);
+    m.b.resize(nc);
+    const Fr one = Fr::one();
+    for (size_t j = 0; j < nc; ++j) {
+      m.a[j].push_back({one, j + 1});
+      m.b[j].push_back({one, j + 2});
+    }
+    m.upload();
+    w.resize(n_vars);
+    w[0] = one;
+    w[1] = Fr::from_u64(3);
+    w[2] = Fr::from_u64(5);
+    for (size_t j = 0; j < nc; ++j) w[j + 3] = Fr::mul(w[j + 1], w[j + 2]);
+    sw.public_inputs.assign(w.begin(), w.begin() + 2);
+    sw.witness.assign(w.begin() + 2, w.end());
+    r = Fr::from_u64(123456789);
+    s = Fr::from_u64(987654321);
+  }
+  // h is only fetched (for the closed-form check) when asked: a prover does not need it on the host
+  void prove(bool want_h) override {
+    proof = CoGroth16<P, T>::template prove_inner<CircomReduction>(nullptr, nullptr, st0, st1, pk, m, sw, &r, &s, want_h ? &h : nullptr);
+    phases = last_prove_times();
+  }
+  static bool eq1(const AffineT<Fq>& x, const AffineT<Fq>& y) { return x.x == y.x && x.y == y.y; }
+  bool closed_form() override {
+    if (h.size() != domain) prove(true);
+    auto dl = [](uint64_t seed, size_t i) { return Fr::from_u64(csh_util_splitmix64(seed + i) | 1ull); };
+    Fr sa = Fr::zero(), sb1 = Fr::zero(), sb2 = Fr::zero(), sl = Fr::zero(), sh = Fr::zero();
+    for (size_t i = 0; i < n_vars; ++i) {
+      sa = Fr::add(sa, Fr::mul(w[i], dl(SA, i)));
+      sb1 = Fr::add(sb1, Fr::mul(w[i], dl(SB1, i)));
+      sb2 = Fr::add(sb2, Fr::mul(w[i], dl(SB2, i)));
+    }
+    for (size_t j = 0; j + 2 < n_vars; ++j) sl = Fr::add(sl, Fr::mul(w[j + 2], dl(SL, j)));
+    for (size_t i = 0; i < domain; ++i) sh = Fr::add(sh, Fr::mul(h[i], dl(SH, i)));
+    const Fr dd = Fr::from_u64(d_delta);
+    Fr dA = Fr::add(Fr::add(Fr::mul(r, dd), Fr::from_u64(d_alpha)), sa);
+    Fr dB1 = Fr::add(Fr::add(Fr::mul(s, dd), Fr::from_u64(d_beta)), sb1);
+    Fr dB2 = Fr::add(Fr::add(Fr::mul(s, dd), Fr::from_u64(d_beta)), sb2);
+    Fr dC = Fr::add(Fr::add(Fr::sub(Fr::add(Fr::mul(s, dA), Fr::mul(r, dB1)), Fr::mul(Fr::mul(r, s), dd)), sl), sh);
+    AffineT<Fq> wa = into_affine(point_mul(into_group(g1), dA)), wc = into_affine(point_mul(into_group(g1), dC));
+    AffineT<Fq2> wb = into_affine(point_mul(into_group(g2), dB2));
+    return eq1(wa, proof.a) && eq1(wc, proof.c) && wb.x == proof.b.x && wb.y == proof.b.y;
+  }
+};
+
+template <class P>
+int bench_synth_t(int log_domain, int iters, double* out_ms, int* check_ok, const uint32_t* g1_words, const uint32_t* g2_words, bool with_rep3,
+                  double* phases_out = nullptr) {
+  using T = PlainGroth16Driver<P>;
+  using Fr = typename P::Fr;
+  using Fq = typename P::Fq;
+  SynthCircuit<P> sc(log_domain, g1_words, g2_words);
+  ProvingKey<P>& pk = sc.pk;
+  ConstraintMatrices<P>& m = sc.m;
+  SharedWitness<P, Fr>& sw = sc.sw;
+  const Fr r = sc.r, s = sc.s;
+  out_ms[3] = sc.key_ms;
+  double best_h = 1e30, best_total = 1e30;
+  ProveTimes best_phases;
   for (int it = 0; it < iters; ++it) {
     auto a0 = std::chrono::steady_clock::now();
-    std::vector<Fr> hh = CircomReduction::witness_map_from_matrices<P, T>(st0, m, sw.public_inputs, sw.witness);
+    std::vector<Fr> hh = CircomReduction::witness_map_from_matrices<P, T>(sc.st0, m, sw.public_inputs, sw.witness);
     auto a1 = std::chrono::steady_clock::now();
-    // h is only fetched (for the closed-form check) on the last iteration: a prover does not need it on the host
-    proof = CoGroth16<P, T>::template prove_inner<CircomReduction>(nullptr, nullptr, st0, st1, pk, m, sw, &r, &s, it + 1 == iters ? &h : nullptr);
-    auto a2 = std::chrono::steady_clock::now();
+    sc.prove(it + 1 == iters);
+    const double total = ms_since(a1);
     best_h = std::min(best_h, std::chrono::duration<double, std::milli>(a1 - a0).count());
-    best_total = std::min(best_total, std::chrono::duration<double, std::milli>(a2 - a1).count());
+    if (total < best_total) {
+      best_total = total;
+      best_phases = sc.phases;
+    }
   }
   out_ms[0] = best_h;               // host-facing witness_map_from_matrices alone (witness up, device pipeline, h down)
-  out_ms[1] = best_total - best_h;  // prove minus that (the device-resident prove skips the h round trip, so this can
-                                    // under-state create_proof_with_assignment; kept for continuity)
+  out_ms[1] = best_phases.msm_ms;   // the five MSM groups of the best prove (create_proof_device up to the join), host clock
   out_ms[2] = best_total;           // Groth16 prove (prove_inner), key resident on the device
-  // closed-form check
-  auto dl = [](uint64_t seed, size_t i) { return Fr::from_u64(csh_util_splitmix64(seed + i) | 1ull); };
-  Fr sa = Fr::zero(), sb1 = Fr::zero(), sb2 = Fr::zero(), sl = Fr::zero(), sh = Fr::zero();
-  for (size_t i = 0; i < n_vars; ++i) {
-    sa = Fr::add(sa, Fr::mul(w[i], dl(SA, i)));
-    sb1 = Fr::add(sb1, Fr::mul(w[i], dl(SB1, i)));
-    sb2 = Fr::add(sb2, Fr::mul(w[i], dl(SB2, i)));
+  if (phases_out) {
+    phases_out[0] = best_phases.witness_ms;  // witness upload + device-resident witness map inside that prove
+    phases_out[1] = best_phases.msm_ms;
+    phases_out[2] = best_phases.finish_ms;
   }
-  for (size_t j = 0; j + 2 < n_vars; ++j) sl = Fr::add(sl, Fr::mul(w[j + 2], dl(SL, j)));
-  for (size_t i = 0; i < domain; ++i) sh = Fr::add(sh, Fr::mul(h[i], dl(SH, i)));
-  const Fr dd = Fr::from_u64(d_delta);
-  Fr dA = Fr::add(Fr::add(Fr::mul(r, dd), Fr::from_u64(d_alpha)), sa);
-  Fr dB1 = Fr::add(Fr::add(Fr::mul(s, dd), Fr::from_u64(d_beta)), sb1);
-  Fr dB2 = Fr::add(Fr::add(Fr::mul(s, dd), Fr::from_u64(d_beta)), sb2);
-  Fr dC = Fr::add(Fr::add(Fr::sub(Fr::add(Fr::mul(s, dA), Fr::mul(r, dB1)), Fr::mul(Fr::mul(r, s), dd)), sl), sh);
+  *check_ok = sc.closed_form();
+  const Proof<P>& proof = sc.proof;
   auto eq1 = [](const AffineT<Fq>& x, const AffineT<Fq>& y) { return x.x == y.x && x.y == y.y; };
-  AffineT<Fq> wa = into_affine(point_mul(into_group(g1), dA)), wc = into_affine(point_mul(into_group(g1), dC));
-  AffineT<Fq2> wb = into_affine(point_mul(into_group(g2), dB2));
-  *check_ok = eq1(wa, proof.a) && eq1(wc, proof.c) && wb.x == proof.b.x && wb.y == proof.b.y;
 
   // BASELINE config 4 at scale: three in-process Rep3 parties (device ChaCha12 masks, two-component NTTs, half-share MSMs)
   // prove the same circuit with the same r, s; they share this GPU (or take one GPU each when the node has several, with
@@ -1117,10 +1164,15 @@ int cog16_prove_shamir(int curve, const uint8_t* zkey, size_t zlen, const uint8_
 
 // out_ms[6] = {witness_map ms, create_proof ms, total prove ms, key generation+upload ms, three-party Rep3 prove wall ms,
 // Rep3 proofs == plain proof (1/0)}; best of `iters`.
+int cog16_bench_synthetic2(int curve, int log_domain, int iters, double* out_ms /* 6 entries */, int* check_ok, int with_rep3,
+                           double* phases_out /* 3 entries: witness, msm, finish ms of the best prove; nullable */);
 int cog16_bench_synthetic(int curve, int log_domain, int iters, double* out_ms /* 6 entries */, int* check_ok, int with_rep3) {
+  return cog16_bench_synthetic2(curve, log_domain, iters, out_ms, check_ok, with_rep3, nullptr);
+}
+int cog16_bench_synthetic2(int curve, int log_domain, int iters, double* out_ms, int* check_ok, int with_rep3, double* phases_out) {
   try {
-    if (curve == 0) return bench_synth_t<Bn254>(log_domain, iters, out_ms, check_ok, csh::Bn254G1Gen, csh::Bn254G2Gen, with_rep3 != 0);
-    if (curve == 1) return bench_synth_t<Bls12_381>(log_domain, iters, out_ms, check_ok, csh::Bls381G1Gen, csh::Bls381G2Gen, with_rep3 != 0);
+    if (curve == 0) return bench_synth_t<Bn254>(log_domain, iters, out_ms, check_ok, csh::Bn254G1Gen, csh::Bn254G2Gen, with_rep3 != 0, phases_out);
+    if (curve == 1) return bench_synth_t<Bls12_381>(log_domain, iters, out_ms, check_ok, csh::Bls381G1Gen, csh::Bls381G2Gen, with_rep3 != 0, phases_out);
     g_err = "unknown curve";
     return -1;
   } catch (const std::exception& e) {
@@ -1131,6 +1183,74 @@ int cog16_bench_synthetic(int curve, int log_domain, int iters, double* out_ms /
 
 
 const char* cog16_last_error(void) { return g_err.c_str(); }
+
+// The synthetic circuit as an object: open (key + matrices + witness resident), prove (one plain prove_inner, phases out),
+// check (closed form), close. bench.py's `--workload groth16_prove` times K cog16_synth_prove calls between barriers.
+int cog16_synth_open(int curve, int log_domain, void** out) {
+  try {
+    if (!out || log_domain < 3 || log_domain > 26) throw Error("cog16_synth_open: bad arguments");
+    if (curve == 0) *out = static_cast<SynthBase*>(new SynthCircuit<Bn254>(log_domain, csh::Bn254G1Gen, csh::Bn254G2Gen));
+    else if (curve == 1) *out = static_cast<SynthBase*>(new SynthCircuit<Bls12_381>(log_domain, csh::Bls381G1Gen, csh::Bls381G2Gen));
+    else throw Error("unknown curve");
+    return 0;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+int cog16_synth_prove(void* h, double* phases_out /* witness, msm, finish ms; nullable */, double* key_ms /* nullable */) {
+  try {
+    if (!h) throw Error("cog16_synth_prove: NULL handle");
+    SynthBase* c = static_cast<SynthBase*>(h);
+    c->prove(false);
+    if (phases_out) {
+      phases_out[0] = c->phases.witness_ms;
+      phases_out[1] = c->phases.msm_ms;
+      phases_out[2] = c->phases.finish_ms;
+    }
+    if (key_ms) *key_ms = c->key_ms;
+    return 0;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+int cog16_synth_check(void* h, int* ok) {
+  try {
+    if (!h || !ok) throw Error("cog16_synth_check: NULL argument");
+    SynthBase* c = static_cast<SynthBase*>(h);
+    c->prove(true);
+    *ok = c->closed_form() ? 1 : 0;
+    return 0;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+int cog16_synth_close(void* h) {
+  delete static_cast<SynthBase*>(h);
+  return 0;
+}
+
+// One prover's five query MSMs over several GPUs: keys built after this call clone their queries onto `devices` (entry 0 = the
+// key's home GPU; a GPU may be listed more than once, which is how the single-GPU tests exercise the path). n <= 1 switches it off.
+int cog16_set_prover_devices(const int* devices, int n) {
+  try {
+    int ndev = 0;
+    check(csh_device_count(&ndev), "csh_device_count");
+    std::vector<int> d;
+    for (int i = 0; i < n; ++i) {
+      if (!devices || devices[i] < 0 || devices[i] >= (ndev > 0 ? ndev : 1)) throw Error("cog16_set_prover_devices: device out of range");
+      d.push_back(devices[i]);
+    }
+    std::lock_guard<std::mutex> g(ProverDevices::get().mu);
+    ProverDevices::get().devices = d.size() > 1 ? d : std::vector<int>();
+    return 0;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return -1;
+  }
+}
 
 int cog16_prove_plain(int curve, const uint8_t* zkey, size_t zlen, const uint8_t* wtns, size_t wlen, const uint64_t* r, const uint64_t* s,
                       char* out_json, size_t cap, uint64_t* h_out, size_t h_cap_elems) {

@@ -2,6 +2,7 @@
 // create_proof_with_assignment}, groth16_roots_of_unity) and groth16/reduction.rs (R1CSToQAP,
 // CircomReduction) above the C ABI. Same control flow, line-cited; the hot calls go to the device.
 #pragma once
+#include <memory>
 #include <map>
 #include <tuple>
 #include <type_traits>
@@ -100,11 +101,11 @@ struct CircomReduction {
     if constexpr (T::DEVICE_MASKS) {
       auto run = state.rand.take_device_run(2 * domain_size);
       rc = csh_groth16_witness_map_dev(domain, (const uint64_t*)&coset_shift, T::PROTOCOL, state.id, matrices.a_dev, matrices.b_dev, num_constraints,
-                                       (const uint64_t*)public_inputs.data(), num_inputs, (const uint64_t*)witness_dev.dev, run.seed1, run.off1,
+                                       (const uint64_t*)public_inputs.data(), num_inputs, (const uint64_t*)witness_dev.dev, witness_dev.n, run.seed1, run.off1,
                                        run.seed2, run.off2, (uint64_t*)h.dev, nullptr);
     } else {
       rc = csh_groth16_witness_map_dev(domain, (const uint64_t*)&coset_shift, T::PROTOCOL, state.id, matrices.a_dev, matrices.b_dev, num_constraints,
-                                       (const uint64_t*)public_inputs.data(), num_inputs, (const uint64_t*)witness_dev.dev, nullptr, 0, nullptr, 0,
+                                       (const uint64_t*)public_inputs.data(), num_inputs, (const uint64_t*)witness_dev.dev, witness_dev.n, nullptr, 0, nullptr, 0,
                                        (uint64_t*)h.dev, nullptr);
     }
     check(rc, "csh_groth16_witness_map_dev");
@@ -323,30 +324,78 @@ struct CoGroth16 {
     // rayon_join5 (:227-294): five independent MSM groups. The four that consume aux_assignment (A, B/G1, B/G2, L) share
     // one digit decomposition + bucket sort on the device (csh_msm_multi_dev); h_query runs from a second host thread.
     Span* sp_msm = new Span("5 msm groups (compute A, B/G1, B/G2, msm l_query, msm h_query)");
+    const auto t_msm0 = std::chrono::steady_clock::now();
     int cur_dev = 0;
     (void)csh_current_device(&cur_dev);
     // workers carry their exception back to join() (a plain std::thread would std::terminate on a HIP OOM in an MSM)
-    Joined t5([&] {
-      check(csh_init(cur_dev), "csh_init");  // a new host thread is not bound to the parent's GPU
-      h_acc = T::template msm_public_points_hs<Fq>(BasesView{pkey.h_query.dev, 0, pkey.h_query.size()}, h_dev);
-    });
     const size_t pub_len = inputs.size();
     const size_t n_aux = aux_dev.n;
     const bool same_len = pkey.a_query.size() == 1 + pub_len + n_aux && pkey.b_g1_query.size() == 1 + pub_len + n_aux &&
                           pkey.b_g2_query.size() == 1 + pub_len + n_aux && pkey.l_query.size() == n_aux && n_aux > 0 &&
                           !getenv("COG16_SEPARATE_MSMS");
+    // (a placement only applies to the shared-sort path: the fallback below runs every MSM on this GPU)
+    const bool h_at_home = !same_len || !pkey.placed() || pkey.placement.slot[ProvingKey<P>::Q_H] == 0;
+    Joined t5([&] {
+      if (!h_at_home) return;
+      check(csh_init(cur_dev), "csh_init");  // a new host thread is not bound to the parent's GPU
+      h_acc = T::template msm_public_points_hs<Fq>(BasesView{pkey.h_query.dev, 0, pkey.h_query.size()}, h_dev);
+    });
     if (same_len) {
+      using PK = ProvingKey<P>;
       csh::Jac<Fq> ja, jb1, jl;
       csh::Jac<Fq2> jb2;
-      // G2 first: its host fold (Horner over Fp2 windows, ~3x a G1 fold) then runs under the G1 bucket stages that follow
-      const csh_bases_t hs[4] = {pkey.b_g2_query.dev, pkey.a_query.dev, pkey.b_g1_query.dev, pkey.l_query.dev};
-      const size_t offs[4] = {1 + pub_len, 1 + pub_len, 1 + pub_len, 0};
-      void* const outs[4] = {&jb2, &ja, &jb1, &jl};
-      int rc = csh_msm_multi_dev(hs, offs, 4, n_aux, reinterpret_cast<const uint64_t*>(aux_dev.dev), 1, outs, nullptr);
-      if (rc != CSH_OK) {
-        t5.join_quiet();
-        check(rc, "csh_msm_multi_dev");
+      // One slot = the queries placed on one GPU (ProvingKey::place; without a placement everything is slot 0 = this GPU). The
+      // queries of a slot that consume aux_assignment share one digit decomposition + bucket sort (csh_msm_multi_dev), G2 first:
+      // its host fold (Horner over Fp2 windows, ~3x a G1 fold) then runs under the G1 bucket stages that follow.
+      auto run_aux_queries = [&](int slot, const void* aux_scalars) {
+        const int qs[4] = {PK::Q_B2, PK::Q_A, PK::Q_B1, PK::Q_L};
+        void* const res[4] = {&jb2, &ja, &jb1, &jl};
+        csh_bases_t hs[4];
+        size_t offs[4];
+        void* outs[4];
+        size_t k = 0;
+        for (int i = 0; i < 4; ++i) {
+          if (pkey.placement.slot[qs[i]] != slot) continue;
+          hs[k] = pkey.handle_for(qs[i]);
+          offs[k] = qs[i] == PK::Q_L ? 0 : 1 + pub_len;
+          outs[k] = res[i];
+          ++k;
+        }
+        if (k) check(csh_msm_multi_dev(hs, offs, k, n_aux, reinterpret_cast<const uint64_t*>(aux_scalars), 1, outs, nullptr), "csh_msm_multi_dev");
+      };
+      // the slots on other GPUs: one host thread each, bound to its GPU; the scalars arrive by peer copy (32 bytes per entry over
+      // xGMI), the results are 3 curve points per query on the host
+      std::vector<std::unique_ptr<Joined>> remote;
+      const size_t nslots = pkey.placed() ? pkey.placement.devices.size() : 1;  // (unplaced: every slot[] entry is 0)
+      for (size_t sl = 1; sl < nslots; ++sl) {
+        bool any_aux = false;
+        for (int q : {PK::Q_B2, PK::Q_A, PK::Q_B1, PK::Q_L}) any_aux |= pkey.placement.slot[q] == (int)sl;
+        const bool has_h = pkey.placement.slot[PK::Q_H] == (int)sl;
+        if (!any_aux && !has_h) continue;
+        const int dev = pkey.placement.devices[sl];
+        remote.emplace_back(new Joined([&, sl, dev, any_aux, has_h] {
+          check(csh_init(dev), "csh_init");
+          Span sp("msm group on another GPU (peer copy of the scalars + its queries)");
+          if (any_aux) {
+            const DeviceScalars aux_l(n_aux);
+            check(csh_memcpy_peer(aux_l.dev, dev, aux_dev.dev, aux_dev.device, n_aux * sizeof(Half), nullptr), "csh_memcpy_peer");
+            run_aux_queries((int)sl, aux_l.dev);
+          }
+          if (has_h) {
+            const DeviceScalars h_l(h_dev.n);
+            check(csh_memcpy_peer(h_l.dev, dev, h_dev.dev, h_dev.device, h_dev.n * sizeof(Half), nullptr), "csh_memcpy_peer");
+            h_acc = T::template msm_public_points_hs<Fq>(BasesView{pkey.handle_for(PK::Q_H), 0, pkey.h_query.size()}, h_l);
+          }
+        }));
       }
+      try {
+        run_aux_queries(0, aux_dev.dev);
+      } catch (...) {
+        t5.join_quiet();
+        for (auto& r : remote) r->join_quiet();
+        throw;
+      }
+      for (auto& r : remote) r->join();
       auto to_proj = [](const auto& j) {
         using F = typename std::decay<decltype(j.x)>::type;
         return j.is_inf() ? Proj<F>::inf() : Proj<F>::from_affine(AffineT<F>{j.x, j.y});
@@ -366,6 +415,8 @@ struct CoGroth16 {
       t1.join(); t2.join(); t3.join(); t4.join(); t5.join();  // the first failure is rethrown; ~Joined reaps the rest
     }
     delete sp_msm;
+    last_prove_times().msm_ms = ms_since(t_msm0);
+    const auto t_fin0 = std::chrono::steady_clock::now();
     Span sp_fin("finish - open two points and some adds");
 
     Half rs = T::local_mul_vec({r}, {s}, state0).back();                                     // :297
@@ -389,7 +440,9 @@ struct CoGroth16 {
       net_leg(net0, net1, [&] { g_c_opened = T::template open_half_point<Fq>(g_c, net0, state0); });
       n1.join();
     }
-    return Proof<P>{into_affine(g_a_opened), into_affine(g_c_opened), into_affine(g2_b_opened)};
+    Proof<P> proof{into_affine(g_a_opened), into_affine(g_c_opened), into_affine(g2_b_opened)};
+    last_prove_times().finish_ms = ms_since(t_fin0);
+    return proof;
   }
 
   // prove_inner for a witness that is already a device vector of shares (e.g. ingested straight from a wtns image,
@@ -432,10 +485,12 @@ struct CoGroth16 {
       if (R::template device_map_available<P>(matrices)) {
         // device-resident proof: the witness shares cross PCIe once, h never leaves the device unless asked for
         constexpr size_t COMPS = sizeof(Share) / sizeof(Fr);
+        const auto t_wit0 = std::chrono::steady_clock::now();
         Span* sp_up = new Span("upload witness shares");
         const DeviceScalars wit_dev(w.witness.data(), w.witness.size(), COMPS);
         delete sp_up;
         const DeviceScalars h_dev = R::template witness_map_device<P, T>(state0, matrices, w.public_inputs, wit_dev);
+        last_prove_times().witness_ms = ms_since(t_wit0);
         Share r = T::rand(net0, state0), s = T::rand(net0, state0);
         if (r_in) r = *r_in;
         if (s_in) s = *s_in;

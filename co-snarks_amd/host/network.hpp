@@ -70,8 +70,8 @@ struct LocalFabric {
 // A worker thread whose exception is carried back to the joiner (std::thread would call std::terminate): the two network
 // legs of mpc_net::join (mpc-net/src/lib.rs:139-148) and the MSM closures of rayon_join5 (groth16.rs:227-294).
 struct Joined {
+  std::exception_ptr err;  // declared (hence initialised) BEFORE the thread that may assign it starts
   std::thread th;
-  std::exception_ptr err;
   template <class Fn>
   explicit Joined(Fn fn) : th([this, fn]() mutable {
     try {

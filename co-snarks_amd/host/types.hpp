@@ -95,6 +95,34 @@ inline void parallel_for(size_t n, size_t min_len, Fn fn) {
   for (auto& t : th) t.join();
 }
 
+// Process-wide device list for one prover's MSM placement (cog16_set_prover_devices): keys built afterwards spread their five
+// queries over these GPUs (ProvingKey::place); entry 0 stands for the key's home GPU whatever its value. Empty / one entry: off.
+struct ProverDevices {
+  std::mutex mu;
+  std::vector<int> devices;
+  static ProverDevices& get() {
+    static ProverDevices d;
+    return d;
+  }
+  std::vector<int> snapshot() {
+    std::lock_guard<std::mutex> g(mu);
+    return devices;
+  }
+};
+
+// wall-clock phases of the calling thread's last prove_inner (host clock around synchronous device work): witness upload + map,
+// the five MSM groups, the finish (openings, a few point operations)
+struct ProveTimes {
+  double witness_ms = 0, msm_ms = 0, finish_ms = 0;
+};
+inline ProveTimes& last_prove_times() {
+  static thread_local ProveTimes t;
+  return t;
+}
+inline double ms_since(std::chrono::steady_clock::time_point t0) {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
 // scalars uploaded once and shared by several MSMs (the four queries that consume aux_assignment)
 // Device buffers are recycled across proofs: hipMalloc / hipFree cost 0.1-1 ms each (hipFree also drains the device),
 // a prover asks for the same few sizes every time.
@@ -234,17 +262,74 @@ struct ProvingKey {
   void build_tables() {
     size_t big = 0;
     for (size_t n : {a_query.size(), b_g1_query.size(), l_query.size(), h_query.size(), b_g2_query.size()}) big = n > big ? n : big;
-    // up to 2^18 points one row per window pays (every window into one bucket set: 2^16 3.4 -> 3.2 ms, 2^18 5.4 -> 5.0 ms per
-    // proof, profiles/r02_g_prove_table_rows.log); above, 4 / 8 / 16 rows measure the same and 4 cost the least memory
-    int rows = big <= (size_t(3) << 17) ? 16 : 4;  // (a 2^18-constraint key has 2^18 + a few wires)
+    // the policy lives in the library (csh_bases_table_policy: 16 rows up to ~2^18 points, 4 above, none outside 2^14..2^21), shared
+    // with the Rust bases cache; profiles/r02_g_prove_table_rows.log
+    int c = 0, rows = 0;
+    check(csh_bases_table_policy(big, &c, &rows), "csh_bases_table_policy");
     if (const char* e = getenv("COG16_TABLES")) rows = atoi(e);
-    if (rows < 2 || big < (size_t(1) << 14) || big > (size_t(1) << 21)) return;
-    int c = 16;
-    while (c > 10 && (size_t(1) << (c + 1)) > big) --c;
-    for (csh_bases_t h : {a_query.dev, b_g1_query.dev, l_query.dev, h_query.dev, b_g2_query.dev})
-      if (h) check(csh_bases_precompute_grouped(h, c, rows), "csh_bases_precompute_grouped");
+    if (rows < 2 || c == 0) return;
+    for (csh_bases_t h : {a_query.dev, b_g1_query.dev, l_query.dev, h_query.dev, b_g2_query.dev}) {
+      if (!h) continue;
+      const int rc = csh_bases_precompute_grouped(h, c, rows);
+      if (rc == CSH_ERR_OOM) {  // tables are an optimisation: a key that does not leave room for them proves from the plain points
+        for (csh_bases_t g : {a_query.dev, b_g1_query.dev, l_query.dev, h_query.dev, b_g2_query.dev})
+          if (g) (void)csh_bases_drop_tables(g);
+        return;
+      }
+      check(rc, "csh_bases_precompute_grouped");
+    }
   }
+  // ---- per-commitment device placement ---------------------------------------------------------------------------------
+  // The five query MSMs of one proof are independent (rayon_join5, groth16.rs:227-294); on a node with several GPUs each can run
+  // on its own device (north star: "independent MSM instances ... per polynomial commitment shard across the 8 GPUs"). `place`
+  // assigns the queries to the slots of `devices` (slot 0 = the key's home GPU, where witness map and scalars live; a physical GPU
+  // may appear more than once -- tests fold every slot onto one GPU) by longest-processing-time-first with the measured cost
+  // ratio of a G2 to a G1 MSM (2.5), and clones each non-home query onto its GPU (csh_bases_clone: device to device, tables
+  // included). create_proof_device then ships the scalars by peer copy (32 bytes per entry) and runs the groups concurrently.
+  enum { Q_A = 0, Q_B1 = 1, Q_B2 = 2, Q_L = 3, Q_H = 4 };
+  struct Placement {
+    std::vector<int> devices;
+    int slot[5] = {0, 0, 0, 0, 0};
+    csh_bases_t clone[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  } placement;
+  size_t query_size(int q) const {
+    return q == Q_A ? a_query.size() : q == Q_B1 ? b_g1_query.size() : q == Q_B2 ? b_g2_query.size() : q == Q_L ? l_query.size() : h_query.size();
+  }
+  csh_bases_t home_handle(int q) const {
+    return q == Q_A ? a_query.dev : q == Q_B1 ? b_g1_query.dev : q == Q_B2 ? b_g2_query.dev : q == Q_L ? l_query.dev : h_query.dev;
+  }
+  csh_bases_t handle_for(int q) const { return placement.slot[q] ? placement.clone[q] : home_handle(q); }
+  bool placed() const { return placement.devices.size() > 1; }
+  void unplace() {
+    for (auto& c : placement.clone) {
+      if (c) csh_bases_free(c);
+      c = nullptr;
+    }
+    for (auto& sl : placement.slot) sl = 0;
+    placement.devices.clear();
+  }
+  void place(const std::vector<int>& devices) {
+    unplace();
+    if (devices.size() < 2) return;
+    placement.devices = devices;
+    const size_t ns = devices.size();
+    std::vector<double> load(ns, 0.0);
+    int order[5] = {Q_B2, Q_A, Q_B1, Q_L, Q_H};
+    auto weight = [&](int q) { return (q == Q_B2 ? 2.5 : 1.0) * (double)query_size(q); };
+    std::stable_sort(order, order + 5, [&](int x, int y) { return weight(x) > weight(y); });
+    for (int q : order) {
+      if (!home_handle(q) || query_size(q) == 0) continue;
+      size_t best = 0;
+      for (size_t sl = 1; sl < ns; ++sl)
+        if (load[sl] < load[best]) best = sl;
+      load[best] += weight(q);
+      placement.slot[q] = (int)best;
+      if (best) check(csh_bases_clone(home_handle(q), devices[best], &placement.clone[q]), "csh_bases_clone");
+    }
+  }
+  void place_default() { place(ProverDevices::get().snapshot()); }
   ~ProvingKey() {
+    unplace();
     a_query.release();
     b_g1_query.release();
     l_query.release();

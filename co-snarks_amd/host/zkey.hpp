@@ -126,7 +126,10 @@ void parse_zkey(const uint8_t* d, size_t n, ProvingKey<P>& pk, ConstraintMatrice
     expect(7, l, 4 * n8q, n_vars);
     pk.b_g2_query.upload_from(P::ID, CSH_G2, d + o, n_vars, keep, upload);
   }
-  if (upload) pk.build_tables();
+  if (upload) {
+    pk.build_tables();
+    pk.place_default();  // one prover's queries over several GPUs when cog16_set_prover_devices asked for it
+  }
   // coefficients -> ConstraintMatrices (public-input rows, constraint index >= num_constraints, are dropped:
   // the reference overwrites exactly those evaluation slots, groth16/reduction.rs:111-113)
   auto [c, cl] = s.at(4);

@@ -83,6 +83,8 @@ int csh_malloc(void** dev_ptr, size_t bytes);
 int csh_free(void* dev_ptr);
 int csh_memcpy_h2d(void* dev_dst, const void* host_src, size_t bytes);
 int csh_memcpy_d2h(void* host_dst, const void* dev_src, size_t bytes);
+/* device-to-device between GPUs (scalars of one prover to the GPU that runs one of its MSMs). stream NULL = synchronous. */
+int csh_memcpy_peer(void* dst, int dst_device, const void* src, int src_device, size_t bytes, void* stream);
 int csh_sync(void* stream);
 /* out[i] = component `comp` of the i-th share (ncomp 32-byte field elements per share), device to device: the
  * `to_half_share` map over the witness (groth16.rs:159-163; Rep3 = take `.a`, mpc/rep3.rs:120-122) without a host pass. */
@@ -112,6 +114,19 @@ int csh_bases_precompute(csh_bases_t bases, int c);
  * groups x the memory of the points. groups = 2 or 4 keeps the sort stage in its efficient regime (the full merge above runs it
  * on a single window). Same results; replaces any tables already on the handle. */
 int csh_bases_precompute_grouped(csh_bases_t bases, int c, int groups);
+/* The table policy of the library for the queries of ONE proving key whose largest query has `key_points` points (host-only,
+ * no device needed): window width *c_out and row count *rows_out to pass to csh_bases_precompute_grouped for every query of
+ * the key (equal (c, rows) on all of them lets csh_msm_multi_dev share one digit pass), or *rows_out = 0 when tables do not pay
+ * (keys below 2^14 or above 2^21 points). 16 rows up to 3 * 2^17 points (the precompute keeps only the rows its W' = ceil(W / 16)
+ * references), 4 rows above. The C++ host mirror
+ * (ProvingKey::build_tables) and the Rust bases cache (rust/co-groth16-hip/src/bases.rs) both take the policy from here. */
+int csh_bases_table_policy(size_t key_points, int* c_out, int* rows_out);
+/* Free the fixed-base tables of a handle (the plain points stay): the fallback when a key's tables do not fit the device. */
+int csh_bases_drop_tables(csh_bases_t bases);
+/* A copy of a handle -- points and fixed-base tables, as stored -- on GPU `device` (device-to-device, no re-encoding): how one
+ * prover places its five independent query MSMs (groth16.rs:227-294, rayon_join5) on several GPUs, and how a party gets its own
+ * copy of a key. Free with csh_bases_free. */
+int csh_bases_clone(csh_bases_t bases, int device, csh_bases_t* out);
 int csh_bases_free(csh_bases_t bases);
 
 /* sum_{i<n} scalars[i] * bases[offset+i].  "unchecked": the caller passes the shorter length
@@ -282,11 +297,11 @@ typedef struct csh_matrix_s* csh_matrix_t;
 int csh_matrix_upload(csh_curve_t field_of, const uint64_t* row_ptr, const uint32_t* col_idx, const uint64_t* coeffs,
                       size_t n_rows, size_t nnz, csh_matrix_t* out);
 int csh_matrix_free(csh_matrix_t m);
-/* rows, non-zeros, the largest column index (a caller that passes device witness pointers validates it against n_public +
- * n_witness itself; the host-pointer entry points below check it) and the device the handle lives on; any pointer may be NULL */
+/* rows, non-zeros, the largest column index (every entry point below checks it against the n_public + n_witness the caller
+ * states, host or device pointers alike) and the device the handle lives on; any pointer may be NULL */
 int csh_matrix_info(csh_matrix_t m, size_t* n_rows, size_t* nnz, uint32_t* max_column, int* device);
 int csh_evaluate_constraints_dev(csh_matrix_t m, int protocol, int party_id, const uint64_t* public_dev, size_t n_public,
-                                 const uint64_t* witness_dev, uint64_t* out_dev, size_t n_out, void* stream);
+                                 const uint64_t* witness_dev, size_t n_witness, uint64_t* out_dev, size_t n_out, void* stream);
 /* witness_map_from_matrices of CircomReduction (reduction.rs:77-193) entirely on the device: evaluate A and B rows,
  * overwrite the public-input slots a[num_constraints .. +n_public] with the promoted public inputs (:111-113), then the
  * fused pipeline of csh_groth16_h. Host pointers; witness = n_witness entries (1 or 2 components). For protocol 1 the
@@ -299,8 +314,8 @@ int csh_groth16_witness_map(csh_domain_t dom, const uint64_t shift[4], int proto
  * groth16.rs:286-292): no PCIe traffic besides the n_public public inputs (host pointer). */
 int csh_groth16_witness_map_dev(csh_domain_t dom, const uint64_t shift[4], int protocol, int party_id, csh_matrix_t a, csh_matrix_t b,
                                 size_t num_constraints, const uint64_t* public_inputs, size_t n_public, const uint64_t* witness_dev,
-                                const uint8_t seed1[32], uint64_t elem_offset1, const uint8_t seed2[32], uint64_t elem_offset2,
-                                uint64_t* h_out_dev, void* stream);
+                                size_t n_witness, const uint8_t seed1[32], uint64_t elem_offset1, const uint8_t seed2[32],
+                                uint64_t elem_offset2, uint64_t* h_out_dev, void* stream);
 /* LibSnarkReduction::witness_map_from_matrices (reduction.rs:241-342) on the device: rows of a, b through
  * evaluate_constraint, rows of c through evaluate_constraint_half_share (mpc/rep3.rs:51-74, mpc/shamir.rs:51-68,
  * mpc/plain.rs:45-60), then csh_groth16_h_libsnark. dom = Domain::new (NULL generator at csh_domain_create),

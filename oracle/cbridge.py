@@ -234,7 +234,51 @@ def _best_of(f, reps=2):
     return best, r
 
 
-def cpu_baseline_suite(pts20, sc20, gpu_affine20=None, pts24=None, sc24=None, gpu_affine24=None, curve=0, group=0, budget_s=30.0, host_cpus=None):
+def groth16_prove_composition(pts_g1, sc, pts_g2, logn, threads):
+    """CPU figure beside `groth16_prove_synthetic_2p20`: the stages of one plain Groth16 prove of a 2^logn-constraint circuit
+    (groth16.rs:125-338 with CircomReduction, reduction.rs:77-193) composed from this restatement's own routines on inputs of the
+    prove's shapes: witness map = c = a.b, 3 x (ifft_in_to_out, coset-table multiplication, fft_out_to_in), a.b - c over BN254 Fr
+    at n = 2^logn; then four G1 MSMs and one G2 MSM of 2^logn points (the bench step's own G1 bases and scalars; G2 bases from
+    the same known-dlog family generated on the GPU and copied back). Stages run back to back (the reference overlaps them with
+    rayon; with every core busy in each stage the sum is the comparable figure)."""
+    n = 1 << logn
+    r = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    g = pow(pow(5, (r - 1) >> 28, r), 1 << (28 - logn), r) * ((1 << 256) % r) % r
+    gen = np.array([(g >> (64 * i)) & (2**64 - 1) for i in range(4)], dtype=np.uint64)
+    rs = np.random.RandomState(11)
+    a, b = (np.ascontiguousarray(rs.randint(0, 1 << 62, size=(n, 4), dtype=np.uint64)) for _ in range(2))
+    table = np.ascontiguousarray(rs.randint(0, 1 << 62, size=(n, 4), dtype=np.uint64))
+    fn = lib().oc_ntt
+    t0 = time.perf_counter()
+    c = vec_mul(0, a, b, threads=threads)                                   # reduction.rs:155-156 (on the evaluations)
+    vs = [a.copy(), b.copy(), np.ascontiguousarray(c)]
+    for v in vs:                                                            # :141-174
+        assert fn(0, _p(v), logn, _p(gen), 1, 1, int(threads)) == 0        # ifft_in_to_out (DIF)
+        lib().oc_vec_mul_table(0, _p(v), _p(table), C.c_size_t(n), 1, _t(threads))   # distribute_powers_and_mul_by_const / *= table (in place)
+        assert fn(0, _p(v), logn, _p(gen), 1, 0, int(threads)) == 0        # fft_out_to_in (DIT)
+    ab = vec_mul(0, vs[0], vs[1], threads=threads)                          # :176-181
+    vec_sub(0, ab, vs[2], threads=threads)                                  # :185-190
+    t_map = time.perf_counter() - t0
+    p1 = np.ascontiguousarray(pts_g1).reshape(-1, 8)[:n]
+    s1 = np.ascontiguousarray(sc).reshape(-1, 4)[:n]
+    t0 = time.perf_counter()
+    for _ in range(4):                                                      # a_query, b_g1_query, l_query, h_query (groth16.rs:237-292)
+        msm_fast(0, 0, p1, s1, True, threads=threads)
+    t_g1 = time.perf_counter() - t0
+    t_g2 = None
+    if pts_g2 is not None:
+        p2 = np.ascontiguousarray(pts_g2).reshape(-1, 16)[:n]
+        t0 = time.perf_counter()
+        msm_fast(0, 1, p2, s1, True, threads=threads)                       # b_g2_query (:262-272)
+        t_g2 = time.perf_counter() - t0
+    total = t_map + t_g1 + (t_g2 or 0.0)
+    return {"prove_ms": round(total * 1e3, 1), "witness_map_ms": round(t_map * 1e3, 1), "four_g1_msms_ms": round(t_g1 * 1e3, 1),
+            "g2_msm_ms": round(t_g2 * 1e3, 1) if t_g2 is not None else None, "threads": threads, "log_n": logn,
+            "sample": "stage sum of oracle/c routines on prove-shaped inputs (see groth16_prove_composition); no zkey parsing, no openings"}
+
+
+def cpu_baseline_suite(pts20, sc20, gpu_affine20=None, pts24=None, sc24=None, gpu_affine24=None, curve=0, group=0, budget_s=30.0, host_cpus=None,
+                       pts20_g2=None):
     """bench.py's ``cpu_baseline`` object (kind "port"): the tuned restatement `oc_msm_fast` timed on THIS box's host cores on
     the SAME inputs as the GPU line (the arrays are the GPU's bases / scalars copied back): BN254 G1 MSM at 2^20 (the bench
     workload) and at 2^24 (the north star's >= 10x target size), a thread-scaling table, plus NTT 2^22 and Rep3 local_mul_vec
@@ -267,7 +311,11 @@ def cpu_baseline_suite(pts20, sc20, gpu_affine20=None, pts24=None, sc24=None, gp
     dt1, _ = _best_of(lambda: msm_fast(curve, group, np.ascontiguousarray(pts20).reshape(n20, -1)[:m], np.ascontiguousarray(sc20).reshape(n20, 4)[:m], True, threads=1, stages=st), reps=1)
     table.insert(0, {"threads": 1, "points_per_s": round(m / dt1), "ms": round(dt1 * 1e3, 2), "mixed_adds_per_s_per_thread": round(m * st[4] / max(st[1], 1e-9)),
                      "c": int(st[3]), "windows": int(st[4]), "sample": f"first 2^{m.bit_length() - 1} points"})
-    out = {"value": best_v, "unit": "points/s", "cores": best_t, "kind": "port", "host_cpus_available": hw, "cgroup_cpu_quota": quota, "build": flags,
+    # `cores` = CPUs' worth of compute the measurement actually had (the thread count capped by the container's CPU-time quota);
+    # `threads` = OpenMP threads of the best row; `cpus_granted` = what the cgroup grants this container (None = unlimited)
+    eff = best_t if quota is None else max(1, min(best_t, int(round(quota))))
+    out = {"value": best_v, "unit": "points/s", "cores": eff, "threads": best_t, "cpus_granted": quota, "kind": "port", "host_cpus_available": hw,
+           "cgroup_cpu_quota": quota, "build": flags,
            "sample": f"BN254 G1 MSM, the bench step's own 2^{n20.bit_length() - 1} bases and scalars copied back from the GPU; oracle/c oc_msm_fast "
                      f"(Booth signed digits, XYZZ mixed additions, thread-private buckets, __int128 Montgomery; OpenMP x{best_t}), best of 2; "
                      "a restatement of the published Pippenger shape, NOT arkworks (no Rust toolchain / un-vendored crates here)",
@@ -320,5 +368,10 @@ def cpu_baseline_suite(pts20, sc20, gpu_affine20=None, pts24=None, sc24=None, gp
                                           "sample": "oc_rep3_local_mul_vec (three products as written, ops.rs:69-76), incl. the output allocation"}
     except Exception as e:  # noqa: BLE001 -- extras never break the baseline
         out["extras_error"] = repr(e)
+    try:
+        if n20 >= (1 << 20):
+            out["groth16_prove_synthetic_2p20"] = groth16_prove_composition(pts20, sc20, pts20_g2, 20, best_t)
+    except Exception as e:  # noqa: BLE001
+        out["groth16_prove_error"] = repr(e)
     out["wall_s"] = round(time.perf_counter() - spent, 1)
     return out

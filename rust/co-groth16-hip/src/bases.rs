@@ -1,19 +1,26 @@
-//! Proving-key queries live on the device: uploaded the first time a slice is seen, reused by every later proof
-//! (`csh_bases_upload` once per key; groth16.rs:219-290 passes sub-slices of the same five queries on every call).
+//! Proving-key queries live on the device: uploaded the first time a slice is seen ON THE CALLING THREAD'S GPU, reused by every
+//! later proof on that GPU (`csh_bases_upload` once per key and device; groth16.rs:219-290 passes sub-slices of the same five
+//! queries on every call).
+//!
+//! Ownership: the cache is keyed by (device, host address range) and every entry carries a fingerprint of the points it was
+//! uploaded from, so a proving key that is dropped and another one allocated at the same address is detected and re-uploaded
+//! instead of silently proving against stale bases. [`KeyGuard`] ties the entries of one key to a scope: uploads made while a
+//! guard for the key's address range is alive are evicted when it drops.
 use crate::error::hip_ok;
 use crate::layout::{curve_id, group_id};
 use ark_ec::pairing::Pairing;
 use ark_ec::short_weierstrass::{Affine, SWCurveConfig};
 use cosnarks_hip_sys as sys;
 use parking_lot::Mutex;
-use std::collections::HashMap;
 use std::sync::Arc;
 
 pub struct DeviceBases {
     pub handle: sys::CshBases,
+    pub device: i32,  // the GPU the handle lives on (`csh_msm*` checks it against the calling thread's device)
     host_base: usize, // address of the first uploaded point: sub-slices of the same query map to an offset
     len: usize,
     stride: usize,
+    fingerprint: u64, // FNV-1a over the first, middle and last point as uploaded
 }
 unsafe impl Send for DeviceBases {}
 unsafe impl Sync for DeviceBases {}
@@ -30,48 +37,119 @@ impl DeviceBases {
         (a >= self.host_base && a + points.len() * self.stride <= end && (a - self.host_base) % self.stride == 0)
             .then(|| (a - self.host_base) / self.stride)
     }
+    fn overlaps(&self, lo: usize, hi: usize) -> bool {
+        self.host_base < hi && lo < self.host_base + self.len * self.stride
+    }
 }
 
-type Key = (i32 /* device */, usize /* address */, usize /* len */);
-static CACHE: Mutex<Option<HashMap<Key, Arc<DeviceBases>>>> = Mutex::new(None);
-
-/// The device copy of `points` (a whole query or a sub-slice of one already uploaded) and the offset of `points` in it.
-/// A query holding flagged points at infinity must have x = y = 0 on them (the zkey convention, which the reference's parser
-/// produces); `normalize_infinity` below does that for keys built elsewhere.
-pub fn get_or_upload<P: Pairing, C: SWCurveConfig>(points: &[Affine<C>]) -> (Arc<DeviceBases>, usize) {
-    let mut dev = 0i32;
-    hip_ok(unsafe { sys::csh_current_device(&mut dev) });
-    let mut guard = CACHE.lock();
-    let map = guard.get_or_insert_with(HashMap::new);
-    for b in map.values() {
-        if let Some(off) = b.offset_of(points) {
-            return (b.clone(), off);
+fn fingerprint_at(base: usize, len: usize, stride: usize) -> u64 {
+    let mut h = 0xcbf29ce484222325u64;
+    if len == 0 {
+        return h;
+    }
+    for idx in [0, len / 2, len - 1] {
+        // SAFETY: [base, base + len * stride) is a live slice of points of `stride` bytes each (the caller holds it)
+        let bytes = unsafe { core::slice::from_raw_parts((base + idx * stride) as *const u8, stride) };
+        for &b in bytes {
+            h = (h ^ b as u64).wrapping_mul(0x100000001b3);
         }
     }
-    let mut handle: sys::CshBases = core::ptr::null_mut();
+    h
+}
+
+static CACHE: Mutex<Vec<Arc<DeviceBases>>> = Mutex::new(Vec::new());
+
+fn current_device() -> i32 {
+    let mut dev = 0i32;
+    hip_ok(unsafe { sys::csh_current_device(&mut dev) });
+    dev
+}
+
+/// The device copy of `points` on the calling thread's GPU (a whole query or a sub-slice of one already uploaded there) and the
+/// offset of `points` in it. A query holding flagged points at infinity must have x = y = 0 on them (the zkey convention, which
+/// the reference's parser produces); `normalize_infinity` below does that for keys built elsewhere.
+pub fn get_or_upload<P: Pairing, C: SWCurveConfig>(points: &[Affine<C>]) -> (Arc<DeviceBases>, usize) {
+    get_or_upload_sized::<P, C>(points, points.len())
+}
+
+/// The same with the size of the LARGEST query of the proving key as the table-policy hint (all queries of a key must get the
+/// same (c, rows) for `csh_msm_multi_dev` to share one digit pass; `KeyGuard::new` passes it).
+pub fn get_or_upload_sized<P: Pairing, C: SWCurveConfig>(points: &[Affine<C>], key_points: usize) -> (Arc<DeviceBases>, usize) {
+    let dev = current_device();
     let stride = core::mem::size_of::<Affine<C>>();
+    let mut cache = CACHE.lock();
+    let mut stale = None;
+    for (i, b) in cache.iter().enumerate() {
+        if b.device != dev {
+            continue; // handles are per device: a thread bound to GPU 1 never gets GPU 0's copy
+        }
+        if let Some(off) = b.offset_of(points) {
+            if b.stride == stride && b.fingerprint == fingerprint_at(b.host_base, b.len, b.stride) {
+                return (b.clone(), off);
+            }
+            stale = Some(i); // same addresses, other contents: the key this entry came from is gone
+            break;
+        }
+    }
+    if let Some(i) = stale {
+        cache.swap_remove(i);
+    }
+    let mut handle: sys::CshBases = core::ptr::null_mut();
     hip_ok(unsafe {
         sys::csh_bases_upload(curve_id::<P>(), group_id::<C>(), points.as_ptr().cast(), points.len(), stride, &mut handle)
     });
-    // Proving-key queries are reused across proofs: four-row fixed-base tables (4x the key memory on the device, built once)
-    // let windows w, w + W', w + 2W', w + 3W' share a bucket set. Same policy as ProvingKey::build_tables of the C++ mirror:
-    // only for 2^14..2^21 points. The width follows the slice length (the cache sees slices, not keys): queries of one key whose
-    // lengths straddle a power of two get different widths and csh_msm_multi_dev then runs that call on the plain points.
-    if (1usize << 14..=1usize << 21).contains(&points.len()) {
-        let mut c = 16i32;
-        while c > 10 && (1usize << (c + 1)) > points.len() {
-            c -= 1;
+    // Fixed-base tables, the library's own policy (csh_bases_table_policy; the C++ mirror's ProvingKey::build_tables asks the same
+    // function). Tables are an optimisation: when they do not fit the device the MSM runs on the plain points.
+    let (mut c, mut rows) = (0i32, 0i32);
+    hip_ok(unsafe { sys::csh_bases_table_policy(key_points, &mut c, &mut rows) });
+    if rows >= 2 {
+        let rc = unsafe { sys::csh_bases_precompute_grouped(handle, c, rows) };
+        if rc == sys::CSH_ERR_OOM {
+            hip_ok(unsafe { sys::csh_bases_drop_tables(handle) });
+        } else {
+            hip_ok(rc);
         }
-        hip_ok(unsafe { sys::csh_bases_precompute_grouped(handle, c, 4) });
     }
-    let b = Arc::new(DeviceBases { handle, host_base: points.as_ptr() as usize, len: points.len(), stride });
-    map.insert((dev, points.as_ptr() as usize, points.len()), b.clone());
+    let base = points.as_ptr() as usize;
+    let b = Arc::new(DeviceBases { handle, device: dev, host_base: base, len: points.len(), stride, fingerprint: fingerprint_at(base, points.len(), stride) });
+    cache.push(b.clone());
     (b, 0)
 }
 
-/// Drop every cached upload (call when a proving key is dropped: the cache is keyed by host addresses).
+/// Scope of one proving key on one GPU: uploads the five queries up front with a common table policy and evicts them on drop.
+/// `ProvingKey<P>` (ark-groth16) fields: `a_query`, `b_g1_query`, `b_g2_query`, `h_query`, `l_query` (groth16.rs:219-290).
+pub struct KeyGuard {
+    device: i32,
+    ranges: Vec<(usize, usize)>,
+}
+impl KeyGuard {
+    pub fn new<P, C1, C2>(pk: &ark_groth16::ProvingKey<P>) -> Self
+    where
+        P: Pairing<G1Affine = Affine<C1>, G2Affine = Affine<C2>>,
+        C1: SWCurveConfig,
+        C2: SWCurveConfig,
+    {
+        let big = [pk.a_query.len(), pk.b_g1_query.len(), pk.l_query.len(), pk.h_query.len(), pk.b_g2_query.len()].into_iter().max().unwrap_or(0);
+        let mut ranges = Vec::new();
+        for q in [&pk.a_query, &pk.b_g1_query, &pk.l_query, &pk.h_query] {
+            get_or_upload_sized::<P, C1>(q, big);
+            ranges.push((q.as_ptr() as usize, q.as_ptr() as usize + q.len() * core::mem::size_of::<Affine<C1>>()));
+        }
+        get_or_upload_sized::<P, C2>(&pk.b_g2_query, big);
+        ranges.push((pk.b_g2_query.as_ptr() as usize, pk.b_g2_query.as_ptr() as usize + pk.b_g2_query.len() * core::mem::size_of::<Affine<C2>>()));
+        Self { device: current_device(), ranges }
+    }
+}
+impl Drop for KeyGuard {
+    fn drop(&mut self) {
+        let mut cache = CACHE.lock();
+        cache.retain(|b| !(b.device == self.device && self.ranges.iter().any(|&(lo, hi)| b.overlaps(lo, hi))));
+    }
+}
+
+/// Drop every cached upload on every device.
 pub fn clear() {
-    *CACHE.lock() = None;
+    CACHE.lock().clear();
 }
 
 /// arkworks marks infinity with the flag and leaves x, y unspecified; the library reads x = y = 0 as infinity and ignores the flag.

@@ -11,15 +11,41 @@ use crate::domain::HipDomain;
 use crate::error::check;
 use crate::layout::{curve_id, limbs, limbs_mut, limbs_of};
 use ark_ec::pairing::Pairing;
-use ark_ff::{FftField, Field, One, PrimeField};
+use ark_ff::{FftField, Field, LegendreSymbol, One, PrimeField};
 use ark_relations::utils::matrix::Matrix;
-use co_groth16::groth16_roots_of_unity; // reduction.rs:14 `super::groth16_roots_of_unity` (re-exported for implementors)
 use co_groth16::mpc::CircomGroth16Prover;
 use co_groth16::R1CSToQAP;
 use cosnarks_hip_sys as sys;
 use mpc_core::MpcState;
 use rayon::prelude::*;
 use taceo_groth16::ConstraintMatrices;
+
+/// snarkjs' roots of unity, restated: `roots_of_unity` / `groth16_roots_of_unity` are PRIVATE functions of the reference
+/// (co-circom/co-groth16/src/groth16.rs:60-74 and :91-100; `lib.rs:9-13` exports neither), so an out-of-tree implementor of
+/// `R1CSToQAP` has to carry its own copy. q = the smallest quadratic non-residue, z = q^TRACE generates the 2^TWO_ADICITY-th
+/// roots; `roots[i]` generates the domain of size 2^i.
+fn roots_of_unity<F: PrimeField + FftField>() -> (F, Vec<F>) {
+    let mut roots = vec![F::zero(); F::TWO_ADICITY as usize + 1];
+    let mut q = F::one();
+    while q.legendre() != LegendreSymbol::QuadraticNonResidue {
+        q += F::one();
+    }
+    roots[0] = q.pow(F::TRACE);
+    for i in 1..roots.len() {
+        roots[i] = roots[i - 1].square();
+    }
+    roots.reverse();
+    (q, roots)
+}
+
+/// (generator of the domain of size 2^pow, shift onto the odd coset = generator of the domain twice as large); for
+/// pow == TWO_ADICITY there is no larger domain and snarkjs takes q^2 (groth16.rs:91-100).
+fn groth16_roots_of_unity<F: PrimeField + FftField>(pow: usize) -> (F, F) {
+    let (q, roots) = roots_of_unity::<F>();
+    let group_gen = roots[pow];
+    let coset_shift = if F::TWO_ADICITY as usize == pow { q.square() } else { roots[pow + 1] };
+    (group_gen, coset_shift)
+}
 
 fn eval_rows<P: Pairing, T: CircomGroth16Prover<P>>(
     id: <T::State as MpcState>::PartyID,
@@ -47,14 +73,14 @@ impl R1CSToQAP for HipCircomReduction {
     ) -> eyre::Result<Vec<T::ArithmeticHalfShare>> {
         let num_constraints = matrices.num_constraints;
         let num_inputs = matrices.num_instance_variables;
-        let power = ((num_constraints + num_inputs).next_power_of_two().trailing_zeros()).max(1) as usize; // reduction.rs:84-86
-        let domain_size = 1usize << power;
+        let domain_size = (num_constraints + num_inputs).next_power_of_two(); // reduction.rs:84-86
+        let power = domain_size.ilog2() as usize;
         if power > <P::ScalarField as FftField>::TWO_ADICITY as usize {
-            eyre::bail!("Polynomial Degree too large"); // reduction.rs:87-94
+            eyre::bail!("Polynomial Degree too large"); // reduction.rs:87-89
         }
-        let (_, roots) = groth16_roots_of_unity::<P::ScalarField>();
-        let dom = HipDomain::new(curve_id::<P>(), power as u32, Some(&roots[power]))?; // Domain::with_group_gen (:93)
-        let coset_shift = roots[power + 1]; // the 2n-th root that selects the odd coset (:129-133)
+        // snarkjs' root for the domain and the root of the domain twice as large as the coset shift (:90-94)
+        let (group_gen, coset_shift) = groth16_roots_of_unity::<P::ScalarField>(power);
+        let dom = HipDomain::new(curve_id::<P>(), power as u32, Some(&group_gen))?; // Domain::with_group_gen (:93)
         let id = state.id();
 
         // rows of A and B; the public inputs take the slots after the constraints (:99-113)

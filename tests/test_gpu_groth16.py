@@ -189,6 +189,115 @@ def test_synthetic_circuit_prove_closed_form(gpu, curve, logd):
     assert res["closed_form_check"], res
 
 
+# ---- one prover's five query MSMs placed on several GPUs (groth16.rs:227-294: the closures of rayon_join5 are independent) ----
+# The device list may name a GPU more than once: every slot then clones its queries (csh_bases_clone), receives the scalars by
+# csh_memcpy_peer and runs its MSM group from its own host thread -- the whole multi-GPU code path on the one GPU of this box.
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0], [0, 0, 0, 0, 0, 0]])
+@pytest.mark.parametrize("curve,circ", [("bn254", "poseidon"), ("bls12_381", "multiplier2")])
+def test_plain_prove_with_placed_queries_matches_golden(gpu, curve, circ, devices):
+    from cosnarks_amd import groth16 as g
+    zk, wt, vk, pub = _load(curve, circ)
+    zko = oz.parse_zkey(zk)
+    gold = json.load(open(os.path.join(GOLD, "groth16_golden.json")))[f"{curve}/{circ}"]
+    g.set_prover_devices(devices)
+    try:
+        proof, h = g.prove_plain(H.CURVE_IDS[curve], zk, wt, R, S, want_h=True, h_elems=zko.domain_size)
+    finally:
+        g.set_prover_devices(None)
+    assert proof["pi_a"][:2] == gold["a"] and proof["pi_b"][:2] == gold["b"] and proof["pi_c"][:2] == gold["c"]
+    assert [str(x) for x in H.unpack(zko.Fr, h)] == gold["h"]
+    assert og.verify(curve, zko.G1, vk, _as_points(proof), pub)
+
+
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0, 0, 0]])
+def test_rep3_prove_with_placed_queries_matches_golden(gpu, devices):
+    from cosnarks_amd import groth16 as g
+    curve, circ = "bn254", "poseidon"
+    zk, wt, vk, pub = _load(curve, circ)
+    zko = oz.parse_zkey(zk)
+    gold = json.load(open(os.path.join(GOLD, "groth16_golden.json")))[f"{curve}/{circ}"]
+    g.set_prover_devices(devices)
+    try:
+        proof, _ = g.prove_rep3(H.CURVE_IDS[curve], zk, wt, seed=42, r=R, s=S)
+        shamir = g.prove_shamir(H.CURVE_IDS[curve], zk, wt, 3, 1, seed=11, r=R, s=S)
+    finally:
+        g.set_prover_devices(None)
+    for p in (proof, shamir):
+        assert p["pi_a"][:2] == gold["a"] and p["pi_b"][:2] == gold["b"] and p["pi_c"][:2] == gold["c"]
+    assert og.verify(curve, zko.G1, vk, _as_points(proof), pub)
+
+
+@pytest.mark.parametrize("curve,logd,devices", [("bn254", 14, [0, 0, 0]), ("bn254", 16, [0, 0]), ("bls12_381", 14, [0, 0, 0, 0, 0])])
+def test_synthetic_prove_with_placed_queries_closed_form(gpu, curve, logd, devices):
+    """keys large enough for fixed-base tables: the clones carry the tables; plain + three Rep3 parties, closed form"""
+    from cosnarks_amd import groth16 as g
+    g.set_prover_devices(devices)
+    try:
+        res = g.bench_synthetic(H.CURVE_IDS[curve], logd, iters=2, with_rep3=(logd == 14))
+    finally:
+        g.set_prover_devices(None)
+    assert res["closed_form_check"], res
+    if logd == 14:
+        assert res["rep3_proofs_equal_plain"]
+    ph = res["prove_phases_ms"]
+    assert ph["msm_groups"] > 0 and ph["witness_upload_and_map"] > 0 and ph["msm_groups"] + ph["witness_upload_and_map"] <= res["prove_ms"] + 1e-6
+
+
+def test_set_prover_devices_rejects_unknown_device(gpu):
+    from cosnarks_amd import groth16 as g
+    with pytest.raises(gpu.CoSnarksHipError, match="device out of range"):
+        g.set_prover_devices([0, 97])
+    g.set_prover_devices(None)
+
+
+def test_bases_clone_and_peer_copy(gpu):
+    """csh_bases_clone: an MSM on the clone (tables included) equals the MSM on the original; csh_memcpy_peer moves the scalars"""
+    import ctypes as C
+
+    import numpy as np
+
+    from cosnarks_amd import bindings as B
+    L = gpu.lib()
+    n = 5000
+    buf = gpu.DeviceBuffer(n * 64)
+    B._check(L.csh_util_generate_bases_dev(0, 0, C.c_uint64(7), C.c_size_t(n), buf.ptr, None))
+    B.sync()
+    h, h2 = C.c_void_p(), C.c_void_p()
+    B._check(L.csh_bases_upload_dev(0, 0, buf.ptr, C.c_size_t(n), C.c_size_t(0), None, C.byref(h)))
+    B._check(L.csh_bases_precompute_grouped(h, 12, 4))
+    B._check(L.csh_bases_clone(h, 0, C.byref(h2)))
+    rs = np.random.RandomState(3)
+    sc = rs.randint(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+    d1 = gpu.DeviceBuffer.from_host(sc)
+    d2 = gpu.DeviceBuffer(n * 32)
+    B._check(L.csh_memcpy_peer(d2.ptr, 0, d1.ptr, 0, C.c_size_t(n * 32), None))
+    o1, o2 = np.zeros(12, dtype=np.uint64), np.zeros(12, dtype=np.uint64)
+    B._check(L.csh_msm_dev(h, C.c_size_t(0), C.c_size_t(n), d1.ptr, 1, o1.ctypes.data_as(C.c_void_p), None))
+    B._check(L.csh_msm_dev(h2, C.c_size_t(0), C.c_size_t(n), d2.ptr, 1, o2.ctypes.data_as(C.c_void_p), None))
+    assert (o1 == o2).all() and o1.any()
+    B.tune_set("msm_no_table", 1)
+    try:
+        o3 = np.zeros(12, dtype=np.uint64)
+        B._check(L.csh_msm_dev(h2, C.c_size_t(0), C.c_size_t(n), d2.ptr, 1, o3.ctypes.data_as(C.c_void_p), None))
+    finally:
+        B.tune_set("msm_no_table", 0)
+    assert (o3 == o1).all()
+    B._check(L.csh_bases_drop_tables(h2))
+    B._check(L.csh_msm_dev(h2, C.c_size_t(0), C.c_size_t(n), d2.ptr, 1, o3.ctypes.data_as(C.c_void_p), None))
+    assert (o3 == o1).all()
+    c, rows = C.c_int(0), C.c_int(0)
+    B._check(L.csh_bases_table_policy(C.c_size_t(1 << 20), C.byref(c), C.byref(rows)))
+    assert (c.value, rows.value) == (16, 4)
+    B._check(L.csh_bases_table_policy(C.c_size_t(1 << 16), C.byref(c), C.byref(rows)))
+    assert (c.value, rows.value) == (15, 16)
+    B._check(L.csh_bases_table_policy(C.c_size_t(1000), C.byref(c), C.byref(rows)))
+    assert rows.value == 0
+    for x in (h, h2):
+        L.csh_bases_free(x)
+    for d in (buf, d1, d2):
+        d.free()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("curve,generator", [("bn254", 5), ("bls12_381", 7)])
 @pytest.mark.parametrize("n_public,n_constraints", [(1, 2), (3, 29), (2, 3000)])
