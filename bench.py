@@ -467,19 +467,19 @@ def secondary_multi_gpu(cx: Ctx, args):
     if cx.rank == 0:
         try:
             devs = [0] * cx.world if cx.folded else list(range(cx.world))
-            out["groth16_prove_synthetic_2p20_placed"] = prove_over_devices(devs)
+            out["groth16_prove_synthetic_2p20_placed"] = {"by_query": prove_over_devices(devs, mode=1), "by_range": prove_over_devices(devs, mode=2)}
         except Exception as e:  # noqa: BLE001
             out["groth16_prove_synthetic_2p20_placed"] = {"error": repr(e)}
     cx.barrier()
     return out
 
 
-def prove_over_devices(devices, logn=20, steps=5, warmup=2, timeout=300):
+def prove_over_devices(devices, logn=20, steps=5, warmup=2, timeout=300, mode=0):
     """Plain Groth16 prove of the synthetic 2^logn circuit with the five query MSMs placed on `devices` (one process, one host
     thread per GPU): tools/bench_prove_devices.py in a subprocess with a timeout, so nothing it does can stall the caller."""
     import subprocess
     cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_prove_devices.py"), "--devices", ",".join(str(d) for d in devices),
-           "--log-n", str(logn), "--steps", str(steps), "--warmup", str(warmup)]
+           "--log-n", str(logn), "--steps", str(steps), "--warmup", str(warmup), "--mode", str(mode)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     if r.returncode != 0 or not lines:
@@ -503,7 +503,7 @@ def run_groth16_prove(cx: Ctx, args):
     circ, err = None, None
     if rank == 0:
         try:
-            g16.set_prover_devices(devices if len(devices) > 1 else None)
+            g16.set_prover_devices(devices if len(devices) > 1 else None, args.placement)
             circ = g16.SynthCircuit(cx.hip.BN254, args.log_n)
             for _ in range(args.warmup):
                 circ.prove()
@@ -531,7 +531,8 @@ def run_groth16_prove(cx: Ctx, args):
                 "dtype": "BN254: i32x9 29-bit-limb lazy Montgomery (MSM, NTT butterflies), Fp2 for the G2 query", "data": "synthetic",
                 "config": {"workload": f"plain Groth16 prove (CircomReduction), synthetic 2^{args.log_n}-constraint BN254 circuit with a known-dlog key, key resident; "
                                        "one prover, its five query MSMs placed on the GPUs", "devices": devices,
-                           "placement": "LPT over the queries (G2 = 2.5 x G1), csh_bases_clone + csh_memcpy_peer, one host thread per GPU"},
+                           "placement": {0: "auto (whole queries per GPU up to 2 GPUs, ranges of every query from 3 on)", 1: "whole queries per GPU (LPT, G2 = 2.5 x G1)",
+                                         2: "the k-th range of every query per GPU"}[args.placement] + "; csh_bases_clone + csh_memcpy_peer, one host thread per GPU"},
                 "phases_ms_median": {k: med(k) for k in ("witness_upload_and_map", "msm_groups", "finish")}, "result_check": ok, "error": err,
                 "roofline": None, "cpu_baseline": None}
         print(json.dumps(line))
@@ -567,6 +568,7 @@ def main():
     ap.add_argument("--exchange", choices=["rccl", "harness"], default="rccl", help="N > 1: RCCL behind the C ABI (default) or the gloo harness all-gather")
     ap.add_argument("--spinup", type=int, default=int(os.environ.get("BENCH_SPINUP", "0")),
                     help="untimed steps issued during setup, before the W warmup steps (brings the GPU out of its idle clocks)")
+    ap.add_argument("--placement", type=int, choices=[0, 1, 2], default=0, help="groth16_prove at N > 1: 0 auto, 1 whole queries per GPU, 2 ranges of every query per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary metrics")

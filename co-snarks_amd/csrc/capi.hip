@@ -275,8 +275,12 @@ int csh_memcpy_peer(void* dst, int dst_device, const void* src, int src_device, 
   CSH_REQUIRE((dst && src) || bytes == 0, "NULL argument");
   CSH_TRY(ensure_device());
   if (bytes == 0) return CSH_OK;
-  if (stream) CSH_HIP(hipMemcpyPeerAsync(dst, dst_device, src, src_device, bytes, resolve_stream(stream)));
-  else CSH_HIP(hipMemcpyPeer(dst, dst_device, src, src_device, bytes));
+  // Always on a stream of the calling thread (its lane stream when none is given): a device-to-device hipMemcpy[Peer] runs on the
+  // NULL stream and may return before the copy has finished, and the lane streams are non-blocking -- an MSM launched right after
+  // would race it (seen as wrong Rep3 proofs with three parties copying at once).
+  hipStream_t st = resolve_stream(stream);
+  CSH_HIP(hipMemcpyPeerAsync(dst, dst_device, src, src_device, bytes, st));
+  if (!stream) CSH_HIP(hipStreamSynchronize(st));
   return CSH_OK;
 }
 int csh_extract_component_dev(const uint64_t* shares_dev, uint32_t ncomp, uint32_t comp, size_t n, uint64_t* out_dev, void* stream) {

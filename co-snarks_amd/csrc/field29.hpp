@@ -190,8 +190,15 @@ using Fq29 = FpLazy<Bn254Fq29Params, Bn254Fq>;
 #ifndef CSH_REDUCE_SCAN
 #define CSH_REDUCE_SCAN 1
 #endif
+// CSH_PIN_MADS: per translation unit. 0 (default): the compiler is free to reassociate a column's terms -- it moves the incoming
+// carry to the end of the chain and pays a separate 64-bit addition per column, i.e. the instruction count of the row-wise form.
+// 3: every partial sum gets a second (empty, input-only asm) use, which keeps the chain in the written order: the carry is the
+// addend of the column's first multiply-add. Worth -4 % on the accumulate kernels and -5.5 % on the NTT passes (profiles/r03_a_*);
+// set by the translation units of those kernels only (msm_accum_*.hip, ntt.hip): the volatile asm statements are ordered among
+// themselves, and in the four-lane tail kernels (long independent chains the scheduler wants to interleave) that ordering blew the
+// register allocation up to 512 VGPRs + spills (tails +13 % on G1, x2 on G2 / BLS12-381).
 #ifndef CSH_PIN_MADS
-#define CSH_PIN_MADS (CSH_REDUCE_SCAN ? 3 : 0)
+#define CSH_PIN_MADS 0
 #endif
 // acc = x * y + acc as ONE v_mad_i64_i32 in the order written: the empty asm makes every partial sum opaque to the compiler's
 // reassociation pass, which otherwise sorts a column's terms by rank, moves the incoming carry (the latest value) to the end of
@@ -206,6 +213,12 @@ CSH_HD inline int64_t mad_pinned(int32_t x, int32_t y, int64_t acc) {
   asm("" : "+v"(acc));
 #elif defined(__HIP_DEVICE_COMPILE__) && CSH_PIN_MADS == 3
   asm volatile("" ::"v"(acc));  // a second use of the partial sum: the reassociation pass only linearises single-use chains
+#elif defined(__HIP_DEVICE_COMPILE__) && CSH_PIN_MADS == 4
+  // a second use that exists only in the optimiser: the comparison feeding llvm.assume keeps the partial sum out of the
+  // reassociation pass's single-use chains and is dropped before instruction selection, so the machine scheduler and the register
+  // allocator see plain multiply-adds (the volatile asm of variant 3 orders thousands of statements and blew the four-lane
+  // tail kernels up to 512 VGPRs + spills)
+  __builtin_assume(acc != INT64_MIN);
 #endif
 #endif
   return acc;

@@ -126,6 +126,10 @@ int csh_bases_clone(csh_bases_t src, int device, csh_bases_t* out) {
   if (e == hipSuccess && pbytes) e = hipMemcpyPeer(B->points, device, S->points, S->device, pbytes);
   if (e == hipSuccess && tbytes) e = hipMemcpyPeer(B->table, device, S->table, S->device, tbytes);
   if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess && S->device != device) {  // and the source side of the copies
+    e = hipSetDevice(S->device);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+  }
   (void)hipSetDevice(cur);
   if (e != hipSuccess) {
     const bool oom = e == hipErrorOutOfMemory;

@@ -1092,6 +1092,16 @@ int repack_bases_t(Bases* B, hipStream_t st) {
   return CSH_OK;
 }
 
+// The accumulate kernels are instantiated in their own translation units (msm_accum_*.hip, which define CSH_PIN_MADS 3: the
+// product-scanning Montgomery multiplication with its multiply-add order pinned); the per-configuration units below see them
+// as explicit-instantiation declarations, so their own copy of the field code stays unpinned for the tail kernels.
+#define CSH_MSM_ACCUM_INSTANTIATE(KW, CFG)                                                                                               \
+  KW template __global__ void k_msm_accum<CFG>(const Affine<typename CFG::Fq>* __restrict__, MsmParams, const uint32_t* __restrict__,  \
+                                               const uint32_t* __restrict__, const uint32_t* __restrict__, LazyPt<CFG>*, uint32_t*);
+#define CSH_MSM_ACCUM_PAIR_INSTANTIATE(KW, CFG)                                                                                               \
+  KW template __global__ void k_msm_accum_pair<CFG>(const Affine<typename CFG::Fq>* __restrict__, MsmParams, const uint32_t* __restrict__,  \
+                                                    const uint32_t* __restrict__, const uint32_t* __restrict__, LazyPt<CFG>*, uint32_t*);
+
 // one explicit instantiation set per configuration (msm_inst_*.hip); everyone else only sees the declarations
 #define CSH_MSM_INSTANTIATE(KW, CFG)                                                                                            \
   KW template int msm_t<CFG>(const Bases*, size_t, size_t, const uint64_t*, int, void*, hipStream_t);                           \

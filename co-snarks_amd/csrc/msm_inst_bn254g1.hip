@@ -2,5 +2,6 @@
 #include "msm_impl.hpp"
 
 namespace csh {
+CSH_MSM_ACCUM_INSTANTIATE(extern, Bn254G1Cfg)
 CSH_MSM_INSTANTIATE(, Bn254G1Cfg)
 }  // namespace csh

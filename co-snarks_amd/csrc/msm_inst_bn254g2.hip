@@ -2,5 +2,7 @@
 #include "msm_impl.hpp"
 
 namespace csh {
+CSH_MSM_ACCUM_INSTANTIATE(extern, Bn254G2Cfg)
+CSH_MSM_ACCUM_PAIR_INSTANTIATE(extern, Bn254G2Cfg)
 CSH_MSM_INSTANTIATE(, Bn254G2Cfg)
 }  // namespace csh

@@ -2,5 +2,6 @@
 #include "msm_impl.hpp"
 
 namespace csh {
+CSH_MSM_ACCUM_INSTANTIATE(extern, GrumpkinG1Cfg)
 CSH_MSM_INSTANTIATE(, GrumpkinG1Cfg)
 }  // namespace csh

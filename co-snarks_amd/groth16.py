@@ -134,12 +134,16 @@ def translate_witness(curve: int, files):
     return res
 
 
-def set_prover_devices(devices):
+PLACE_AUTO, PLACE_BY_QUERY, PLACE_BY_RANGE = 0, 1, 2
+
+
+def set_prover_devices(devices, mode=PLACE_AUTO):
     """One prover's five query MSMs (rayon_join5, groth16.rs:227-294) over several GPUs: keys built afterwards clone their queries
-    onto `devices` (entry 0 = the key's home GPU; a GPU may be listed more than once). None / one entry switches it off."""
+    onto `devices` (entry 0 = the key's home GPU; a GPU may be listed more than once). mode: whole queries per GPU (BY_QUERY), the
+    k-th range of every query per GPU (BY_RANGE), or AUTO (by query up to two GPUs, by range from three on). None / one entry: off."""
     d = list(devices or [])
     arr = (C.c_int * max(1, len(d)))(*d) if d else None
-    if glib().cog16_set_prover_devices(arr, len(d)) != 0:
+    if glib().cog16_set_prover_devices_mode(arr, len(d), int(mode)) != 0:
         raise CoSnarksHipError(glib().cog16_last_error().decode())
 
 

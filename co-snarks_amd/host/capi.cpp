@@ -1234,8 +1234,12 @@ int cog16_synth_close(void* h) {
 
 // One prover's five query MSMs over several GPUs: keys built after this call clone their queries onto `devices` (entry 0 = the
 // key's home GPU; a GPU may be listed more than once, which is how the single-GPU tests exercise the path). n <= 1 switches it off.
-int cog16_set_prover_devices(const int* devices, int n) {
+int cog16_set_prover_devices_mode(const int* devices, int n, int mode);
+int cog16_set_prover_devices(const int* devices, int n) { return cog16_set_prover_devices_mode(devices, n, 0); }
+// mode: 0 = automatic (whole queries per GPU up to two GPUs, ranges of every query from three on), 1 = whole queries, 2 = ranges
+int cog16_set_prover_devices_mode(const int* devices, int n, int mode) {
   try {
+    if (mode < 0 || mode > 2) throw Error("cog16_set_prover_devices: mode must be 0 (auto), 1 (by query) or 2 (by range)");
     int ndev = 0;
     check(csh_device_count(&ndev), "csh_device_count");
     std::vector<int> d;
@@ -1245,6 +1249,7 @@ int cog16_set_prover_devices(const int* devices, int n) {
     }
     std::lock_guard<std::mutex> g(ProverDevices::get().mu);
     ProverDevices::get().devices = d.size() > 1 ? d : std::vector<int>();
+    ProverDevices::get().mode = mode;
     return 0;
   } catch (const std::exception& e) {
     g_err = e.what();

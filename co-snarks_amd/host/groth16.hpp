@@ -334,77 +334,117 @@ struct CoGroth16 {
                           pkey.b_g2_query.size() == 1 + pub_len + n_aux && pkey.l_query.size() == n_aux && n_aux > 0 &&
                           !getenv("COG16_SEPARATE_MSMS");
     // (a placement only applies to the shared-sort path: the fallback below runs every MSM on this GPU)
-    const bool h_at_home = !same_len || !pkey.placed() || pkey.placement.slot[ProvingKey<P>::Q_H] == 0;
+    const bool h_at_home = !same_len || pkey.slot_has(0, ProvingKey<P>::Q_H);
+    h_acc = Proj<Fq>::inf();
     Joined t5([&] {
       if (!h_at_home) return;
       check(csh_init(cur_dev), "csh_init");  // a new host thread is not bound to the parent's GPU
-      h_acc = T::template msm_public_points_hs<Fq>(BasesView{pkey.h_query.dev, 0, pkey.h_query.size()}, h_dev);
+      size_t lo = 0, hi = pkey.h_query.size();
+      if (same_len) pkey.slot_range(0, pkey.h_query.size() < h_dev.n ? pkey.h_query.size() : h_dev.n, &lo, &hi);
+      if (lo == 0 && hi == pkey.h_query.size()) {
+        h_acc = T::template msm_public_points_hs<Fq>(BasesView{pkey.h_query.dev, 0, pkey.h_query.size()}, h_dev);
+      } else if (hi > lo) {  // BY_RANGE: this GPU's part of h, read in place (every driver's msm_public_points_hs is this MSM)
+        h_acc = msm_device_resident_ptr<Fq>(BasesView{pkey.h_query.dev, lo, hi - lo}, static_cast<const char*>(h_dev.dev) + lo * sizeof(Half), hi - lo);
+      }
     });
     if (same_len) {
       using PK = ProvingKey<P>;
-      csh::Jac<Fq> ja, jb1, jl;
-      csh::Jac<Fq2> jb2;
-      // One slot = the queries placed on one GPU (ProvingKey::place; without a placement everything is slot 0 = this GPU). The
-      // queries of a slot that consume aux_assignment share one digit decomposition + bucket sort (csh_msm_multi_dev), G2 first:
-      // its host fold (Horner over Fp2 windows, ~3x a G1 fold) then runs under the G1 bucket stages that follow.
-      auto run_aux_queries = [&](int slot, const void* aux_scalars) {
+      // One slot = the work placed on one GPU (ProvingKey::place; without a placement everything is slot 0 = this GPU): whole
+      // queries (BY_QUERY) or the slot's contiguous range of every query (BY_RANGE). The aux queries of a slot share one digit
+      // decomposition + bucket sort (csh_msm_multi_dev), G2 first: its host fold (Horner over Fp2 windows, ~3x a G1 fold) then runs
+      // under the G1 bucket stages that follow. Results are per (slot, query) and summed on the host.
+      const size_t nslots = pkey.slots();
+      struct SlotOut {
+        csh::Jac<Fq> a, b1, l;
+        csh::Jac<Fq2> b2;
+        Proj<Fq> h;
+      };
+      std::vector<SlotOut> outs_by_slot(nslots);
+      for (auto& o : outs_by_slot) {
+        o.a = o.b1 = o.l = csh::Jac<Fq>::inf();
+        o.b2 = csh::Jac<Fq2>::inf();
+        o.h = Proj<Fq>::inf();
+      }
+      auto run_aux_queries = [&](size_t slot, const void* aux_scalars_of_range) {
+        SlotOut& o = outs_by_slot[slot];
         const int qs[4] = {PK::Q_B2, PK::Q_A, PK::Q_B1, PK::Q_L};
-        void* const res[4] = {&jb2, &ja, &jb1, &jl};
+        void* const res[4] = {&o.b2, &o.a, &o.b1, &o.l};
+        size_t lo = 0, hi = 0;
+        pkey.slot_range(slot, n_aux, &lo, &hi);
         csh_bases_t hs[4];
         size_t offs[4];
         void* outs[4];
         size_t k = 0;
         for (int i = 0; i < 4; ++i) {
-          if (pkey.placement.slot[qs[i]] != slot) continue;
-          hs[k] = pkey.handle_for(qs[i]);
-          offs[k] = qs[i] == PK::Q_L ? 0 : 1 + pub_len;
+          if (!pkey.slot_has(slot, qs[i])) continue;
+          hs[k] = pkey.handle_for(slot, qs[i]);
+          offs[k] = (qs[i] == PK::Q_L ? 0 : 1 + pub_len) + lo;
           outs[k] = res[i];
           ++k;
         }
-        if (k) check(csh_msm_multi_dev(hs, offs, k, n_aux, reinterpret_cast<const uint64_t*>(aux_scalars), 1, outs, nullptr), "csh_msm_multi_dev");
+        if (k && hi > lo) check(csh_msm_multi_dev(hs, offs, k, hi - lo, reinterpret_cast<const uint64_t*>(aux_scalars_of_range), 1, outs, nullptr), "csh_msm_multi_dev");
       };
-      // the slots on other GPUs: one host thread each, bound to its GPU; the scalars arrive by peer copy (32 bytes per entry over
-      // xGMI), the results are 3 curve points per query on the host
+      // the slots on other GPUs: one host thread each, bound to its GPU; its part of the scalars arrives by peer copy (32 bytes per
+      // entry over xGMI), the results are 3 curve points per query on the host
       std::vector<std::unique_ptr<Joined>> remote;
-      const size_t nslots = pkey.placed() ? pkey.placement.devices.size() : 1;  // (unplaced: every slot[] entry is 0)
       for (size_t sl = 1; sl < nslots; ++sl) {
         bool any_aux = false;
-        for (int q : {PK::Q_B2, PK::Q_A, PK::Q_B1, PK::Q_L}) any_aux |= pkey.placement.slot[q] == (int)sl;
-        const bool has_h = pkey.placement.slot[PK::Q_H] == (int)sl;
+        for (int q : {PK::Q_B2, PK::Q_A, PK::Q_B1, PK::Q_L}) any_aux |= pkey.slot_has(sl, q);
+        const bool has_h = pkey.slot_has(sl, PK::Q_H);
         if (!any_aux && !has_h) continue;
         const int dev = pkey.placement.devices[sl];
         remote.emplace_back(new Joined([&, sl, dev, any_aux, has_h] {
           check(csh_init(dev), "csh_init");
           Span sp("msm group on another GPU (peer copy of the scalars + its queries)");
+          size_t lo = 0, hi = 0;
           if (any_aux) {
-            const DeviceScalars aux_l(n_aux);
-            check(csh_memcpy_peer(aux_l.dev, dev, aux_dev.dev, aux_dev.device, n_aux * sizeof(Half), nullptr), "csh_memcpy_peer");
-            run_aux_queries((int)sl, aux_l.dev);
+            pkey.slot_range(sl, n_aux, &lo, &hi);
+            if (hi > lo) {
+              const DeviceScalars aux_l(hi - lo);
+              check(csh_memcpy_peer(aux_l.dev, dev, static_cast<const char*>(aux_dev.dev) + lo * sizeof(Half), aux_dev.device, (hi - lo) * sizeof(Half), nullptr),
+                    "csh_memcpy_peer");
+              run_aux_queries(sl, aux_l.dev);
+            }
           }
           if (has_h) {
-            const DeviceScalars h_l(h_dev.n);
-            check(csh_memcpy_peer(h_l.dev, dev, h_dev.dev, h_dev.device, h_dev.n * sizeof(Half), nullptr), "csh_memcpy_peer");
-            h_acc = T::template msm_public_points_hs<Fq>(BasesView{pkey.handle_for(PK::Q_H), 0, pkey.h_query.size()}, h_l);
+            pkey.slot_range(sl, pkey.h_query.size() < h_dev.n ? pkey.h_query.size() : h_dev.n, &lo, &hi);
+            if (hi > lo) {
+              const DeviceScalars h_l(hi - lo);
+              check(csh_memcpy_peer(h_l.dev, dev, static_cast<const char*>(h_dev.dev) + lo * sizeof(Half), h_dev.device, (hi - lo) * sizeof(Half), nullptr),
+                    "csh_memcpy_peer");
+              outs_by_slot[sl].h = T::template msm_public_points_hs<Fq>(BasesView{pkey.handle_for(sl, PK::Q_H), lo, hi - lo}, h_l);
+            }
           }
         }));
       }
       try {
-        run_aux_queries(0, aux_dev.dev);
+        size_t lo = 0, hi = 0;
+        pkey.slot_range(0, n_aux, &lo, &hi);
+        run_aux_queries(0, static_cast<const char*>(aux_dev.dev) + lo * sizeof(Half));
       } catch (...) {
         t5.join_quiet();
         for (auto& r : remote) r->join_quiet();
         throw;
       }
       for (auto& r : remote) r->join();
+      t5.join();
       auto to_proj = [](const auto& j) {
         using F = typename std::decay<decltype(j.x)>::type;
         return j.is_inf() ? Proj<F>::inf() : Proj<F>::from_affine(AffineT<F>{j.x, j.y});
       };
-      r_g1 = finish_coeff<Fq>(id, T::template scalar_mul_public_point_hs<Fq>(delta_g1, T::to_half_share(r)), pkey.a_query, pkey.alpha_g1, inputs, to_proj(ja));
-      s_g1 = finish_coeff<Fq>(id, T::template scalar_mul_public_point_hs<Fq>(delta_g1, T::to_half_share(s)), pkey.b_g1_query, pkey.beta_g1, inputs, to_proj(jb1));
-      s_g2 = finish_coeff<Fq2>(id, T::template scalar_mul_public_point_hs<Fq2>(delta_g2, T::to_half_share(s)), pkey.b_g2_query, pkey.beta_g2, inputs, to_proj(jb2));
-      l_acc = to_proj(jl);
-      t5.join();
+      Proj<Fq> ja = Proj<Fq>::inf(), jb1 = Proj<Fq>::inf(), jl = Proj<Fq>::inf();
+      Proj<Fq2> jb2 = Proj<Fq2>::inf();
+      for (size_t sl = 0; sl < nslots; ++sl) {  // BY_QUERY: one slot contributes per query; BY_RANGE: N partial sums each
+        ja = point_add(ja, to_proj(outs_by_slot[sl].a));
+        jb1 = point_add(jb1, to_proj(outs_by_slot[sl].b1));
+        jl = point_add(jl, to_proj(outs_by_slot[sl].l));
+        jb2 = point_add(jb2, to_proj(outs_by_slot[sl].b2));
+        if (sl) h_acc = point_add(h_acc, outs_by_slot[sl].h);
+      }
+      r_g1 = finish_coeff<Fq>(id, T::template scalar_mul_public_point_hs<Fq>(delta_g1, T::to_half_share(r)), pkey.a_query, pkey.alpha_g1, inputs, ja);
+      s_g1 = finish_coeff<Fq>(id, T::template scalar_mul_public_point_hs<Fq>(delta_g1, T::to_half_share(s)), pkey.b_g1_query, pkey.beta_g1, inputs, jb1);
+      s_g2 = finish_coeff<Fq2>(id, T::template scalar_mul_public_point_hs<Fq2>(delta_g2, T::to_half_share(s)), pkey.b_g2_query, pkey.beta_g2, inputs, jb2);
+      l_acc = jl;
     } else {
       // (fallback: separate MSMs from separate host threads, each bound to the parent's GPU)
       auto bind = [cur_dev] { check(csh_init(cur_dev), "csh_init"); };

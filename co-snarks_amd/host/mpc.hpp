@@ -27,14 +27,17 @@ inline Proj<F> msm_device(const BasesView& v, const void* scalars_mont, size_t n
   return Proj<F>::from_affine(AffineT<F>{out.x, out.y});
 }
 
+// scalars already in HBM, given as a raw device pointer (a range of a resident vector)
 template <class F>
-inline Proj<F> msm_device_resident(const BasesView& v, const DeviceScalars& s) {
+inline Proj<F> msm_device_resident_ptr(const BasesView& v, const void* scalars_dev, size_t n) {
   csh::Jac<F> out;
-  const size_t cnt = s.n < v.len ? s.n : v.len;
-  check(csh_msm_dev(v.bases, v.offset, cnt, reinterpret_cast<const uint64_t*>(s.dev), 1, &out, nullptr), "csh_msm_dev");
+  const size_t cnt = n < v.len ? n : v.len;
+  check(csh_msm_dev(v.bases, v.offset, cnt, reinterpret_cast<const uint64_t*>(scalars_dev), 1, &out, nullptr), "csh_msm_dev");
   if (out.is_inf()) return Proj<F>::inf();
   return Proj<F>::from_affine(AffineT<F>{out.x, out.y});
 }
+template <class F>
+inline Proj<F> msm_device_resident(const BasesView& v, const DeviceScalars& s) { return msm_device_resident_ptr<F>(v, s.dev, s.n); }
 
 // ---- Rep3 types (mpc-core/src/protocols/rep3/arithmetic/types.rs:21-28, rngs.rs:83-187) -----------------------
 template <class Fr>

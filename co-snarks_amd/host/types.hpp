@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <stdio.h>
 #include <stdlib.h>
@@ -104,8 +105,10 @@ struct ProverDevices {
     static ProverDevices d;
     return d;
   }
-  std::vector<int> snapshot() {
+  int mode = 0;  // ProvingKey::PLACE_AUTO / PLACE_BY_QUERY / PLACE_BY_RANGE
+  std::vector<int> snapshot(int* mode_out = nullptr) {
     std::lock_guard<std::mutex> g(mu);
+    if (mode_out) *mode_out = mode;
     return devices;
   }
 };
@@ -287,10 +290,17 @@ struct ProvingKey {
   // ratio of a G2 to a G1 MSM (2.5), and clones each non-home query onto its GPU (csh_bases_clone: device to device, tables
   // included). create_proof_device then ships the scalars by peer copy (32 bytes per entry) and runs the groups concurrently.
   enum { Q_A = 0, Q_B1 = 1, Q_B2 = 2, Q_L = 3, Q_H = 4 };
+  // Two shapes of the same idea. BY_QUERY: whole queries are assigned to slots (LPT); the G2 query bounds the gain (N >= 3 GPUs:
+  // ~2.5 G1-units on its slot). BY_RANGE: every slot takes the k-th contiguous range of EVERY query (the four aux queries of a
+  // range still share one digit sort on their slot; the host adds the N partial results per query: N - 1 point additions), so
+  // the work per slot is total / N whatever N is, at the price of smaller MSMs per slot. AUTO = BY_QUERY up to two GPUs,
+  // BY_RANGE from three on.
+  enum { PLACE_AUTO = 0, PLACE_BY_QUERY = 1, PLACE_BY_RANGE = 2 };
   struct Placement {
     std::vector<int> devices;
-    int slot[5] = {0, 0, 0, 0, 0};
-    csh_bases_t clone[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    int mode = PLACE_BY_QUERY;
+    int slot[5] = {0, 0, 0, 0, 0};                    // BY_QUERY: the slot of each query
+    std::vector<std::array<csh_bases_t, 5>> handles;  // [slot][query]; slot 0 = the home handles (not owned)
   } placement;
   size_t query_size(int q) const {
     return q == Q_A ? a_query.size() : q == Q_B1 ? b_g1_query.size() : q == Q_B2 ? b_g2_query.size() : q == Q_L ? l_query.size() : h_query.size();
@@ -298,36 +308,70 @@ struct ProvingKey {
   csh_bases_t home_handle(int q) const {
     return q == Q_A ? a_query.dev : q == Q_B1 ? b_g1_query.dev : q == Q_B2 ? b_g2_query.dev : q == Q_L ? l_query.dev : h_query.dev;
   }
-  csh_bases_t handle_for(int q) const { return placement.slot[q] ? placement.clone[q] : home_handle(q); }
   bool placed() const { return placement.devices.size() > 1; }
-  void unplace() {
-    for (auto& c : placement.clone) {
-      if (c) csh_bases_free(c);
-      c = nullptr;
+  size_t slots() const { return placed() ? placement.devices.size() : 1; }
+  csh_bases_t handle_for(size_t slot, int q) const { return slot == 0 || !placed() ? home_handle(q) : placement.handles[slot][q]; }
+  // does `slot` work on query q, and on which part [lo, hi) of an index space of n entries?
+  bool slot_has(size_t slot, int q) const {
+    if (!placed()) return slot == 0;
+    return placement.mode == PLACE_BY_RANGE ? true : placement.slot[q] == (int)slot;
+  }
+  void slot_range(size_t slot, size_t n, size_t* lo, size_t* hi) const {
+    if (!placed() || placement.mode != PLACE_BY_RANGE) {
+      *lo = 0;
+      *hi = n;
+      return;
     }
+    const size_t ns = placement.devices.size();
+    *lo = n / ns * slot + std::min(slot, n % ns);
+    *hi = *lo + n / ns + (slot < n % ns ? 1 : 0);
+  }
+  void unplace() {
+    for (size_t sl = 1; sl < placement.handles.size(); ++sl)
+      for (auto& c : placement.handles[sl])
+        if (c) csh_bases_free(c);
+    placement.handles.clear();
     for (auto& sl : placement.slot) sl = 0;
     placement.devices.clear();
   }
-  void place(const std::vector<int>& devices) {
+  void place(const std::vector<int>& devices, int mode = PLACE_AUTO) {
     unplace();
     if (devices.size() < 2) return;
-    placement.devices = devices;
     const size_t ns = devices.size();
-    std::vector<double> load(ns, 0.0);
-    int order[5] = {Q_B2, Q_A, Q_B1, Q_L, Q_H};
-    auto weight = [&](int q) { return (q == Q_B2 ? 2.5 : 1.0) * (double)query_size(q); };
-    std::stable_sort(order, order + 5, [&](int x, int y) { return weight(x) > weight(y); });
-    for (int q : order) {
-      if (!home_handle(q) || query_size(q) == 0) continue;
-      size_t best = 0;
-      for (size_t sl = 1; sl < ns; ++sl)
-        if (load[sl] < load[best]) best = sl;
-      load[best] += weight(q);
-      placement.slot[q] = (int)best;
-      if (best) check(csh_bases_clone(home_handle(q), devices[best], &placement.clone[q]), "csh_bases_clone");
+    placement.mode = mode == PLACE_AUTO ? (ns <= 2 ? PLACE_BY_QUERY : PLACE_BY_RANGE) : mode;
+    placement.handles.assign(ns, std::array<csh_bases_t, 5>{nullptr, nullptr, nullptr, nullptr, nullptr});
+    for (int q = 0; q < 5; ++q) placement.handles[0][q] = home_handle(q);
+    placement.devices = devices;  // (set before the clones: unplace() on a failure below frees what was made)
+    try {
+      if (placement.mode == PLACE_BY_RANGE) {
+        for (size_t sl = 1; sl < ns; ++sl)
+          for (int q = 0; q < 5; ++q)
+            if (home_handle(q) && query_size(q)) check(csh_bases_clone(home_handle(q), devices[sl], &placement.handles[sl][q]), "csh_bases_clone");
+        return;
+      }
+      std::vector<double> load(ns, 0.0);
+      int order[5] = {Q_B2, Q_A, Q_B1, Q_L, Q_H};
+      auto weight = [&](int q) { return (q == Q_B2 ? 2.5 : 1.0) * (double)query_size(q); };
+      std::stable_sort(order, order + 5, [&](int x, int y) { return weight(x) > weight(y); });
+      for (int q : order) {
+        if (!home_handle(q) || query_size(q) == 0) continue;
+        size_t best = 0;
+        for (size_t sl = 1; sl < ns; ++sl)
+          if (load[sl] < load[best]) best = sl;
+        load[best] += weight(q);
+        placement.slot[q] = (int)best;
+        if (best) check(csh_bases_clone(home_handle(q), devices[best], &placement.handles[best][q]), "csh_bases_clone");
+      }
+    } catch (...) {
+      unplace();
+      throw;
     }
   }
-  void place_default() { place(ProverDevices::get().snapshot()); }
+  void place_default() {
+    int mode = PLACE_AUTO;
+    const std::vector<int> d = ProverDevices::get().snapshot(&mode);
+    place(d, mode);
+  }
   ~ProvingKey() {
     unplace();
     a_query.release();

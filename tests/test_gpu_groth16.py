@@ -192,14 +192,16 @@ def test_synthetic_circuit_prove_closed_form(gpu, curve, logd):
 # ---- one prover's five query MSMs placed on several GPUs (groth16.rs:227-294: the closures of rayon_join5 are independent) ----
 # The device list may name a GPU more than once: every slot then clones its queries (csh_bases_clone), receives the scalars by
 # csh_memcpy_peer and runs its MSM group from its own host thread -- the whole multi-GPU code path on the one GPU of this box.
-@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0], [0, 0, 0, 0, 0, 0]])
+@pytest.mark.parametrize("devices,mode", [([0, 0], 0), ([0, 0, 0], 0), ([0, 0, 0], 1), ([0, 0, 0, 0, 0, 0], 1), ([0, 0], 2), ([0] * 8, 2)])
 @pytest.mark.parametrize("curve,circ", [("bn254", "poseidon"), ("bls12_381", "multiplier2")])
-def test_plain_prove_with_placed_queries_matches_golden(gpu, curve, circ, devices):
+def test_plain_prove_with_placed_queries_matches_golden(gpu, curve, circ, devices, mode):
+    """mode 1: whole queries per slot; mode 2: the k-th range of every query per slot (multiplier2 has fewer entries than slots:
+    some ranges are empty); mode 0: automatic"""
     from cosnarks_amd import groth16 as g
     zk, wt, vk, pub = _load(curve, circ)
     zko = oz.parse_zkey(zk)
     gold = json.load(open(os.path.join(GOLD, "groth16_golden.json")))[f"{curve}/{circ}"]
-    g.set_prover_devices(devices)
+    g.set_prover_devices(devices, mode)
     try:
         proof, h = g.prove_plain(H.CURVE_IDS[curve], zk, wt, R, S, want_h=True, h_elems=zko.domain_size)
     finally:
@@ -209,14 +211,14 @@ def test_plain_prove_with_placed_queries_matches_golden(gpu, curve, circ, device
     assert og.verify(curve, zko.G1, vk, _as_points(proof), pub)
 
 
-@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0, 0, 0]])
-def test_rep3_prove_with_placed_queries_matches_golden(gpu, devices):
+@pytest.mark.parametrize("devices,mode", [([0, 0], 1), ([0, 0, 0, 0, 0], 1), ([0, 0, 0], 2)])
+def test_rep3_prove_with_placed_queries_matches_golden(gpu, devices, mode):
     from cosnarks_amd import groth16 as g
     curve, circ = "bn254", "poseidon"
     zk, wt, vk, pub = _load(curve, circ)
     zko = oz.parse_zkey(zk)
     gold = json.load(open(os.path.join(GOLD, "groth16_golden.json")))[f"{curve}/{circ}"]
-    g.set_prover_devices(devices)
+    g.set_prover_devices(devices, mode)
     try:
         proof, _ = g.prove_rep3(H.CURVE_IDS[curve], zk, wt, seed=42, r=R, s=S)
         shamir = g.prove_shamir(H.CURVE_IDS[curve], zk, wt, 3, 1, seed=11, r=R, s=S)
@@ -227,11 +229,12 @@ def test_rep3_prove_with_placed_queries_matches_golden(gpu, devices):
     assert og.verify(curve, zko.G1, vk, _as_points(proof), pub)
 
 
-@pytest.mark.parametrize("curve,logd,devices", [("bn254", 14, [0, 0, 0]), ("bn254", 16, [0, 0]), ("bls12_381", 14, [0, 0, 0, 0, 0])])
-def test_synthetic_prove_with_placed_queries_closed_form(gpu, curve, logd, devices):
+@pytest.mark.parametrize("curve,logd,devices,mode", [("bn254", 14, [0, 0, 0], 1), ("bn254", 14, [0, 0, 0], 2), ("bn254", 16, [0, 0], 0),
+                                                     ("bn254", 16, [0] * 8, 2), ("bls12_381", 14, [0, 0, 0, 0, 0], 1), ("bls12_381", 14, [0, 0, 0], 2)])
+def test_synthetic_prove_with_placed_queries_closed_form(gpu, curve, logd, devices, mode):
     """keys large enough for fixed-base tables: the clones carry the tables; plain + three Rep3 parties, closed form"""
     from cosnarks_amd import groth16 as g
-    g.set_prover_devices(devices)
+    g.set_prover_devices(devices, mode)
     try:
         res = g.bench_synthetic(H.CURVE_IDS[curve], logd, iters=2, with_rep3=(logd == 14))
     finally:

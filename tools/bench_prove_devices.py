@@ -21,10 +21,11 @@ ap.add_argument("--log-n", type=int, default=20)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--warmup", type=int, default=2)
 ap.add_argument("--curve", type=int, default=0)
+ap.add_argument("--mode", type=int, default=0, help="0 auto, 1 whole queries per GPU, 2 ranges of every query per GPU")
 a = ap.parse_args()
 devs = [int(x) for x in a.devices.split(",") if x != ""]
 B._check(hip.lib().csh_init(devs[0]))
-g16.set_prover_devices(devs if len(devs) > 1 else None)
+g16.set_prover_devices(devs if len(devs) > 1 else None, a.mode)
 c = g16.SynthCircuit(a.curve, a.log_n)
 for _ in range(a.warmup):
     c.prove()
@@ -35,7 +36,7 @@ for _ in range(a.steps):
     ts.append((time.perf_counter() - t0) * 1e3)
 ok = c.check()
 med = lambda xs: sorted(xs)[len(xs) // 2]
-print(json.dumps({"devices": devs, "log_n": a.log_n, "prove_ms_median": med(ts), "prove_ms_min": min(ts),
+print(json.dumps({"devices": devs, "mode": a.mode, "log_n": a.log_n, "prove_ms_median": med(ts), "prove_ms_min": min(ts),
                   "phases_ms_median": {k: med([p[k] for p in ph]) for k in ("witness_upload_and_map", "msm_groups", "finish")},
                   "key_setup_ms": ph[0]["key_setup_ms"], "closed_form_check": ok}))
 c.close()
