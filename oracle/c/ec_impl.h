@@ -347,6 +347,52 @@ static void EC(gen_bases_wide)(EC(aff)* out, const EC(aff)* gen, uint64_t seed, 
   }
 }
 
+/* Full-range bases, cheap enough for 2^20 points on G2: blocks of PROG_BLK consecutive points S_b + j D_b with S_b = s_b G and
+ * D_b = d_b G for 253-bit s_b, d_b drawn per block (so the discrete logs are s_b + j d_b: full width, a different progression per
+ * block, nothing an MSM could exploit) -- one mixed Jacobian addition per point instead of a 253-bit scalar multiplication, and
+ * one field inversion per block (Montgomery's trick) for the affine forms. */
+#define PROG_BLK 256
+static void EC(gen_bases_progression)(EC(aff)* out, const EC(aff)* gen, uint64_t seed, size_t n, int nthreads) {
+  const size_t nblk = (n + PROG_BLK - 1) / PROG_BLK;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads)
+  for (size_t b = 0; b < nblk; b++) {
+    uint64_t k[8];
+    for (int l = 0; l < 8; l++) {
+      uint64_t x = seed + 8 * b + l + 0x9E3779B97F4A7C15ull;
+      x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+      x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+      k[l] = x ^ (x >> 31);
+    }
+    k[3] >>= 3;
+    k[7] >>= 3;
+    k[4] |= 1;
+    EC(jac) s, d; EC(aff) da;
+    EC(mul_u256)(&s, gen, k);
+    EC(mul_u256)(&d, gen, k + 4);
+    EC(jac_to_aff)(&da, &d);
+    const size_t lo = b * PROG_BLK, cnt = (lo + PROG_BLK <= n ? PROG_BLK : n - lo);
+    EC(jac) pts[PROG_BLK];
+    FE(t) pref[PROG_BLK], inv, t;
+    for (size_t j = 0; j < cnt; j++) {     /* pts[j] = S + j D */
+      pts[j] = s;
+      EC(jac) nx; EC(jac_add_mixed)(&nx, &s, &da); s = nx;
+    }
+    /* batch inversion of the z coordinates (a point at infinity -- z = 0 -- takes no part) */
+    FE(set_one)(&t);
+    for (size_t j = 0; j < cnt; j++) { pref[j] = t; if (!EC(jac_is_inf)(&pts[j])) FE(mul)(&t, &t, &pts[j].z); }
+    FE(inv)(&inv, &t);
+    for (size_t j = cnt; j-- > 0;) {
+      if (EC(jac_is_inf)(&pts[j])) { FE(set_zero)(&out[lo + j].x); FE(set_zero)(&out[lo + j].y); continue; }
+      FE(t) zi, zi2, zi3;
+      FE(mul)(&zi, &inv, &pref[j]);
+      FE(mul)(&inv, &inv, &pts[j].z);
+      FE(sqr)(&zi2, &zi); FE(mul)(&zi3, &zi2, &zi);
+      FE(mul)(&out[lo + j].x, &pts[j].x, &zi2);
+      FE(mul)(&out[lo + j].y, &pts[j].y, &zi3);
+    }
+  }
+}
+
 /* bases[i] = (splitmix64(seed+i)|1) * G (the product's csh_util_generate_bases_dev family) */
 static void EC(gen_bases)(EC(aff)* out, const EC(aff)* gen, uint64_t seed, size_t n, int nthreads) {
 #pragma omp parallel for schedule(static) num_threads(nthreads)

@@ -171,6 +171,15 @@ int oc_generate_bases_wide(int curve, int group, uint64_t seed, size_t n, int nt
   return -1;
 }
 
+int oc_generate_bases_progression(int curve, int group, uint64_t seed, size_t n, int nthreads, uint64_t* out) {
+  nthreads = threads_or_default(nthreads);
+  if (curve == 0 && group == 0) { bn_g1_gen_bases_progression((bn_g1_aff*)out, (const bn_g1_aff*)BN254_G1_GEN, seed, n, nthreads); return 0; }
+  if (curve == 0 && group == 1) { bn_g2_gen_bases_progression((bn_g2_aff*)out, (const bn_g2_aff*)BN254_G2_GEN, seed, n, nthreads); return 0; }
+  if (curve == 1 && group == 0) { bl_g1_gen_bases_progression((bl_g1_aff*)out, (const bl_g1_aff*)BLS381_G1_GEN, seed, n, nthreads); return 0; }
+  if (curve == 1 && group == 1) { bl_g2_gen_bases_progression((bl_g2_aff*)out, (const bl_g2_aff*)BLS381_G2_GEN, seed, n, nthreads); return 0; }
+  return -1;
+}
+
 /* BN254 G1 "hashed" points (family i): x = splitmix-derived field element, incremented until x^3 + 3 is
  * a square; y = rhs^((q+1)/4) (q = 3 mod 4), sign from a PRNG bit. Cofactor 1: every curve point is in the group. No
  * relation to the generator whatsoever. */

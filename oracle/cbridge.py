@@ -93,6 +93,14 @@ def generate_bases_wide(curve: int, group: int, seed: int, n: int, threads=0):
     return out
 
 
+def generate_bases_progression(curve: int, group: int, seed: int, n: int, threads=0):
+    """Full-range points in blocks of 256: S_b + j D_b with 253-bit discrete logs s_b, d_b per block (one addition per point: 2^20
+    G2 points in seconds where k G per point takes minutes)."""
+    out = np.zeros((n, point_words(curve, group)), dtype=np.uint64)
+    assert lib().oc_generate_bases_progression(curve, group, C.c_uint64(seed), C.c_size_t(n), _t(threads), _p(out)) == 0
+    return out
+
+
 def hash_points_bn254_g1(seed: int, n: int, threads=0):
     """SURVEY 8d family (i): x hashed, incremented until x^3 + 3 is a square; y = sqrt, sign from a PRNG bit."""
     out = np.zeros((n, 8), dtype=np.uint64)

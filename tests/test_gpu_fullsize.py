@@ -23,6 +23,25 @@ def _uniform_limbs(rs, n):
     return v
 
 
+@pytest.mark.parametrize("curve,logn", [("bn254", 20), ("bls12_381", 20), ("bls12_381", 22)])
+def test_msm_g2_full_range_points_equals_cpu_restatement(gpu, curve, logn):
+    """G2 at BASELINE sizes on full-range points (oracle/c's progression family: blocks S_b + j D_b with 253-bit discrete logs --
+    k G per point would take minutes on G2), uniform scalars: the affine result is bit-identical to oracle/c's independent
+    Pippenger. 2^22 on BLS12-381 G2 is config 5's kernel at a size where the two-level sort and 16 windows are in play."""
+    cid = H.CURVE_IDS[curve]
+    n = 1 << logn
+    pts = cbridge.generate_bases_progression(cid, 1, 0xD1CE + logn, n)
+    sc = _uniform_limbs(np.random.RandomState(31 + logn), n)
+    sc[:16] = 0
+    bases = gpu.Bases(cid, 1, pts)
+    got = bases.msm(sc, montgomery=True)
+    w = got.size // 3
+    got_aff = np.zeros(2 * w, dtype=np.uint64) if not got[2 * w:].any() else got[:2 * w]
+    want = cbridge.msm_fast(cid, 1, pts, sc, montgomery=True)
+    assert np.array_equal(got_aff, want), (curve, logn)
+    bases.free()
+
+
 @pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
 @pytest.mark.parametrize("logn,ncomp", [(20, 1), (20, 2), (22, 1), (22, 2)])
 def test_ntt_full_size_equals_cpu_restatement(gpu, curve, logn, ncomp):

@@ -55,7 +55,7 @@ def test_plain_prove_with_fresh_randomness_verifies(gpu, curve, circ):
     assert og.verify(curve, zko.G1, vk, _as_points(p2), pub)
 
 
-@pytest.mark.parametrize("curve,circ", [("bn254", "multiplier2"), ("bn254", "poseidon"), ("bls12_381", "multiplier2")])
+@pytest.mark.parametrize("curve,circ", [("bn254", "multiplier2"), ("bn254", "poseidon"), ("bls12_381", "multiplier2"), ("bls12_381", "poseidon")])
 def test_rep3_three_parties_agree_and_match_plain(gpu, curve, circ):
     from cosnarks_amd import groth16 as g
     zk, wt, vk, pub = _load(curve, circ)

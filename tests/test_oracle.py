@@ -144,6 +144,30 @@ def test_c_msm_matches_python(curve, group):
     assert G.eq(G.msm(pts, sc), G.msm_naive(pts, sc))
 
 
+@pytest.mark.parametrize("curve,group", [("bn254", 0), ("bn254", 1), ("bls12_381", 1)])
+def test_c_progression_bases_match_python(curve, group):
+    """oracle/c's cheap full-range point family (the G2 full-size GPU compares run on it): block b holds (s_b + j d_b) G"""
+    G = cv.CURVES[curve][group]
+    seed, n = 77, 600
+    pts = cv.unpack_points(G, cbridge.generate_bases_progression(H.CURVE_IDS[curve], group, seed, n))
+
+    def sm(x):
+        x = (x + 0x9E3779B97F4A7C15) & (2**64 - 1)
+        x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & (2**64 - 1)
+        x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & (2**64 - 1)
+        return x ^ (x >> 31)
+
+    for i in (0, 1, 255, 256, 257, 599):
+        b, j = divmod(i, 256)
+        k = [sm(seed + 8 * b + l) for l in range(8)]
+        k[3] >>= 3
+        k[7] >>= 3
+        k[4] |= 1
+        s_b = sum(k[l] << (64 * l) for l in range(4))
+        d_b = sum(k[4 + l] << (64 * l) for l in range(4))
+        assert G.eq(pts[i], G.mul(G.gen, s_b + j * d_b)), i
+
+
 @pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
 def test_c_ntt_and_vec_ops_match_python(curve):
     F = H.FR[curve]
