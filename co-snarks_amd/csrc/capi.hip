@@ -78,6 +78,7 @@ static const TuneEntry kTune[] = {
     {"msm_seg_buckets", "CSH_MSM_SEG_BUCKETS", &Tune::msm_seg_buckets},
     {"allow_unmasked_rep3", "CSH_ALLOW_UNMASKED_REP3", &Tune::allow_unmasked_rep3},
     {"ntt_variant", "CSH_NTT_VARIANT", &Tune::ntt_variant},
+    {"h_unfused", "CSH_H_UNFUSED", &Tune::h_unfused},
 };
 Tune& tune() {
   static Tune* t = [] {

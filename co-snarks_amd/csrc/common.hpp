@@ -89,6 +89,12 @@ struct HostStage {
 struct Domain;
 int ntt_run(const Domain* d, uint64_t* data, uint32_t ncomp, bool dif, hipStream_t st);
 int ntt_coset_table(const Domain* d, const uint64_t* shift, uint64_t* out_dev, hipStream_t st);
+bool ntt_scale_table_supported(const Domain* d);
+int ntt_run_dif_table(const Domain* d, uint64_t* data, uint32_t ncomp, const uint64_t* scale_table, hipStream_t st);
+int ntt_coset_table_scaled(const Domain* d, const uint64_t* shift, uint64_t* out_dev, hipStream_t st);
+// out = a * b - c (plain / Shamir) and out = rep3_local_mul(a, b) + mask - c: the last step of a witness map in one sweep
+int vec_mul_sub_dev(csh_curve_t f, const uint64_t* a, const uint64_t* b, const uint64_t* c, uint64_t* out, size_t n, hipStream_t st);
+int rep3_local_mul_sub_dev(csh_curve_t f, const uint64_t* a, const uint64_t* b, const uint64_t* mask, const uint64_t* c, uint64_t* out, size_t n, hipStream_t st);
 int ntt_bit_reverse(csh_curve_t c, uint64_t* data, uint32_t log_n, uint32_t ncomp, hipStream_t st);
 size_t domain_size_of(const Domain* d);
 csh_curve_t domain_curve_of(const Domain* d);
@@ -110,6 +116,7 @@ struct Tune {
   std::atomic<int> msm_seg_buckets{0};   // buckets per window-reduction segment (0 = as many segments as fit one round)
   std::atomic<int> allow_unmasked_rep3{0};  // Rep3 products without the re-randomising masks: refused unless set (tests)
   std::atomic<int> ntt_variant{0};
+  std::atomic<int> h_unfused{0};          // Groth16 h pipeline: 1 = the unfused step-by-step sequence (A/B, tests)
 };
 Tune& tune();
 

@@ -1,7 +1,8 @@
-// Fused CircomReduction tail on the device: h = (A*B - C) evaluated on the coset, from the constraint
-// evaluations a, b. Mirrors co-circom/co-groth16/src/groth16/reduction.rs:135-192 step by step
-// (6 NTTs, 2 local_mul_vec, 3 coset-table multiplications, 1 subtraction) on one HIP stream, so a proof
-// needs one upload of a, b (+ masks) and one download of h instead of 12 host<->device round trips.
+// CircomReduction tail on the device: h = (A*B - C) evaluated on the coset, from the constraint evaluations a, b:
+// co-circom/co-groth16/src/groth16/reduction.rs:135-192 (6 NTTs, 2 local_mul_vec, 3 coset-table multiplications, 1 subtraction)
+// on one HIP stream, so a proof needs one upload of a, b (+ masks) and one download of h instead of 12 host<->device round
+// trips. Kernel-level fusion: the three coset-table multiplications ride on the last pass of the inverse transforms (the table
+// carries their 1/n), and the final product and subtraction are one kernel: 8 launches / HBM sweeps of n elements less.
 #include <string.h>
 
 #include "common.hpp"
@@ -44,6 +45,28 @@ int csh_groth16_h_dev(csh_domain_t dom, const uint64_t shift[4], int protocol, u
   uint64_t* ab2 = ar.take<uint64_t>(4 * n);
   uint64_t* ab = h_out;
 
+  // Fused form (default): the coset table carries the inverse transform's 1/n and is applied by the LAST PASS of each
+  // ifft_in_to_out where that pass multiplies by 1/n anyway (no table sweep, no extra multiplication: three sweeps and 3 n
+  // modmuls less), and h = a b - c is one kernel. The unfused sequence below it is the reference's order step by step and runs
+  // when the lazy NTT passes are switched off (CSH_NTT_LAZY=0) or tune "h_unfused" asks for it (A/B, tests).
+  if (ntt_scale_table_supported(d) && !tune().h_unfused.load(std::memory_order_relaxed)) {
+    CSH_TRY(ntt_coset_table_scaled(d, shift, table, st));                                    // reduction.rs:100 (45-60), times 1/n
+    if (protocol == 1)
+      CSH_TRY(csh_rep3_local_mul_vec_dev(f, a, b, mask_c, ab, n, st));                       // :160
+    else
+      CSH_TRY(csh_vec_mul_dev(f, a, b, ab, n, st));
+    for (uint64_t* v : {a, b}) {                                                             // :139-155
+      CSH_TRY(ntt_run_dif_table(d, v, ncomp, table, st));                                    // ifft_in_to_out + distribute_powers
+      CSH_TRY(ntt_run(d, v, ncomp, false, st));
+    }
+    CSH_TRY(ntt_run_dif_table(d, ab, 1, table, st));                                         // :163-171
+    CSH_TRY(ntt_run(d, ab, 1, false, st));                                                   // :174
+    if (protocol == 1)
+      CSH_TRY(rep3_local_mul_sub_dev(f, a, b, mask_ab, ab, h_out, n, st));                   // :182-190 (ab aliases h_out: element-wise)
+    else
+      CSH_TRY(vec_mul_sub_dev(f, a, b, ab, h_out, n, st));
+    return CSH_OK;
+  }
   CSH_TRY(ntt_coset_table(d, shift, table, st));                                             // reduction.rs:100 (45-60)
   if (protocol == 1)
     CSH_TRY(csh_rep3_local_mul_vec_dev(f, a, b, mask_c, ab, n, st));                         // :160

@@ -160,7 +160,7 @@ struct LazyLds {
 
 template <class F, class LZ, bool DIF>
 __global__ __launch_bounds__(NTT_MAX_THREADS) __attribute__((amdgpu_waves_per_eu(8))) void k_ntt_pass_lazy(F* __restrict__ data, const F* __restrict__ twl, int L, int s0, int k, int cb,
-                                                                    int ncomp_log, F scale_lazy, int do_scale) {
+                                                                    int ncomp_log, F scale_lazy, int do_scale, const F* __restrict__ scale_tbl) {
   extern __shared__ uint4 lds_raw[];
   const int cc_log = cb + ncomp_log;
   const int CC = 1 << cc_log;
@@ -231,7 +231,148 @@ __global__ __launch_bounds__(NTT_MAX_THREADS) __attribute__((amdgpu_waves_per_eu
     const size_t t = e >> cc_log;
     const size_t g = ((((hi_idx << k) | t) << mid_bits) | mid) * CC + cc;
     LZ f = lds.get(e);
-    if (do_scale) f = LZ::mul(f, sc);
+    // the 1/n of the inverse transform, or -- witness maps -- a per-entry table that already carries it (1/n times the coset
+    // power of the entry, in the pass's output order): the coset shift costs no sweep and no multiplication of its own
+    if (do_scale) f = LZ::mul(f, scale_tbl ? LZ::unpack(scale_tbl[g >> ncomp_log]) : sc);
+    data[g] = f.canonical_wide().pack();
+  }
+}
+
+// ---- radix-4 form of the lazy pass ---------------------------------------------------------------------------------
+// Two butterfly stages per LDS round trip: a lane owns the four tile entries that stages (q, q + 1) connect, keeps them in
+// registers across both stages and touches LDS once per pair of stages (half the ds traffic, address arithmetic, waits and
+// barriers of the radix-2 loop; three twiddle loads per four butterflies instead of four: the second stage's two twiddles are
+// w and w * omega^(n/4), both straight from the table). 512 lanes per 2048-entry tile (one radix-4 unit per lane and round), two
+// tiles per CU, up to 128 VGPRs per lane. The arithmetic per element is the radix-2 pass's, operation for operation (same
+// operand classes: a round starts from normalised values, the second stage multiplies two-term sums, the outputs are normalised
+// once; in decimation in frequency every sum is folded), so the limb-bound contracts checked by the host self-test carry over.
+// An odd stage count leaves one radix-2 stage (last in DIT, last = local stage 0 in DIF).
+template <class F, class LZ, bool DIF>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_ntt_pass_r4(F* __restrict__ data, const F* __restrict__ twl, int L, int s0, int k,
+                                                                                             int cb, int ncomp_log, F scale_lazy, int do_scale, const F* __restrict__ scale_tbl) {
+  extern __shared__ uint4 lds_raw[];
+  const int cc_log = cb + ncomp_log;
+  const int CC = 1 << cc_log;
+  const int E = 1 << (k + cc_log);
+  const LazyLds<LZ> lds{reinterpret_cast<int32_t*>(lds_raw), E};
+  const int mid_bits = s0 - cb;
+  const size_t tile = blockIdx.x;
+  const size_t mid = tile & ((size_t(1) << mid_bits) - 1);
+  const size_t hi_idx = tile >> mid_bits;
+  const int tid = threadIdx.x;
+  const int NT = blockDim.x;
+
+  for (int e = tid; e < E; e += NT) {
+    const int cc = e & (CC - 1);
+    const size_t t = e >> cc_log;
+    const size_t g = ((((hi_idx << k) | t) << mid_bits) | mid) * CC + cc;
+    lds.put(e, LZ::unpack(data[g]));
+  }
+  __syncthreads();
+
+  // twiddle of global stage s0 + q for the pair whose lower index has local stage bits t_lo (< 2^q)
+  auto twiddle = [&](int q, int t_lo, int cc) {
+    const size_t imod = ((size_t)t_lo << s0) | (mid << cb) | (size_t)(cc >> ncomp_log);
+    return LZ::unpack(twl[imod << (L - 1 - (s0 + q))]);
+  };
+  // stages (q, q + 1) on the four entries t0 + {0, 1, 2, 3} * 2^q of every unit
+  auto round4 = [&](int q) {
+    const int quarter_E = E >> 2;
+    for (int u = tid; u < quarter_E; u += NT) {
+      const int cc = u & (CC - 1);
+      const int tb = u >> cc_log;
+      const int t_lo = tb & ((1 << q) - 1);
+      const int t0 = ((tb >> q) << (q + 2)) | t_lo;
+      const int e0 = (t0 << cc_log) | cc;
+      const int st = 1 << (q + cc_log);
+      LZ x0 = lds.get(e0), x1 = lds.get(e0 + st), x2 = lds.get(e0 + 2 * st), x3 = lds.get(e0 + 3 * st);
+      if (DIF) {
+        {  // stage q + 1: (x0, x2) with w, (x1, x3) with w * omega^(n/4)
+          const LZ w2 = twiddle(q + 1, t_lo, cc), w3 = twiddle(q + 1, t_lo + (1 << q), cc);
+          const LZ d02 = LZ::mul(LZ::sub(x0, x2), w2), d13 = LZ::mul(LZ::sub(x1, x3), w3);
+          x0 = LZ::add(x0, x2).fold_top();
+          x1 = LZ::add(x1, x3).fold_top();
+          x2 = d02;
+          x3 = d13;
+        }
+        {  // stage q: (x0, x1), (x2, x3), one twiddle
+          const LZ w1 = twiddle(q, t_lo, cc);
+          const LZ d01 = LZ::mul(LZ::sub(x0, x1), w1), d23 = LZ::mul(LZ::sub(x2, x3), w1);
+          x0 = LZ::add(x0, x1).fold_top();
+          x2 = LZ::add(x2, x3).fold_top();
+          x1 = d01;
+          x3 = d23;
+        }
+      } else {
+        {  // stage q: inputs normalised, outputs two-term sums (admissible product operands as they are)
+          const LZ w1 = twiddle(q, t_lo, cc);
+          const LZ p1 = LZ::mul(x1, w1), p3 = LZ::mul(x3, w1);
+          x1 = LZ::sub(x0, p1);
+          x0 = LZ::add(x0, p1);
+          x3 = LZ::sub(x2, p3);
+          x2 = LZ::add(x2, p3);
+        }
+        {  // stage q + 1: the carry step runs once per round, on the outputs
+          const LZ w2 = twiddle(q + 1, t_lo, cc), w3 = twiddle(q + 1, t_lo + (1 << q), cc);
+          const LZ p2 = LZ::mul(x2, w2), p3 = LZ::mul(x3, w3);
+          x2 = LZ::sub(x0, p2).normalized();
+          x0 = LZ::add(x0, p2).normalized();
+          x3 = LZ::sub(x1, p3).normalized();
+          x1 = LZ::add(x1, p3).normalized();
+        }
+      }
+      lds.put(e0, x0);
+      lds.put(e0 + st, x1);
+      lds.put(e0 + 2 * st, x2);
+      lds.put(e0 + 3 * st, x3);
+    }
+    __syncthreads();
+  };
+  // one radix-2 stage (odd stage counts): the radix-2 pass's butterfly; in DIT it is the pass's last stage (outputs leave
+  // through mul / canonical_wide, which take two-term limbs), in DIF its inputs come normalised out of the last round
+  auto stage2 = [&](int q) {
+    const int half_E = E >> 1;
+    const int half = 1 << q;
+    for (int bidx = tid; bidx < half_E; bidx += NT) {
+      const int cc = bidx & (CC - 1);
+      const int tb = bidx >> cc_log;
+      const int t_lo = tb & (half - 1);
+      const int t0 = ((tb >> q) << (q + 1)) | t_lo;
+      const int e0 = (t0 << cc_log) | cc;
+      const int e1 = e0 + (half << cc_log);
+      const LZ w = twiddle(q, t_lo, cc);
+      const LZ u = lds.get(e0);
+      const LZ v = lds.get(e1);
+      if (DIF) {
+        lds.put(e0, LZ::add(u, v).fold_top());
+        lds.put(e1, LZ::mul(LZ::sub(u, v), w));
+      } else {
+        const LZ x = LZ::mul(v, w);
+        lds.put(e0, LZ::add(u, x));
+        lds.put(e1, LZ::sub(u, x));
+      }
+    }
+    __syncthreads();
+  };
+  if (DIF) {
+    int q = k;
+    for (; q >= 2; q -= 2) round4(q - 2);
+    if (q == 1) stage2(0);
+  } else {
+    int q = 0;
+    for (; q + 2 <= k; q += 2) round4(q);
+    if (q < k) stage2(q);
+  }
+
+  const LZ sc = LZ::unpack(scale_lazy);
+  for (int e = tid; e < E; e += NT) {
+    const int cc = e & (CC - 1);
+    const size_t t = e >> cc_log;
+    const size_t g = ((((hi_idx << k) | t) << mid_bits) | mid) * CC + cc;
+    LZ f = lds.get(e);
+    // the 1/n of the inverse transform, or -- witness maps -- a per-entry table that already carries it (1/n times the coset
+    // power of the entry, in the pass's output order): the coset shift costs no sweep and no multiplication of its own
+    if (do_scale) f = LZ::mul(f, scale_tbl ? LZ::unpack(scale_tbl[g >> ncomp_log]) : sc);
     data[g] = f.canonical_wide().pack();
   }
 }
@@ -279,6 +420,23 @@ __global__ __launch_bounds__(256) void k_powers(F* out, F base, size_t n, int lo
   }
 }
 
+// out[bitrev(i)] = storage form (packed canonical x * R', what the lazy passes multiply by) of scale * base^i: the coset table of
+// a witness map with the inverse transform's 1/n folded in
+template <class F, class LZ>
+__global__ __launch_bounds__(256) void k_powers_lazy_scaled(F* out, F base, F scale, size_t n, int log_n) {
+  const size_t chunks = (n + POW_CHUNK - 1) / POW_CHUNK;
+  for (size_t c = blockIdx.x * (size_t)256 + threadIdx.x; c < chunks; c += (size_t)gridDim.x * 256) {
+    const size_t i0 = c * POW_CHUNK;
+    F cur = F::mul(F::pow_u64(base, (uint64_t)i0), scale);
+    for (int k = 0; k < POW_CHUNK; ++k) {
+      const size_t i = i0 + k;
+      if (i >= n) break;
+      out[bitrev_n((uint32_t)i, log_n)] = LZ::repack_for_storage(cur);
+      cur = F::mul(cur, base);
+    }
+  }
+}
+
 // ---- host-side helpers -----------------------------------------------------------------------------
 template <class F>
 static F f_from_words(const void* p) {
@@ -316,13 +474,17 @@ static int plan_passes(int L, int ncomp_log, Pass* out) {
 }
 
 template <class F>
-static int run_ntt(const Domain* d, F* data, uint32_t ncomp, bool dif, hipStream_t st) {
+static int run_ntt(const Domain* d, F* data, uint32_t ncomp, bool dif, hipStream_t st, const F* scale_tbl = nullptr) {
   const int L = (int)d->log_n;
   if (L == 0) return CSH_OK;  // size-1 transform is the identity (1/n = 1)
   const int ncomp_log = ncomp == 2 ? 1 : 0;
   Pass passes[8];
   const int np = plan_passes(L, ncomp_log, passes);
   const bool use_lazy = tune().ntt_lazy.load(std::memory_order_relaxed) != 0;
+  if (scale_tbl && (!use_lazy || !dif)) {
+    set_error("a scale table needs the lazy decimation-in-frequency passes");
+    return CSH_ERR_INVALID;
+  }
   using LZ = typename LazyOf<F>::type;
   const F* tw = reinterpret_cast<const F*>(use_lazy ? (dif ? d->tw_inv_lazy : d->tw_fwd_lazy) : (dif ? d->tw_inv : d->tw_fwd));
   F scale = f_from_words<F>(use_lazy ? d->n_inv_lazy : d->n_inv);
@@ -345,12 +507,36 @@ static int run_ntt(const Domain* d, F* data, uint32_t ncomp, bool dif, hipStream
           raised_lazy[dif ? 1 : 0] = true;
         }
       }
+      // tune "ntt_variant" bit 0 set: the radix-4 pass (two stages per LDS round trip, 512 lanes per tile) for passes of at least two
+      // stages. Measured against the radix-2 pass (profiles/r03_c_ntt_r4.log): 11 % fewer instructions per butterfly and the same
+      // time at 2^16..2^22 (0.609 / 0.557 against 0.602 / 0.560 ms at 2^22), -4 % at 2^24; with the next tile prefetched into
+      // registers by persistent workgroups it spilled at the 128-VGPR budget and lost 5-15 % (profiles/r03_d_ntt_r4p.log). The pass
+      // is not bound by its instruction count alone; the radix-2 pass stays the default, this one is kept for A/B runs and tests.
+      const bool r4 = (tune().ntt_variant.load(std::memory_order_relaxed) & 1) != 0 && p.k >= 2 && tile_log + ncomp_log >= 2;
+      if (r4) {
+        if (lds_bytes > 48 * 1024) {
+          static thread_local bool raised_r4[2] = {false, false};
+          if (!raised_r4[dif ? 1 : 0]) {
+            const void* fn = dif ? (const void*)k_ntt_pass_r4<F, LZ, true> : (const void*)k_ntt_pass_r4<F, LZ, false>;
+            CSH_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (4 * LZ::NL) << NTT_TILE_LOG));
+            raised_r4[dif ? 1 : 0] = true;
+          }
+        }
+        const size_t units = (size_t(1) << (tile_log + ncomp_log)) >> 2;
+        const int nt = units >= 512 ? 512 : (units >= 64 ? (int)units : 64);
+        if (dif)
+          hipLaunchKernelGGL((k_ntt_pass_r4<F, LZ, true>), dim3((unsigned)tiles), dim3(nt), lds_bytes, st, data, tw, L, p.s0, p.k, p.cb, ncomp_log, scale, do_scale, scale_tbl);
+        else
+          hipLaunchKernelGGL((k_ntt_pass_r4<F, LZ, false>), dim3((unsigned)tiles), dim3(nt), lds_bytes, st, data, tw, L, p.s0, p.k, p.cb, ncomp_log, scale, 0, (const F*)nullptr);
+        CSH_HIP(hipGetLastError());
+        continue;
+      }
       if (dif)
         hipLaunchKernelGGL((k_ntt_pass_lazy<F, LZ, true>), dim3((unsigned)tiles), dim3(NTT_THREADS), lds_bytes, st, data, tw, L, p.s0, p.k, p.cb,
-                           ncomp_log, scale, do_scale);
+                           ncomp_log, scale, do_scale, scale_tbl);
       else
         hipLaunchKernelGGL((k_ntt_pass_lazy<F, LZ, false>), dim3((unsigned)tiles), dim3(NTT_THREADS), lds_bytes, st, data, tw, L, p.s0, p.k, p.cb,
-                           ncomp_log, scale, 0);
+                           ncomp_log, scale, 0, (const F*)nullptr);
       CSH_HIP(hipGetLastError());
       continue;
     }
@@ -488,6 +674,28 @@ int ntt_run(const Domain* d, uint64_t* data, uint32_t ncomp, bool dif, hipStream
   if (d->curve == CSH_BN254) return run_ntt<Bn254Fr>(d, (Bn254Fr*)data, ncomp, dif, st);
   if (d->curve == CSH_BLS12_377) return run_ntt<Bls377Fr>(d, (Bls377Fr*)data, ncomp, dif, st);
   return run_ntt<Bls381Fr>(d, (Bls381Fr*)data, ncomp, dif, st);
+}
+// ifft_in_to_out whose last pass multiplies entry i by table[i] instead of 1/n (table from ntt_coset_table_scaled); false when
+// the lazy passes are switched off (the caller then runs the unfused sequence)
+bool ntt_scale_table_supported(const Domain* d) { return tune().ntt_lazy.load(std::memory_order_relaxed) != 0 && d->log_n >= 1; }
+int ntt_run_dif_table(const Domain* d, uint64_t* data, uint32_t ncomp, const uint64_t* scale_table, hipStream_t st) {
+  if (d->curve == CSH_BN254) return run_ntt<Bn254Fr>(d, (Bn254Fr*)data, ncomp, true, st, (const Bn254Fr*)scale_table);
+  if (d->curve == CSH_BLS12_377) return run_ntt<Bls377Fr>(d, (Bls377Fr*)data, ncomp, true, st, (const Bls377Fr*)scale_table);
+  return run_ntt<Bls381Fr>(d, (Bls381Fr*)data, ncomp, true, st, (const Bls381Fr*)scale_table);
+}
+template <class F>
+static int coset_table_scaled_t(const Domain* d, const uint64_t* shift, uint64_t* out_dev, hipStream_t st) {
+  using LZ = typename LazyOf<F>::type;
+  hipLaunchKernelGGL((k_powers_lazy_scaled<F, LZ>), dim3(grid_for((d->n + POW_CHUNK - 1) / POW_CHUNK, 256)), dim3(256), 0, st, (F*)out_dev, f_from_words<F>(shift),
+                     f_from_words<F>(d->n_inv), d->n, (int)d->log_n);
+  CSH_HIP(hipGetLastError());
+  return CSH_OK;
+}
+// table[bitrev(i)] = shift^i / n in the storage form of the lazy passes
+int ntt_coset_table_scaled(const Domain* d, const uint64_t* shift, uint64_t* out_dev, hipStream_t st) {
+  if (d->curve == CSH_BN254) return coset_table_scaled_t<Bn254Fr>(d, shift, out_dev, st);
+  if (d->curve == CSH_BLS12_377) return coset_table_scaled_t<Bls377Fr>(d, shift, out_dev, st);
+  return coset_table_scaled_t<Bls381Fr>(d, shift, out_dev, st);
 }
 int ntt_coset_table(const Domain* d, const uint64_t* shift, uint64_t* out_dev, hipStream_t st) {
   if (d->curve == CSH_BN254) return coset_table_t<Bn254Fr>(d, shift, out_dev, st);

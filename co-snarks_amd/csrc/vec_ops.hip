@@ -27,6 +27,14 @@ __global__ __launch_bounds__(VB) void k_vec_mul(const F* __restrict__ a, const F
     out[i] = LZ::mul(LZ::unpack(a[i]), LZ::unpack(b[i]).times32()).canonical_wide().pack();
   }
 }
+// out = a * b - c in one sweep (h = a b - c, reduction.rs:176-190): the difference is limb-wise on the reduced product
+template <class F>
+__global__ __launch_bounds__(VB) void k_vec_mul_sub(const F* __restrict__ a, const F* __restrict__ b, const F* c /* may alias out */, F* out, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)VB + threadIdx.x; i < n; i += (size_t)gridDim.x * VB) {
+    using LZ = typename LazyOf<F>::type;
+    out[i] = LZ::sub(LZ::mul(LZ::unpack(a[i]), LZ::unpack(b[i]).times32()), LZ::unpack(c[i])).canonical_wide().pack();
+  }
+}
 
 template <class F, bool SUB>
 __global__ __launch_bounds__(VB) void k_vec_addsub(const F* __restrict__ a, const F* __restrict__ b, F* out, size_t n) {
@@ -48,7 +56,7 @@ __global__ __launch_bounds__(VB) void k_vec_mul_table(F* v, const F* __restrict_
 // Rep3 local multiplication (mpc-core rep3/arithmetic/ops.rs:69-76) + mask
 template <class F>
 __global__ __launch_bounds__(VB) void k_rep3_local_mul(const F* __restrict__ lhs, const F* __restrict__ rhs,
-                                                       const F* __restrict__ mask, F* out, size_t n) {
+                                                       const F* __restrict__ mask, const F* sub /* may alias out */, F* out, size_t n) {
   for (size_t i = blockIdx.x * (size_t)VB + threadIdx.x; i < n; i += (size_t)gridDim.x * VB) {
     F la = lhs[2 * i], lb = lhs[2 * i + 1];
     F ra = rhs[2 * i], rb = rhs[2 * i + 1];
@@ -58,6 +66,7 @@ __global__ __launch_bounds__(VB) void k_rep3_local_mul(const F* __restrict__ lhs
     const LZ xa = LZ::unpack(la), xb = LZ::unpack(lb), ya = LZ::unpack(ra), yb = LZ::unpack(rb);
     LZ r = LZ::reduce(LZ::mul_add_wide(xa, LZ::add(ya, yb).times32(), xb, ya.times32()));
     if (mask) r = LZ::add(r, LZ::unpack(mask[i]));
+    if (sub) r = LZ::sub(r, LZ::unpack(sub[i]));
     out[i] = r.canonical_wide().pack();
   }
 }
@@ -112,6 +121,13 @@ static int vec_mul_t(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t
   return CSH_OK;
 }
 template <class F>
+static int vec_mul_sub_t(const uint64_t* a, const uint64_t* b, const uint64_t* c, uint64_t* out, size_t n, hipStream_t st) {
+  if (n == 0) return CSH_OK;
+  hipLaunchKernelGGL(k_vec_mul_sub<F>, dim3(vec_grid(n)), dim3(VB), 0, st, (const F*)a, (const F*)b, (const F*)c, (F*)out, n);
+  CSH_HIP(hipGetLastError());
+  return CSH_OK;
+}
+template <class F>
 static int vec_addsub_t(bool sub, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n_elems, hipStream_t st) {
   if (n_elems == 0) return CSH_OK;
   if (sub)
@@ -129,9 +145,9 @@ static int vec_mul_table_t(uint64_t* v, const uint64_t* table, size_t n, uint32_
   return CSH_OK;
 }
 template <class F>
-static int rep3_local_mul_t(const uint64_t* l, const uint64_t* r, const uint64_t* m, uint64_t* out, size_t n, hipStream_t st) {
+static int rep3_local_mul_t(const uint64_t* l, const uint64_t* r, const uint64_t* m, uint64_t* out, size_t n, hipStream_t st, const uint64_t* sub = nullptr) {
   if (n == 0) return CSH_OK;
-  hipLaunchKernelGGL(k_rep3_local_mul<F>, dim3(vec_grid(n)), dim3(VB), 0, st, (const F*)l, (const F*)r, (const F*)m, (F*)out, n);
+  hipLaunchKernelGGL(k_rep3_local_mul<F>, dim3(vec_grid(n)), dim3(VB), 0, st, (const F*)l, (const F*)r, (const F*)m, (const F*)sub, (F*)out, n);
   CSH_HIP(hipGetLastError());
   return CSH_OK;
 }
@@ -184,6 +200,15 @@ using namespace csh;
     case CSH_BLS12_377: { using F = Bls377Fr; return CALL; }         \
     default: set_error("unknown curve %d", (int)(field_of)); return CSH_ERR_INVALID; \
   }
+
+namespace csh {
+int vec_mul_sub_dev(csh_curve_t f, const uint64_t* a, const uint64_t* b, const uint64_t* c, uint64_t* out, size_t n, hipStream_t st) {
+  FR_DISPATCH(f, vec_mul_sub_t<F>(a, b, c, out, n, st));
+}
+int rep3_local_mul_sub_dev(csh_curve_t f, const uint64_t* a, const uint64_t* b, const uint64_t* mask, const uint64_t* c, uint64_t* out, size_t n, hipStream_t st) {
+  FR_DISPATCH(f, rep3_local_mul_t<F>(a, b, mask, out, n, st, c));
+}
+}  // namespace csh
 
 extern "C" {
 

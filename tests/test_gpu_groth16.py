@@ -43,6 +43,25 @@ def test_plain_prove_matches_golden_and_verifies(gpu, curve, circ):
     assert proof["protocol"] == "groth16" and proof["pi_a"][2] == "1"    # circom.proof schema
 
 
+@pytest.mark.parametrize("curve,circ", [("bn254", "poseidon"), ("bls12_381", "poseidon")])
+def test_h_pipeline_unfused_sequence_matches_golden(gpu, curve, circ):
+    """The default h pipeline folds the coset table into the last pass of the inverse transforms and a b - c into one kernel; the
+    step-by-step sequence of reduction.rs:135-192 (tune h_unfused) must give the same h, plain and with three Rep3 parties."""
+    from cosnarks_amd import groth16 as g
+    zk, wt, vk, pub = _load(curve, circ)
+    zko = oz.parse_zkey(zk)
+    gold = json.load(open(os.path.join(GOLD, "groth16_golden.json")))[f"{curve}/{circ}"]
+    with gpu.tuned(h_unfused=1):
+        proof, h = g.prove_plain(H.CURVE_IDS[curve], zk, wt, R, S, want_h=True, h_elems=zko.domain_size)
+        proof3, hs = g.prove_rep3(H.CURVE_IDS[curve], zk, wt, seed=42, r=R, s=S, want_h=True, h_elems=zko.domain_size)
+    assert [str(x) for x in H.unpack(zko.Fr, h)] == gold["h"]
+    n = zko.domain_size
+    parts = [H.unpack(zko.Fr, hs[4 * n * p:4 * n * (p + 1)]) for p in range(3)]
+    assert [str((a + b + c) % zko.Fr.p) for a, b, c in zip(*parts)] == gold["h"]
+    for p in (proof, proof3):
+        assert p["pi_a"][:2] == gold["a"] and p["pi_b"][:2] == gold["b"] and p["pi_c"][:2] == gold["c"]
+
+
 @pytest.mark.parametrize("curve,circ", [("bn254", "multiplier2"), ("bn254", "poseidon")])
 def test_plain_prove_with_fresh_randomness_verifies(gpu, curve, circ):
     from cosnarks_amd import groth16 as g

@@ -75,9 +75,33 @@ def hist(insts):
     return h, c
 
 
+def scratch_report(path, sub):
+    """--scratch: where a kernel touches scratch (spills / stack traffic of out-of-line calls): per basic block with scratch
+    instructions, its size and multiply-add count. Hot-loop blocks carry hundreds to thousands of multiply-adds; a block with
+    scratch traffic and none is a call site / cold path."""
+    text = open(path).read()
+    name, body = kernel_body(text, sub)
+    bl = blocks(body)
+    hot = sorted(bl, key=lambda x: -sum(1 for m, _ in x[1] if classify(m) == "mad64"))[:4]
+    print("kernel", name[:110])
+    print("  %d blocks; largest multiply-add blocks: %s" % (len(bl), ", ".join("%s (%d instr, %d mad64, %d scratch)" % (
+        b, len(i), sum(1 for m, _ in i if classify(m) == "mad64"), sum(1 for m, _ in i if m.startswith("scratch_"))) for b, i in hot)))
+    any_sc = False
+    for bname, insts in bl:
+        sc = [s for m, s in insts if m.startswith("scratch_")]
+        if sc:
+            any_sc = True
+            print("  scratch in block %-14s %5d instr, %4d mad64, %3d scratch ops (%d loads, %d stores)" % (
+                bname, len(insts), sum(1 for m, _ in insts if classify(m) == "mad64"), len(sc), sum("load" in x for x in sc), sum("store" in x for x in sc)))
+    if not any_sc:
+        print("  no scratch instructions")
+
+
 def main():
     if len(sys.argv) < 3:
         raise SystemExit(__doc__)
+    if "--scratch" in sys.argv:
+        return scratch_report(sys.argv[1], sys.argv[2])
     text = open(sys.argv[1]).read()
     nblocks = int(sys.argv[sys.argv.index("--blocks") + 1]) if "--blocks" in sys.argv else 6
     name, body = kernel_body(text, sys.argv[2])
