@@ -2,6 +2,8 @@
 // Montgomery multiplication is made of, and modmul throughput of candidate limb representations.
 // Results drive the choice of field representation in the MSM kernels (DESIGN.md "integer roofline").
 // Not part of include/cosnarks_hip.h; exported for bench/profiling harnesses only.
+// (the signed-lazy multiplier is probed in the form the accumulate and NTT kernels run it: multiply-add order pinned)
+#define CSH_PIN_MADS 3
 #include "common.hpp"
 #include "field.hpp"
 #include "field29.hpp"
@@ -110,6 +112,17 @@ __global__ __launch_bounds__(UB_BLK) void k_modmul29(const Bn254Fq* in, Bn254Fq*
   out[i] = Fq29::add(x, y).to_fp();
 }
 
+// the multiplier of the bucket and NTT kernels: signed lazy 9 x 29-bit limbs, product scanning (field29.hpp FpS::mul)
+__global__ __launch_bounds__(UB_BLK) void k_modmul29s(const Bn254Fq* in, Bn254Fq* out, int iters) {
+  const int i = blockIdx.x * UB_BLK + threadIdx.x;
+  Fq29s x = Fq29s::from_fp(in[i]), y = Fq29s::from_fp(in[i ^ 1]);
+  for (int it = 0; it < iters; ++it) {
+    x = Fq29s::mul(x, y);
+    y = Fq29s::mul(y, x);
+  }
+  out[i] = Fq29s::add(x, y).normalized().to_fp();
+}
+
 // FETCH_SIZE / WRITE_SIZE calibration (tools/gpu_calib.py under rocprofv3 --pmc): every lane reads ONE record of REC bytes
 // from a table far larger than the 256 MiB Infinity Cache -- at a hashed index (the access pattern of k_msm_accum's base
 // gather: REC = 64 / 96 / 128 / 192 for the four groups) or at its own index (SEQ: the coalesced streaming pattern the
@@ -204,6 +217,8 @@ int csh_microbench(int kind, int iters, double* ops_per_s) {
     rc = time_kernel(k_modmul<Bn254Fq>, dim3(blocks), dim3(UB_BLK), &ms, (const Bn254Fq*)in, (Bn254Fq*)out, iters);
   else if (kind == 11)
     rc = time_kernel(k_modmul29, dim3(blocks), dim3(UB_BLK), &ms, (const Bn254Fq*)in, (Bn254Fq*)out, iters);
+  else if (kind == 14)
+    rc = time_kernel(k_modmul29s, dim3(blocks), dim3(UB_BLK), &ms, (const Bn254Fq*)in, (Bn254Fq*)out, iters);
   else
     rc = time_kernel(k_modmul<Bls381Fq>, dim3(blocks), dim3(UB_BLK), &ms, (const Bls381Fq*)in, (Bls381Fq*)out, iters);
   (void)hipFree(in);

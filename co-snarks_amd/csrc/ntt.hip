@@ -198,14 +198,26 @@ __global__ __launch_bounds__(NTT_MAX_THREADS) __attribute__((amdgpu_waves_per_eu
       const int e0 = (t0 << cc_log) | cc;
       const int e1 = e0 + (half << cc_log);
       const size_t imod = ((size_t)t_lo << s0) | (mid << cb) | (size_t)(cc >> ncomp_log);
+#ifdef CSH_NTT_ABLATE_TW  // ablation builds only (tools/experiments/gpu_r3_h.sh): one of 64 table entries -- wrong results, no gather
+      const LZ w = LZ::unpack(twl[(imod << tw_shift) & 63]);
+#else
       const LZ w = LZ::unpack(twl[imod << tw_shift]);
+#endif
       const LZ u = lds.get(e0);
       const LZ v = lds.get(e1);
       if (DIF) {
         lds.put(e0, LZ::add(u, v).fold_top());   // sums feed sums here: keep the value within (-p, 2p) every stage
+#ifdef CSH_NTT_ABLATE_MUL
+        lds.put(e1, LZ::add(LZ::sub(u, v), w));
+#else
         lds.put(e1, LZ::mul(LZ::sub(u, v), w));  // the two-term difference is an admissible product operand as is
+#endif
       } else {
+#ifdef CSH_NTT_ABLATE_MUL  // ablation builds only: no multiplication (wrong results): the memory / LDS / barrier floor of the pass
+        const LZ x = LZ::add(v, w);
+#else
         const LZ x = LZ::mul(v, w);
+#endif
         if (NORM) {
           lds.put(e0, LZ::add(u, x).normalized());
           lds.put(e1, LZ::sub(u, x).normalized());

@@ -15,7 +15,8 @@ L = hip.lib()
 res = {"microbench_Gops": {}, "msm": []}
 names = {0: "v_mad_u64_u32", 8: "v_mad_i64_i32", 1: "v_lshl_add_u64", 6: "v_ashrrev_i64", 2: "v_add_co+addc_u32", 7: "v_alignbit+ashr_i32",
          3: "v_mul_lo_u32", 4: "v_add_u32", 5: "v_mul_hi_u32", 13: "v_fma_f64",
-         10: "modmul_bn254_fq_32x8_cios", 11: "modmul_bn254_fq_29x9_lazy", 12: "modmul_bls381_fq_32x12_cios"}
+         10: "modmul_bn254_fq_32x8_cios", 11: "modmul_bn254_fq_29x9_lazy", 12: "modmul_bls381_fq_32x12_cios",
+         14: "modmul_bn254_fq_29x9_signed_scan"}
 for kind, nm in ([] if os.environ.get("PROBE_SKIP_UB") else names.items()):
     v = C.c_double(0)
     iters = 2000 if (kind < 10 or kind == 13) else 200
