@@ -505,8 +505,8 @@ def run_groth16_prove(cx: Ctx, args):
         try:
             g16.set_prover_devices(devices if len(devices) > 1 else None, args.placement)
             circ = g16.SynthCircuit(cx.hip.BN254, args.log_n)
-            for _ in range(args.warmup):
-                circ.prove()
+            for _ in range(args.warmup + 2):      # + 2 untimed setup proofs: the slot threads' streams, arenas and pooled buffers are
+                circ.prove()                      # created on first use (the same role as --spinup in the MSM workloads)
         except Exception as e:  # noqa: BLE001
             err = repr(e)
     cx.barrier()
