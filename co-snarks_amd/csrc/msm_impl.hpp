@@ -284,11 +284,60 @@ __global__ __launch_bounds__(256) void k_msm_merge_giant(MsmParams p, const uint
   }
 }
 
+// ---- fused merge (round 3) -----------------------------------------------------------------------------------------
+// Variant (msm_variant bit 4; measured slower on G1, see bucket_group): the window reduction folds a bucket's partial slots itself
+// while it walks its segment (a bucket of ~32 entries spans 1.6 lanes of 55 on average: ~0.6 extra additions per bucket on the
+// reduction's chain) instead of reading a dense array that a separate merge launch wrote. Buckets with more than MERGE_CAP partials
+// still go through the block-wide tree (k_msm_merge_giant), which writes their sum to dense[]; k_msm_mark_giant queues them (what
+// k_msm_merge does on the side).
+template <class Cfg>
+__global__ __launch_bounds__(256) void k_msm_mark_giant(MsmParams p, const uint32_t* __restrict__ start, uint32_t* giant_count, uint32_t* giant_list) {
+  const int w = blockIdx.y;
+  const uint32_t b = blockIdx.x * 256 + threadIdx.x + 1;
+  if (b > p.NB) return;
+  const uint32_t* st = start + (size_t)w * (p.NB + 2);
+  const uint32_t lo = st[b], hi = st[b + 1];
+  if (hi > lo && (hi - 1) / p.L - lo / p.L >= MERGE_CAP) {
+    const uint32_t g = atomicAdd(giant_count, 1u);
+    giant_list[2 * g] = (uint32_t)w;
+    giant_list[2 * g + 1] = b;
+  }
+}
+// sum of bucket t of one window: four lanes per point / two lanes per Fp2 point
+template <class Cfg>
+__device__ __forceinline__ QPt<typename Cfg::L> qbucket_merged(const MsmParams& p, const uint32_t* __restrict__ st, const LazyPt<Cfg>* __restrict__ pw,
+                                                               const LazyPt<Cfg>* __restrict__ dw, uint32_t t, int role) {
+  using L = typename Cfg::L;
+  const uint32_t lo = st[t], hi = st[t + 1];
+  if (hi <= lo) return qpt_inf<L>();
+  const uint32_t k0 = lo / p.L, k1 = (hi - 1) / p.L;
+  if (k1 - k0 >= MERGE_CAP) return qpt_load<L>(&dw[t], role);
+  QPt<L> acc = qpt_load<L>(&pw[t + k0], role);
+  for (uint32_t k = k0 + 1; k <= k1; ++k) qadd<L>(acc, qpt_load<L>(&pw[t + k], role), role);
+  return acc;
+}
+template <class Cfg>
+__device__ __forceinline__ XYZZLazy<typename Cfg::LP> pbucket_merged(const MsmParams& p, const uint32_t* __restrict__ st, const LazyPt<Cfg>* __restrict__ pw,
+                                                                     const LazyPt<Cfg>* __restrict__ dw, uint32_t t, int role) {
+  using L = typename Cfg::LP;
+  const uint32_t lo = st[t], hi = st[t + 1];
+  if (hi <= lo) return XYZZLazy<L>::inf();
+  const uint32_t k0 = lo / p.L, k1 = (hi - 1) / p.L;
+  if (k1 - k0 >= MERGE_CAP) return dw[t].empty ? XYZZLazy<L>::inf() : pair_load(&dw[t], role);
+  XYZZLazy<L> acc = pw[t + k0].empty ? XYZZLazy<L>::inf() : pair_load(&pw[t + k0], role);
+  for (uint32_t k = k0 + 1; k <= k1; ++k) {
+    if (pw[t + k].empty) continue;
+    const XYZZLazy<L> q = pair_load(&pw[t + k], role);
+    lazy_add_inl<L>(acc, q);
+  }
+  return acc;
+}
+
 // Segment k of window w folds dense buckets [t0, t1): returns sum_t t * B_t by the running-sum trick with explicit gaps
 // (empty buckets are skipped; a gap of more than 4 empty buckets is bridged by one small scalar multiple).
-template <class Cfg>
+template <class Cfg, bool FUSED>
 __global__ __launch_bounds__(256) void k_msm_reduce(MsmParams p, const LazyPt<Cfg>* __restrict__ dense,
-                                                    LazyPt<Cfg>* segres) {
+                                                    LazyPt<Cfg>* segres, const uint32_t* __restrict__ start, const LazyPt<Cfg>* __restrict__ partial) {
   using L = typename Cfg::L;
   const int w = blockIdx.y;
   const int role = threadIdx.x & 3;
@@ -302,8 +351,12 @@ __global__ __launch_bounds__(256) void k_msm_reduce(MsmParams p, const LazyPt<Cf
   uint32_t prev_b = 0;
   if (t0 < t1) {
     const LazyPt<Cfg>* dw = dense + (size_t)w * (p.NB + 1);
+    const uint32_t* st = FUSED ? start + (size_t)w * (p.NB + 2) : nullptr;
+    const LazyPt<Cfg>* pw = FUSED ? partial + (size_t)w * p.tmax : nullptr;
     for (uint32_t t = t1; t-- > t0;) {
-      const QPt<L> pt = qpt_load<L>(&dw[t], role);
+      QPt<L> pt;
+      if constexpr (FUSED) pt = qbucket_merged<Cfg>(p, st, pw, dw, t, role);
+      else pt = qpt_load<L>(&dw[t], role);
       if (pt.empty) continue;
       uint32_t gap = prev_b ? prev_b - t : 0;
       if (gap) {
@@ -373,8 +426,9 @@ __global__ __launch_bounds__(RED_BLK) void k_msm_reduce_serial(MsmParams p, cons
 
 // The lane-serial reduction with two lanes per segment (G2, curve_pair.hpp): half the registers per lane (no scratch) and half
 // the instructions on the dependent chain of every point operation.
-template <class Cfg>
-__global__ __launch_bounds__(RED_BLK) void k_msm_reduce_pair(MsmParams p, const LazyPt<Cfg>* __restrict__ dense, LazyPt<Cfg>* segres) {
+template <class Cfg, bool FUSED>
+__global__ __launch_bounds__(RED_BLK) void k_msm_reduce_pair(MsmParams p, const LazyPt<Cfg>* __restrict__ dense, LazyPt<Cfg>* segres,
+                                                             const uint32_t* __restrict__ start, const LazyPt<Cfg>* __restrict__ partial) {
   using L = typename Cfg::LP;
   const int w = blockIdx.y;
   const int role = pair_role();
@@ -388,9 +442,17 @@ __global__ __launch_bounds__(RED_BLK) void k_msm_reduce_pair(MsmParams p, const 
   uint32_t prev_b = 0;
   if (t0 < t1) {
     const LazyPt<Cfg>* dw = dense + (size_t)w * (p.NB + 1);
+    const uint32_t* st = FUSED ? start + (size_t)w * (p.NB + 2) : nullptr;
+    const LazyPt<Cfg>* pw = FUSED ? partial + (size_t)w * p.tmax : nullptr;
     for (uint32_t t = t1; t-- > t0;) {
-      if (dw[t].empty) continue;
-      const XYZZLazy<L> pt = pair_load(&dw[t], role);
+      XYZZLazy<L> pt;
+      if constexpr (FUSED) {
+        pt = pbucket_merged<Cfg>(p, st, pw, dw, t, role);
+        if (pt.empty) continue;
+      } else {
+        if (dw[t].empty) continue;
+        pt = pair_load(&dw[t], role);
+      }
       uint32_t gap = prev_b ? prev_b - t : 0;
       if (gap) {
         if (gap <= 4) {
@@ -753,7 +815,20 @@ int bucket_group(const void* points, const MsmParams& p, const SortOut& so, cons
     }
   }
   if (ev) CSH_HIP(hipEventRecord(ev[4], st));
-  hipLaunchKernelGGL(k_msm_merge<Cfg>, dim3((p.NB + TAIL_Q - 1) / TAIL_Q, nw), dim3(TAIL_BLK), 0, st, p, start, partial, dense, giant, giant + 2);
+  const int variant = tune().msm_variant.load(std::memory_order_relaxed);
+  int form;  // 0 lane-serial, 1 quad, 2 pair
+  if constexpr (Cfg::PAIR) form = (variant & 1) ? 1 : ((variant & 4) ? 0 : 2);
+  else form = (variant & 1) ? 0 : 1;
+  // tune "msm_variant" bit 4 (16): the reduction merges a bucket's partial slots itself (fused merge above) instead of reading the
+  // dense array of a separate merge launch. Measured (profiles/r03_i_fused_merge.log): it LOSES on G1 -- tail 0.36 against 0.33 ms at
+  // 2^20, 0.69 / 0.46 at 2^22, 1.00 / 0.54 at 2^24 (at L = 256 a bucket spans 2-3 lanes: the extra additions sit on the reduction's
+  // dependent chain, while the merge launch does them with one quad per bucket, all buckets at once) and gains 5 % of the tail on
+  // BLS12-381 G2 only. Kept as a parity-tested variant; the separate merge launch stays the default.
+  const bool fused = form != 0 && (variant & 16) != 0;
+  if (fused)
+    hipLaunchKernelGGL(k_msm_mark_giant<Cfg>, dim3((p.NB + 255) / 256, nw), dim3(256), 0, st, p, start, giant, giant + 2);
+  else
+    hipLaunchKernelGGL(k_msm_merge<Cfg>, dim3((p.NB + TAIL_Q - 1) / TAIL_Q, nw), dim3(TAIL_BLK), 0, st, p, start, partial, dense, giant, giant + 2);
   // buckets with > MERGE_CAP partials (heavily repeated scalars): block-wide tree, grid-stride over the queue
   hipLaunchKernelGGL(k_msm_merge_giant<Cfg>, dim3(bb.giant_blocks), dim3(256), 0, st, p, start, partial, dense, giant, giant + 2);
   // Window reduction, three forms of the same segment walk, each with as many segments as fit one round of its waves
@@ -763,17 +838,17 @@ int bucket_group(const void* points, const MsmParams& p, const SortOut& so, cons
   // form needs 437-512 VGPRs + scratch -- and half the dependent chain per point operation; BN254 G2 2^20 tail 1.05 -> 0.81 ms,
   // BLS12-381 G2 3.2 -> 2.1 ms, profiles/r02_g_seg_stages2.log), or one lane per segment. tune "msm_variant" picks another
   // form for A/B runs and tests: G1: bit 0 -> lane-serial; G2: bit 0 -> four lanes, bit 2 -> lane-serial.
-  const int variant = tune().msm_variant.load(std::memory_order_relaxed);
-  int form;  // 0 lane-serial, 1 quad, 2 pair
-  if constexpr (Cfg::PAIR) form = (variant & 1) ? 1 : ((variant & 4) ? 0 : 2);
-  else form = (variant & 1) ? 0 : 1;
   MsmParams pr = p;  // the reduction's own segmentation (never more segments than the plan sized the buffers for)
   if (form == 1) {
     pr.S = std::min(p.S, reduce_segments(p.NB, p.W, 4));
-    hipLaunchKernelGGL(k_msm_reduce<Cfg>, dim3((pr.S + 63) / 64, nw), dim3(256), 0, st, pr, dense, segres);
+    if (fused) hipLaunchKernelGGL((k_msm_reduce<Cfg, true>), dim3((pr.S + 63) / 64, nw), dim3(256), 0, st, pr, dense, segres, start, partial);
+    else hipLaunchKernelGGL((k_msm_reduce<Cfg, false>), dim3((pr.S + 63) / 64, nw), dim3(256), 0, st, pr, dense, segres, start, partial);
   } else if (form == 2) {
     pr.S = std::min(p.S, reduce_segments(p.NB, p.W, 2));
-    if constexpr (Cfg::PAIR) hipLaunchKernelGGL(k_msm_reduce_pair<Cfg>, dim3((pr.S + RED_BLK / 2 - 1) / (RED_BLK / 2), nw), dim3(RED_BLK), 0, st, pr, dense, segres);
+    if constexpr (Cfg::PAIR) {
+      if (fused) hipLaunchKernelGGL((k_msm_reduce_pair<Cfg, true>), dim3((pr.S + RED_BLK / 2 - 1) / (RED_BLK / 2), nw), dim3(RED_BLK), 0, st, pr, dense, segres, start, partial);
+      else hipLaunchKernelGGL((k_msm_reduce_pair<Cfg, false>), dim3((pr.S + RED_BLK / 2 - 1) / (RED_BLK / 2), nw), dim3(RED_BLK), 0, st, pr, dense, segres, start, partial);
+    }
   } else {
     hipLaunchKernelGGL(k_msm_reduce_serial<Cfg>, dim3((pr.S + RED_BLK - 1) / RED_BLK, nw), dim3(RED_BLK), 0, st, pr, dense, segres);
   }

@@ -18,6 +18,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <string>
 #include <vector>
 
 #include "msm_impl.hpp"
@@ -257,7 +258,15 @@ int csh_msm_split_rank_dev(csh_comm_t comm, csh_bases_t bases, size_t offset, si
   }
   hipStream_t st = resolve_stream(stream);
   const size_t pb = partial_bytes_of(B->curve, B->group);
-  CSH_TRY(partial_async(B, offset, n, scalars_dev, mont, c->part_dev, st));
+  // A rank whose own range fails (out of memory in the sort arena, ...) must still enter the collective, or its peers wait in
+  // ncclAllGather forever: it contributes a zeroed record (no magic), every rank's fold then refuses the gathered set, and this
+  // rank reports its original error.
+  const int rc_local = partial_async(B, offset, n, scalars_dev, mont, c->part_dev, st);
+  std::string local_err;
+  if (rc_local != CSH_OK) {
+    local_err = csh_last_error();
+    (void)hipMemsetAsync(c->part_dev, 0, pb, st);
+  }
   const char* src = c->part_dev;
   if (c->nranks > 1) {
     Rccl* R = rccl();
@@ -266,6 +275,10 @@ int csh_msm_split_rank_dev(csh_comm_t comm, csh_bases_t bases, size_t offset, si
   }
   CSH_HIP(hipMemcpyAsync(c->gather_host, src, pb * (size_t)c->nranks, hipMemcpyDeviceToHost, st));
   CSH_HIP(hipStreamSynchronize(st));
+  if (rc_local != CSH_OK) {
+    set_error("%s", local_err.c_str());
+    return rc_local;
+  }
   return fold(B->curve, B->group, c->gather_host, (size_t)c->nranks, out_jacobian);
 }
 
@@ -305,6 +318,7 @@ int csh_msm_split(const csh_bases_t* bases, const size_t* offsets, const size_t*
     if (std::find(devs.begin(), devs.end(), parts[i].dev) == devs.end()) devs.push_back(parts[i].dev);
   }
   int rc = CSH_OK;
+  std::vector<hipEvent_t> peer_events;
   auto body = [&]() -> int {
     for (int d : devs) {
       CSH_TRY(csh_init(d));
@@ -340,7 +354,7 @@ int csh_msm_split(const csh_bases_t* bases, const size_t* offsets, const size_t*
       host = host_plain.data();
     } else if (mode == CSH_SPLIT_PEER) {
       const int root = devs[0];
-      std::vector<hipEvent_t> evs;
+      std::vector<hipEvent_t>& evs = peer_events;  // destroyed by the caller on every path (error returns included)
       for (size_t i = 0; i < k; ++i) {
         if (parts[i].dev == root) continue;
         CSH_TRY(csh_init(parts[i].dev));
@@ -365,7 +379,6 @@ int csh_msm_split(const csh_bases_t* bases, const size_t* offsets, const size_t*
       host_plain.resize(pb * k);
       CSH_HIP(hipMemcpyAsync(host_plain.data(), gather, pb * k, hipMemcpyDeviceToHost, rs));
       CSH_HIP(hipStreamSynchronize(rs));
-      for (hipEvent_t e : evs) (void)hipEventDestroy(e);
       host = host_plain.data();
     } else {
       Rccl* R = rccl();
@@ -397,6 +410,13 @@ int csh_msm_split(const csh_bases_t* bases, const size_t* offsets, const size_t*
   };
   rc = body();
   std::string keep = rc != CSH_OK ? std::string(csh_last_error()) : std::string();
+  if (rc != CSH_OK) {
+    // An error return must not leave kernels or copies of the earlier parts in flight: they write arena and communicator
+    // buffers the next call reuses. Drain the lane stream of every device this call touched before handing control back.
+    for (int d : devs)
+      if (csh_init(d) == CSH_OK) (void)hipStreamSynchronize(resolve_stream(nullptr));
+  }
+  for (hipEvent_t e : peer_events) (void)hipEventDestroy(e);
   (void)csh_init(saved);
   if (rc != CSH_OK) set_error("%s", keep.c_str());
   return rc;

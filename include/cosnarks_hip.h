@@ -162,7 +162,10 @@ int csh_comm_info(csh_comm_t comm, int* rank, int* nranks, int* device); /* any 
 int csh_comm_destroy(csh_comm_t comm);
 /* This rank's share of one split MSM: sum_{i<n} scalars[i] * bases[offset+i] over its own range -> window sums -> all-gather
  * over the communicator -> fold. Every rank receives the full result in out_jacobian (host, as csh_msm). Synchronous;
- * collective: every rank of the communicator must call it (n may be 0 on a rank). */
+ * collective: every rank of the communicator must call it (n may be 0 on a rank). A rank whose own range fails on the device still
+ * takes part in the exchange with an empty record, so that its peers return an error ("bad partial header") instead of waiting for
+ * it; argument errors (NULL pointers, wrong device, range outside the bases) are reported before the collective and must be avoided
+ * by the caller on every rank alike. */
 int csh_msm_split_rank_dev(csh_comm_t comm, csh_bases_t bases, size_t offset, size_t n, const uint64_t* scalars_dev,
                            int scalars_are_montgomery, void* out_jacobian, void* stream);
 /* One thread driving all GPUs: part i = counts[i] points from offsets[i] of bases[i] (a handle on any device; several parts

@@ -87,14 +87,16 @@ def test_msm_window_sizes(gpu):
 
 
 @pytest.mark.parametrize("curve,group", [("bn254", 1), ("bls12_381", 1), ("bn254", 0), ("bls12_381", 0)])
-@pytest.mark.parametrize("variant", [1, 2, 4, 6])
+@pytest.mark.parametrize("variant", [1, 2, 4, 6, 16, 17])
 def test_msm_kernel_form_variants(gpu, curve, group, variant):
     """Every form of the bucket kernels that is not the default of its group (tune "msm_variant"): G2: bit 1 = two lanes per point in
     the accumulate kernel (csrc/curve_pair.hpp), bit 0 / bit 2 = four-lane / lane-serial window reduction instead of the two-lane
-    one; G1: bit 0 = lane-serial window reduction instead of the four-lane one. Same group element as the oracle on random points
-    with duplicates, P / -P, points at infinity and the edge scalars, at several window widths (the doubling and cancellation
-    paths run through the DPP exchanges too)."""
-    if group == 0 and variant != 1:
+    one; G1: bit 0 = lane-serial window reduction instead of the four-lane one; bit 4 (16) = the reduction merges each bucket's
+    partial slots itself instead of reading the merge launch's dense array (17 on G2: the same with the four-lane reduction). Same
+    group element as the oracle on random points with duplicates, P / -P, points at infinity and the edge scalars (r - 1 on every
+    point = one giant bucket: the queue of k_msm_mark_giant), at several window widths (the doubling and cancellation paths run
+    through the DPP exchanges too)."""
+    if group == 0 and variant not in (1, 16):
         pytest.skip("bits 1 and 2 only select G2 kernels")
     G = cv.CURVES[curve][group]
     F = H.FR[curve]
