@@ -33,7 +33,7 @@ struct Domain {
   size_t n;
   void* tw_fwd;  // w^j, j < n/2
   void* tw_inv;  // w^-j
-  void* tw_fwd_lazy;  // same powers as packed canonical w^j * R' (R' = 2^261): twiddles of the lazy-field butterflies
+  void* tw_fwd_lazy;  // the powers the lazy butterflies use, as packed canonical w^j * R' (R' = 2^261), one contiguous run per stage
   void* tw_inv_lazy;
   uint32_t n_inv_lazy[8];  // (1/n) * R', packed
   uint32_t gen[8], gen_inv[8], n_inv[8];  // Montgomery
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(NTT_MAX_THREADS) __attribute__((amdgpu_waves_per_eu
   auto stage = [&](int q, auto norm_tag) {
     constexpr bool NORM = decltype(norm_tag)::value;
     const int half = 1 << q;
-    const int tw_shift = L - 1 - (s0 + q);
+    const size_t stage_base = (size_t(1) << (s0 + q)) - 1;
     for (int bidx = tid; bidx < half_E; bidx += NT) {
       const int cc = bidx & (CC - 1);
       const int tb = bidx >> cc_log;
@@ -199,9 +199,9 @@ __global__ __launch_bounds__(NTT_MAX_THREADS) __attribute__((amdgpu_waves_per_eu
       const int e1 = e0 + (half << cc_log);
       const size_t imod = ((size_t)t_lo << s0) | (mid << cb) | (size_t)(cc >> ncomp_log);
 #ifdef CSH_NTT_ABLATE_TW  // ablation builds only (tools/experiments/gpu_r3_h.sh): one of 64 table entries -- wrong results, no gather
-      const LZ w = LZ::unpack(twl[(imod << tw_shift) & 63]);
+      const LZ w = LZ::unpack(twl[imod & 63]);
 #else
-      const LZ w = LZ::unpack(twl[imod << tw_shift]);
+      const LZ w = LZ::unpack(twl[stage_base + imod]);  // staged table: stage s0 + q starts at 2^(s0 + q) - 1
 #endif
       const LZ u = lds.get(e0);
       const LZ v = lds.get(e1);
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   // twiddle of global stage s0 + q for the pair whose lower index has local stage bits t_lo (< 2^q)
   auto twiddle = [&](int q, int t_lo, int cc) {
     const size_t imod = ((size_t)t_lo << s0) | (mid << cb) | (size_t)(cc >> ncomp_log);
-    return LZ::unpack(twl[imod << (L - 1 - (s0 + q))]);
+    return LZ::unpack(twl[((size_t(1) << (s0 + q)) - 1) + imod]);  // staged table
   };
   // stages (q, q + 1) on the four entries t0 + {0, 1, 2, 3} * 2^q of every unit
   auto round4 = [&](int q) {
@@ -299,11 +299,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       const int st = 1 << (q + cc_log);
       LZ x0 = lds.get(e0), x1 = lds.get(e0 + st), x2 = lds.get(e0 + 2 * st), x3 = lds.get(e0 + 3 * st);
       if (DIF) {
+        // Value / limb bounds of a round (inputs: normalised limbs, values within (-p, 2.2 p)): the first stage's sums stay below
+        // 4.4 p and only take the parallel carry step (their differences, < 6.5 p in magnitude with two-term limbs, are admissible
+        // product operands: the contract is |value| < 8 p); the second stage's sum of sums (< 8.8 p) is folded below 2 p; the sum of
+        // the two fresh products (< 2.2 p) again only takes the carry step. Two folds per round instead of four.
         {  // stage q + 1: (x0, x2) with w, (x1, x3) with w * omega^(n/4)
           const LZ w2 = twiddle(q + 1, t_lo, cc), w3 = twiddle(q + 1, t_lo + (1 << q), cc);
           const LZ d02 = LZ::mul(LZ::sub(x0, x2), w2), d13 = LZ::mul(LZ::sub(x1, x3), w3);
-          x0 = LZ::add(x0, x2).fold_top();
-          x1 = LZ::add(x1, x3).fold_top();
+          x0 = LZ::add(x0, x2).normalized();
+          x1 = LZ::add(x1, x3).normalized();
           x2 = d02;
           x3 = d13;
         }
@@ -311,7 +315,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
           const LZ w1 = twiddle(q, t_lo, cc);
           const LZ d01 = LZ::mul(LZ::sub(x0, x1), w1), d23 = LZ::mul(LZ::sub(x2, x3), w1);
           x0 = LZ::add(x0, x1).fold_top();
-          x2 = LZ::add(x2, x3).fold_top();
+          x2 = LZ::add(x2, x3).normalized();
           x1 = d01;
           x3 = d23;
         }
@@ -390,9 +394,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 }
 
 // out[i] = in[i] re-encoded from x * 2^256 to packed canonical x * R'
+// Twiddle table of the lazy passes, STAGED: stage s (half-size m = 2^s) reads w^(j * n / 2m), j < 2^s, i.e. every 2^(L-1-s)-th
+// entry of the natural table -- for the late stages of a tile, 64 lanes of a wave gathered 64 cache lines up to 64 KiB apart. Here
+// every stage has its own contiguous run: out[(2^s - 1) + j] = storage form of in[j << (L - 1 - s)], 2^L - 1 entries in all (twice
+// the natural table), so that neighbouring lanes (neighbouring j) read neighbouring 32-byte entries.
 template <class F, class LZ>
-__global__ __launch_bounds__(256) void k_to_lazy_table(const F* __restrict__ in, F* __restrict__ out, size_t n) {
-  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = LZ::repack_for_storage(in[i]);
+__global__ __launch_bounds__(256) void k_to_lazy_table(const F* __restrict__ in, F* __restrict__ out, int L) {
+  const size_t total = (size_t(1) << L) - 1;
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int s = 63 - __clzll((unsigned long long)(i + 1));  // stage: 2^s - 1 <= i < 2^(s+1) - 1
+    const size_t j = i + 1 - (size_t(1) << s);
+    out[i] = LZ::repack_for_storage(in[j << (L - 1 - s)]);
+  }
 }
 
 __device__ __forceinline__ uint32_t bitrev_n(uint32_t i, int log_n) { return log_n == 0 ? 0 : (__brev(i) >> (32 - log_n)); }
@@ -519,12 +532,14 @@ static int run_ntt(const Domain* d, F* data, uint32_t ncomp, bool dif, hipStream
           raised_lazy[dif ? 1 : 0] = true;
         }
       }
-      // tune "ntt_variant" bit 0 set: the radix-4 pass (two stages per LDS round trip, 512 lanes per tile) for passes of at least two
-      // stages. Measured against the radix-2 pass (profiles/r03_c_ntt_r4.log): 11 % fewer instructions per butterfly and the same
-      // time at 2^16..2^22 (0.609 / 0.557 against 0.602 / 0.560 ms at 2^22), -4 % at 2^24; with the next tile prefetched into
-      // registers by persistent workgroups it spilled at the 128-VGPR budget and lost 5-15 % (profiles/r03_d_ntt_r4p.log). The pass
-      // is not bound by its instruction count alone; the radix-2 pass stays the default, this one is kept for A/B runs and tests.
-      const bool r4 = (tune().ntt_variant.load(std::memory_order_relaxed) & 1) != 0 && p.k >= 2 && tile_log + ncomp_log >= 2;
+      // Radix-4 pass (two stages per LDS round trip, 512 lanes per tile) or radix-2 pass. With the staged twiddle tables and two
+      // folds per decimation-in-frequency round the radix-4 pass wins from 2^20 points on (one box, inverse / forward ms: 2^22
+      // 0.583 / 0.541 -> 0.553 / 0.526, 2^24 2.36 / 2.04 -> 2.31 / 2.06, 2^20 0.153 / 0.142 -> 0.150 / 0.141; another box 2^22 forward
+      // 0.549 -> 0.510) and ties or loses below (profiles/r03_k_ntt_staged.log, r03_l_ntt_mix.log). Default: transforms of >= 2^20
+      // points take it; tune "ntt_variant" 1 forces it everywhere, 2 forces the radix-2 pass.
+      const int nv = tune().ntt_variant.load(std::memory_order_relaxed);
+      const bool r4_default = L >= 20;
+      const bool r4 = ((nv & 1) != 0 || (r4_default && (nv & 2) == 0)) && p.k >= 2 && tile_log + ncomp_log >= 2;
       if (r4) {
         if (lds_bytes > 48 * 1024) {
           static thread_local bool raised_r4[2] = {false, false};
@@ -648,11 +663,12 @@ static int create_domain_t(csh_curve_t curve, uint32_t log_n, const uint64_t* ge
   hipLaunchKernelGGL((k_powers<F, false>), dim3(grid_for((half + POW_CHUNK - 1) / POW_CHUNK, 256)), dim3(256), 0, st, (F*)d->tw_inv, gen_inv, half, 0);
   using LZ = typename LazyOf<F>::type;
   d->tw_fwd_lazy = d->tw_inv_lazy = nullptr;
-  hipError_t e4 = hipMalloc(&d->tw_fwd_lazy, half * sizeof(F));
-  hipError_t e5 = hipMalloc(&d->tw_inv_lazy, half * sizeof(F));
-  if (e4 == hipSuccess && e5 == hipSuccess) {
-    hipLaunchKernelGGL((k_to_lazy_table<F, LZ>), dim3(grid_for(half, 256)), dim3(256), 0, st, (const F*)d->tw_fwd, (F*)d->tw_fwd_lazy, half);
-    hipLaunchKernelGGL((k_to_lazy_table<F, LZ>), dim3(grid_for(half, 256)), dim3(256), 0, st, (const F*)d->tw_inv, (F*)d->tw_inv_lazy, half);
+  const size_t staged = d->n > 1 ? d->n - 1 : 1;  // one contiguous run per stage: 2^L - 1 entries
+  hipError_t e4 = hipMalloc(&d->tw_fwd_lazy, staged * sizeof(F));
+  hipError_t e5 = hipMalloc(&d->tw_inv_lazy, staged * sizeof(F));
+  if (e4 == hipSuccess && e5 == hipSuccess && d->log_n >= 1) {
+    hipLaunchKernelGGL((k_to_lazy_table<F, LZ>), dim3(grid_for(staged, 256)), dim3(256), 0, st, (const F*)d->tw_fwd, (F*)d->tw_fwd_lazy, (int)d->log_n);
+    hipLaunchKernelGGL((k_to_lazy_table<F, LZ>), dim3(grid_for(staged, 256)), dim3(256), 0, st, (const F*)d->tw_inv, (F*)d->tw_inv_lazy, (int)d->log_n);
   }
   {
     const F nl = LZ::repack_for_storage(n_inv);  // host evaluation of the same template

@@ -61,7 +61,7 @@ for r in rows("vecops_ntt_pmc_hbm_bytes.csv"):
         f = ff.get("stream_64", 2.0)
         out["kernels"]["k_rep3_local_mul 2^24"] = {"traffic_bytes": int(fb * f + wb), "fetch_bytes_raw": int(fb), "fetch_factor": f, "write_bytes": int(wb),
                                                    "file": f"profiles/{tag}_vecops_ntt_pmc_hbm_bytes.csv"}
-    if "k_ntt_pass_lazy" in r["kernel"]:
+    if "k_ntt_pass_lazy" in r["kernel"] or "k_ntt_pass_r4" in r["kernel"]:
         seen_ntt.append((fb, wb, int(r["launches"])))
 if seen_ntt:
     # one transform = 3 passes; the loop runs inverse and forward transforms alternately: average per transform over both kinds
