@@ -133,6 +133,19 @@ __global__ __launch_bounds__(NTT_MAX_THREADS) void k_ntt_pass(F* __restrict__ da
 // tile is brought back to [0, p) once per pass when it is stored (canonical_wide).
 // limb-major LDS tile: limbs (2i, 2i+1) of element e live in an 8-byte slot of pair-array i (ds_read/write_b64, lane
 // stride 8 bytes: conflict-free), the odd last limb in a 4-byte array behind them -- 5 LDS accesses per element instead of 9
+// Entry idx of a staged twiddle table: limbs 0..7 of the canonical w * R' as the 8 words of slot idx (two 16-byte loads), limb 8
+// in an int32 array behind the `slots` slots -- ready to multiply by, no re-slicing per butterfly.
+template <class F, class LZ>
+__device__ __forceinline__ LZ load_sliced_twiddle(const F* __restrict__ twl, size_t idx, size_t slots) {
+  static_assert(LZ::NL == F::N + 1, "one limb more than 32-bit words");
+  const F f = twl[idx];
+  LZ r;
+#pragma unroll
+  for (int i = 0; i < F::N; ++i) r.l[i] = (int32_t)f.l[i];
+  r.l[F::N] = reinterpret_cast<const int32_t*>(twl + slots)[idx];
+  return r;
+}
+
 template <class LZ>
 struct LazyLds {
   int32_t* base;
@@ -199,9 +212,9 @@ __global__ __launch_bounds__(NTT_MAX_THREADS) __attribute__((amdgpu_waves_per_eu
       const int e1 = e0 + (half << cc_log);
       const size_t imod = ((size_t)t_lo << s0) | (mid << cb) | (size_t)(cc >> ncomp_log);
 #ifdef CSH_NTT_ABLATE_TW  // ablation builds only (tools/experiments/gpu_r3_h.sh): one of 64 table entries -- wrong results, no gather
-      const LZ w = LZ::unpack(twl[imod & 63]);
+      const LZ w = load_sliced_twiddle<F, LZ>(twl, imod & 63, (size_t(1) << L) - 1);
 #else
-      const LZ w = LZ::unpack(twl[stage_base + imod]);  // staged table: stage s0 + q starts at 2^(s0 + q) - 1
+      const LZ w = load_sliced_twiddle<F, LZ>(twl, stage_base + imod, (size_t(1) << L) - 1);  // staged table: stage s0 + q starts at 2^(s0 + q) - 1
 #endif
       const LZ u = lds.get(e0);
       const LZ v = lds.get(e1);
@@ -285,7 +298,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   // twiddle of global stage s0 + q for the pair whose lower index has local stage bits t_lo (< 2^q)
   auto twiddle = [&](int q, int t_lo, int cc) {
     const size_t imod = ((size_t)t_lo << s0) | (mid << cb) | (size_t)(cc >> ncomp_log);
-    return LZ::unpack(twl[((size_t(1) << (s0 + q)) - 1) + imod]);  // staged table
+    return load_sliced_twiddle<F, LZ>(twl, ((size_t(1) << (s0 + q)) - 1) + imod, (size_t(1) << L) - 1);  // staged table
   };
   // stages (q, q + 1) on the four entries t0 + {0, 1, 2, 3} * 2^q of every unit
   auto round4 = [&](int q) {
@@ -401,10 +414,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 template <class F, class LZ>
 __global__ __launch_bounds__(256) void k_to_lazy_table(const F* __restrict__ in, F* __restrict__ out, int L) {
   const size_t total = (size_t(1) << L) - 1;
+  int32_t* top = reinterpret_cast<int32_t*>(out + total);  // limb 8 of every entry, behind the slots of limbs 0..7
   for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int s = 63 - __clzll((unsigned long long)(i + 1));  // stage: 2^s - 1 <= i < 2^(s+1) - 1
     const size_t j = i + 1 - (size_t(1) << s);
-    out[i] = LZ::repack_for_storage(in[j << (L - 1 - s)]);
+    const LZ v = LZ::from_fp(in[j << (L - 1 - s)]).canonical();
+    F f;
+#pragma unroll
+    for (int k = 0; k < F::N; ++k) f.l[k] = (uint32_t)v.l[k];
+    out[i] = f;
+    top[i] = v.l[F::N];
   }
 }
 
@@ -664,8 +683,8 @@ static int create_domain_t(csh_curve_t curve, uint32_t log_n, const uint64_t* ge
   using LZ = typename LazyOf<F>::type;
   d->tw_fwd_lazy = d->tw_inv_lazy = nullptr;
   const size_t staged = d->n > 1 ? d->n - 1 : 1;  // one contiguous run per stage: 2^L - 1 entries
-  hipError_t e4 = hipMalloc(&d->tw_fwd_lazy, staged * sizeof(F));
-  hipError_t e5 = hipMalloc(&d->tw_inv_lazy, staged * sizeof(F));
+  hipError_t e4 = hipMalloc(&d->tw_fwd_lazy, staged * (sizeof(F) + sizeof(int32_t)));  // pre-sliced: 8 + 1 limbs per entry
+  hipError_t e5 = hipMalloc(&d->tw_inv_lazy, staged * (sizeof(F) + sizeof(int32_t)));
   if (e4 == hipSuccess && e5 == hipSuccess && d->log_n >= 1) {
     hipLaunchKernelGGL((k_to_lazy_table<F, LZ>), dim3(grid_for(staged, 256)), dim3(256), 0, st, (const F*)d->tw_fwd, (F*)d->tw_fwd_lazy, (int)d->log_n);
     hipLaunchKernelGGL((k_to_lazy_table<F, LZ>), dim3(grid_for(staged, 256)), dim3(256), 0, st, (const F*)d->tw_inv, (F*)d->tw_inv_lazy, (int)d->log_n);
