@@ -301,17 +301,41 @@ class MsmJob:
         self._pts_dev = None
 
 
+_LIVE = {}
+
+
+def live_probe(cx, kind: int, iters: int):
+    """Instruction-rate / modmul-rate probe of the library (csh_microbench, the same chains tools/gpu_probe.py runs) on THIS box, once
+    per process: the boxes of the pool differ by ~5 % in clocks, so a peak read from a file measured elsewhere would shift every
+    `alu.frac` by that much. None if the probe is unavailable."""
+    if kind not in _LIVE:
+        try:
+            v = cx.C.c_double(0)
+            best = 0.0
+            for _ in range(3):
+                cx.B._check(cx.L.csh_microbench(kind, iters, cx.C.byref(v)))
+                best = max(best, v.value)
+            _LIVE[kind] = best
+        except Exception:  # noqa: BLE001
+            _LIVE[kind] = None
+    return _LIVE[kind]
+
+
 def msm_roofline(job: MsmJob, rin: dict, log_n_local: int):
     stage_ms, (c_bits, n_win, lane_len, n_seg) = job.stage_timing()
     t_acc = stage_ms[3] * 1e-3
     kname = {"bn254_g1": "Bn254G1", "bn254_g2": "Bn254G2", "bls12_381_g1": "Bls381G1", "bls12_381_g2": "Bls381G2", "grumpkin_g1": "GrumpkinG1"}[job.workload]
     alg_bytes = job.n * (32.0 + job.pbytes)                  # SURVEY 8d: scalar + affine base per point
     achieved = alg_bytes / t_acc / 1e9
+    hbm_peak = float(rin.get("hbm_peak_GBps", 8000.0))     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
     kin = rin.get("kernels", {}).get(f"k_msm_accum<{kname}> 2^{log_n_local}", {})
     mads = rin.get("mads_per_madd", {}).get(kname)
-    mad_peak = rin.get("mad_peak_T")
-    roof = {"bound": "hbm", "kernel": f"k_msm_accum<{kname}Cfg>", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
-            "frac": round(achieved / 8000.0, 5), "traffic": kin.get("traffic_bytes"), "traffic_source": kin.get("file"),
+    mad_peak, mad_src = rin.get("mad_peak_T"), rin.get("mad_peak_source")
+    lv = [x for x in (live_probe(job.cx, 0, 2000), live_probe(job.cx, 8, 2000)) if x]
+    if lv:   # forced v_mad_u64_u32 / v_mad_i64_i32 chains on this box, lane-ops/s
+        mad_peak, mad_src = round(max(lv) / 1e12, 2), "csh_microbench on this box, this run (v_mad_u64_u32 / v_mad_i64_i32 chains; file value: %s T/s, %s)" % (rin.get("mad_peak_T"), rin.get("mad_peak_source"))
+    roof = {"bound": "hbm", "kernel": f"k_msm_accum<{kname}Cfg>", "achieved": round(achieved, 2), "peak": hbm_peak, "unit": "GB/s",
+            "frac": round(achieved / hbm_peak, 5), "traffic": kin.get("traffic_bytes"), "traffic_source": kin.get("file"),
             "algorithmic_bytes_per_launch": alg_bytes,
             "note": "the MSM is integer-ALU bound (v_mad_i64_i32 issue), not HBM bound, by construction (W mixed additions ~ 160 modmuls per 96 B); "
                     "see `alu` and DESIGN.md 3.1",
@@ -321,7 +345,7 @@ def msm_roofline(job: MsmJob, rin: dict, log_n_local: int):
     if mads and mad_peak:
         a = job.n * n_win * mads / t_acc / 1e12
         roof["alu"] = {"unit": "Tmad/s", "achieved": round(a, 2), "peak": mad_peak, "frac": round(a / mad_peak, 3), "mads_per_madd": mads,
-                       "madds_per_s": round(job.n * n_win / t_acc), "peak_source": rin.get("mad_peak_source")}
+                       "madds_per_s": round(job.n * n_win / t_acc), "peak_source": mad_src}
     return roof
 
 
@@ -375,14 +399,17 @@ def secondary_single_gpu(cx: Ctx, rin: dict, args):
     e1.record(stream)
     ms = e0.elapsed_ms(e1) / 20
     modmuls = (1 << logn) // 2 * logn                      # one twiddle multiplication per butterfly
-    mm_peak = rin.get("modmul_peak_G")
+    mm_peak, mm_src = rin.get("modmul_peak_G"), rin.get("modmul_peak_source")
+    lv = [x for x in (live_probe(cx, 11, 200), live_probe(cx, 14, 200)) if x]
+    if lv:   # dependent 9 x 29-bit Montgomery products (unsigned row-wise / signed product-scanning multiplier) on this box
+        mm_peak, mm_src = round(max(lv) / 1e9, 2), "csh_microbench on this box, this run (k_modmul29 / k_modmul29s; file value: %s G/s)" % rin.get("modmul_peak_G")
     kin = rin.get("kernels", {}).get("k_ntt_pass_lazy 2^22", {})
     out["ntt_bn254_2p22"] = {"elements_per_s": (1 << logn) / ms * 1e3, "ms": ms,
                              "roofline": {"bound": "hbm", "kernel": "k_ntt_pass_r4 / k_ntt_pass_lazy (all passes of one transform)", "achieved": round(64.0 * (1 << logn) / ms / 1e6, 1),
-                                          "peak": 8000.0, "unit": "GB/s", "frac": round(64.0 * (1 << logn) / ms / 1e6 / 8000.0, 4), "traffic": kin.get("traffic_bytes"),
+                                          "peak": float(rin.get("hbm_peak_GBps", 8000.0)), "unit": "GB/s", "frac": round(64.0 * (1 << logn) / ms / 1e6 / float(rin.get("hbm_peak_GBps", 8000.0)), 4), "traffic": kin.get("traffic_bytes"),
                                           "traffic_source": kin.get("file"),
                                           "alu": {"unit": "G modmul/s", "achieved": round(modmuls / ms / 1e6, 1), "peak": mm_peak,
-                                                  "frac": round(modmuls / ms / 1e6 / mm_peak, 3) if mm_peak else None, "peak_source": rin.get("modmul_peak_source")}}}
+                                                  "frac": round(modmuls / ms / 1e6 / mm_peak, 3) if mm_peak else None, "peak_source": mm_src}}}
     dom.free()
     del data
     # Rep3 local_mul_vec 2^24 (192 B/element)
@@ -404,8 +431,8 @@ def secondary_single_gpu(cx: Ctx, rin: dict, args):
     ms = e0.elapsed_ms(e1) / 20
     kin = rin.get("kernels", {}).get("k_rep3_local_mul 2^24", {})
     out["rep3_local_mul_vec_2p24"] = {"elements_per_s": n / ms * 1e3, "ms": ms,
-                                      "roofline": {"bound": "hbm", "kernel": "k_rep3_local_mul<Bn254Fr>", "achieved": round(192.0 * n / ms / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
-                                                   "frac": round(192.0 * n / ms / 1e6 / 8000.0, 4), "traffic": kin.get("traffic_bytes"), "traffic_source": kin.get("file")}}
+                                      "roofline": {"bound": "hbm", "kernel": "k_rep3_local_mul<Bn254Fr>", "achieved": round(192.0 * n / ms / 1e6, 1), "peak": float(rin.get("hbm_peak_GBps", 8000.0)), "unit": "GB/s",
+                                                   "frac": round(192.0 * n / ms / 1e6 / float(rin.get("hbm_peak_GBps", 8000.0)), 4), "traffic": kin.get("traffic_bytes"), "traffic_source": kin.get("file")}}
     del a, b, m, o
     # Groth16 plain prove, synthetic 2^20-constraint circuit with a known-dlog key (closed-form checked), key resident
     from cosnarks_amd import groth16 as g16

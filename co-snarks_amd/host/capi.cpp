@@ -1232,6 +1232,28 @@ int cog16_synth_close(void* h) {
   return 0;
 }
 
+// The placement plan for a key whose five queries (a, b_g1, b_g2, l, h) have `sizes` points, on `nslots` GPUs: host-only (no device
+// needed). slots_out[q] = the slot of query q (by query), ranges_out[2 * slot + {0, 1}] = [lo, hi) of n_range entries (by range);
+// returns the effective mode (1 by query, 2 by range) or -1.
+int cog16_placement_plan(const size_t sizes[5], int nslots, int mode, size_t n_range, int slots_out[5], size_t* ranges_out) {
+  try {
+    if (!sizes || !slots_out || nslots < 1 || nslots > 64 || mode < 0 || mode > 2) throw Error("cog16_placement_plan: bad arguments");
+    const int eff = plan_placement(sizes, (size_t)nslots, mode, slots_out);
+    if (ranges_out)
+      for (int sl = 0; sl < nslots; ++sl) {
+        if (eff == PLACE_BY_RANGE && nslots > 1) plan_range(n_range, (size_t)nslots, (size_t)sl, &ranges_out[2 * sl], &ranges_out[2 * sl + 1]);
+        else {
+          ranges_out[2 * sl] = 0;
+          ranges_out[2 * sl + 1] = n_range;
+        }
+      }
+    return eff;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+
 // One prover's five query MSMs over several GPUs: keys built after this call clone their queries onto `devices` (entry 0 = the
 // key's home GPU; a GPU may be listed more than once, which is how the single-GPU tests exercise the path). n <= 1 switches it off.
 int cog16_set_prover_devices_mode(const int* devices, int n, int mode);

@@ -248,6 +248,36 @@ struct Query {
   }
 };
 
+// The planning half of ProvingKey::place, free of handles and devices (CPU-testable through cog16_placement_plan): which slot takes
+// which query (by query: longest-processing-time-first with the measured G2 : G1 cost ratio 2.5; slot 0 = the home GPU), and the
+// effective mode (AUTO -> by query up to two slots, by range from three on).
+enum { PLACE_AUTO = 0, PLACE_BY_QUERY = 1, PLACE_BY_RANGE = 2 };
+enum { Q_A = 0, Q_B1 = 1, Q_B2 = 2, Q_L = 3, Q_H = 4 };
+inline int plan_placement(const size_t sizes[5], size_t nslots, int mode, int slot_out[5]) {
+  for (int q = 0; q < 5; ++q) slot_out[q] = 0;
+  if (nslots < 2) return PLACE_BY_QUERY;
+  const int eff = mode == PLACE_AUTO ? (nslots <= 2 ? PLACE_BY_QUERY : PLACE_BY_RANGE) : mode;
+  if (eff == PLACE_BY_RANGE) return eff;
+  std::vector<double> load(nslots, 0.0);
+  int order[5] = {Q_B2, Q_A, Q_B1, Q_L, Q_H};
+  auto weight = [&](int q) { return (q == Q_B2 ? 2.5 : 1.0) * (double)sizes[q]; };
+  std::stable_sort(order, order + 5, [&](int x, int y) { return weight(x) > weight(y); });
+  for (int q : order) {
+    if (sizes[q] == 0) continue;
+    size_t best = 0;
+    for (size_t sl = 1; sl < nslots; ++sl)
+      if (load[sl] < load[best]) best = sl;
+    load[best] += weight(q);
+    slot_out[q] = (int)best;
+  }
+  return eff;
+}
+// the k-th of ns contiguous ranges of n entries (by range)
+inline void plan_range(size_t n, size_t ns, size_t slot, size_t* lo, size_t* hi) {
+  *lo = n / ns * slot + std::min(slot, n % ns);
+  *hi = *lo + n / ns + (slot < n % ns ? 1 : 0);
+}
+
 template <class P>
 struct ProvingKey {
   using G1 = AffineT<typename P::Fq>;
@@ -289,13 +319,13 @@ struct ProvingKey {
   // may appear more than once -- tests fold every slot onto one GPU) by longest-processing-time-first with the measured cost
   // ratio of a G2 to a G1 MSM (2.5), and clones each non-home query onto its GPU (csh_bases_clone: device to device, tables
   // included). create_proof_device then ships the scalars by peer copy (32 bytes per entry) and runs the groups concurrently.
-  enum { Q_A = 0, Q_B1 = 1, Q_B2 = 2, Q_L = 3, Q_H = 4 };
+  enum { Q_A = cosnarks::Q_A, Q_B1 = cosnarks::Q_B1, Q_B2 = cosnarks::Q_B2, Q_L = cosnarks::Q_L, Q_H = cosnarks::Q_H };
   // Two shapes of the same idea. BY_QUERY: whole queries are assigned to slots (LPT); the G2 query bounds the gain (N >= 3 GPUs:
   // ~2.5 G1-units on its slot). BY_RANGE: every slot takes the k-th contiguous range of EVERY query (the four aux queries of a
   // range still share one digit sort on their slot; the host adds the N partial results per query: N - 1 point additions), so
   // the work per slot is total / N whatever N is, at the price of smaller MSMs per slot. AUTO = BY_QUERY up to two GPUs,
   // BY_RANGE from three on.
-  enum { PLACE_AUTO = 0, PLACE_BY_QUERY = 1, PLACE_BY_RANGE = 2 };
+  enum { PLACE_AUTO = cosnarks::PLACE_AUTO, PLACE_BY_QUERY = cosnarks::PLACE_BY_QUERY, PLACE_BY_RANGE = cosnarks::PLACE_BY_RANGE };
   struct Placement {
     std::vector<int> devices;
     int mode = PLACE_BY_QUERY;
@@ -322,9 +352,7 @@ struct ProvingKey {
       *hi = n;
       return;
     }
-    const size_t ns = placement.devices.size();
-    *lo = n / ns * slot + std::min(slot, n % ns);
-    *hi = *lo + n / ns + (slot < n % ns ? 1 : 0);
+    plan_range(n, placement.devices.size(), slot, lo, hi);
   }
   void unplace() {
     for (size_t sl = 1; sl < placement.handles.size(); ++sl)
@@ -338,30 +366,18 @@ struct ProvingKey {
     unplace();
     if (devices.size() < 2) return;
     const size_t ns = devices.size();
-    placement.mode = mode == PLACE_AUTO ? (ns <= 2 ? PLACE_BY_QUERY : PLACE_BY_RANGE) : mode;
+    size_t sizes[5];
+    for (int q = 0; q < 5; ++q) sizes[q] = home_handle(q) ? query_size(q) : 0;
+    placement.mode = plan_placement(sizes, ns, mode, placement.slot);
     placement.handles.assign(ns, std::array<csh_bases_t, 5>{nullptr, nullptr, nullptr, nullptr, nullptr});
     for (int q = 0; q < 5; ++q) placement.handles[0][q] = home_handle(q);
     placement.devices = devices;  // (set before the clones: unplace() on a failure below frees what was made)
     try {
-      if (placement.mode == PLACE_BY_RANGE) {
-        for (size_t sl = 1; sl < ns; ++sl)
-          for (int q = 0; q < 5; ++q)
-            if (home_handle(q) && query_size(q)) check(csh_bases_clone(home_handle(q), devices[sl], &placement.handles[sl][q]), "csh_bases_clone");
-        return;
-      }
-      std::vector<double> load(ns, 0.0);
-      int order[5] = {Q_B2, Q_A, Q_B1, Q_L, Q_H};
-      auto weight = [&](int q) { return (q == Q_B2 ? 2.5 : 1.0) * (double)query_size(q); };
-      std::stable_sort(order, order + 5, [&](int x, int y) { return weight(x) > weight(y); });
-      for (int q : order) {
-        if (!home_handle(q) || query_size(q) == 0) continue;
-        size_t best = 0;
-        for (size_t sl = 1; sl < ns; ++sl)
-          if (load[sl] < load[best]) best = sl;
-        load[best] += weight(q);
-        placement.slot[q] = (int)best;
-        if (best) check(csh_bases_clone(home_handle(q), devices[best], &placement.handles[best][q]), "csh_bases_clone");
-      }
+      for (size_t sl = 1; sl < ns; ++sl)
+        for (int q = 0; q < 5; ++q) {
+          const bool wanted = placement.mode == PLACE_BY_RANGE ? true : placement.slot[q] == (int)sl;
+          if (wanted && sizes[q]) check(csh_bases_clone(home_handle(q), devices[sl], &placement.handles[sl][q]), "csh_bases_clone");
+        }
     } catch (...) {
       unplace();
       throw;
