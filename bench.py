@@ -346,6 +346,9 @@ def msm_roofline(job: MsmJob, rin: dict, log_n_local: int):
         a = job.n * n_win * mads / t_acc / 1e12
         roof["alu"] = {"unit": "Tmad/s", "achieved": round(a, 2), "peak": mad_peak, "frac": round(a / mad_peak, 3), "mads_per_madd": mads,
                        "madds_per_s": round(job.n * n_win / t_acc), "peak_source": mad_src}
+        if rin.get("mad_peak_T"):   # the constant of profiles/roofline_inputs.json (tools/gpu_probe.py: one cold pass per process), for continuity with earlier rounds
+            roof["alu"]["peak_file"] = rin["mad_peak_T"]
+            roof["alu"]["frac_vs_file"] = round(a / rin["mad_peak_T"], 3)
     return roof
 
 
