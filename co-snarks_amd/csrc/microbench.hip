@@ -69,6 +69,29 @@ __global__ __launch_bounds__(UB_BLK) void k_ub(uint32_t* out, int iters, uint32_
   out[blockIdx.x * UB_BLK + threadIdx.x] = (uint32_t)s ^ (uint32_t)(s >> 32);
 }
 
+// Dependent-chain probe: CH independent accumulators per lane, every v_mad_i64_i32 depends on the previous one of its own chain
+// only (the multiplicands are loop-invariant) -- the dependency structure of the pinned product-scanning multiplication, where a
+// lane's multiply-adds form ONE chain. Launched with a chosen number of waves per SIMD, it tells how much instruction-level or
+// wave-level parallelism the 64-bit multiply-add pipe needs before it issues at its peak rate.
+template <int CH>
+__global__ __launch_bounds__(UB_BLK) void k_ub_chain(uint32_t* out, int iters, uint32_t seed) {
+  const uint32_t a = threadIdx.x * 2654435761u + seed, b = blockIdx.x * 40503u + seed * 3u + 1u;
+  uint64_t acc[CH];
+#pragma unroll
+  for (int k = 0; k < CH; ++k) acc[k] = ((uint64_t)a << 20) + k * 977u + b;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+#pragma unroll
+      for (int k = 0; k < CH; ++k) asm volatile("v_mad_i64_i32 %0, s[4:5], %1, %2, %0" : "+v"(acc[k]) : "v"(a + k), "s"(b) : "s4", "s5");
+    }
+  }
+  uint64_t s = 0;
+#pragma unroll
+  for (int k = 0; k < CH; ++k) s ^= acc[k];
+  out[blockIdx.x * UB_BLK + threadIdx.x] = (uint32_t)s ^ (uint32_t)(s >> 32);
+}
+
 // v_fma_f64 issue rate (kind 13): the building block of the double-precision "split product" multiplier (two FMAs give the
 // exact high and low halves of a 52 x 52-bit limb product). Measured to price that alternative against the 29-bit integer
 // scheme: each limb product there costs 2 FMA + 1 subtraction + 2 64-bit integer additions.
@@ -225,6 +248,26 @@ int csh_microbench(int kind, int iters, double* ops_per_s) {
   (void)hipFree(out);
   if (rc != CSH_OK) return rc;
   *ops_per_s = 2.0 * iters * threads / (ms * 1e-3);
+  return CSH_OK;
+}
+
+// chains in {1, 2, 4}, waves_per_simd in 1..8: lane-ops/s of dependent v_mad_i64_i32 chains at that occupancy (workgroups of four
+// waves = one per SIMD of a CU; waves_per_simd workgroups per CU)
+int csh_microbench_chain(int chains, int waves_per_simd, int iters, double* ops_per_s) {
+  CSH_REQUIRE(ops_per_s && iters > 0 && waves_per_simd >= 1 && waves_per_simd <= 8 && (chains == 1 || chains == 2 || chains == 4), "bad argument");
+  CSH_TRY(ensure_device());
+  const int blocks = (device_simds() / 4) * waves_per_simd;
+  const size_t threads = (size_t)blocks * UB_BLK;
+  uint32_t* out;
+  CSH_HIP(hipMalloc((void**)&out, threads * 4));
+  float ms = 0;
+  int rc;
+  if (chains == 1) rc = time_kernel(k_ub_chain<1>, dim3(blocks), dim3(UB_BLK), &ms, out, iters, 7u);
+  else if (chains == 2) rc = time_kernel(k_ub_chain<2>, dim3(blocks), dim3(UB_BLK), &ms, out, iters, 7u);
+  else rc = time_kernel(k_ub_chain<4>, dim3(blocks), dim3(UB_BLK), &ms, out, iters, 7u);
+  (void)hipFree(out);
+  if (rc != CSH_OK) return rc;
+  *ops_per_s = (double)iters * 16 * chains * threads / (ms * 1e-3);
   return CSH_OK;
 }
 

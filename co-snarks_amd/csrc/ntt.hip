@@ -318,7 +318,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         // the two fresh products (< 2.2 p) again only takes the carry step. Two folds per round instead of four.
         {  // stage q + 1: (x0, x2) with w, (x1, x3) with w * omega^(n/4)
           const LZ w2 = twiddle(q + 1, t_lo, cc), w3 = twiddle(q + 1, t_lo + (1 << q), cc);
-          const LZ d02 = LZ::mul(LZ::sub(x0, x2), w2), d13 = LZ::mul(LZ::sub(x1, x3), w3);
+          LZ d02, d13;  // the two products of a fold are independent: their multiply-adds alternate (FpS::mul2)
+          LZ::mul2(LZ::sub(x0, x2), w2, LZ::sub(x1, x3), w3, d02, d13);
           x0 = LZ::add(x0, x2).normalized();
           x1 = LZ::add(x1, x3).normalized();
           x2 = d02;
@@ -326,7 +327,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
         {  // stage q: (x0, x1), (x2, x3), one twiddle
           const LZ w1 = twiddle(q, t_lo, cc);
-          const LZ d01 = LZ::mul(LZ::sub(x0, x1), w1), d23 = LZ::mul(LZ::sub(x2, x3), w1);
+          LZ d01, d23;
+          LZ::mul2(LZ::sub(x0, x1), w1, LZ::sub(x2, x3), w1, d01, d23);
           x0 = LZ::add(x0, x1).fold_top();
           x2 = LZ::add(x2, x3).normalized();
           x1 = d01;
@@ -335,7 +337,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       } else {
         {  // stage q: inputs normalised, outputs two-term sums (admissible product operands as they are)
           const LZ w1 = twiddle(q, t_lo, cc);
-          const LZ p1 = LZ::mul(x1, w1), p3 = LZ::mul(x3, w1);
+          LZ p1, p3;
+          LZ::mul2(x1, w1, x3, w1, p1, p3);
           x1 = LZ::sub(x0, p1);
           x0 = LZ::add(x0, p1);
           x3 = LZ::sub(x2, p3);
@@ -343,7 +346,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
         {  // stage q + 1: the carry step runs once per round, on the outputs
           const LZ w2 = twiddle(q + 1, t_lo, cc), w3 = twiddle(q + 1, t_lo + (1 << q), cc);
-          const LZ p2 = LZ::mul(x2, w2), p3 = LZ::mul(x3, w3);
+          LZ p2, p3;
+          LZ::mul2(x2, w2, x3, w3, p2, p3);
           x2 = LZ::sub(x0, p2).normalized();
           x0 = LZ::add(x0, p2).normalized();
           x3 = LZ::sub(x1, p3).normalized();

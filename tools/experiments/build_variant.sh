@@ -13,7 +13,7 @@ for o in co-snarks_amd/build/*.o; do
   [ $skip = 0 ] && objs="$objs $o"
 done
 for tu in "$@"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value $flags -c co-snarks_amd/csrc/$tu.hip -o gpurun_ab/obj_$name/$tu.o &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -fno-slp-vectorize $flags -c co-snarks_amd/csrc/$tu.hip -o gpurun_ab/obj_$name/$tu.o &
 done
 wait
 for tu in "$@"; do objs="$objs gpurun_ab/obj_$name/$tu.o"; done
