@@ -87,9 +87,8 @@ CSH_HD void lazy_madd(XYZZLazy<L>& acc, const L& x2, const L& y2, const AffT* sr
     acc.empty = false;
     return;
   }
-  // independent products run in pairs, their multiply-adds alternating (FpS::reduce_scan2): (u2, s2), (ppp, q), (x3, zzz3), (y3, zz3)
-  L u2, s2;
-  L::mul2(x2, acc.zz, y2, acc.zzz, u2, s2);
+  const L u2 = L::mul(x2, acc.zz);
+  const L s2 = L::mul(y2, acc.zzz);
   const L p = L::sub(u2, acc.x);
   const L r = L::sub(s2, acc.y);
   if (p.maybe_zero()) {
@@ -115,16 +114,14 @@ CSH_HD void lazy_madd(XYZZLazy<L>& acc, const L& x2, const L& y2, const AffT* sr
     }
   }
   const L pp = L::sqr(p);
-  L ppp, q;
-  L::mul2(p, pp, acc.x, pp, ppp, q);
-  L x3, zzz3;
-  L::sqr_sub_mul2(r, L::add(ppp, L::add(q, q)), acc.zzz, ppp, x3, zzz3);   // x3 = r^2 - ppp - 2q, normalised by the reduction's own carry chain
-  L y3, zz3;
-  L::mul_sub_mul2(r, L::sub(q, x3), acc.y, ppp, acc.zz, pp, y3, zz3);       // y3 = r*(q - x3) - y1*ppp, one reduction
+  const L ppp = L::mul(p, pp);
+  const L q = L::mul(acc.x, pp);
+  const L x3 = L::sqr_sub(r, L::add(ppp, L::add(q, q)));   // r^2 - ppp - 2q, normalised by the reduction's own carry chain
+  const L y3 = L::mul_sub(r, L::sub(q, x3), acc.y, ppp);   // r*(q - x3) - y1*ppp, one reduction
   acc.x = x3;
   acc.y = y3;
-  acc.zz = zz3;
-  acc.zzz = zzz3;
+  acc.zz = L::mul(acc.zz, pp);
+  acc.zzz = L::mul(acc.zzz, ppp);
 }
 
 // ---- general XYZZ arithmetic in the lazy field (bucket merge / window reduction kernels) -------------------------

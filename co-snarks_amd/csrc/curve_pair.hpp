@@ -103,20 +103,6 @@ struct Fp2Pair {
       return {LF::reduce(w)};
     }
   }
-  // paired forms (curve_lazy.hpp): the lane pair already splits every Fp2 operation over two lanes
-  __device__ __forceinline__ static void mul2(const Fp2Pair& a, const Fp2Pair& b, const Fp2Pair& c, const Fp2Pair& d, Fp2Pair& r1, Fp2Pair& r2) {
-    r1 = mul(a, b);
-    r2 = mul(c, d);
-  }
-  __device__ __forceinline__ static void sqr_sub_mul2(const Fp2Pair& a, const Fp2Pair& s, const Fp2Pair& c, const Fp2Pair& d, Fp2Pair& r1, Fp2Pair& r2) {
-    r1 = sqr_sub(a, s);
-    r2 = mul(c, d);
-  }
-  __device__ __forceinline__ static void mul_sub_mul2(const Fp2Pair& a, const Fp2Pair& b, const Fp2Pair& c, const Fp2Pair& d, const Fp2Pair& e, const Fp2Pair& f,
-                                                      Fp2Pair& r1, Fp2Pair& r2) {
-    r1 = mul_sub(a, b, c, d);
-    r2 = mul(e, f);
-  }
   __device__ __forceinline__ bool maybe_zero() const { return pair_all(v.maybe_zero()); }
   __device__ __forceinline__ bool is_zero_slow() const { return pair_all(v.is_zero_slow()); }
   __device__ __forceinline__ bool is_zero() const { return maybe_zero() && is_zero_slow(); }

@@ -198,7 +198,7 @@ using Fq29 = FpLazy<Bn254Fq29Params, Bn254Fq>;
 // themselves, and in the four-lane tail kernels (long independent chains the scheduler wants to interleave) that ordering blew the
 // register allocation up to 512 VGPRs + spills (tails +13 % on G1, x2 on G2 / BLS12-381).
 #ifndef CSH_DUAL_CHAIN
-#define CSH_DUAL_CHAIN 1  // independent multiplications run in lockstep (FpS::reduce_scan2); 0 = one after the other (A/B builds)
+#define CSH_DUAL_CHAIN 1  // FpS::mul2 runs its two multiplications in lockstep (reduce_scan2); 0 = one after the other (A/B builds)
 #endif
 #ifndef CSH_PIN_MADS
 #define CSH_PIN_MADS 0
@@ -479,12 +479,14 @@ struct FpS {
     return r;
   }
   // ---- two multiplications in lockstep ---------------------------------------------------------------------------------------
-  // A lane's multiply-adds of ONE product-scanning multiplication form a single dependent chain, and a dependent v_mad_i64_i32
-  // issues every ~13.5 cycles from one wave against ~4.7 for independent ones (tools/gpu_probe_chain.py, profiles/r03_o_probe_chain.log:
-  // one chain per lane, two waves per SIMD: 21.9 T mad/s; two chains: 26.3; four: 30.1; the pipe's peak: 33.4). reduce_scan2 runs two
-  // INDEPENDENT multiplications column by column with their terms alternating A, B, A, B in program order (which the pin of
-  // mad_pinned preserves), so that every multiply-add has an independent neighbour. `ta(k, i, acc)` / `tb(k, i, acc)` add term slot i
-  // (0 <= i < NTA / NTB) of column k of their multiplication, if that slot exists in that column.
+  // A lane's multiply-adds of ONE product-scanning multiplication form a single dependent chain; in a register-only probe a dependent
+  // v_mad_i64_i32 chain issues at 21.9 T mad/s (two waves per SIMD) against 26.3 for two chains per lane and 33.4 at the pipe's peak
+  // (tools/gpu_probe_chain.py, profiles/r03_o_probe_chain.log). reduce_scan2 runs two INDEPENDENT multiplications column by column with
+  // their terms alternating A, B, A, B in program order (which the pin of mad_pinned preserves). Measured (profiles/r03_p_*, A/B on one
+  // box): the radix-4 NTT pass, whose folds hold two independent products, gains ~1.5 %; the bucket accumulation gains nothing (its
+  // mixed addition paired as (u2, s2) (ppp, q) (x3, zzz3) (y3, zz3): BN254 G1 +-0, BN254 G2 +2 %, BLS12-381 G2 +10 % from spills) --
+  // the other VALU work between a real multiplication's multiply-adds already fills the chain's latency -- so only the NTT uses it.
+  // `ta(k, i, acc)` / `tb(k, i, acc)` add term slot i (0 <= i < NTA / NTB) of column k of their multiplication, if that slot exists.
   template <int K, int NTA, int NTB, class TA, class TB>
   CSH_HD static void scan_column2(TA& ta, TB& tb, int32_t* ma, int32_t* mb, FpS& ra, FpS& rb, int64_t& acca, int64_t& accb) {
 #pragma unroll
@@ -547,20 +549,6 @@ struct FpS {
     if (i >= 0 && i < NL && j >= 0 && j < NL) acc = mad_pinned(a.l[i], b.l[j], acc);
     return acc;
   }
-  // a^2 with a2 = 2 a (slots 0..NL-1)
-  CSH_HD static int64_t term_sqr(const FpS& a, const FpS& a2, int k, int i, int64_t acc) {
-    const int j = k - i;
-    if (i >= 0 && i < NL) {
-      if (j == i) acc = mad_pinned(a.l[i], a.l[i], acc);
-      else if (j > i && j < NL) acc = mad_pinned(a2.l[i], a.l[j], acc);
-    }
-    return acc;
-  }
-  // - s_(k - NL) in the upper columns (one slot)
-  CSH_HD static int64_t term_sub_hi(const FpS& s, int32_t m1, int k, int i, int64_t acc) {
-    if (i == 0 && k >= NL) acc = mad_pinned_s(s.l[k - NL], m1, acc);
-    return acc;
-  }
   // (r1, r2) = (a b, c d)
   CSH_HD static void mul2(const FpS& a, const FpS& b, const FpS& c, const FpS& d, FpS& r1, FpS& r2) {
     CSH_LIMB_BOUND(a, LIM2, "mul2(a)");
@@ -569,28 +557,6 @@ struct FpS {
     CSH_LIMB_BOUND(d, LIM1, "mul2(d)");
     reduce_scan2<NL, NL>([&](int k, int i, int64_t acc) CSH_LAMBDA_INLINE { return term_mul(a, b, k, i, acc); },
                          [&](int k, int i, int64_t acc) CSH_LAMBDA_INLINE { return term_mul(c, d, k, i, acc); }, r1, r2);
-  }
-  // (r1, r2) = (a^2 - s, c d)
-  CSH_HD static void sqr_sub_mul2(const FpS& a, const FpS& s, const FpS& c, const FpS& d, FpS& r1, FpS& r2) {
-    CSH_LIMB_BOUND(a, LIM1, "sqr_sub_mul2(a)");
-    CSH_LIMB_BOUND(c, LIM2, "sqr_sub_mul2(c)");
-    CSH_LIMB_BOUND(d, LIM1, "sqr_sub_mul2(d)");
-    const FpS a2 = add(a, a);
-    const int32_t m1 = opaque_minus_one();
-    reduce_scan2<NL + 1, NL>([&](int k, int i, int64_t acc) CSH_LAMBDA_INLINE { return i < NL ? term_sqr(a, a2, k, i, acc) : term_sub_hi(s, m1, k, i - NL, acc); },
-                             [&](int k, int i, int64_t acc) CSH_LAMBDA_INLINE { return term_mul(c, d, k, i, acc); }, r1, r2);
-  }
-  // (r1, r2) = (a b - c d, e f)
-  CSH_HD static void mul_sub_mul2(const FpS& a, const FpS& b, const FpS& c, const FpS& d, const FpS& e, const FpS& f, FpS& r1, FpS& r2) {
-    CSH_LIMB_BOUND(a, LIM1, "mul_sub_mul2(a)");
-    CSH_LIMB_BOUND(b, LIM1, "mul_sub_mul2(b)");
-    CSH_LIMB_BOUND(c, LIM1, "mul_sub_mul2(c)");
-    CSH_LIMB_BOUND(d, LIM1, "mul_sub_mul2(d)");
-    CSH_LIMB_BOUND(e, LIM2, "mul_sub_mul2(e)");
-    CSH_LIMB_BOUND(f, LIM1, "mul_sub_mul2(f)");
-    const FpS nc = neg(c);
-    reduce_scan2<2 * NL, NL>([&](int k, int i, int64_t acc) CSH_LAMBDA_INLINE { return i < NL ? term_mul(a, b, k, i, acc) : term_mul(nc, d, k, i - NL, acc); },
-                             [&](int k, int i, int64_t acc) CSH_LAMBDA_INLINE { return term_mul(e, f, k, i, acc); }, r1, r2);
   }
 
   // operand products of column k
@@ -846,46 +812,22 @@ struct Fp2S {
   CSH_HD Fp2S neg_unpacked() const { return {c0.neg_unpacked(), c1.neg_unpacked()}; }
   CSH_HD Fp2S cneg_unpacked(uint32_t neg01) const { return {c0.cneg_unpacked(neg01), c1.cneg_unpacked(neg01)}; }
 #if CSH_REDUCE_SCAN
-  // the two components of every Fp2 operation are independent multiplications: they run in lockstep (LF::reduce_scan2)
   CSH_HD static Fp2S mul(const Fp2S& a, const Fp2S& b) {
-    constexpr int NL = LF::NL;
     const LF na1 = LF::neg(a.c1);
-    Fp2S r;
-    LF::template reduce_scan2<2 * NL, 2 * NL>(
-        [&](int k, int i, int64_t acc) CSH_LAMBDA_INLINE { return i < NL ? LF::term_mul(a.c0, b.c0, k, i, acc) : LF::term_mul(na1, b.c1, k, i - NL, acc); },
-        [&](int k, int i, int64_t acc) CSH_LAMBDA_INLINE { return i < NL ? LF::term_mul(a.c0, b.c1, k, i, acc) : LF::term_mul(a.c1, b.c0, k, i - NL, acc); }, r.c0, r.c1);
-    return r;
+    return {LF::reduce_scan([&](int k, int64_t acc) CSH_LAMBDA_INLINE { return LF::col_mul(na1, b.c1, k, LF::col_mul(a.c0, b.c0, k, acc)); }),
+            LF::reduce_scan([&](int k, int64_t acc) CSH_LAMBDA_INLINE { return LF::col_mul(a.c1, b.c0, k, LF::col_mul(a.c0, b.c1, k, acc)); })};
   }
   CSH_HD static Fp2S sqr(const Fp2S& a) {
-    constexpr int NL = LF::NL;
     const LF a2 = LF::add(a.c0, a.c0), nb = LF::neg(a.c1), nb2 = LF::add(nb, nb);
-    Fp2S r;
-    LF::template reduce_scan2<2 * NL, NL>(
-        [&](int k, int i, int64_t acc) CSH_LAMBDA_INLINE { return i < NL ? LF::term_sqr(a.c0, a2, k, i, acc) : term_nsqr(a.c1, nb, nb2, k, i - NL, acc); },
-        [&](int k, int i, int64_t acc) CSH_LAMBDA_INLINE { return LF::term_mul(a2, a.c1, k, i, acc); }, r.c0, r.c1);
-    return r;
+    return {LF::reduce_scan([&](int k, int64_t acc) CSH_LAMBDA_INLINE { return LF::col_nsqr(a.c1, nb, nb2, k, LF::col_sqr(a.c0, a2, k, acc)); }),
+            LF::mul(a2, a.c1)};
   }
   // a^2 - s (s: |limb| < 2^31)
   CSH_HD static Fp2S sqr_sub(const Fp2S& a, const Fp2S& s) {
-    constexpr int NL = LF::NL;
     const LF a2 = LF::add(a.c0, a.c0), nb = LF::neg(a.c1), nb2 = LF::add(nb, nb);
     const int32_t m1 = LF::opaque_minus_one();
-    Fp2S r;
-    LF::template reduce_scan2<2 * NL + 1, NL + 1>(
-        [&](int k, int i, int64_t acc) CSH_LAMBDA_INLINE {
-          return i < NL ? LF::term_sqr(a.c0, a2, k, i, acc) : (i < 2 * NL ? term_nsqr(a.c1, nb, nb2, k, i - NL, acc) : LF::term_sub_hi(s.c0, m1, k, i - 2 * NL, acc));
-        },
-        [&](int k, int i, int64_t acc) CSH_LAMBDA_INLINE { return i < NL ? LF::term_mul(a2, a.c1, k, i, acc) : LF::term_sub_hi(s.c1, m1, k, i - NL, acc); }, r.c0, r.c1);
-    return r;
-  }
-  // - b^2 (nb = -b, nb2 = -2 b), term slot i
-  CSH_HD static int64_t term_nsqr(const LF& b, const LF& nb, const LF& nb2, int k, int i, int64_t acc) {
-    const int j = k - i;
-    if (i >= 0 && i < LF::NL) {
-      if (j == i) acc = mad_pinned(nb.l[i], b.l[i], acc);
-      else if (j > i && j < LF::NL) acc = mad_pinned(nb2.l[i], b.l[j], acc);
-    }
-    return acc;
+    return {LF::reduce_scan([&](int k, int64_t acc) CSH_LAMBDA_INLINE { return LF::col_sub_hi(s.c0, m1, k, LF::col_nsqr(a.c1, nb, nb2, k, LF::col_sqr(a.c0, a2, k, acc))); }),
+            LF::reduce_scan([&](int k, int64_t acc) CSH_LAMBDA_INLINE { return LF::col_sub_hi(s.c1, m1, k, LF::col_mul(a2, a.c1, k, acc)); })};
   }
 #else
   CSH_HD static Fp2S mul(const Fp2S& a, const Fp2S& b) {
@@ -903,17 +845,13 @@ struct Fp2S {
   CSH_HD static Fp2S mul_sub(const Fp2S& a, const Fp2S& b, const Fp2S& c, const Fp2S& d) {
     if constexpr (LF::FOUR_PRODUCTS_FIT) {
 #if CSH_REDUCE_SCAN
-      constexpr int NL = LF::NL;
       const LF na1 = LF::neg(a.c1), nc0 = LF::neg(c.c0), nc1 = LF::neg(c.c1);
-      Fp2S r;
-      LF::template reduce_scan2<4 * NL, 4 * NL>(
-          [&](int k, int i, int64_t acc) CSH_LAMBDA_INLINE {
-            return i < NL ? LF::term_mul(a.c0, b.c0, k, i, acc) : (i < 2 * NL ? LF::term_mul(na1, b.c1, k, i - NL, acc) : (i < 3 * NL ? LF::term_mul(nc0, d.c0, k, i - 2 * NL, acc) : LF::term_mul(c.c1, d.c1, k, i - 3 * NL, acc)));
-          },
-          [&](int k, int i, int64_t acc) CSH_LAMBDA_INLINE {
-            return i < NL ? LF::term_mul(a.c0, b.c1, k, i, acc) : (i < 2 * NL ? LF::term_mul(a.c1, b.c0, k, i - NL, acc) : (i < 3 * NL ? LF::term_mul(nc0, d.c1, k, i - 2 * NL, acc) : LF::term_mul(nc1, d.c0, k, i - 3 * NL, acc)));
-          }, r.c0, r.c1);
-      return r;
+      return {LF::reduce_scan([&](int k, int64_t acc) CSH_LAMBDA_INLINE {
+                return LF::col_mul(c.c1, d.c1, k, LF::col_mul(nc0, d.c0, k, LF::col_mul(na1, b.c1, k, LF::col_mul(a.c0, b.c0, k, acc))));
+              }),
+              LF::reduce_scan([&](int k, int64_t acc) CSH_LAMBDA_INLINE {
+                return LF::col_mul(nc1, d.c0, k, LF::col_mul(nc0, d.c1, k, LF::col_mul(a.c1, b.c0, k, LF::col_mul(a.c0, b.c1, k, acc))));
+              })};
 #else
       typename LF::Wide w0 = LF::mul_sub_wide(a.c0, b.c0, a.c1, b.c1);
       LF::mac_wide(w0, c.c0, d.c0, true);
@@ -934,28 +872,8 @@ struct Fp2S {
       typename LF::Wide v1 = LF::mul_wide(LF::neg(c.c0), d.c1);          // - c0 d1 - c1 d0
       LF::mac_wide(v1, c.c1, d.c0, true);
       LF::add_wide(w1, v1);
-#if CSH_REDUCE_SCAN
-      Fp2S r;
-      LF::template reduce_scan2<1, 1>([&](int k, int i, int64_t acc) CSH_LAMBDA_INLINE { return acc + w0.t[k]; },
-                                      [&](int k, int i, int64_t acc) CSH_LAMBDA_INLINE { return acc + w1.t[k]; }, r.c0, r.c1);
-      return r;
-#else
       return {LF::reduce(w0), LF::reduce(w1)};
-#endif
     }
-  }
-  // paired forms of curve_lazy.hpp's mixed addition: over Fp2 every operation already runs its two components in lockstep
-  CSH_HD static void mul2(const Fp2S& a, const Fp2S& b, const Fp2S& c, const Fp2S& d, Fp2S& r1, Fp2S& r2) {
-    r1 = mul(a, b);
-    r2 = mul(c, d);
-  }
-  CSH_HD static void sqr_sub_mul2(const Fp2S& a, const Fp2S& s, const Fp2S& c, const Fp2S& d, Fp2S& r1, Fp2S& r2) {
-    r1 = sqr_sub(a, s);
-    r2 = mul(c, d);
-  }
-  CSH_HD static void mul_sub_mul2(const Fp2S& a, const Fp2S& b, const Fp2S& c, const Fp2S& d, const Fp2S& e, const Fp2S& f, Fp2S& r1, Fp2S& r2) {
-    r1 = mul_sub(a, b, c, d);
-    r2 = mul(e, f);
   }
   CSH_HD bool maybe_zero() const { return c0.maybe_zero() && c1.maybe_zero(); }
   CSH_HD bool is_zero_slow() const { return c0.is_zero_slow() && c1.is_zero_slow(); }
