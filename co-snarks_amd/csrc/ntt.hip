@@ -499,13 +499,14 @@ struct Pass {
 
 static int plan_passes(int L, int ncomp_log, Pass* out) {
   const int TE = NTT_TILE_LOG - ncomp_log;  // log2(entries per tile)
-  // Contiguous run of a strided pass: 2^cb entries of ncomp x 32 bytes. 128-byte runs (64-byte for share pairs) cost nothing against
-  // 256-byte ones and save a whole sweep where the stages then fit two passes: 2^20 points 11 + 9 stages instead of 11 + 5 + 4, inverse /
-  // forward 0.143 / 0.135 -> 0.132 / 0.123 ms, share pairs 0.258 / 0.259 -> 0.246 / 0.242 ms (profiles/r03_q_ntt_runs.log, r03_r_ntt_tiles.log).
+  // Contiguous run of a strided pass: 2^cb entries of ncomp x 32 bytes. 64-byte runs cost nothing against 256-byte ones and save a whole
+  // sweep where the stages then fit two passes: 2^20 points 11 + 9 stages (128-byte runs) instead of 11 + 5 + 4, inverse / forward 0.143 / 0.135 ->
+  // 0.132 / 0.123 ms, share pairs 0.258 / 0.259 -> 0.246 / 0.242 ms; 2^21 points 11 + 10 (64-byte runs) 0.268 / 0.285 -> 0.261 / 0.270
+  // (profiles/r03_q_ntt_runs.log, r03_r_ntt_tiles.log, r03_s_ntt_runs64.log).
   // 32-byte runs do not pay (2^22 as 11 + 11: 0.53 -> 0.60 ms), nor do 2^12-entry tiles at one tile per CU (2^22 as 12 + 10: 0.53 -> 0.55,
   // 2^24 2.2 -> 2.4 ms). tune "ntt_variant" bits 4-6 = log2(run entries) + 1 overrides the run length for A/B runs (0: this default).
   const int nv_run = (tune().ntt_variant.load(std::memory_order_relaxed) >> 4) & 7;
-  const int cb_min = nv_run ? (nv_run - 1 > ncomp_log ? nv_run - 1 - ncomp_log : 0) : (2 - 2 * ncomp_log);
+  const int cb_min = nv_run ? (nv_run - 1 > ncomp_log ? nv_run - 1 - ncomp_log : 0) : (1 - ncomp_log);
   int np = 0;
   int k0 = L < TE ? L : TE;
   out[np++] = {0, k0, 0};
