@@ -22,11 +22,11 @@ namespace csh {
 // re-encoded as canonical x*R' (same 32 bytes per coordinate), converted once at upload.
 // PAIR (the G2 groups): accumulate and window reduction can run with two lanes per point, one Fp2 component each (curve_pair.hpp)
 struct Bn254G1Cfg { using Fq = Bn254Fq;   using Fr = Bn254Fr; static constexpr bool LAZY = true;  using L = Fq29s; static constexpr bool INLINE_ADD = true; static constexpr bool PAIR = false; };
-struct Bn254G2Cfg { using Fq = Bn254Fq2;  using Fr = Bn254Fr; static constexpr bool LAZY = true;  using L = Fq29s2; static constexpr bool INLINE_ADD = true; static constexpr bool PAIR = true; using LP = Fp2Pair<Fq29s>; };
+struct Bn254G2Cfg { using Fq = Bn254Fq2;  using Fr = Bn254Fr; static constexpr bool LAZY = true;  using L = Fq29s2; static constexpr bool INLINE_ADD = true; static constexpr bool PAIR = true; static constexpr bool PAIR_ACC_DEFAULT = false; using LP = Fp2Pair<Fq29s>; };
 struct Bls381G1Cfg { using Fq = Bls381Fq;  using Fr = Bls381Fr; static constexpr bool LAZY = true;  using L = Fq28s; static constexpr bool INLINE_ADD = true; static constexpr bool PAIR = false; };
 // Grumpkin: base field = BN254 Fr, scalars = BN254 Fq (the 2-cycle partner of BN254)
 struct GrumpkinG1Cfg { using Fq = Bn254Fr;   using Fr = Bn254Fq; static constexpr bool LAZY = true;  using L = Fr29s; static constexpr bool INLINE_ADD = true; static constexpr bool PAIR = false; };
-struct Bls381G2Cfg { using Fq = Bls381Fq2; using Fr = Bls381Fr; static constexpr bool LAZY = true;  using L = Fq28s2; static constexpr bool INLINE_ADD = true; static constexpr bool PAIR = true; using LP = Fp2Pair<Fq28s>; };
+struct Bls381G2Cfg { using Fq = Bls381Fq2; using Fr = Bls381Fr; static constexpr bool LAZY = true;  using L = Fq28s2; static constexpr bool INLINE_ADD = true; static constexpr bool PAIR = true; static constexpr bool PAIR_ACC_DEFAULT = true; using LP = Fp2Pair<Fq28s>; };
 
 struct Bases {
   csh_curve_t curve;
@@ -137,28 +137,7 @@ __global__ __launch_bounds__(ACC_BLK) void k_msm_accum(const Affine<typename Cfg
     uint32_t e_next2 = (INDEX_AHEAD && lo + 1 < hi) ? so[lo + 1] : 0;
     for (uint32_t pos = lo; pos < hi; ++pos) {
       const uint32_t e = e_next;
-#ifndef CSH_ACC_TOUCH
       const Affine<Fq> pt = pt_next;
-#endif
-#ifdef CSH_ACC_TOUCH  // experiment (large points): no register prefetch of the next point, only a touch of its cache lines
-      Affine<Fq> pt;
-      uint32_t touch0 = 0, touch1 = 0;
-      if constexpr (sizeof(Affine<Fq>) >= 192) {
-        pt = bases[e & 0x7fffffffu];
-        if (pos + 1 < hi) {
-          e_next = so[pos + 1];
-          const uint32_t* nx = reinterpret_cast<const uint32_t*>(bases + (e_next & 0x7fffffffu));
-          touch0 = nx[0];
-          touch1 = nx[32];
-        }
-      } else {
-        pt = pt_next;
-        if (pos + 1 < hi) {
-          e_next = so[pos + 1];
-          pt_next = bases[e_next & 0x7fffffffu];
-        }
-      }
-#else
       if (pos + 1 < hi) {
         if constexpr (INDEX_AHEAD) {
           e_next = e_next2;
@@ -169,7 +148,6 @@ __global__ __launch_bounds__(ACC_BLK) void k_msm_accum(const Affine<typename Cfg
           pt_next = bases[e_next & 0x7fffffffu];
         }
       }
-#endif
       const bool inf = stored_is_inf(pt);
       const L x = L::unpack(pt.x);
       const L y = L::unpack(pt.y).cneg_unpacked(e >> 31);  // limbs stay in [0, 2^B]: lazy_madd subtracts acc.y limb-wise
@@ -185,9 +163,6 @@ __global__ __launch_bounds__(ACC_BLK) void k_msm_accum(const Affine<typename Cfg
       }
       if (inf) continue;
       lazy_madd<L, Affine<Fq>>(acc, x, y, bases + (e & 0x7fffffffu), e >> 31);
-#ifdef CSH_ACC_TOUCH
-      asm volatile("" ::"v"(touch0), "v"(touch1));
-#endif
     }
     pw[b + k] = acc;
   }
@@ -257,7 +232,10 @@ constexpr int TAIL_Q = TAIL_BLK / 4;
 
 // Bucket merge: the partials of bucket b sit in consecutive slots b + k0 .. b + k1 (k0, k1 = first / last lane that
 // touched it). One quad per bucket folds them into the dense array dense[w][b]; buckets with more than MERGE_CAP
-// partials (heavily repeated scalars) are queued for the block-wide tree kernel below.
+// partials (heavily repeated scalars) are queued for the block-wide tree kernel below. (One LANE per bucket with whole-point additions,
+// compiled with the accumulate kernel's pinned multiplier, was measured in round 3: tail 0.34 -> 0.55 ms at 2^20, 0.53 -> 1.05 ms at 2^24,
+// profiles/r03_w_merge_lane.log -- 1-3 additions per lane under divergent trip counts and the empty / doubling branches of the full
+// addition; not kept.)
 constexpr uint32_t MERGE_CAP = 16;
 template <class Cfg>
 __global__ __launch_bounds__(TAIL_BLK) void k_msm_merge(MsmParams p, const uint32_t* __restrict__ start,
@@ -837,8 +815,12 @@ int bucket_group(const void* points, const MsmParams& p, const SortOut& so, cons
     // tune "msm_variant" bit 1: two lanes per point on the G2 groups (curve_pair.hpp). Measured a wash against whole points
     // per lane (profiles/r02_g_pair_stages.log): one wave of multiply-add code already saturates the SIMD's integer pipe, so
     // the second wave the smaller footprint buys has nothing to fill. Kept for A/B runs and covered by the GPU parity suite.
+    // Round 3: on BLS12-381 G2 the lane pair IS the default (304 VGPRs, no VGPR spills, against 419 + 6 spills): the whole-point kernel
+    // measured 7.13 .. 7.85 ms at 2^20 from box to box (its accumulation-register traffic makes it the more sensitive one), the pair
+    // 7.24 .. 7.49, and 29.1 against 30.9 ms at 2^22 on the last box (profiles/r03_c_g2_acc_forms.log, r03_v_g2_acc_forms.log). Bit 1
+    // selects the other form of the group's default.
     bool pair = false;
-    if constexpr (Cfg::PAIR) pair = (tune().msm_variant.load(std::memory_order_relaxed) & 2) != 0;
+    if constexpr (Cfg::PAIR) pair = Cfg::PAIR_ACC_DEFAULT != ((tune().msm_variant.load(std::memory_order_relaxed) & 2) != 0);
     if constexpr (Cfg::PAIR) {
       if (pair) {
         const dim3 ag((2 * bb.max_lanes + blk - 1) / blk, nw), ab(blk);

@@ -71,7 +71,8 @@ int csh_device_count(int* count);
  * as fit one round of waves), "msm_timing" (record csh_msm_last_timing), "msm_no_table", "msm_multi_overlap", "acc_blk",
  * "sort_two_level" (-1 auto), "vec_max_blocks", "ntt_lazy", "ntt_threads", "ntt_variant", "allow_unmasked_rep3" (see
  * csh_rep3_local_mul_vec), "msm_variant" (bit mask of non-default kernel forms, same results: bit 0 = window reduction
- * lane-serial on G1 / four-lane on G2, bit 1 = two lanes per point in the G2 accumulate kernel, bit 2 = lane-serial window
+ * lane-serial on G1 / four-lane on G2, bit 1 = the other form of the G2 accumulate kernel (BN254 G2: two lanes per point instead of whole points; BLS12-381 G2: whole
+ * points instead of two lanes per point), bit 2 = lane-serial window
  * reduction on G2, bit 3 = 8-byte sort records at every size). */
 int csh_tune_set(const char* key, int value);
 int csh_tune_get(const char* key, int* value);

@@ -43,10 +43,11 @@ def test_msm_g2_full_range_points_equals_cpu_restatement(gpu, curve, logn):
 
 
 @pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
-@pytest.mark.parametrize("logn,ncomp", [(20, 1), (20, 2), (22, 1), (22, 2)])
+@pytest.mark.parametrize("logn,ncomp", [(20, 1), (20, 2), (21, 1), (21, 2), (22, 1), (22, 2), (23, 1)])
 def test_ntt_full_size_equals_cpu_restatement(gpu, curve, logn, ncomp):
     """BASELINE config 3 (BN254, 2^22) and the Rep3 two-component form: both directions bit-identical to oracle/c's radix-2
-    NTT over the whole vector, the round trip, and 16 output indices re-derived by Horner (no NTT code involved)."""
+    NTT over the whole vector, the round trip, and 16 output indices re-derived by Horner (no NTT code involved). 2^20 / 2^21 run as two
+    sweeps (128- and 64-byte runs in the strided pass, 32-byte ones for share pairs at 2^20), 2^22 / 2^23 as three: every pass plan."""
     if curve == "bls12_381" and (logn, ncomp) != (22, 1):
         pytest.skip("one full-size BLS12-381 case is enough")
     F = H.FR[curve]
