@@ -60,21 +60,38 @@ __device__ __forceinline__ void load_scalar(const Fr* __restrict__ scalars, size
 }
 
 
+// Signed-digit codes of every scalar, dig[row(w) * n + i] (row(w) = w, or the grouped-table order (w % W') * g + w / W'). Straight-line
+// per window: the scalar is shifted right by c bits after every digit (constant register indices, no indexed register access), the code
+// is selected without branches and every row gets exactly one 2-byte store per scalar (rows past W hold no digits). Same recoding
+// as for_each_digit (msm_digits.hpp), which the host self-test and the oracle comparison pin. Round 3: stage "digits + histogram" 0.081-0.087 -> 0.071 ms at 2^20, 0.91 -> 0.68 ms at 2^24 (profiles/r03_x_digits_stages.log)
+// (the former loop over for_each_digit compiled to 116 basic blocks with indexed register moves and an integer division per row).
 template <class Fr>
 __global__ __launch_bounds__(MSM_BLK) void k_msm_digits(const Fr* __restrict__ scalars, MsmParams p, uint16_t* __restrict__ dig) {
+  const uint32_t g = p.dig_g > 1 ? p.dig_g : 1u, wp = p.dig_g > 1 ? p.dig_wp : (uint32_t)p.W;
+  const uint32_t rows = g * wp;  // >= W: the windows past W (grouped tables, g * W' > W) hold no digits
+  const uint32_t c = (uint32_t)p.c, mask = (1u << c) - 1, half = 1u << (c - 1), W = (uint32_t)p.W;
   for (size_t i = blockIdx.x * (size_t)MSM_BLK + threadIdx.x; i < p.n; i += (size_t)gridDim.x * MSM_BLK) {
     uint32_t s[Fr::N];
     load_scalar<Fr>(scalars, i, p.mont, s);
-    const uint32_t g = p.dig_g > 1 ? p.dig_g : 1u, wp = p.dig_g > 1 ? p.dig_wp : (uint32_t)p.W;
-    const int rows = (int)(g * wp);  // >= W: the windows past W (grouped tables, g * W' > W) hold no digits
-    auto row = [&](int w) -> size_t { return g > 1 ? (size_t)((uint32_t)w % wp) * g + (uint32_t)w / wp : (size_t)w; };
-    int next = 0;
-    for_each_digit<Fr::N>(s, p.c, p.W, [&](int w, uint32_t b, uint32_t neg) {
-      for (; next < w; ++next) dig[row(next) * p.n + i] = (uint16_t)DIG_ZERO;
-      dig[row(w) * p.n + i] = (uint16_t)((b - 1) | (neg << 15));
-      next = w + 1;
-    });
-    for (; next < rows; ++next) dig[row(next) * p.n + i] = (uint16_t)DIG_ZERO;
+    uint32_t carry = 0, rq = 0, rr = 0;  // w = rq * wp + rr
+    for (uint32_t w = 0; w < rows; ++w) {
+      uint32_t code = DIG_ZERO;
+      if (w < W) {
+        const uint32_t v = (s[0] & mask) + carry;
+#pragma unroll
+        for (int k = 0; k + 1 < Fr::N; ++k) s[k] = (s[k] >> c) | (s[k + 1] << (32 - c));
+        s[Fr::N - 1] >>= c;
+        const uint32_t neg = v > half ? 1u : 0u;
+        const uint32_t mag = neg ? (1u << c) - v : v;  // 0 .. half
+        carry = neg;
+        code = mag ? ((mag - 1) | (neg << 15)) : (uint32_t)DIG_ZERO;
+      }
+      dig[(size_t)(rr * g + rq) * p.n + i] = (uint16_t)code;
+      if (++rr == wp) {
+        rr = 0;
+        ++rq;
+      }
+    }
   }
 }
 
