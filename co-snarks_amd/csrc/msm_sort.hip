@@ -212,10 +212,19 @@ __global__ __launch_bounds__(256) void k_msm_part_offsets(MsmParams p, const uin
 // written out as 8-byte records (index | sign << 31 | low bucket byte << 32) in runs of neighbouring addresses.
 // REC = 1 (entry ids < 2^23, i.e. n <= 2^23 and no table remap): 4-byte records (index | sign << 23 | low bucket byte << 24)
 // -- 14 instead of 22 bytes of HBM traffic per entry over the two levels. REC = 0: the 8-byte records.
+#ifndef CSH_L1_WPE
+#define CSH_L1_WPE 8  // two 1024-lane blocks per CU (64 VGPRs instead of 75): one block's barriers and LDS phases under the other's loads;
+                      // scatter stage 0.124 -> 0.110 ms at 2^20, 0.384 -> 0.351 at 2^22 (profiles/r03_y_scatter_l1_occupancy.log)
+#endif
+#if CSH_L1_WPE > 0
+#define CSH_L1_OCC __attribute__((amdgpu_waves_per_eu(CSH_L1_WPE)))
+#else
+#define CSH_L1_OCC
+#endif
 constexpr int L1_EPT = 8;
 constexpr int L1_TILE = L1_EPT * SORT_BLK;
 template <int REC>
-__global__ __launch_bounds__(SORT_BLK) void k_msm_scatter_l1(MsmParams p, const uint16_t* __restrict__ dig, const uint32_t* __restrict__ part_off,
+__global__ __launch_bounds__(SORT_BLK) CSH_L1_OCC void k_msm_scatter_l1(MsmParams p, const uint16_t* __restrict__ dig, const uint32_t* __restrict__ part_off,
                                                              void* __restrict__ inter) {
   using Rec = typename std::conditional<REC != 0, uint32_t, uint64_t>::type;
   constexpr uint32_t MAXP = 128;  // NB <= 2^15
