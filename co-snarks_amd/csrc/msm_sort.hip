@@ -114,10 +114,7 @@ __global__ __launch_bounds__(1024) void k_msm_scan(MsmParams p, uint32_t* hist, 
   uint32_t* h = hist + (size_t)w * len;
   uint32_t* st = start + (size_t)w * len;
   uint32_t* wave_tot = sc_lds + len;
-  for (uint32_t b = threadIdx.x; b < len; b += 1024) {
-    sc_lds[b] = h[b];
-    h[b] = 0;  // ready for the next MSM on this arena
-  }
+  for (uint32_t b = threadIdx.x; b < len; b += 1024) sc_lds[b] = h[b];
   __syncthreads();
   const uint32_t per = (len + 1023) / 1024;
   const uint32_t b0 = threadIdx.x * per;
@@ -153,7 +150,10 @@ __global__ __launch_bounds__(1024) void k_msm_scan(MsmParams p, uint32_t* hist, 
     }
   }
   __syncthreads();
-  for (uint32_t b = threadIdx.x; b < len; b += 1024) st[b] = sc_lds[b];
+  for (uint32_t b = threadIdx.x; b < len; b += 1024) {
+    st[b] = sc_lds[b];
+    h[b] = sc_lds[b];  // the same offsets again, as the global bucket cursors of the tile-parallel level-2 scatter (consumed by atomicAdd)
+  }
   if (threadIdx.x == 0) nlanes[w] = (total + p.L - 1) / p.L;
 }
 
@@ -392,6 +392,130 @@ __global__ __launch_bounds__(SORT_BLK) void k_msm_scatter_l2(MsmParams p, const 
   }
 }
 
+// Level 2, tile-parallel (the default since the end of round 3). The kernel above gives one block a whole partition, so a skewed
+// digit distribution -- a 0/1-heavy witness puts every "1" into bucket 1 of window 0, a repeated value one bucket per window -- leaves
+// ONE block to sort a quarter or half of a window's entries tile after tile while the rest of the chip is idle (scatter 0.11 -> 0.42 ms
+// at 2^20 with half the scalars in {0, 1} and a quarter equal). Here every partition is cut into slices of about one tile, one block
+// each: the block finds its (partition, slice) from the partitions' sizes (a 128-entry scan of `start`), counting-sorts its tiles by the
+// low bucket byte in LDS as before, and reserves the output run of every bucket with ONE global atomicAdd per bucket and tile on the
+// cursor array k_msm_scan left in `hist`. The order of the entries inside a bucket then depends on the order in which blocks reserve --
+// the bucket sums are sums in a group, the results are bit-identical (parity suite), and `start` is untouched.
+template <int REC>
+__global__ __launch_bounds__(SORT_BLK) void k_msm_scatter_l2t(MsmParams p, const uint32_t* __restrict__ start, uint32_t* __restrict__ cursor,
+                                                              const void* __restrict__ inter, uint32_t* __restrict__ sorted) {
+  using Rec = typename std::conditional<REC != 0, uint32_t, uint64_t>::type;
+  constexpr int BIN_SHIFT = REC != 0 ? 24 : 32;
+  constexpr uint32_t MAXP = 128;  // NB <= 2^15
+  __shared__ uint32_t gbase[PART_BUCKETS];  // reserved output run of every bucket for the current tile
+  __shared__ uint32_t cnt[PART_BUCKETS];    // tile histogram
+  __shared__ uint32_t toff[PART_BUCKETS];   // tile-local exclusive offsets
+  __shared__ uint32_t wsum[4];
+  __shared__ uint32_t job[3];               // partition, first and one-past-last intermediate slot of this block's slice
+  __shared__ uint32_t pay[L2_TILE];
+  __shared__ uint8_t sbin[L2_TILE];
+  const uint32_t x = blockIdx.x, w = blockIdx.y, tid = threadIdx.x;
+  const uint32_t P = p.NB / PART_BUCKETS;
+  const uint32_t* stw = start + (size_t)w * (p.NB + 2);
+  {  // which slice of which partition is block x: partitions get max(1, round(entries / tile)) blocks each (none when empty)
+    uint32_t lo_p = 0, hi_p = 0, nb = 0, incl = 0;
+    if (tid < MAXP) {
+      if (tid < P) {
+        lo_p = stw[(size_t)tid * PART_BUCKETS + 1];
+        hi_p = stw[(size_t)(tid + 1) * PART_BUCKETS + 1];
+        const uint32_t c = hi_p - lo_p;
+        nb = c ? (c + L2_TILE / 2) / L2_TILE : 0;
+        if (c && nb == 0) nb = 1;
+      }
+      incl = nb;
+      const int lane = tid & 63;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)incl, d);
+        if (lane >= d) incl += t;
+      }
+      if (lane == 63) wsum[tid >> 6] = incl;
+    }
+    if (tid == 0) job[0] = 0xffffffffu;
+    __syncthreads();
+    if (tid < MAXP) {
+      const uint32_t pre = (tid >= 64 ? wsum[0] : 0) + incl - nb;  // blocks of earlier partitions
+      if (nb && x >= pre && x < pre + nb) {
+        const uint32_t c = hi_p - lo_p, slice = (c + nb - 1) / nb, j = x - pre;
+        uint32_t a = lo_p + j * slice, b = a + slice;
+        if (b > hi_p) b = hi_p;
+        if (a > hi_p) a = hi_p;
+        job[0] = tid;
+        job[1] = a;
+        job[2] = b;
+      }
+    }
+    __syncthreads();
+  }
+  const uint32_t part = job[0];
+  if (part == 0xffffffffu) return;  // the grid is sized for the worst case (entries / tile + partitions blocks per window)
+  const uint32_t lo = job[1], hi = job[2];
+  if (tid < PART_BUCKETS) cnt[tid] = 0;
+  __syncthreads();
+  uint32_t* cur = cursor + (size_t)w * (p.NB + 2) + (size_t)part * PART_BUCKETS + 1;
+  const Rec* in = reinterpret_cast<const Rec*>(inter) + (size_t)w * p.n;
+  uint32_t* so = sorted + (size_t)w * p.n;
+  for (uint32_t t0 = lo; t0 < hi; t0 += L2_TILE) {
+    Rec e[L2_EPT];
+    uint32_t rank[L2_EPT];
+#pragma unroll
+    for (int k = 0; k < L2_EPT; ++k) {
+      const uint32_t i = t0 + k * SORT_BLK + tid;
+      e[k] = i < hi ? __builtin_nontemporal_load(in + i) : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < L2_EPT; ++k) rank[k] = lds_slot(cnt, (uint32_t)(e[k] >> BIN_SHIFT), t0 + k * SORT_BLK + tid < hi);
+    __syncthreads();
+    uint32_t v = 0, incl = 0;
+    if (tid < PART_BUCKETS) {  // waves 0..3, fully active: wave scan + 4 wave totals; and the output run of every bucket of the tile
+      v = cnt[tid];
+      gbase[tid] = v ? atomicAdd(&cur[tid], v) : 0u;
+      incl = v;
+      const int lane = tid & 63;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)incl, d);
+        if (lane >= d) incl += t;
+      }
+      if (lane == 63) wsum[tid >> 6] = incl;
+    }
+    __syncthreads();
+    if (tid < PART_BUCKETS) {
+      uint32_t base = 0;
+      for (uint32_t q = 0; q < (tid >> 6); ++q) base += wsum[q];
+      toff[tid] = base + incl - v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < L2_EPT; ++k) {
+      if (t0 + k * SORT_BLK + tid < hi) {
+        const uint32_t bin = (uint32_t)(e[k] >> BIN_SHIFT);
+        const uint32_t slot = toff[bin] + rank[k];
+        if constexpr (REC == 1) pay[slot] = ((uint32_t)e[k] & 0x7fffffu) | ((((uint32_t)e[k] >> 23) & 1u) << 31);
+        else pay[slot] = (uint32_t)e[k];
+        sbin[slot] = (uint8_t)bin;
+      }
+    }
+    __syncthreads();
+    const uint32_t tile_n = hi - t0 < (uint32_t)L2_TILE ? hi - t0 : (uint32_t)L2_TILE;
+#pragma unroll
+    for (int k = 0; k < L2_EPT; ++k) {
+      const uint32_t sl = k * SORT_BLK + tid;
+      if (sl < tile_n) {
+        const uint32_t bin = sbin[sl];
+        so[gbase[bin] + (sl - toff[bin])] = pay[sl];
+      }
+    }
+    __syncthreads();
+    if (tid < PART_BUCKETS) cnt[tid] = 0;
+    __syncthreads();
+  }
+}
+
 // Two-level mode pays off once a (partition, window) block has enough records to fill its tiles: n >= 2^20
 // (measured: 2^20 0.22 -> 0.12 ms, 2^24 6.2 -> 2.1 ms; slower at 2^18). csh_tune_set("sort_two_level", 0/1) forces a mode (tests).
 bool msm_sort_two_level(const MsmParams& p) {
@@ -440,12 +564,17 @@ int msm_sort_launch(const MsmParams& p, const SortBuffers& b, hipStream_t st, hi
     // writes cost more than the 3 bytes per entry they save, profiles/r02_g_rec_stages.log.)
     const uint64_t max_id = p.remap_n ? (uint64_t)(p.n / p.remap_n) * p.remap_stride : (uint64_t)p.n;  // stored ids: table indices
     const bool wide_only = (tune().msm_variant.load(std::memory_order_relaxed) & 8) != 0;
+    // level 2: one block per slice of about one tile of a partition (default), or -- tune "msm_variant" bit 5 -- one block per partition
+    const bool by_partition = (tune().msm_variant.load(std::memory_order_relaxed) & 32) != 0;
+    const uint32_t l2_blocks = (uint32_t)(p.n / L2_TILE) + nparts + 1;
     if (!wide_only && max_id <= (1u << 23)) {
       hipLaunchKernelGGL(k_msm_scatter_l1<1>, dim3(p.CH, p.W), dim3(SORT_BLK), 0, st, p, b.dig, b.part_cnt, (void*)b.inter);
-      hipLaunchKernelGGL(k_msm_scatter_l2<1>, dim3(nparts, p.W), dim3(SORT_BLK), 0, st, p, b.start, (const void*)b.inter, b.sorted);
+      if (by_partition) hipLaunchKernelGGL(k_msm_scatter_l2<1>, dim3(nparts, p.W), dim3(SORT_BLK), 0, st, p, b.start, (const void*)b.inter, b.sorted);
+      else hipLaunchKernelGGL(k_msm_scatter_l2t<1>, dim3(l2_blocks, p.W), dim3(SORT_BLK), 0, st, p, b.start, b.hist, (const void*)b.inter, b.sorted);
     } else {
       hipLaunchKernelGGL(k_msm_scatter_l1<0>, dim3(p.CH, p.W), dim3(SORT_BLK), 0, st, p, b.dig, b.part_cnt, (void*)b.inter);
-      hipLaunchKernelGGL(k_msm_scatter_l2<0>, dim3(nparts, p.W), dim3(SORT_BLK), 0, st, p, b.start, (const void*)b.inter, b.sorted);
+      if (by_partition) hipLaunchKernelGGL(k_msm_scatter_l2<0>, dim3(nparts, p.W), dim3(SORT_BLK), 0, st, p, b.start, (const void*)b.inter, b.sorted);
+      else hipLaunchKernelGGL(k_msm_scatter_l2t<0>, dim3(l2_blocks, p.W), dim3(SORT_BLK), 0, st, p, b.start, b.hist, (const void*)b.inter, b.sorted);
     }
   } else {
     hipLaunchKernelGGL(k_msm_scatter_lds, dim3(p.CH, p.W), dim3(SORT_BLK), sort_lds, st, p, b.dig, b.start, b.blkcnt, b.sorted);

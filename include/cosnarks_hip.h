@@ -73,7 +73,8 @@ int csh_device_count(int* count);
  * csh_rep3_local_mul_vec), "msm_variant" (bit mask of non-default kernel forms, same results: bit 0 = window reduction
  * lane-serial on G1 / four-lane on G2, bit 1 = the other form of the G2 accumulate kernel (BN254 G2: two lanes per point instead of whole points; BLS12-381 G2: whole
  * points instead of two lanes per point), bit 2 = lane-serial window
- * reduction on G2, bit 3 = 8-byte sort records at every size). */
+ * reduction on G2, bit 3 = 8-byte sort records at every size, bit 4 = merge fused into the window reduction, bit 5 = level 2 of the
+ * two-level sort with one block per partition instead of one per tile-sized slice). */
 int csh_tune_set(const char* key, int value);
 int csh_tune_get(const char* key, int* value);
 

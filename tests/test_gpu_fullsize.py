@@ -42,6 +42,30 @@ def test_msm_g2_full_range_points_equals_cpu_restatement(gpu, curve, logn):
     bases.free()
 
 
+@pytest.mark.parametrize("variant", [0, 32])
+def test_msm_2p20_witness_like_scalars_equals_cpu_restatement(gpu, variant):
+    """A 0/1-heavy witness at BASELINE config 2's size (canonical scalars, msm_bigint): a quarter zero, a quarter one (every "1" lands
+    in bucket 1 of window 0), a quarter one repeated 253-bit value (one bucket per window holds a quarter of the window's entries), a
+    quarter uniform. Bit-identical to oracle/c. variant 0: level 2 of the sort with one block per tile-sized slice of a partition (the
+    default: a skewed partition is spread over the chip); 32: one block per partition."""
+    cid = H.CURVE_IDS["bn254"]
+    n = 1 << 20
+    pts = cbridge.hash_points_bn254_g1(0xFEED, n)
+    rs = np.random.RandomState(99)
+    sc = _uniform_limbs(rs, n)
+    kind = rs.randint(0, 4, size=n)
+    sc[kind == 0] = 0
+    sc[kind == 1] = np.array([1, 0, 0, 0], dtype=np.uint64)
+    sc[kind == 2] = sc[0]
+    bases = gpu.Bases(cid, 0, pts)
+    with gpu.tuned(msm_variant=variant):
+        got = bases.msm(sc, montgomery=False)
+    bases.free()
+    w = got.size // 3
+    got_aff = np.zeros(2 * w, dtype=np.uint64) if not got[2 * w:].any() else got[:2 * w]
+    assert np.array_equal(got_aff, cbridge.msm_fast(cid, 0, pts, sc, montgomery=False))
+
+
 @pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
 @pytest.mark.parametrize("logn,ncomp", [(20, 1), (20, 2), (21, 1), (21, 2), (22, 1), (22, 2), (23, 1)])
 def test_ntt_full_size_equals_cpu_restatement(gpu, curve, logn, ncomp):
@@ -186,7 +210,7 @@ def test_msm_fuzz_sizes_and_plans_vs_cpu_restatement(gpu, curve, group, rounds):
             pm1 = np.array([((F.p - 1) >> (64 * i)) & (2**64 - 1) for i in range(4)], dtype=np.uint64)
             sc[: max(1, n // 5)] = pm1                    # canonical r - 1
         knobs = {"msm_c": r.choice([0, 0, 3, 7, 10, 12, 13, 14, 15, 16]), "msm_l": r.choice([0, 0, 1, 5, 16, 64]),
-                 "sort_two_level": r.choice([-1, -1, 0, 1])}
+                 "sort_two_level": r.choice([-1, -1, 0, 1]), "msm_variant": r.choice([0, 0, 32])}
         bases = gpu.Bases(cid, group, pts_all[off:off + n])
         with gpu.tuned(**knobs):
             got = bases.msm(sc, montgomery=False)

@@ -75,11 +75,12 @@ def test_msm_window_sizes(gpu):
     # both scatter variants (single-level LDS cursors / two-level tile sort), uniform and skewed digits
     sk2 = [1] * 120 + [F.p - 1] * 80 + [5 << 200] * 60 + sc[:40]
     want2 = G.msm(pts, sk2)
-    for mode in [0, 1]:
+    # msm_variant 32: level 2 of the two-level sort with one block per partition instead of one per tile-sized slice (the default)
+    for mode, variant in [(0, 0), (1, 0), (1, 32)]:
         for c in [11, 14, 16]:
-            with gpu.tuned(sort_two_level=mode, msm_c=c):
-                assert G.eq(_run(gpu, "bn254", 0, pts, sc), want), (mode, c)
-                assert G.eq(_run(gpu, "bn254", 0, pts, sk2), want2), (mode, c)
+            with gpu.tuned(sort_two_level=mode, msm_c=c, msm_variant=variant):
+                assert G.eq(_run(gpu, "bn254", 0, pts, sc), want), (mode, variant, c)
+                assert G.eq(_run(gpu, "bn254", 0, pts, sk2), want2), (mode, variant, c)
     # tiny task length: forces many tasks per bucket (the skew path) on a skewed scalar set
     with gpu.tuned(msm_l=3):
         sk = [1] * 150 + [F.p - 1] * 100 + sc[:50]

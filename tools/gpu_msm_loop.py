@@ -38,6 +38,12 @@ for job in args:
     rs = np.random.RandomState(1)
     limbs = rs.randint(0, 1 << 63, size=(n, 4), dtype=np.uint64)
     limbs[:, 3] >>= np.uint64(3)
+    if os.environ.get("LOOP_SKEW"):   # a 0/1-heavy witness: half the scalars are 0 or 1, a quarter one repeated value
+        kind = rs.randint(0, 4, size=n)
+        limbs[kind == 0] = 0
+        limbs[kind == 1] = 0
+        limbs[kind == 1, 0] = 1
+        limbs[kind == 2] = limbs[0]
     sc = hip.DeviceBuffer.from_host(limbs)
     out = np.zeros(3 * pb // 16, dtype=np.uint64)
     if timing:
