@@ -131,7 +131,10 @@ __global__ __launch_bounds__(ACC_BLK) void k_msm_accum(const Affine<typename Cfg
   static_assert(Cfg::LAZY, "the bucket pipeline runs in the signed lazy field");
   const int w = blockIdx.y;
   const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k == 0 && w == 0) *giant_count = 0;  // the merge kernel's queue of oversized buckets (stream-ordered after this kernel)
+  if (k == 0 && w == 0) {  // the merge kernel's queue of oversized buckets and its count of sliced ones (stream-ordered after this kernel)
+    giant_count[0] = 0;
+    giant_count[1] = 0;
+  }
   if (k >= nlanes[w]) return;
   const uint32_t* st = start + (size_t)w * (p.NB + 2);
   const uint32_t total = st[p.NB + 1];
@@ -199,7 +202,10 @@ __global__ __launch_bounds__(ACC_BLK) void k_msm_accum_pair(const Affine<typenam
   const int w = blockIdx.y;
   const int role = pair_role();
   const uint32_t k = (blockIdx.x * blockDim.x + threadIdx.x) >> 1;
-  if (blockIdx.x == 0 && threadIdx.x == 0 && w == 0) *giant_count = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && w == 0) {
+    giant_count[0] = 0;
+    giant_count[1] = 0;
+  }
   if (k >= nlanes[w]) return;
   const uint32_t* st = start + (size_t)w * (p.NB + 2);
   const uint32_t total = st[p.NB + 1];
@@ -254,10 +260,30 @@ constexpr int TAIL_Q = TAIL_BLK / 4;
 // profiles/r03_w_merge_lane.log -- 1-3 additions per lane under divergent trip counts and the empty / doubling branches of the full
 // addition; not kept.)
 constexpr uint32_t MERGE_CAP = 16;
+// Oversized buckets of a witness-like scalar vector are few and huge (every "1" lands in bucket 1 of window 0: a quarter of a 2^20 vector
+// in {1} = 4766 partials of 55 entries): one block walking such a bucket took 0.5 ms of a 2.2 ms MSM. Buckets with >= GIANT_BIG
+// partials are therefore SLICED: their queue entry carries a flag, k_msm_giant_slices sums GIANT_SLICES slices of the partial run with
+// one block each into a scratch array, and k_msm_merge_giant folds the slice sums. Up to GIANT_BIG_CAP sliced buckets per launch (more
+// cannot hold a large share of the entries each); the rest take the one-block path.
+constexpr uint32_t GIANT_BIG = 256, GIANT_SLICES = 16, GIANT_BIG_CAP = 128, GIANT_SLICED_FLAG = 0x80000000u;
+__device__ __forceinline__ void giant_enqueue(uint32_t* giant_count, uint32_t* giant_list, uint32_t* big_list, uint32_t w, uint32_t b, uint32_t nparts) {
+  uint32_t tag = w;
+  if (nparts >= GIANT_BIG) {
+    const uint32_t q = atomicAdd(giant_count + 1, 1u);
+    if (q < GIANT_BIG_CAP) {
+      big_list[2 * q] = w;
+      big_list[2 * q + 1] = b;
+      tag |= GIANT_SLICED_FLAG;
+    }
+  }
+  const uint32_t g = atomicAdd(giant_count, 1u);
+  giant_list[2 * g] = tag;
+  giant_list[2 * g + 1] = b;
+}
 template <class Cfg>
 __global__ __launch_bounds__(TAIL_BLK) void k_msm_merge(MsmParams p, const uint32_t* __restrict__ start,
                                                         const LazyPt<Cfg>* __restrict__ partial, LazyPt<Cfg>* dense,
-                                                        uint32_t* giant_count, uint32_t* giant_list) {
+                                                        uint32_t* giant_count, uint32_t* giant_list, uint32_t* big_list) {
   using L = typename Cfg::L;
   const int w = blockIdx.y;
   const int role = threadIdx.x & 3;
@@ -270,11 +296,7 @@ __global__ __launch_bounds__(TAIL_BLK) void k_msm_merge(MsmParams p, const uint3
     const uint32_t k0 = lo / p.L, k1 = (hi - 1) / p.L;
     const LazyPt<Cfg>* pw = partial + (size_t)w * p.tmax + b;
     if (k1 - k0 >= MERGE_CAP) {
-      if (role == 0) {
-        const uint32_t g = atomicAdd(giant_count, 1u);
-        giant_list[2 * g] = (uint32_t)w;
-        giant_list[2 * g + 1] = b;
-      }
+      if (role == 0) giant_enqueue(giant_count, giant_list, big_list, (uint32_t)w, b, k1 - k0 + 1);
     } else {
       acc = qpt_load<L>(&pw[k0], role);
       for (uint32_t k = k0 + 1; k <= k1; ++k) qadd<L>(acc, qpt_load<L>(&pw[k], role), role);
@@ -294,22 +316,57 @@ __device__ __forceinline__ void quad_block_tree(QPt<L>& x, XYZZLazy<L>* sh, int 
   }
 }
 
-// One 256-thread block (64 quads) per queued bucket: strided private sums, then the LDS tree.
+// One 256-thread block (64 quads) per slice of a sliced bucket: strided private sums over the slice's partials, then the LDS tree.
+template <class Cfg>
+__global__ __launch_bounds__(256) void k_msm_giant_slices(MsmParams p, const uint32_t* __restrict__ start, const LazyPt<Cfg>* __restrict__ partial,
+                                                          const uint32_t* __restrict__ giant_count, const uint32_t* __restrict__ big_list,
+                                                          LazyPt<Cfg>* gscratch) {
+  using L = typename Cfg::L;
+  __shared__ XYZZLazy<L> sh[32];
+  const uint32_t q = blockIdx.y, sl = blockIdx.x;
+  const uint32_t nbig = giant_count[1] < GIANT_BIG_CAP ? giant_count[1] : GIANT_BIG_CAP;
+  if (q >= nbig) return;
+  const int role = threadIdx.x & 3, qd = threadIdx.x >> 2;
+  const uint32_t w = big_list[2 * q], b = big_list[2 * q + 1];
+  const uint32_t* st = start + (size_t)w * (p.NB + 2);
+  const uint32_t k0 = st[b] / p.L, k1 = (st[b + 1] - 1) / p.L;
+  const uint32_t per = (k1 - k0 + GIANT_SLICES) / GIANT_SLICES;  // ceil((k1 - k0 + 1) / slices)
+  const uint32_t a = k0 + sl * per;
+  uint32_t e = a + per;  // one past the slice's last partial
+  if (e > k1 + 1) e = k1 + 1;
+  const LazyPt<Cfg>* pw = partial + (size_t)w * p.tmax + b;
+  QPt<L> acc = qpt_inf<L>();
+  for (uint32_t k = a + qd; k < e; k += 64) qadd<L>(acc, qpt_load<L>(&pw[k], role), role);
+  quad_block_tree<L>(acc, sh, qd, 64, role);
+  if (qd == 0) qpt_store<L>(&gscratch[(size_t)q * GIANT_SLICES + sl], role, acc);
+}
+
+// One 256-thread block (64 quads) per queued bucket: strided private sums, then the LDS tree; a sliced bucket folds its slice sums.
 template <class Cfg>
 __global__ __launch_bounds__(256) void k_msm_merge_giant(MsmParams p, const uint32_t* __restrict__ start,
                                                          const LazyPt<Cfg>* __restrict__ partial, LazyPt<Cfg>* dense,
-                                                         const uint32_t* __restrict__ giant_count, const uint32_t* __restrict__ giant_list) {
+                                                         const uint32_t* __restrict__ giant_count, const uint32_t* __restrict__ giant_list,
+                                                         const uint32_t* __restrict__ big_list, const LazyPt<Cfg>* __restrict__ gscratch) {
   using L = typename Cfg::L;
   __shared__ XYZZLazy<L> sh[32];
-  const uint32_t count = *giant_count;
+  __shared__ uint32_t slot;
+  const uint32_t count = giant_count[0];
+  const uint32_t nbig = giant_count[1] < GIANT_BIG_CAP ? giant_count[1] : GIANT_BIG_CAP;
   const int role = threadIdx.x & 3, q = threadIdx.x >> 2;
   for (uint32_t g = blockIdx.x; g < count; g += gridDim.x) {
-    const uint32_t w = giant_list[2 * g], b = giant_list[2 * g + 1];
-    const uint32_t* st = start + (size_t)w * (p.NB + 2);
-    const uint32_t k0 = st[b] / p.L, k1 = (st[b + 1] - 1) / p.L;
-    const LazyPt<Cfg>* pw = partial + (size_t)w * p.tmax + b;
+    const uint32_t tag = giant_list[2 * g], w = tag & ~GIANT_SLICED_FLAG, b = giant_list[2 * g + 1];
     QPt<L> acc = qpt_inf<L>();
-    for (uint32_t k = k0 + q; k <= k1; k += 64) qadd<L>(acc, qpt_load<L>(&pw[k], role), role);
+    if (tag & GIANT_SLICED_FLAG) {
+      __syncthreads();  // `slot` of the previous queue entry has been read by everyone
+      if (threadIdx.x < nbig && big_list[2 * threadIdx.x] == w && big_list[2 * threadIdx.x + 1] == b) slot = threadIdx.x;
+      __syncthreads();
+      if ((uint32_t)q < GIANT_SLICES) acc = qpt_load<L>(&gscratch[(size_t)slot * GIANT_SLICES + q], role);
+    } else {
+      const uint32_t* st = start + (size_t)w * (p.NB + 2);
+      const uint32_t k0 = st[b] / p.L, k1 = (st[b + 1] - 1) / p.L;
+      const LazyPt<Cfg>* pw = partial + (size_t)w * p.tmax + b;
+      for (uint32_t k = k0 + q; k <= k1; k += 64) qadd<L>(acc, qpt_load<L>(&pw[k], role), role);
+    }
     quad_block_tree<L>(acc, sh, q, 64, role);
     if (q == 0) qpt_store<L>(&dense[(size_t)w * (p.NB + 1) + b], role, acc);
   }
@@ -322,17 +379,14 @@ __global__ __launch_bounds__(256) void k_msm_merge_giant(MsmParams p, const uint
 // still go through the block-wide tree (k_msm_merge_giant), which writes their sum to dense[]; k_msm_mark_giant queues them (what
 // k_msm_merge does on the side).
 template <class Cfg>
-__global__ __launch_bounds__(256) void k_msm_mark_giant(MsmParams p, const uint32_t* __restrict__ start, uint32_t* giant_count, uint32_t* giant_list) {
+__global__ __launch_bounds__(256) void k_msm_mark_giant(MsmParams p, const uint32_t* __restrict__ start, uint32_t* giant_count, uint32_t* giant_list,
+                                                        uint32_t* big_list) {
   const int w = blockIdx.y;
   const uint32_t b = blockIdx.x * 256 + threadIdx.x + 1;
   if (b > p.NB) return;
   const uint32_t* st = start + (size_t)w * (p.NB + 2);
   const uint32_t lo = st[b], hi = st[b + 1];
-  if (hi > lo && (hi - 1) / p.L - lo / p.L >= MERGE_CAP) {
-    const uint32_t g = atomicAdd(giant_count, 1u);
-    giant_list[2 * g] = (uint32_t)w;
-    giant_list[2 * g + 1] = b;
-  }
+  if (hi > lo && (hi - 1) / p.L - lo / p.L >= MERGE_CAP) giant_enqueue(giant_count, giant_list, big_list, (uint32_t)w, b, (hi - 1) / p.L - lo / p.L + 1);
 }
 // sum of bucket t of one window: four lanes per point / two lanes per Fp2 point
 template <class Cfg>
@@ -780,6 +834,7 @@ size_t msm_bucket_bytes(const MsmParams* pp) {
   need += Arena::padded(sizeof(LazyPt<Cfg>) * (size_t)p.S * p.W);          // segment results
   need += Arena::padded(sizeof(LazyPt<Cfg>) * (size_t)(p.NB + 1) * p.W);   // dense bucket sums
   need += Arena::padded(sizeof(uint32_t) * (2 * (size_t)max_giant + 2) * 8 /* MAX_GROUPS */);
+  need += Arena::padded(sizeof(uint32_t) * 2 * GIANT_BIG_CAP * 8) + Arena::padded(sizeof(LazyPt<Cfg>) * (size_t)GIANT_BIG_CAP * GIANT_SLICES * 8);  // sliced giants
   need += 2 * Arena::padded(sizeof(LazyPt<Cfg>) * (size_t)((p.S + 127) / 128) * p.W);  // fold-tree ping / pong
   (void)giant_blocks;
   return need;
@@ -789,7 +844,9 @@ size_t msm_bucket_bytes(const MsmParams* pp) {
 template <class Cfg>
 struct BucketBufs {
   LazyPt<Cfg>*partial, *segres, *dense, *fold_a, *fold_b;
-  uint32_t* giant;  // MAX_GROUPS x ([0] = count, list from [2])
+  uint32_t* giant;  // MAX_GROUPS x ([0] = count, [1] = count of sliced buckets, list from [2])
+  uint32_t* big;    // MAX_GROUPS x GIANT_BIG_CAP x (window, bucket) of the sliced buckets
+  LazyPt<Cfg>* gscratch;  // MAX_GROUPS x GIANT_BIG_CAP x GIANT_SLICES slice sums
   uint32_t fold_n1, max_lanes, max_giant, giant_blocks;
 };
 constexpr int MAX_GROUPS = 8;
@@ -803,6 +860,8 @@ BucketBufs<Cfg> bucket_take(const MsmParams& p, Arena& ar) {
   b.segres = ar.take<LazyPt<Cfg>>((size_t)p.S * p.W);
   b.dense = ar.take<LazyPt<Cfg>>((size_t)(p.NB + 1) * p.W);
   b.giant = ar.take<uint32_t>((2 * (size_t)b.max_giant + 2) * MAX_GROUPS);
+  b.big = ar.take<uint32_t>((size_t)2 * GIANT_BIG_CAP * MAX_GROUPS);
+  b.gscratch = ar.take<LazyPt<Cfg>>((size_t)GIANT_BIG_CAP * GIANT_SLICES * MAX_GROUPS);
   b.fold_n1 = (p.S + 127) / 128;
   b.fold_a = ar.take<LazyPt<Cfg>>((size_t)b.fold_n1 * p.W);
   b.fold_b = ar.take<LazyPt<Cfg>>((size_t)b.fold_n1 * p.W);
@@ -825,6 +884,8 @@ int bucket_group(const void* points, const MsmParams& p, const SortOut& so, cons
   LazyPt<Cfg>* fold_a = bb.fold_a + (size_t)bb.fold_n1 * w0;
   LazyPt<Cfg>* fold_b = bb.fold_b + (size_t)bb.fold_n1 * w0;
   uint32_t* giant = bb.giant + (2 * (size_t)bb.max_giant + 2) * group;
+  uint32_t* big = bb.big + (size_t)2 * GIANT_BIG_CAP * group;
+  LazyPt<Cfg>* gscratch = bb.gscratch + (size_t)GIANT_BIG_CAP * GIANT_SLICES * group;
   const Affine<Fq>* bases = reinterpret_cast<const Affine<Fq>*>(points);
   {
     const int tb = tune().acc_blk.load(std::memory_order_relaxed);
@@ -861,11 +922,13 @@ int bucket_group(const void* points, const MsmParams& p, const SortOut& so, cons
   // BLS12-381 G2 only. Kept as a parity-tested variant; the separate merge launch stays the default.
   const bool fused = form != 0 && (variant & 16) != 0;
   if (fused)
-    hipLaunchKernelGGL(k_msm_mark_giant<Cfg>, dim3((p.NB + 255) / 256, nw), dim3(256), 0, st, p, start, giant, giant + 2);
+    hipLaunchKernelGGL(k_msm_mark_giant<Cfg>, dim3((p.NB + 255) / 256, nw), dim3(256), 0, st, p, start, giant, giant + 2, big);
   else
-    hipLaunchKernelGGL(k_msm_merge<Cfg>, dim3((p.NB + TAIL_Q - 1) / TAIL_Q, nw), dim3(TAIL_BLK), 0, st, p, start, partial, dense, giant, giant + 2);
-  // buckets with > MERGE_CAP partials (heavily repeated scalars): block-wide tree, grid-stride over the queue
-  hipLaunchKernelGGL(k_msm_merge_giant<Cfg>, dim3(bb.giant_blocks), dim3(256), 0, st, p, start, partial, dense, giant, giant + 2);
+    hipLaunchKernelGGL(k_msm_merge<Cfg>, dim3((p.NB + TAIL_Q - 1) / TAIL_Q, nw), dim3(TAIL_BLK), 0, st, p, start, partial, dense, giant, giant + 2, big);
+  // buckets with > MERGE_CAP partials (heavily repeated scalars): block-wide tree, grid-stride over the queue; the few with >= GIANT_BIG
+  // partials (a witness's "1"s, a repeated value) are summed in GIANT_SLICES slices by one block each first (blocks past the count return)
+  hipLaunchKernelGGL(k_msm_giant_slices<Cfg>, dim3(GIANT_SLICES, GIANT_BIG_CAP), dim3(256), 0, st, p, start, partial, giant, big, gscratch);
+  hipLaunchKernelGGL(k_msm_merge_giant<Cfg>, dim3(bb.giant_blocks), dim3(256), 0, st, p, start, partial, dense, giant, giant + 2, big, gscratch);
   // Window reduction, three forms of the same segment walk, each with as many segments as fit one round of its waves
   // (reduce_segments): four lanes per point (curve_quad.hpp; the default on the G1 groups: BN254 G1 2^20 tail 0.41 -> 0.33 ms,
   // BLS12-381 G1 0.96 -> 0.80 ms against the lane-serial form at equal launch width, profiles/r02_g_seg_stages3.log), two lanes

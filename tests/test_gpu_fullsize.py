@@ -66,6 +66,31 @@ def test_msm_2p20_witness_like_scalars_equals_cpu_restatement(gpu, variant):
     assert np.array_equal(got_aff, cbridge.msm_fast(cid, 0, pts, sc, montgomery=False))
 
 
+@pytest.mark.parametrize("curve,group", [("bn254", 0), ("bn254", 1), ("bls12_381", 0)])
+@pytest.mark.parametrize("case", ["one_value", "many_values"])
+def test_msm_sliced_giant_buckets_equal_cpu_restatement(gpu, curve, group, case):
+    """Buckets with hundreds to thousands of partial sums (csrc/msm_impl.hpp: k_msm_giant_slices + k_msm_merge_giant). one_value: every
+    scalar equal, one entry per accumulate lane (msm_l = 1): ONE bucket per window holds all 3000 partials -- sliced on every window.
+    many_values: 400 distinct scalars repeated 300 times each at a narrow window: far more than GIANT_BIG_CAP = 128 buckets of >= 256
+    partials, so the first 128 to register are sliced and the rest take the one-block path in the same launch. Bit-identical to oracle/c."""
+    cid = H.CURVE_IDS[curve]
+    rs = np.random.RandomState(5 + group)
+    if case == "one_value":
+        n, knobs = 3000, {"msm_l": 1, "msm_c": 12}
+        sc = np.repeat(_uniform_limbs(rs, 1), n, axis=0)
+    else:
+        n, knobs = 120000, {"msm_l": 1, "msm_c": 11}
+        sc = np.repeat(_uniform_limbs(rs, 400), 300, axis=0)
+    pts = cbridge.generate_bases_progression(cid, group, 0xC0DE + group, n)
+    bases = gpu.Bases(cid, group, pts)
+    with gpu.tuned(**knobs):
+        got = bases.msm(sc, montgomery=False)
+    bases.free()
+    w = got.size // 3
+    got_aff = np.zeros(2 * w, dtype=np.uint64) if not got[2 * w:].any() else got[:2 * w]
+    assert np.array_equal(got_aff, cbridge.msm_fast(cid, group, pts, sc, montgomery=False)), (curve, group, case)
+
+
 @pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
 @pytest.mark.parametrize("logn,ncomp", [(20, 1), (20, 2), (21, 1), (21, 2), (22, 1), (22, 2), (23, 1)])
 def test_ntt_full_size_equals_cpu_restatement(gpu, curve, logn, ncomp):
