@@ -421,6 +421,32 @@ def secondary_single_gpu(cx: Ctx, rin: dict, args):
         del job
     except Exception as e:  # noqa: BLE001
         out["msm_bn254_g1_2p20_two_callers"] = {"error": repr(e)}
+    # The headline workload on a witness-like scalar vector instead of a uniform one (what the PLAIN prover's a / b / l queries see on a
+    # circuit full of booleans; secret shares of a witness are uniform, so the MPC provers see the headline's distribution): a quarter of
+    # the scalars 0, a quarter 1 (every one of them in bucket 1 of window 0), a quarter one repeated value (one bucket per window holds a
+    # quarter of the window's entries), a quarter uniform. Exercises the tile-parallel level 2 of the sort and the sliced merge of
+    # oversized buckets; closed-form checked like every other line.
+    try:
+        job = MsmJob(cx, "bn254_g1", 0, 1 << 20, 1234)
+        job.drop_point_copy()
+        gk = torch.Generator(device=dev)
+        gk.manual_seed(4242)
+        kind = torch.randint(0, 4, (job.n,), device=dev, generator=gk)
+        r_mod = SCALAR_MODULUS[job.curve]
+        mont_one = (1 << 256) % r_mod
+        one = torch.from_numpy(np.array([(mont_one >> (64 * i)) & (2**64 - 1) for i in range(4)], dtype=np.uint64).view(np.int64)).to(dev)
+        rep = job.sc[0].clone()
+        job.sc[kind == 0] = 0
+        job.sc[kind == 1] = one
+        job.sc[kind == 2] = rep
+        torch.cuda.synchronize()
+        dt, res = job.timed(20, 5)
+        out["msm_bn254_g1_2p20_witness_like"] = {"points_per_s": job.n * 20 / dt, "ms": dt / 20 * 1e3, "result_check": job.check(res),
+                                                 "scalars": "1/4 zero, 1/4 one, 1/4 one repeated value, 1/4 uniform (Montgomery form)"}
+        job.free()
+        del job
+    except Exception as e:  # noqa: BLE001
+        out["msm_bn254_g1_2p20_witness_like"] = {"error": repr(e)}
     # NTT 2^22 (snarkjs root), data resident; HIP events on the launch stream
     logn = 22
     r = 21888242871839275222246405745257275088548364400416034343698204186575808495617
