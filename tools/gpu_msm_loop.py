@@ -38,7 +38,9 @@ for job in args:
     rs = np.random.RandomState(1)
     limbs = rs.randint(0, 1 << 63, size=(n, 4), dtype=np.uint64)
     limbs[:, 3] >>= np.uint64(3)
-    if os.environ.get("LOOP_SKEW"):   # a 0/1-heavy witness: half the scalars are 0 or 1, a quarter one repeated value
+    if os.environ.get("LOOP_SKEW"):   # witness-like skew: a quarter zero, two repeated values a quarter each (the scalars are passed as
+        # Montgomery encodings, so the limbs {1, 0, 0, 0} decode to a full-range value: one heavy bucket per window for each repeated value;
+        # bench.py's witness_like line and tests/test_gpu_fullsize.py use true ones)
         kind = rs.randint(0, 4, size=n)
         limbs[kind == 0] = 0
         limbs[kind == 1] = 0
