@@ -265,7 +265,7 @@ constexpr uint32_t MERGE_CAP = 16;
 // partials are therefore SLICED: their queue entry carries a flag, k_msm_giant_slices sums GIANT_SLICES slices of the partial run with
 // one block each into a scratch array, and k_msm_merge_giant folds the slice sums. Up to GIANT_BIG_CAP sliced buckets per launch (more
 // cannot hold a large share of the entries each); the rest take the one-block path.
-constexpr uint32_t GIANT_BIG = 256, GIANT_SLICES = 16, GIANT_BIG_CAP = 128, GIANT_SLICED_FLAG = 0x80000000u;
+constexpr uint32_t GIANT_BIG = 256, GIANT_SLICES = 16, GIANT_BIG_CAP = 128, GIANT_ROWS = 32, GIANT_SLICED_FLAG = 0x80000000u;
 __device__ __forceinline__ void giant_enqueue(uint32_t* giant_count, uint32_t* giant_list, uint32_t* big_list, uint32_t w, uint32_t b, uint32_t nparts) {
   uint32_t tag = w;
   if (nparts >= GIANT_BIG) {
@@ -323,22 +323,23 @@ __global__ __launch_bounds__(256) void k_msm_giant_slices(MsmParams p, const uin
                                                           LazyPt<Cfg>* gscratch) {
   using L = typename Cfg::L;
   __shared__ XYZZLazy<L> sh[32];
-  const uint32_t q = blockIdx.y, sl = blockIdx.x;
+  const uint32_t sl = blockIdx.x;
   const uint32_t nbig = giant_count[1] < GIANT_BIG_CAP ? giant_count[1] : GIANT_BIG_CAP;
-  if (q >= nbig) return;
   const int role = threadIdx.x & 3, qd = threadIdx.x >> 2;
-  const uint32_t w = big_list[2 * q], b = big_list[2 * q + 1];
-  const uint32_t* st = start + (size_t)w * (p.NB + 2);
-  const uint32_t k0 = st[b] / p.L, k1 = (st[b + 1] - 1) / p.L;
-  const uint32_t per = (k1 - k0 + GIANT_SLICES) / GIANT_SLICES;  // ceil((k1 - k0 + 1) / slices)
-  const uint32_t a = k0 + sl * per;
-  uint32_t e = a + per;  // one past the slice's last partial
-  if (e > k1 + 1) e = k1 + 1;
-  const LazyPt<Cfg>* pw = partial + (size_t)w * p.tmax + b;
-  QPt<L> acc = qpt_inf<L>();
-  for (uint32_t k = a + qd; k < e; k += 64) qadd<L>(acc, qpt_load<L>(&pw[k], role), role);
-  quad_block_tree<L>(acc, sh, qd, 64, role);
-  if (qd == 0) qpt_store<L>(&gscratch[(size_t)q * GIANT_SLICES + sl], role, acc);
+  for (uint32_t q = blockIdx.y; q < nbig; q += gridDim.y) {  // usually none: the launch is GIANT_SLICES x GIANT_ROWS blocks that return at once
+    const uint32_t w = big_list[2 * q], b = big_list[2 * q + 1];
+    const uint32_t* st = start + (size_t)w * (p.NB + 2);
+    const uint32_t k0 = st[b] / p.L, k1 = (st[b + 1] - 1) / p.L;
+    const uint32_t per = (k1 - k0 + GIANT_SLICES) / GIANT_SLICES;  // ceil((k1 - k0 + 1) / slices)
+    const uint32_t a = k0 + sl * per;
+    uint32_t e = a + per;  // one past the slice's last partial
+    if (e > k1 + 1) e = k1 + 1;
+    const LazyPt<Cfg>* pw = partial + (size_t)w * p.tmax + b;
+    QPt<L> acc = qpt_inf<L>();
+    for (uint32_t k = a + qd; k < e; k += 64) qadd<L>(acc, qpt_load<L>(&pw[k], role), role);
+    quad_block_tree<L>(acc, sh, qd, 64, role);
+    if (qd == 0) qpt_store<L>(&gscratch[(size_t)q * GIANT_SLICES + sl], role, acc);
+  }
 }
 
 // One 256-thread block (64 quads) per queued bucket: strided private sums, then the LDS tree; a sliced bucket folds its slice sums.
@@ -927,7 +928,7 @@ int bucket_group(const void* points, const MsmParams& p, const SortOut& so, cons
     hipLaunchKernelGGL(k_msm_merge<Cfg>, dim3((p.NB + TAIL_Q - 1) / TAIL_Q, nw), dim3(TAIL_BLK), 0, st, p, start, partial, dense, giant, giant + 2, big);
   // buckets with > MERGE_CAP partials (heavily repeated scalars): block-wide tree, grid-stride over the queue; the few with >= GIANT_BIG
   // partials (a witness's "1"s, a repeated value) are summed in GIANT_SLICES slices by one block each first (blocks past the count return)
-  hipLaunchKernelGGL(k_msm_giant_slices<Cfg>, dim3(GIANT_SLICES, GIANT_BIG_CAP), dim3(256), 0, st, p, start, partial, giant, big, gscratch);
+  hipLaunchKernelGGL(k_msm_giant_slices<Cfg>, dim3(GIANT_SLICES, GIANT_ROWS), dim3(256), 0, st, p, start, partial, giant, big, gscratch);
   hipLaunchKernelGGL(k_msm_merge_giant<Cfg>, dim3(bb.giant_blocks), dim3(256), 0, st, p, start, partial, dense, giant, giant + 2, big, gscratch);
   // Window reduction, three forms of the same segment walk, each with as many segments as fit one round of its waves
   // (reduce_segments): four lanes per point (curve_quad.hpp; the default on the G1 groups: BN254 G1 2^20 tail 0.41 -> 0.33 ms,
