@@ -584,70 +584,6 @@ __global__ __launch_bounds__(256) void k_msm_fold_tree(const LazyPt<Cfg>* __rest
   }
 }
 
-// ---- bit-sliced window reduction (tune "msm_variant" bit 6; round 3, experimental) ---------------------------------------------------
-// sum_{t=1..NB} t B_t = sum_u D_u + sum_i 2^i U_i with D_u = B_(u+1) and U_i = the sum of the D_u whose index u has bit i set. With
-// u = 128 r + c the seven low U_i are sums of COLUMN sums C_c, the high ones sums of ROW sums R_r, and sum_u D_u = sum_r R_r. Three
-// launches of LDS trees (no running sums, no per-segment scalar multiple): rows and columns (2 additions per bucket, depth 7), the bit
-// sums (64-leaf trees), a Horner over the bits per window.
-constexpr uint32_t BS_COLS = 128, BS_RC_STRIDE = 256 + BS_COLS, BS_U_STRIDE = 16;
-template <class Cfg>
-__global__ __launch_bounds__(256) void k_msm_rowcol(MsmParams p, const LazyPt<Cfg>* __restrict__ dense, LazyPt<Cfg>* rc) {
-  using L = typename Cfg::L;
-  __shared__ XYZZLazy<L> sh[32];
-  const int w = blockIdx.y;
-  const int role = threadIdx.x & 3, q = threadIdx.x >> 2;
-  const uint32_t RN = p.NB / BS_COLS, i = blockIdx.x;
-  const LazyPt<Cfg>* d = dense + (size_t)w * (p.NB + 1) + 1;  // d[u] = bucket u + 1
-  QPt<L> x = qpt_inf<L>();
-  if (i < RN) {  // row i: 128 consecutive buckets
-    x = qpt_load<L>(&d[(size_t)i * BS_COLS + q], role);
-    qadd<L>(x, qpt_load<L>(&d[(size_t)i * BS_COLS + q + 64], role), role);
-  } else {       // column i - RN: one bucket of every row
-    const uint32_t c = i - RN;
-    for (uint32_t r = q; r < RN; r += 64) qadd<L>(x, qpt_load<L>(&d[(size_t)r * BS_COLS + c], role), role);
-  }
-  quad_block_tree<L>(x, sh, q, 64, role);
-  if (q == 0) qpt_store<L>(&rc[(size_t)w * BS_RC_STRIDE + i], role, x);
-}
-__device__ __forceinline__ uint32_t bs_insert_one(uint32_t v, uint32_t bit) {  // v with a 1 inserted at position `bit`
-  return ((v >> bit) << (bit + 1)) | (1u << bit) | (v & ((1u << bit) - 1u));
-}
-template <class Cfg>
-__global__ __launch_bounds__(256) void k_msm_bitsums(MsmParams p, const LazyPt<Cfg>* __restrict__ rc, LazyPt<Cfg>* U) {
-  using L = typename Cfg::L;
-  __shared__ XYZZLazy<L> sh[32];
-  const int w = blockIdx.y;
-  const int role = threadIdx.x & 3, q = threadIdx.x >> 2;
-  const uint32_t RN = p.NB / BS_COLS, j = blockIdx.x, nbits = gridDim.x - 1;
-  const LazyPt<Cfg>* rows = rc + (size_t)w * BS_RC_STRIDE;
-  const LazyPt<Cfg>* cols = rows + RN;
-  QPt<L> x = qpt_inf<L>();
-  if (j < 7) {            // low bit j: the 64 columns with that bit set
-    x = qpt_load<L>(&cols[bs_insert_one((uint32_t)q, j)], role);
-  } else if (j < nbits) { // high bit j: the RN / 2 rows with bit j - 7 set
-    for (uint32_t h = q; h < RN / 2; h += 64) qadd<L>(x, qpt_load<L>(&rows[bs_insert_one(h, j - 7)], role), role);
-  } else {                // every row: the plain sum of the window's buckets
-    for (uint32_t r = q; r < RN; r += 64) qadd<L>(x, qpt_load<L>(&rows[r], role), role);
-  }
-  quad_block_tree<L>(x, sh, q, 64, role);
-  if (q == 0) qpt_store<L>(&U[(size_t)w * BS_U_STRIDE + j], role, x);
-}
-template <class Cfg>
-__global__ __launch_bounds__(64) void k_msm_bithorner(const LazyPt<Cfg>* __restrict__ U, uint32_t nbits, XYZZ<typename Cfg::Fq>* win_out) {
-  using L = typename Cfg::L;
-  using Fq = typename Cfg::Fq;
-  const int w = blockIdx.x;
-  const int role = threadIdx.x & 3;
-  const LazyPt<Cfg>* u = U + (size_t)w * BS_U_STRIDE;
-  QPt<L> acc = qpt_load<L>(&u[nbits - 1], role);  // every quad of the wave computes the same value; quad 0 writes it
-  for (int i = (int)nbits - 2; i >= 0; --i) {
-    qdbl<L>(acc, role);
-    qadd<L>(acc, qpt_load<L>(&u[i], role), role);
-  }
-  qadd<L>(acc, qpt_load<L>(&u[nbits], role), role);
-  if (threadIdx.x < 4) (&win_out[w].x)[role] = acc.empty ? Fq::zero() : acc.v.to_fp();
-}
-
 // In-place re-encoding of uploaded bases for LAZY curves: x*2^(32N) -> canonical x*R' (infinity stays 0,0)
 template <class Cfg>
 __global__ __launch_bounds__(256) void k_bases_repack(Affine<typename Cfg::Fq>* pts, size_t n) {
@@ -900,7 +836,6 @@ size_t msm_bucket_bytes(const MsmParams* pp) {
   need += Arena::padded(sizeof(LazyPt<Cfg>) * (size_t)(p.NB + 1) * p.W);   // dense bucket sums
   need += Arena::padded(sizeof(uint32_t) * (2 * (size_t)max_giant + 2) * 8 /* MAX_GROUPS */);
   need += Arena::padded(sizeof(uint32_t) * 2 * GIANT_BIG_CAP * 8) + Arena::padded(sizeof(LazyPt<Cfg>) * (size_t)GIANT_BIG_CAP * GIANT_SLICES * 8);  // sliced giants
-  need += Arena::padded(sizeof(LazyPt<Cfg>) * (size_t)BS_RC_STRIDE * p.W) + Arena::padded(sizeof(LazyPt<Cfg>) * (size_t)BS_U_STRIDE * p.W);  // bit-sliced reduction
   need += 2 * Arena::padded(sizeof(LazyPt<Cfg>) * (size_t)((p.S + 127) / 128) * p.W);  // fold-tree ping / pong
   (void)giant_blocks;
   return need;
@@ -913,7 +848,6 @@ struct BucketBufs {
   uint32_t* giant;  // MAX_GROUPS x ([0] = count, [1] = count of sliced buckets, list from [2])
   uint32_t* big;    // MAX_GROUPS x GIANT_BIG_CAP x (window, bucket) of the sliced buckets
   LazyPt<Cfg>* gscratch;  // MAX_GROUPS x GIANT_BIG_CAP x GIANT_SLICES slice sums
-  LazyPt<Cfg>*bs_rc, *bs_u;  // bit-sliced reduction: row / column sums and bit sums per window
   uint32_t fold_n1, max_lanes, max_giant, giant_blocks;
 };
 constexpr int MAX_GROUPS = 8;
@@ -929,8 +863,6 @@ BucketBufs<Cfg> bucket_take(const MsmParams& p, Arena& ar) {
   b.giant = ar.take<uint32_t>((2 * (size_t)b.max_giant + 2) * MAX_GROUPS);
   b.big = ar.take<uint32_t>((size_t)2 * GIANT_BIG_CAP * MAX_GROUPS);
   b.gscratch = ar.take<LazyPt<Cfg>>((size_t)GIANT_BIG_CAP * GIANT_SLICES * MAX_GROUPS);
-  b.bs_rc = ar.take<LazyPt<Cfg>>((size_t)BS_RC_STRIDE * p.W);
-  b.bs_u = ar.take<LazyPt<Cfg>>((size_t)BS_U_STRIDE * p.W);
   b.fold_n1 = (p.S + 127) / 128;
   b.fold_a = ar.take<LazyPt<Cfg>>((size_t)b.fold_n1 * p.W);
   b.fold_b = ar.take<LazyPt<Cfg>>((size_t)b.fold_n1 * p.W);
@@ -1005,19 +937,6 @@ int bucket_group(const void* points, const MsmParams& p, const SortOut& so, cons
   // form needs 437-512 VGPRs + scratch -- and half the dependent chain per point operation; BN254 G2 2^20 tail 1.05 -> 0.81 ms,
   // BLS12-381 G2 3.2 -> 2.1 ms, profiles/r02_g_seg_stages2.log), or one lane per segment. tune "msm_variant" picks another
   // form for A/B runs and tests: G1: bit 0 -> lane-serial; G2: bit 0 -> four lanes, bit 2 -> lane-serial.
-  // tune "msm_variant" bit 6: the bit-sliced reduction above instead of the segment walk + fold tree (four lanes per point on every group)
-  if ((variant & 64) != 0 && !fused && p.NB >= 8 * BS_COLS && p.NB <= 256 * BS_COLS) {
-    uint32_t rbits = 0;
-    while ((BS_COLS << (rbits + 1)) <= p.NB) ++rbits;  // log2(rows)
-    const uint32_t nbits = 7 + rbits;
-    LazyPt<Cfg>* rc = bb.bs_rc + (size_t)BS_RC_STRIDE * w0;
-    LazyPt<Cfg>* U = bb.bs_u + (size_t)BS_U_STRIDE * w0;
-    hipLaunchKernelGGL(k_msm_rowcol<Cfg>, dim3(p.NB / BS_COLS + BS_COLS, nw), dim3(256), 0, st, p, dense, rc);
-    hipLaunchKernelGGL(k_msm_bitsums<Cfg>, dim3(nbits + 1, nw), dim3(256), 0, st, p, rc, U);
-    hipLaunchKernelGGL(k_msm_bithorner<Cfg>, dim3(nw), dim3(64), 0, st, U, nbits, reinterpret_cast<XYZZ<Fq>*>(win_out_dev) + w0);
-    CSH_HIP(hipGetLastError());
-    return CSH_OK;
-  }
   MsmParams pr = p;  // the reduction's own segmentation (never more segments than the plan sized the buffers for)
   if (form == 1) {
     pr.S = std::min(p.S, reduce_segments(p.NB, p.W, 4));

@@ -235,7 +235,7 @@ def test_msm_fuzz_sizes_and_plans_vs_cpu_restatement(gpu, curve, group, rounds):
             pm1 = np.array([((F.p - 1) >> (64 * i)) & (2**64 - 1) for i in range(4)], dtype=np.uint64)
             sc[: max(1, n // 5)] = pm1                    # canonical r - 1
         knobs = {"msm_c": r.choice([0, 0, 3, 7, 10, 12, 13, 14, 15, 16]), "msm_l": r.choice([0, 0, 1, 5, 16, 64]),
-                 "sort_two_level": r.choice([-1, -1, 0, 1]), "msm_variant": r.choice([0, 0, 32, 64, 64])}
+                 "sort_two_level": r.choice([-1, -1, 0, 1]), "msm_variant": r.choice([0, 0, 32])}
         bases = gpu.Bases(cid, group, pts_all[off:off + n])
         with gpu.tuned(**knobs):
             got = bases.msm(sc, montgomery=False)

@@ -88,17 +88,16 @@ def test_msm_window_sizes(gpu):
 
 
 @pytest.mark.parametrize("curve,group", [("bn254", 1), ("bls12_381", 1), ("bn254", 0), ("bls12_381", 0)])
-@pytest.mark.parametrize("variant", [1, 2, 4, 6, 16, 17, 64])
+@pytest.mark.parametrize("variant", [1, 2, 4, 6, 16, 17])
 def test_msm_kernel_form_variants(gpu, curve, group, variant):
     """Every form of the bucket kernels that is not the default of its group (tune "msm_variant"): G2: bit 1 = the other accumulate
     form of the group (two lanes per point, csrc/curve_pair.hpp, on BN254 G2; whole points per lane on BLS12-381 G2, whose default is the pair), bit 0 / bit 2 = four-lane / lane-serial window reduction instead of the two-lane
     one; G1: bit 0 = lane-serial window reduction instead of the four-lane one; bit 4 (16) = the reduction merges each bucket's
-    partial slots itself instead of reading the merge launch's dense array (17 on G2: the same with the four-lane reduction); bit 6 (64) = the bit-sliced window reduction (row / column sums, bit sums, a Horner
-    over the bucket-index bits; takes effect from 1024 buckets per window on: c = 11 here). Same
+    partial slots itself instead of reading the merge launch's dense array (17 on G2: the same with the four-lane reduction). Same
     group element as the oracle on random points with duplicates, P / -P, points at infinity and the edge scalars (r - 1 on every
     point = one giant bucket: the queue of k_msm_mark_giant), at several window widths (the doubling and cancellation paths run
     through the DPP exchanges too)."""
-    if group == 0 and variant not in (1, 16, 64):
+    if group == 0 and variant not in (1, 16):
         pytest.skip("bits 1 and 2 only select G2 kernels")
     G = cv.CURVES[curve][group]
     F = H.FR[curve]
