@@ -359,9 +359,18 @@ __global__ __launch_bounds__(256) void k_msm_merge_giant(MsmParams p, const uint
     QPt<L> acc = qpt_inf<L>();
     if (tag & GIANT_SLICED_FLAG) {
       __syncthreads();  // `slot` of the previous queue entry has been read by everyone
+      if (threadIdx.x == 0) slot = GIANT_BIG_CAP;  // "not found": cannot happen for a flagged entry; then the bucket takes the walk below
+      __syncthreads();
       if (threadIdx.x < nbig && big_list[2 * threadIdx.x] == w && big_list[2 * threadIdx.x + 1] == b) slot = threadIdx.x;
       __syncthreads();
-      if ((uint32_t)q < GIANT_SLICES) acc = qpt_load<L>(&gscratch[(size_t)slot * GIANT_SLICES + q], role);
+      if (slot < GIANT_BIG_CAP) {
+        if ((uint32_t)q < GIANT_SLICES) acc = qpt_load<L>(&gscratch[(size_t)slot * GIANT_SLICES + q], role);
+      } else {
+        const uint32_t* st = start + (size_t)w * (p.NB + 2);
+        const uint32_t k0 = st[b] / p.L, k1 = (st[b + 1] - 1) / p.L;
+        const LazyPt<Cfg>* pw = partial + (size_t)w * p.tmax + b;
+        for (uint32_t k = k0 + q; k <= k1; k += 64) qadd<L>(acc, qpt_load<L>(&pw[k], role), role);
+      }
     } else {
       const uint32_t* st = start + (size_t)w * (p.NB + 2);
       const uint32_t k0 = st[b] / p.L, k1 = (st[b + 1] - 1) / p.L;
