@@ -217,3 +217,112 @@ def proof_to_json(proof, curve: str) -> str:
         "protocol": "groth16",
         "curve": "bn128" if curve == "bn254" else "bls12381",
     })
+
+
+# ---------------------------------------------------------------------------------------------
+# snarkjs PLONK zkey (protocol id 2).  The reference reads it with the same external crate and uses
+# `zkey.{qm,ql,qr,qo,qc}_poly.{coeffs, evaluations}`, `zkey.s{1,2,3}_poly`, `zkey.p_tau`
+# (co-circom/co-plonk/src/round3.rs:325-332, round5.rs:154, round1.rs commitments over p_tau) and the
+# verifying key's Qm..S3 commitments (co-plonk/src/lib.rs:295-312 load both files of
+# test_vectors/Plonk/*/multiplier2).  Each polynomial section holds n coefficients followed by their
+# 4n evaluations over the extended domain whose generator is the snarkjs root `roots[pow + 2]`
+# (co-plonk/src/types.rs:70-109): a raw `EvaluationDomain::fft` vector held by the reference; the
+# header's Qm..S3 are the KZG commitments msm(p_tau[0..n], coeffs): a raw `msm_unchecked` vector.
+# ---------------------------------------------------------------------------------------------
+PLONK_POLY_SECTIONS = {"Qm": (7, 0), "Ql": (8, 0), "Qr": (9, 0), "Qo": (10, 0), "Qc": (11, 0),
+                       "S1": (12, 0), "S2": (12, 1), "S3": (12, 2)}
+
+
+@dataclass
+class PlonkZKey:
+    curve: str
+    n8q: int
+    n8r: int
+    n_vars: int
+    n_public: int
+    domain_size: int
+    n_additions: int
+    n_constraints: int
+    k1: int
+    k2: int
+    commitments: dict  # name -> affine G1 point (header copy of vk.Qm .. vk.S3)
+    x_2: tuple
+    polys: dict        # name -> (coeffs[n], evaluations[4n]) canonical integers
+    lagrange: list     # [(coeffs[n], evaluations[4n])] for L_1 .. L_max(n_public,1)
+    p_tau: list        # affine G1 points tau^i G
+
+    @property
+    def Fr(self):
+        return fl.BN254_FR if self.curve == "bn254" else fl.BLS381_FR
+
+    @property
+    def G1(self):
+        return cv.CURVES[self.curve][0]
+
+
+def parse_plonk_zkey(data: bytes) -> PlonkZKey:
+    secs = _sections(data, b"zkey")
+    off, _ = secs[1][0]
+    assert struct.unpack_from("<I", data, off)[0] == 2, "not a plonk zkey"
+    off, ln = secs[2][0]
+    end = off + ln
+    n8q = struct.unpack_from("<I", data, off)[0]
+    off += 4
+    q = int.from_bytes(data[off:off + n8q], "little")
+    off += n8q
+    n8r = struct.unpack_from("<I", data, off)[0]
+    off += 4
+    r = int.from_bytes(data[off:off + n8r], "little")
+    off += n8r
+    n_vars, n_public, n, n_add, n_cons = struct.unpack_from("<IIIII", data, off)
+    off += 20
+    curve = "bn254" if q == fl.BN254_Q else "bls12_381" if q == fl.BLS381_Q else None
+    if curve is None:
+        raise ValueError("unsupported curve modulus")
+    G1, G2 = cv.CURVES[curve]
+    Fq = G1.F
+    Fr = fl.BN254_FR if curve == "bn254" else fl.BLS381_FR
+    assert r == Fr.p
+
+    def fr(o):
+        return Fr.from_mont(int.from_bytes(data[o:o + n8r], "little"))
+
+    def g1(o):
+        x = Fq.from_mont(int.from_bytes(data[o:o + n8q], "little"))
+        y = Fq.from_mont(int.from_bytes(data[o + n8q:o + 2 * n8q], "little"))
+        return None if x == 0 and y == 0 else (x, y)
+
+    k1, k2 = fr(off), fr(off + n8r)
+    off += 2 * n8r
+    commitments = {}
+    for nm in PLONK_POLY_SECTIONS:
+        commitments[nm] = g1(off)
+        off += 2 * n8q
+    v = [Fq.from_mont(int.from_bytes(data[off + i * n8q:off + (i + 1) * n8q], "little")) for i in range(4)]
+    x_2 = ((v[0], v[1]), (v[2], v[3]))
+    off += 4 * n8q
+    assert off == end, (off, end)
+
+    def poly(sec, idx):
+        o, l = secs[sec][0]
+        assert l % (5 * n * n8r) == 0 and idx < l // (5 * n * n8r)
+        o += idx * 5 * n * n8r
+        co = [fr(o + i * n8r) for i in range(n)]
+        o += n * n8r
+        ev = [fr(o + i * n8r) for i in range(4 * n)]
+        return co, ev
+
+    polys = {nm: poly(*loc) for nm, loc in PLONK_POLY_SECTIONS.items()}
+    n_lag = secs[13][0][1] // (5 * n * n8r)
+    lagrange = [poly(13, i) for i in range(n_lag)]
+    o, l = secs[14][0]
+    p_tau = [g1(o + i * 2 * n8q) for i in range(l // (2 * n8q))]
+    return PlonkZKey(curve, n8q, n8r, n_vars, n_public, n, n_add, n_cons, k1, k2, commitments, x_2, polys, lagrange, p_tau)
+
+
+def parse_plonk_vk(text: str):
+    j = json.loads(text)
+    out = {nm: _g1_json(j[nm]) for nm in PLONK_POLY_SECTIONS}
+    out.update({"curve": j.get("curve"), "n_public": j["nPublic"], "power": j["power"], "k1": int(j["k1"]), "k2": int(j["k2"]),
+                "X_2": _g2_json(j["X_2"]), "w": int(j["w"])})
+    return out
