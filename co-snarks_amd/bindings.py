@@ -455,6 +455,34 @@ def groth16_h(dom: Domain, shift, protocol: int, a, b, mask_c=None, mask_ab=None
     return out
 
 
+def groth16_witness_map_masks(dom: Domain, shift, protocol: int, party: int, a: "Matrix", b: "Matrix", num_constraints: int, public, witness,
+                              mask_c=None, mask_ab=None, fresh_output: bool = True):
+    """csh_groth16_witness_map_masks: CircomReduction::witness_map_from_matrices in one call, Rep3 masks handed over by the caller.
+    fresh_output: h is written into memory that was allocated but never touched (np.empty), as the Rust shim does."""
+    pub, wit, sh = _u64(public), _u64(witness), _u64(shift)
+    comp = 2 if protocol == 1 else 1
+    out = np.empty(dom.n * 4, dtype=np.uint64) if fresh_output else np.zeros(dom.n * 4, dtype=np.uint64)
+    mc = _u64(mask_c) if mask_c is not None else None
+    mab = _u64(mask_ab) if mask_ab is not None else None
+    _check(lib().csh_groth16_witness_map_masks(dom.h, _p(sh), int(protocol), int(party), a.h, b.h, C.c_size_t(num_constraints), _p(pub),
+                                               C.c_size_t(pub.size // 4), _p(wit), C.c_size_t(wit.size // (4 * comp)), _p(mc), _p(mab), _p(out)))
+    return out
+
+
+def groth16_witness_map_seeded(dom: Domain, shift, protocol: int, party: int, a: "Matrix", b: "Matrix", num_constraints: int, public, witness,
+                               seed1=None, off1: int = 0, seed2=None, off2: int = 0):
+    """csh_groth16_witness_map: the same map with the masks generated on the device from the party's two ChaCha12 keys."""
+    pub, wit, sh = _u64(public), _u64(witness), _u64(shift)
+    comp = 2 if protocol == 1 else 1
+    out = np.empty(dom.n * 4, dtype=np.uint64)
+    s1 = (C.c_uint8 * 32)(*seed1) if seed1 is not None else None
+    s2 = (C.c_uint8 * 32)(*seed2) if seed2 is not None else None
+    _check(lib().csh_groth16_witness_map(dom.h, _p(sh), int(protocol), int(party), a.h, b.h, C.c_size_t(num_constraints), _p(pub),
+                                         C.c_size_t(pub.size // 4), _p(wit), C.c_size_t(wit.size // (4 * comp)), s1, C.c_uint64(off1), s2,
+                                         C.c_uint64(off2), _p(out)))
+    return out
+
+
 def sync(stream=None):
     _check(lib().csh_sync(_stream(stream)))
 

@@ -3,9 +3,45 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <sys/mman.h>
+
 #include "common.hpp"
 
+#ifndef MADV_POPULATE_WRITE
+#define MADV_POPULATE_WRITE 23
+#endif
+
 namespace csh {
+
+// Populate the pages of a D2H destination from a few host threads while the device is still busy (see HostXfer in common.hpp).
+// MADV_POPULATE_WRITE (Linux >= 5.14) faults the pages in writable without touching their content; on kernels without it the
+// call fails with EINVAL and the copy simply pays the first touch itself, as before.
+void host_populate_begin(void* p, size_t bytes, std::vector<std::thread>& workers) {
+  const int threads = tune().host_populate.load(std::memory_order_relaxed);
+  if (!p || threads <= 0 || bytes < (size_t(4) << 20)) return;
+  char* lo = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(p) + 4095) & ~uintptr_t(4095));  // whole pages inside the buffer only
+  char* hi = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(p) + bytes) & ~uintptr_t(4095));
+  if (hi <= lo) return;
+  const size_t span = (size_t)(hi - lo);
+  const size_t per = ((span / (size_t)threads) + 4095) & ~size_t(4095);
+  for (int t = 0; t < threads; ++t) {
+    char* a = lo + per * (size_t)t;
+    if (a >= hi) break;
+    const size_t len = (size_t)(hi - a) < per ? (size_t)(hi - a) : per;
+    try {
+      workers.emplace_back([a, len] { (void)madvise(a, len, MADV_POPULATE_WRITE); });
+    } catch (...) {  // no thread to be had: the copy populates the rest
+      break;
+    }
+  }
+}
+
+int HostStage::down(void* host, const void* dev, size_t bytes) {
+  HostXfer x;
+  x.expect_d2h(host, bytes);  // overlaps whatever the stream still has queued
+  CSH_TRY(x.d2h(host, dev, bytes, st));
+  return x.finish(st);
+}
 
 static thread_local std::string tl_error;
 static thread_local int tl_device = -1;
@@ -79,6 +115,7 @@ static const TuneEntry kTune[] = {
     {"allow_unmasked_rep3", "CSH_ALLOW_UNMASKED_REP3", &Tune::allow_unmasked_rep3},
     {"ntt_variant", "CSH_NTT_VARIANT", &Tune::ntt_variant},
     {"h_unfused", "CSH_H_UNFUSED", &Tune::h_unfused},
+    {"host_populate", "CSH_HOST_POPULATE", &Tune::host_populate},
 };
 Tune& tune() {
   static Tune* t = [] {

@@ -8,6 +8,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/cosnarks_hip.h"
@@ -78,8 +79,37 @@ struct HostStage {
     if (host && bytes) CSH_HIP(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, st));
     return CSH_OK;
   }
-  int down(void* host, const void* dev, size_t bytes) {
+  int down(void* host, const void* dev, size_t bytes);  // capi.hip: populates a large destination's pages first (see HostXfer)
+};
+
+// Host-pointer entry points that hand the caller LARGE buffers back (h of a witness map, a transformed vector). Measured on the MI355X
+// boxes (profiles/r04_a_pcie_probe.jsonl, r04_b_prefault_probe.jsonl): a copy from / to pageable memory whose pages are present runs
+// at the PCIe rate (32 MB in 0.60 ms = 56 GB/s, the same as from hipHostMalloc memory; hipHostRegister is a ~1 us no-op on these hosts),
+// but a D2H into memory the caller has only just allocated pays the DMA engine's first touch of every page: 3.9 ms for 32 MB.
+// HostXfer therefore populates the destination's pages from a few host threads (MADV_POPULATE_WRITE: no content change) WHILE the
+// device works, and joins them before the copy is enqueued.
+void host_populate_begin(void* p, size_t bytes, std::vector<std::thread>& workers);  // no-op below 4 MiB or with tune host_populate = 0
+struct HostXfer {
+  std::vector<std::thread> workers;
+  ~HostXfer() { join(); }
+  void join() {
+    for (auto& t : workers)
+      if (t.joinable()) t.join();
+    workers.clear();
+  }
+  // call as early as the destination is known: the pages are populated while uploads and kernels run
+  void expect_d2h(void* host, size_t bytes) { host_populate_begin(host, bytes, workers); }
+  int h2d(void* dev, const void* host, size_t bytes, hipStream_t st) {
+    if (bytes) CSH_HIP(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, st));
+    return CSH_OK;
+  }
+  int d2h(void* host, const void* dev, size_t bytes, hipStream_t st) {
+    join();
     if (bytes) CSH_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, st));
+    return CSH_OK;
+  }
+  int finish(hipStream_t st) {
+    join();
     CSH_HIP(hipStreamSynchronize(st));
     return CSH_OK;
   }
@@ -117,6 +147,7 @@ struct Tune {
   std::atomic<int> allow_unmasked_rep3{0};  // Rep3 products without the re-randomising masks: refused unless set (tests)
   std::atomic<int> ntt_variant{0};
   std::atomic<int> h_unfused{0};          // Groth16 h pipeline: 1 = the unfused step-by-step sequence (A/B, tests)
+  std::atomic<int> host_populate{4};      // threads populating a large D2H destination's pages before the copy (0 = off)
 };
 Tune& tune();
 

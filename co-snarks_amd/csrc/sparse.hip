@@ -181,13 +181,28 @@ int csh_evaluate_constraints_dev(csh_matrix_t mm, int protocol, int party_id, co
   return eval_t<Bls381Fr>(m, protocol, party_id, public_dev, n_public, witness_dev, out_dev, n_out, st);
 }
 
+}  // extern "C"
+
+namespace {
+// Where the two Rep3 mask vectors of a witness map come from (reduction.rs:160 then :182): the party's ChaCha12 keys (generated on the
+// device) or two vectors the caller drew itself through the reference's public surface (`masking_field_elements_vec`, rngs.rs:137).
+struct MaskSource {
+  const uint8_t* seed1 = nullptr;
+  uint64_t off1 = 0;
+  const uint8_t* seed2 = nullptr;
+  uint64_t off2 = 0;
+  const uint64_t* mask_c_dev = nullptr;
+  const uint64_t* mask_ab_dev = nullptr;
+  bool have() const { return (seed1 && seed2) || (mask_c_dev && mask_ab_dev); }
+};
+
 // Device-resident core: witness already on the device, h stays on the device (scratch from the stream's arena)
-int csh_groth16_witness_map_dev(csh_domain_t dom, const uint64_t shift[4], int protocol, int party_id, csh_matrix_t ma, csh_matrix_t mb,
-                                size_t num_constraints, const uint64_t* public_inputs, size_t n_public, const uint64_t* witness_dev, size_t n_witness,
-                                const uint8_t seed1[32], uint64_t off1, const uint8_t seed2[32], uint64_t off2, uint64_t* h_out_dev, void* stream) {
+int witness_map_core(csh_domain_t dom, const uint64_t shift[4], int protocol, int party_id, csh_matrix_t ma, csh_matrix_t mb, size_t num_constraints,
+                     const uint64_t* public_inputs, size_t n_public, const uint64_t* witness_dev, size_t n_witness, const MaskSource& ms,
+                     uint64_t* h_out_dev, void* stream) {
   CSH_REQUIRE(dom && shift && ma && mb && h_out_dev && (public_inputs || n_public == 0) && witness_dev, "witness_map_dev: NULL argument");
   CSH_REQUIRE(protocol == 0 || protocol == 1, "protocol must be 0 (plain/Shamir) or 1 (Rep3)");
-  if (protocol == 1) CSH_TRY(require_rep3_masks(seed1 && seed2, "groth16_witness_map"));
+  if (protocol == 1) CSH_TRY(require_rep3_masks(ms.have(), "groth16_witness_map"));
   CSH_TRY(ensure_device());
   const Domain* d = reinterpret_cast<const Domain*>(dom);
   const size_t n = domain_size_of(d);
@@ -201,27 +216,30 @@ int csh_groth16_witness_map_dev(csh_domain_t dom, const uint64_t shift[4], int p
   uint64_t* da = reinterpret_cast<uint64_t*>(ar.take<char>(sb));
   uint64_t* db = reinterpret_cast<uint64_t*>(ar.take<char>(sb));
   uint64_t* dpub = reinterpret_cast<uint64_t*>(ar.take<char>(32 * n_public + 32));
-  uint64_t *dmc = nullptr, *dmab = nullptr;
+  const uint64_t *dmc = ms.mask_c_dev, *dmab = ms.mask_ab_dev;
   if (n_public) CSH_HIP(hipMemcpyAsync(dpub, public_inputs, 32 * n_public, hipMemcpyHostToDevice, st));
   CSH_TRY(csh_evaluate_constraints_dev(ma, protocol, party_id, dpub, n_public, witness_dev, n_witness, da, n, st));   // reduction.rs:102-110
   CSH_TRY(csh_evaluate_constraints_dev(mb, protocol, party_id, dpub, n_public, witness_dev, n_witness, db, n, st));   // :118-127
   if (f == CSH_BN254) CSH_TRY(promote_t<Bn254Fr>(protocol, da, num_constraints, dpub, n_public, party_id, st));  // :111-113
   else if (f == CSH_BLS12_377) CSH_TRY(promote_t<Bls377Fr>(protocol, da, num_constraints, dpub, n_public, party_id, st));
   else CSH_TRY(promote_t<Bls381Fr>(protocol, da, num_constraints, dpub, n_public, party_id, st));
-  if (protocol == 1 && seed1 && seed2) {
-    dmc = reinterpret_cast<uint64_t*>(ar.take<char>(eb));
-    dmab = reinterpret_cast<uint64_t*>(ar.take<char>(eb));
-    CSH_TRY(csh_rep3_masks_dev(f, seed1, off1, seed2, off2, dmc, n, st));
-    CSH_TRY(csh_rep3_masks_dev(f, seed1, off1 + n, seed2, off2 + n, dmab, n, st));
+  if (protocol == 1 && !(dmc && dmab) && ms.seed1 && ms.seed2) {
+    uint64_t* gc = reinterpret_cast<uint64_t*>(ar.take<char>(eb));
+    uint64_t* gab = reinterpret_cast<uint64_t*>(ar.take<char>(eb));
+    CSH_TRY(csh_rep3_masks_dev(f, ms.seed1, ms.off1, ms.seed2, ms.off2, gc, n, st));
+    CSH_TRY(csh_rep3_masks_dev(f, ms.seed1, ms.off1 + n, ms.seed2, ms.off2 + n, gab, n, st));
+    dmc = gc, dmab = gab;
   }
   CSH_TRY(csh_groth16_h_dev(dom, shift, protocol, da, db, dmc, dmab, h_out_dev, st));
   if (n_public) CSH_HIP(hipStreamSynchronize(st));  // public_inputs (host) must outlive the async copy
   return CSH_OK;
 }
 
-int csh_groth16_witness_map(csh_domain_t dom, const uint64_t shift[4], int protocol, int party_id, csh_matrix_t ma, csh_matrix_t mb,
-                            size_t num_constraints, const uint64_t* public_inputs, size_t n_public, const uint64_t* witness, size_t n_witness,
-                            const uint8_t seed1[32], uint64_t off1, const uint8_t seed2[32], uint64_t off2, uint64_t* h_out) {
+// Host-facing shell: witness shares (and, for the masks variant, the two mask vectors) up, h down; the pages of h_out are populated
+// from host threads while the device works (HostXfer, common.hpp), so a freshly allocated result vector costs no first-touch in the copy.
+int witness_map_host(csh_domain_t dom, const uint64_t shift[4], int protocol, int party_id, csh_matrix_t ma, csh_matrix_t mb, size_t num_constraints,
+                     const uint64_t* public_inputs, size_t n_public, const uint64_t* witness, size_t n_witness, const uint8_t* seed1, uint64_t off1,
+                     const uint8_t* seed2, uint64_t off2, const uint64_t* mask_c, const uint64_t* mask_ab, uint64_t* h_out) {
   CSH_REQUIRE(dom && ma && mb && h_out && (witness || n_witness == 0), "witness_map: NULL argument");
   CSH_REQUIRE(protocol == 0 || protocol == 1, "protocol must be 0 (plain/Shamir) or 1 (Rep3)");
   {  // a column index beyond public || witness would be an out-of-bounds device read in the row kernel
@@ -232,31 +250,79 @@ int csh_groth16_witness_map(csh_domain_t dom, const uint64_t shift[4], int proto
   }
   const size_t n = domain_size_of(reinterpret_cast<const Domain*>(dom));
   const size_t comp = protocol == 1 ? 2 : 1;
+  const bool host_masks = protocol == 1 && mask_c && mask_ab;
   CSH_TRY(ensure_device());
   hipStream_t st = resolve_stream(nullptr);
-  Arena& ar = arena_for((hipStream_t)((uintptr_t)st ^ 0x2));  // staging arena (the _dev core uses ^0x1 and the stream's own)
-  CSH_TRY(ar.reserve(Arena::padded(32 * comp * n_witness + 32) + Arena::padded(32 * n)));
+  Arena& ar = arena_for((hipStream_t)((uintptr_t)st ^ 0x2));  // staging arena (the core uses ^0x1 and the stream's own)
+  CSH_TRY(ar.reserve(Arena::padded(32 * comp * n_witness + 32) + (host_masks ? 3 : 1) * Arena::padded(32 * n)));
   uint64_t* dwit = reinterpret_cast<uint64_t*>(ar.take<char>(32 * comp * n_witness + 32));
   uint64_t* dh = reinterpret_cast<uint64_t*>(ar.take<char>(32 * n));
-  if (n_witness) CSH_HIP(hipMemcpyAsync(dwit, witness, 32 * comp * n_witness, hipMemcpyHostToDevice, st));
-  CSH_TRY(csh_groth16_witness_map_dev(dom, shift, protocol, party_id, ma, mb, num_constraints, public_inputs, n_public, dwit, n_witness, seed1, off1, seed2, off2,
-                                      dh, st));
-  CSH_HIP(hipMemcpyAsync(h_out, dh, 32 * n, hipMemcpyDeviceToHost, st));
-  CSH_HIP(hipStreamSynchronize(st));
-  return CSH_OK;
+  HostXfer pins;
+  pins.expect_d2h(h_out, 32 * n);
+  MaskSource ms;
+  ms.seed1 = seed1, ms.off1 = off1, ms.seed2 = seed2, ms.off2 = off2;
+  if (n_witness) CSH_TRY(pins.h2d(dwit, witness, 32 * comp * n_witness, st));
+  if (host_masks) {
+    uint64_t* dmc = reinterpret_cast<uint64_t*>(ar.take<char>(32 * n));
+    uint64_t* dmab = reinterpret_cast<uint64_t*>(ar.take<char>(32 * n));
+    CSH_TRY(pins.h2d(dmc, mask_c, 32 * n, st));
+    CSH_TRY(pins.h2d(dmab, mask_ab, 32 * n, st));
+    ms.mask_c_dev = dmc, ms.mask_ab_dev = dmab;
+  }
+  CSH_TRY(witness_map_core(dom, shift, protocol, party_id, ma, mb, num_constraints, public_inputs, n_public, dwit, n_witness, ms, dh, st));
+  CSH_TRY(pins.d2h(h_out, dh, 32 * n, st));
+  return pins.finish(st);
+}
+}  // namespace
+
+extern "C" {
+
+int csh_groth16_witness_map_dev(csh_domain_t dom, const uint64_t shift[4], int protocol, int party_id, csh_matrix_t ma, csh_matrix_t mb,
+                                size_t num_constraints, const uint64_t* public_inputs, size_t n_public, const uint64_t* witness_dev, size_t n_witness,
+                                const uint8_t seed1[32], uint64_t off1, const uint8_t seed2[32], uint64_t off2, uint64_t* h_out_dev, void* stream) {
+  MaskSource ms;
+  ms.seed1 = seed1, ms.off1 = off1, ms.seed2 = seed2, ms.off2 = off2;
+  return witness_map_core(dom, shift, protocol, party_id, ma, mb, num_constraints, public_inputs, n_public, witness_dev, n_witness, ms, h_out_dev, stream);
+}
+
+int csh_groth16_witness_map_masks_dev(csh_domain_t dom, const uint64_t shift[4], int protocol, int party_id, csh_matrix_t ma, csh_matrix_t mb,
+                                      size_t num_constraints, const uint64_t* public_inputs, size_t n_public, const uint64_t* witness_dev, size_t n_witness,
+                                      const uint64_t* mask_c_dev, const uint64_t* mask_ab_dev, uint64_t* h_out_dev, void* stream) {
+  MaskSource ms;
+  ms.mask_c_dev = mask_c_dev, ms.mask_ab_dev = mask_ab_dev;
+  return witness_map_core(dom, shift, protocol, party_id, ma, mb, num_constraints, public_inputs, n_public, witness_dev, n_witness, ms, h_out_dev, stream);
+}
+
+int csh_groth16_witness_map(csh_domain_t dom, const uint64_t shift[4], int protocol, int party_id, csh_matrix_t ma, csh_matrix_t mb,
+                            size_t num_constraints, const uint64_t* public_inputs, size_t n_public, const uint64_t* witness, size_t n_witness,
+                            const uint8_t seed1[32], uint64_t off1, const uint8_t seed2[32], uint64_t off2, uint64_t* h_out) {
+  return witness_map_host(dom, shift, protocol, party_id, ma, mb, num_constraints, public_inputs, n_public, witness, n_witness, seed1, off1, seed2, off2,
+                          nullptr, nullptr, h_out);
+}
+
+// The same with the two mask vectors handed over by the caller (host), in the order the reference draws them: mask_c for "c:
+// local_mul_vec" (reduction.rs:160), mask_ab for the last product (:182). This is the form an UNCHANGED reference can drive: Rep3Rand's
+// generators are private (rngs.rs:83-86), `masking_field_elements_vec` (rngs.rs:137) is public, and for a generic driver
+// T::local_mul_vec on two zero vectors returns exactly the mask. NULL masks for protocol 0.
+int csh_groth16_witness_map_masks(csh_domain_t dom, const uint64_t shift[4], int protocol, int party_id, csh_matrix_t ma, csh_matrix_t mb,
+                                  size_t num_constraints, const uint64_t* public_inputs, size_t n_public, const uint64_t* witness, size_t n_witness,
+                                  const uint64_t* mask_c, const uint64_t* mask_ab, uint64_t* h_out) {
+  if (protocol == 1) CSH_TRY(require_rep3_masks(mask_c && mask_ab, "groth16_witness_map_masks"));
+  return witness_map_host(dom, shift, protocol, party_id, ma, mb, num_constraints, public_inputs, n_public, witness, n_witness, nullptr, 0, nullptr, 0,
+                          mask_c, mask_ab, h_out);
 }
 
 // LibSnarkReduction::witness_map_from_matrices (reduction.rs:241-342) on the device: a, b as above; c through
 // evaluate_constraint_half_share (mpc/rep3.rs:51-74: the `a` component of the full-share row kernel, public terms on
 // party 0 only; plain / Shamir: the row value itself), then csh_groth16_h_libsnark_dev. One mask vector (one local_mul_vec).
-int csh_groth16_witness_map_libsnark(csh_domain_t dom, const uint64_t generator[4], int protocol, int party_id, csh_matrix_t ma, csh_matrix_t mb,
-                                     csh_matrix_t mc, size_t num_constraints, const uint64_t* public_inputs, size_t n_public,
-                                     const uint64_t* witness, size_t n_witness, const uint8_t seed1[32], uint64_t off1, const uint8_t seed2[32],
-                                     uint64_t off2, uint64_t* h_out) {
+static int witness_map_libsnark_host(csh_domain_t dom, const uint64_t generator[4], int protocol, int party_id, csh_matrix_t ma, csh_matrix_t mb,
+                                     csh_matrix_t mc, size_t num_constraints, const uint64_t* public_inputs, size_t n_public, const uint64_t* witness,
+                                     size_t n_witness, const uint8_t* seed1, uint64_t off1, const uint8_t* seed2, uint64_t off2, const uint64_t* mask,
+                                     uint64_t* h_out) {
   CSH_REQUIRE(dom && generator && ma && mb && mc && h_out && (public_inputs || n_public == 0) && (witness || n_witness == 0),
               "witness_map_libsnark: NULL argument");
   CSH_REQUIRE(protocol == 0 || protocol == 1, "protocol must be 0 (plain/Shamir) or 1 (Rep3)");
-  if (protocol == 1) CSH_TRY(require_rep3_masks(seed1 && seed2, "groth16_witness_map_libsnark"));
+  if (protocol == 1) CSH_TRY(require_rep3_masks((seed1 && seed2) || mask, "groth16_witness_map_libsnark"));
   for (csh_matrix_t mm : {ma, mb, mc}) {
     const Matrix* M = reinterpret_cast<const Matrix*>(mm);
     CSH_REQUIRE(M->nnz == 0 || (size_t)M->max_col < n_public + n_witness, "witness_map_libsnark: a matrix column index exceeds n_public + n_witness");
@@ -269,6 +335,8 @@ int csh_groth16_witness_map_libsnark(csh_domain_t dom, const uint64_t generator[
   const size_t sb = 32 * n * comp, eb = 32 * n;
   HostStage h;
   CSH_TRY(h.begin(3 * Arena::padded(sb) + 3 * Arena::padded(eb) + Arena::padded(32 * n_public + 32) + Arena::padded(32 * comp * n_witness + 32)));
+  HostXfer x;
+  x.expect_d2h(h_out, eb);
   uint64_t *da, *db, *dcf, *dc, *dm = nullptr, *dh, *dpub, *dwit;
   CSH_TRY(h.up(da, nullptr, sb));
   CSH_TRY(h.up(db, nullptr, sb));
@@ -285,7 +353,9 @@ int csh_groth16_witness_map_libsnark(csh_domain_t dom, const uint64_t generator[
   if (protocol == 1) {  // half share = component a
     CSH_TRY(h.up(dc, nullptr, eb));
     CSH_HIP(hipMemcpy2DAsync(dc, 32, dcf, 64, 32, n, hipMemcpyDeviceToDevice, h.st));
-    if (seed1 && seed2) {
+    if (mask) {
+      CSH_TRY(h.up(dm, mask, eb));
+    } else if (seed1 && seed2) {
       CSH_TRY(h.up(dm, nullptr, eb));
       CSH_TRY(csh_rep3_masks_dev(f, seed1, off1, seed2, off2, dm, n, h.st));
     }
@@ -293,7 +363,25 @@ int csh_groth16_witness_map_libsnark(csh_domain_t dom, const uint64_t generator[
     dc = dcf;
   }
   CSH_TRY(csh_groth16_h_libsnark_dev(dom, generator, protocol, da, db, dc, dm, dh, h.st));
-  return h.down(h_out, dh, eb);
+  CSH_TRY(x.d2h(h_out, dh, eb, h.st));
+  return x.finish(h.st);
+}
+
+int csh_groth16_witness_map_libsnark(csh_domain_t dom, const uint64_t generator[4], int protocol, int party_id, csh_matrix_t ma, csh_matrix_t mb,
+                                     csh_matrix_t mc, size_t num_constraints, const uint64_t* public_inputs, size_t n_public,
+                                     const uint64_t* witness, size_t n_witness, const uint8_t seed1[32], uint64_t off1, const uint8_t seed2[32],
+                                     uint64_t off2, uint64_t* h_out) {
+  return witness_map_libsnark_host(dom, generator, protocol, party_id, ma, mb, mc, num_constraints, public_inputs, n_public, witness, n_witness, seed1, off1,
+                                   seed2, off2, nullptr, h_out);
+}
+
+// The same with the one mask vector of its local_mul_vec (reduction.rs:289) handed over by the caller: see csh_groth16_witness_map_masks.
+int csh_groth16_witness_map_libsnark_masks(csh_domain_t dom, const uint64_t generator[4], int protocol, int party_id, csh_matrix_t ma, csh_matrix_t mb,
+                                           csh_matrix_t mc, size_t num_constraints, const uint64_t* public_inputs, size_t n_public,
+                                           const uint64_t* witness, size_t n_witness, const uint64_t* mask, uint64_t* h_out) {
+  if (protocol == 1) CSH_TRY(require_rep3_masks(mask != nullptr, "groth16_witness_map_libsnark_masks"));
+  return witness_map_libsnark_host(dom, generator, protocol, party_id, ma, mb, mc, num_constraints, public_inputs, n_public, witness, n_witness, nullptr, 0,
+                                   nullptr, 0, mask, h_out);
 }
 
 }  // extern "C"

@@ -155,17 +155,40 @@ def bench_synthetic(curve: int, log_domain: int, iters: int = 3, with_rep3: bool
     witness_map_from_matrices (h returned to the host), a different code path."""
     ms = (C.c_double * 6)()
     ph = (C.c_double * 3)()
+    tr = (C.c_double * 5)()
     ok = C.c_int(0)
-    rc = glib().cog16_bench_synthetic2(curve, log_domain, iters, ms, C.byref(ok), int(with_rep3), ph)
+    rc = glib().cog16_bench_synthetic3(curve, log_domain, iters, ms, C.byref(ok), int(with_rep3), ph, tr)
     if rc != 0:
         raise CoSnarksHipError(glib().cog16_last_error().decode())
     out = {"log_domain": log_domain, "witness_map_ms": ms[0], "prove_ms": ms[2],
            "prove_phases_ms": {"witness_upload_and_map": ph[0], "msm_groups": ph[1], "finish": ph[2]},
+           # the same prove driven the way rust/co-groth16-hip drives the C ABI behind the UNCHANGED reference: host slices in and out
+           # of every seam call (one csh_groth16_witness_map_masks, h on the host, five concurrent csh_msm calls with host scalars)
+           "trait_path_ms": tr[0], "trait_path_phases_ms": {"witness_map_host_slices": tr[1], "msm_groups_host_scalars": tr[2], "finish": tr[3]},
+           "trait_path_closed_form_check": bool(tr[4]),
            "key_setup_ms": ms[3], "closed_form_check": bool(ok.value)}
     if with_rep3:
         out["rep3_three_parties_prove_ms"] = ms[4]
         out["rep3_proofs_equal_plain"] = bool(ms[5])
     return out
+
+
+class trait_path:
+    """`with trait_path():` -- every prove of the host mirror inside the block runs the way rust/co-groth16-hip drives the C ABI behind
+    the unchanged reference: host slices in and out of every seam call (one csh_groth16_witness_map_masks per witness map, h on the
+    host, five concurrent csh_msm calls with host scalars)."""
+
+    def __init__(self, on: bool = True):
+        self.on = on
+
+    def __enter__(self):
+        self.prev = glib().cog16_get_trait_path()
+        glib().cog16_set_trait_path(int(self.on))
+        return self
+
+    def __exit__(self, *exc):
+        glib().cog16_set_trait_path(self.prev)
+        return False
 
 
 class SynthCircuit:

@@ -83,7 +83,7 @@ int prove_plain_t(const uint8_t* zkey, size_t zlen, const uint8_t* wtns, size_t 
   if (s) ss = fr_from_canonical<P>(s);
   std::vector<Fr> h;
   Proof<P> pr;
-  if (getenv("COG16_HOST_WTNS")) {  // witness values converted on the host, SharedWitness as in the reference's CLI
+  if (getenv("COG16_HOST_WTNS") || trait_path_flag().load()) {  // witness values converted on the host, SharedWitness as in the reference's CLI
     std::vector<Fr> w = parse_wtns<P>(wtns, wlen);
     SharedWitness<P, Fr> sw;
     sw.public_inputs.assign(w.begin(), w.begin() + m.num_instance_variables);
@@ -529,7 +529,7 @@ struct SynthCircuit : SynthBase {
 
 template <class P>
 int bench_synth_t(int log_domain, int iters, double* out_ms, int* check_ok, const uint32_t* g1_words, const uint32_t* g2_words, bool with_rep3,
-                  double* phases_out = nullptr) {
+                  double* phases_out = nullptr, double* trait_out = nullptr) {
   using T = PlainGroth16Driver<P>;
   using Fr = typename P::Fr;
   using Fq = typename P::Fq;
@@ -562,6 +562,30 @@ int bench_synth_t(int log_domain, int iters, double* out_ms, int* check_ok, cons
     phases_out[2] = best_phases.finish_ms;
   }
   *check_ok = sc.closed_form();
+  if (trait_out) {
+    // The same circuit, key and witness through the "trait path" (groth16.hpp): the sequence rust/co-groth16-hip drives behind the unchanged
+    // reference -- one host-slice witness-map call, h on the host, five concurrent host-scalar MSMs. trait_out = {prove ms (best of iters),
+    // witness map ms, five MSMs ms, finish ms (of that prove), closed-form check of the trait-path proof (1 / 0)}.
+    struct Restore {
+      int prev = trait_path_flag().exchange(1);
+      ~Restore() { trait_path_flag().store(prev); }
+    } restore;
+    double best = 1e30;
+    ProveTimes ph;
+    sc.prove(false);  // warm the lanes of the five MSM threads
+    for (int it = 0; it < iters + 2; ++it) {
+      auto a1 = std::chrono::steady_clock::now();
+      sc.prove(false);
+      const double total = ms_since(a1);
+      if (total < best) best = total, ph = sc.phases;
+    }
+    sc.prove(true);
+    trait_out[0] = best;
+    trait_out[1] = ph.witness_ms;
+    trait_out[2] = ph.msm_ms;
+    trait_out[3] = ph.finish_ms;
+    trait_out[4] = sc.closed_form() ? 1.0 : 0.0;
+  }
   const Proof<P>& proof = sc.proof;
   auto eq1 = [](const AffineT<Fq>& x, const AffineT<Fq>& y) { return x.x == y.x && x.y == y.y; };
 
@@ -1166,13 +1190,18 @@ int cog16_prove_shamir(int curve, const uint8_t* zkey, size_t zlen, const uint8_
 // Rep3 proofs == plain proof (1/0)}; best of `iters`.
 int cog16_bench_synthetic2(int curve, int log_domain, int iters, double* out_ms /* 6 entries */, int* check_ok, int with_rep3,
                            double* phases_out /* 3 entries: witness, msm, finish ms of the best prove; nullable */);
+int cog16_bench_synthetic3(int curve, int log_domain, int iters, double* out_ms, int* check_ok, int with_rep3, double* phases_out, double* trait_out);
 int cog16_bench_synthetic(int curve, int log_domain, int iters, double* out_ms /* 6 entries */, int* check_ok, int with_rep3) {
   return cog16_bench_synthetic2(curve, log_domain, iters, out_ms, check_ok, with_rep3, nullptr);
 }
 int cog16_bench_synthetic2(int curve, int log_domain, int iters, double* out_ms, int* check_ok, int with_rep3, double* phases_out) {
+  return cog16_bench_synthetic3(curve, log_domain, iters, out_ms, check_ok, with_rep3, phases_out, nullptr);
+}
+// ... and trait_out (5 entries, nullable): the same prove through the trait path (see bench_synth_t)
+int cog16_bench_synthetic3(int curve, int log_domain, int iters, double* out_ms, int* check_ok, int with_rep3, double* phases_out, double* trait_out) {
   try {
-    if (curve == 0) return bench_synth_t<Bn254>(log_domain, iters, out_ms, check_ok, csh::Bn254G1Gen, csh::Bn254G2Gen, with_rep3 != 0, phases_out);
-    if (curve == 1) return bench_synth_t<Bls12_381>(log_domain, iters, out_ms, check_ok, csh::Bls381G1Gen, csh::Bls381G2Gen, with_rep3 != 0, phases_out);
+    if (curve == 0) return bench_synth_t<Bn254>(log_domain, iters, out_ms, check_ok, csh::Bn254G1Gen, csh::Bn254G2Gen, with_rep3 != 0, phases_out, trait_out);
+    if (curve == 1) return bench_synth_t<Bls12_381>(log_domain, iters, out_ms, check_ok, csh::Bls381G1Gen, csh::Bls381G2Gen, with_rep3 != 0, phases_out, trait_out);
     g_err = "unknown curve";
     return -1;
   } catch (const std::exception& e) {
@@ -1183,6 +1212,14 @@ int cog16_bench_synthetic2(int curve, int log_domain, int iters, double* out_ms,
 
 
 const char* cog16_last_error(void) { return g_err.c_str(); }
+
+// 1: every prove_inner of this process runs the "trait path" (groth16.hpp: the sequence rust/co-groth16-hip drives behind the unchanged
+// reference -- host slices at every seam, one witness-map call, five concurrent host-scalar MSMs); 0: the device-resident prove.
+int cog16_set_trait_path(int on) {
+  trait_path_flag().store(on ? 1 : 0);
+  return 0;
+}
+int cog16_get_trait_path(void) { return trait_path_flag().load(); }
 
 // The synthetic circuit as an object: open (key + matrices + witness resident), prove (one plain prove_inner, phases out),
 // check (closed form), close. bench.py's `--workload groth16_prove` times K cog16_synth_prove calls between barriers.

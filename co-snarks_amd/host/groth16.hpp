@@ -2,6 +2,8 @@
 // create_proof_with_assignment}, groth16_roots_of_unity) and groth16/reduction.rs (R1CSToQAP,
 // CircomReduction) above the C ABI. Same control flow, line-cited; the hot calls go to the device.
 #pragma once
+#include <array>
+#include <atomic>
 #include <memory>
 #include <map>
 #include <tuple>
@@ -47,7 +49,9 @@ inline void groth16_roots_of_unity(size_t pow, Fr& group_gen, Fr& coset_shift) {
 // same circuit needs the same (curve, size, generator) every time.
 struct DomainCache {
   std::mutex mu;
-  std::map<std::tuple<int, int, uint32_t>, csh_domain_t> doms;  // (device, curve, log size): twiddle tables live on one GPU
+  // (device, curve, log size, generator limbs; all-zero = arkworks' default root): twiddle tables live on one GPU, and two
+  // reductions of the same size with different roots (snarkjs' vs arkworks') must not share one
+  std::map<std::tuple<int, int, uint32_t, std::array<uint64_t, 4>>, csh_domain_t> doms;
   static DomainCache& get() {
     static DomainCache c;
     return c;
@@ -56,7 +60,9 @@ struct DomainCache {
     std::lock_guard<std::mutex> g(mu);
     int dev = 0;
     (void)csh_current_device(&dev);
-    auto key = std::make_tuple(dev, (int)curve, log_n);
+    std::array<uint64_t, 4> gen_limbs{};
+    if (gen) memcpy(gen_limbs.data(), gen, 32);
+    auto key = std::make_tuple(dev, (int)curve, log_n, gen_limbs);
     auto it = doms.find(key);
     if (it != doms.end()) {
       *rc_out = CSH_OK;
@@ -67,6 +73,42 @@ struct DomainCache {
     if (*rc_out == CSH_OK) doms[key] = d;
     return d;
   }
+};
+
+// The "trait path": the mirror driven exactly as rust/co-groth16-hip drives the C ABI from the UNCHANGED reference -- every seam call
+// takes and returns host slices (one csh_groth16_witness_map_masks per witness map, h back on the host; to_half_share on the host; five
+// concurrent csh_msm calls with host scalars, rayon_join5 of groth16.rs:227-294). Off by default: the mirror's own prove keeps the
+// witness and h on the device. cog16_set_trait_path(1) / COG16_TRAIT_PATH=1 switch every prove_inner of the process over.
+inline std::atomic<int>& trait_path_flag() {
+  static std::atomic<int> f{getenv("COG16_TRAIT_PATH") ? atoi(getenv("COG16_TRAIT_PATH")) : 0};
+  return f;
+}
+
+// Allocated, never zero-filled host memory for a result the library writes in full: what `Vec::with_capacity(n)` + `set_len(n)` is in
+// the Rust shim. (A value-initialised std::vector of 32 MB costs 4.7 ms of page faults and zero fill on the GPU hosts,
+// profiles/r04_b_prefault_probe.jsonl; the library populates the pages from helper threads while the device works.)
+template <class E>
+struct UninitBuf {
+  E* p = nullptr;
+  size_t n = 0;
+  UninitBuf() = default;
+  explicit UninitBuf(size_t count) : p(static_cast<E*>(malloc(count * sizeof(E) + 1))), n(count) {
+    if (!p) throw Error("out of host memory");
+  }
+  UninitBuf(UninitBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; }
+  UninitBuf& operator=(UninitBuf&& o) noexcept {
+    if (this != &o) {
+      free(p);
+      p = o.p, n = o.n, o.p = nullptr;
+    }
+    return *this;
+  }
+  UninitBuf(const UninitBuf&) = delete;
+  UninitBuf& operator=(const UninitBuf&) = delete;
+  ~UninitBuf() { free(p); }
+  E* data() { return p; }
+  const E* data() const { return p; }
+  size_t size() const { return n; }
 };
 
 // ---- R1CSToQAP: CircomReduction::witness_map_from_matrices (reduction.rs:77-193) ------------------------------
@@ -110,6 +152,41 @@ struct CircomReduction {
     }
     check(rc, "csh_groth16_witness_map_dev");
     check(csh_sync(nullptr), "csh_sync");  // the MSM threads run on other streams
+    return h;
+  }
+
+  // What rust/co-groth16-hip/src/hip_reduction.rs::HipCircomReduction does: host slices in, ONE library call, h on the host. The two
+  // mask vectors are drawn through the driver's public surface in the reference's order (T::masks = masking_field_elements_vec,
+  // rngs.rs:137-156 -- what T::local_mul_vec of two zero vectors returns), so the party's generators advance as in the reference.
+  template <class P, class T>
+  static UninitBuf<typename T::ArithmeticHalfShare> witness_map_trait_path(typename T::State& state, const ConstraintMatrices<P>& matrices,
+                                                                          const std::vector<typename P::Fr>& public_inputs,
+                                                                          const std::vector<typename T::ArithmeticShare>& private_witness) {
+    using Fr = typename P::Fr;
+    const size_t num_constraints = matrices.num_constraints;
+    const size_t num_inputs = matrices.num_instance_variables;
+    size_t domain_size = 1, power = 0;
+    while (domain_size < num_constraints + num_inputs) {
+      domain_size <<= 1;
+      ++power;
+    }
+    if (power > (size_t)Fr::Params::TWO_ADICITY) throw Error("Polynomial Degree too large");  // :87-89
+    if (!matrices.a_dev || !matrices.b_dev) throw Error("trait path: constraint matrices are not on the device");
+    Span span_all("witness map from matrices (trait path: one call, host slices)");
+    Fr group_gen, coset_shift;
+    groth16_roots_of_unity<Fr>(power, group_gen, coset_shift);                                  // :92
+    int rc = CSH_OK;
+    csh_domain_t domain = DomainCache::get().lookup(P::ID, (uint32_t)power, (const uint64_t*)&group_gen, &rc);  // :93
+    if (rc == CSH_ERR_DOMAIN) throw Error("Polynomial Degree too large");
+    check(rc, "csh_domain_create");
+    const std::vector<Fr> mask_c = T::masks(state, domain_size);   // "c: local_mul_vec" (:160)
+    const std::vector<Fr> mask_ab = T::masks(state, domain_size);  // "ab" (:182)
+    UninitBuf<typename T::ArithmeticHalfShare> h(domain_size);
+    rc = csh_groth16_witness_map_masks(domain, (const uint64_t*)&coset_shift, T::PROTOCOL, state.id, matrices.a_dev, matrices.b_dev, num_constraints,
+                                       (const uint64_t*)public_inputs.data(), num_inputs, (const uint64_t*)private_witness.data(), private_witness.size(),
+                                       mask_c.empty() ? nullptr : (const uint64_t*)mask_c.data(), mask_ab.empty() ? nullptr : (const uint64_t*)mask_ab.data(),
+                                       (uint64_t*)h.data());
+    check(rc, "csh_groth16_witness_map_masks");
     return h;
   }
 
@@ -311,6 +388,73 @@ struct CoGroth16 {
     return create_proof_device(net0, net1, state0, state1, pkey, r, s, h_dev, input_assignment, aux_dev);
   }
 
+  // groth16.rs:296-337: everything after the five MSM groups
+  static Proof<P> finish_proof(const Net* net0, const Net* net1, State& state0, State& state1, const ProvingKey<P>& pkey, const Share& r, const Share& s,
+                               const Proj<Fq>& r_g1, const Proj<Fq>& s_g1, const Proj<Fq2>& s_g2, const Proj<Fq>& l_acc, const Proj<Fq>& h_acc) {
+    const Proj<Fq> delta_g1 = into_group(pkey.delta_g1);
+    const auto t_fin0 = std::chrono::steady_clock::now();
+    Span sp_fin("finish - open two points and some adds");
+
+    Half rs = T::local_mul_vec({r}, {s}, state0).back();                                     // :297
+    Proj<Fq> r_s_delta_g1 = T::template scalar_mul_public_point_hs<Fq>(delta_g1, rs);        // :298
+    Proj<Fq> g_a_opened, r_g1_b;
+    {  // mpc_net::join (:305-308): two network legs
+      // a leg that throws aborts both networks first, so that the other leg (and the peers) unwind instead of waiting
+      Joined n1([&] { net_leg(net0, net1, [&] { r_g1_b = scalar_mul_dispatch(s_g1, r, net1, state1); }); });
+      net_leg(net0, net1, [&] { g_a_opened = T::template open_half_point<Fq>(r_g1, net0, state0); });
+      n1.join();
+    }
+    Proj<Fq> g_c = T::template scalar_mul_public_point_hs<Fq>(g_a_opened, T::to_half_share(s));  // :313-314
+    g_c = point_add(g_c, r_g1_b);
+    g_c = point_add(g_c, point_neg(r_s_delta_g1));
+    g_c = point_add(g_c, l_acc);
+    g_c = point_add(g_c, h_acc);
+    Proj<Fq> g_c_opened;
+    Proj<Fq2> g2_b_opened;
+    {  // :325-328
+      Joined n1([&] { net_leg(net0, net1, [&] { g2_b_opened = T::template open_half_point<Fq2>(s_g2, net1, state1); }); });
+      net_leg(net0, net1, [&] { g_c_opened = T::template open_half_point<Fq>(g_c, net0, state0); });
+      n1.join();
+    }
+    Proof<P> proof{into_affine(g_a_opened), into_affine(g_c_opened), into_affine(g2_b_opened)};
+    last_prove_times().finish_ms = ms_since(t_fin0);
+    return proof;
+  }
+
+  // create_proof_with_assignment as the Rust drivers run it behind the reference's rayon_join5 (groth16.rs:227-294): five host threads,
+  // each calling the driver's msm_public_points_hs with HOST scalars (one synchronous csh_msm per query: scalars up on the thread's
+  // own lane stream, so one call's upload, sort and tail overlap another's accumulation); h is consumed from the host buffer the
+  // witness map returned. No shared digit sort, no device-resident operands: nothing the unchanged reference could not do.
+  static Proof<P> create_proof_trait_path(const Net* net0, const Net* net1, State& state0, State& state1, const ProvingKey<P>& pkey, const Share& r,
+                                          const Share& s, const Half* h, size_t h_len, const std::vector<Fr>& input_assignment, const Half* aux,
+                                          size_t n_aux) {
+    const Proj<Fq> delta_g1 = into_group(pkey.delta_g1);
+    const Proj<Fq2> delta_g2 = into_group(pkey.delta_g2);
+    const int id = state0.id;
+    std::vector<Fr> inputs(input_assignment.begin() + 1, input_assignment.end());  // &input_assignment[1..]
+    const size_t pub_len = inputs.size();
+    Proj<Fq> r_g1, s_g1, l_acc, h_acc;
+    Proj<Fq2> s_g2;
+    const auto t_msm0 = std::chrono::steady_clock::now();
+    int cur_dev = 0;
+    (void)csh_current_device(&cur_dev);
+    auto bind = [cur_dev] { check(csh_init(cur_dev), "csh_init"); };
+    {
+      Span sp_msm("5 msm groups, host scalars (trait path)");
+      Joined t1([&] { bind(); r_g1 = finish_coeff<Fq>(id, T::template scalar_mul_public_point_hs<Fq>(delta_g1, T::to_half_share(r)), pkey.a_query, pkey.alpha_g1, inputs,
+                                                     msm_device<Fq>(BasesView{pkey.a_query.dev, 1 + pub_len, pkey.a_query.size() - 1 - pub_len}, aux, n_aux)); });
+      Joined t2([&] { bind(); s_g1 = finish_coeff<Fq>(id, T::template scalar_mul_public_point_hs<Fq>(delta_g1, T::to_half_share(s)), pkey.b_g1_query, pkey.beta_g1, inputs,
+                                                     msm_device<Fq>(BasesView{pkey.b_g1_query.dev, 1 + pub_len, pkey.b_g1_query.size() - 1 - pub_len}, aux, n_aux)); });
+      Joined t3([&] { bind(); s_g2 = finish_coeff<Fq2>(id, T::template scalar_mul_public_point_hs<Fq2>(delta_g2, T::to_half_share(s)), pkey.b_g2_query, pkey.beta_g2, inputs,
+                                                      msm_device<Fq2>(BasesView{pkey.b_g2_query.dev, 1 + pub_len, pkey.b_g2_query.size() - 1 - pub_len}, aux, n_aux)); });
+      Joined t4([&] { bind(); l_acc = msm_device<Fq>(BasesView{pkey.l_query.dev, 0, pkey.l_query.size()}, aux, n_aux); });
+      Joined t5([&] { bind(); h_acc = msm_device<Fq>(BasesView{pkey.h_query.dev, 0, pkey.h_query.size()}, h, h_len); });
+      t1.join(); t2.join(); t3.join(); t4.join(); t5.join();  // the first failure is rethrown; ~Joined reaps the rest
+    }
+    last_prove_times().msm_ms = ms_since(t_msm0);
+    return finish_proof(net0, net1, state0, state1, pkey, r, s, r_g1, s_g1, s_g2, l_acc, h_acc);
+  }
+
   // the same with h and aux_assignment already resident on the device
   static Proof<P> create_proof_device(const Net* net0, const Net* net1, State& state0, State& state1, const ProvingKey<P>& pkey, const Share& r,
                                       const Share& s, const DeviceScalars& h_dev, const std::vector<Fr>& input_assignment,
@@ -456,33 +600,7 @@ struct CoGroth16 {
     }
     delete sp_msm;
     last_prove_times().msm_ms = ms_since(t_msm0);
-    const auto t_fin0 = std::chrono::steady_clock::now();
-    Span sp_fin("finish - open two points and some adds");
-
-    Half rs = T::local_mul_vec({r}, {s}, state0).back();                                     // :297
-    Proj<Fq> r_s_delta_g1 = T::template scalar_mul_public_point_hs<Fq>(delta_g1, rs);        // :298
-    Proj<Fq> g_a_opened, r_g1_b;
-    {  // mpc_net::join (:305-308): two network legs
-      // a leg that throws aborts both networks first, so that the other leg (and the peers) unwind instead of waiting
-      Joined n1([&] { net_leg(net0, net1, [&] { r_g1_b = scalar_mul_dispatch(s_g1, r, net1, state1); }); });
-      net_leg(net0, net1, [&] { g_a_opened = T::template open_half_point<Fq>(r_g1, net0, state0); });
-      n1.join();
-    }
-    Proj<Fq> g_c = T::template scalar_mul_public_point_hs<Fq>(g_a_opened, T::to_half_share(s));  // :313-314
-    g_c = point_add(g_c, r_g1_b);
-    g_c = point_add(g_c, point_neg(r_s_delta_g1));
-    g_c = point_add(g_c, l_acc);
-    g_c = point_add(g_c, h_acc);
-    Proj<Fq> g_c_opened;
-    Proj<Fq2> g2_b_opened;
-    {  // :325-328
-      Joined n1([&] { net_leg(net0, net1, [&] { g2_b_opened = T::template open_half_point<Fq2>(s_g2, net1, state1); }); });
-      net_leg(net0, net1, [&] { g_c_opened = T::template open_half_point<Fq>(g_c, net0, state0); });
-      n1.join();
-    }
-    Proof<P> proof{into_affine(g_a_opened), into_affine(g_c_opened), into_affine(g2_b_opened)};
-    last_prove_times().finish_ms = ms_since(t_fin0);
-    return proof;
+    return finish_proof(net0, net1, state0, state1, pkey, r, s, r_g1, s_g1, s_g2, l_acc, h_acc);
   }
 
   // prove_inner for a witness that is already a device vector of shares (e.g. ingested straight from a wtns image,
@@ -522,6 +640,28 @@ struct CoGroth16 {
       throw Error("amount of private witness variables does not match with provided constraint system! Expected " +
                   std::to_string(matrices.num_witness_variables) + ", but got " + std::to_string(w.witness.size()));
     if constexpr (R::HAS_DEVICE_MAP) {
+      if (trait_path_flag().load(std::memory_order_relaxed) && R::template device_map_available<P>(matrices)) {
+        // the Rust shim's sequence behind the unchanged reference (groth16.rs:125-177): host slices at every seam
+        const auto t_wit0 = std::chrono::steady_clock::now();
+        UninitBuf<Half> h = R::template witness_map_trait_path<P, T>(state0, matrices, w.public_inputs, w.witness);
+        last_prove_times().witness_ms = ms_since(t_wit0);
+        Share r = T::rand(net0, state0), s = T::rand(net0, state0);
+        if (r_in) r = *r_in;
+        if (s_in) s = *s_in;
+        if (h_out) h_out->assign(h.data(), h.data() + h.size());
+        // private_witness.into_iter().map(T::to_half_share).collect() (groth16.rs:159-163): Rust collects in place over the witness
+        // allocation; the mirror's witness is const, so single-component shares are read where they lie and Rep3 shares are
+        // compacted into a buffer that is not zero-filled first
+        if constexpr (std::is_same<Share, Half>::value) {
+          return create_proof_trait_path(net0, net1, state0, state1, pkey, r, s, h.data(), h.size(), w.public_inputs, w.witness.data(), w.witness.size());
+        } else {
+          UninitBuf<Half> half(w.witness.size());
+          parallel_for(half.size(), 1 << 16, [&](size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; ++i) half.data()[i] = T::to_half_share(w.witness[i]);
+          });
+          return create_proof_trait_path(net0, net1, state0, state1, pkey, r, s, h.data(), h.size(), w.public_inputs, half.data(), half.size());
+        }
+      }
       if (R::template device_map_available<P>(matrices)) {
         // device-resident proof: the witness shares cross PCIe once, h never leaves the device unless asked for
         constexpr size_t COMPS = sizeof(Share) / sizeof(Fr);

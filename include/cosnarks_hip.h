@@ -321,6 +321,22 @@ int csh_groth16_witness_map_dev(csh_domain_t dom, const uint64_t shift[4], int p
                                 size_t num_constraints, const uint64_t* public_inputs, size_t n_public, const uint64_t* witness_dev,
                                 size_t n_witness, const uint8_t seed1[32], uint64_t elem_offset1, const uint8_t seed2[32],
                                 uint64_t elem_offset2, uint64_t* h_out_dev, void* stream);
+/* The same map with the two Rep3 mask vectors handed over by the CALLER instead of ChaCha12 seeds: mask_c is the vector the
+ * "c: local_mul_vec" draws (reduction.rs:160), mask_ab the one of the last product (:182), n = domain size elements each; NULL for
+ * protocol 0. This is the form an unchanged reference can drive in ONE call per witness map: `Rep3Rand`'s generators are private
+ * (mpc-core/src/protocols/rep3/rngs.rs:83-86) but `masking_field_elements_vec` (rngs.rs:137-156) is public, and for a generic
+ * driver `T::local_mul_vec` of two zero vectors returns exactly the mask (rep3/arithmetic.rs:132-146) -- so the implementor of
+ * R1CSToQAP (reduction.rs:27-36) draws both vectors through the public surface, in the reference's order, and passes them here.
+ * Host pointers: witness shares (+ masks) up, h down; the pages of h_out are populated from host threads while the device works, so
+ * h_out may be freshly allocated, uninitialised memory (Vec::with_capacity + set_len). The _dev variant takes device pointers for the
+ * witness shares, the masks and h (public_inputs stays a host pointer) and is asynchronous on `stream` like csh_groth16_witness_map_dev. */
+int csh_groth16_witness_map_masks(csh_domain_t dom, const uint64_t shift[4], int protocol, int party_id, csh_matrix_t a, csh_matrix_t b,
+                                  size_t num_constraints, const uint64_t* public_inputs, size_t n_public, const uint64_t* witness,
+                                  size_t n_witness, const uint64_t* mask_c, const uint64_t* mask_ab, uint64_t* h_out);
+int csh_groth16_witness_map_masks_dev(csh_domain_t dom, const uint64_t shift[4], int protocol, int party_id, csh_matrix_t a, csh_matrix_t b,
+                                      size_t num_constraints, const uint64_t* public_inputs, size_t n_public, const uint64_t* witness_dev,
+                                      size_t n_witness, const uint64_t* mask_c_dev, const uint64_t* mask_ab_dev, uint64_t* h_out_dev,
+                                      void* stream);
 /* LibSnarkReduction::witness_map_from_matrices (reduction.rs:241-342) on the device: rows of a, b through
  * evaluate_constraint, rows of c through evaluate_constraint_half_share (mpc/rep3.rs:51-74, mpc/shamir.rs:51-68,
  * mpc/plain.rs:45-60), then csh_groth16_h_libsnark. dom = Domain::new (NULL generator at csh_domain_create),
@@ -329,6 +345,10 @@ int csh_groth16_witness_map_libsnark(csh_domain_t dom, const uint64_t generator[
                                      csh_matrix_t b, csh_matrix_t c, size_t num_constraints, const uint64_t* public_inputs,
                                      size_t n_public, const uint64_t* witness, size_t n_witness, const uint8_t seed1[32],
                                      uint64_t elem_offset1, const uint8_t seed2[32], uint64_t elem_offset2, uint64_t* h_out);
+/* ... and with its ONE mask vector (the local_mul_vec of reduction.rs:289) drawn by the caller, as for csh_groth16_witness_map_masks. */
+int csh_groth16_witness_map_libsnark_masks(csh_domain_t dom, const uint64_t generator[4], int protocol, int party_id, csh_matrix_t a,
+                                           csh_matrix_t b, csh_matrix_t c, size_t num_constraints, const uint64_t* public_inputs,
+                                           size_t n_public, const uint64_t* witness, size_t n_witness, const uint64_t* mask, uint64_t* h_out);
 
 /* ---- measurement hooks (bench.py / profiles) ----------------------------------------------------------
  * HIP-event timing on the stream the kernels are launched on. */

@@ -2,9 +2,10 @@
 //! later proof on that GPU (`csh_bases_upload` once per key and device; groth16.rs:219-290 passes sub-slices of the same five
 //! queries on every call).
 //!
-//! Ownership: the cache is keyed by (device, host address range) and every entry carries a fingerprint of the points it was
-//! uploaded from, so a proving key that is dropped and another one allocated at the same address is detected and re-uploaded
-//! instead of silently proving against stale bases. [`KeyGuard`] ties the entries of one key to a scope: uploads made while a
+//! Ownership: the cache is keyed by (device, host address range) and every entry carries checkpoint hashes of up to 65 evenly
+//! spaced points it was uploaded from. A lookup re-hashes ONLY the checkpoints that lie inside the slice the caller passed (memory
+//! the caller holds -- never the rest of the entry's old range, which may have been freed), so a proving key that is dropped and
+//! another one allocated at the same address is detected and re-uploaded instead of silently proving against stale bases. [`KeyGuard`] ties the entries of one key to a scope: uploads made while a
 //! guard for the key's address range is alive are evicted when it drops.
 use crate::error::hip_ok;
 use crate::layout::{curve_id, group_id};
@@ -20,7 +21,7 @@ pub struct DeviceBases {
     host_base: usize, // address of the first uploaded point: sub-slices of the same query map to an offset
     len: usize,
     stride: usize,
-    fingerprint: u64, // FNV-1a over the first, middle and last point as uploaded
+    checkpoints: Vec<(usize, u64)>, // (point index, FNV-1a of that point as uploaded), ascending
 }
 unsafe impl Send for DeviceBases {}
 unsafe impl Sync for DeviceBases {}
@@ -42,19 +43,44 @@ impl DeviceBases {
     }
 }
 
-fn fingerprint_at(base: usize, len: usize, stride: usize) -> u64 {
-    let mut h = 0xcbf29ce484222325u64;
+fn point_hash(base: usize, idx: usize, stride: usize) -> u64 {
+    // SAFETY: the caller guarantees that point `idx` of the slice starting at `base` is inside a slice it currently holds
+    let bytes = unsafe { core::slice::from_raw_parts((base + idx * stride) as *const u8, stride) };
+    bytes.iter().fold(0xcbf29ce484222325u64, |h, &b| (h ^ b as u64).wrapping_mul(0x100000001b3))
+}
+
+/// Checkpoints of a freshly uploaded slice: every (len / 64)-th point and the last one.
+fn checkpoints_of(base: usize, len: usize, stride: usize) -> Vec<(usize, u64)> {
     if len == 0 {
-        return h;
+        return Vec::new();
     }
-    for idx in [0, len / 2, len - 1] {
-        // SAFETY: [base, base + len * stride) is a live slice of points of `stride` bytes each (the caller holds it)
-        let bytes = unsafe { core::slice::from_raw_parts((base + idx * stride) as *const u8, stride) };
-        for &b in bytes {
-            h = (h ^ b as u64).wrapping_mul(0x100000001b3);
+    let step = (len / 64).max(1);
+    let mut idx: Vec<usize> = (0..len).step_by(step).collect();
+    if *idx.last().unwrap() != len - 1 {
+        idx.push(len - 1);
+    }
+    idx.into_iter().map(|i| (i, point_hash(base, i, stride))).collect()
+}
+
+enum Check {
+    Same,      // every checkpoint inside the caller's slice still hashes to what was uploaded
+    Different, // at least one differs: the entry is stale
+    Unknown,   // no checkpoint falls inside the caller's slice (a sub-slice shorter than the checkpoint spacing)
+}
+
+impl DeviceBases {
+    /// Compare the entry with `points` (a sub-slice of its address range starting at point `off`), reading only `points`.
+    fn check<T>(&self, points: &[T], off: usize) -> Check {
+        let base = points.as_ptr() as usize;
+        let mut seen = false;
+        for &(i, h) in self.checkpoints.iter().filter(|(i, _)| *i >= off && *i < off + points.len()) {
+            seen = true;
+            if point_hash(base, i - off, self.stride) != h {
+                return Check::Different;
+            }
         }
+        if seen || (points.is_empty() && self.len == 0) { Check::Same } else { Check::Unknown }
     }
-    h
 }
 
 static CACHE: Mutex<Vec<Arc<DeviceBases>>> = Mutex::new(Vec::new());
@@ -79,20 +105,27 @@ pub fn get_or_upload_sized<P: Pairing, C: SWCurveConfig>(points: &[Affine<C>], k
     let stride = core::mem::size_of::<Affine<C>>();
     let mut cache = CACHE.lock();
     let mut stale = None;
+    let mut cacheable = true;
     for (i, b) in cache.iter().enumerate() {
         if b.device != dev {
             continue; // handles are per device: a thread bound to GPU 1 never gets GPU 0's copy
         }
         if let Some(off) = b.offset_of(points) {
-            if b.stride == stride && b.fingerprint == fingerprint_at(b.host_base, b.len, b.stride) {
-                return (b.clone(), off);
+            match if b.stride == stride { b.check(points, off) } else { Check::Different } {
+                Check::Same => return (b.clone(), off),
+                Check::Different => stale = Some(i), // same addresses, other contents: the key this entry came from is gone
+                Check::Unknown => cacheable = false,  // too short to verify against the entry: upload it on its own, uncached
             }
-            stale = Some(i); // same addresses, other contents: the key this entry came from is gone
             break;
         }
     }
     if let Some(i) = stale {
         cache.swap_remove(i);
+    }
+    // an entry of another stride or one that only partly overlaps the caller's range is stale by construction: evict it unread
+    let (lo, hi) = (points.as_ptr() as usize, points.as_ptr() as usize + points.len() * stride);
+    if cacheable {
+        cache.retain(|b| !(b.device == dev && b.overlaps(lo, hi)));
     }
     let mut handle: sys::CshBases = core::ptr::null_mut();
     hip_ok(unsafe {
@@ -102,7 +135,7 @@ pub fn get_or_upload_sized<P: Pairing, C: SWCurveConfig>(points: &[Affine<C>], k
     // function). Tables are an optimisation: when they do not fit the device the MSM runs on the plain points.
     let (mut c, mut rows) = (0i32, 0i32);
     hip_ok(unsafe { sys::csh_bases_table_policy(key_points, &mut c, &mut rows) });
-    if rows >= 2 {
+    if rows >= 2 && cacheable {
         let rc = unsafe { sys::csh_bases_precompute_grouped(handle, c, rows) };
         if rc == sys::CSH_ERR_OOM {
             hip_ok(unsafe { sys::csh_bases_drop_tables(handle) });
@@ -111,8 +144,10 @@ pub fn get_or_upload_sized<P: Pairing, C: SWCurveConfig>(points: &[Affine<C>], k
         }
     }
     let base = points.as_ptr() as usize;
-    let b = Arc::new(DeviceBases { handle, device: dev, host_base: base, len: points.len(), stride, fingerprint: fingerprint_at(base, points.len(), stride) });
-    cache.push(b.clone());
+    let b = Arc::new(DeviceBases { handle, device: dev, host_base: base, len: points.len(), stride, checkpoints: checkpoints_of(base, points.len(), stride) });
+    if cacheable {
+        cache.push(b.clone());
+    }
     (b, 0)
 }
 

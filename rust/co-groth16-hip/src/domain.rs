@@ -14,7 +14,30 @@ impl Drop for HipDomain {
         unsafe { sys::csh_domain_free(self.raw) };
     }
 }
+/// Domains are reused across proofs: building one is a hipMalloc + a kernel, and a proof of the same circuit asks for the same
+/// (device, curve, size, generator) every time. Entries are shared (`Arc`), freed by `clear_cache`.
+static DOMAINS: parking_lot::Mutex<Vec<((i32, i32, u32, [u64; 4]), std::sync::Arc<HipDomain>)>> = parking_lot::Mutex::new(Vec::new());
+
+pub fn clear_cache() {
+    DOMAINS.lock().clear();
+}
+
 impl HipDomain {
+    /// `new` through the process-wide cache, keyed by (device, curve, log size, generator limbs; all-zero = arkworks' default root).
+    pub fn cached<F>(curve: i32, log_n: u32, group_gen: Option<&F>) -> eyre::Result<std::sync::Arc<Self>> {
+        assert!(core::mem::size_of::<F>() == 32, "scalar fields are four 64-bit limbs");
+        let mut dev = 0i32;
+        check(unsafe { sys::csh_current_device(&mut dev) })?;
+        let gen_limbs: [u64; 4] = group_gen.map_or([0; 4], |g| unsafe { core::ptr::read(limbs(g).cast()) });
+        let key = (dev, curve, log_n, gen_limbs);
+        let mut cache = DOMAINS.lock();
+        if let Some((_, d)) = cache.iter().find(|(k, _)| *k == key) {
+            return Ok(d.clone());
+        }
+        let d = std::sync::Arc::new(Self::new(curve, log_n, group_gen)?);
+        cache.push((key, d.clone()));
+        Ok(d)
+    }
     /// `Domain::with_group_gen` (snarkjs roots, reduction.rs:93) when `group_gen` is given, `Domain::new` otherwise (:249).
     pub fn new<F>(curve: i32, log_n: u32, group_gen: Option<&F>) -> eyre::Result<Self> {
         let mut raw: sys::CshDomain = core::ptr::null_mut();

@@ -15,6 +15,26 @@ use mpc_core::protocols::shamir::{ShamirPrimeFieldShare, ShamirState};
 use mpc_core::MpcState;
 use mpc_net::Network;
 
+thread_local! {
+    /// Set while a witness map draws its mask vectors through `T::local_mul_vec(zeros, zeros, state)` (hip_reduction.rs): the
+    /// product of two zero vectors IS the mask, so the Hip Rep3 driver returns `masking_field_elements_vec` directly instead of
+    /// shipping 160 bytes per entry of zeros and masks through the GPU. Any other driver ignores the flag and multiplies.
+    static MASK_ONLY: core::cell::Cell<bool> = const { core::cell::Cell::new(false) };
+}
+
+/// Run `f` (one `T::local_mul_vec` call on the CALLING thread) with the mask-only hint set.
+pub fn mask_only<R>(f: impl FnOnce() -> R) -> R {
+    struct Reset;
+    impl Drop for Reset {
+        fn drop(&mut self) {
+            MASK_ONLY.with(|m| m.set(false));
+        }
+    }
+    MASK_ONLY.with(|m| m.set(true));
+    let _reset = Reset; // also on unwind
+    f()
+}
+
 /// `msm_unchecked(points, scalars)` (external taceo-ark-algebra; call sites mpc/plain.rs:66-74, mpc/rep3.rs:124-132,
 /// mpc/shamir.rs:111-119): "unchecked" = the shorter of the two lengths (honk_curve.rs:33-34).
 fn hip_msm<P: Pairing, C>(points: &[Affine<C>], scalars: &[P::ScalarField]) -> Projective<C>
@@ -128,6 +148,9 @@ impl<P: Pairing> CircomGroth16Prover<P> for HipRep3Groth16Driver {
     fn local_mul_vec(a: Vec<Self::ArithmeticShare>, b: Vec<Self::ArithmeticShare>, state: &mut Rep3State) -> Vec<P::ScalarField> {
         assert_eq!(a.len(), b.len());
         let mask = state.rngs.rand.masking_field_elements_vec::<P::ScalarField>(a.len());
+        if MASK_ONLY.with(|m| m.get()) {
+            return mask; // the caller passed zero vectors to learn the mask (hip_reduction.rs::draw_mask): 0 * 0 + mask
+        }
         let mut out = mask; // in place over the mask vector
         hip_ok(unsafe {
             sys::csh_rep3_local_mul_vec(curve_id::<P>(), limbs_of(&a), limbs_of(&b), limbs_of(&out), limbs_mut(&mut out), a.len())

@@ -2,22 +2,31 @@
 //! its witness maps (reduction.rs:141-174, 255-328), not behind the driver trait, so the NTT offload is a new implementor of
 //! this trait; it is a type parameter of every `prove`, hence a one-identifier change at the call site.
 //!
-//! The implementor is generic over `T: CircomGroth16Prover<P>` exactly like the reference: constraint rows are evaluated with
-//! `T::evaluate_constraint` (host, rayon -- or on the device through `witness_map_device` below when the matrices are
-//! resident), the transforms run through the C ABI on the share vectors as they lie in memory (`ncomp` = 1 or 2 field elements
-//! per entry), and `T::local_mul_vec` / `T::distribute_powers_and_mul_by_const` are the driver's (GPU-backed for the Hip
-//! drivers, the reference's otherwise -- both give the same field elements).
+//! ONE call into the library per witness map: the constraint matrices are resident on the device (`matrices.rs`, uploaded once
+//! per circuit and GPU), the witness shares go up as they lie in memory, the whole of reduction.rs:99-192 (rows, six transforms,
+//! two local multiplications, three coset shifts, the subtraction) runs on one stream, and `h` comes back into a vector that is
+//! allocated but never zero-filled (the library populates its pages while the device works).
+//!
+//! Generic over `T: CircomGroth16Prover<P>` exactly like the reference, through the PUBLIC surface only:
+//! * the protocol is read off the share type (one field element per entry = plain / Shamir, two = Rep3);
+//! * the party index is read off `T::promote_to_trivial_shares(id, [1])` (rep3/arithmetic.rs `promote_to_trivial_share`:
+//!   party 0 -> (1, 0), party 1 -> (0, 1), party 2 -> (0, 0)); `PartyID` itself carries no integer conversion in its bounds
+//!   (mpc-core/src/lib.rs:21-31);
+//! * the two Rep3 mask vectors are drawn by `T::local_mul_vec` on two zero vectors, which returns exactly the mask
+//!   (rep3/arithmetic.rs:132-146), in the reference's order (reduction.rs:160 then :182): the party's generators advance as
+//!   they would have, and the three parties' masks still cancel. The Hip Rep3 driver short-circuits such a call to
+//!   `masking_field_elements_vec` (rngs.rs:137-156) without touching the GPU (`drivers::mask_only`).
 use crate::domain::HipDomain;
 use crate::error::check;
-use crate::layout::{curve_id, limbs, limbs_mut, limbs_of};
+use crate::layout::{curve_id, limbs, limbs_of, ncomp};
+use crate::{drivers, matrices};
 use ark_ec::pairing::Pairing;
-use ark_ff::{FftField, Field, LegendreSymbol, One, PrimeField};
-use ark_relations::utils::matrix::Matrix;
+use ark_ff::{FftField, Field, LegendreSymbol, One, PrimeField, Zero};
 use co_groth16::mpc::CircomGroth16Prover;
 use co_groth16::R1CSToQAP;
+use core::mem::size_of;
 use cosnarks_hip_sys as sys;
 use mpc_core::MpcState;
-use rayon::prelude::*;
 use taceo_groth16::ConstraintMatrices;
 
 /// snarkjs' roots of unity, restated: `roots_of_unity` / `groth16_roots_of_unity` are PRIVATE functions of the reference
@@ -47,18 +56,41 @@ fn groth16_roots_of_unity<F: PrimeField + FftField>(pow: usize) -> (F, F) {
     (group_gen, coset_shift)
 }
 
-fn eval_rows<P: Pairing, T: CircomGroth16Prover<P>>(
-    id: <T::State as MpcState>::PartyID,
-    rows: &Matrix<P::ScalarField>,
-    public_inputs: &[P::ScalarField],
-    private_witness: &[T::ArithmeticShare],
-    domain_size: usize,
-) -> Vec<T::ArithmeticShare> {
-    // reduction.rs:196-210: one sparse dot product per constraint, zero-padded to the domain
-    let mut out: Vec<T::ArithmeticShare> =
-        rows.par_iter().with_min_len(256).map(|r| T::evaluate_constraint(id, r, public_inputs, private_witness)).collect();
-    out.resize(domain_size, T::ArithmeticShare::default());
-    out
+/// What the library needs to know about the driver, learnt through its public methods.
+struct Protocol {
+    id: i32,    // 0 = one field element per share (plain, Shamir), 1 = Rep3 {a, b}
+    party: i32, // Rep3: where public terms go (0 -> a, 1 -> b, 2 -> nowhere); 0 otherwise
+}
+
+fn protocol_of<P: Pairing, T: CircomGroth16Prover<P>>(id: <T::State as MpcState>::PartyID) -> eyre::Result<Protocol> {
+    assert_eq!(size_of::<T::ArithmeticHalfShare>(), size_of::<P::ScalarField>(), "half shares are single field elements (mpc.rs:36-49)");
+    match ncomp::<T::ArithmeticShare>() {
+        1 => Ok(Protocol { id: 0, party: 0 }),
+        2 => {
+            let one = T::promote_to_trivial_shares(id, &[P::ScalarField::one()]);
+            // SAFETY: a two-component share is {a, b}: two consecutive field elements (layout.rs asserts it for Rep3PrimeFieldShare)
+            let ab: [P::ScalarField; 2] = unsafe { core::ptr::read((one.as_ptr()).cast()) };
+            let party = match (ab[0].is_one(), ab[1].is_one(), ab[0].is_zero(), ab[1].is_zero()) {
+                (true, _, _, true) => 0,
+                (_, true, true, _) => 1,
+                (_, _, true, true) => 2,
+                _ => eyre::bail!("unrecognised two-component share type: promote_to_trivial_shares(1) is neither (1,0), (0,1) nor (0,0)"),
+            };
+            Ok(Protocol { id: 1, party })
+        }
+        k => eyre::bail!("unsupported share type: {k} field elements per entry"),
+    }
+}
+
+/// The mask vector the next `T::local_mul_vec` of `n` entries would add: the product of two zero vectors.
+fn draw_mask<P: Pairing, T: CircomGroth16Prover<P>>(state: &mut T::State, n: usize) -> Vec<T::ArithmeticHalfShare> {
+    let zeros = || vec![T::ArithmeticShare::default(); n];
+    drivers::mask_only(|| T::local_mul_vec(zeros(), zeros(), state))
+}
+
+/// `n` half shares of allocated, uninitialised memory for the library to fill (no zero fill: 4.7 ms per 32 MB on the GPU hosts).
+fn uninit_half_shares<H>(n: usize) -> Vec<H> {
+    Vec::with_capacity(n)
 }
 
 /// snarkjs' witness map (the odd coset of a domain twice as large): drop-in for `CircomReduction` (reduction.rs:62-193).
@@ -80,32 +112,25 @@ impl R1CSToQAP for HipCircomReduction {
         }
         // snarkjs' root for the domain and the root of the domain twice as large as the coset shift (:90-94)
         let (group_gen, coset_shift) = groth16_roots_of_unity::<P::ScalarField>(power);
-        let dom = HipDomain::new(curve_id::<P>(), power as u32, Some(&group_gen))?; // Domain::with_group_gen (:93)
-        let id = state.id();
-
-        // rows of A and B; the public inputs take the slots after the constraints (:99-113)
-        let mut a = eval_rows::<P, T>(id, &matrices.a, public_inputs, private_witness, domain_size);
-        let mut b = eval_rows::<P, T>(id, &matrices.b, public_inputs, private_witness, domain_size);
-        let promoted = T::promote_to_trivial_shares(id, public_inputs);
-        a[num_constraints..num_constraints + num_inputs].clone_from_slice(&promoted[..num_inputs]);
-
-        // c = a * b in the evaluation domain, before a and b leave it (:135-160)
-        let mut c = T::local_mul_vec(a.clone(), b.clone(), state);
-        // a, b, c onto the odd coset: ifft -> multiply by shift^i (bit-reversed table) -> fft (:141-174)
-        let table = dom.coset_table(&coset_shift);
-        dom.ifft_in_to_out(&mut a);
-        dom.ifft_in_to_out(&mut b);
-        dom.ifft_in_to_out(&mut c);
-        T::distribute_powers_and_mul_by_const(&mut a, &table);
-        T::distribute_powers_and_mul_by_const(&mut b, &table);
-        check(unsafe { sys::csh_vec_mul_table(curve_id::<P>(), limbs_mut(&mut c), limbs_of(&table), domain_size, 1) })?; // c *= table (:166-171)
-        dom.fft_out_to_in(&mut a);
-        dom.fft_out_to_in(&mut b);
-        dom.fft_out_to_in(&mut c);
-        // h = a * b - c on the coset (:176-192)
-        let mut ab = T::local_mul_vec(a, b, state);
-        check(unsafe { sys::csh_vec_sub(curve_id::<P>(), limbs_of(&ab), limbs_of(&c), limbs_mut(&mut ab), domain_size, 1) })?;
-        Ok(ab)
+        let dom = HipDomain::cached(curve_id::<P>(), power as u32, Some(&group_gen))?; // Domain::with_group_gen (:93)
+        let proto = protocol_of::<P, T>(state.id())?;
+        let dm = matrices::get_or_upload::<P>(matrices, false)?;
+        // the two mask vectors in the reference's order: "c: local_mul_vec" (:160), then "ab" (:182)
+        let (mask_c, mask_ab) = if proto.id == 1 {
+            (draw_mask::<P, T>(state, domain_size), draw_mask::<P, T>(state, domain_size))
+        } else {
+            (Vec::new(), Vec::new())
+        };
+        let mask_ptr = |m: &Vec<T::ArithmeticHalfShare>| if m.is_empty() { core::ptr::null() } else { limbs_of(m) };
+        let mut h = uninit_half_shares::<T::ArithmeticHalfShare>(domain_size);
+        check(unsafe {
+            sys::csh_groth16_witness_map_masks(dom.raw, limbs(&coset_shift), proto.id, proto.party, dm.a.handle, dm.b.handle, num_constraints,
+                                               limbs_of(public_inputs), num_inputs.min(public_inputs.len()), limbs_of(private_witness),
+                                               private_witness.len(), mask_ptr(&mask_c), mask_ptr(&mask_ab), h.as_mut_ptr().cast())
+        })?;
+        // SAFETY: the call returned CSH_OK, so all `domain_size` elements were written (canonical Montgomery limbs = valid field elements)
+        unsafe { h.set_len(domain_size) };
+        Ok(h)
     }
 }
 
@@ -126,73 +151,21 @@ impl R1CSToQAP for HipLibSnarkReduction {
         if log_n > <P::ScalarField as FftField>::TWO_ADICITY {
             eyre::bail!("Polynomial Degree too large");
         }
-        let dom = HipDomain::new::<P::ScalarField>(curve_id::<P>(), log_n, None)?;
-        let id = state.id();
-        let mut a = eval_rows::<P, T>(id, &matrices.a, public_inputs, private_witness, domain_size);
-        let mut b = eval_rows::<P, T>(id, &matrices.b, public_inputs, private_witness, domain_size);
-        let promoted = T::promote_to_trivial_shares(id, public_inputs);
-        a[num_constraints..num_constraints + num_inputs].clone_from_slice(&promoted[..num_inputs]);
-        let mut c: Vec<T::ArithmeticHalfShare> = matrices
-            .c
-            .par_iter()
-            .with_min_len(256)
-            .map(|r| T::evaluate_constraint_half_share(id, r, public_inputs, private_witness))
-            .collect();
-        c.resize(domain_size, T::ArithmeticHalfShare::default());
-        // coefficients, then evaluations on the coset g * <w> (g = F::GENERATOR), (:255-300)
-        let g = <P::ScalarField as FftField>::GENERATOR;
-        let table = dom.coset_table(&g);
-        for v in [&mut a, &mut b] {
-            dom.ifft_in_to_out(v);
-            T::distribute_powers_and_mul_by_const(v, &table);
-            dom.fft_out_to_in(v);
-        }
-        dom.ifft_in_to_out(&mut c);
-        check(unsafe { sys::csh_vec_mul_table(curve_id::<P>(), limbs_mut(&mut c), limbs_of(&table), domain_size, 1) })?;
-        dom.fft_out_to_in(&mut c);
-        let mut ab = T::local_mul_vec(a, b, state);
-        check(unsafe { sys::csh_vec_sub(curve_id::<P>(), limbs_of(&ab), limbs_of(&c), limbs_mut(&mut ab), domain_size, 1) })?;
-        // divide by Z(g x) = g^n - 1 (constant on the coset), interpolate, undo the shift (:312-340): the inverse powers are applied
-        // in bit-reversed order straight after ifft_in_to_out, then the permutation -- the same values as permuting first
-        let z_inv = (g.pow([domain_size as u64]) - P::ScalarField::one()).inverse().expect("g^n != 1");
-        let g_inv = g.inverse().expect("generator is non-zero");
-        let mut back = dom.coset_table(&g_inv);
-        back.par_iter_mut().for_each(|t| *t *= z_inv);
-        dom.ifft_in_to_out(&mut ab);
-        check(unsafe { sys::csh_vec_mul_table(curve_id::<P>(), limbs_mut(&mut ab), limbs_of(&back), domain_size, 1) })?;
-        check(unsafe { sys::csh_bit_reverse(curve_id::<P>(), limbs_mut(&mut ab), log_n, 1) })?; // natural-order coefficients
-        Ok(ab)
+        let dom = HipDomain::cached::<P::ScalarField>(curve_id::<P>(), log_n, None)?;
+        let proto = protocol_of::<P, T>(state.id())?;
+        let dm = matrices::get_or_upload::<P>(matrices, true)?;
+        let g = <P::ScalarField as FftField>::GENERATOR; // the coset g * <w> (:255)
+        // one local_mul_vec (:289), one mask vector
+        let mask = if proto.id == 1 { draw_mask::<P, T>(state, domain_size) } else { Vec::new() };
+        let mut h = uninit_half_shares::<T::ArithmeticHalfShare>(domain_size);
+        check(unsafe {
+            sys::csh_groth16_witness_map_libsnark_masks(dom.raw, limbs(&g), proto.id, proto.party, dm.a.handle, dm.b.handle,
+                                                        dm.c.as_ref().expect("uploaded with the C side").handle, num_constraints,
+                                                        limbs_of(public_inputs), num_inputs.min(public_inputs.len()), limbs_of(private_witness),
+                                                        private_witness.len(), if mask.is_empty() { core::ptr::null() } else { limbs_of(&mask) },
+                                                        h.as_mut_ptr().cast())
+        })?;
+        unsafe { h.set_len(domain_size) }; // SAFETY: as above
+        Ok(h)
     }
-}
-
-/// Device-resident variant for callers that keep the constraint matrices on the GPU (`csh_matrix_upload` once per circuit):
-/// the whole of reduction.rs:77-193 -- rows, six transforms, two local multiplications, three coset shifts -- in ONE call with
-/// no PCIe traffic besides the witness shares in and h out. `protocol` 0 = plain / Shamir, 1 = Rep3; `mask_seeds` = the party's
-/// two ChaCha12 keys and the number of 32-byte chunks already drawn from each (needs an accessor on `Rep3Rand`, whose
-/// `rng1` / `rng2` fields are private upstream: rngs.rs:83-86; without it use the trait path above).
-#[allow(clippy::too_many_arguments)]
-pub fn witness_map_device<F: PrimeField>(
-    curve: i32,
-    dom: &HipDomain,
-    coset_shift: &F,
-    protocol: i32,
-    party_id: i32,
-    a: sys::CshMatrix,
-    b: sys::CshMatrix,
-    num_constraints: usize,
-    public_inputs: &[F],
-    witness_shares: *const u64,
-    n_witness: usize,
-    mask_seeds: Option<(&[u8; 32], u64, &[u8; 32], u64)>,
-    h_out: &mut [F],
-) -> eyre::Result<()> {
-    let _ = curve;
-    let (s1, o1, s2, o2) = match mask_seeds {
-        Some((s1, o1, s2, o2)) => (s1.as_ptr(), o1, s2.as_ptr(), o2),
-        None => (core::ptr::null(), 0, core::ptr::null(), 0),
-    };
-    check(unsafe {
-        sys::csh_groth16_witness_map(dom.raw, limbs(coset_shift), protocol, party_id, a, b, num_constraints, limbs_of(public_inputs),
-                                     public_inputs.len(), witness_shares, n_witness, s1, o1, s2, o2, limbs_mut(h_out))
-    })
 }

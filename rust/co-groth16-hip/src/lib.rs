@@ -12,6 +12,7 @@ pub mod drivers;
 pub mod error;
 pub mod hip_reduction;
 pub mod layout;
+pub mod matrices;
 pub mod split;
 
 pub use drivers::{HipPlainGroth16Driver, HipRep3Groth16Driver, HipShamirGroth16Driver};

@@ -1,0 +1,174 @@
+"""GPU parity of the zero-upstream-edit path: csh_groth16_witness_map_masks -- the fused witness map with the two Rep3
+mask vectors handed over by the caller, the form rust/co-groth16-hip's HipCircomReduction calls ONCE per witness map -- and the host
+mirror's "trait path" (host slices at every seam, five concurrent host-scalar MSMs), against the pinned oracle and the golden h / A / B / C
+of the reference's own circuits. Bit-exact."""
+import ctypes as C
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+from oracle import groth16 as og
+from oracle import mpc, ntt
+from oracle import zkey as oz
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CIRCUITS = [("bn254", "multiplier2"), ("bn254", "poseidon"), ("bls12_381", "multiplier2"), ("bls12_381", "poseidon")]
+R, S = 123456789, 987654321
+
+
+def _load(curve, circ):
+    d = os.path.join(GOLD, "Groth16", curve, circ)
+    rd = lambda f, m="rb": open(os.path.join(d, f), m).read()
+    return rd("circuit.zkey"), rd("witness.wtns"), oz.parse_vk(rd("verification_key.json", "r")), oz.parse_public(rd("public.json", "r"))
+
+
+def _gold(curve, circ):
+    return json.load(open(os.path.join(GOLD, "groth16_golden.json")))[f"{curve}/{circ}"]
+
+
+def _setup(gpu, curve, circ):
+    zk, wt, _vk, _pub = _load(curve, circ)
+    zko = oz.parse_zkey(zk)
+    F = zko.Fr
+    cid = H.CURVE_IDS[curve]
+    w = [x % F.p for x in oz.parse_wtns(wt)]
+    npub = zko.num_inputs
+    A, B = zko.matrices()
+    mk = lambda M: gpu.bindings.Matrix(cid, [[(H.pack(F, [c]), idx) for c, idx in row] for row in M])
+    power = zko.domain_size.bit_length() - 1
+    gen, shift = ntt.groth16_roots_of_unity(F, power)
+    dom = gpu.Domain(cid, power, H.pack(F, [gen]))
+    return zko, F, cid, w[:npub], w[npub:], mk(A), mk(B), dom, H.pack(F, [shift])
+
+
+@pytest.mark.parametrize("curve,circ", CIRCUITS)
+def test_witness_map_masks_plain_equals_golden_h(gpu, curve, circ):
+    zko, F, cid, pub, wit, MA, MB, dom, shift = _setup(gpu, curve, circ)
+    got = gpu.bindings.groth16_witness_map_masks(dom, shift, 0, 0, MA, MB, zko.num_constraints, H.pack(F, pub), H.pack(F, wit))
+    assert [str(x) for x in H.unpack(F, got)] == _gold(curve, circ)["h"]
+    # masks are ignored by protocol 0 (plain / Shamir shares are multiplied without re-randomisation, shamir/arithmetic.rs:73-79)
+    junk = H.pack(F, H.rand_elems(F, dom.n, H.rng(1)))
+    again = gpu.bindings.groth16_witness_map_masks(dom, shift, 0, 0, MA, MB, zko.num_constraints, H.pack(F, pub), H.pack(F, wit), junk, junk, fresh_output=False)
+    assert np.array_equal(again, got)
+
+
+@pytest.mark.parametrize("curve,circ", [("bn254", "multiplier2"), ("bn254", "poseidon"), ("bls12_381", "poseidon")])
+def test_witness_map_masks_rep3_parties_match_oracle_and_cancel(gpu, curve, circ):
+    """Every party's h equals the oracle's reduction.rs:77-193 run with the SAME two mask vectors in the reference's order (:160 then :182);
+    with correlated masks (m_p = t_p - t_{p-1}, rngs.rs:103-106) the three h vectors sum to the plain golden h."""
+    zko, F, cid, pub, wit, MA, MB, dom, shift = _setup(gpu, curve, circ)
+    r = random.Random(9)
+    n = dom.n
+    shares = mpc.rep3_share_vec(F, wit, lambda: r.randrange(F.p))
+    t = [[H.rand_elems(F, n, r) for _ in range(3)] for _ in range(2)]          # two draws (c, ab) of every party's stream
+    masks = [[[(t[k][p][i] - t[k][(p + 2) % 3][i]) % F.p for i in range(n)] for k in range(2)] for p in range(3)]
+    hs = []
+    for p in range(3):
+        got = gpu.bindings.groth16_witness_map_masks(dom, shift, 1, p, MA, MB, zko.num_constraints, H.pack(F, pub), H.pack_shares(F, shares[p]),
+                                                     H.pack(F, masks[p][0]), H.pack(F, masks[p][1]))
+        hs.append(H.unpack(F, got))
+        if dom.n <= 512:
+            it = iter(masks[p])
+            drv = og.Rep3Driver(F, p, mask_fn=lambda k: next(it))
+            assert hs[-1] == og.witness_map_circom(zko, drv, pub, shares[p]), p
+    assert [str((a + b + c) % F.p) for a, b, c in zip(*hs)] == _gold(curve, circ)["h"]
+    assert hs[0] != hs[1]
+    # swapping the two vectors is a different (wrong-order) draw: the result must change -- the order is part of the contract
+    swapped = gpu.bindings.groth16_witness_map_masks(dom, shift, 1, 0, MA, MB, zko.num_constraints, H.pack(F, pub), H.pack_shares(F, shares[0]),
+                                                     H.pack(F, masks[0][1]), H.pack(F, masks[0][0]))
+    assert H.unpack(F, swapped) != hs[0]
+
+
+@pytest.mark.parametrize("curve,circ", [("bn254", "poseidon"), ("bls12_381", "multiplier2")])
+def test_witness_map_masks_equals_the_seeded_entry_point(gpu, curve, circ):
+    """The caller-mask form and the ChaCha12-seed form are the same map: masks drawn as csh_rep3_masks draws them (= Rep3Rand::
+    masking_field_elements_vec, rngs.rs:137-156; chunks [off, off + n) then [off + n, off + 2n)) give bit-identical h."""
+    zko, F, cid, pub, wit, MA, MB, dom, shift = _setup(gpu, curve, circ)
+    r = random.Random(4)
+    shares = mpc.rep3_share_vec(F, wit, lambda: r.randrange(F.p))
+    n = dom.n
+    keys = [bytes([7 * k + 3] * 32) for k in range(3)]
+    off = 11
+    for p in range(3):
+        k1, k2 = keys[p], keys[(p + 2) % 3]
+        seeded = gpu.bindings.groth16_witness_map_seeded(dom, shift, 1, p, MA, MB, zko.num_constraints, H.pack(F, pub), H.pack_shares(F, shares[p]),
+                                                         k1, off, k2, off)
+        ms = []
+        for j in range(2):
+            out = np.zeros(4 * n, dtype=np.uint64)
+            gpu.bindings._check(gpu.lib().csh_rep3_masks(cid, k1, C.c_uint64(off + j * n), k2, C.c_uint64(off + j * n), out.ctypes.data_as(C.c_void_p), C.c_size_t(n)))
+            ms.append(out)
+        got = gpu.bindings.groth16_witness_map_masks(dom, shift, 1, p, MA, MB, zko.num_constraints, H.pack(F, pub), H.pack_shares(F, shares[p]), ms[0], ms[1])
+        assert np.array_equal(got, seeded), p
+
+
+def test_witness_map_masks_error_behaviour(gpu):
+    zko, F, cid, pub, wit, MA, MB, dom, shift = _setup(gpu, "bn254", "multiplier2")
+    r = random.Random(2)
+    shares = mpc.rep3_share_vec(F, wit, lambda: r.randrange(F.p))
+    m = H.pack(F, [1] * dom.n)
+    args = (dom, shift, 1, 0, MA, MB, zko.num_constraints, H.pack(F, pub), H.pack_shares(F, shares[0]))
+    for mc, mab in ((None, None), (m, None), (None, m)):                      # Rep3 without both masks is refused (unmasked products leak)
+        with pytest.raises(gpu.CoSnarksHipError, match="needs its masks"):
+            gpu.bindings.groth16_witness_map_masks(*args, mc, mab)
+    with pytest.raises(gpu.CoSnarksHipError, match="protocol must be"):
+        gpu.bindings.groth16_witness_map_masks(dom, shift, 2, 0, MA, MB, zko.num_constraints, H.pack(F, pub), H.pack(F, wit))
+    with pytest.raises(gpu.CoSnarksHipError, match="column index exceeds"):     # a witness shorter than the matrices index
+        gpu.bindings.groth16_witness_map_masks(dom, shift, 0, 0, MA, MB, zko.num_constraints, H.pack(F, pub), H.pack(F, wit[:-1]))
+    small = gpu.Domain(cid, 1, H.pack(F, [ntt.groth16_roots_of_unity(F, 1)[0]]))
+    with pytest.raises(gpu.CoSnarksHipError, match="Polynomial Degree too large"):  # the message of reduction.rs:87-94
+        gpu.bindings.groth16_witness_map_masks(small, shift, 0, 0, MA, MB, zko.num_constraints, H.pack(F, pub), H.pack(F, wit))
+
+
+# ---- the host mirror driven the way the Rust shim drives the ABI ("trait path") --------------------------------------------------------
+@pytest.mark.parametrize("curve,circ", CIRCUITS)
+def test_trait_path_plain_prove_matches_golden(gpu, curve, circ):
+    from cosnarks_amd import groth16 as g
+    zk, wt, vk, pub = _load(curve, circ)
+    zko = oz.parse_zkey(zk)
+    with g.trait_path():
+        proof, h = g.prove_plain(H.CURVE_IDS[curve], zk, wt, R, S, want_h=True, h_elems=zko.domain_size)
+    gold = _gold(curve, circ)
+    assert proof["pi_a"][:2] == gold["a"] and proof["pi_b"][:2] == gold["b"] and proof["pi_c"][:2] == gold["c"]
+    assert [str(x) for x in H.unpack(zko.Fr, h)] == gold["h"]
+    assert og.verify(curve, zko.G1, vk, oz.parse_proof(json.dumps(proof)), pub)
+
+
+@pytest.mark.parametrize("curve,circ", [("bn254", "multiplier2"), ("bn254", "poseidon"), ("bls12_381", "poseidon")])
+def test_trait_path_rep3_and_shamir_match_golden_and_the_device_resident_path(gpu, curve, circ):
+    from cosnarks_amd import groth16 as g
+    zk, wt, vk, pub = _load(curve, circ)
+    zko = oz.parse_zkey(zk)
+    F = zko.Fr
+    cid = H.CURVE_IDS[curve]
+    gold = _gold(curve, circ)
+    ref_proof, ref_hs = g.prove_rep3(cid, zk, wt, seed=42, r=R, s=S, want_h=True, h_elems=zko.domain_size)
+    with g.trait_path():
+        proof, hs = g.prove_rep3(cid, zk, wt, seed=42, r=R, s=S, want_h=True, h_elems=zko.domain_size)
+        sh = g.prove_shamir(cid, zk, wt, 3, 1, seed=11, r=R, s=S)
+        fresh, _ = g.prove_rep3(cid, zk, wt, seed=7)
+    for p in (proof, sh):
+        assert p["pi_a"][:2] == gold["a"] and p["pi_b"][:2] == gold["b"] and p["pi_c"][:2] == gold["c"]
+    n = zko.domain_size
+    parts = [H.unpack(F, hs[4 * n * p:4 * n * (p + 1)]) for p in range(3)]
+    assert [str((a + b + c) % F.p) for a, b, c in zip(*parts)] == gold["h"]
+    # host-drawn masks (masking_field_elements_vec twice) consume the party's streams exactly as the device generator's run of 2n
+    # chunks does: the h SHARES, not only their sum, are those of the device-resident prove with the same seeds
+    assert np.array_equal(np.asarray(hs), np.asarray(ref_hs)) and proof == ref_proof
+    assert og.verify(curve, zko.G1, vk, oz.parse_proof(json.dumps(fresh)), pub)
+
+
+def test_trait_path_synthetic_circuit_closed_form(gpu):
+    """The synthetic 2^14 circuit with a known-dlog key through the trait path: the closed-form check of bench.py's prove line."""
+    from cosnarks_amd import groth16 as g
+    with g.trait_path():
+        c = g.SynthCircuit(0, 14)
+        ph = c.prove()
+        assert c.check()
+        c.close()
+    assert ph["msm_groups"] > 0 and ph["witness_upload_and_map"] > 0
