@@ -722,7 +722,39 @@ struct FpS {
   // canonical() for values that drifted further from [0, p): |value| < 32p (sums over up to ~11 butterfly stages).
   // A quotient estimate from the top limb (float reciprocal: off by at most one for |k| <= 32) brings the value into
   // (-p - eps, 2p + eps), inside canonical()'s range. Dividing by T + 1 instead of T keeps the remainder's sign.
-  CSH_HD FpS canonical_wide() const { return fold_top().canonical(); }
+  CSH_HD FpS canonical_wide() const { return fold_top().canonical_narrow(); }
+
+  // Exact value in [0, p) for an input in [-p, 2p) whose limbs 0..NL-2 lie in [0, 2^B) -- what fold_top() returns, with a wide margin:
+  // its quotient estimate floor(top / (T + 1)) differs from floor(value / p) only when value / p lies within ~|k| / T (1e-5 for the
+  // 9 x 29-bit scalar fields) of an integer, and then by one, so its result is in (-p 1e-5, p (1 + 1e-5)). Branch-free: add p when
+  // negative, then subtract p unless that borrows -- ~75 straight-line instructions where canonical()'s data-dependent correction
+  // loops (a wave executes the union of its lanes' paths) cost 180-250; the canonicalise-and-store tail of an NTT pass, the kernel's
+  // per-sweep fixed cost, spends most of its ~370 instructions per element there (profiles/r04_e_ntt_per_pass.log).
+  CSH_HD FpS canonical_narrow() const {
+    FpS r;
+    const int32_t m = l[NL - 1] >> 31;  // all ones when the value is negative (the top limb carries the sign)
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < NL - 1; ++i) {
+      const int32_t v = l[i] + ((int32_t)LP::MOD[i] & m) + c;
+      r.l[i] = (int32_t)((uint32_t)v & LP::MASK);
+      c = v >> B;
+    }
+    r.l[NL - 1] = l[NL - 1] + ((int32_t)LP::MOD[NL - 1] & m) + c;
+    int32_t d[NL];
+    c = 0;
+#pragma unroll
+    for (int i = 0; i < NL - 1; ++i) {
+      const int32_t v = r.l[i] - (int32_t)LP::MOD[i] + c;
+      d[i] = (int32_t)((uint32_t)v & LP::MASK);
+      c = v >> B;
+    }
+    d[NL - 1] = r.l[NL - 1] - (int32_t)LP::MOD[NL - 1] + c;
+    const bool ge = d[NL - 1] >= 0;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) r.l[i] = ge ? d[i] : r.l[i];
+    return r;
+  }
 
   // cheap necessary condition for value == 0 (mod p), valid for |value| < 8p: value = k p with |k| < 8
   CSH_HD bool maybe_zero() const {

@@ -186,11 +186,25 @@ __global__ __launch_bounds__(NTT_MAX_THREADS) __attribute__((amdgpu_waves_per_eu
   const int tid = threadIdx.x;
   const int NT = blockDim.x;
 
-  for (int e = tid; e < E; e += NT) {
-    const int cc = e & (CC - 1);
-    const size_t t = e >> cc_log;
-    const size_t g = ((((hi_idx << k) | t) << mid_bits) | mid) * CC + cc;
-    lds.put(e, LZ::unpack(data[g]));
+  // Tile load, four entries per lane with all four global loads issued before the first is consumed: written as one rolled loop
+  // (load, unpack, put per iteration) every lane paid four SERIAL trips to HBM per tile -- the 0.04-0.05 ms per sweep that no butterfly
+  // stage accounts for (profiles/r04_e_ntt_per_pass.log; shortening the store tail by a third changed nothing, r04_l_ntt.log).
+  for (int base = 0; base < E; base += 4 * NT) {
+    F raw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = base + tid + i * NT;
+      if (e < E) {
+        const int cc = e & (CC - 1);
+        const size_t t = e >> cc_log;
+        raw[i] = data[((((hi_idx << k) | t) << mid_bits) | mid) * CC + cc];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = base + tid + i * NT;
+      if (e < E) lds.put(e, LZ::unpack(raw[i]));
+    }
   }
   __syncthreads();
 
@@ -286,12 +300,31 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const size_t hi_idx = tile >> mid_bits;
   const int tid = threadIdx.x;
   const int NT = blockDim.x;
+  // timing experiments only (tune "ntt_variant" bits 16-19, wrong results): 1 = no butterfly rounds, 2 = no global loads, 4 = no stores,
+  // 8 = no canonicalisation before the store
+  const int ablate = do_scale >> 8;
+  do_scale &= 1;
 
-  for (int e = tid; e < E; e += NT) {
-    const int cc = e & (CC - 1);
-    const size_t t = e >> cc_log;
-    const size_t g = ((((hi_idx << k) | t) << mid_bits) | mid) * CC + cc;
-    lds.put(e, LZ::unpack(data[g]));
+  // Tile load, four entries per lane with all four global loads issued before the first is consumed: written as one rolled loop
+  // (load, unpack, put per iteration) every lane paid four SERIAL trips to HBM per tile -- the 0.04-0.05 ms per sweep that no butterfly
+  // stage accounts for (profiles/r04_e_ntt_per_pass.log; shortening the store tail by a third changed nothing, r04_l_ntt.log).
+  for (int base = 0; base < E; base += 4 * NT) {
+    F raw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = base + tid + i * NT;
+      if (e < E) {
+        const int cc = e & (CC - 1);
+        const size_t t = e >> cc_log;
+        if (ablate & 2) raw[i] = scale_lazy; else
+        raw[i] = data[((((hi_idx << k) | t) << mid_bits) | mid) * CC + cc];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = base + tid + i * NT;
+      if (e < E) lds.put(e, LZ::unpack(raw[i]));
+    }
   }
   __syncthreads();
 
@@ -387,7 +420,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
     __syncthreads();
   };
-  if (DIF) {
+  if (ablate & 1) {
+  } else if (DIF) {
     int q = k;
     for (; q >= 2; q -= 2) round4(q - 2);
     if (q == 1) stage2(0);
@@ -406,7 +440,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // the 1/n of the inverse transform, or -- witness maps -- a per-entry table that already carries it (1/n times the coset
     // power of the entry, in the pass's output order): the coset shift costs no sweep and no multiplication of its own
     if (do_scale) f = LZ::mul(f, scale_tbl ? LZ::unpack(scale_tbl[g >> ncomp_log]) : sc);
-    data[g] = f.canonical_wide().pack();
+    if (ablate & 4) continue;
+    data[g] = (ablate & 8) ? f.pack() : f.canonical_wide().pack();
   }
 }
 
@@ -497,8 +532,26 @@ struct Pass {
   int s0, k, cb;
 };
 
+// log2(field elements per LDS tile) for a transform of 2^L entries of 2^ncomp_log elements. The tile is the unit of parallelism (one
+// workgroup each): 2^11-element tiles give a 2^16-point transform 32 workgroups for 256 CUs and make every workgroup walk 11 dependent
+// stages, so small transforms were latency-bound on a handful of CUs. Measured, interleaved (profiles/r04_o_ntt_small.log, ms per
+// transform, 2^11-element tiles -> best): 2^12 0.038 -> 0.015 (2^8), 2^14 0.043 -> 0.017 (2^8), 2^16 0.048 -> 0.021 (2^9), 2^17
+// 0.052 -> 0.028 (2^9), 2^18 0.058 -> 0.039 (2^10); 2^19 .. 2^21 are best at 2^11 (more passes cost more than the parallelism gains);
+// from 2^22 elements on 2^10-element tiles (four independent tiles per CU instead of two: their load / compute / store phases
+// interleave) gain 1-4 % (r04_d_ntt_tile_ab.log, r04_k_ntt_tiles.log). tune "ntt_variant" bits 8-10 = v forces 2^(12-v) (A/B runs).
+static int ntt_tile_log(int L, int ncomp_log) {
+  const int v = (tune().ntt_variant.load(std::memory_order_relaxed) >> 8) & 7;
+  if (v >= 1 && v <= 4) return 12 - v;
+  const int total = L + ncomp_log;
+  if (total <= 15) return 8;
+  if (total <= 17) return 9;
+  if (total == 18) return 10;
+  if (total >= 22) return 10;
+  return NTT_TILE_LOG;
+}
+
 static int plan_passes(int L, int ncomp_log, Pass* out) {
-  const int TE = NTT_TILE_LOG - ncomp_log;  // log2(entries per tile)
+  const int TE = ntt_tile_log(L, ncomp_log) - ncomp_log;  // log2(entries per tile)
   // Contiguous run of a strided pass: 2^cb entries of ncomp x 32 bytes. 64-byte runs cost nothing against 256-byte ones and save a whole
   // sweep where the stages then fit two passes: 2^20 points 11 + 9 stages (128-byte runs) instead of 11 + 5 + 4, inverse / forward 0.143 / 0.135 ->
   // 0.132 / 0.123 ms, share pairs 0.258 / 0.259 -> 0.246 / 0.242 ms; 2^21 points 11 + 10 (64-byte runs) 0.268 / 0.285 -> 0.261 / 0.270
@@ -543,14 +596,19 @@ static int run_ntt(const Domain* d, F* data, uint32_t ncomp, bool dif, hipStream
   using LZ = typename LazyOf<F>::type;
   const F* tw = reinterpret_cast<const F*>(use_lazy ? (dif ? d->tw_inv_lazy : d->tw_fwd_lazy) : (dif ? d->tw_inv : d->tw_fwd));
   F scale = f_from_words<F>(use_lazy ? d->n_inv_lazy : d->n_inv);
-  const int NTT_THREADS = [] {
-    const int v = tune().ntt_threads.load(std::memory_order_relaxed);  // 16 waves per tile: measured best for both field representations
+  const int NTT_THREADS_MAX = [] {
+    const int v = tune().ntt_threads.load(std::memory_order_relaxed);  // 16 waves per 2^11-element tile: measured best for both field representations
     return (v == 256 || v == 512 || v == 1024) ? v : 1024;
   }();
+  const int only_pass = (tune().ntt_variant.load(std::memory_order_relaxed) >> 12) & 3;  // timing experiments: run ONE pass of the plan (wrong results)
   for (int pi = 0; pi < np; ++pi) {
     const Pass& p = dif ? passes[np - 1 - pi] : passes[pi];
+    if (only_pass && (dif ? np - 1 - pi : pi) != only_pass - 1) continue;
     const int tile_log = p.k + p.cb;  // entries
     const size_t tiles = d->n >> tile_log;
+    // radix-2 passes: one lane per butterfly of a stage, at least one wave
+    const size_t bfly = (size_t(1) << (tile_log + ncomp_log)) >> 1;
+    const int NTT_THREADS = bfly >= (size_t)NTT_THREADS_MAX ? NTT_THREADS_MAX : (bfly >= 64 ? (int)bfly : 64);
     const size_t lds_bytes = use_lazy ? (size_t(4 * LZ::NL) << (tile_log + ncomp_log)) : (size_t(32) << (tile_log + ncomp_log));
     const int do_scale = dif && (p.s0 == 0);
     if (use_lazy) {
@@ -582,9 +640,9 @@ static int run_ntt(const Domain* d, F* data, uint32_t ncomp, bool dif, hipStream
         const size_t units = (size_t(1) << (tile_log + ncomp_log)) >> 2;
         const int nt = units >= 512 ? 512 : (units >= 64 ? (int)units : 64);
         if (dif)
-          hipLaunchKernelGGL((k_ntt_pass_r4<F, LZ, true>), dim3((unsigned)tiles), dim3(nt), lds_bytes, st, data, tw, L, p.s0, p.k, p.cb, ncomp_log, scale, do_scale, scale_tbl);
+          hipLaunchKernelGGL((k_ntt_pass_r4<F, LZ, true>), dim3((unsigned)tiles), dim3(nt), lds_bytes, st, data, tw, L, p.s0, p.k, p.cb, ncomp_log, scale, do_scale | (((nv >> 16) & 0xf) << 8), scale_tbl);
         else
-          hipLaunchKernelGGL((k_ntt_pass_r4<F, LZ, false>), dim3((unsigned)tiles), dim3(nt), lds_bytes, st, data, tw, L, p.s0, p.k, p.cb, ncomp_log, scale, 0, (const F*)nullptr);
+          hipLaunchKernelGGL((k_ntt_pass_r4<F, LZ, false>), dim3((unsigned)tiles), dim3(nt), lds_bytes, st, data, tw, L, p.s0, p.k, p.cb, ncomp_log, scale, ((nv >> 16) & 0xf) << 8, (const F*)nullptr);
         CSH_HIP(hipGetLastError());
         continue;
       }

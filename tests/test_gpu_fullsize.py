@@ -246,12 +246,15 @@ def test_msm_fuzz_sizes_and_plans_vs_cpu_restatement(gpu, curve, group, rounds):
         assert np.array_equal(got_aff, want), (curve, group, it, n, off, k, knobs)
 
 
-@pytest.mark.parametrize("variant", [2, 1])
+@pytest.mark.parametrize("variant", [0, 2, 1, 0x102, 0x101, 0x201, 0x302, 0x402, 0x401])
 @pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
 def test_ntt_every_size_up_to_2p19_vs_cpu_restatement(gpu, curve, variant):
-    """Every domain size 2^1 .. 2^19 (all pass plans: one, two and three sweeps; even and odd stage counts per pass), both
-    directions, ncomp 1 and 2, against oracle/c's radix-2 NTT over the whole vector. variant 2: the radix-2 pass everywhere,
-    1: the radix-4 pass everywhere (tune ntt_variant; the default mixes them by direction and size)."""
+    """Every domain size 2^1 .. 2^19 (all pass plans: one, two, three and more sweeps; even and odd stage counts per pass), both
+    directions, ncomp 1 and 2, against oracle/c's radix-2 NTT over the whole vector. variant 0: the default (tile size by transform
+    size, radix-2 passes below 2^20 points); 2: the radix-2 pass everywhere, 1: the radix-4 pass everywhere; bits 8-10 = v force
+    2^(12-v)-element tiles (tune ntt_variant), each with either pass form."""
+    if curve == "bls12_381" and variant in (0x101, 0x302):
+        pytest.skip("the forced tile sizes run on both fields with one pass form each")
     with gpu.tuned(ntt_variant=variant):
         _ntt_every_size(gpu, curve)
 

@@ -333,6 +333,25 @@ def test_lazy_ntt_butterfly_arithmetic(hip, curve):
 
 
 @pytest.mark.parametrize("curve", ["bn254", "bls12_381", "bls12_377"])
+def test_lazy_canonicalisation_at_the_multiples_of_p(hip, curve):
+    """canonical_wide() = fold_top() + the branch-free canonical_narrow(): results that land on, just below and just above a multiple of p
+    (a +/- k with a in {0, 1, p - 1, ...}: the product b w = 1 comes out of a Montgomery reduction as 1 or 1 + p, so the drifted sum sits
+    within a few units of k' p for every k' the drift reaches) must come out exact and canonical."""
+    F = H.FR[curve]
+    cid = H.CURVE_IDS[curve]
+    L = hip.lib()
+    one = H.pack(F, [1]).ctypes.data_as(C.c_void_p)
+    for a in (0, 1, 2, 23, 24, 25, F.p - 1, F.p - 2, F.p - 24, F.p - 25, (F.p - 1) // 2, (F.p + 1) // 2):
+        for k in list(range(0, 26)):
+            for neg in (0, 1):
+                out = np.zeros(4, dtype=np.uint64)
+                rc = L.csh_selftest_lazy_fr_chain(cid, H.pack(F, [a]).ctypes.data_as(C.c_void_p), one, one, k, neg, out.ctypes.data_as(C.c_void_p))
+                assert rc == 0
+                assert H.unpack(F, out) == [(a - k) % F.p if neg else (a + k) % F.p], (a, k, neg)
+                assert int.from_bytes(out.tobytes(), "little") == F.to_mont((a - k) % F.p if neg else (a + k) % F.p)   # the canonical encoding itself
+
+
+@pytest.mark.parametrize("curve", ["bn254", "bls12_381", "bls12_377"])
 def test_lazy_share_vector_products(hip, curve):
     """The lazy-field products of the share-vector kernels (vec_ops.hip; operands re-sliced as they are, one scaled by
     2^5 = R'/2^256) run on the host with limb-bound assertions: a*b and the Rep3 local multiplication, edge values included."""
