@@ -346,10 +346,49 @@ def msm_roofline(job: MsmJob, rin: dict, log_n_local: int):
         a = job.n * n_win * mads / t_acc / 1e12
         roof["alu"] = {"unit": "Tmad/s", "achieved": round(a, 2), "peak": mad_peak, "frac": round(a / mad_peak, 3), "mads_per_madd": mads,
                        "madds_per_s": round(job.n * n_win / t_acc), "peak_source": mad_src}
+        # a denominator this repository did not measure itself: one VALU lane-operation per lane and clock, 256 CUs x 4 SIMDs x 16 lanes x
+        # 2.4 GHz (/opt/skills/guides/MI355X_MICROARCH.md) = 39.3 T lane-ops/s; a 64-bit multiply-add is one such operation at best
+        nominal = 256 * 4 * 16 * 2.4e9 / 1e12
+        roof["alu"]["peak_nominal"] = round(nominal, 1)
+        roof["alu"]["frac_vs_nominal"] = round(a / nominal, 3)
         if rin.get("mad_peak_T"):   # the constant of profiles/roofline_inputs.json (tools/gpu_probe.py: one cold pass per process), for continuity with earlier rounds
             roof["alu"]["peak_file"] = rin["mad_peak_T"]
             roof["alu"]["frac_vs_file"] = round(a / rin["mad_peak_T"], 3)
     return roof
+
+
+def ntt_transforms(cx: Ctx, logn: int, warm_transforms: int, timed_pairs: int):
+    """One independent BN254 transform pipeline on this rank's GPU (snarkjs root, data resident): `timed_pairs` back-to-back
+    ifft_in_to_out + fft_out_to_in pairs between two HIP events on the launch stream, after `warm_transforms` untimed transforms.
+    -> ms per transform (warm), the same measured right after a single warm-up transform, and the number of untimed transforms."""
+    hip, B, torch = cx.hip, cx.B, cx.torch
+    r = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    g = pow(pow(5, (r - 1) >> 28, r), 1 << (28 - logn), r) * ((1 << 256) % r) % r
+    gen = cx.np.array([(g >> (64 * i)) & (2**64 - 1) for i in range(4)], dtype=cx.np.uint64)
+    dom = hip.Domain(hip.BN254, logn, gen)
+    data = torch.randint(0, 1 << 62, (1 << logn, 4), dtype=torch.int64, device=cx.dev)
+    data[:, 3] >>= 1   # canonical (< r)
+    torch.cuda.synchronize()
+    e0, e1 = B.Event(), B.Event()
+
+    def pairs(k):
+        e0.record(cx.stream)
+        for _ in range(k):
+            dom.ifft_in_to_out_dev(data.data_ptr(), 1, cx.stream)
+            dom.fft_out_to_in_dev(data.data_ptr(), 1, cx.stream)
+        e1.record(cx.stream)
+        return e0.elapsed_ms(e1) / (2 * k)
+
+    dom.ifft_in_to_out_dev(data.data_ptr(), 1, cx.stream)
+    first = pairs(timed_pairs)
+    done = 1 + 2 * timed_pairs
+    while done < warm_transforms:
+        pairs(10)
+        done += 20
+    ms = pairs(timed_pairs)
+    dom.free()
+    del data
+    return {"ms": ms, "ms_first_batch": first, "warm_transforms": done}
 
 
 def secondary_single_gpu(cx: Ctx, rin: dict, args):
@@ -359,7 +398,7 @@ def secondary_single_gpu(cx: Ctx, rin: dict, args):
     out = {}
     torch.cuda.synchronize()
     cpu_inputs = None
-    for wl, logn, steps in (("bn254_g1", 24, 5), ("bls12_381_g1", 24, 3), ("bls12_381_g2", 24, 2)):
+    for wl, logn, steps in (("bn254_g1", args.split_log_n, 5), ("bls12_381_g1", args.split_log_n, 3), ("bls12_381_g2", args.split_log_n, 2)):
         job = MsmJob(cx, wl, 0, 1 << logn, 4321 + logn)
         keep = wl == "bn254_g1" and not args.no_cpu_baseline
         pts_host = job.points_to_host() if keep else None
@@ -448,37 +487,27 @@ def secondary_single_gpu(cx: Ctx, rin: dict, args):
     except Exception as e:  # noqa: BLE001
         out["msm_bn254_g1_2p20_witness_like"] = {"error": repr(e)}
     # NTT 2^22 (snarkjs root), data resident; HIP events on the launch stream
-    logn = 22
-    r = 21888242871839275222246405745257275088548364400416034343698204186575808495617
-    g = pow(pow(5, (r - 1) >> 28, r), 1 << (28 - logn), r) * ((1 << 256) % r) % r
-    gen = np.array([(g >> (64 * i)) & (2**64 - 1) for i in range(4)], dtype=np.uint64)
-    dom = hip.Domain(hip.BN254, logn, gen)
-    data = torch.randint(0, 1 << 62, (1 << logn, 4), dtype=torch.int64, device=dev)
-    data[:, 3] >>= 1   # canonical (< r)
-    e0, e1 = B.Event(), B.Event()
-    dom.ifft_in_to_out_dev(data.data_ptr(), 1, stream)
-    e0.record(stream)
-    for _ in range(10):
-        dom.ifft_in_to_out_dev(data.data_ptr(), 1, stream)
-        dom.fft_out_to_in_dev(data.data_ptr(), 1, stream)
-    e1.record(stream)
-    ms = e0.elapsed_ms(e1) / 20
+    logn = args.ntt_log_n
+    nt = ntt_transforms(cx, logn, warm_transforms=120, timed_pairs=20)
+    ms = nt["ms"]
     modmuls = (1 << logn) // 2 * logn                      # one twiddle multiplication per butterfly
     mm_peak, mm_src = rin.get("modmul_peak_G"), rin.get("modmul_peak_source")
     lv = [x for x in (live_probe(cx, 11, 200), live_probe(cx, 14, 200)) if x]
     if lv:   # dependent 9 x 29-bit Montgomery products (unsigned row-wise / signed product-scanning multiplier) on this box
         mm_peak, mm_src = round(max(lv) / 1e9, 2), "csh_microbench on this box, this run (k_modmul29 / k_modmul29s; file value: %s G/s)" % rin.get("modmul_peak_G")
-    kin = rin.get("kernels", {}).get("k_ntt_pass_lazy 2^22", {})
-    out["ntt_bn254_2p22"] = {"elements_per_s": (1 << logn) / ms * 1e3, "ms": ms,
+    kin = rin.get("kernels", {}).get("k_ntt_pass_lazy 2^22", {}) if logn == 22 else {}
+    out[f"ntt_bn254_2p{logn}"] = {"elements_per_s": (1 << logn) / ms * 1e3, "ms": ms,
+                             # the same 20 pairs right after ONE warm-up transform (what rounds 1-3 reported): the clocks of an idle GPU take tens of
+                             # ms of continuous work to come up (profiles/r04_j_ntt_context.log: 0.566 -> 0.503 -> 0.480 -> 0.467 ms over four batches)
+                             "ms_first_batch_after_idle": nt["ms_first_batch"], "warm_up_transforms": nt["warm_transforms"],
                              "roofline": {"bound": "hbm", "kernel": "k_ntt_pass_r4 / k_ntt_pass_lazy (all passes of one transform)", "achieved": round(64.0 * (1 << logn) / ms / 1e6, 1),
                                           "peak": float(rin.get("hbm_peak_GBps", 8000.0)), "unit": "GB/s", "frac": round(64.0 * (1 << logn) / ms / 1e6 / float(rin.get("hbm_peak_GBps", 8000.0)), 4), "traffic": kin.get("traffic_bytes"),
                                           "traffic_source": kin.get("file"),
                                           "alu": {"unit": "G modmul/s", "achieved": round(modmuls / ms / 1e6, 1), "peak": mm_peak,
                                                   "frac": round(modmuls / ms / 1e6 / mm_peak, 3) if mm_peak else None, "peak_source": mm_src}}}
-    dom.free()
-    del data
+    e0, e1 = B.Event(), B.Event()
     # Rep3 local_mul_vec 2^24 (192 B/element)
-    n = 1 << 24
+    n = 1 << (18 if args.quick else 24)
     a = torch.randint(0, 1 << 62, (2 * n, 4), dtype=torch.int64, device=dev)
     b = torch.randint(0, 1 << 62, (2 * n, 4), dtype=torch.int64, device=dev)
     m = torch.randint(0, 1 << 62, (n, 4), dtype=torch.int64, device=dev)
@@ -501,7 +530,7 @@ def secondary_single_gpu(cx: Ctx, rin: dict, args):
     del a, b, m, o
     # Groth16 plain prove, synthetic 2^20-constraint circuit with a known-dlog key (closed-form checked), key resident
     from cosnarks_amd import groth16 as g16
-    out["groth16_prove_synthetic_2p20"] = g16.bench_synthetic(hip.BN254, 20, 3, with_rep3=True)
+    out[f"groth16_prove_synthetic_2p{args.prove_log_n}"] = g16.bench_synthetic(hip.BN254, args.prove_log_n, 3, with_rep3=True)
     # BASELINE configs 1 and 4 on the reference's own circuits (tests/golden copies of test_vectors/Groth16/bn254): plain
     # prove of multiplier2 (domain 4) and poseidon (domain 256), and a three-party Rep3 prove of poseidon (in-process
     # parties sharing this GPU). Wall ms per proof incl. zkey parse + key upload; these sizes are launch-latency bound.
@@ -534,7 +563,7 @@ def secondary_multi_gpu(cx: Ctx, args):
     BLS12-381 G1 / G2 and BN254 G1, closed-form checked; then, on rank 0 alone, the single-thread `csh_msm_split` over all N
     devices with its three exchanges (hipMemcpyPeer / host copies / grouped RCCL) so both exchanges are measured."""
     out = {}
-    logn = 24
+    logn = args.split_log_n
     total = 1 << logn
     per = total // cx.world
     for wl, steps in (("bn254_g1", 5), ("bls12_381_g1", 3), ("bls12_381_g2", 2)):
@@ -548,6 +577,27 @@ def secondary_multi_gpu(cx: Ctx, args):
                                             "points_per_rank": per}
         job.free()
         del job
+    # independent NTT instances, one per rank (north star: "independent MSM/NTT instances ... shard across the GPUs": replicas, no
+    # collective): every rank transforms its own 2^k vector; elements/s summed over the ranks on the slowest rank's clock
+    try:
+        nl = args.ntt_log_n
+        cx.barrier()
+        nt = ntt_transforms(cx, nl, warm_transforms=120, timed_pairs=20)
+        slow = cx.max_over_ranks(nt["ms"])
+        out[f"ntt_bn254_2p{nl}_replicas"] = {"elements_per_s": cx.world * (1 << nl) / slow * 1e3, "ms_per_transform_slowest_rank": slow,
+                                             "ms_per_transform_this_rank": nt["ms"], "ranks": cx.world, "scaling": "weak (one independent transform per GPU)"}
+    except Exception as e:  # noqa: BLE001
+        out[f"ntt_bn254_2p{args.ntt_log_n}_replicas"] = {"error": repr(e)}
+    cx.barrier()
+    # BASELINE config 4 with one GPU per party: three in-process Rep3 parties on devices 0..2 (folded: on the GPUs that exist), each with
+    # its own copy of the proving key; rank 0 drives them (the parties are host threads of one process, as in the reference's tests)
+    if cx.rank == 0:
+        try:
+            from cosnarks_amd import groth16 as g16
+            ndev = 1 if cx.folded else cx.world
+            out["groth16_rep3_party_per_gpu"] = g16.bench_rep3_party_per_gpu(cx.hip.BN254, args.prove_log_n, [p % ndev for p in range(3)], iters=2)
+        except Exception as e:  # noqa: BLE001
+            out["groth16_rep3_party_per_gpu"] = {"error": repr(e)}
     cx.barrier()
     if cx.rank == 0 and not cx.folded:
         try:
@@ -559,9 +609,10 @@ def secondary_multi_gpu(cx: Ctx, args):
     if cx.rank == 0:
         try:
             devs = [0] * cx.world if cx.folded else list(range(cx.world))
-            out["groth16_prove_synthetic_2p20_placed"] = {"by_query": prove_over_devices(devs, mode=1), "by_range": prove_over_devices(devs, mode=2)}
+            out[f"groth16_prove_synthetic_2p{args.prove_log_n}_placed"] = {"by_query": prove_over_devices(devs, logn=args.prove_log_n, mode=1),
+                                                                            "by_range": prove_over_devices(devs, logn=args.prove_log_n, mode=2)}
         except Exception as e:  # noqa: BLE001
-            out["groth16_prove_synthetic_2p20_placed"] = {"error": repr(e)}
+            out[f"groth16_prove_synthetic_2p{args.prove_log_n}_placed"] = {"error": repr(e)}
     cx.barrier()
     return out
 
@@ -652,8 +703,8 @@ def single_process_split(cx: Ctx, curve, group, logn):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)   # 100 steps of 1.7 ms: the 20-step region of rounds 1-3 (34 ms) sat inside the clock ramp of an idle GPU
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--workload", choices=sorted(WORKLOADS) + ["groth16_prove"], default="bn254_g1")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
@@ -664,7 +715,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary metrics")
+    ap.add_argument("--quick", action="store_true", help="shrink the secondary workloads (schema tests of the N > 1 line on a small box): "
+                                                         "split MSM 2^18, NTT 2^16, prove 2^14")
     args = ap.parse_args()
+    args.split_log_n, args.ntt_log_n, args.prove_log_n = (18, 16, 14) if args.quick else (24, 22, 20)
 
     if args.workload == "groth16_prove":
         args.exchange = "harness"      # no split MSM in this workload: no RCCL communicator to build

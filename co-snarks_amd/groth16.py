@@ -173,6 +173,17 @@ def bench_synthetic(curve: int, log_domain: int, iters: int = 3, with_rep3: bool
     return out
 
 
+def bench_rep3_party_per_gpu(curve: int, log_domain: int, devices, iters: int = 3):
+    """Three in-process Rep3 parties prove the synthetic circuit, party p bound to devices[p] with its own key copy there (BASELINE
+    config 4: one GPU per party; `devices` may repeat to fold the parties onto fewer GPUs)."""
+    dv = (C.c_int * 3)(*[int(d) for d in devices])
+    out = (C.c_double * 3)()
+    if glib().cog16_bench_rep3_party_per_gpu(curve, log_domain, iters, dv, out) != 0:
+        raise CoSnarksHipError(glib().cog16_last_error().decode())
+    return {"log_domain": log_domain, "party_devices": [int(d) for d in devices], "three_parties_prove_ms": out[0], "proofs_equal_plain": bool(out[1]),
+            "key_setup_ms_per_device": out[2]}
+
+
 class trait_path:
     """`with trait_path():` -- every prove of the host mirror inside the block runs the way rust/co-groth16-hip drives the C ABI behind
     the unchanged reference: host slices in and out of every seam call (one csh_groth16_witness_map_masks per witness map, h on the

@@ -651,6 +651,97 @@ int bench_synth_t(int log_domain, int iters, double* out_ms, int* check_ok, cons
   return 0;
 }
 
+// BASELINE config 4 at scale with ONE GPU PER PARTY: three in-process Rep3 parties prove the synthetic 2^log_domain circuit, party p bound
+// to devices[p] with its own copy of the proving key and matrices on that GPU (independent instances: no data-path collective, the
+// parties exchange three curve points over the in-process network). devices may repeat (the three parties folded onto fewer GPUs).
+// out = {wall ms of the best of `iters` three-party proves, proofs agree and equal the plain proof (1 / 0), key setup ms per device}.
+template <class P>
+int bench_rep3_party_per_gpu_t(int log_domain, int iters, const int devices[3], double* out, const uint32_t* g1_words, const uint32_t* g2_words) {
+  using T3 = Rep3Groth16Driver<P>;
+  using Fr = typename P::Fr;
+  using Fq = typename P::Fq;
+  using Share = Rep3PrimeFieldShare<Fr>;
+  int home = 0;
+  (void)csh_current_device(&home);
+  // one circuit (key + matrices + witness) per distinct device, built on that device
+  std::map<int, std::unique_ptr<SynthCircuit<P>>> circuits;
+  double key_ms = 0;
+  for (int p = 0; p < 3; ++p) {
+    if (circuits.count(devices[p])) continue;
+    std::string err;
+    Joined th([&] {
+      check(csh_init(devices[p]), "csh_init");
+      circuits[devices[p]].reset(new SynthCircuit<P>(log_domain, g1_words, g2_words));
+    });
+    th.join();
+    key_ms = std::max(key_ms, circuits[devices[p]]->key_ms);
+  }
+  SynthCircuit<P>& c0 = *circuits[devices[0]];
+  const Fr r = c0.r, s = c0.s;
+  Rep3Sharer<Fr> sharer(99);
+  std::vector<Share> wsh[3];
+  sharer.share(c0.sw.witness, wsh);
+  Share r3[3], s3[3];
+  {
+    std::vector<Share> t[3];
+    sharer.share({r, s}, t);
+    for (int p = 0; p < 3; ++p) r3[p] = t[p][0], s3[p] = t[p][1];
+  }
+  SharedWitness<P, Share> sw3[3];
+  for (int p = 0; p < 3; ++p) {
+    sw3[p].public_inputs = c0.sw.public_inputs;
+    sw3[p].witness = std::move(wsh[p]);
+  }
+  double best3 = 1e30;
+  Proof<P> proofs[3];
+  for (int it = 0; it < iters + 1; ++it) {  // + 1 warm-up round (lanes, arenas and pooled buffers of every party thread)
+    auto nets0 = LocalNetwork::new_parties(3), nets1 = LocalNetwork::new_parties(3);
+    std::string errs[3];
+    auto b0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> th;
+    for (int p = 0; p < 3; ++p) {
+      th.emplace_back([&, p] {
+        try {
+          check(csh_init(devices[p]), "csh_init");
+          SynthCircuit<P>& c = *circuits[devices[p]];
+          uint8_t my_seed[32];
+          ShareRng(4242ull + it, 100 + p).fill(my_seed, 32);
+          Rep3State state0 = Rep3State::create(nets0[p], my_seed);
+          Rep3State state1 = state0.fork(0);
+          proofs[p] = CoGroth16<P, T3>::template prove_inner<CircomReduction>(&nets0[p], &nets1[p], state0, state1, c.pk, c.m, sw3[p], &r3[p], &s3[p]);
+        } catch (const std::exception& e) {
+          errs[p] = e.what();
+          nets0[p].abort();
+          nets1[p].abort();
+        }
+      });
+    }
+    for (auto& t : th) t.join();
+    if (it) best3 = std::min(best3, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - b0).count());
+    for (int p = 0; p < 3; ++p)
+      if (!errs[p].empty()) throw Error("rep3 party " + std::to_string(p) + ": " + errs[p]);
+  }
+  // the plain proof of the same circuit with the same r, s, on the home device's circuit
+  check(csh_init(devices[0]), "csh_init");
+  c0.prove(false);
+  auto eq1 = [](const AffineT<Fq>& x, const AffineT<Fq>& y) { return x.x == y.x && x.y == y.y; };
+  bool ok3 = true;
+  for (int p = 0; p < 3; ++p)
+    ok3 = ok3 && eq1(proofs[p].a, c0.proof.a) && eq1(proofs[p].c, c0.proof.c) && proofs[p].b.x == c0.proof.b.x && proofs[p].b.y == c0.proof.b.y;
+  for (auto& kv : circuits) {  // free every device's key on a thread bound to that device
+    Joined th([&] {
+      check(csh_init(kv.first), "csh_init");
+      kv.second.reset();
+    });
+    th.join();
+  }
+  check(csh_init(home), "csh_init");
+  out[0] = best3;
+  out[1] = ok3 ? 1.0 : 0.0;
+  out[2] = key_ms;
+  return 0;
+}
+
 // witness_map_from_matrices of either reduction on caller-supplied matrices (CSR) and a full witness: plain (mode 0) or
 // three in-process Rep3 parties (mode 1; h_out receives the three parties' half-share vectors back to back).
 template <class P>
@@ -1210,6 +1301,18 @@ int cog16_bench_synthetic3(int curve, int log_domain, int iters, double* out_ms,
   }
 }
 
+
+int cog16_bench_rep3_party_per_gpu(int curve, int log_domain, int iters, const int devices[3], double* out /* 3 entries */) {
+  try {
+    if (!devices || !out || iters < 1) throw Error("cog16_bench_rep3_party_per_gpu: bad arguments");
+    if (curve == 0) return bench_rep3_party_per_gpu_t<Bn254>(log_domain, iters, devices, out, csh::Bn254G1Gen, csh::Bn254G2Gen);
+    if (curve == 1) return bench_rep3_party_per_gpu_t<Bls12_381>(log_domain, iters, devices, out, csh::Bls381G1Gen, csh::Bls381G2Gen);
+    throw Error("unknown curve");
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return -1;
+  }
+}
 
 const char* cog16_last_error(void) { return g_err.c_str(); }
 
