@@ -239,6 +239,25 @@ int csh_msm(csh_bases_t bases, size_t offset, size_t n, const uint64_t* scalars,
   return csh_msm_dev(bases, offset, n, ds, mont, out, h.st);
 }
 
+// One MSM per share component over the same bases: the Rep3PointShare {a, b} of pointshare::msm_public_points. The AoS share vector
+// crosses PCIe once; each component is cut out on the device (a strided device copy) and runs the ordinary pipeline.
+int csh_msm_shares(csh_bases_t bases, size_t offset, size_t n, const uint64_t* shares, uint32_t ncomp, int mont, void* const* outs) {
+  CSH_REQUIRE(ncomp >= 1 && ncomp <= 2 && outs, "msm_shares: ncomp must be 1 or 2 and outs non-NULL");
+  for (uint32_t c = 0; c < ncomp; ++c) CSH_REQUIRE(outs[c], "msm_shares: NULL output");
+  CSH_TRY(msm_args(bases, offset, n, shares, outs[0]));
+  if (ncomp == 1) return csh_msm(bases, offset, n, shares, mont, outs[0]);
+  HostStage h;
+  CSH_TRY(h.begin(Arena::padded(32 * (size_t)ncomp * n) + Arena::padded(32 * n)));
+  uint64_t *dsh, *dcomp;
+  CSH_TRY(h.up(dsh, shares, 32 * (size_t)ncomp * n));
+  CSH_TRY(h.up(dcomp, nullptr, 32 * n));
+  for (uint32_t c = 0; c < ncomp; ++c) {
+    CSH_TRY(csh_extract_component_dev(dsh, ncomp, c, n, dcomp, h.st));
+    CSH_TRY(csh_msm_dev(bases, offset, n, dcomp, mont, outs[c], h.st));  // synchronous: dcomp is free again when it returns
+  }
+  return CSH_OK;
+}
+
 int csh_msm_partial_bytes(csh_curve_t curve, csh_group_t group, size_t* bytes) {
   CSH_REQUIRE(bytes, "bytes is NULL");
   CSH_TRY(valid_cg(curve, group));

@@ -172,26 +172,20 @@ struct Rep3PlonkDriver {
   // pointshare::msm_public_points (rep3/pointshare.rs:201-222) / the fast_msm pair of co-noir rep3.rs:258-266: split the
   // shares into their a and b vectors, one MSM each
   static PointShareG1 msm_public_points_g1(const std::vector<AffineT<Fq>>& points, const std::vector<ArithmeticShare>& scalars) {
-    std::vector<Fr> a(scalars.size()), b(scalars.size());
-    for (size_t i = 0; i < scalars.size(); ++i) {
-      a[i] = scalars[i].a;
-      b[i] = scalars[i].b;
-    }
     const size_t cnt = std::min(scalars.size(), points.size());
     PointShareG1 out{Proj<Fq>::inf(), Proj<Fq>::inf()};
     if (cnt == 0) return out;
     csh_bases_t h = nullptr;
     check(csh_bases_upload(P::ID, CSH_G1, points.data(), cnt, 0, &h), "csh_bases_upload");  // uploaded once for both MSMs
-    const BasesView v{h, 0, cnt};
-    try {
-      Joined t([&] { out.b = msm_device<Fq>(v, b.data(), cnt); });  // rayon::join; an exception is rethrown by join()
-      out.a = msm_device<Fq>(v, a.data(), cnt);
-      t.join();
-    } catch (...) {
-      csh_bases_free(h);
-      throw;
-    }
+    // the shares go up as they lie in memory ({a, b} pairs); the library cuts the two component vectors out on the device
+    // (csh_msm_shares) instead of the host unzip + two uploads of the reference's call sites
+    csh::Jac<Fq> ja, jb;
+    void* outs[2] = {&ja, &jb};
+    const int rc = csh_msm_shares(h, 0, cnt, reinterpret_cast<const uint64_t*>(scalars.data()), 2, 1, outs);
     csh_bases_free(h);
+    check(rc, "csh_msm_shares");
+    out.a = ja.is_inf() ? Proj<Fq>::inf() : Proj<Fq>::from_affine(AffineT<Fq>{ja.x, ja.y});
+    out.b = jb.is_inf() ? Proj<Fq>::inf() : Proj<Fq>::from_affine(AffineT<Fq>{jb.x, jb.y});
     return out;
   }
   static PointShareG1 msm_public_points(const std::vector<AffineT<Fq>>& points, const std::vector<ArithmeticShare>& scalars) {

@@ -136,6 +136,13 @@ int csh_bases_free(csh_bases_t bases);
  * out_jacobian: 3 base-field elements (X, Y, Z) on the host. */
 int csh_msm(csh_bases_t bases, size_t offset, size_t n, const uint64_t* scalars,
             int scalars_are_montgomery, void* out_jacobian);
+/* One MSM per share component over the same bases, from ONE host vector of shares: shares = n entries of ncomp (1 or 2) consecutive
+ * field elements, outs[c] = Jacobian result of component c. ncomp = 2 is the Rep3PointShare {a, b} of pointshare::msm_public_points
+ * (mpc-core/src/protocols/rep3/pointshare.rs:201-222; call sites CircomPlonkProver::msm_public_points_g1, co-plonk/src/mpc/rep3.rs:170-175,
+ * and NoirUltraHonkProver::msm_public_points, co-noir-common/src/mpc/rep3.rs:259-266, which unzip the shares on the host and run two
+ * MSMs): here the share vector crosses PCIe once and the components are cut out on the device. */
+int csh_msm_shares(csh_bases_t bases, size_t offset, size_t n, const uint64_t* shares, uint32_t ncomp, int scalars_are_montgomery,
+                   void* const* outs_jacobian);
 int csh_msm_dev(csh_bases_t bases, size_t offset, size_t n, const uint64_t* scalars_dev,
                 int scalars_are_montgomery, void* out_jacobian_host, void* stream);
 /* Split-MSM building blocks (the entry points below compose them): the un-normalised partial result of one range -- a

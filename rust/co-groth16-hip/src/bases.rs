@@ -33,9 +33,11 @@ impl Drop for DeviceBases {
 impl DeviceBases {
     /// Offset (in points) of `points` inside the uploaded query, if it is a sub-slice of it.
     pub fn offset_of<T>(&self, points: &[T]) -> Option<usize> {
-        let a = points.as_ptr() as usize;
+        self.offset_of_raw(points.as_ptr() as usize, points.len())
+    }
+    fn offset_of_raw(&self, a: usize, len: usize) -> Option<usize> {
         let end = self.host_base + self.len * self.stride;
-        (a >= self.host_base && a + points.len() * self.stride <= end && (a - self.host_base) % self.stride == 0)
+        (a >= self.host_base && a + len * self.stride <= end && (a - self.host_base) % self.stride == 0)
             .then(|| (a - self.host_base) / self.stride)
     }
     fn overlaps(&self, lo: usize, hi: usize) -> bool {
@@ -70,16 +72,15 @@ enum Check {
 
 impl DeviceBases {
     /// Compare the entry with `points` (a sub-slice of its address range starting at point `off`), reading only `points`.
-    fn check<T>(&self, points: &[T], off: usize) -> Check {
-        let base = points.as_ptr() as usize;
+    fn check(&self, base: usize, len: usize, off: usize) -> Check {
         let mut seen = false;
-        for &(i, h) in self.checkpoints.iter().filter(|(i, _)| *i >= off && *i < off + points.len()) {
+        for &(i, h) in self.checkpoints.iter().filter(|(i, _)| *i >= off && *i < off + len) {
             seen = true;
             if point_hash(base, i - off, self.stride) != h {
                 return Check::Different;
             }
         }
-        if seen || (points.is_empty() && self.len == 0) { Check::Same } else { Check::Unknown }
+        if seen || (len == 0 && self.len == 0) { Check::Same } else { Check::Unknown }
     }
 }
 
@@ -101,8 +102,17 @@ pub fn get_or_upload<P: Pairing, C: SWCurveConfig>(points: &[Affine<C>]) -> (Arc
 /// The same with the size of the LARGEST query of the proving key as the table-policy hint (all queries of a key must get the
 /// same (c, rows) for `csh_msm_multi_dev` to share one digit pass; `KeyGuard::new` passes it).
 pub fn get_or_upload_sized<P: Pairing, C: SWCurveConfig>(points: &[Affine<C>], key_points: usize) -> (Arc<DeviceBases>, usize) {
+    // SAFETY: `points` is a live slice of `size_of::<Affine<C>>()`-byte points for the duration of the call
+    unsafe { get_or_upload_raw(curve_id::<P>(), group_id::<C>(), points.as_ptr().cast(), points.len(), core::mem::size_of::<Affine<C>>(), key_points) }
+}
+
+/// The untyped core (co-noir's curves are not pairings: BN254 G1 and Grumpkin come in as `P: HonkCurve`): `len` points of `stride`
+/// bytes each at `ptr`, x then y as the first two coordinates (the flag byte behind them is ignored), on curve / group `curve` / `group`.
+/// # Safety
+/// `[ptr, ptr + len * stride)` must be a live slice the caller holds for the duration of the call.
+pub unsafe fn get_or_upload_raw(curve: i32, group: i32, ptr: *const u8, len: usize, stride: usize, key_points: usize) -> (Arc<DeviceBases>, usize) {
     let dev = current_device();
-    let stride = core::mem::size_of::<Affine<C>>();
+    let base_addr = ptr as usize;
     let mut cache = CACHE.lock();
     let mut stale = None;
     let mut cacheable = true;
@@ -110,8 +120,8 @@ pub fn get_or_upload_sized<P: Pairing, C: SWCurveConfig>(points: &[Affine<C>], k
         if b.device != dev {
             continue; // handles are per device: a thread bound to GPU 1 never gets GPU 0's copy
         }
-        if let Some(off) = b.offset_of(points) {
-            match if b.stride == stride { b.check(points, off) } else { Check::Different } {
+        if let Some(off) = b.offset_of_raw(base_addr, len) {
+            match if b.stride == stride { b.check(base_addr, len, off) } else { Check::Different } {
                 Check::Same => return (b.clone(), off),
                 Check::Different => stale = Some(i), // same addresses, other contents: the key this entry came from is gone
                 Check::Unknown => cacheable = false,  // too short to verify against the entry: upload it on its own, uncached
@@ -123,14 +133,12 @@ pub fn get_or_upload_sized<P: Pairing, C: SWCurveConfig>(points: &[Affine<C>], k
         cache.swap_remove(i);
     }
     // an entry of another stride or one that only partly overlaps the caller's range is stale by construction: evict it unread
-    let (lo, hi) = (points.as_ptr() as usize, points.as_ptr() as usize + points.len() * stride);
+    let (lo, hi) = (base_addr, base_addr + len * stride);
     if cacheable {
         cache.retain(|b| !(b.device == dev && b.overlaps(lo, hi)));
     }
     let mut handle: sys::CshBases = core::ptr::null_mut();
-    hip_ok(unsafe {
-        sys::csh_bases_upload(curve_id::<P>(), group_id::<C>(), points.as_ptr().cast(), points.len(), stride, &mut handle)
-    });
+    hip_ok(unsafe { sys::csh_bases_upload(curve, group, ptr.cast(), len, stride, &mut handle) });
     // Fixed-base tables, the library's own policy (csh_bases_table_policy; the C++ mirror's ProvingKey::build_tables asks the same
     // function). Tables are an optimisation: when they do not fit the device the MSM runs on the plain points.
     let (mut c, mut rows) = (0i32, 0i32);
@@ -143,8 +151,7 @@ pub fn get_or_upload_sized<P: Pairing, C: SWCurveConfig>(points: &[Affine<C>], k
             hip_ok(rc);
         }
     }
-    let base = points.as_ptr() as usize;
-    let b = Arc::new(DeviceBases { handle, device: dev, host_base: base, len: points.len(), stride, checkpoints: checkpoints_of(base, points.len(), stride) });
+    let b = Arc::new(DeviceBases { handle, device: dev, host_base: base_addr, len, stride, checkpoints: checkpoints_of(base_addr, len, stride) });
     if cacheable {
         cache.push(b.clone());
     }

@@ -45,6 +45,10 @@ impl HipDomain {
         check(unsafe { sys::csh_domain_create(curve, log_n, g, &mut raw) })?;
         Ok(Self { raw, size: 1usize << log_n })
     }
+    /// The C ABI handle (for sibling crates that call `csh_fft` / `csh_ifft` on it).
+    pub fn raw(&self) -> sys::CshDomain {
+        self.raw
+    }
     /// natural-order evaluations -> bit-reversed coefficients (scaled by 1/n); `S` = F, a Shamir share or a Rep3 share
     pub fn ifft_in_to_out<S>(&self, data: &mut [S]) {
         assert_eq!(data.len(), self.size);

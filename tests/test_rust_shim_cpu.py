@@ -14,7 +14,9 @@ import pytest
 REF = "/root/reference"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RUST = os.path.join(ROOT, "rust", "co-groth16-hip", "src")
-CRATES = {"co_groth16": "co-circom/co-groth16/src", "mpc_core": "mpc-core/src", "mpc_net": "mpc-net/src"}
+CRATES = {"co_groth16": "co-circom/co-groth16/src", "mpc_core": "mpc-core/src", "mpc_net": "mpc-net/src", "co_plonk": "co-circom/co-plonk/src",
+          "co_noir_common": "co-noir/co-noir-common/src"}
+SHIMS = ["co-groth16-hip", "co-plonk-hip", "co-noir-hip"]
 
 pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present on this box")
 
@@ -53,12 +55,15 @@ def _expand_use(path):
 
 def _shim_paths():
     paths = set()
-    for f in sorted(os.listdir(RUST)):
-        s = _strip_comments(open(os.path.join(RUST, f)).read())
-        for m in re.finditer(r"\buse\s+((?:co_groth16|mpc_core|mpc_net)\b[^;]*);", s):
-            paths.update(_expand_use(re.sub(r"\s+", " ", m.group(1))))
-        for m in re.finditer(r"\b((?:co_groth16|mpc_core|mpc_net)(?:::\w+)+)", s):  # fully qualified uses outside `use`
-            paths.add(m.group(1))
+    names = "|".join(CRATES)
+    for crate in SHIMS:
+        d = os.path.join(ROOT, "rust", crate, "src")
+        for f in sorted(os.listdir(d)):
+            s = _strip_comments(open(os.path.join(d, f)).read())
+            for m in re.finditer(r"\buse\s+((?:%s)\b[^;]*);" % names, s):
+                paths.update(_expand_use(re.sub(r"\s+", " ", m.group(1))))
+            for m in re.finditer(r"\b((?:%s)(?:::\w+)+)" % names, s):  # fully qualified uses outside `use`
+                paths.add(m.group(1))
     return sorted(p for p in paths if "::" in p)
 
 
@@ -123,7 +128,7 @@ def _resolve(path, depth=0):
 
 def test_every_reference_path_named_by_the_shim_is_public():
     paths = _shim_paths()
-    assert len(paths) >= 8, paths
+    assert len(paths) >= 25, paths
     for p in paths:
         assert _resolve(p), p
 
@@ -303,3 +308,67 @@ def test_circom_reduction_is_one_abi_call_through_the_public_surface():
     m = re.search(r"pub fn promote_to_trivial_share<F: PrimeField>\(id: PartyID, public_value: F\) -> FieldShare<F> \{(.*?)\n\}", ar, re.S)
     assert m and "PartyID::ID0 => Rep3PrimeFieldShare::new(public_value, F::zero())" in m.group(1)
     assert "PartyID::ID1 => Rep3PrimeFieldShare::new(F::zero(), public_value)" in m.group(1)
+
+
+# ---- seam 3: CircomPlonkProver / NoirUltraHonkProver implementors (rust/co-plonk-hip, rust/co-noir-hip) -----------------------------------
+SEAM3 = [("co-plonk-hip", "co-circom/co-plonk/src/mpc.rs", "CircomPlonkProver", ["local_mul_vec", "fft", "ifft", "msm_public_points_g1"],
+          [("Plain", "co-circom/co-plonk/src/mpc/plain.rs", "PlainPlonkDriver"), ("Rep3", "co-circom/co-plonk/src/mpc/rep3.rs", "Rep3PlonkDriver"),
+           ("Shamir", "co-circom/co-plonk/src/mpc/shamir.rs", "ShamirPlonkDriver")], "Hip%sPlonkDriver"),
+         ("co-noir-hip", "co-noir/co-noir-common/src/mpc/mod.rs", "NoirUltraHonkProver", ["local_mul_vec", "fft", "ifft", "msm_public_points"],
+          [("Plain", "co-noir/co-noir-common/src/mpc/plain.rs", "PlainUltraHonkDriver"), ("Rep3", "co-noir/co-noir-common/src/mpc/rep3.rs", "Rep3UltraHonkDriver"),
+           ("Shamir", "co-noir/co-noir-common/src/mpc/shamir.rs", "ShamirUltraHonkDriver")], "Hip%sUltraHonkDriver")]
+
+
+def _impl_block(text, struct):
+    i = text.index("for %s" % struct)
+    j = text.index("{", i)
+    depth, k = 0, j
+    while True:
+        depth += text[k] == "{"
+        depth -= text[k] == "}"
+        if depth == 0:
+            break
+        k += 1
+    h = text.rindex("impl", 0, i)
+    return text[h:j], text[j + 1:k]
+
+
+@pytest.mark.parametrize("crate,trait_file,trait,hot,drivers,pattern", SEAM3)
+def test_seam3_implementors_cover_the_trait_with_the_reference_signatures(crate, trait_file, trait, hot, drivers, pattern):
+    ref = _trait_methods(open(os.path.join(REF, trait_file)).read(), trait)
+    src = os.path.join(ROOT, "rust", crate, "src")
+    cold = _fn_params(_strip_comments(open(os.path.join(src, "cold.rs")).read()))
+    shim = _strip_comments(open(os.path.join(src, "drivers.rs")).read())
+    assert set(cold) == set(ref) - set(hot), (sorted(set(ref) - set(hot) - set(cold)), sorted(set(cold) - set(ref)))
+    for name, params in ref.items():
+        (want,) = params
+        if name in cold:
+            (have,) = cold[name]
+            assert len(have) == len(want) and all(h == w or w == "_" for h, w in zip(have, want)), (name, have, want)
+    for proto, ref_file, ref_struct in drivers:
+        hip = pattern % proto
+        head, body = _impl_block(shim, hip)
+        rhead, rbody = _impl_block(_strip_comments(open(os.path.join(REF, ref_file)).read()), ref_struct)
+        # same impl header (generic parameters and where clause), same associated types as the reference driver
+        norm = lambda t: re.sub(r"\s+", " ", t).strip().rstrip(",")
+        assert norm(head.replace(hip, "X")) == norm(rhead.replace(ref_struct, "X")), (hip, head, rhead)
+        assert sorted(norm(t) for t in re.findall(r"type \w+ = [^;]+;", body)) == sorted(norm(t) for t in re.findall(r"type \w+ = [^;]+;", rbody)), hip
+        assert "_cold_methods!(%s);" % ref_struct in body, hip
+        got = _fn_params(body)
+        assert set(got) == set(hot), (hip, sorted(got))
+        for name in hot:                       # the hand-written hot methods: the trait's parameter list
+            (want,) = ref[name]
+            (have,) = got[name]
+            assert len(have) == len(want) and all(h == w or h.lstrip("_") == w or w == "_" for h, w in zip(have, want)), (hip, name, have, want)
+
+
+def test_generated_delegations_are_up_to_date():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_rust_delegates", os.path.join(ROOT, "tools", "gen_rust_delegates.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    for src, trait, macro, hot, dst in gen.JOBS:
+        text = gen.strip_comments(open(os.path.join(REF, src)).read())
+        body = gen.emit_macro(macro, trait, gen.methods(gen.trait_body(text, trait)), set(hot))
+        have = open(os.path.join(ROOT, dst)).read()
+        assert have.endswith(body), dst + " is stale: run python tools/gen_rust_delegates.py"
