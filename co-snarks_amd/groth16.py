@@ -94,6 +94,38 @@ def share_file_roundtrip(curve: int, protocol: str, data: bytes):
     return bytes(out)[:rc], variant.value, npub.value, nwit.value
 
 
+def rep3_send_many(curve: int, items: np.ndarray, points: bool = False) -> bytes:
+    """Rep3NetworkExt::send_many payload (mpc-core/src/protocols/rep3/network.rs:103-109): items = Montgomery limbs of n field elements
+    (4 u64 each) or n G1 affine points in the C-ABI layout -> the bytes of the one message the reference puts on the wire."""
+    arr = np.ascontiguousarray(items, dtype=np.uint64)
+    per = (point_words(curve) if points else 4)
+    n = arr.size // per
+    cap = 16 + arr.nbytes
+    out = (C.c_uint8 * cap)()
+    fn = glib().cog16_rep3_wire
+    fn.restype = C.c_long
+    rc = fn(curve, 0, int(points), arr.ctypes.data_as(C.c_void_p), C.c_size_t(n), out, C.c_size_t(cap))
+    if rc < 0:
+        raise CoSnarksHipError(glib().cog16_last_error().decode())
+    return bytes(out)[:rc]
+
+
+def rep3_recv_many(curve: int, message: bytes, points: bool = False) -> np.ndarray:
+    """Rep3NetworkExt::recv_many (network.rs:152-156): one received message -> Montgomery limbs / C-ABI points."""
+    per = (point_words(curve) if points else 4)
+    out = np.zeros(max(1, len(message) // 8 + 8), dtype=np.uint64)
+    fn = glib().cog16_rep3_wire
+    fn.restype = C.c_long
+    rc = fn(curve, 1, int(points), message, C.c_size_t(len(message)), out.ctypes.data_as(C.c_void_p), C.c_size_t(out.nbytes))
+    if rc < 0:
+        raise CoSnarksHipError(glib().cog16_last_error().decode())
+    return out[:rc * per].copy()
+
+
+def point_words(curve: int) -> int:
+    return 8 if curve == 0 else 12     # G1 affine x || y in u64 words
+
+
 def public_inputs_json(curve: int, protocol: str, share_file: bytes) -> str:
     """The public-input JSON `generate-proof` writes (decimal strings, constant 1 skipped), from a `.shared` file."""
     out = C.create_string_buffer(64 + 80 * 4096)

@@ -106,7 +106,7 @@ inline void write_g1(std::vector<uint8_t>& out, const AffineT<Fq>& pt) {
   if (y_is_negative(pt.y)) out.back() |= 0x80;
 }
 template <class Fq>
-inline AffineT<Fq> read_g1(Reader& r) {
+inline AffineT<Fq> read_g1(Reader& r, bool check_sign_flag = true) {
   r.need(2 * sizeof(Fq));
   Fq x, y;
   memcpy(&x, r.p + r.off, sizeof(Fq));
@@ -117,8 +117,47 @@ inline AffineT<Fq> read_g1(Reader& r) {
   if (flags & 1) return AffineT<Fq>::inf();  // bit 6 of the last byte
   if (csh::limbs_geq<Fq::N>(x.l, Fq::Params::MOD) || csh::limbs_geq<Fq::N>(y.l, Fq::Params::MOD)) throw Error("ark-serialize: coordinate not canonical");
   AffineT<Fq> pt{x.to_mont(), y.to_mont()};
-  if (((flags >> 1) & 1) != (y_is_negative(pt.y) ? 1u : 0u)) throw Error("ark-serialize: y-sign flag does not match y");
+  if (check_sign_flag && ((flags >> 1) & 1) != (y_is_negative(pt.y) ? 1u : 0u)) throw Error("ark-serialize: y-sign flag does not match y");
   return pt;
+}
+
+// ---- Rep3NetworkExt::{send_many, recv_many} payloads (mpc-core/src/protocols/rep3/network.rs:103-109, 152-156) ----------------------------
+// What a GPU party has to put on / take off the wire to face two reference CPU parties: ONE `Network::send(to, Bytes)` per call whose
+// payload is `data.serialize_uncompressed()` of the slice -- ark-serialize's impl for `[T]`: the count as u64 little-endian, then every
+// item uncompressed -- and `recv_many` is `Vec::<F>::deserialize_uncompressed_unchecked(&data[..])` of one received message (Validate::No:
+// no curve / subgroup check; a field element >= p still fails, Fp::from_bigint; an uncompressed point's y-sign bit is not consulted).
+// `send_to` / `recv_from` / `send_next` / `broadcast` ... are the same with a one-item slice (:96-99, 140-149). The transports below
+// (TCP / TLS / QUIC length-delimited frames, mpc-net) carry these payloads opaquely and stay in the Rust host.
+template <class Fr>
+inline std::vector<uint8_t> send_many_fields(const std::vector<Fr>& data) {
+  std::vector<uint8_t> out;
+  out.reserve(8 + sizeof(Fr) * data.size());  // Vec::with_capacity(data.serialized_size(Compress::No))
+  write_vec(out, data);
+  return out;
+}
+template <class Fr>
+inline std::vector<Fr> recv_many_fields(const uint8_t* msg, size_t len) {
+  Reader r(msg, len);
+  std::vector<Fr> v = read_vec<Fr>(r);
+  // trailing bytes are not an error for ark's reader (it deserializes a prefix); a short message is
+  return v;
+}
+template <class Fq>
+inline std::vector<uint8_t> send_many_g1(const std::vector<AffineT<Fq>>& data) {  // curve points travel in affine form, uncompressed
+  std::vector<uint8_t> out;
+  out.reserve(8 + 2 * sizeof(Fq) * data.size());
+  write_u64(out, data.size());
+  for (auto& pt : data) write_g1(out, pt);
+  return out;
+}
+template <class Fq>
+inline std::vector<AffineT<Fq>> recv_many_g1(const uint8_t* msg, size_t len) {
+  Reader r(msg, len);
+  const uint64_t n = r.u64();
+  if (n > (r.n - r.off) / (2 * sizeof(Fq))) throw Error("ark-serialize: Vec length exceeds the input");
+  std::vector<AffineT<Fq>> v(n);
+  for (auto& pt : v) pt = read_g1<Fq>(r, /*check_sign_flag=*/false);
+  return v;
 }
 
 // snarkjs wtns container as the reference's Witness::from_reader consumes it; tolerant of zeroed section headers (the

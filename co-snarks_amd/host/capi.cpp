@@ -1054,6 +1054,56 @@ int cog16_ark_roundtrip(int curve, int mode, const void* in, size_t n, uint8_t* 
   }
 }
 
+// Rep3NetworkExt::{send_many, recv_many} payloads (arkwire.hpp). kind 0: field elements (Fr, Montgomery limbs on the C-ABI side), kind 1: G1
+// affine points (C-ABI layout). op 0 = send_many: `in` holds n items -> message bytes in `out`, returns the message length; op 1 =
+// recv_many: `in` holds a message of n BYTES -> items in `out` (cap in bytes), returns the item count. -1 on error.
+long cog16_rep3_wire(int curve, int op, int kind, const void* in, size_t n, void* out, size_t cap) {
+  try {
+    long result = -1;
+    auto run = [&](auto tag) {
+      using P = decltype(tag);
+      using Fr = typename P::Fr;
+      using Fq = typename P::Fq;
+      if (op == 0) {
+        std::vector<uint8_t> msg;
+        if (kind == 0) {
+          std::vector<Fr> v(n);
+          if (n) memcpy((void*)v.data(), in, sizeof(Fr) * n);
+          msg = ark::send_many_fields(v);
+        } else {
+          std::vector<AffineT<Fq>> v(n);
+          if (n) memcpy((void*)v.data(), in, sizeof(AffineT<Fq>) * n);
+          msg = ark::send_many_g1(v);
+        }
+        if (msg.size() > cap) throw Error("output buffer too small");
+        memcpy(out, msg.data(), msg.size());
+        result = (long)msg.size();
+      } else {
+        if (kind == 0) {
+          std::vector<Fr> v = ark::recv_many_fields<Fr>(static_cast<const uint8_t*>(in), n);
+          if (v.size() * sizeof(Fr) > cap) throw Error("output buffer too small");
+          if (!v.empty()) memcpy(out, v.data(), v.size() * sizeof(Fr));
+          result = (long)v.size();
+        } else {
+          std::vector<AffineT<Fq>> v = ark::recv_many_g1<Fq>(static_cast<const uint8_t*>(in), n);
+          if (v.size() * sizeof(AffineT<Fq>) > cap) throw Error("output buffer too small");
+          if (!v.empty()) memcpy(out, v.data(), v.size() * sizeof(AffineT<Fq>));
+          result = (long)v.size();
+        }
+      }
+    };
+    if (op != 0 && op != 1) throw Error("op must be 0 (send_many) or 1 (recv_many)");
+    if (kind != 0 && kind != 1) throw Error("kind must be 0 (field elements) or 1 (G1 affine points)");
+    if (curve == 0) run(Bn254{});
+    else if (curve == 1) run(Bls12_381{});
+    else throw Error("unknown curve");
+    return result;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+
 // Returns the domain size (entries per party in h_out) or -1. reduction: 0 CircomReduction, 1 LibSnarkReduction (needs
 // the C matrix); mode: 0 plain, 1 three Rep3 parties. CSR triples for a, b, c (c may be NULL for reduction 0).
 int cog16_witness_map(int curve, int reduction, int mode, const uint64_t* const row_ptr[3], const uint32_t* const col[3],
