@@ -127,7 +127,6 @@ class Ctx:
         B._check(self.L.csh_init(self.dev_index))
         self.stream = torch.cuda.current_stream().cuda_stream
         self.comm = None
-        self.hard_exit = False
         self.exchange = "single GPU"
         if self.world > 1:
             self._make_comm(args)
@@ -143,30 +142,11 @@ class Ctx:
                 if self.rank == 0:
                     uid = torch.tensor(list(B.comm_unique_id()), dtype=torch.uint8)
                 dist.broadcast(uid, 0)
-                # ncclCommInitRank is collective: if the fabric bootstrap wedges on one rank it wedges on all, and nothing can
-                # interrupt it. Run it on a daemon thread with a deadline; past it every rank falls back to the harness
-                # exchange (the flag is agreed below) and the process leaves through os._exit once the line is printed.
-                import threading
-                box = {}
-
-                def init():
-                    try:
-                        L = self.L
-                        B._check(L.csh_init(self.dev_index))        # the thread needs its own device binding
-                        box["comm"] = B.Comm.init_rank(bytes(uid.tolist()), self.world, self.rank)
-                    except Exception as e:  # noqa: BLE001
-                        box["err"] = repr(e)
-
-                th = threading.Thread(target=init, daemon=True)
-                th.start()
-                th.join(timeout=float(os.environ.get("BENCH_RCCL_INIT_TIMEOUT", "120")))
-                if th.is_alive():
-                    ok, err = 0, "ncclCommInitRank did not return within the deadline"
-                    self.hard_exit = True
-                elif "err" in box:
-                    ok, err = 0, box["err"]
-                else:
-                    self.comm = box["comm"]
+                # ncclCommInitRank is collective: the library builds the communicator non-blocking and polls it against a deadline
+                # (csh_comm_init_rank, tune comm_timeout_ms), so a wedged bootstrap comes back as an error on every rank and the ranks
+                # agree below to fall back to the harness exchange
+                B.tune_set("comm_timeout_ms", int(float(os.environ.get("BENCH_RCCL_INIT_TIMEOUT", "120")) * 1000))
+                self.comm = B.Comm.init_rank(bytes(uid.tolist()), self.world, self.rank)
             except Exception as e:  # noqa: BLE001
                 ok, err = 0, repr(e)
         flag = torch.tensor([ok if want_rccl else 0], dtype=torch.int32)
@@ -800,8 +780,6 @@ def main():
         }
         print(json.dumps(line))
     sys.stdout.flush()
-    if cx.hard_exit:          # a wedged RCCL bootstrap thread is still alive: skip interpreter teardown
-        os._exit(0)
     if cx.comm is not None:
         cx.comm.destroy()
     if world > 1:

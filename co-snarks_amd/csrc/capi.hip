@@ -116,6 +116,7 @@ static const TuneEntry kTune[] = {
     {"ntt_variant", "CSH_NTT_VARIANT", &Tune::ntt_variant},
     {"h_unfused", "CSH_H_UNFUSED", &Tune::h_unfused},
     {"host_populate", "CSH_HOST_POPULATE", &Tune::host_populate},
+    {"comm_timeout_ms", "CSH_COMM_TIMEOUT_MS", &Tune::comm_timeout_ms},
 };
 Tune& tune() {
   static Tune* t = [] {

@@ -147,6 +147,7 @@ struct Tune {
   std::atomic<int> allow_unmasked_rep3{0};  // Rep3 products without the re-randomising masks: refused unless set (tests)
   std::atomic<int> ntt_variant{0};
   std::atomic<int> h_unfused{0};          // Groth16 h pipeline: 1 = the unfused step-by-step sequence (A/B, tests)
+  std::atomic<int> comm_timeout_ms{120000};  // deadline of a non-blocking RCCL communicator's construction / pending operation (0 = blocking calls)
   std::atomic<int> host_populate{4};      // threads populating a large D2H destination's pages before the copy (0 = off)
 };
 Tune& tune();

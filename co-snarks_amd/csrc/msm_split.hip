@@ -18,7 +18,12 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "msm_impl.hpp"
@@ -41,6 +46,11 @@ struct Rccl {
   void* lib = nullptr;
   int (*GetUniqueId)(NcclId*) = nullptr;
   int (*CommInitRank)(void**, int, NcclId, int) = nullptr;
+  // optional (RCCL >= 2.14 semantics): non-blocking communicator construction
+  int (*CommInitRankConfig)(void**, int, NcclId, int, void*) = nullptr;
+  int (*CommGetAsyncError)(void*, int*) = nullptr;
+  int (*CommAbort)(void*) = nullptr;
+  int (*GetVersion)(int*) = nullptr;
   int (*CommInitAll)(void**, int, const int*) = nullptr;
   int (*CommDestroy)(void*) = nullptr;
   int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
@@ -83,7 +93,12 @@ static Rccl* rccl() {
     if (!ok) {
       dlclose(x->lib);
       x->lib = nullptr;
+      return x;
     }
+    x->CommInitRankConfig = reinterpret_cast<decltype(x->CommInitRankConfig)>(dlsym(x->lib, "ncclCommInitRankConfig"));
+    x->CommGetAsyncError = reinterpret_cast<decltype(x->CommGetAsyncError)>(dlsym(x->lib, "ncclCommGetAsyncError"));
+    x->CommAbort = reinterpret_cast<decltype(x->CommAbort)>(dlsym(x->lib, "ncclCommAbort"));
+    x->GetVersion = reinterpret_cast<decltype(x->GetVersion)>(dlsym(x->lib, "ncclGetVersion"));
     return x;
   }();
   return r;
@@ -108,7 +123,22 @@ static Rccl* rccl() {
 // the largest partial buffer of any group (BLS12-381 G2): communicator buffers are sized once for it
 constexpr size_t MAX_PARTIAL_BYTES = sizeof(PartialHeader) + 2 * 192 * (size_t)MAX_WINDOWS;
 
+// ncclConfig_t as the public header declares it (rccl.h, ncclConfig_v22700; fields are only ever appended and the library reads `size`
+// bytes, padding the rest with its defaults): used for ONE attribute, blocking = 0.
+struct NcclConfig {
+  size_t size;
+  unsigned int magic, version;
+  int blocking, cgaClusterSize, minCTAs, maxCTAs;
+  const char* netName;
+  int splitShare, trafficClass;
+  const char* commName;
+  int collnetEnable, CTAPolicy, shrinkShare, nvlsCTAs;
+};
+constexpr int NCCL_IN_PROGRESS = 7;          // ncclResult_t ncclInProgress
+constexpr int NCCL_UNDEF_INT = INT32_MIN;    // NCCL_CONFIG_UNDEF_INT
+
 struct Comm {
+  bool nonblocking = false;  // built with blocking = 0: every RCCL call on it may return ncclInProgress and is then polled
   void* nccl = nullptr;  // ncclComm_t; nullptr for a 1-rank communicator made without RCCL
   int rank = 0, nranks = 1, device = 0;
   char* part_dev = nullptr;    // this rank's partial
@@ -127,6 +157,26 @@ static void comm_release(Comm* c) {
   if (c->gather_dev) (void)hipFree(c->gather_dev);
   if (c->gather_host) (void)hipHostFree(c->gather_host);
   delete c;
+}
+
+// Poll a non-blocking communicator until its pending operation has finished, failed or `timeout_ms` has passed (<= 0: no deadline).
+// -> the final ncclResult_t, or ncclInProgress on a timeout.
+static int comm_wait(Rccl* R, void* nccl, long timeout_ms) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    int st = 0;
+    const int rc = R->CommGetAsyncError(nccl, &st);
+    if (rc != 0) return rc;
+    if (st != NCCL_IN_PROGRESS) return st;
+    if (timeout_ms > 0 && std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() > timeout_ms) return NCCL_IN_PROGRESS;
+    std::this_thread::sleep_for(std::chrono::microseconds(200));
+  }
+}
+// ncclAllGather on a communicator of either kind
+static int comm_all_gather(Rccl* R, Comm* c, const void* send, void* recv, size_t bytes, hipStream_t st) {
+  int rc = R->AllGather(send, recv, bytes, NCCL_UINT8, c->nccl, st);
+  if (rc == NCCL_IN_PROGRESS && c->nonblocking) rc = comm_wait(R, c->nccl, tune().comm_timeout_ms.load(std::memory_order_relaxed));
+  return rc;
 }
 
 static int split_args(const Bases* B, size_t offset, size_t n, const void* scalars) {
@@ -177,7 +227,76 @@ int csh_comm_init_rank(const uint8_t id[CSH_COMM_ID_BYTES], int nranks, int rank
     }
     NcclId nid;
     memcpy(&nid, id, sizeof nid);
-    const int rc = R->CommInitRank(&c->nccl, nranks, nid, rank);
+    // ncclCommInitRank is collective and cannot be interrupted: a rank whose peers never arrive (or a fabric bootstrap that wedges)
+    // would hang its host for good. The construction therefore runs on a helper thread and the caller waits for it against a deadline
+    // -- tune "comm_timeout_ms", default 120 s, 0 = call it on this thread as before. Past the deadline the caller gets an error it
+    // can act on (fall back to its own exchange) and the helper is left behind: if the bootstrap ever completes it tears the
+    // communicator down itself. (RCCL's own non-blocking construction -- ncclCommInitRankConfig with blocking = 0 polled through
+    // ncclCommGetAsyncError -- is what the helper uses where the symbols exist, but on this stack (RCCL 2.27.7, ROCm 7.2) that call
+    // itself does not return while a peer is missing, with or without ncclCommAbort: profiles/r04_s_rccl_deadline.log. One rank
+    // cannot wait for anybody and is built inline.)
+    const long timeout_ms = tune().comm_timeout_ms.load(std::memory_order_relaxed);
+    struct Job {
+      std::mutex mu;
+      std::condition_variable cv;
+      bool done = false, abandoned = false;
+      int rc = 0;
+      void* nccl = nullptr;
+      bool nonblocking = false;
+    };
+    auto build = [R, nid, nranks, rank](void** out_comm, bool* nonblocking) -> int {
+      int ver = 0;
+      if (R->CommInitRankConfig && R->CommGetAsyncError && R->GetVersion && R->GetVersion(&ver) == 0) {
+        NcclConfig cfg;
+        cfg.size = sizeof(NcclConfig);
+        cfg.magic = 0xcafebeef;
+        cfg.version = (unsigned)ver;
+        cfg.blocking = 0;
+        cfg.cgaClusterSize = cfg.minCTAs = cfg.maxCTAs = NCCL_UNDEF_INT;
+        cfg.netName = nullptr;
+        cfg.splitShare = cfg.trafficClass = NCCL_UNDEF_INT;
+        cfg.commName = nullptr;
+        cfg.collnetEnable = cfg.CTAPolicy = cfg.shrinkShare = cfg.nvlsCTAs = NCCL_UNDEF_INT;
+        int rc = R->CommInitRankConfig(out_comm, nranks, nid, rank, &cfg);
+        if (rc == NCCL_IN_PROGRESS || (rc == 0 && *out_comm)) rc = comm_wait(R, *out_comm, 0);
+        *nonblocking = rc == 0;
+        return rc;
+      }
+      *nonblocking = false;
+      return R->CommInitRank(out_comm, nranks, nid, rank);
+    };
+    int rc = 0;
+    if (timeout_ms <= 0 || nranks == 1) {
+      rc = build(&c->nccl, &c->nonblocking);
+    } else {
+      auto job = std::make_shared<Job>();
+      const int device = c->device;
+      std::thread([job, build, device, R] {
+        void* comm = nullptr;
+        bool nb = false;
+        int r = hipSetDevice(device) == hipSuccess ? build(&comm, &nb) : 1;
+        std::unique_lock<std::mutex> lk(job->mu);
+        if (job->abandoned) {  // nobody is waiting any more: the communicator is ours to take down
+          lk.unlock();
+          if (r == 0 && comm) (void)R->CommDestroy(comm);
+          return;
+        }
+        job->rc = r, job->nccl = comm, job->nonblocking = nb, job->done = true;
+        job->cv.notify_all();
+      }).detach();
+      std::unique_lock<std::mutex> lk(job->mu);
+      if (!job->cv.wait_for(lk, std::chrono::milliseconds(timeout_ms), [&] { return job->done; })) {
+        job->abandoned = true;
+        lk.unlock();
+        delete c;
+        set_error("csh_comm_init_rank(rank %d of %d): the communicator did not come up within %ld ms (csh_tune_set(\"comm_timeout_ms\", ..)); "
+                  "the construction was abandoned", rank, nranks, timeout_ms);
+        return CSH_ERR_HIP;
+      }
+      rc = job->rc;
+      c->nccl = job->nccl;
+      c->nonblocking = job->nonblocking;
+    }
     if (rc != 0) {
       delete c;
       set_error("ncclCommInitRank(rank %d of %d) failed: %s", rank, nranks, R->GetErrorString(rc));
@@ -270,7 +389,7 @@ int csh_msm_split_rank_dev(csh_comm_t comm, csh_bases_t bases, size_t offset, si
   const char* src = c->part_dev;
   if (c->nranks > 1) {
     Rccl* R = rccl();
-    CSH_NCCL(R, R->AllGather(c->part_dev, c->gather_dev, pb, NCCL_UINT8, c->nccl, st));
+    CSH_NCCL(R, comm_all_gather(R, c, c->part_dev, c->gather_dev, pb, st));
     src = c->gather_dev;
   }
   CSH_HIP(hipMemcpyAsync(c->gather_host, src, pb * (size_t)c->nranks, hipMemcpyDeviceToHost, st));
@@ -387,7 +506,7 @@ int csh_msm_split(const csh_bases_t* bases, const size_t* offsets, const size_t*
         CSH_NCCL(R, R->GroupStart());
         for (size_t i = 0; i < k; ++i) {
           Comm* c = reinterpret_cast<Comm*>(comms[i]);
-          const int rcg = R->AllGather(c->part_dev, c->gather_dev, pb, NCCL_UINT8, c->nccl, parts[i].st);
+          const int rcg = comm_all_gather(R, c, c->part_dev, c->gather_dev, pb, parts[i].st);
           if (rcg != 0) {
             (void)R->GroupEnd();
             set_error("ncclAllGather(part %zu) failed: %s", i, R->GetErrorString(rcg));

@@ -162,7 +162,11 @@ int csh_msm_partial_dev(csh_bases_t bases, size_t offset, size_t n, const uint64
 typedef struct csh_comm_s* csh_comm_t;
 /* One process (or thread) per GPU: rank 0 draws an id (ncclGetUniqueId), ships the 128 bytes to the other ranks by whatever
  * channel the host has, every rank calls csh_comm_init_rank on the thread bound (csh_init) to its GPU. nranks == 1 with
- * id == NULL makes a local communicator without loading RCCL. A communicator is used by one thread at a time. */
+ * id == NULL makes a local communicator without loading RCCL. A communicator is used by one thread at a time.
+ * ncclCommInitRank is collective and cannot be interrupted, so with more than one rank the construction runs on a helper thread and the
+ * caller waits for it against a deadline -- csh_tune_set("comm_timeout_ms", ms), default 120000, 0 = construct on the calling thread: a
+ * rank whose peers never arrive gets CSH_ERR_HIP with "did not come up within ..." instead of a hang (the abandoned helper takes the
+ * communicator down itself if the bootstrap ever completes). */
 int csh_comm_unique_id(uint8_t id[CSH_COMM_ID_BYTES]);
 int csh_comm_init_rank(const uint8_t id[CSH_COMM_ID_BYTES], int nranks, int rank, csh_comm_t* out);
 /* One process driving `ndev` distinct GPUs (ncclCommInitAll): out[i] = rank i on devices[i]. */

@@ -4,6 +4,7 @@ HOST / RCCL exchange) and `csh_comm_init_rank` + `csh_msm_split_rank_dev` (one r
 share device 0 (the exchange code is the same; RCCL runs with one rank); the multi-rank exchange is covered on CPU by
 tests/test_distributed_cpu.py and measured by the driver's 1/2/4/8-GPU bench."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -143,9 +144,39 @@ def test_rccl_rank_path_with_one_rank(gpu, curve, group):
     dsc.free()
 
 
+def test_comm_init_deadline_and_blocking_fallback(gpu):
+    """csh_comm_init_rank with more than one rank runs the (uninterruptible, collective) construction on a helper thread and waits for
+    it against tune comm_timeout_ms: a rank whose peer never arrives (rank 0 of 2, nobody else calls) gets an error at the deadline
+    instead of hanging for good, and the library stays usable. Run in a subprocess that leaves through os._exit: the abandoned
+    bootstrap thread of that process is still waiting for its peer. comm_timeout_ms = 0 constructs on the calling thread as before."""
+    import subprocess
+    import sys
+    G = cv.BN254_G1
+    F = H.FR["bn254"]
+    r = H.rng(11)
+    n = 300
+    pts = H.rand_points(G, n, r)
+    sc = H.rand_elems(F, n, r)
+    want = G.msm(pts, sc)
+    bases = gpu.Bases(0, 0, cv.pack_points(G, pts))
+    dsc = gpu.DeviceBuffer.from_host(H.pack(F, sc))
+    for timeout_ms in (0, 60000):
+        with gpu.tuned(comm_timeout_ms=timeout_ms):
+            comm = gpu.Comm.init_rank(gpu.bindings.comm_unique_id(), 1, 0)
+            assert G.eq(H.jac_to_affine(G, comm.msm_split_rank_dev(bases, dsc, n)), want)
+            comm.destroy()
+    bases.free()
+    dsc.free()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "experiments", "rccl_deadline_probe.py"), "1"], capture_output=True, text=True, timeout=120)
+    out = p.stdout
+    assert "did not come up within 2000 ms" in out and "error after 2." in out, (out, p.stderr[-500:])
+    assert "ok (0, 1, 0)" in out and out.rstrip().endswith("done"), out                 # a one-rank communicator right after the abandoned one
+
+
 def test_comm_created_on_a_helper_thread(gpu):
-    """bench.py builds the RCCL communicator on a daemon thread (so that a wedged fabric bootstrap cannot hang the rank) and
-    uses it from the main thread: the communicator and its buffers must not depend on the creating thread's stream lane."""
+    """A communicator built on one host thread and used from another (what a host with a bootstrap thread does): the communicator and
+    its buffers must not depend on the creating thread's stream lane."""
     import threading
     G = cv.BN254_G1
     F = H.FR["bn254"]
