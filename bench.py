@@ -55,6 +55,21 @@ SCALAR_MODULUS = {
 }
 
 
+def ge_modulus(torch, v, modulus):
+    """Row-wise (v >= modulus) for n x 4 little-endian u64 limbs held as int64 bit patterns. Unsigned limb order is mapped onto signed
+    order on BOTH sides by subtracting 2^63: the tensor limb u becomes u ^ (1 << 63) = u - 2^63 as a signed value, the modulus limb m
+    becomes m - 2^63 (the top limb of a < 2^255 modulus is below 2^63 and compares as it is)."""
+    m = [(modulus >> (64 * i)) & (2**64 - 1) for i in range(4)]
+    assert m[3] < (1 << 63)
+    flip = -(1 << 63)
+    ms = [x - (1 << 63) if i < 3 else x for i, x in enumerate(m)]
+    ge = torch.ones(v.shape[0], dtype=torch.bool, device=v.device)     # equal so far => (v >= m) holds on the empty suffix
+    for i in range(4):                                                 # from the least significant limb up
+        x = v[:, i] ^ flip if i < 3 else v[:, i]
+        ge = (x > ms[i]) | ((x == ms[i]) & ge)
+    return ge
+
+
 def uniform_scalars(torch, dev, n, modulus, seed):
     """n x 4 little-endian u64 limbs (as int64 bit patterns), uniform in [0, modulus) by rejection sampling (SURVEY 8d config 2:
     "random scalars"): every limb carries 64 random bits, the top limb as many as the modulus has, draws >= modulus are redrawn.
@@ -62,9 +77,6 @@ def uniform_scalars(torch, dev, n, modulus, seed):
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
     top_bits = modulus.bit_length() - 192
-    m = [(modulus >> (64 * i)) & (2**64 - 1) for i in range(4)]
-    flip = -(1 << 63)                     # x ^ flip maps unsigned order onto signed order
-    ms = [((x ^ (1 << 63)) - (1 << 63)) if i < 3 else x for i, x in enumerate(m)]   # flipped signed images of the modulus limbs (top limb < 2^63 as is)
 
     def draw(k):
         lo = torch.randint(0, 1 << 32, (k, 4), dtype=torch.int64, device=dev, generator=g)
@@ -73,19 +85,12 @@ def uniform_scalars(torch, dev, n, modulus, seed):
         v[:, 3] = (v[:, 3] >> (64 - top_bits)) & ((1 << top_bits) - 1)     # logical shift: top_bits random bits
         return v
 
-    def ge_modulus(v):
-        ge = torch.ones(v.shape[0], dtype=torch.bool, device=dev)      # equal so far => (v >= m) holds on the empty suffix
-        for i in range(4):                                             # from the least significant limb up
-            x = v[:, i] ^ flip if i < 3 else v[:, i]
-            ge = (x > ms[i]) | ((x == ms[i]) & ge)
-        return ge
-
     sc = draw(n)
-    bad = ge_modulus(sc)
+    bad = ge_modulus(torch, sc, modulus)
     while bool(bad.any()):
         idx = bad.nonzero().flatten()
         sc[idx] = draw(idx.numel())
-        bad = ge_modulus(sc)
+        bad = ge_modulus(torch, sc, modulus)
     return sc
 
 

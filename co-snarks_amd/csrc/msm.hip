@@ -106,25 +106,30 @@ int csh_bases_len(csh_bases_t bases, size_t* n) {
   *n = reinterpret_cast<Bases*>(bases)->n;
   return CSH_OK;
 }
-// A copy of a handle (points and fixed-base tables, already in the stored encoding) on another GPU: device-to-device, no host
-// staging and no re-encoding. The calling thread's device binding is restored.
-int csh_bases_clone(csh_bases_t src, int device, csh_bases_t* out) {
+// A copy of a handle, or of the range [offset, offset + n) of it (points and the matching columns of every fixed-base table row, already
+// in the stored encoding) on another GPU: device-to-device, no host staging and no re-encoding. The calling thread's device binding is
+// restored. A range clone is its own handle of n bases: point i of the clone is point offset + i of the source.
+int csh_bases_clone_range(csh_bases_t src, size_t offset, size_t n, int device, csh_bases_t* out) {
   CSH_REQUIRE(src && out, "NULL argument");
   const Bases* S = reinterpret_cast<const Bases*>(src);
+  CSH_REQUIRE(offset <= S->n && n <= S->n - offset, "csh_bases_clone_range: offset + n exceeds the number of bases");
   int ndev = 0, cur = 0;
   CSH_HIP(hipGetDeviceCount(&ndev));
   CSH_REQUIRE(device >= 0 && device < ndev, "device out of range");
   CSH_HIP(hipGetDevice(&cur));
   Bases* B = new Bases(*S);
   B->device = device;
+  B->n = n;
   B->points = nullptr;
   B->table = nullptr;
-  const size_t pbytes = S->n * S->point_bytes, tbytes = S->table ? pbytes * (size_t)S->table_W : 0;
+  const size_t pb = S->point_bytes, pbytes = n * pb, rows = S->table ? (size_t)S->table_W : 0;
+  if (!rows) B->table_c = B->table_W = 0;
   hipError_t e = hipSetDevice(device);
   if (e == hipSuccess && pbytes) e = hipMalloc(&B->points, pbytes);
-  if (e == hipSuccess && tbytes) e = hipMalloc(&B->table, tbytes);
-  if (e == hipSuccess && pbytes) e = hipMemcpyPeer(B->points, device, S->points, S->device, pbytes);
-  if (e == hipSuccess && tbytes) e = hipMemcpyPeer(B->table, device, S->table, S->device, tbytes);
+  if (e == hipSuccess && pbytes && rows) e = hipMalloc(&B->table, pbytes * rows);
+  if (e == hipSuccess && pbytes) e = hipMemcpyPeer(B->points, device, static_cast<const char*>(S->points) + offset * pb, S->device, pbytes);
+  for (size_t k = 0; e == hipSuccess && pbytes && k < rows; ++k)  // row k of the table: table[k * n + i]
+    e = hipMemcpyPeer(static_cast<char*>(B->table) + k * pbytes, device, static_cast<const char*>(S->table) + (k * S->n + offset) * pb, S->device, pbytes);
   if (e == hipSuccess) e = hipDeviceSynchronize();
   if (e == hipSuccess && S->device != device) {  // and the source side of the copies
     e = hipSetDevice(S->device);
@@ -136,11 +141,15 @@ int csh_bases_clone(csh_bases_t src, int device, csh_bases_t* out) {
     if (B->points) (void)hipFree(B->points);
     if (B->table) (void)hipFree(B->table);
     delete B;
-    set_error("csh_bases_clone to device %d failed: %s", device, hipGetErrorString(e));
+    set_error("csh_bases_clone_range to device %d failed: %s", device, hipGetErrorString(e));
     return oom ? CSH_ERR_OOM : CSH_ERR_HIP;
   }
   *out = reinterpret_cast<csh_bases_t>(B);
   return CSH_OK;
+}
+int csh_bases_clone(csh_bases_t src, int device, csh_bases_t* out) {
+  CSH_REQUIRE(src && out, "NULL argument");
+  return csh_bases_clone_range(src, 0, reinterpret_cast<const Bases*>(src)->n, device, out);
 }
 int csh_bases_free(csh_bases_t bases) {
   if (!bases) return CSH_OK;

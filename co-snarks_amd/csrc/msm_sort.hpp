@@ -30,7 +30,13 @@ constexpr uint32_t DIG_ZERO = 0xFFFFu;
 constexpr int MAX_WINDOWS = 128;
 
 struct SortBuffers {
-  uint32_t* hist;      // [W][NB+2] scratch (zeroed by the caller)
+  // [W][NB+2] scratch. Contract: CONSUMED AND LEFT DIRTY. k_msm_colscan rewrites every entry on every call (which is why
+  // nothing zeroes it between calls: colscan must always run before scan), k_msm_scan turns it into exclusive starts, and the two-level
+  // scatter (k_msm_scatter_l2t) then uses it as the buckets' write cursors, advanced with global atomics -- after a call it holds
+  // end-of-bucket positions. Consequence of the atomic reservation: the ORDER of the entries inside a bucket, hence the order of the
+  // additions in k_msm_accum, varies from run to run (same group element, different device intermediates); the per-partition
+  // level 2 (tune msm_variant bit 5) is the deterministic form kept for debugging.
+  uint32_t* hist;
   uint32_t* start;     // [W][NB+2] out: first sorted slot per bucket; [NB+1] = entries of the window
   uint32_t* nlanes;    // [MAX_WINDOWS] out: ceil(entries / L) per window
   uint32_t* sorted;    // [W][n] out: (point index | sign << 31) in bucket order

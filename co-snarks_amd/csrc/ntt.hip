@@ -14,6 +14,8 @@
 // the butterflies' products run with the pinned multiply-add order (field29.hpp): -5.5 % per transform, 52-61 VGPRs as before
 #define CSH_PIN_MADS 3
 #include <stdlib.h>
+
+#include <mutex>
 #include <string.h>
 #include <type_traits>
 
@@ -581,6 +583,29 @@ static int plan_passes(int L, int ncomp_log, Pass* out) {
   return np;
 }
 
+// the natural-order twiddle tables of the 32-bit pass, (re)built when that pass is asked for on a domain that has released them
+template <class F>
+static int plain_tables(const Domain* cd) {
+  static std::mutex mu;
+  std::lock_guard<std::mutex> g(mu);
+  Domain* d = const_cast<Domain*>(cd);
+  if (d->tw_fwd && d->tw_inv) return CSH_OK;
+  const size_t half = d->n / 2 ? d->n / 2 : 1;
+  void *f = nullptr, *i = nullptr;
+  if (hipMalloc(&f, half * sizeof(F)) != hipSuccess || hipMalloc(&i, half * sizeof(F)) != hipSuccess) {
+    if (f) (void)hipFree(f);
+    set_error("hipMalloc of twiddle tables failed");
+    return CSH_ERR_OOM;
+  }
+  hipStream_t st = resolve_stream(nullptr);
+  hipLaunchKernelGGL((k_powers<F, false>), dim3(grid_for((half + POW_CHUNK - 1) / POW_CHUNK, 256)), dim3(256), 0, st, (F*)f, f_from_words<F>(d->gen), half, 0);
+  hipLaunchKernelGGL((k_powers<F, false>), dim3(grid_for((half + POW_CHUNK - 1) / POW_CHUNK, 256)), dim3(256), 0, st, (F*)i, f_from_words<F>(d->gen_inv), half, 0);
+  CSH_HIP(hipStreamSynchronize(st));
+  d->tw_fwd = f;
+  d->tw_inv = i;
+  return CSH_OK;
+}
+
 template <class F>
 static int run_ntt(const Domain* d, F* data, uint32_t ncomp, bool dif, hipStream_t st, const F* scale_tbl = nullptr) {
   const int L = (int)d->log_n;
@@ -594,6 +619,7 @@ static int run_ntt(const Domain* d, F* data, uint32_t ncomp, bool dif, hipStream
     return CSH_ERR_INVALID;
   }
   using LZ = typename LazyOf<F>::type;
+  if (!use_lazy && !(d->tw_fwd && d->tw_inv)) CSH_TRY(plain_tables<F>(d));
   const F* tw = reinterpret_cast<const F*>(use_lazy ? (dif ? d->tw_inv_lazy : d->tw_fwd_lazy) : (dif ? d->tw_inv : d->tw_fwd));
   F scale = f_from_words<F>(use_lazy ? d->n_inv_lazy : d->n_inv);
   const int NTT_THREADS_MAX = [] {
@@ -763,6 +789,14 @@ static int create_domain_t(csh_curve_t curve, uint32_t log_n, const uint64_t* ge
     memcpy(d->n_inv_lazy, &nl, 32);
   }
   hipError_t e3 = hipStreamSynchronize(st);
+  // Footprint: the staged, pre-sliced tables are (2^L - 1) x 36 bytes per direction (2^24: 1.2 GB for both, 2^26: 4.8 GB);
+  // the natural tables they were made from (2^(L-1) x 32 bytes per direction) are only read by the 32-bit pass (CSH_NTT_LAZY=0, A/B
+  // runs), so they are released here and rebuilt on demand (plain_tables) -- a third less per cached domain.
+  if (e3 == hipSuccess && e4 == hipSuccess && e5 == hipSuccess && tune().ntt_lazy.load(std::memory_order_relaxed) != 0) {
+    (void)hipFree(d->tw_fwd);
+    (void)hipFree(d->tw_inv);
+    d->tw_fwd = d->tw_inv = nullptr;
+  }
   if (e3 != hipSuccess || e4 != hipSuccess || e5 != hipSuccess) {
     set_error("twiddle generation failed: %s", hipGetErrorString(e3 != hipSuccess ? e3 : (e4 != hipSuccess ? e4 : e5)));
     (void)hipFree(d->tw_fwd);

@@ -522,7 +522,7 @@ struct CoGroth16 {
         for (int i = 0; i < 4; ++i) {
           if (!pkey.slot_has(slot, qs[i])) continue;
           hs[k] = pkey.handle_for(slot, qs[i]);
-          offs[k] = (qs[i] == PK::Q_L ? 0 : 1 + pub_len) + lo;
+          offs[k] = pkey.offset_in(slot, qs[i], (qs[i] == PK::Q_L ? 0 : 1 + pub_len) + lo, hi - lo);
           outs[k] = res[i];
           ++k;
         }
@@ -556,7 +556,7 @@ struct CoGroth16 {
               const DeviceScalars h_l(hi - lo);
               check(csh_memcpy_peer(h_l.dev, dev, static_cast<const char*>(h_dev.dev) + lo * sizeof(Half), h_dev.device, (hi - lo) * sizeof(Half), nullptr),
                     "csh_memcpy_peer");
-              outs_by_slot[sl].h = T::template msm_public_points_hs<Fq>(BasesView{pkey.handle_for(sl, PK::Q_H), lo, hi - lo}, h_l);
+              outs_by_slot[sl].h = T::template msm_public_points_hs<Fq>(BasesView{pkey.handle_for(sl, PK::Q_H), pkey.offset_in(sl, PK::Q_H, lo, hi - lo), hi - lo}, h_l);
             }
           }
         }));

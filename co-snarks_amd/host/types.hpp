@@ -331,6 +331,9 @@ struct ProvingKey {
     int mode = PLACE_BY_QUERY;
     int slot[5] = {0, 0, 0, 0, 0};                    // BY_QUERY: the slot of each query
     std::vector<std::array<csh_bases_t, 5>> handles;  // [slot][query]; slot 0 = the home handles (not owned)
+    // BY_RANGE: a slot's clone holds only the slot's range of the query: base[slot][q] = index (in the home query) of the clone's
+    // first point, count[slot][q] = its length (slot 0 and BY_QUERY clones: 0 and the whole query)
+    std::vector<std::array<size_t, 5>> base, count;
   } placement;
   size_t query_size(int q) const {
     return q == Q_A ? a_query.size() : q == Q_B1 ? b_g1_query.size() : q == Q_B2 ? b_g2_query.size() : q == Q_L ? l_query.size() : h_query.size();
@@ -341,6 +344,13 @@ struct ProvingKey {
   bool placed() const { return placement.devices.size() > 1; }
   size_t slots() const { return placed() ? placement.devices.size() : 1; }
   csh_bases_t handle_for(size_t slot, int q) const { return slot == 0 || !placed() ? home_handle(q) : placement.handles[slot][q]; }
+  // offset of home-query point `index` inside the handle handle_for(slot, q); throws if the slot's clone does not hold [index, index + n)
+  size_t offset_in(size_t slot, int q, size_t index, size_t n) const {
+    if (slot == 0 || !placed() || placement.base.empty()) return index;
+    const size_t b = placement.base[slot][q], c = placement.count[slot][q];
+    if (index < b || index + n > b + c) throw Error("placement: the slot's clone of the query does not hold the requested range");
+    return index - b;
+  }
   // does `slot` work on query q, and on which part [lo, hi) of an index space of n entries?
   bool slot_has(size_t slot, int q) const {
     if (!placed()) return slot == 0;
@@ -359,6 +369,8 @@ struct ProvingKey {
       for (auto& c : placement.handles[sl])
         if (c) csh_bases_free(c);
     placement.handles.clear();
+    placement.base.clear();
+    placement.count.clear();
     for (auto& sl : placement.slot) sl = 0;
     placement.devices.clear();
   }
@@ -370,18 +382,41 @@ struct ProvingKey {
     for (int q = 0; q < 5; ++q) sizes[q] = home_handle(q) ? query_size(q) : 0;
     placement.mode = plan_placement(sizes, ns, mode, placement.slot);
     placement.handles.assign(ns, std::array<csh_bases_t, 5>{nullptr, nullptr, nullptr, nullptr, nullptr});
+    placement.base.assign(ns, std::array<size_t, 5>{0, 0, 0, 0, 0});
+    placement.count.assign(ns, std::array<size_t, 5>{sizes[0], sizes[1], sizes[2], sizes[3], sizes[4]});
     for (int q = 0; q < 5; ++q) placement.handles[0][q] = home_handle(q);
     placement.devices = devices;  // (set before the clones: unplace() on a failure below frees what was made)
+    // BY_RANGE: slot sl works on the sl-th range of the aux index space (the n_aux = |l_query| private-witness entries; a / b_g1 / b_g2
+    // hold 1 + n_public points in front of them, groth16.rs:179-203) and on the sl-th range of h: it gets those points only -- 1/N of the
+    // key per GPU instead of N copies of all of it. Keys whose queries do not have that shape are cloned whole.
+    const size_t n_aux = sizes[Q_L];
+    const bool aux_shape = sizes[Q_A] >= n_aux && sizes[Q_A] == sizes[Q_B1] && sizes[Q_A] == sizes[Q_B2] && n_aux > 0;
+    const size_t lead = aux_shape ? sizes[Q_A] - n_aux : 0;
+    bool oom = false;
     try {
-      for (size_t sl = 1; sl < ns; ++sl)
-        for (int q = 0; q < 5; ++q) {
+      for (size_t sl = 1; sl < ns && !oom; ++sl)
+        for (int q = 0; q < 5 && !oom; ++q) {
           const bool wanted = placement.mode == PLACE_BY_RANGE ? true : placement.slot[q] == (int)sl;
-          if (wanted && sizes[q]) check(csh_bases_clone(home_handle(q), devices[sl], &placement.handles[sl][q]), "csh_bases_clone");
+          if (!wanted || !sizes[q]) continue;
+          int rc = CSH_OK;
+          if (placement.mode == PLACE_BY_RANGE && aux_shape) {
+            size_t lo = 0, hi = 0;
+            plan_range(q == Q_H ? sizes[Q_H] : n_aux, ns, sl, &lo, &hi);
+            const size_t first = (q == Q_H || q == Q_L ? 0 : lead) + lo;
+            placement.base[sl][q] = first;
+            placement.count[sl][q] = hi - lo;
+            if (hi > lo) rc = csh_bases_clone_range(home_handle(q), first, hi - lo, devices[sl], &placement.handles[sl][q]);
+          } else {
+            rc = csh_bases_clone(home_handle(q), devices[sl], &placement.handles[sl][q]);
+          }
+          if (rc == CSH_ERR_OOM) oom = true;  // does not fit next to what that GPU already holds
+          else check(rc, "csh_bases_clone");
         }
     } catch (...) {
       unplace();
       throw;
     }
+    if (oom) unplace();  // prove unplaced rather than fail to load the key (build_tables falls back the same way)
   }
   void place_default() {
     int mode = PLACE_AUTO;

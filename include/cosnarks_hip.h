@@ -129,6 +129,9 @@ int csh_bases_drop_tables(csh_bases_t bases);
  * prover places its five independent query MSMs (groth16.rs:227-294, rayon_join5) on several GPUs, and how a party gets its own
  * copy of a key. Free with csh_bases_free. */
 int csh_bases_clone(csh_bases_t bases, int device, csh_bases_t* out);
+/* The same for the points [offset, offset + n) only (and the matching columns of every table row): a GPU that works on the k-th range
+ * of every query (placement by range) holds 1/N of the key instead of all of it. Point i of the clone is point offset + i of the source. */
+int csh_bases_clone_range(csh_bases_t bases, size_t offset, size_t n, int device, csh_bases_t* out);
 int csh_bases_free(csh_bases_t bases);
 
 /* sum_{i<n} scalars[i] * bases[offset+i].  "unchecked": the caller passes the shorter length

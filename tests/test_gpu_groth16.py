@@ -314,9 +314,24 @@ def test_bases_clone_and_peer_copy(gpu):
     assert (c.value, rows.value) == (15, 16)
     B._check(L.csh_bases_table_policy(C.c_size_t(1000), C.byref(c), C.byref(rows)))
     assert rows.value == 0
-    for x in (h, h2):
+    # csh_bases_clone_range: point i of the clone = point offset + i of the source, tables included (placement by range holds 1 / N of a
+    # key per GPU): the MSM of a sub-range on the range clone equals the same sub-range on the original, with and without tables
+    h3 = C.c_void_p()
+    B._check(L.csh_bases_precompute_grouped(h, 12, 4))
+    off, cnt = 1234, 3001
+    B._check(L.csh_bases_clone_range(h, C.c_size_t(off), C.c_size_t(cnt), 0, C.byref(h3)))
+    ln = C.c_size_t(0)
+    B._check(L.csh_bases_len(h3, C.byref(ln)))
+    assert ln.value == cnt
+    d3 = gpu.DeviceBuffer.from_host(sc[off:off + cnt])
+    for sub_off, sub_n in ((0, cnt), (17, 2500), (cnt - 1, 1), (5, 0)):
+        B._check(L.csh_msm_dev(h, C.c_size_t(off + sub_off), C.c_size_t(sub_n), C.c_void_p(d1.ptr.value + 32 * (off + sub_off)), 1, o1.ctypes.data_as(C.c_void_p), None))
+        B._check(L.csh_msm_dev(h3, C.c_size_t(sub_off), C.c_size_t(sub_n), C.c_void_p(d3.ptr.value + 32 * sub_off), 1, o2.ctypes.data_as(C.c_void_p), None))
+        assert (o1 == o2).all(), (sub_off, sub_n)
+    assert L.csh_bases_clone_range(h, C.c_size_t(n - 10), C.c_size_t(11), 0, C.byref(h2)) != 0      # range past the end
+    for x in (h, h2, h3):
         L.csh_bases_free(x)
-    for d in (buf, d1, d2):
+    for d in (buf, d1, d2, d3):
         d.free()
 
 
