@@ -225,3 +225,22 @@ def test_extract_component_and_current_device(gpu):
     src.free()
     dst.free()
 
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_ntt_32bit_pass_rebuilds_its_tables_on_demand(gpu, curve):
+    """The 32-bit CIOS pass (tune ntt_lazy = 0, kept for A/B runs) reads the natural-order twiddle tables, which a domain releases once
+    its staged tables exist: asking for that pass rebuilds them, and both passes give the oracle's transform on the same domain."""
+    F = H.FR[curve]
+    r = H.rng(9)
+    for logn in (3, 11, 13):
+        n = 1 << logn
+        dg, do = _domain(gpu, curve, logn)
+        v = H.rand_elems(F, n, r)
+        pv = H.pack(F, v)
+        want_i, want_f = do.ifft_in_to_out(v), do.fft_out_to_in(v)
+        assert H.unpack(F, dg.ifft_in_to_out(pv)) == want_i
+        with gpu.tuned(ntt_lazy=0):
+            assert H.unpack(F, dg.ifft_in_to_out(pv)) == want_i
+            assert H.unpack(F, dg.fft_out_to_in(pv)) == want_f
+        assert H.unpack(F, dg.fft_out_to_in(pv)) == want_f
