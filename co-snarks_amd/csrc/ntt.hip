@@ -148,12 +148,23 @@ __device__ __forceinline__ LZ load_sliced_twiddle(const F* __restrict__ twl, siz
   return r;
 }
 
+// Bank swizzle of the tile index: entry e lives at slot e ^ ((e >> 2) & 31). A radix-4 round at local stage q reads / writes, per lane, the
+// entries t0 + j 2^q: for q = 0 the lanes of a wave touch every FOURTH 8-byte slot (8-way bank conflicts on ds_read_b64, whose 32-lane
+// groups need 32 distinct slots mod 32, and on ds_write_b64, whose 16-lane groups need 16 distinct slots mod 16), for q = 1..4 runs of
+// 2^q slots 2^(q+2) apart. XOR-ing bits 2..6 of the index into bits 0..4 makes every one of those patterns a bijection onto the slots of
+// its lane group (checked exhaustively over GF(2) for all rounds q = 0..9, tile and strided passes, with one or two components per entry;
+// only the 32-lane read of the single left-over radix-2 stage at q = 0 keeps a 2-way conflict), while runs of >= 32 consecutive entries
+// (tile load / store, late rounds) stay conflict-free: the map permutes entries inside aligned blocks of 128. Two instructions per address.
+// SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE of k_ntt_pass_r4 before: 0.28-0.30 (profiles/r03_f_vecops_ntt_pmc_sq.csv).
 template <class LZ>
 struct LazyLds {
   int32_t* base;
   int E;
+  int swz;  // 31, or 0 to switch the swizzle off (A/B runs: tune "ntt_variant" bit 11)
   static constexpr int NP = LZ::NL / 2;
-  __device__ __forceinline__ LZ get(int e) const {
+  __device__ __forceinline__ int slot(int e) const { return e ^ ((e >> 2) & swz); }
+  __device__ __forceinline__ LZ get(int e0) const {
+    const int e = slot(e0);
     LZ r;
     const int2* pairs = reinterpret_cast<const int2*>(base);
 #pragma unroll
@@ -165,7 +176,8 @@ struct LazyLds {
     if (LZ::NL & 1) r.l[LZ::NL - 1] = base[2 * NP * E + e];
     return r;
   }
-  __device__ __forceinline__ void put(int e, const LZ& v) const {
+  __device__ __forceinline__ void put(int e0, const LZ& v) const {
+    const int e = slot(e0);
     int2* pairs = reinterpret_cast<int2*>(base);
 #pragma unroll
     for (int i = 0; i < NP; ++i) pairs[i * E + e] = make_int2(v.l[2 * i], v.l[2 * i + 1]);
@@ -180,7 +192,8 @@ __global__ __launch_bounds__(NTT_MAX_THREADS) __attribute__((amdgpu_waves_per_eu
   const int cc_log = cb + ncomp_log;
   const int CC = 1 << cc_log;
   const int E = 1 << (k + cc_log);
-  const LazyLds<LZ> lds{reinterpret_cast<int32_t*>(lds_raw), E};
+  const LazyLds<LZ> lds{reinterpret_cast<int32_t*>(lds_raw), E, (do_scale & 0x1000) ? 0 : 31};
+  do_scale &= 1;
   const int mid_bits = s0 - cb;
   const size_t tile = blockIdx.x;
   const size_t mid = tile & ((size_t(1) << mid_bits) - 1);
@@ -295,7 +308,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const int cc_log = cb + ncomp_log;
   const int CC = 1 << cc_log;
   const int E = 1 << (k + cc_log);
-  const LazyLds<LZ> lds{reinterpret_cast<int32_t*>(lds_raw), E};
+  const LazyLds<LZ> lds{reinterpret_cast<int32_t*>(lds_raw), E, (do_scale & 0x1000) ? 0 : 31};
   const int mid_bits = s0 - cb;
   const size_t tile = blockIdx.x;
   const size_t mid = tile & ((size_t(1) << mid_bits) - 1);
@@ -304,7 +317,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const int NT = blockDim.x;
   // timing experiments only (tune "ntt_variant" bits 16-19, wrong results): 1 = no butterfly rounds, 2 = no global loads, 4 = no stores,
   // 8 = no canonicalisation before the store
-  const int ablate = do_scale >> 8;
+  const int ablate = (do_scale >> 8) & 0xf;
   do_scale &= 1;
 
   // Tile load, four entries per lane with all four global loads issued before the first is consumed: written as one rolled loop
@@ -637,6 +650,7 @@ static int run_ntt(const Domain* d, F* data, uint32_t ncomp, bool dif, hipStream
     const int NTT_THREADS = bfly >= (size_t)NTT_THREADS_MAX ? NTT_THREADS_MAX : (bfly >= 64 ? (int)bfly : 64);
     const size_t lds_bytes = use_lazy ? (size_t(4 * LZ::NL) << (tile_log + ncomp_log)) : (size_t(32) << (tile_log + ncomp_log));
     const int do_scale = dif && (p.s0 == 0);
+    const int noswz = (tune().ntt_variant.load(std::memory_order_relaxed) & 0x800) ? 0x1000 : 0;  // LDS bank swizzle off (A/B runs)
     if (use_lazy) {
       if (lds_bytes > 48 * 1024) {
         static thread_local bool raised_lazy[2] = {false, false};
@@ -666,18 +680,18 @@ static int run_ntt(const Domain* d, F* data, uint32_t ncomp, bool dif, hipStream
         const size_t units = (size_t(1) << (tile_log + ncomp_log)) >> 2;
         const int nt = units >= 512 ? 512 : (units >= 64 ? (int)units : 64);
         if (dif)
-          hipLaunchKernelGGL((k_ntt_pass_r4<F, LZ, true>), dim3((unsigned)tiles), dim3(nt), lds_bytes, st, data, tw, L, p.s0, p.k, p.cb, ncomp_log, scale, do_scale | (((nv >> 16) & 0xf) << 8), scale_tbl);
+          hipLaunchKernelGGL((k_ntt_pass_r4<F, LZ, true>), dim3((unsigned)tiles), dim3(nt), lds_bytes, st, data, tw, L, p.s0, p.k, p.cb, ncomp_log, scale, do_scale | (((nv >> 16) & 0xf) << 8) | noswz, scale_tbl);
         else
-          hipLaunchKernelGGL((k_ntt_pass_r4<F, LZ, false>), dim3((unsigned)tiles), dim3(nt), lds_bytes, st, data, tw, L, p.s0, p.k, p.cb, ncomp_log, scale, ((nv >> 16) & 0xf) << 8, (const F*)nullptr);
+          hipLaunchKernelGGL((k_ntt_pass_r4<F, LZ, false>), dim3((unsigned)tiles), dim3(nt), lds_bytes, st, data, tw, L, p.s0, p.k, p.cb, ncomp_log, scale, (((nv >> 16) & 0xf) << 8) | noswz, (const F*)nullptr);
         CSH_HIP(hipGetLastError());
         continue;
       }
       if (dif)
         hipLaunchKernelGGL((k_ntt_pass_lazy<F, LZ, true>), dim3((unsigned)tiles), dim3(NTT_THREADS), lds_bytes, st, data, tw, L, p.s0, p.k, p.cb,
-                           ncomp_log, scale, do_scale, scale_tbl);
+                           ncomp_log, scale, do_scale | noswz, scale_tbl);
       else
         hipLaunchKernelGGL((k_ntt_pass_lazy<F, LZ, false>), dim3((unsigned)tiles), dim3(NTT_THREADS), lds_bytes, st, data, tw, L, p.s0, p.k, p.cb,
-                           ncomp_log, scale, 0, (const F*)nullptr);
+                           ncomp_log, scale, noswz, (const F*)nullptr);
       CSH_HIP(hipGetLastError());
       continue;
     }
