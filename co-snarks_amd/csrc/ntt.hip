@@ -193,6 +193,7 @@ __global__ __launch_bounds__(NTT_MAX_THREADS) __attribute__((amdgpu_waves_per_eu
   const int CC = 1 << cc_log;
   const int E = 1 << (k + cc_log);
   const LazyLds<LZ> lds{reinterpret_cast<int32_t*>(lds_raw), E, (do_scale & 0x1000) ? 0 : 31};
+  const bool unit_skip = !(do_scale & 0x2000);  // stage 0 of the whole transform has twiddle 1 everywhere: no multiplication (see k_ntt_pass_r4)
   do_scale &= 1;
   const int mid_bits = s0 - cb;
   const size_t tile = blockIdx.x;
@@ -247,6 +248,16 @@ __global__ __launch_bounds__(NTT_MAX_THREADS) __attribute__((amdgpu_waves_per_eu
 #endif
       const LZ u = lds.get(e0);
       const LZ v = lds.get(e1);
+      if (unit_skip && s0 + q == 0) {  // w = 1 for every butterfly of global stage 0 (wave-uniform branch)
+        if (DIF) {
+          lds.put(e0, LZ::add(u, v).fold_top());
+          lds.put(e1, LZ::sub(u, v));            // the pass's last stage: leaves through mul / canonical_wide, which take two-term limbs
+        } else {
+          lds.put(e0, LZ::add(u, v));            // the pass's first stage: u, v are unpack() outputs, the sums two-term operands as after a product
+          lds.put(e1, LZ::sub(u, v));
+        }
+        continue;
+      }
       if (DIF) {
         lds.put(e0, LZ::add(u, v).fold_top());   // sums feed sums here: keep the value within (-p, 2p) every stage
 #ifdef CSH_NTT_ABLATE_MUL
@@ -318,6 +329,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   // timing experiments only (tune "ntt_variant" bits 16-19, wrong results): 1 = no butterfly rounds, 2 = no global loads, 4 = no stores,
   // 8 = no canonicalisation before the store
   const int ablate = (do_scale >> 8) & 0xf;
+  const bool unit_skip = !(do_scale & 0x2000);  // tune "ntt_variant" bit 20 switches the unit-twiddle rounds off (A/B runs)
   do_scale &= 1;
 
   // Tile load, four entries per lane with all four global loads issued before the first is consumed: written as one rolled loop
@@ -409,6 +421,48 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
     __syncthreads();
   };
+  // Global stages 0 and 1 of the whole transform (the pass with s0 = 0, local round q = 0): stage 0 has twiddle 1 everywhere, stage 1 has
+  // 1 on its first pair and omega^(n/4) -- one table entry, the same for every lane -- on its second: ONE multiplication per unit
+  // instead of four (3 of the 22 x 2 multiplications a 4-entry unit meets in a 2^22 transform). Limb / value bounds: decimation in time
+  // meets this round first, on unpack() outputs (limbs 0..NL-2 in [0, 2^B), value in [0, p)): the four-term sum x0 + x1 + x2 + x3 stays
+  // below 2^(B+2) <= 2^31 - 4 per limb and below 4 p, what the general round reaches with three fresh products. Decimation in frequency
+  // meets it last, on normalised values within (-p, 2.2 p): sums are carried / folded stage by stage as in the general round; the two
+  // differences that are no longer passed through a multiplication stay two- or (carried) three-term sums within (-6.4 p, 6.4 p) and
+  // leave through the tail's mul / canonical_wide, whose contracts (two-term limbs, |value| < 8 p resp. 32 p) they meet.
+  auto round4_unit = [&]() {
+    const int quarter_E = E >> 2;
+    const LZ w4 = twiddle(1, 1, 0);  // omega^(n/4) (forward table) / its inverse (inverse table): staged entry 2
+    for (int u = tid; u < quarter_E; u += NT) {
+      const int cc = u & (CC - 1);
+      const int tb = u >> cc_log;
+      const int e0 = ((tb << 2) << cc_log) | cc;
+      const int st = 1 << cc_log;
+      LZ x0 = lds.get(e0), x1 = lds.get(e0 + st), x2 = lds.get(e0 + 2 * st), x3 = lds.get(e0 + 3 * st);
+      if (DIF) {
+        const LZ d13 = LZ::mul(LZ::sub(x1, x3), w4);   // stage 1, second pair
+        const LZ d02 = LZ::sub(x0, x2);                // stage 1, first pair: times 1
+        x0 = LZ::add(x0, x2).normalized();
+        x1 = LZ::add(x1, x3).normalized();
+        const LZ o1 = LZ::sub(x0, x1);                 // stage 0: times 1
+        x0 = LZ::add(x0, x1).fold_top();
+        x1 = o1;
+        x2 = LZ::add(d02, d13).normalized();
+        x3 = LZ::sub(d02, d13).normalized();
+      } else {
+        const LZ a0 = LZ::add(x0, x1), a1 = LZ::sub(x0, x1), a2 = LZ::add(x2, x3), a3 = LZ::sub(x2, x3);  // stage 0: times 1
+        const LZ p3 = LZ::mul(a3, w4);                                                                  // stage 1, second pair
+        x0 = LZ::add(a0, a2).normalized();
+        x2 = LZ::sub(a0, a2).normalized();
+        x1 = LZ::add(a1, p3).normalized();
+        x3 = LZ::sub(a1, p3).normalized();
+      }
+      lds.put(e0, x0);
+      lds.put(e0 + st, x1);
+      lds.put(e0 + 2 * st, x2);
+      lds.put(e0 + 3 * st, x3);
+    }
+    __syncthreads();
+  };
   // one radix-2 stage (odd stage counts): the radix-2 pass's butterfly; in DIT it is the pass's last stage (outputs leave
   // through mul / canonical_wide, which take two-term limbs), in DIF its inputs come normalised out of the last round
   auto stage2 = [&](int q) {
@@ -421,9 +475,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       const int t0 = ((tb >> q) << (q + 1)) | t_lo;
       const int e0 = (t0 << cc_log) | cc;
       const int e1 = e0 + (half << cc_log);
-      const LZ w = twiddle(q, t_lo, cc);
       const LZ u = lds.get(e0);
       const LZ v = lds.get(e1);
+      if (unit_skip && s0 + q == 0) {  // global stage 0: twiddle 1 everywhere (wave-uniform branch)
+        lds.put(e0, DIF ? LZ::add(u, v).fold_top() : LZ::add(u, v));
+        lds.put(e1, LZ::sub(u, v));
+        continue;
+      }
+      const LZ w = twiddle(q, t_lo, cc);
       if (DIF) {
         lds.put(e0, LZ::add(u, v).fold_top());
         lds.put(e1, LZ::mul(LZ::sub(u, v), w));
@@ -435,14 +494,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
     __syncthreads();
   };
+  const bool unit_round = unit_skip && s0 == 0 && k >= 2;
   if (ablate & 1) {
   } else if (DIF) {
     int q = k;
-    for (; q >= 2; q -= 2) round4(q - 2);
+    for (; q >= 2; q -= 2) {
+      if (q == 2 && unit_round) round4_unit();
+      else round4(q - 2);
+    }
     if (q == 1) stage2(0);
   } else {
     int q = 0;
-    for (; q + 2 <= k; q += 2) round4(q);
+    for (; q + 2 <= k; q += 2) {
+      if (q == 0 && unit_round) round4_unit();
+      else round4(q);
+    }
     if (q < k) stage2(q);
   }
 
@@ -650,7 +716,8 @@ static int run_ntt(const Domain* d, F* data, uint32_t ncomp, bool dif, hipStream
     const int NTT_THREADS = bfly >= (size_t)NTT_THREADS_MAX ? NTT_THREADS_MAX : (bfly >= 64 ? (int)bfly : 64);
     const size_t lds_bytes = use_lazy ? (size_t(4 * LZ::NL) << (tile_log + ncomp_log)) : (size_t(32) << (tile_log + ncomp_log));
     const int do_scale = dif && (p.s0 == 0);
-    const int noswz = (tune().ntt_variant.load(std::memory_order_relaxed) & 0x800) ? 0x1000 : 0;  // LDS bank swizzle off (A/B runs)
+    const int noswz = ((tune().ntt_variant.load(std::memory_order_relaxed) & 0x800) ? 0x1000 : 0) |        // LDS bank swizzle off (A/B runs)
+                      ((tune().ntt_variant.load(std::memory_order_relaxed) & 0x100000) ? 0x2000 : 0);   // unit-twiddle rounds off (A/B runs)
     if (use_lazy) {
       if (lds_bytes > 48 * 1024) {
         static thread_local bool raised_lazy[2] = {false, false};

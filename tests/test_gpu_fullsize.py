@@ -246,13 +246,14 @@ def test_msm_fuzz_sizes_and_plans_vs_cpu_restatement(gpu, curve, group, rounds):
         assert np.array_equal(got_aff, want), (curve, group, it, n, off, k, knobs)
 
 
-@pytest.mark.parametrize("variant", [0, 2, 1, 0x102, 0x101, 0x201, 0x302, 0x402, 0x401])
+@pytest.mark.parametrize("variant", [0, 2, 1, 0x102, 0x101, 0x201, 0x302, 0x402, 0x401, 0x100801])
 @pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
 def test_ntt_every_size_up_to_2p19_vs_cpu_restatement(gpu, curve, variant):
     """Every domain size 2^1 .. 2^19 (all pass plans: one, two, three and more sweeps; even and odd stage counts per pass), both
     directions, ncomp 1 and 2, against oracle/c's radix-2 NTT over the whole vector. variant 0: the default (tile size by transform
     size, radix-2 passes below 2^20 points); 2: the radix-2 pass everywhere, 1: the radix-4 pass everywhere; bits 8-10 = v force
-    2^(12-v)-element tiles (tune ntt_variant), each with either pass form."""
+    2^(12-v)-element tiles (tune ntt_variant), each with either pass form; 0x100801: the radix-4 pass with the unit-twiddle rounds and the
+    LDS bank swizzle switched off (the plain form both are measured against)."""
     if curve == "bls12_381" and variant in (0x101, 0x302):
         pytest.skip("the forced tile sizes run on both fields with one pass form each")
     with gpu.tuned(ntt_variant=variant):
