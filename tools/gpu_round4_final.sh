@@ -5,7 +5,7 @@
 mkdir -p gpurun_out; export TMPDIR=/tmp; R=$PWD; O=$R/gpurun_out; S=$O/summaries; rm -rf $S; mkdir -p $S
 python -c "import os, cosnarks_amd as h; print('devices', h.device_count(), h.lib().csh_version()); print('affinity', len(os.sched_getaffinity(0)), 'cpu_count', os.cpu_count())" > $O/info.log 2>&1
 (echo -n "cgroup cpu.max: "; cat /sys/fs/cgroup/cpu.max 2>/dev/null; lscpu | grep -E "Model name|^CPU\(s\)"; uptime) >> $O/info.log 2>&1
-timeout -s KILL 1500 python -m pytest tests -m gpu -q --timeout -s KILL 600 --maxfail 20 -p no:cacheprovider --durations=8 > $O/pytest_gpu.log 2>&1
+timeout -s KILL 1500 python -m pytest tests -m gpu -q --timeout 600 --maxfail 20 -p no:cacheprovider --durations=8 > $O/pytest_gpu.log 2>&1
 echo "pytest exit $?" >> $O/pytest_gpu.log; grep -E "passed|failed" $O/pytest_gpu.log | tail -2
 timeout -s KILL 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
 timeout -s KILL 900 python bench.py > $O/bench.log 2>&1; tail -c 600 $O/bench.log
