@@ -17,12 +17,14 @@ namespace csh {
 // MADV_POPULATE_WRITE (Linux >= 5.14) faults the pages in writable without touching their content; on kernels without it the
 // call fails with EINVAL and the copy simply pays the first touch itself, as before.
 void host_populate_begin(void* p, size_t bytes, std::vector<std::thread>& workers) {
-  const int threads = tune().host_populate.load(std::memory_order_relaxed);
+  const int knob = tune().host_populate.load(std::memory_order_relaxed);
+  const int threads = knob & 0xff;  // bit 8: ask for transparent huge pages on the range first (MADV_HUGEPAGE; a hint, A/B runs)
   if (!p || threads <= 0 || bytes < (size_t(4) << 20)) return;
   char* lo = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(p) + 4095) & ~uintptr_t(4095));  // whole pages inside the buffer only
   char* hi = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(p) + bytes) & ~uintptr_t(4095));
   if (hi <= lo) return;
   const size_t span = (size_t)(hi - lo);
+  if (knob & 0x100) (void)madvise(lo, span, MADV_HUGEPAGE);
   const size_t per = ((span / (size_t)threads) + 4095) & ~size_t(4095);
   for (int t = 0; t < threads; ++t) {
     char* a = lo + per * (size_t)t;
