@@ -1,4 +1,5 @@
 // Context, memory plumbing, events: the non-compute part of the C ABI (include/cosnarks_hip.h).
+#include <errno.h>
 #include <stdarg.h>
 #include <stdlib.h>
 #include <string.h>
@@ -18,20 +19,42 @@ namespace csh {
 // call fails with EINVAL and the copy simply pays the first touch itself, as before.
 void host_populate_begin(void* p, size_t bytes, std::vector<std::thread>& workers) {
   const int knob = tune().host_populate.load(std::memory_order_relaxed);
-  const int threads = knob & 0xff;  // bit 8: ask for transparent huge pages on the range first (MADV_HUGEPAGE; a hint, A/B runs)
+  const int threads = knob & 0xff;  // bit 8 (default on): ask for transparent huge pages on the range first (MADV_HUGEPAGE, a hint)
   if (!p || threads <= 0 || bytes < (size_t(4) << 20)) return;
   char* lo = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(p) + 4095) & ~uintptr_t(4095));  // whole pages inside the buffer only
   char* hi = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(p) + bytes) & ~uintptr_t(4095));
   if (hi <= lo) return;
   const size_t span = (size_t)(hi - lo);
+  // 2 MiB pages where the kernel grants them: 16 faults instead of 8192 for a 32 MB result (the hosts run THP in "madvise" mode)
   if (knob & 0x100) (void)madvise(lo, span, MADV_HUGEPAGE);
-  const size_t per = ((span / (size_t)threads) + 4095) & ~size_t(4095);
+  const size_t per = ((span / (size_t)threads) + (size_t(2) << 20) - 1) & ~((size_t(2) << 20) - 1);  // 2 MiB-granular shares
   for (int t = 0; t < threads; ++t) {
     char* a = lo + per * (size_t)t;
     if (a >= hi) break;
     const size_t len = (size_t)(hi - a) < per ? (size_t)(hi - a) : per;
     try {
-      workers.emplace_back([a, len] { (void)madvise(a, len, MADV_POPULATE_WRITE); });
+      workers.emplace_back([a, len] {
+        // MADV_POPULATE_WRITE faults the pages in writable without touching their content; it may stop early (EINTR / EAGAIN under
+        // memory-management contention with the driver pinning the upload's source pages: seen as 11-16 ms witness maps when the copy
+        // then first-touched the rest itself), so it is retried piecewise, and where the kernel lacks it (EINVAL) the pages are
+        // touched with a store -- the buffer is an output nobody has read yet.
+        size_t done = 0;
+        const size_t piece = size_t(2) << 20;
+        int tries = 0;
+        while (done < len) {
+          const size_t l = len - done < piece ? len - done : piece;
+          if (madvise(a + done, l, MADV_POPULATE_WRITE) == 0) {
+            done += l;
+            tries = 0;
+          } else if ((errno == EINTR || errno == EAGAIN) && ++tries < 64) {
+            continue;
+          } else {
+            for (size_t i = 0; i < l; i += 4096) reinterpret_cast<volatile char*>(a + done)[i] = 0;
+            done += l;
+            tries = 0;
+          }
+        }
+      });
     } catch (...) {  // no thread to be had: the copy populates the rest
       break;
     }

@@ -86,8 +86,11 @@ struct HostStage {
 // boxes (profiles/r04_a_pcie_probe.jsonl, r04_b_prefault_probe.jsonl): a copy from / to pageable memory whose pages are present runs
 // at the PCIe rate (32 MB in 0.60 ms = 56 GB/s, the same as from hipHostMalloc memory; hipHostRegister is a ~1 us no-op on these hosts),
 // but a D2H into memory the caller has only just allocated pays the DMA engine's first touch of every page: 3.9 ms for 32 MB.
-// HostXfer therefore populates the destination's pages from a few host threads (MADV_POPULATE_WRITE: no content change) WHILE the
-// device works, and joins them before the copy is enqueued.
+// HostXfer therefore populates the destination's pages from a helper thread (MADV_POPULATE_WRITE: no content change) WHILE the
+// device works, and joins it before the copy is enqueued. Measured (profiles/r04_y_populate.log, six alternating trials per setting,
+// host-facing witness map at 2^20): one thread with a transparent-huge-page hint on the range 2.36-2.47 ms (= upload + device + copy:
+// nothing left exposed); two / four threads with the hint 3.1-3.8 / 2.9-3.4 (they contend); WITHOUT the hint 4.3-22 ms, bimodal
+// (8192 4-KiB faults interleaved with the driver's own page handling) -- the hint is what makes it reliable.
 void host_populate_begin(void* p, size_t bytes, std::vector<std::thread>& workers);  // no-op below 4 MiB or with tune host_populate = 0
 struct HostXfer {
   std::vector<std::thread> workers;
@@ -148,7 +151,7 @@ struct Tune {
   std::atomic<int> ntt_variant{0};
   std::atomic<int> h_unfused{0};          // Groth16 h pipeline: 1 = the unfused step-by-step sequence (A/B, tests)
   std::atomic<int> comm_timeout_ms{120000};  // deadline of a non-blocking RCCL communicator's construction / pending operation (0 = blocking calls)
-  std::atomic<int> host_populate{4};      // threads populating a large D2H destination's pages before the copy (0 = off)
+  std::atomic<int> host_populate{0x101};  // low byte: threads populating a large D2H destination's pages before the copy (0 = off); bit 8: huge-page hint
 };
 Tune& tune();
 
