@@ -36,8 +36,8 @@ void host_populate_begin(void* p, size_t bytes, std::vector<std::thread>& worker
       workers.emplace_back([a, len] {
         // MADV_POPULATE_WRITE faults the pages in writable without touching their content; it may stop early (EINTR / EAGAIN under
         // memory-management contention with the driver pinning the upload's source pages: seen as 11-16 ms witness maps when the copy
-        // then first-touched the rest itself), so it is retried piecewise, and where the kernel lacks it (EINVAL) the pages are
-        // touched with a store -- the buffer is an output nobody has read yet.
+        // then first-touched the rest itself), so it is retried piecewise, and where the kernel lacks it (EINVAL) every page is
+        // touched by storing back the byte it holds (content unchanged: the copy that fills the buffer is enqueued after the join).
         size_t done = 0;
         const size_t piece = size_t(2) << 20;
         int tries = 0;
@@ -49,7 +49,10 @@ void host_populate_begin(void* p, size_t bytes, std::vector<std::thread>& worker
           } else if ((errno == EINTR || errno == EAGAIN) && ++tries < 64) {
             continue;
           } else {
-            for (size_t i = 0; i < l; i += 4096) reinterpret_cast<volatile char*>(a + done)[i] = 0;
+            for (size_t i = 0; i < l; i += 4096) {  // write back what is there: in-place entry points pass their INPUT buffer here
+              volatile char* q = reinterpret_cast<volatile char*>(a + done + i);
+              *q = *q;
+            }
             done += l;
             tries = 0;
           }
