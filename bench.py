@@ -515,7 +515,12 @@ def secondary_single_gpu(cx: Ctx, rin: dict, args):
     del a, b, m, o
     # Groth16 plain prove, synthetic 2^20-constraint circuit with a known-dlog key (closed-form checked), key resident
     from cosnarks_amd import groth16 as g16
+    xfer_keys = ("stat_populate_us", "stat_join_wait_us", "stat_finish_us", "stat_d2h_slow", "stat_d2h_staged")
+    xfer0 = {k: cx.B.tune_get(k) for k in xfer_keys}
     out[f"groth16_prove_synthetic_2p{args.prove_log_n}"] = g16.bench_synthetic(hip.BN254, args.prove_log_n, 3, with_rep3=True)
+    # the host side of the trait path on THIS box: page population (worker time, the caller's wait for it), result copies that stalled /
+    # were staged (HostXfer, csrc/capi.hip) -- summed over the witness maps of the entry above
+    out[f"groth16_prove_synthetic_2p{args.prove_log_n}"]["host_result_copies"] = {k[5:]: cx.B.tune_get(k) - xfer0[k] for k in xfer_keys}
     # BASELINE configs 1 and 4 on the reference's own circuits (tests/golden copies of test_vectors/Groth16/bn254): plain
     # prove of multiplier2 (domain 4) and poseidon (domain 256), and a three-party Rep3 prove of poseidon (in-process
     # parties sharing this GPU). Wall ms per proof incl. zkey parse + key upload; these sizes are launch-latency bound.

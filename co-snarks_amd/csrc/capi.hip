@@ -6,6 +6,8 @@
 
 #include <sys/mman.h>
 
+#include <chrono>
+
 #include "common.hpp"
 
 #ifndef MADV_POPULATE_WRITE
@@ -17,6 +19,9 @@ namespace csh {
 // Populate the pages of a D2H destination from a few host threads while the device is still busy (see HostXfer in common.hpp).
 // MADV_POPULATE_WRITE (Linux >= 5.14) faults the pages in writable without touching their content; on kernels without it the
 // call fails with EINVAL and the copy simply pays the first touch itself, as before.
+static inline int us_since(std::chrono::steady_clock::time_point t0) {
+  return (int)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+}
 void host_populate_begin(void* p, size_t bytes, std::vector<std::thread>& workers) {
   const int knob = tune().host_populate.load(std::memory_order_relaxed);
   const int threads = knob & 0xff;  // bit 8 (default on): ask for transparent huge pages on the range first (MADV_HUGEPAGE, a hint)
@@ -38,6 +43,7 @@ void host_populate_begin(void* p, size_t bytes, std::vector<std::thread>& worker
         // memory-management contention with the driver pinning the upload's source pages: seen as 11-16 ms witness maps when the copy
         // then first-touched the rest itself), so it is retried piecewise, and where the kernel lacks it (EINVAL) every page is
         // touched by storing back the byte it holds (content unchanged: the copy that fills the buffer is enqueued after the join).
+        const auto t0 = std::chrono::steady_clock::now();
         size_t done = 0;
         const size_t piece = size_t(2) << 20;
         int tries = 0;
@@ -57,11 +63,131 @@ void host_populate_begin(void* p, size_t bytes, std::vector<std::thread>& worker
             tries = 0;
           }
         }
+        tune().stat_populate_us.fetch_add(us_since(t0), std::memory_order_relaxed);
       });
     } catch (...) {  // no thread to be had: the copy populates the rest
       break;
     }
   }
+}
+
+void HostXfer::join() {
+  if (workers.empty()) return;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (auto& t : workers)
+    if (t.joinable()) t.join();
+  workers.clear();
+  tune().stat_join_wait_us.fetch_add(us_since(t0), std::memory_order_relaxed);
+}
+HostXfer::~HostXfer() {
+  join();
+  for (Staged& s : staged)
+    for (hipEvent_t e : s.landed)
+      if (e) (void)hipEventDestroy(e);
+}
+// Result copy. Direct: one DMA into the caller's pages (the runtime pins them for the duration). Staged (tune "host_d2h" = 1): the
+// driver never touches the caller's memory -- chunks land in the lane's page-locked buffer and host threads move them on. On most
+// boxes the direct copy of 32 MB takes 0.6 ms once the pages are present; on some (profiles/r04_zd_trait_modes.log, same code, same
+// sizes) the host-facing witness map took 12-24 ms instead of 2.4 in steps of ~10 ms while every device-resident path ran at
+// its usual speed, i.e. the stall sits in the driver's handling of freshly populated caller pages.
+int HostXfer::d2h(void* host, const void* dev, size_t bytes, hipStream_t st) {
+  // tune "host_d2h": 0 = always direct, 1 = always staged, 2 (default) = direct, timed; two copies in a row that take more than three times their
+  // PCIe time + 4 ms send the next 256 large results of the process through the staged path, after which a direct copy is tried again.
+  static std::atomic<int> staged_left{0};
+  const int mode = tune().host_d2h.load(std::memory_order_relaxed);
+  const bool large = bytes >= (size_t(4) << 20);
+  bool stage = large && mode == 1;
+  if (large && mode == 2 && staged_left.load(std::memory_order_relaxed) > 0) {
+    staged_left.fetch_sub(1, std::memory_order_relaxed);
+    stage = true;
+  }
+  void *ph = nullptr, *pd = nullptr;
+  if (stage && pinned_for((hipStream_t)((uintptr_t)st ^ 0x8), bytes, &ph, &pd)) {
+    Staged sg;
+    sg.host = host, sg.pinned = static_cast<const char*>(ph), sg.bytes = bytes;
+    sg.chunk = (((bytes + 15) / 16) + (size_t(2) << 20) - 1) & ~((size_t(2) << 20) - 1);  // <= 16 chunks, 2 MiB-granular
+    for (size_t off = 0; off < bytes; off += sg.chunk) {
+      const size_t l = bytes - off < sg.chunk ? bytes - off : sg.chunk;
+      hipEvent_t e = nullptr;
+      hipError_t rc = hipMemcpyAsync(static_cast<char*>(ph) + off, static_cast<const char*>(dev) + off, l, hipMemcpyDeviceToHost, st);
+      if (rc == hipSuccess) rc = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+      if (rc == hipSuccess) rc = hipEventRecord(e, st);
+      sg.landed.push_back(e);
+      if (rc != hipSuccess) {
+        staged.push_back(std::move(sg));  // the destructor releases the events
+        set_error("staged result copy failed: %s", hipGetErrorString(rc));
+        return CSH_ERR_HIP;
+      }
+    }
+    staged.push_back(std::move(sg));
+    tune().stat_d2h_staged.fetch_add(1, std::memory_order_relaxed);
+    return CSH_OK;
+  }
+  if (large && mode == 2) {  // the copy alone between two stream waits (a copy into pageable memory returns when it is done anyway)
+    CSH_HIP(hipStreamSynchronize(st));
+    join();
+    const auto t0 = std::chrono::steady_clock::now();
+    CSH_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, st));
+    CSH_HIP(hipStreamSynchronize(st));
+    const double ms = us_since(t0) * 1e-3;
+    static std::atomic<int> slow_run{0};  // consecutive stalled copies (one alone may be the process's first: runtime start-up)
+    if (ms > 3.0 * (double)bytes / 20e6 + 4.0) {
+      tune().stat_d2h_slow.fetch_add(1, std::memory_order_relaxed);
+      if (slow_run.fetch_add(1, std::memory_order_relaxed) + 1 >= 2) {
+        staged_left.store(256, std::memory_order_relaxed);
+        slow_run.store(1, std::memory_order_relaxed);  // the probe after the staged spell switches back at once if it stalls again
+      }
+    } else {
+      slow_run.store(0, std::memory_order_relaxed);
+    }
+    return CSH_OK;
+  }
+  join();
+  if (bytes) CSH_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, st));
+  return CSH_OK;
+}
+int HostXfer::finish(hipStream_t st) {
+  join();  // the destination's pages are present from here on
+  if (!staged.empty()) {
+    int device = 0;
+    (void)hipGetDevice(&device);
+    const auto t0 = std::chrono::steady_clock::now();
+    std::atomic<int> failed{0};
+    for (Staged& sg : staged) {
+      const size_t nchunks = sg.landed.size();
+      std::atomic<size_t> next{0};
+      auto work = [&] {
+        for (;;) {
+          const size_t c = next.fetch_add(1, std::memory_order_relaxed);
+          if (c >= nchunks) return;
+          if (hipEventSynchronize(sg.landed[c]) != hipSuccess) {
+            failed.store(1);
+            return;
+          }
+          const size_t off = c * sg.chunk, l = sg.bytes - off < sg.chunk ? sg.bytes - off : sg.chunk;
+          memcpy(static_cast<char*>(sg.host) + off, sg.pinned + off, l);
+        }
+      };
+      std::vector<std::thread> movers;
+      const int extra = nchunks > 1 ? 3 : 0;
+      try {
+        for (int t = 0; t < extra; ++t) movers.emplace_back([&, device] { (void)hipSetDevice(device); work(); });
+      } catch (...) {  // no thread to be had: the caller moves the rest itself
+      }
+      work();
+      for (auto& t : movers) t.join();
+    }
+    tune().stat_finish_us.fetch_add(us_since(t0), std::memory_order_relaxed);
+    if (failed.load()) {
+      (void)hipStreamSynchronize(st);
+      set_error("staged result copy: a chunk failed on the device");
+      return CSH_ERR_HIP;
+    }
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  CSH_HIP(hipStreamSynchronize(st));
+  if (staged.empty()) tune().stat_finish_us.fetch_add(us_since(t0), std::memory_order_relaxed);
+  return CSH_OK;
 }
 
 int HostStage::down(void* host, const void* dev, size_t bytes) {
@@ -110,6 +236,7 @@ struct LaneHolder {
     if (!l) {
       l = new Lane();
       l->device = device;
+      tune().stat_lanes.fetch_add(1, std::memory_order_relaxed);
       if (hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking) != hipSuccess) l->stream = nullptr;  // fall back to the null stream
     }
     by_device[key] = l;
@@ -144,7 +271,15 @@ static const TuneEntry kTune[] = {
     {"ntt_variant", "CSH_NTT_VARIANT", &Tune::ntt_variant},
     {"h_unfused", "CSH_H_UNFUSED", &Tune::h_unfused},
     {"host_populate", "CSH_HOST_POPULATE", &Tune::host_populate},
+    {"host_d2h", "CSH_HOST_D2H", &Tune::host_d2h},
     {"comm_timeout_ms", "CSH_COMM_TIMEOUT_MS", &Tune::comm_timeout_ms},
+    {"stat_arena_grows", "CSH_STAT_ARENA_GROWS", &Tune::stat_arena_grows},
+    {"stat_lanes", "CSH_STAT_LANES", &Tune::stat_lanes},
+    {"stat_populate_us", "CSH_STAT_POPULATE_US", &Tune::stat_populate_us},
+    {"stat_join_wait_us", "CSH_STAT_JOIN_WAIT_US", &Tune::stat_join_wait_us},
+    {"stat_finish_us", "CSH_STAT_FINISH_US", &Tune::stat_finish_us},
+    {"stat_d2h_slow", "CSH_STAT_D2H_SLOW", &Tune::stat_d2h_slow},
+    {"stat_d2h_staged", "CSH_STAT_D2H_STAGED", &Tune::stat_d2h_staged},
 };
 Tune& tune() {
   static Tune* t = [] {
@@ -198,6 +333,7 @@ int Arena::reserve(size_t bytes) {
     cap = 0;
   }
   size_t want = bytes + (bytes >> 3) + (1 << 20);
+  tune().stat_arena_grows.fetch_add(1, std::memory_order_relaxed);
   void* p = nullptr;
   CSH_HIP(hipMalloc(&p, want));
   base = static_cast<char*>(p);

@@ -94,28 +94,25 @@ struct HostStage {
 void host_populate_begin(void* p, size_t bytes, std::vector<std::thread>& workers);  // no-op below 4 MiB or with tune host_populate = 0
 struct HostXfer {
   std::vector<std::thread> workers;
-  ~HostXfer() { join(); }
-  void join() {
-    for (auto& t : workers)
-      if (t.joinable()) t.join();
-    workers.clear();
-  }
+  // a large result staged through the lane's page-locked buffer (tune "host_d2h" = 1): chunked copies into it, an event per chunk,
+  // host threads copy each chunk on into the caller's memory as it lands (finish())
+  struct Staged {
+    void* host = nullptr;
+    const char* pinned = nullptr;
+    size_t bytes = 0, chunk = 0;
+    std::vector<hipEvent_t> landed;
+  };
+  std::vector<Staged> staged;
+  ~HostXfer();
+  void join();  // capi.hip (counts the time the caller waited: stat_join_wait_us)
   // call as early as the destination is known: the pages are populated while uploads and kernels run
   void expect_d2h(void* host, size_t bytes) { host_populate_begin(host, bytes, workers); }
   int h2d(void* dev, const void* host, size_t bytes, hipStream_t st) {
     if (bytes) CSH_HIP(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, st));
     return CSH_OK;
   }
-  int d2h(void* host, const void* dev, size_t bytes, hipStream_t st) {
-    join();
-    if (bytes) CSH_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, st));
-    return CSH_OK;
-  }
-  int finish(hipStream_t st) {
-    join();
-    CSH_HIP(hipStreamSynchronize(st));
-    return CSH_OK;
-  }
+  int d2h(void* host, const void* dev, size_t bytes, hipStream_t st);  // capi.hip
+  int finish(hipStream_t st);                                          // capi.hip
 };
 
 // ntt.hip internals reused by the fused Groth16 pipeline
@@ -139,6 +136,9 @@ struct Tune {
   std::atomic<int> msm_l{0};             // forced entries per accumulate lane (0 = from the launch width)
   std::atomic<int> msm_timing{0};        // record per-stage HIP events (csh_msm_last_timing)
   std::atomic<int> msm_no_table{0};      // ignore fixed-base tables
+  std::atomic<int> stat_arena_grows{0};  // counters (read with csh_tune_get): scratch arenas (re)allocated, lanes (streams) created
+  std::atomic<int> stat_lanes{0};
+  std::atomic<int> stat_populate_us{0}, stat_join_wait_us{0}, stat_finish_us{0}, stat_d2h_slow{0}, stat_d2h_staged{0};  // page population: worker time, caller's wait for it, final stream wait
   std::atomic<int> msm_multi_overlap{1}; // alternate bucket stages of csh_msm_multi_dev between two streams
   std::atomic<int> acc_blk{0};           // accumulate workgroup size (0 = default)
   std::atomic<int> sort_two_level{-1};   // -1 auto, 0 / 1 forced
@@ -150,6 +150,8 @@ struct Tune {
   std::atomic<int> allow_unmasked_rep3{0};  // Rep3 products without the re-randomising masks: refused unless set (tests)
   std::atomic<int> ntt_variant{0};
   std::atomic<int> h_unfused{0};          // Groth16 h pipeline: 1 = the unfused step-by-step sequence (A/B, tests)
+  std::atomic<int> host_d2h{2};  // large results to pageable memory: 0 = one copy straight into the caller's pages, 1 = staged through a page-locked
+                                 // buffer + host threads, 2 = direct, timed, staged for a while after a copy that stalled (HostXfer::d2h)
   std::atomic<int> comm_timeout_ms{120000};  // deadline of a non-blocking RCCL communicator's construction / pending operation (0 = blocking calls)
   std::atomic<int> host_populate{0x101};  // low byte: threads populating a large D2H destination's pages before the copy (0 = off); bit 8: huge-page hint
 };

@@ -172,3 +172,32 @@ def test_trait_path_synthetic_circuit_closed_form(gpu):
         assert c.check()
         c.close()
     assert ph["msm_groups"] > 0 and ph["witness_upload_and_map"] > 0
+
+
+def test_large_results_direct_and_staged_copies_agree(gpu):
+    """Results of >= 4 MiB reach the caller's pageable memory either by one copy into its pages or staged through the lane's page-locked
+    buffer (tune host_d2h: 0 / 1; 2 = direct, timed, staged after a stalled copy): a 2^18-point host-pointer transform and the h of a
+    2^17-constraint witness map (inside a trait-path prove, closed-form checked) are the same bytes either way."""
+    from cosnarks_amd import bindings as B
+    from cosnarks_amd import groth16 as g
+    F = H.FR["bn254"]
+    logn = 18
+    gen = ntt.roots_of_unity(F)[1][logn]
+    dom = gpu.Domain(H.CURVE_IDS["bn254"], logn, H.pack(F, [gen]))
+    x = np.random.RandomState(3).randint(0, 1 << 62, size=(1 << logn, 4), dtype=np.uint64)
+    x[:, 3] >>= np.uint64(2)
+    outs = {}
+    for mode in (0, 1, 2):
+        staged0 = B.tune_get("stat_d2h_staged")
+        with gpu.tuned(host_d2h=mode):
+            outs[mode] = np.array(dom.ifft_in_to_out(x.copy()), copy=True)
+            with g.trait_path():
+                c = g.SynthCircuit(0, 17)
+                c.prove()
+                assert c.check(), mode
+                c.close()
+        if mode != 2:  # 2 stages only after stalled copies, which depends on the host
+            assert (B.tune_get("stat_d2h_staged") > staged0) == (mode == 1), mode
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    assert np.array_equal(np.asarray(dom.fft_out_to_in(outs[1].copy())).reshape(-1), x.reshape(-1))
+    dom.free()
