@@ -74,7 +74,13 @@ int csh_device_count(int* count);
  * lane-serial on G1 / four-lane on G2, bit 1 = the other form of the G2 accumulate kernel (BN254 G2: two lanes per point instead of whole points; BLS12-381 G2: whole
  * points instead of two lanes per point), bit 2 = lane-serial window
  * reduction on G2, bit 3 = 8-byte sort records at every size, bit 4 = merge fused into the window reduction, bit 5 = level 2 of the
- * two-level sort with one block per partition instead of one per tile-sized slice). */
+ * two-level sort with one block per partition instead of one per tile-sized slice), "h_unfused", "comm_timeout_ms" (csh_comm_init_rank),
+ * "host_populate" (results of >= 4 MiB handed back in pageable memory: low byte = host threads that populate the destination's
+ * pages while the device works, 0 = none; bit 8 = transparent-huge-page hint on the range; default 0x101), "host_d2h" (the copy of such
+ * a result: 0 = one DMA into the caller's pages, 1 = staged through the lane's page-locked buffer and moved on by host threads,
+ * 2 = default: direct and timed, staged for the next 256 results after two stalled copies in a row). Read-only counters
+ * (csh_tune_get): "stat_arena_grows", "stat_lanes", "stat_populate_us", "stat_join_wait_us", "stat_finish_us", "stat_d2h_slow",
+ * "stat_d2h_staged". */
 int csh_tune_set(const char* key, int value);
 int csh_tune_get(const char* key, int* value);
 
