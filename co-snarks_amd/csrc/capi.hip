@@ -273,6 +273,7 @@ static const TuneEntry kTune[] = {
     {"host_populate", "CSH_HOST_POPULATE", &Tune::host_populate},
     {"host_d2h", "CSH_HOST_D2H", &Tune::host_d2h},
     {"comm_timeout_ms", "CSH_COMM_TIMEOUT_MS", &Tune::comm_timeout_ms},
+    {"comm_nonblocking", "CSH_COMM_NONBLOCKING", &Tune::comm_nonblocking},
     {"stat_arena_grows", "CSH_STAT_ARENA_GROWS", &Tune::stat_arena_grows},
     {"stat_lanes", "CSH_STAT_LANES", &Tune::stat_lanes},
     {"stat_populate_us", "CSH_STAT_POPULATE_US", &Tune::stat_populate_us},

@@ -152,7 +152,8 @@ struct Tune {
   std::atomic<int> h_unfused{0};          // Groth16 h pipeline: 1 = the unfused step-by-step sequence (A/B, tests)
   std::atomic<int> host_d2h{2};  // large results to pageable memory: 0 = one copy straight into the caller's pages, 1 = staged through a page-locked
                                  // buffer + host threads, 2 = direct, timed, staged for a while after a copy that stalled (HostXfer::d2h)
-  std::atomic<int> comm_timeout_ms{120000};  // deadline of a non-blocking RCCL communicator's construction / pending operation (0 = blocking calls)
+  std::atomic<int> comm_timeout_ms{120000};  // deadline of an RCCL communicator's construction (0 = on the calling thread, no deadline)
+  std::atomic<int> comm_nonblocking{0};  // csh_comm_init_rank: 1 = ncclCommInitRankConfig(blocking = 0) + polling instead of ncclCommInitRank
   std::atomic<int> host_populate{0x101};  // low byte: threads populating a large D2H destination's pages before the copy (0 = off); bit 8: huge-page hint
 };
 Tune& tune();

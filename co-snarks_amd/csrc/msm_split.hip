@@ -232,9 +232,10 @@ int csh_comm_init_rank(const uint8_t id[CSH_COMM_ID_BYTES], int nranks, int rank
     // -- tune "comm_timeout_ms", default 120 s, 0 = call it on this thread as before. Past the deadline the caller gets an error it
     // can act on (fall back to its own exchange) and the helper is left behind: if the bootstrap ever completes it tears the
     // communicator down itself. (RCCL's own non-blocking construction -- ncclCommInitRankConfig with blocking = 0 polled through
-    // ncclCommGetAsyncError -- is what the helper uses where the symbols exist, but on this stack (RCCL 2.27.7, ROCm 7.2) that call
-    // itself does not return while a peer is missing, with or without ncclCommAbort: profiles/r04_s_rccl_deadline.log. One rank
-    // cannot wait for anybody and is built inline.)
+    // ncclCommGetAsyncError -- buys nothing on this stack (RCCL 2.27.7, ROCm 7.2): that call itself does not return while a peer is
+    // missing, with or without ncclCommAbort, profiles/r04_s_rccl_deadline.log. The helper therefore makes the plain blocking call,
+    // the path every RCCL user exercises; tune "comm_nonblocking" = 1 selects the other one. One rank cannot wait for anybody and is
+    // built inline.)
     const long timeout_ms = tune().comm_timeout_ms.load(std::memory_order_relaxed);
     struct Job {
       std::mutex mu;
@@ -246,7 +247,7 @@ int csh_comm_init_rank(const uint8_t id[CSH_COMM_ID_BYTES], int nranks, int rank
     };
     auto build = [R, nid, nranks, rank](void** out_comm, bool* nonblocking) -> int {
       int ver = 0;
-      if (R->CommInitRankConfig && R->CommGetAsyncError && R->GetVersion && R->GetVersion(&ver) == 0) {
+      if (tune().comm_nonblocking.load(std::memory_order_relaxed) != 0 && R->CommInitRankConfig && R->CommGetAsyncError && R->GetVersion && R->GetVersion(&ver) == 0) {
         NcclConfig cfg;
         cfg.size = sizeof(NcclConfig);
         cfg.magic = 0xcafebeef;

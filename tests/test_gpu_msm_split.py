@@ -108,8 +108,9 @@ def test_split_rejects_bad_arguments(gpu):
         gpu.Comm.init_all([0, 0])                                                      # a device twice
 
 
+@pytest.mark.parametrize("nonblocking", [0, 1])
 @pytest.mark.parametrize("curve,group", [("bn254", 0), ("bls12_381", 1)])
-def test_rccl_rank_path_with_one_rank(gpu, curve, group):
+def test_rccl_rank_path_with_one_rank(gpu, curve, group, nonblocking):
     """csh_comm_unique_id -> csh_comm_init_rank -> csh_msm_split_rank_dev: RCCL is dlopen'ed and a real communicator is built
     (one rank here; N ranks under the driver's multi-GPU bench). Also the RCCL-free local communicator (id = NULL) and the
     single-thread RCCL mode over csh_comm_init_all([0])."""
@@ -125,7 +126,8 @@ def test_rccl_rank_path_with_one_rank(gpu, curve, group):
     dsc = gpu.DeviceBuffer.from_host(H.pack(F, sc))
     uid = gpu.bindings.comm_unique_id()
     assert len(uid) == 128 and any(uid)
-    comm = gpu.Comm.init_rank(uid, 1, 0)
+    with gpu.tuned(comm_nonblocking=nonblocking):      # ncclCommInitRank (default) / ncclCommInitRankConfig(blocking = 0) + polling
+        comm = gpu.Comm.init_rank(uid, 1, 0)
     assert comm.info() == (0, 1, 0)
     for _ in range(2):                                     # communicator buffers are reused across calls
         assert G.eq(H.jac_to_affine(G, comm.msm_split_rank_dev(bases, dsc, n)), want)
