@@ -651,7 +651,13 @@ inline int choose_c(size_t n, int bits) {
 // n W / 64 is not a multiple of the SIMD count: 17 windows (BN254 at 2^20: L = 32 meant 8.5 waves per SIMD, 9 rounds of 32
 // where 5 of 55 do, accumulate + merge 1.78 -> 1.73 ms; BN254 G2 5.48 -> 5.2 ms; 2^19: 1.33 -> 1.25 ms) and the arbitrary sizes of
 // real proving keys.
-inline uint32_t choose_lane_length(size_t n, int W) {
+// Small MSMs (round 4, profiles/r04_zj_plan_sweep.log, r04_zk_short_lanes.log, interleaved): the round-count model above prices a
+// SIMD with ONE wave on it, but a group whose accumulate kernel fits `occ` waves per SIMD (BN254 G1: 144 VGPRs -> 3) runs them
+// interleaved, and with fewer than occ waves per SIMD in the whole launch the shorter lane wins: 2^15 c = 11 L = 16 -> 8 0.440 ->
+// 0.371 ms, 2^16 c = 12 L = 23 -> 12 0.489 -> 0.426, 2^17 c = 13 L = 21 -> 12..16 0.569 -> 0.531..0.534; at 2^18 (L = 27 = exactly
+// three waves per SIMD) and above the model's choice stands. Rule: never longer than the lane that fills occ waves per SIMD, down to 8
+// entries (below ~6 10^5 entries the launch is latency, not throughput: left alone). occ = 1 (the G2 kernels, shared plans): unchanged.
+inline uint32_t choose_lane_length(size_t n, int W, int occ = 1) {
   if (const int fl = tune().msm_l.load(std::memory_order_relaxed); fl > 0) return (uint32_t)fl;
   const double simds = (double)device_simds();
   const int wpb = ACC_BLK / 64;
@@ -667,6 +673,12 @@ inline uint32_t choose_lane_length(size_t n, int W) {
       best_L = L;
     }
     if (rounds <= 1) break;  // one round already: longer lanes only cost
+  }
+  const double entries = (double)n * W;
+  if (occ >= 2 && entries >= 6e5) {
+    uint32_t fill = (uint32_t)ceil(entries / (64.0 * simds * occ));
+    if (fill < 8) fill = 8;
+    if (fill < best_L) best_L = fill;
   }
   return best_L;
 }
@@ -694,13 +706,13 @@ struct PartialHeader {
 constexpr uint32_t PARTIAL_MAGIC = 0x4d534d50u;  // "PMSM"
 
 // ---- the pipeline in three pieces: plan, sort stage (depends on the scalars only), bucket stage (per set of bases) ----
-inline MsmParams msm_plan(size_t n, int scalar_bits, int mont) {
+inline MsmParams msm_plan(size_t n, int scalar_bits, int mont, int occ = 1) {
   MsmParams p;
   p.n = (uint32_t)n;
   p.c = choose_c(n, scalar_bits);
   p.W = windows_for(scalar_bits, p.c);
   p.NB = 1u << (p.c - 1);
-  p.L = choose_lane_length(n, p.W);
+  p.L = choose_lane_length(n, p.W, occ);
   const uint32_t max_lanes = (uint32_t)((n + p.L - 1) / p.L);
   p.tmax = p.NB + max_lanes + 2;  // partial slots per window: slot = bucket + lane
   p.S = reduce_segments(p.NB, p.W, 1);
@@ -1007,6 +1019,25 @@ inline bool msm_use_table(const Bases* B, size_t n) {
   return n * 8 >= B->n;
 }
 
+// accumulate waves of this group's kernel that fit one SIMD together (register-limited: 3 on BN254 G1 / Grumpkin, 2 on BLS12-381 G1,
+// 1 on the G2 groups); 1 where it cannot be asked (no device)
+template <class Cfg>
+int accum_occupancy() {
+  static std::atomic<int> cache{0};
+  int v = cache.load(std::memory_order_relaxed);
+  if (v) return v;
+  v = 1;
+  if constexpr (!Cfg::PAIR) {
+    int blocks = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_msm_accum<Cfg>, ACC_BLK, 0) == hipSuccess && blocks > 0) {
+      v = blocks * (ACC_BLK / 64) / 4;
+      v = v < 1 ? 1 : (v > 8 ? 8 : v);
+    }
+  }
+  cache.store(v, std::memory_order_relaxed);
+  return v;
+}
+
 template <class Cfg>
 int msm_windows_dev(const Bases* B, size_t offset, size_t n, const uint64_t* scalars_dev, int mont, hipStream_t st,
                     XYZZ<typename Cfg::Fq>* win_out_dev /* W entries, device */, MsmParams* p_out) {
@@ -1021,7 +1052,7 @@ int msm_windows_dev(const Bases* B, size_t offset, size_t n, const uint64_t* sca
     pdig = m.dig;
     points = B->table;
   } else {
-    p = pdig = msm_plan(n, Fr::Params::BITS, mont);
+    p = pdig = msm_plan(n, Fr::Params::BITS, mont, accum_occupancy<Cfg>());
     points = reinterpret_cast<const Affine<Fq>*>(B->points) + offset;
   }
   *p_out = p;  // merged: W = 1 (the single window sum is the result)

@@ -385,7 +385,10 @@ int csh_msm_last_params(uint32_t out[4]);
 /* The plan an n-point MSM on `curve` would run with on the calling thread's device (no device: a 256-CU part is assumed), without
  * running it: [window bits c, windows W, entries per accumulate lane L, window-reduction segments S, accumulate waves, SIMDs].
  * The accumulate kernel takes ceil(waves / SIMDs) rounds of L mixed additions; L and S are chosen so that every SIMD runs a
- * whole number of equal rounds. Host-only: for capacity planning and for tests of the planner. */
+ * whole number of equal rounds. This is the plan of the G2 groups and of plans shared by several groups
+ * (csh_msm_multi_dev); a G1 MSM on its own whose launch would leave SIMDs with fewer accumulate waves than fit them together (below
+ * ~2^18 points) runs with a shorter lane, down to 8 entries: csh_msm_last_params reports what ran. Host-only: for capacity planning
+ * and for tests of the planner. */
 int csh_msm_plan(csh_curve_t curve, size_t n, uint32_t out[6]);
 
 /* ---- synthetic inputs (bench / full-size parity) -------------------------------------------------------
