@@ -318,9 +318,10 @@ int csh_msm_multi_dev(const csh_bases_t* bases, const size_t* offsets, size_t k,
     int (*bucket)(const void*, const MsmParams*, const SortOut*, hipStream_t, Arena*, void*, hipEvent_t*);
     void (*fold)(const void*, int, int, void*);
     size_t xyzz_bytes;
+    int (*occ)();  // accumulate waves of the group's kernel that fit one SIMD
   };
   auto ops_of = [](const Bases* B, Ops* o) -> bool {
-#define CSH_OPS(CFG) *o = Ops{msm_bucket_bytes<CFG>, msm_bucket_stage<CFG>, fold_windows_erased<CFG>, sizeof(XYZZ<CFG::Fq>)}; return true
+#define CSH_OPS(CFG) *o = Ops{msm_bucket_bytes<CFG>, msm_bucket_stage<CFG>, fold_windows_erased<CFG>, sizeof(XYZZ<CFG::Fq>), accum_occupancy<CFG>}; return true
     if (B->curve == CSH_BN254 && B->group == CSH_G1) { CSH_OPS(Bn254G1Cfg); }
     if (B->curve == CSH_BN254 && B->group == CSH_G2) { CSH_OPS(Bn254G2Cfg); }
     if (B->curve == CSH_BLS12_381 && B->group == CSH_G1) { CSH_OPS(Bls381G1Cfg); }
@@ -342,8 +343,10 @@ int csh_msm_multi_dev(const csh_bases_t* bases, const size_t* offsets, size_t k,
     const Bases* B = reinterpret_cast<const Bases*>(bases[i]);
     merged = merged && msm_use_table(B, n) && B->table_c == B0->table_c && B->table_W == B0->table_W;
   }
-  const MsmParams pdig = merged ? msm_plan_merged(n, bits, mont, B0->table_c, B0->table_W, B0->n, 0).dig : msm_plan(n, bits, mont);
-  MsmParams p = merged ? msm_plan_merged(n, bits, mont, B0->table_c, B0->table_W, B0->n, 0).srt : pdig;
+  int occ = 8;  // the shared plan's lane length suits the group with the fewest co-resident accumulate waves (a G2 handle: 1)
+  for (auto& o : ops) occ = std::min(occ, o.occ());
+  const MsmParams pdig = merged ? msm_plan_merged(n, bits, mont, B0->table_c, B0->table_W, B0->n, 0, occ).dig : msm_plan(n, bits, mont, occ);
+  MsmParams p = merged ? msm_plan_merged(n, bits, mont, B0->table_c, B0->table_W, B0->n, 0, occ).srt : pdig;
   size_t bucket_max = 0, win_bytes = 0;
   for (auto& o : ops) {
     bucket_max = std::max(bucket_max, o.bytes(&p));

@@ -741,7 +741,7 @@ struct MergedPlan {
   MsmParams dig;  // n points, W windows: digit kernel
   MsmParams srt;  // n g entries per window, W' windows: sort + bucket stages
 };
-inline MergedPlan msm_plan_merged(size_t n, int scalar_bits, int mont, int c, int groups, size_t table_stride, size_t offset) {
+inline MergedPlan msm_plan_merged(size_t n, int scalar_bits, int mont, int c, int groups, size_t table_stride, size_t offset, int occ = 1) {
   MergedPlan m;
   MsmParams& d = m.dig;
   d.n = (uint32_t)n;
@@ -761,7 +761,7 @@ inline MergedPlan msm_plan_merged(size_t n, int scalar_bits, int mont, int c, in
   p.c = c;
   p.W = wp;
   p.NB = d.NB;
-  p.L = choose_lane_length((size_t)n2, p.W);
+  p.L = choose_lane_length((size_t)n2, p.W, occ);
   const uint32_t max_lanes = (uint32_t)((n2 + p.L - 1) / p.L);
   p.tmax = p.NB + max_lanes + 2;
   p.S = reduce_segments(p.NB, p.W, 1);
@@ -1047,7 +1047,7 @@ int msm_windows_dev(const Bases* B, size_t offset, size_t n, const uint64_t* sca
   MsmParams p, pdig;
   const void* points;
   if (merged) {
-    const MergedPlan m = msm_plan_merged(n, Fr::Params::BITS, mont, B->table_c, B->table_W, B->n, offset);
+    const MergedPlan m = msm_plan_merged(n, Fr::Params::BITS, mont, B->table_c, B->table_W, B->n, offset, accum_occupancy<Cfg>());
     p = m.srt;
     pdig = m.dig;
     points = B->table;
