@@ -132,6 +132,7 @@ class Ctx:
         B._check(self.L.csh_init(self.dev_index))
         self.stream = torch.cuda.current_stream().cuda_stream
         self.comm = None
+        self.hard_exit = False   # set when csh_comm_init_rank timed out: a detached helper thread is still blocked inside ncclCommInitRank
         self.exchange = "single GPU"
         if self.world > 1:
             self._make_comm(args)
@@ -147,13 +148,16 @@ class Ctx:
                 if self.rank == 0:
                     uid = torch.tensor(list(B.comm_unique_id()), dtype=torch.uint8)
                 dist.broadcast(uid, 0)
-                # ncclCommInitRank is collective: the library builds the communicator non-blocking and polls it against a deadline
+                # ncclCommInitRank is collective: the library makes the blocking call on a helper thread and waits for it against a deadline
                 # (csh_comm_init_rank, tune comm_timeout_ms), so a wedged bootstrap comes back as an error on every rank and the ranks
-                # agree below to fall back to the harness exchange
+                # agree below to fall back to the harness exchange. The helper thread of a timed-out call stays blocked inside RCCL: the
+                # process then leaves through os._exit once its line is printed (self.hard_exit), never through interpreter teardown.
                 B.tune_set("comm_timeout_ms", int(float(os.environ.get("BENCH_RCCL_INIT_TIMEOUT", "120")) * 1000))
                 self.comm = B.Comm.init_rank(bytes(uid.tolist()), self.world, self.rank)
             except Exception as e:  # noqa: BLE001
                 ok, err = 0, repr(e)
+                if "did not come up within" in err:
+                    self.hard_exit = True
         flag = torch.tensor([ok if want_rccl else 0], dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 1:
@@ -230,6 +234,33 @@ class MsmJob:
         if self.part is None:
             self.part = cx.torch.zeros(cx.hip.msm_partial_bytes(self.curve, self.group), dtype=cx.torch.uint8, device=cx.dev)
         B._check(L.csh_msm_partial_dev(self.h, C.c_size_t(0), C.c_size_t(self.n), C.c_void_p(self.sc.data_ptr()), 1, C.c_void_p(self.part.data_ptr()), C.c_void_p(cx.stream)))
+
+    def spin_up(self, min_s: float = 0.3, max_s: float = 3.0, batch: int = 10, tol: float = 0.02):
+        """Untimed steps BEFORE the W warm-up steps, whatever flags were passed: an idle MI355X needs a few hundred ms of continuous
+        work to reach its steady clocks (profiles/r04_j_ntt_context.log), and a 20-step region of 1.6 ms steps sits entirely inside that
+        ramp. Batches of `batch` steps run for at least `min_s` and until two consecutive batch medians agree within `tol` (cap `max_s`).
+        -> (steps issued, wall ms, median ms of the last batch)."""
+        cx = self.cx
+        t_begin = time.perf_counter()
+        prev, issued, last = None, 0, None
+        while True:
+            ts = []
+            for _ in range(batch):
+                t0 = time.perf_counter()
+                self.step()
+                ts.append(time.perf_counter() - t0)
+            issued += batch
+            last = sorted(ts)[len(ts) // 2]
+            el = time.perf_counter() - t_begin
+            done = el >= min_s and prev is not None and abs(last - prev) <= tol * prev
+            if cx.world > 1:   # all ranks leave together (a rank that stopped early would stall a collective step)
+                done = cx.max_over_ranks(0.0 if done or el >= max_s else 1.0) == 0.0
+            elif el >= max_s:
+                done = True
+            if done:
+                break
+            prev = last
+        return issued, (time.perf_counter() - t_begin) * 1e3, last * 1e3
 
     def timed(self, steps: int, warmup: int):
         cx = self.cx
@@ -367,13 +398,20 @@ def ntt_transforms(cx: Ctx, logn: int, warm_transforms: int, timed_pairs: int):
     dom.ifft_in_to_out_dev(data.data_ptr(), 1, cx.stream)
     first = pairs(timed_pairs)
     done = 1 + 2 * timed_pairs
-    while done < warm_transforms:
-        pairs(10)
+    # spin-up, same rule as the MSM lines: untimed batches (10 pairs) for at least `warm_transforms` transforms AND 0.3 s, until two
+    # consecutive batches agree within 2 % (cap 3 s)
+    t_begin, prev = time.perf_counter(), None
+    while True:
+        cur = pairs(10)
         done += 20
+        el = time.perf_counter() - t_begin
+        if el >= 3.0 or (done >= warm_transforms and el >= 0.3 and prev is not None and abs(cur - prev) <= 0.02 * prev):
+            break
+        prev = cur
     ms = pairs(timed_pairs)
     dom.free()
     del data
-    return {"ms": ms, "ms_first_batch": first, "warm_transforms": done}
+    return {"ms": ms, "ms_first_batch": first, "warm_transforms": done, "spinup_ms": round((time.perf_counter() - t_begin) * 1e3, 1)}
 
 
 def secondary_single_gpu(cx: Ctx, rin: dict, args):
@@ -388,9 +426,11 @@ def secondary_single_gpu(cx: Ctx, rin: dict, args):
         keep = wl == "bn254_g1" and not args.no_cpu_baseline
         pts_host = job.points_to_host() if keep else None
         job.drop_point_copy()
+        spin = job.spin_up(min_s=args.spinup_s, batch=3) if args.spinup_s > 0 else (0, 0.0, None)
         dt, res = job.timed(steps, 1)
         roof = msm_roofline(job, rin, logn)
         out[f"msm_{wl}_2p{logn}"] = {"points_per_s": job.n * steps / dt, "ms": dt / steps * 1e3, "result_check": job.check(res),
+                                     "steps": steps, "spinup_steps": spin[0], "spinup_ms": round(spin[1], 1),
                                      "roofline": {k: roof[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "traffic", "alu", "stage_ms") if k in roof}}
         if keep:
             cpu_inputs = (pts_host, job.sc.cpu().numpy().view(np.uint64), job.affine_words(res))
@@ -402,6 +442,8 @@ def secondary_single_gpu(cx: Ctx, rin: dict, args):
         job = MsmJob(cx, "bn254_g1", 0, 1 << 20, 1234)
         job.drop_point_copy()
         B._check(L.csh_bases_precompute_grouped(job.h, 16, 2))
+        if args.spinup_s > 0:
+            job.spin_up(min_s=args.spinup_s)
         dt, res = job.timed(20, 5)
         out["msm_bn254_g1_2p20_fixed_base_tables"] = {"points_per_s": job.n * 20 / dt, "ms": dt / 20 * 1e3, "result_check": job.check(res),
                                                       "table_rows": 2, "window_bits": 16}
@@ -464,6 +506,8 @@ def secondary_single_gpu(cx: Ctx, rin: dict, args):
         job.sc[kind == 1] = one
         job.sc[kind == 2] = rep
         torch.cuda.synchronize()
+        if args.spinup_s > 0:
+            job.spin_up(min_s=args.spinup_s)
         dt, res = job.timed(20, 5)
         out["msm_bn254_g1_2p20_witness_like"] = {"points_per_s": job.n * 20 / dt, "ms": dt / 20 * 1e3, "result_check": job.check(res),
                                                  "scalars": "1/4 zero, 1/4 one, 1/4 one repeated value, 1/4 uniform (Montgomery form)"}
@@ -484,7 +528,7 @@ def secondary_single_gpu(cx: Ctx, rin: dict, args):
     out[f"ntt_bn254_2p{logn}"] = {"elements_per_s": (1 << logn) / ms * 1e3, "ms": ms,
                              # the same 20 pairs right after ONE warm-up transform (what rounds 1-3 reported): the clocks of an idle GPU take tens of
                              # ms of continuous work to come up (profiles/r04_j_ntt_context.log: 0.566 -> 0.503 -> 0.480 -> 0.467 ms over four batches)
-                             "ms_first_batch_after_idle": nt["ms_first_batch"], "warm_up_transforms": nt["warm_transforms"],
+                             "ms_first_batch_after_idle": nt["ms_first_batch"], "warm_up_transforms": nt["warm_transforms"], "spinup_ms": nt["spinup_ms"],
                              "roofline": {"bound": "hbm", "kernel": "k_ntt_pass_r4 / k_ntt_pass_lazy (all passes of one transform)", "achieved": round(64.0 * (1 << logn) / ms / 1e6, 1),
                                           "peak": float(rin.get("hbm_peak_GBps", 8000.0)), "unit": "GB/s", "frac": round(64.0 * (1 << logn) / ms / 1e6 / float(rin.get("hbm_peak_GBps", 8000.0)), 4), "traffic": kin.get("traffic_bytes"),
                                           "traffic_source": kin.get("file"),
@@ -517,7 +561,7 @@ def secondary_single_gpu(cx: Ctx, rin: dict, args):
     from cosnarks_amd import groth16 as g16
     xfer_keys = ("stat_populate_us", "stat_join_wait_us", "stat_finish_us", "stat_d2h_slow", "stat_d2h_staged")
     xfer0 = {k: cx.B.tune_get(k) for k in xfer_keys}
-    out[f"groth16_prove_synthetic_2p{args.prove_log_n}"] = g16.bench_synthetic(hip.BN254, args.prove_log_n, 3, with_rep3=True)
+    out[f"groth16_prove_synthetic_2p{args.prove_log_n}"] = g16.bench_synthetic(hip.BN254, args.prove_log_n, 7 if args.quick else 21, with_rep3=True)
     # the host side of the trait path on THIS box: page population (worker time, the caller's wait for it), result copies that stalled /
     # were staged (HostXfer, csrc/capi.hip) -- summed over the witness maps of the entry above
     out[f"groth16_prove_synthetic_2p{args.prove_log_n}"]["host_result_copies"] = {k[5:]: cx.B.tune_get(k) - xfer0[k] for k in xfer_keys}
@@ -561,6 +605,8 @@ def secondary_multi_gpu(cx: Ctx, args):
         cnt = per if cx.rank < cx.world - 1 else total - start
         job = MsmJob(cx, wl, start, cnt, 777 + cx.rank)
         job.drop_point_copy()
+        if args.spinup_s > 0:
+            job.spin_up(min_s=args.spinup_s, batch=3)
         dt, res = job.timed(steps, 1)
         ok = job.check(res)
         out[f"msm_{wl}_2p{logn}_strong"] = {"points_per_s": total * steps / dt, "ms": dt / steps * 1e3, "result_check": ok, "ranks": cx.world,
@@ -701,6 +747,8 @@ def main():
     ap.add_argument("--exchange", choices=["rccl", "harness"], default="rccl", help="N > 1: RCCL behind the C ABI (default) or the gloo harness all-gather")
     ap.add_argument("--spinup", type=int, default=int(os.environ.get("BENCH_SPINUP", "0")),
                     help="untimed steps issued during setup, before the W warmup steps (brings the GPU out of its idle clocks)")
+    ap.add_argument("--spinup-s", type=float, default=float(os.environ.get("BENCH_SPINUP_S", "0.3")),
+                    help="minimum wall time of the automatic spin-up (0 disables it)")
     ap.add_argument("--placement", type=int, choices=[0, 1, 2], default=0, help="groth16_prove at N > 1: 0 auto, 1 whole queries per GPU, 2 ranges of every query per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
@@ -731,8 +779,14 @@ def main():
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "bn254_g1"
     pts_host = job.points_to_host() if want_cpu else None
     job.drop_point_copy()
+    # the first 20 steps after setup (what rounds 1-4 recorded under the driver's `--steps 20 --warmup 5`: inside the clock ramp of an idle GPU),
+    # kept beside `value`; then the spin-up (untimed, >= 0.3 s, until two consecutive 10-step medians agree within 2 %), then W warm-up
+    # steps and EXACTLY K timed steps between barriers
+    cold_dt, _ = job.timed(20, 3)
+    value_first_20 = total * 20 / cold_dt
     for _ in range(args.spinup):
         job.step()
+    spin_steps, spin_ms, spin_last_ms = job.spin_up(min_s=args.spinup_s) if args.spinup_s > 0 else (0, 0.0, None)
     dt, res = job.timed(args.steps, args.warmup)
     ms_per_step = dt / args.steps * 1e3
     value = total * args.steps / dt
@@ -785,11 +839,19 @@ def main():
             "config": {"workload": f"{label} Pippenger MSM, uniform scalars / known-dlog points, {per_rank}"
                                    + (" (BASELINE config 2)" if args.workload == "bn254_g1" and args.log_n == 20 else "")
                                    + (" (BASELINE config 5)" if args.workload.startswith("bls12_381") and args.log_n == 24 and args.scaling == "strong" else ""),
-                       "points_total": total, "points_per_gpu": n_local, "split": cx.exchange, "spinup_steps": args.spinup},
+                       "points_total": total, "points_per_gpu": n_local, "split": cx.exchange, "spinup_steps": args.spinup + spin_steps,
+                       "spinup_ms": round(spin_ms, 1), "spinup_last_batch_median_ms": spin_last_ms,
+                       "spinup_rule": "untimed steps before the W warm-up steps: batches of 10 for >= %.1f s until two consecutive batch medians agree within 2 %% (cap 3 s)" % args.spinup_s},
+            "value_first_20_steps": value_first_20, "ms_per_step_first_20_steps": cold_dt / 20 * 1e3,
             "roofline": roofline, "cpu_baseline": cpu_baseline, "result_check": check, "secondary": extras,
         }
         print(json.dumps(line))
     sys.stdout.flush()
+    if cx.hard_exit:           # a wedged RCCL bootstrap left a helper thread inside ncclCommInitRank: normal teardown could hang on it
+        if world > 1:
+            cx.dist.barrier()  # every rank has printed / finished its part
+        sys.stderr.flush()
+        os._exit(0)
     if cx.comm is not None:
         cx.comm.destroy()
     if world > 1:

@@ -188,20 +188,44 @@ def bench_synthetic(curve: int, log_domain: int, iters: int = 3, with_rep3: bool
     ms = (C.c_double * 6)()
     ph = (C.c_double * 3)()
     tr = (C.c_double * 5)()
+    r3 = (C.c_double * 26)()
+    mn = (C.c_double * 3)()
     ok = C.c_int(0)
-    rc = glib().cog16_bench_synthetic3(curve, log_domain, iters, ms, C.byref(ok), int(with_rep3), ph, tr)
+    rc = glib().cog16_bench_synthetic4(curve, log_domain, iters, ms, C.byref(ok), int(with_rep3), ph, tr, r3 if with_rep3 else None, mn)
     if rc != 0:
         raise CoSnarksHipError(glib().cog16_last_error().decode())
-    out = {"log_domain": log_domain, "witness_map_ms": ms[0], "prove_ms": ms[2],
+    out = {"log_domain": log_domain, "statistic": "median of %d runs after 2 warm-up runs (minimum beside it)" % iters,
+           "witness_map_ms": ms[0], "prove_ms": ms[2], "prove_ms_min": mn[0],
            "prove_phases_ms": {"witness_upload_and_map": ph[0], "msm_groups": ph[1], "finish": ph[2]},
            # the same prove driven the way rust/co-groth16-hip drives the C ABI behind the UNCHANGED reference: host slices in and out
            # of every seam call (one csh_groth16_witness_map_masks, h on the host, five concurrent csh_msm calls with host scalars)
-           "trait_path_ms": tr[0], "trait_path_phases_ms": {"witness_map_host_slices": tr[1], "msm_groups_host_scalars": tr[2], "finish": tr[3]},
+           "trait_path_ms": tr[0], "trait_path_ms_min": mn[1],
+           "trait_path_phases_ms": {"witness_map_host_slices": tr[1], "msm_groups_host_scalars": tr[2], "finish": tr[3]},
            "trait_path_closed_form_check": bool(tr[4]),
            "key_setup_ms": ms[3], "closed_form_check": bool(ok.value)}
     if with_rep3:
+        # the device-resident mirror: masks from the party's own ChaCha12 keys on the device -- NOT reachable behind the unchanged
+        # reference (Rep3Rand's generators are private, mpc-core/src/protocols/rep3/rngs.rs:83-86)
         out["rep3_three_parties_prove_ms"] = ms[4]
+        out["rep3_three_parties_prove_ms_min"] = mn[2]
         out["rep3_proofs_equal_plain"] = bool(ms[5])
+
+        def mode(o):
+            return {"three_parties_one_gpu_ms": o[0], "three_parties_one_gpu_ms_min": o[1],
+                    "party0_phases_ms": {"mask_draw": o[2], "witness_map_host_slices_incl_masks": o[3], "to_half_share": o[4],
+                                         "msm_groups_host_scalars": o[5], "finish": o[6]},
+                    "proofs_equal_plain": bool(o[7]),
+                    # one party with the GPU to itself (one GPU per party), its compute between the network rounds: witness map +
+                    # to_half_share + five MSMs (the finish's three curve points on the wire left out)
+                    "one_party_alone_ms": o[8],
+                    "one_party_alone_phases_ms": {"mask_draw": o[9], "witness_map_host_slices_incl_masks": o[10], "to_half_share": o[11],
+                                                  "msm_groups_host_scalars": o[12]}}
+
+        # BASELINE config 4 through the zero-upstream-edit path: what rust/co-groth16-hip drives for a Rep3 party. "host_masks" = its
+        # default (two masking_field_elements_vec draws per witness map on the host, rngs.rs:137-156, inside the timed region);
+        # "seeded_device_masks" = its opt-in all-GPU-parties mode (one public Rep3Rand::random_seeds() draw, rngs.rs:233, masks generated
+        # on the device; not wire-compatible with a reference CPU party in the same session)
+        out["rep3_trait_path"] = {"host_masks": mode(r3[0:13]), "seeded_device_masks": mode(r3[13:26])}
     return out
 
 
@@ -226,7 +250,7 @@ class trait_path:
 
     def __enter__(self):
         self.prev = glib().cog16_get_trait_path()
-        glib().cog16_set_trait_path(int(self.on))
+        glib().cog16_set_trait_path(int(self.on))   # True / 1: host masks; 2: seeded device masks for Rep3 (all parties must use it)
         return self
 
     def __exit__(self, *exc):

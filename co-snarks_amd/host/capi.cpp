@@ -527,9 +527,23 @@ struct SynthCircuit : SynthBase {
   }
 };
 
+// median of a sample and the index of the element that realises it (the phases reported beside a median are those of THAT run)
+static size_t median_index(const std::vector<double>& v) {
+  std::vector<size_t> idx(v.size());
+  for (size_t i = 0; i < idx.size(); ++i) idx[i] = i;
+  std::sort(idx.begin(), idx.end(), [&](size_t x, size_t y) { return v[x] < v[y]; });
+  return idx[idx.size() / 2];
+}
+
+// Every figure is the MEDIAN of `iters` runs after warm-up runs (median of >= 20; rounds 1-4 reported the minimum, which hid
+// a 17.7 -> 40 ms spread on one box, profiles/r04_zd_trait_modes.log); *_min entries keep the minimum beside it.
+// rep3_trait_out (nullable, 2 x 13 doubles: [0..12] host masks = the shim's default, [13..25] seeded device masks = its opt-in
+// all-GPU-parties mode): {three parties on this GPU: wall ms median, min; party 0 of the median run: mask draw, witness map (incl. masks),
+// to_half_share, five MSMs, finish; proofs equal the plain proof (1 / 0); ONE party alone on the GPU, no peers (witness map + to_half_share
+// + five MSMs, the finish's three curve points left out): ms median, mask draw, witness map, to_half_share, five MSMs}.
 template <class P>
 int bench_synth_t(int log_domain, int iters, double* out_ms, int* check_ok, const uint32_t* g1_words, const uint32_t* g2_words, bool with_rep3,
-                  double* phases_out = nullptr, double* trait_out = nullptr) {
+                  double* phases_out = nullptr, double* trait_out = nullptr, double* rep3_trait_out = nullptr, double* mins_out = nullptr) {
   using T = PlainGroth16Driver<P>;
   using Fr = typename P::Fr;
   using Fq = typename P::Fq;
@@ -539,59 +553,63 @@ int bench_synth_t(int log_domain, int iters, double* out_ms, int* check_ok, cons
   SharedWitness<P, Fr>& sw = sc.sw;
   const Fr r = sc.r, s = sc.s;
   out_ms[3] = sc.key_ms;
-  double best_h = 1e30, best_total = 1e30;
-  ProveTimes best_phases;
-  for (int it = 0; it < iters; ++it) {
+  std::vector<double> hs, totals;
+  std::vector<ProveTimes> phs;
+  for (int it = 0; it < iters + 2; ++it) {  // two warm-up rounds (streams, arenas and pooled buffers of the worker threads)
     auto a0 = std::chrono::steady_clock::now();
     std::vector<Fr> hh = CircomReduction::witness_map_from_matrices<P, T>(sc.st0, m, sw.public_inputs, sw.witness);
     auto a1 = std::chrono::steady_clock::now();
-    sc.prove(it + 1 == iters);
+    sc.prove(it + 1 == iters + 2);
     const double total = ms_since(a1);
-    best_h = std::min(best_h, std::chrono::duration<double, std::milli>(a1 - a0).count());
-    if (total < best_total) {
-      best_total = total;
-      best_phases = sc.phases;
-    }
+    if (it < 2) continue;
+    hs.push_back(std::chrono::duration<double, std::milli>(a1 - a0).count());
+    totals.push_back(total);
+    phs.push_back(sc.phases);
   }
-  out_ms[0] = best_h;               // host-facing witness_map_from_matrices alone (witness up, device pipeline, h down)
-  out_ms[1] = best_phases.msm_ms;   // the five MSM groups of the best prove (create_proof_device up to the join), host clock
-  out_ms[2] = best_total;           // Groth16 prove (prove_inner), key resident on the device
+  const size_t mi = median_index(totals);
+  out_ms[0] = hs[median_index(hs)];  // host-facing witness_map_from_matrices alone (witness up, device pipeline, h down)
+  out_ms[1] = phs[mi].msm_ms;        // the five MSM groups of the median prove (create_proof_device up to the join), host clock
+  out_ms[2] = totals[mi];            // Groth16 prove (prove_inner), key resident on the device
+  if (mins_out) mins_out[0] = *std::min_element(totals.begin(), totals.end());
   if (phases_out) {
-    phases_out[0] = best_phases.witness_ms;  // witness upload + device-resident witness map inside that prove
-    phases_out[1] = best_phases.msm_ms;
-    phases_out[2] = best_phases.finish_ms;
+    phases_out[0] = phs[mi].witness_ms;  // witness upload + device-resident witness map inside that prove
+    phases_out[1] = phs[mi].msm_ms;
+    phases_out[2] = phs[mi].finish_ms;
   }
   *check_ok = sc.closed_form();
   if (trait_out) {
     // The same circuit, key and witness through the "trait path" (groth16.hpp): the sequence rust/co-groth16-hip drives behind the unchanged
-    // reference -- one host-slice witness-map call, h on the host, five concurrent host-scalar MSMs. trait_out = {prove ms (best of iters),
+    // reference -- one host-slice witness-map call, h on the host, five concurrent host-scalar MSMs. trait_out = {prove ms (median of iters),
     // witness map ms, five MSMs ms, finish ms (of that prove), closed-form check of the trait-path proof (1 / 0)}.
     struct Restore {
       int prev = trait_path_flag().exchange(1);
       ~Restore() { trait_path_flag().store(prev); }
     } restore;
-    double best = 1e30;
-    ProveTimes ph;
-    sc.prove(false);  // warm the lanes of the five MSM threads
+    std::vector<double> tt;
+    std::vector<ProveTimes> tp;
     for (int it = 0; it < iters + 2; ++it) {
       auto a1 = std::chrono::steady_clock::now();
       sc.prove(false);
-      const double total = ms_since(a1);
-      if (total < best) best = total, ph = sc.phases;
+      if (it < 2) continue;  // warm the lanes of the five MSM threads
+      tt.push_back(ms_since(a1));
+      tp.push_back(sc.phases);
     }
     sc.prove(true);
-    trait_out[0] = best;
-    trait_out[1] = ph.witness_ms;
-    trait_out[2] = ph.msm_ms;
-    trait_out[3] = ph.finish_ms;
+    const size_t ti = median_index(tt);
+    trait_out[0] = tt[ti];
+    trait_out[1] = tp[ti].witness_ms;
+    trait_out[2] = tp[ti].msm_ms;
+    trait_out[3] = tp[ti].finish_ms;
     trait_out[4] = sc.closed_form() ? 1.0 : 0.0;
+    if (mins_out) mins_out[1] = *std::min_element(tt.begin(), tt.end());
   }
   const Proof<P>& proof = sc.proof;
   auto eq1 = [](const AffineT<Fq>& x, const AffineT<Fq>& y) { return x.x == y.x && x.y == y.y; };
 
-  // BASELINE config 4 at scale: three in-process Rep3 parties (device ChaCha12 masks, two-component NTTs, half-share MSMs)
-  // prove the same circuit with the same r, s; they share this GPU (or take one GPU each when the node has several, with
-  // key copies per device). Wall time of the whole three-party run; the agreed proof must equal the plain one.
+  // BASELINE config 4 at scale: three in-process Rep3 parties prove the same circuit with the same r, s; they share this GPU (or take
+  // one GPU each when the node has several, with key copies per device). Wall time of the whole three-party run; the agreed proof
+  // must equal the plain one. Three ways to drive a party: the device-resident mirror (device ChaCha12 masks from the party's own keys --
+  // reachable only with an upstream edit, the generators of Rep3Rand are private), and the two modes of the zero-upstream-edit trait path.
   out_ms[4] = 0;
   out_ms[5] = 0;
   if (with_rep3) {
@@ -614,39 +632,112 @@ int bench_synth_t(int log_domain, int iters, double* out_ms, int* check_ok, cons
       sw3[p].public_inputs = sw.public_inputs;
       sw3[p].witness = std::move(wsh[p]);
     }
-    double best3 = 1e30;
-    Proof<P> proofs[3];
-    for (int it = 0; it < iters; ++it) {
-      auto nets0 = LocalNetwork::new_parties(3), nets1 = LocalNetwork::new_parties(3);
-      std::string errs[3];
-      auto b0 = std::chrono::steady_clock::now();
-      std::vector<std::thread> th;
-      for (int p = 0; p < 3; ++p) {
-        th.emplace_back([&, p] {
-          try {
-            check(csh_init(0), "csh_init");
-            uint8_t my_seed[32];
-            ShareRng(4242ull + it, 100 + p).fill(my_seed, 32);
-            Rep3State state0 = Rep3State::create(nets0[p], my_seed);
-            Rep3State state1 = state0.fork(0);
-            proofs[p] = CoGroth16<P, T3>::template prove_inner<CircomReduction>(&nets0[p], &nets1[p], state0, state1, pk, m, sw3[p], &r3[p], &s3[p]);
-          } catch (const std::exception& e) {
-            errs[p] = e.what();
-        nets0[p].abort();  // let the other parties unwind instead of waiting on this one
-        nets1[p].abort();  // let the other parties unwind instead of waiting on this one
-          }
-        });
+    const int iters3 = iters < 7 ? iters : 7;  // 40-60 ms per round
+    // mode 0: device-resident mirror; 1: trait path with host masks; 2: trait path with seeded device masks
+    auto three_parties = [&](int mode, double* med_out, double* min_out, ProveTimes* party0, bool* ok_out) {
+      struct Restore {
+        int prev;
+        explicit Restore(int m) : prev(trait_path_flag().exchange(m)) {}
+        ~Restore() { trait_path_flag().store(prev); }
+      } restore(mode);
+      std::vector<double> walls;
+      std::vector<ProveTimes> p0;
+      Proof<P> proofs[3];
+      for (int it = 0; it < iters3 + 1; ++it) {  // one warm-up round
+        auto nets0 = LocalNetwork::new_parties(3), nets1 = LocalNetwork::new_parties(3);
+        std::string errs[3];
+        ProveTimes times[3];
+        auto b0 = std::chrono::steady_clock::now();
+        std::vector<std::thread> th;
+        for (int p = 0; p < 3; ++p) {
+          th.emplace_back([&, p] {
+            try {
+              check(csh_init(0), "csh_init");
+              uint8_t my_seed[32];
+              ShareRng(4242ull + it, 100 + p).fill(my_seed, 32);
+              Rep3State state0 = Rep3State::create(nets0[p], my_seed);
+              Rep3State state1 = state0.fork(0);
+              proofs[p] = CoGroth16<P, T3>::template prove_inner<CircomReduction>(&nets0[p], &nets1[p], state0, state1, pk, m, sw3[p], &r3[p], &s3[p]);
+              times[p] = last_prove_times();
+            } catch (const std::exception& e) {
+              errs[p] = e.what();
+              nets0[p].abort();  // let the other parties unwind instead of waiting on this one
+              nets1[p].abort();
+            }
+          });
+        }
+        for (auto& t : th) t.join();
+        const double wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - b0).count();
+        for (int p = 0; p < 3; ++p)
+          if (!errs[p].empty()) throw Error("rep3 party " + std::to_string(p) + ": " + errs[p]);
+        if (it == 0) continue;
+        walls.push_back(wall);
+        p0.push_back(times[0]);
       }
-      for (auto& t : th) t.join();
-      best3 = std::min(best3, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - b0).count());
+      const size_t wi = median_index(walls);
+      *med_out = walls[wi];
+      *min_out = *std::min_element(walls.begin(), walls.end());
+      if (party0) *party0 = p0[wi];
+      bool ok3 = true;
       for (int p = 0; p < 3; ++p)
-        if (!errs[p].empty()) throw Error("rep3 party " + std::to_string(p) + ": " + errs[p]);
-    }
-    out_ms[4] = best3;
-    bool ok3 = true;
-    for (int p = 0; p < 3; ++p)
-      ok3 = ok3 && eq1(proofs[p].a, proof.a) && eq1(proofs[p].c, proof.c) && proofs[p].b.x == proof.b.x && proofs[p].b.y == proof.b.y;
+        ok3 = ok3 && eq1(proofs[p].a, proof.a) && eq1(proofs[p].c, proof.c) && proofs[p].b.x == proof.b.x && proofs[p].b.y == proof.b.y;
+      *ok_out = ok3;
+    };
+    double med = 0, mn = 0;
+    bool ok3 = false;
+    three_parties(0, &med, &mn, nullptr, &ok3);
+    out_ms[4] = med;
     out_ms[5] = ok3 ? 1.0 : 0.0;
+    if (mins_out) mins_out[2] = mn;
+    if (rep3_trait_out) {
+      for (int mode = 1; mode <= 2; ++mode) {
+        double* o = rep3_trait_out + 13 * (mode - 1);
+        ProveTimes t0;
+        three_parties(mode, &o[0], &o[1], &t0, &ok3);
+        o[2] = t0.mask_ms;
+        o[3] = t0.witness_ms;
+        o[4] = t0.half_ms;
+        o[5] = t0.msm_ms;
+        o[6] = t0.finish_ms;
+        o[7] = ok3 ? 1.0 : 0.0;
+        // ONE party with the GPU to itself: what a party of a one-GPU-per-party deployment computes between its network rounds
+        struct Restore {
+          int prev;
+          explicit Restore(int m) : prev(trait_path_flag().exchange(m)) {}
+          ~Restore() { trait_path_flag().store(prev); }
+        } restore(mode);
+        uint8_t sd1[32], sd2[32];
+        ShareRng(777, 1).fill(sd1, 32);
+        ShareRng(777, 2).fill(sd2, 32);
+        Rep3State st{0, Rep3Rand(sd1, sd2)};
+        std::vector<double> alone;
+        std::vector<ProveTimes> ap;
+        for (int it = 0; it < iters + 2; ++it) {
+          auto a0 = std::chrono::steady_clock::now();
+          ProveTimes pt;
+          UninitBuf<Fr> h = CircomReduction::witness_map_trait_path<P, T3>(st, m, sw3[0].public_inputs, sw3[0].witness);
+          pt.mask_ms = last_prove_times().mask_ms;
+          pt.witness_ms = ms_since(a0);
+          auto a1 = std::chrono::steady_clock::now();
+          UninitBuf<Fr> half(sw3[0].witness.size());
+          parallel_for(half.size(), 1 << 16, [&](size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; ++i) half.data()[i] = T3::to_half_share(sw3[0].witness[i]);
+          });
+          pt.half_ms = ms_since(a1);
+          (void)CoGroth16<P, T3>::msm_groups_trait_path(0, pk, r3[0], s3[0], h.data(), h.size(), sw3[0].public_inputs, half.data(), half.size());
+          pt.msm_ms = last_prove_times().msm_ms;
+          if (it < 2) continue;
+          alone.push_back(ms_since(a0));
+          ap.push_back(pt);
+        }
+        const size_t ai = median_index(alone);
+        o[8] = alone[ai];
+        o[9] = ap[ai].mask_ms;
+        o[10] = ap[ai].witness_ms;
+        o[11] = ap[ai].half_ms;
+        o[12] = ap[ai].msm_ms;
+      }
+    }
   }
   return 0;
 }
@@ -1332,6 +1423,8 @@ int cog16_prove_shamir(int curve, const uint8_t* zkey, size_t zlen, const uint8_
 int cog16_bench_synthetic2(int curve, int log_domain, int iters, double* out_ms /* 6 entries */, int* check_ok, int with_rep3,
                            double* phases_out /* 3 entries: witness, msm, finish ms of the best prove; nullable */);
 int cog16_bench_synthetic3(int curve, int log_domain, int iters, double* out_ms, int* check_ok, int with_rep3, double* phases_out, double* trait_out);
+int cog16_bench_synthetic4(int curve, int log_domain, int iters, double* out_ms, int* check_ok, int with_rep3, double* phases_out, double* trait_out,
+                           double* rep3_trait_out, double* mins_out);
 int cog16_bench_synthetic(int curve, int log_domain, int iters, double* out_ms /* 6 entries */, int* check_ok, int with_rep3) {
   return cog16_bench_synthetic2(curve, log_domain, iters, out_ms, check_ok, with_rep3, nullptr);
 }
@@ -1340,9 +1433,15 @@ int cog16_bench_synthetic2(int curve, int log_domain, int iters, double* out_ms,
 }
 // ... and trait_out (5 entries, nullable): the same prove through the trait path (see bench_synth_t)
 int cog16_bench_synthetic3(int curve, int log_domain, int iters, double* out_ms, int* check_ok, int with_rep3, double* phases_out, double* trait_out) {
+  return cog16_bench_synthetic4(curve, log_domain, iters, out_ms, check_ok, with_rep3, phases_out, trait_out, nullptr, nullptr);
+}
+// + rep3_trait_out (26 doubles, layout at bench_synth_t) and mins_out (3 doubles: minimum of prove, trait path, three Rep3 parties)
+int cog16_bench_synthetic4(int curve, int log_domain, int iters, double* out_ms, int* check_ok, int with_rep3, double* phases_out, double* trait_out,
+                           double* rep3_trait_out, double* mins_out) {
   try {
-    if (curve == 0) return bench_synth_t<Bn254>(log_domain, iters, out_ms, check_ok, csh::Bn254G1Gen, csh::Bn254G2Gen, with_rep3 != 0, phases_out, trait_out);
-    if (curve == 1) return bench_synth_t<Bls12_381>(log_domain, iters, out_ms, check_ok, csh::Bls381G1Gen, csh::Bls381G2Gen, with_rep3 != 0, phases_out, trait_out);
+    if (iters < 1) throw Error("cog16_bench_synthetic: iters < 1");
+    if (curve == 0) return bench_synth_t<Bn254>(log_domain, iters, out_ms, check_ok, csh::Bn254G1Gen, csh::Bn254G2Gen, with_rep3 != 0, phases_out, trait_out, rep3_trait_out, mins_out);
+    if (curve == 1) return bench_synth_t<Bls12_381>(log_domain, iters, out_ms, check_ok, csh::Bls381G1Gen, csh::Bls381G2Gen, with_rep3 != 0, phases_out, trait_out, rep3_trait_out, mins_out);
     g_err = "unknown curve";
     return -1;
   } catch (const std::exception& e) {
@@ -1368,8 +1467,9 @@ const char* cog16_last_error(void) { return g_err.c_str(); }
 
 // 1: every prove_inner of this process runs the "trait path" (groth16.hpp: the sequence rust/co-groth16-hip drives behind the unchanged
 // reference -- host slices at every seam, one witness-map call, five concurrent host-scalar MSMs); 0: the device-resident prove.
+// 2: the trait path with the shim's opt-in seeded Rep3 masks (groth16.hpp witness_map_trait_path).
 int cog16_set_trait_path(int on) {
-  trait_path_flag().store(on ? 1 : 0);
+  trait_path_flag().store(on == 2 ? 2 : (on ? 1 : 0));
   return 0;
 }
 int cog16_get_trait_path(void) { return trait_path_flag().load(); }

@@ -78,38 +78,12 @@ struct DomainCache {
 // The "trait path": the mirror driven exactly as rust/co-groth16-hip drives the C ABI from the UNCHANGED reference -- every seam call
 // takes and returns host slices (one csh_groth16_witness_map_masks per witness map, h back on the host; to_half_share on the host; five
 // concurrent csh_msm calls with host scalars, rayon_join5 of groth16.rs:227-294). Off by default: the mirror's own prove keeps the
-// witness and h on the device. cog16_set_trait_path(1) / COG16_TRAIT_PATH=1 switch every prove_inner of the process over.
+// witness and h on the device. cog16_set_trait_path(1) / COG16_TRAIT_PATH=1 switch every prove_inner of the process over; 2 = the same
+// with the shim's opt-in seeded Rep3 masks (one Rep3Rand::random_seeds() draw per witness map, both mask vectors generated on the device).
 inline std::atomic<int>& trait_path_flag() {
   static std::atomic<int> f{getenv("COG16_TRAIT_PATH") ? atoi(getenv("COG16_TRAIT_PATH")) : 0};
   return f;
 }
-
-// Allocated, never zero-filled host memory for a result the library writes in full: what `Vec::with_capacity(n)` + `set_len(n)` is in
-// the Rust shim. (A value-initialised std::vector of 32 MB costs 4.7 ms of page faults and zero fill on the GPU hosts,
-// profiles/r04_b_prefault_probe.jsonl; the library populates the pages from helper threads while the device works.)
-template <class E>
-struct UninitBuf {
-  E* p = nullptr;
-  size_t n = 0;
-  UninitBuf() = default;
-  explicit UninitBuf(size_t count) : p(static_cast<E*>(malloc(count * sizeof(E) + 1))), n(count) {
-    if (!p) throw Error("out of host memory");
-  }
-  UninitBuf(UninitBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; }
-  UninitBuf& operator=(UninitBuf&& o) noexcept {
-    if (this != &o) {
-      free(p);
-      p = o.p, n = o.n, o.p = nullptr;
-    }
-    return *this;
-  }
-  UninitBuf(const UninitBuf&) = delete;
-  UninitBuf& operator=(const UninitBuf&) = delete;
-  ~UninitBuf() { free(p); }
-  E* data() { return p; }
-  const E* data() const { return p; }
-  size_t size() const { return n; }
-};
 
 // ---- R1CSToQAP: CircomReduction::witness_map_from_matrices (reduction.rs:77-193) ------------------------------
 struct CircomReduction {
@@ -179,9 +153,28 @@ struct CircomReduction {
     csh_domain_t domain = DomainCache::get().lookup(P::ID, (uint32_t)power, (const uint64_t*)&group_gen, &rc);  // :93
     if (rc == CSH_ERR_DOMAIN) throw Error("Polynomial Degree too large");
     check(rc, "csh_domain_create");
-    const std::vector<Fr> mask_c = T::masks(state, domain_size);   // "c: local_mul_vec" (:160)
-    const std::vector<Fr> mask_ab = T::masks(state, domain_size);  // "ab" (:182)
     UninitBuf<typename T::ArithmeticHalfShare> h(domain_size);
+    const auto t_mask0 = std::chrono::steady_clock::now();
+    if constexpr (T::DEVICE_MASKS) {
+      if (trait_path_flag().load(std::memory_order_relaxed) == 2) {
+        // Opt-in "all parties on GPUs" mode of the shim (hip_reduction.rs, COSNARKS_HIP_SEEDED_MASKS): instead of two host mask vectors
+        // the party draws ONE pair of fresh correlated seeds through the public Rep3Rand::random_seeds() (rngs.rs:233) and the device
+        // generates both mask vectors from them (ChaCha12, chunks [0, n) = "c", [n, 2n) = "ab"). Every party consumes the same 2 x 128
+        // keystream bytes, so the pairwise correlation survives and the three masks still cancel; the mask VALUES differ from what a
+        // reference CPU party would draw, so all three parties of a session must run this mode (not wire-compatible with a CPU party).
+        uint8_t s1[32], s2[32];
+        state.rand.random_seeds(s1, s2);
+        last_prove_times().mask_ms = ms_since(t_mask0);
+        rc = csh_groth16_witness_map(domain, (const uint64_t*)&coset_shift, T::PROTOCOL, state.id, matrices.a_dev, matrices.b_dev, num_constraints,
+                                     (const uint64_t*)public_inputs.data(), num_inputs, (const uint64_t*)private_witness.data(), private_witness.size(),
+                                     s1, 0, s2, 0, (uint64_t*)h.data());
+        check(rc, "csh_groth16_witness_map (seeded)");
+        return h;
+      }
+    }
+    const UninitBuf<Fr> mask_c = T::masks(state, domain_size);   // "c: local_mul_vec" (:160)
+    const UninitBuf<Fr> mask_ab = T::masks(state, domain_size);  // "ab" (:182)
+    last_prove_times().mask_ms = ms_since(t_mask0);
     rc = csh_groth16_witness_map_masks(domain, (const uint64_t*)&coset_shift, T::PROTOCOL, state.id, matrices.a_dev, matrices.b_dev, num_constraints,
                                        (const uint64_t*)public_inputs.data(), num_inputs, (const uint64_t*)private_witness.data(), private_witness.size(),
                                        mask_c.empty() ? nullptr : (const uint64_t*)mask_c.data(), mask_ab.empty() ? nullptr : (const uint64_t*)mask_ab.data(),
@@ -261,8 +254,8 @@ struct CircomReduction {
       rc = csh_groth16_h_rep3_seeded(domain, (const uint64_t*)&coset_shift, (uint64_t*)a.data(), (uint64_t*)b.data(), run.seed1, run.off1,
                                      run.seed2, run.off2, (uint64_t*)h.data());
     } else {
-      std::vector<Fr> mask_c = T::masks(state, domain_size);
-      std::vector<Fr> mask_ab = T::masks(state, domain_size);
+      const UninitBuf<Fr> mask_c = T::masks(state, domain_size);
+      const UninitBuf<Fr> mask_ab = T::masks(state, domain_size);
       rc = csh_groth16_h(domain, (const uint64_t*)&coset_shift, T::PROTOCOL, (uint64_t*)a.data(), (uint64_t*)b.data(),
                          mask_c.empty() ? nullptr : (const uint64_t*)mask_c.data(), mask_ab.empty() ? nullptr : (const uint64_t*)mask_ab.data(),
                          (uint64_t*)h.data());
@@ -425,34 +418,42 @@ struct CoGroth16 {
   // each calling the driver's msm_public_points_hs with HOST scalars (one synchronous csh_msm per query: scalars up on the thread's
   // own lane stream, so one call's upload, sort and tail overlap another's accumulation); h is consumed from the host buffer the
   // witness map returned. No shared digit sort, no device-resident operands: nothing the unchanged reference could not do.
-  static Proof<P> create_proof_trait_path(const Net* net0, const Net* net1, State& state0, State& state1, const ProvingKey<P>& pkey, const Share& r,
-                                          const Share& s, const Half* h, size_t h_len, const std::vector<Fr>& input_assignment, const Half* aux,
-                                          size_t n_aux) {
-    const Proj<Fq> delta_g1 = into_group(pkey.delta_g1);
-    const Proj<Fq2> delta_g2 = into_group(pkey.delta_g2);
-    const int id = state0.id;
-    std::vector<Fr> inputs(input_assignment.begin() + 1, input_assignment.end());  // &input_assignment[1..]
-    const size_t pub_len = inputs.size();
+  struct MsmGroups {
     Proj<Fq> r_g1, s_g1, l_acc, h_acc;
     Proj<Fq2> s_g2;
+  };
+  // groth16.rs:227-294 on the trait path: the five closures of rayon_join5, no network involved
+  static MsmGroups msm_groups_trait_path(int id, const ProvingKey<P>& pkey, const Share& r, const Share& s, const Half* h, size_t h_len,
+                                         const std::vector<Fr>& input_assignment, const Half* aux, size_t n_aux) {
+    const Proj<Fq> delta_g1 = into_group(pkey.delta_g1);
+    const Proj<Fq2> delta_g2 = into_group(pkey.delta_g2);
+    std::vector<Fr> inputs(input_assignment.begin() + 1, input_assignment.end());  // &input_assignment[1..]
+    const size_t pub_len = inputs.size();
+    MsmGroups g;
     const auto t_msm0 = std::chrono::steady_clock::now();
     int cur_dev = 0;
     (void)csh_current_device(&cur_dev);
     auto bind = [cur_dev] { check(csh_init(cur_dev), "csh_init"); };
     {
       Span sp_msm("5 msm groups, host scalars (trait path)");
-      Joined t1([&] { bind(); r_g1 = finish_coeff<Fq>(id, T::template scalar_mul_public_point_hs<Fq>(delta_g1, T::to_half_share(r)), pkey.a_query, pkey.alpha_g1, inputs,
-                                                     msm_device<Fq>(BasesView{pkey.a_query.dev, 1 + pub_len, pkey.a_query.size() - 1 - pub_len}, aux, n_aux)); });
-      Joined t2([&] { bind(); s_g1 = finish_coeff<Fq>(id, T::template scalar_mul_public_point_hs<Fq>(delta_g1, T::to_half_share(s)), pkey.b_g1_query, pkey.beta_g1, inputs,
-                                                     msm_device<Fq>(BasesView{pkey.b_g1_query.dev, 1 + pub_len, pkey.b_g1_query.size() - 1 - pub_len}, aux, n_aux)); });
-      Joined t3([&] { bind(); s_g2 = finish_coeff<Fq2>(id, T::template scalar_mul_public_point_hs<Fq2>(delta_g2, T::to_half_share(s)), pkey.b_g2_query, pkey.beta_g2, inputs,
-                                                      msm_device<Fq2>(BasesView{pkey.b_g2_query.dev, 1 + pub_len, pkey.b_g2_query.size() - 1 - pub_len}, aux, n_aux)); });
-      Joined t4([&] { bind(); l_acc = msm_device<Fq>(BasesView{pkey.l_query.dev, 0, pkey.l_query.size()}, aux, n_aux); });
-      Joined t5([&] { bind(); h_acc = msm_device<Fq>(BasesView{pkey.h_query.dev, 0, pkey.h_query.size()}, h, h_len); });
+      Joined t1([&] { bind(); g.r_g1 = finish_coeff<Fq>(id, T::template scalar_mul_public_point_hs<Fq>(delta_g1, T::to_half_share(r)), pkey.a_query, pkey.alpha_g1, inputs,
+                                                       msm_device<Fq>(BasesView{pkey.a_query.dev, 1 + pub_len, pkey.a_query.size() - 1 - pub_len}, aux, n_aux)); });
+      Joined t2([&] { bind(); g.s_g1 = finish_coeff<Fq>(id, T::template scalar_mul_public_point_hs<Fq>(delta_g1, T::to_half_share(s)), pkey.b_g1_query, pkey.beta_g1, inputs,
+                                                       msm_device<Fq>(BasesView{pkey.b_g1_query.dev, 1 + pub_len, pkey.b_g1_query.size() - 1 - pub_len}, aux, n_aux)); });
+      Joined t3([&] { bind(); g.s_g2 = finish_coeff<Fq2>(id, T::template scalar_mul_public_point_hs<Fq2>(delta_g2, T::to_half_share(s)), pkey.b_g2_query, pkey.beta_g2, inputs,
+                                                        msm_device<Fq2>(BasesView{pkey.b_g2_query.dev, 1 + pub_len, pkey.b_g2_query.size() - 1 - pub_len}, aux, n_aux)); });
+      Joined t4([&] { bind(); g.l_acc = msm_device<Fq>(BasesView{pkey.l_query.dev, 0, pkey.l_query.size()}, aux, n_aux); });
+      Joined t5([&] { bind(); g.h_acc = msm_device<Fq>(BasesView{pkey.h_query.dev, 0, pkey.h_query.size()}, h, h_len); });
       t1.join(); t2.join(); t3.join(); t4.join(); t5.join();  // the first failure is rethrown; ~Joined reaps the rest
     }
     last_prove_times().msm_ms = ms_since(t_msm0);
-    return finish_proof(net0, net1, state0, state1, pkey, r, s, r_g1, s_g1, s_g2, l_acc, h_acc);
+    return g;
+  }
+  static Proof<P> create_proof_trait_path(const Net* net0, const Net* net1, State& state0, State& state1, const ProvingKey<P>& pkey, const Share& r,
+                                          const Share& s, const Half* h, size_t h_len, const std::vector<Fr>& input_assignment, const Half* aux,
+                                          size_t n_aux) {
+    const MsmGroups g = msm_groups_trait_path(state0.id, pkey, r, s, h, h_len, input_assignment, aux, n_aux);
+    return finish_proof(net0, net1, state0, state1, pkey, r, s, g.r_g1, g.s_g1, g.s_g2, g.l_acc, g.h_acc);
   }
 
   // the same with h and aux_assignment already resident on the device
@@ -655,10 +656,12 @@ struct CoGroth16 {
         if constexpr (std::is_same<Share, Half>::value) {
           return create_proof_trait_path(net0, net1, state0, state1, pkey, r, s, h.data(), h.size(), w.public_inputs, w.witness.data(), w.witness.size());
         } else {
+          const auto t_half0 = std::chrono::steady_clock::now();
           UninitBuf<Half> half(w.witness.size());
           parallel_for(half.size(), 1 << 16, [&](size_t lo, size_t hi) {
             for (size_t i = lo; i < hi; ++i) half.data()[i] = T::to_half_share(w.witness[i]);
           });
+          last_prove_times().half_ms = ms_since(t_half0);
           return create_proof_trait_path(net0, net1, state0, state1, pkey, r, s, h.data(), h.size(), w.public_inputs, half.data(), half.size());
         }
       }

@@ -48,14 +48,30 @@ struct Rep3PrimeFieldShare {
 struct Rep3Rand {
   ChaCha12 rng1, rng2;  // own key, previous party's key (rep3.rs:71-76 setup_prf)
   Rep3Rand(const uint8_t s1[32], const uint8_t s2[32]) : rng1(s1), rng2(s2) {}
+  // rngs.rs:137-156. The reference fills its two byte vectors under rayon::join and converts them with par_chunks(..).with_min_len(512)
+  // into a freshly collected Vec. The keystream is counter-mode, so the mirror cuts BOTH streams into the same element ranges over the
+  // host's cores (same bytes, same elements, the generators end where a serial draw would leave them) and writes into memory that
+  // is not zero-filled first -- this is the host cost a Rep3 party pays per local_mul_vec on the zero-upstream-edit path
+  // (bench: rep3_trait_path.mask_draw_ms).
   template <class Fr>
-  std::vector<Fr> masking_field_elements_vec(size_t len) {  // rngs.rs:137-156
-    std::vector<uint8_t> a(32 * len), b(32 * len);
-    rng1.fill_bytes(a.data(), a.size());
-    rng2.fill_bytes(b.data(), b.size());
-    std::vector<Fr> out(len);
-    for (size_t i = 0; i < len; ++i)
-      out[i] = Fr::sub(from_be_bytes_mod_order<Fr>(&a[32 * i]), from_be_bytes_mod_order<Fr>(&b[32 * i]));
+  UninitBuf<Fr> masking_field_elements_vec(size_t len) {
+    UninitBuf<Fr> out(len);
+    const uint64_t p1 = rng1.byte_pos(), p2 = rng2.byte_pos();
+    const ChaCha12 &r1 = rng1, &r2 = rng2;
+    Fr* o = out.data();
+    parallel_for(len, 1 << 13, [&r1, &r2, p1, p2, o](size_t lo, size_t hi) {
+      ChaCha12 a = r1, b = r2;
+      a.seek(p1 + 32 * (uint64_t)lo);
+      b.seek(p2 + 32 * (uint64_t)lo);
+      uint8_t x[32], y[32];
+      for (size_t i = lo; i < hi; ++i) {
+        a.fill_bytes(x, 32);
+        b.fill_bytes(y, 32);
+        o[i] = Fr::sub(from_be_bytes_mod_order<Fr>(x), from_be_bytes_mod_order<Fr>(y));
+      }
+    });
+    rng1.seek(p1 + 32 * (uint64_t)len);
+    rng2.seek(p2 + 32 * (uint64_t)len);
     return out;
   }
   template <class Fr>
@@ -84,10 +100,26 @@ struct Rep3Rand {
     rng2.seek(p2 + 32 * (uint64_t)n);
     return r;
   }
+  // `rng.gen::<[u8; 32]>()` of rand 0.8 (the reference pins rand = "0.8", Cargo.toml:70; un-vendored): Standard samples an array element
+  // by element and a u8 as `next_u32() as u8`, so a 32-byte seed consumes 32 keystream WORDS (128 bytes), one low byte each. Restated
+  // from the published crate; no reference fixture pins it (it only matters if a mirror party ever shared a session with a reference
+  // party after a fork -- the Rust shim runs the reference's own code here).
+  static void gen_seed(ChaCha12& rng, uint8_t out[32]) {
+    for (int i = 0; i < 32; ++i) {
+      uint8_t w[4];
+      rng.fill_bytes(w, 4);
+      out[i] = w[0];  // little-endian word: the low byte
+    }
+  }
+  // rngs.rs:233-237: one fresh seed from each generator. Party i's rng1 is party i+1's rng2 (rep3.rs:71-76), so the seed party i draws
+  // from rng1 equals the one party i+1 draws from rng2: streams keyed with them are correlated exactly like the parents.
+  void random_seeds(uint8_t s1[32], uint8_t s2[32]) {
+    gen_seed(rng1, s1);
+    gen_seed(rng2, s2);
+  }
   Rep3Rand fork() {  // rngs.rs:96-100
     uint8_t s1[32], s2[32];
-    rng1.fill_bytes(s1, 32);
-    rng2.fill_bytes(s2, 32);
+    random_seeds(s1, s2);
     return Rep3Rand(s1, s2);
   }
 };
@@ -144,7 +176,7 @@ struct PlainGroth16Driver {
     check(csh_vec_mul_table(P::ID, (uint64_t*)c.data(), (const uint64_t*)roots.data(), c.size(), 1), "csh_vec_mul_table");
   }
   static ArithmeticHalfShare to_half_share(const ArithmeticShare& a) { return a; }
-  static std::vector<Fr> masks(State&, size_t) { return {}; }
+  static UninitBuf<Fr> masks(State&, size_t) { return {}; }
   template <class F>
   static Proj<F> msm_public_points_hs(const BasesView& pts, const std::vector<ArithmeticHalfShare>& s) {  // mpc/plain.rs:66-74
     return msm_device<F>(pts, s.data(), s.size());
@@ -203,9 +235,9 @@ struct Rep3Groth16Driver {
     }
     return out;
   }
-  static std::vector<Fr> masks(State& st, size_t n) { return st.rand.template masking_field_elements_vec<Fr>(n); }
+  static UninitBuf<Fr> masks(State& st, size_t n) { return st.rand.template masking_field_elements_vec<Fr>(n); }
   static std::vector<Fr> local_mul_vec(const std::vector<ArithmeticShare>& a, const std::vector<ArithmeticShare>& b, State& st) {
-    std::vector<Fr> mask = masks(st, a.size());  // arithmetic.rs:132-146
+    const UninitBuf<Fr> mask = masks(st, a.size());  // arithmetic.rs:132-146
     std::vector<Fr> out(a.size());
     check(csh_rep3_local_mul_vec(P::ID, (const uint64_t*)a.data(), (const uint64_t*)b.data(), (const uint64_t*)mask.data(),
                                  (uint64_t*)out.data(), a.size()), "csh_rep3_local_mul_vec");
@@ -344,7 +376,7 @@ struct ShamirGroth16Driver {
     return PlainGroth16Driver<P>::evaluate_constraint(0, lhs, pub, wit);
   }
   static std::vector<ArithmeticShare> promote_to_trivial_shares(int, const std::vector<Fr>& v) { return v; }  // shamir/arithmetic.rs:229-231
-  static std::vector<Fr> masks(State&, size_t) { return {}; }
+  static UninitBuf<Fr> masks(State&, size_t) { return {}; }
   static std::vector<Fr> local_mul_vec(const std::vector<Fr>& a, const std::vector<Fr>& b, State&) {  // shamir/arithmetic.rs:73-79
     std::vector<Fr> out(a.size());
     check(csh_vec_mul(P::ID, (const uint64_t*)a.data(), (const uint64_t*)b.data(), (uint64_t*)out.data(), a.size()), "csh_vec_mul");

@@ -6,6 +6,7 @@
 // ingest the reference delegates to taceo-circom-types (co-circom/src/bin/co-circom.rs:1005-1006).
 // Field / curve arithmetic on the host reuses the kernels' own templates (csrc/field.hpp, curve.hpp).
 #pragma once
+#include <sched.h>
 #include <stdint.h>
 #include <string.h>
 
@@ -76,11 +77,22 @@ struct Span {
 };
 
 // rayon-style parallel for over [0, n) in contiguous chunks (the reference uses par_iter().with_min_len(k))
+// threads worth starting: the CPUs this process may run on (a cgroup / affinity mask on a 256-CPU host often grants 16), as rayon's
+// default pool size does (available_parallelism)
+inline size_t host_threads() {
+  static const size_t n = [] {
+    size_t k = 0;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) k = (size_t)CPU_COUNT(&set);
+    if (k == 0) k = std::thread::hardware_concurrency();
+    if (k == 0) k = 1;
+    return k > 64 ? (size_t)64 : k;
+  }();
+  return n;
+}
 template <class Fn>
 inline void parallel_for(size_t n, size_t min_len, Fn fn) {
-  size_t nt = std::thread::hardware_concurrency();
-  if (nt == 0) nt = 1;
-  if (nt > 64) nt = 64;
+  size_t nt = host_threads();
   size_t chunks = std::min(nt, std::max<size_t>(1, n / std::max<size_t>(1, min_len)));
   if (chunks <= 1) {
     fn(0, n);
@@ -115,8 +127,40 @@ struct ProverDevices {
 
 // wall-clock phases of the calling thread's last prove_inner (host clock around synchronous device work): witness upload + map,
 // the five MSM groups, the finish (openings, a few point operations)
+// Allocated, never zero-filled host memory for a result that is written in full: what `Vec::with_capacity(n)` + `set_len(n)` (or a
+// `.collect()` into a fresh Vec) is in Rust. (A value-initialised std::vector of 32 MB costs 4.7 ms of page faults and zero fill on the
+// GPU hosts, profiles/r04_b_prefault_probe.jsonl; the library populates the pages of its results from helper threads while the device works.)
+template <class E>
+struct UninitBuf {
+  E* p = nullptr;
+  size_t n = 0;
+  UninitBuf() = default;
+  explicit UninitBuf(size_t count) : p(static_cast<E*>(malloc(count * sizeof(E) + 1))), n(count) {
+    if (!p) throw Error("out of host memory");
+  }
+  UninitBuf(UninitBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr, o.n = 0; }
+  UninitBuf& operator=(UninitBuf&& o) noexcept {
+    if (this != &o) {
+      free(p);
+      p = o.p, n = o.n, o.p = nullptr, o.n = 0;
+    }
+    return *this;
+  }
+  UninitBuf(const UninitBuf&) = delete;
+  UninitBuf& operator=(const UninitBuf&) = delete;
+  ~UninitBuf() { free(p); }
+  E* data() { return p; }
+  const E* data() const { return p; }
+  size_t size() const { return n; }
+  bool empty() const { return n == 0; }
+  E& operator[](size_t i) { return p[i]; }
+  const E& operator[](size_t i) const { return p[i]; }
+};
+
 struct ProveTimes {
   double witness_ms = 0, msm_ms = 0, finish_ms = 0;
+  double mask_ms = 0;  // trait path, Rep3: the two host mask draws (or the seed draw) inside witness_ms
+  double half_ms = 0;  // trait path, Rep3: to_half_share over the witness (groth16.rs:159-163), between witness_ms and msm_ms
 };
 inline ProveTimes& last_prove_times() {
   static thread_local ProveTimes t;

@@ -150,30 +150,34 @@ def test_comm_init_deadline_and_blocking_fallback(gpu):
     """csh_comm_init_rank with more than one rank runs the (uninterruptible, collective) construction on a helper thread and waits for
     it against tune comm_timeout_ms: a rank whose peer never arrives (rank 0 of 2, nobody else calls) gets an error at the deadline
     instead of hanging for good, and the library stays usable. Run in a subprocess that leaves through os._exit: the abandoned
-    bootstrap thread of that process is still waiting for its peer. comm_timeout_ms = 0 constructs on the calling thread as before."""
+    bootstrap thread of that process is still waiting for its peer. (Round 5: this test took 107 s of the suite's 209 -- two in-process
+    one-rank RCCL communicators that test_rccl_rank_path_with_one_rank already builds, and a third inside the subprocess; RCCL's own
+    initialisation is 15-35 s per communicator here. What is left is the 2 s deadline itself plus a communicator that needs no RCCL.)"""
     import subprocess
     import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    t0 = time.perf_counter()
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "experiments", "rccl_deadline_probe.py"), "1", "0"], capture_output=True, text=True, timeout=120)
+    out = p.stdout
+    assert "did not come up within 2000 ms" in out and "error after 2." in out, (out, p.stderr[-500:])
+    assert "ok (0, 1, 0)" in out and out.rstrip().endswith("done"), out                 # the library is usable right after the abandoned construction
+    assert time.perf_counter() - t0 < 60, out
+    # comm_timeout_ms = 0 builds on the calling thread (one rank cannot wait for anybody: built inline whatever the deadline says)
     G = cv.BN254_G1
     F = H.FR["bn254"]
     r = H.rng(11)
     n = 300
     pts = H.rand_points(G, n, r)
     sc = H.rand_elems(F, n, r)
-    want = G.msm(pts, sc)
     bases = gpu.Bases(0, 0, cv.pack_points(G, pts))
     dsc = gpu.DeviceBuffer.from_host(H.pack(F, sc))
-    for timeout_ms in (0, 60000):
-        with gpu.tuned(comm_timeout_ms=timeout_ms):
-            comm = gpu.Comm.init_rank(gpu.bindings.comm_unique_id(), 1, 0)
-            assert G.eq(H.jac_to_affine(G, comm.msm_split_rank_dev(bases, dsc, n)), want)
-            comm.destroy()
+    with gpu.tuned(comm_timeout_ms=0):
+        comm = gpu.Comm.init_rank(None, 1, 0)
+        assert G.eq(H.jac_to_affine(G, comm.msm_split_rank_dev(bases, dsc, n)), G.msm(pts, sc))
+        comm.destroy()
     bases.free()
     dsc.free()
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    p = subprocess.run([sys.executable, os.path.join(root, "tools", "experiments", "rccl_deadline_probe.py"), "1"], capture_output=True, text=True, timeout=120)
-    out = p.stdout
-    assert "did not come up within 2000 ms" in out and "error after 2." in out, (out, p.stderr[-500:])
-    assert "ok (0, 1, 0)" in out and out.rstrip().endswith("done"), out                 # a one-rank communicator right after the abandoned one
 
 
 def test_comm_created_on_a_helper_thread(gpu):
