@@ -15,24 +15,42 @@ use mpc_core::protocols::shamir::{ShamirPrimeFieldShare, ShamirState};
 use mpc_core::MpcState;
 use mpc_net::Network;
 
+/// What a witness map (hip_reduction.rs) asks of the next `T::local_mul_vec` on the CALLING thread. The Rep3 generators are private
+/// (`Rep3Rand { rng1, rng2 }`, rngs.rs:83-86) and `R1CSToQAP::witness_map_from_matrices` is generic over `T`, so the only way to the
+/// party's randomness is through `T`'s own methods; the request travels in a thread-local and any driver but the Hip Rep3 one ignores it.
+#[derive(Clone, Copy, PartialEq, Eq, Debug)]
+pub enum MaskRequest {
+    /// an ordinary product
+    None,
+    /// return the mask vector of `n` entries a product of two n-vectors would add, and nothing else: `masking_field_elements_vec(n)`
+    /// (rngs.rs:137-156). The operands are EMPTY vectors -- no zero vectors of n shares are built to be thrown away (round 4 did:
+    /// 4 x 64 MB of element-wise `vec![default; n]` per mask at 2^20).
+    MaskOnly(usize),
+    /// draw one pair of fresh correlated seeds, `Rep3Rand::random_seeds()` (rngs.rs:233, public), leave them in [`take_seeds`] and
+    /// return an empty vector: the opt-in all-GPU-parties mode, the device generates both mask vectors from the seeds
+    Seeds,
+}
 thread_local! {
-    /// Set while a witness map draws its mask vectors through `T::local_mul_vec(zeros, zeros, state)` (hip_reduction.rs): the
-    /// product of two zero vectors IS the mask, so the Hip Rep3 driver returns `masking_field_elements_vec` directly instead of
-    /// shipping 160 bytes per entry of zeros and masks through the GPU. Any other driver ignores the flag and multiplies.
-    static MASK_ONLY: core::cell::Cell<bool> = const { core::cell::Cell::new(false) };
+    static MASK_REQUEST: core::cell::Cell<MaskRequest> = const { core::cell::Cell::new(MaskRequest::None) };
+    static SEEDS: core::cell::Cell<Option<([u8; 32], [u8; 32])>> = const { core::cell::Cell::new(None) };
 }
 
-/// Run `f` (one `T::local_mul_vec` call on the CALLING thread) with the mask-only hint set.
-pub fn mask_only<R>(f: impl FnOnce() -> R) -> R {
+/// Run `f` (one `T::local_mul_vec` call on the CALLING thread) with `req` posted.
+pub fn with_mask_request<R>(req: MaskRequest, f: impl FnOnce() -> R) -> R {
     struct Reset;
     impl Drop for Reset {
         fn drop(&mut self) {
-            MASK_ONLY.with(|m| m.set(false));
+            MASK_REQUEST.with(|m| m.set(MaskRequest::None));
         }
     }
-    MASK_ONLY.with(|m| m.set(true));
+    MASK_REQUEST.with(|m| m.set(req));
     let _reset = Reset; // also on unwind
     f()
+}
+
+/// The seeds the Hip Rep3 driver left for a `MaskRequest::Seeds` call (None: the driver in use did not honour the request).
+pub fn take_seeds() -> Option<([u8; 32], [u8; 32])> {
+    SEEDS.with(|s| s.take())
 }
 
 /// `msm_unchecked(points, scalars)` (external taceo-ark-algebra; call sites mpc/plain.rs:66-74, mpc/rep3.rs:124-132,
@@ -147,10 +165,18 @@ impl<P: Pairing> CircomGroth16Prover<P> for HipRep3Groth16Driver {
     /// (`masking_field_elements_vec`, rngs.rs:137-156) so the three parties' masks still cancel.
     fn local_mul_vec(a: Vec<Self::ArithmeticShare>, b: Vec<Self::ArithmeticShare>, state: &mut Rep3State) -> Vec<P::ScalarField> {
         assert_eq!(a.len(), b.len());
-        let mask = state.rngs.rand.masking_field_elements_vec::<P::ScalarField>(a.len());
-        if MASK_ONLY.with(|m| m.get()) {
-            return mask; // the caller passed zero vectors to learn the mask (hip_reduction.rs::draw_mask): 0 * 0 + mask
+        match MASK_REQUEST.with(|m| m.get()) {
+            // hip_reduction.rs::draw_mask: the mask of an n-entry product, operands empty (0 * 0 + mask without the zeros)
+            MaskRequest::MaskOnly(n) if a.is_empty() => return state.rngs.rand.masking_field_elements_vec::<P::ScalarField>(n),
+            // hip_reduction.rs::draw_seeds: one pair of fresh seeds through the public surface; all three parties consume the same
+            // 2 x 32 words of their streams, so party i's first seed is party i+1's second and the device-made masks still cancel
+            MaskRequest::Seeds if a.is_empty() => {
+                SEEDS.with(|s| s.set(Some(state.rngs.rand.random_seeds())));
+                return Vec::new();
+            }
+            _ => {}
         }
+        let mask = state.rngs.rand.masking_field_elements_vec::<P::ScalarField>(a.len());
         let mut out = mask; // in place over the mask vector
         hip_ok(unsafe {
             sys::csh_rep3_local_mul_vec(curve_id::<P>(), limbs_of(&a), limbs_of(&b), limbs_of(&out), limbs_mut(&mut out), a.len())

@@ -14,8 +14,11 @@
 //!   (mpc-core/src/lib.rs:21-31);
 //! * the two Rep3 mask vectors are drawn by `T::local_mul_vec` on two zero vectors, which returns exactly the mask
 //!   (rep3/arithmetic.rs:132-146), in the reference's order (reduction.rs:160 then :182): the party's generators advance as
-//!   they would have, and the three parties' masks still cancel. The Hip Rep3 driver short-circuits such a call to
-//!   `masking_field_elements_vec` (rngs.rs:137-156) without touching the GPU (`drivers::mask_only`).
+//!   they would have, and the three parties' masks still cancel. The Hip Rep3 driver takes the length from a thread-local request
+//!   and EMPTY operands (`drivers::MaskRequest::MaskOnly`): no zero vectors of n shares, no GPU call, just
+//!   `masking_field_elements_vec(n)` (rngs.rs:137-156); a foreign `T` falls back to the zero-vector form;
+//! * opt-in (`COSNARKS_HIP_SEEDED_MASKS=1`): ONE `Rep3Rand::random_seeds()` draw (rngs.rs:233, public) per witness map and both
+//!   mask vectors generated on the device -- for sessions whose three parties all run this crate (`draw_seeds`).
 use crate::domain::HipDomain;
 use crate::error::check;
 use crate::layout::{curve_id, limbs, limbs_of, ncomp};
@@ -82,10 +85,37 @@ fn protocol_of<P: Pairing, T: CircomGroth16Prover<P>>(id: <T::State as MpcState>
     }
 }
 
-/// The mask vector the next `T::local_mul_vec` of `n` entries would add: the product of two zero vectors.
+/// The mask vector the next `T::local_mul_vec` of `n` entries would add. On the Hip Rep3 driver the length travels in a thread-local
+/// and the operands are EMPTY (`drivers::MaskRequest::MaskOnly`): nothing of size n is built but the mask itself. Any other
+/// `T` ignores the request and returns the (empty) product of the empty operands without touching its generators -- then, and only
+/// then, the generic form runs: the product of two zero vectors of n shares is the mask (rep3/arithmetic.rs:132-146).
 fn draw_mask<P: Pairing, T: CircomGroth16Prover<P>>(state: &mut T::State, n: usize) -> Vec<T::ArithmeticHalfShare> {
+    let m = drivers::with_mask_request(drivers::MaskRequest::MaskOnly(n), || T::local_mul_vec(Vec::new(), Vec::new(), state));
+    if m.len() == n {
+        return m;
+    }
+    debug_assert!(m.is_empty());
     let zeros = || vec![T::ArithmeticShare::default(); n];
-    drivers::mask_only(|| T::local_mul_vec(zeros(), zeros(), state))
+    T::local_mul_vec(zeros(), zeros(), state)
+}
+
+/// Opt-in all-GPU-parties mode (`COSNARKS_HIP_SEEDED_MASKS=1`, read once): one pair of fresh correlated seeds per witness map through
+/// the PUBLIC `Rep3Rand::random_seeds()` (rngs.rs:233) instead of two host mask vectors (2 x 2 n `from_be_bytes_mod_order` + 2 x 32 n
+/// keystream bytes on the host at every witness map); the device then generates both mask vectors with its ChaCha12
+/// (`csh_groth16_witness_map`: chunks [0, n) of both streams for "c", [n, 2n) for "ab"). Every party advances its two generators by
+/// the same 32 words, party i's first seed equals party i+1's second, so the masks of the three parties still sum to zero -- but they
+/// are NOT the values a reference CPU party would draw: all three parties of a session must run this mode. None: `T` is not the Hip
+/// Rep3 driver (the request was ignored) -- the caller falls back to host masks.
+fn draw_seeds<P: Pairing, T: CircomGroth16Prover<P>>(state: &mut T::State) -> Option<([u8; 32], [u8; 32])> {
+    let _ = drivers::take_seeds(); // nothing stale
+    let r = drivers::with_mask_request(drivers::MaskRequest::Seeds, || T::local_mul_vec(Vec::new(), Vec::new(), state));
+    debug_assert!(r.is_empty());
+    drivers::take_seeds()
+}
+
+fn seeded_masks_enabled() -> bool {
+    static ON: std::sync::OnceLock<bool> = std::sync::OnceLock::new();
+    *ON.get_or_init(|| std::env::var("COSNARKS_HIP_SEEDED_MASKS").map(|v| v != "0" && !v.is_empty()).unwrap_or(false))
 }
 
 /// `n` half shares of allocated, uninitialised memory for the library to fill (no zero fill: 4.7 ms per 32 MB on the GPU hosts).
@@ -115,6 +145,18 @@ impl R1CSToQAP for HipCircomReduction {
         let dom = HipDomain::cached(curve_id::<P>(), power as u32, Some(&group_gen))?; // Domain::with_group_gen (:93)
         let proto = protocol_of::<P, T>(state.id())?;
         let dm = matrices::get_or_upload::<P>(matrices, false)?;
+        let mut h = uninit_half_shares::<T::ArithmeticHalfShare>(domain_size);
+        if proto.id == 1 && seeded_masks_enabled() {
+            if let Some((seed1, seed2)) = draw_seeds::<P, T>(state) {
+                check(unsafe {
+                    sys::csh_groth16_witness_map(dom.raw, limbs(&coset_shift), proto.id, proto.party, dm.a.handle, dm.b.handle, num_constraints,
+                                                 limbs_of(public_inputs), num_inputs.min(public_inputs.len()), limbs_of(private_witness),
+                                                 private_witness.len(), seed1.as_ptr(), 0, seed2.as_ptr(), 0, h.as_mut_ptr().cast())
+                })?;
+                unsafe { h.set_len(domain_size) }; // SAFETY: CSH_OK: all `domain_size` elements were written
+                return Ok(h);
+            }
+        }
         // the two mask vectors in the reference's order: "c: local_mul_vec" (:160), then "ab" (:182)
         let (mask_c, mask_ab) = if proto.id == 1 {
             (draw_mask::<P, T>(state, domain_size), draw_mask::<P, T>(state, domain_size))
@@ -122,7 +164,6 @@ impl R1CSToQAP for HipCircomReduction {
             (Vec::new(), Vec::new())
         };
         let mask_ptr = |m: &Vec<T::ArithmeticHalfShare>| if m.is_empty() { core::ptr::null() } else { limbs_of(m) };
-        let mut h = uninit_half_shares::<T::ArithmeticHalfShare>(domain_size);
         check(unsafe {
             sys::csh_groth16_witness_map_masks(dom.raw, limbs(&coset_shift), proto.id, proto.party, dm.a.handle, dm.b.handle, num_constraints,
                                                limbs_of(public_inputs), num_inputs.min(public_inputs.len()), limbs_of(private_witness),
