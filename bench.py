@@ -635,11 +635,11 @@ def secondary_multi_gpu(cx: Ctx, args):
         except Exception as e:  # noqa: BLE001
             out["groth16_rep3_party_per_gpu"] = {"error": repr(e)}
     cx.barrier()
-    if cx.rank == 0 and not cx.folded:
+    if cx.rank == 0:   # folded (BENCH_FOLD_RANKS): every range on device 0, so the code path runs in the one-GPU suite too
         try:
-            out["single_process_split_bn254_g1_2p24"] = single_process_split(cx, 0, 0, logn)
+            out[f"single_process_split_bn254_g1_2p{logn}"] = single_process_split(cx, 0, 0, logn)
         except Exception as e:  # noqa: BLE001
-            out["single_process_split_bn254_g1_2p24"] = {"error": repr(e)}
+            out[f"single_process_split_bn254_g1_2p{logn}"] = {"error": repr(e)}
     cx.barrier()
     # the metric's second half at this N: ONE plain prover with its five query MSMs placed on the N GPUs (rank 0, subprocess)
     if cx.rank == 0:
@@ -728,7 +728,7 @@ def single_process_split(cx: Ctx, curve, group, logn):
     a timeout so that nothing it does can stall the ranks waiting at the barrier."""
     import subprocess
     cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_single_process_split.py"), "--devices", str(cx.world), "--curve", str(curve),
-           "--group", str(group), "--log-n", str(logn)]
+           "--group", str(group), "--log-n", str(logn)] + (["--fold"] if cx.folded else [])
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     if r.returncode != 0 or not lines:

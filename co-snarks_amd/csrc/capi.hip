@@ -257,6 +257,8 @@ struct TuneEntry { const char* key; const char* env; std::atomic<int> Tune::*fie
 static const TuneEntry kTune[] = {
     {"msm_c", "CSH_MSM_C", &Tune::msm_c},
     {"msm_l", "CSH_MSM_L", &Tune::msm_l},
+    {"msm_balanced", "CSH_MSM_BALANCED", &Tune::msm_balanced},
+    {"msm_w", "CSH_MSM_W", &Tune::msm_w},
     {"msm_timing", "CSH_MSM_TIMING", &Tune::msm_timing},
     {"msm_no_table", "CSH_MSM_NO_TABLE", &Tune::msm_no_table},
     {"msm_multi_overlap", "CSH_MSM_MULTI_OVERLAP", &Tune::msm_multi_overlap},

@@ -134,6 +134,8 @@ csh_curve_t domain_curve_of(const Domain* d);
 struct Tune {
   std::atomic<int> msm_c{0};             // forced window width (0 = cost model)
   std::atomic<int> msm_l{0};             // forced entries per accumulate lane (0 = from the launch width)
+  std::atomic<int> msm_balanced{1};      // balanced windows (msm_impl.hpp choose_windows): 0 = uniform c-bit windows as in rounds 1-4
+  std::atomic<int> msm_w{0};             // balanced windows: forced number of windows (0 = cost model)
   std::atomic<int> msm_timing{0};        // record per-stage HIP events (csh_msm_last_timing)
   std::atomic<int> msm_no_table{0};      // ignore fixed-base tables
   std::atomic<int> stat_arena_grows{0};  // counters (read with csh_tune_get): scratch arenas (re)allocated, lanes (streams) created

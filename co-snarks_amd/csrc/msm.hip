@@ -316,7 +316,7 @@ int csh_msm_multi_dev(const csh_bases_t* bases, const size_t* offsets, size_t k,
   struct Ops {
     size_t (*bytes)(const MsmParams*);
     int (*bucket)(const void*, const MsmParams*, const SortOut*, hipStream_t, Arena*, void*, hipEvent_t*);
-    void (*fold)(const void*, int, int, void*);
+    void (*fold)(const void*, int, int, int, void*);
     size_t xyzz_bytes;
     int (*occ)();  // accumulate waves of the group's kernel that fit one SIMD
   };
@@ -333,7 +333,7 @@ int csh_msm_multi_dev(const csh_bases_t* bases, const size_t* offsets, size_t k,
   std::vector<Ops> ops(k);
   for (size_t i = 0; i < k; ++i) CSH_REQUIRE(ops_of(reinterpret_cast<const Bases*>(bases[i]), &ops[i]), "msm_multi: unknown curve/group");
   if (n == 0) {
-    for (size_t i = 0; i < k; ++i) ops[i].fold(nullptr, 0, 2, outs_host[i]);
+    for (size_t i = 0; i < k; ++i) ops[i].fold(nullptr, 0, 2, 0, outs_host[i]);
     return CSH_OK;
   }
   const int bits = B0->curve == CSH_BLS12_381 ? Bls381FrParams::BITS : (B0->curve == CSH_GRUMPKIN ? Bn254FqParams::BITS : Bn254FrParams::BITS);
@@ -448,7 +448,7 @@ int csh_msm_multi_dev(const csh_bases_t* bases, const size_t* offsets, size_t k,
       set_error("msm_multi: result %zu failed on the device: %s", i, hipGetErrorString(e));
       return CSH_ERR_HIP;
     }
-    ops[i].fold(wins + slice * i, p.W, p.c, outs_host[i]);
+    ops[i].fold(wins + slice * i, p.W, p.c, p.wide, outs_host[i]);
   }
   drop_events();
   CSH_HIP(hipStreamSynchronize(st));

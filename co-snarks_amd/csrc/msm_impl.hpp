@@ -69,7 +69,7 @@ template <class Fr>
 __global__ __launch_bounds__(MSM_BLK) void k_msm_digits(const Fr* __restrict__ scalars, MsmParams p, uint16_t* __restrict__ dig) {
   const uint32_t g = p.dig_g > 1 ? p.dig_g : 1u, wp = p.dig_g > 1 ? p.dig_wp : (uint32_t)p.W;
   const uint32_t rows = g * wp;  // >= W: the windows past W (grouped tables, g * W' > W) hold no digits
-  const uint32_t c = (uint32_t)p.c, mask = (1u << c) - 1, half = 1u << (c - 1), W = (uint32_t)p.W;
+  const uint32_t W = (uint32_t)p.W, wide = (uint32_t)p.wide;
   for (size_t i = blockIdx.x * (size_t)MSM_BLK + threadIdx.x; i < p.n; i += (size_t)gridDim.x * MSM_BLK) {
     uint32_t s[Fr::N];
     load_scalar<Fr>(scalars, i, p.mont, s);
@@ -77,6 +77,8 @@ __global__ __launch_bounds__(MSM_BLK) void k_msm_digits(const Fr* __restrict__ s
     for (uint32_t w = 0; w < rows; ++w) {
       uint32_t code = DIG_ZERO;
       if (w < W) {
+        const uint32_t c = (uint32_t)p.c - (w >= wide ? 1u : 0u);  // wave-uniform: balanced windows (MsmParams::wide)
+        const uint32_t mask = (1u << c) - 1, half = 1u << (c - 1);
         const uint32_t v = (s[0] & mask) + carry;
 #pragma unroll
         for (int k = 0; k + 1 < Fr::N; ++k) s[k] = (s[k] >> c) | (s[k + 1] << (32 - c));
@@ -699,8 +701,40 @@ inline uint32_t reduce_segments(uint32_t NB, int W, int lanes_per_segment) {
   return S < 1 ? 1 : S;
 }
 
+// Balanced windows (round 5). Uniform c-bit windows leave the top window whatever bits remain: 3 of 12 at 2^16 (c = 12, W = 22), 2 of 11 at
+// 2^15, 8 of 13 at 2^17 / 2^18 -- a window that costs its n additions like every other, whose few buckets hold n / 4 .. n / 128 entries
+// each (the oversized-bucket path: k_msm_giant_slices + k_msm_merge_giant 48 us of a 417 us MSM at 2^16, profiles/r04_zp_msm_2p16_kernel_stats.csv)
+// and whose bucket stage is sized like a full one. Here W windows share the bits + 1 bits evenly: c = ceil((bits + 1) / W), the low
+// `wide` = bits + 1 - W (c - 1) windows take c bits, the others c - 1. c stays <= 16 (15-bit digit magnitudes). tune "msm_c" forces the
+// uniform form (tests, A/B), "msm_balanced" = 0 turns this off, "msm_w" forces W.
+struct WindowPlan {
+  int c, W, wide;
+};
+inline WindowPlan choose_windows(size_t n, int bits) {
+  const int forced_c = tune().msm_c.load(std::memory_order_relaxed);
+  if ((forced_c >= 2 && forced_c <= 16) || tune().msm_balanced.load(std::memory_order_relaxed) == 0) {
+    const int c = choose_c(n, bits);
+    const int W = windows_for(bits, c);
+    return {c, W, W};
+  }
+  const int total = bits + 1;  // one spare bit absorbs the final carry of the signed recoding
+  auto balanced = [total](int W) {
+    const int c = (total + W - 1) / W;
+    return WindowPlan{c, W, total - W * (c - 1)};
+  };
+  const int forced_w = tune().msm_w.load(std::memory_order_relaxed);
+  if (forced_w >= (total + 15) / 16 && forced_w <= MAX_WINDOWS && (total + forced_w - 1) / forced_w >= 3) return balanced(forced_w);
+  // The number of windows is the one the uniform plan's width gives (choose_c: a cost model re-fitted by sweeps in rounds 2-4); the bits
+  // are then spread evenly over them. Letting the cost model pick W freely was measured first and is worse where the model is least
+  // exact: 2^19 took W = 18 (c = 15, 3 wide windows) for a modelled tie with the uniform W = 17 and ran 16 % slower, 2^18 W = 19 +1 %
+  // (profiles/r05_b_ab_balanced.log).
+  return balanced(windows_for(bits, choose_c(n, bits)));
+}
+// width of window w / bit offset of window w in a plan
+CSH_HD int window_bits(int c, int wide, int w) { return w < wide ? c : c - 1; }
+
 struct PartialHeader {
-  uint32_t magic, c, W, reserved;
+  uint32_t magic, c, W, wide;  // wide == 0 (buffers of earlier builds) means W: uniform windows
   uint32_t pad[4];
 };
 constexpr uint32_t PARTIAL_MAGIC = 0x4d534d50u;  // "PMSM"
@@ -709,8 +743,10 @@ constexpr uint32_t PARTIAL_MAGIC = 0x4d534d50u;  // "PMSM"
 inline MsmParams msm_plan(size_t n, int scalar_bits, int mont, int occ = 1) {
   MsmParams p;
   p.n = (uint32_t)n;
-  p.c = choose_c(n, scalar_bits);
-  p.W = windows_for(scalar_bits, p.c);
+  const WindowPlan wp = choose_windows(n, scalar_bits);
+  p.c = wp.c;
+  p.W = wp.W;
+  p.wide = wp.wide;
   p.NB = 1u << (p.c - 1);
   p.L = choose_lane_length(n, p.W, occ);
   const uint32_t max_lanes = (uint32_t)((n + p.L - 1) / p.L);
@@ -755,6 +791,7 @@ inline MergedPlan msm_plan_merged(size_t n, int scalar_bits, int mont, int c, in
   const int wp = (d.W + g - 1) / g;
   d.dig_g = (uint32_t)g;
   d.dig_wp = (uint32_t)wp;
+  d.wide = d.W;  // table rows are 2^(c W' k) P: uniform windows
   MsmParams& p = m.srt;
   const uint64_t n2 = (uint64_t)n * g;
   p.n = (uint32_t)n2;
@@ -776,6 +813,7 @@ inline MergedPlan msm_plan_merged(size_t n, int scalar_bits, int mont, int c, in
   p.remap_stride = (uint32_t)table_stride;
   p.remap_off = (uint32_t)offset;
   p.dig_g = p.dig_wp = 0;
+  p.wide = p.W;
   tl_msm_params[0] = (uint32_t)c;
   tl_msm_params[1] = (uint32_t)p.W;
   tl_msm_params[2] = p.L;
@@ -1138,26 +1176,26 @@ int precompute_table_t(Bases* B, int c, int groups, hipStream_t st) {
 
 // type-erased host fold (the multi-MSM entry dispatches per set of bases at run time)
 template <class Cfg>
-void fold_windows_erased(const void* wins_host, int W, int c, void* out_jacobian);
+void fold_windows_erased(const void* wins_host, int W, int c, int wide, void* out_jacobian);
 
 // Horner over window sums + affine normalisation -> arkworks Projective (x, y, 1) / (1, 1, 0). Runs on the host in
 // 64-bit limbs (host_fp64.hpp): W*c sequential doublings are latency, not throughput, and a CPU core does them faster.
 template <class F>
-XYZZ<F> horner_windows(const XYZZ<F>* wins, int W, int c);
+XYZZ<F> horner_windows(const XYZZ<F>* wins, int W, int c, int wide);
 template <class Fq>
-void fold_windows_host(const XYZZ<Fq>* wins32, int W, int c, void* out_jacobian) {
+void fold_windows_host(const XYZZ<Fq>* wins32, int W, int c, int wide, void* out_jacobian) {
   using F = typename Host64<Fq>::type;
   static_assert(sizeof(XYZZ<F>) == sizeof(XYZZ<Fq>) && sizeof(Jac<F>) == sizeof(Jac<Fq>), "64-bit view must alias the device encoding");
   std::vector<XYZZ<F>> wins(W);
   memcpy((void*)wins.data(), wins32, sizeof(XYZZ<F>) * W);
-  Affine<F> a = xyzz_to_affine(horner_windows<F>(wins.data(), W, c));
+  Affine<F> a = xyzz_to_affine(horner_windows<F>(wins.data(), W, c, wide));
   Jac<F> j = a.is_inf() ? Jac<F>::inf() : Jac<F>{a.x, a.y, F::one()};
   memcpy(out_jacobian, &j, sizeof(j));
 }
 
 template <class Cfg>
-void fold_windows_erased(const void* wins_host, int W, int c, void* out_jacobian) {
-  fold_windows_host<typename Cfg::Fq>(reinterpret_cast<const XYZZ<typename Cfg::Fq>*>(wins_host), W, c, out_jacobian);
+void fold_windows_erased(const void* wins_host, int W, int c, int wide, void* out_jacobian) {
+  fold_windows_host<typename Cfg::Fq>(reinterpret_cast<const XYZZ<typename Cfg::Fq>*>(wins_host), W, c, wide, out_jacobian);
 }
 
 template <class Cfg>
@@ -1187,18 +1225,18 @@ int msm_t(const Bases* B, size_t offset, size_t n, const uint64_t* scalars_dev, 
   }
   CSH_HIP(hipMemcpyAsync(wins, win_dev, sizeof(XYZZ<Fq>) * p.W, hipMemcpyDeviceToHost, st));
   CSH_HIP(hipStreamSynchronize(st));
-  fold_windows_host<Fq>(wins, p.W, p.c, out_host);
+  fold_windows_host<Fq>(wins, p.W, p.c, p.wide, out_host);
   return CSH_OK;
 }
 
 // header of a partial buffer, written on the stream (no host round trip: the partial stays asynchronous)
 template <int UNUSED = 0>
-__global__ void k_msm_partial_header(PartialHeader* out, uint32_t c, uint32_t W) {
+__global__ void k_msm_partial_header(PartialHeader* out, uint32_t c, uint32_t W, uint32_t wide) {
   PartialHeader h;
   h.magic = PARTIAL_MAGIC;
   h.c = c;
   h.W = W;
-  h.reserved = 0;
+  h.wide = wide;
   for (int i = 0; i < 4; ++i) h.pad[i] = 0;
   *out = h;
 }
@@ -1210,14 +1248,15 @@ int msm_partial_t(const Bases* B, size_t offset, size_t n, const uint64_t* scala
   using Fq = typename Cfg::Fq;
   XYZZ<Fq>* wins = reinterpret_cast<XYZZ<Fq>*>(static_cast<char*>(out_dev) + sizeof(PartialHeader));
   CSH_HIP(hipMemsetAsync(out_dev, 0, sizeof(PartialHeader) + sizeof(XYZZ<Fq>) * MAX_WINDOWS, st));
-  uint32_t c = 0, W = 0;
+  uint32_t c = 0, W = 0, wide = 0;
   if (n > 0) {
     MsmParams p;
     CSH_TRY((msm_windows_dev<Cfg>(B, offset, n, scalars_dev, mont, st, wins, &p)));
     c = (uint32_t)p.c;
     W = (uint32_t)p.W;
+    wide = (uint32_t)p.wide;
   }
-  hipLaunchKernelGGL(k_msm_partial_header<0>, dim3(1), dim3(1), 0, st, reinterpret_cast<PartialHeader*>(out_dev), c, W);
+  hipLaunchKernelGGL(k_msm_partial_header<0>, dim3(1), dim3(1), 0, st, reinterpret_cast<PartialHeader*>(out_dev), c, W, wide);
   CSH_HIP(hipGetLastError());
   if (sync) CSH_HIP(hipStreamSynchronize(st));
   return CSH_OK;
@@ -1248,11 +1287,12 @@ XYZZ<F> xyzz_dbl_many_host(const XYZZ<F>& p, int c) {
 }
 
 // Horner value (not yet normalised) of one set of window sums, 64-bit host limbs
+// (window w holds c bits for w < wide, c - 1 above: sum_w 2^(offset of w) S_w, the shift before adding S_w is the width of window w)
 template <class F>
-XYZZ<F> horner_windows(const XYZZ<F>* wins, int W, int c) {
+XYZZ<F> horner_windows(const XYZZ<F>* wins, int W, int c, int wide) {
   XYZZ<F> acc = XYZZ<F>::inf();
   for (int w = W - 1; w >= 0; --w) {
-    acc = xyzz_dbl_many_host(acc, c);
+    acc = xyzz_dbl_many_host(acc, window_bits(c, wide, w));
     acc = xyzz_add_inl(acc, wins[w]);
   }
   return acc;
@@ -1267,27 +1307,29 @@ int fold_partials_t(const void* partials_host, size_t nparts, void* out_jacobian
   // partials with the same window layout (the usual case: equal shares per rank) are summed window by window first,
   // so the W*c doublings are paid once
   std::vector<XYZZ<F>> sum;
-  uint32_t sum_c = 0, sum_W = 0;
+  uint32_t sum_c = 0, sum_W = 0, sum_wide = 0;
   for (size_t k = 0; k < nparts; ++k) {
     const char* base = static_cast<const char*>(partials_host) + k * stride;
     PartialHeader h;
     memcpy(&h, base, sizeof h);
     CSH_REQUIRE(h.magic == PARTIAL_MAGIC, "fold_partials: bad partial header");
     if (h.W == 0) continue;
-    CSH_REQUIRE(h.W <= (uint32_t)MAX_WINDOWS && h.c >= 2 && h.c <= 22, "fold_partials: bad window parameters");
+    CSH_REQUIRE(h.W <= (uint32_t)MAX_WINDOWS && h.c >= 2 && h.c <= 22 && h.wide <= h.W, "fold_partials: bad window parameters");
+    const uint32_t wide = h.wide ? h.wide : h.W;  // 0: a buffer written before balanced windows existed
     std::vector<XYZZ<F>> wins(h.W);
     memcpy((void*)wins.data(), base + sizeof h, sizeof(XYZZ<F>) * h.W);
     if (sum.empty()) {
       sum.swap(wins);
       sum_c = h.c;
       sum_W = h.W;
-    } else if (h.c == sum_c && h.W == sum_W) {
+      sum_wide = wide;
+    } else if (h.c == sum_c && h.W == sum_W && wide == sum_wide) {
       for (uint32_t w = 0; w < h.W; ++w) sum[w] = xyzz_add_inl(sum[w], wins[w]);
     } else {
-      total = xyzz_add_inl(total, horner_windows<F>(wins.data(), (int)h.W, (int)h.c));
+      total = xyzz_add_inl(total, horner_windows<F>(wins.data(), (int)h.W, (int)h.c, (int)wide));
     }
   }
-  if (!sum.empty()) total = xyzz_add_inl(total, horner_windows<F>(sum.data(), (int)sum_W, (int)sum_c));
+  if (!sum.empty()) total = xyzz_add_inl(total, horner_windows<F>(sum.data(), (int)sum_W, (int)sum_c, (int)sum_wide));
   Affine<F> a = xyzz_to_affine(total);
   Jac<F> j = a.is_inf() ? Jac<F>::inf() : Jac<F>{a.x, a.y, F::one()};
   memcpy(out_jacobian, &j, sizeof(j));
@@ -1325,7 +1367,7 @@ int repack_bases_t(Bases* B, hipStream_t st) {
   KW template size_t msm_bucket_bytes<CFG>(const MsmParams*);                                                                   \
   KW template int msm_bucket_stage<CFG>(const void*, const MsmParams*, const SortOut*, hipStream_t, Arena*, void*, hipEvent_t*);          \
   KW template int precompute_table_t<CFG>(Bases*, int, int, hipStream_t);                                                            \
-  KW template void fold_windows_erased<CFG>(const void*, int, int, void*);
+  KW template void fold_windows_erased<CFG>(const void*, int, int, int, void*);
 
 // the five group configurations, by run-time (curve, group)
 #define CURVE_DISPATCH(curve, group, CALL)                                                      \

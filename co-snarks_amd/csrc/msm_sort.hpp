@@ -23,6 +23,10 @@ struct MsmParams {
   // rows of sort window w' = w % dig_wp are contiguous; rows up to dig_g * dig_wp that no digit window maps to are zero-filled.
   // dig_g <= 1: identity.
   uint32_t dig_g, dig_wp;
+  // balanced windows (round 5): the low `wide` windows take c bits, windows wide .. W-1 take c - 1 bits (their digits only reach the lower
+  // half of the NB buckets; every array keeps the NB stride). wide == W: uniform c-bit windows. Used by the digit kernel and the
+  // Horner fold only -- the sort and bucket stages see windows whose upper buckets happen to be empty.
+  int wide;
 };
 
 // Digit code (one u16 per point and window): bits 0..14 = bucket-1, bit 15 = negative; 0xFFFF = zero digit.

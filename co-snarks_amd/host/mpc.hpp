@@ -67,7 +67,7 @@ struct Rep3Rand {
       for (size_t i = lo; i < hi; ++i) {
         a.fill_bytes(x, 32);
         b.fill_bytes(y, 32);
-        o[i] = Fr::sub(from_be_bytes_mod_order<Fr>(x), from_be_bytes_mod_order<Fr>(y));
+        o[i] = mask_element_from_be_bytes<Fr>(x, y);
       }
     });
     rng1.seek(p1 + 32 * (uint64_t)len);

@@ -14,6 +14,7 @@
 #include <mutex>
 #include <vector>
 
+#include "../csrc/host_fp64.hpp"
 #include "types.hpp"
 
 namespace cosnarks {
@@ -236,6 +237,33 @@ inline Fr from_be_bytes_mod_order(const uint8_t* b) {
     v.l[i] = ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | (uint32_t)q[3];
   }
   return v.to_mont();
+}
+
+// a - b of two 32-byte big-endian draws, each reduced as F::from_be_bytes_mod_order reduces it: the element type of
+// Rep3Rand::masking_field_elements_vec (rngs.rs:137-156). Same result as Fr::sub(from_be_bytes_mod_order(a), from_be_bytes_mod_order(b)),
+// on 64-bit limbs (csrc/host_fp64.hpp: one __int128 CIOS product by R^2 per draw instead of 32-bit-limb code: 87 -> ~25 ns per draw).
+template <class Fr>
+inline Fr mask_element_from_be_bytes(const uint8_t* a, const uint8_t* b) {
+  using F64 = typename csh::Host64<Fr>::type;
+  static_assert(sizeof(Fr) == 32 && sizeof(F64) == 32, "32-byte scalar fields only");
+  static const F64 r2 = [] {
+    F64 x;
+    for (int i = 0; i < F64::N; ++i) x.l[i] = F64::word(Fr::Params::R2, i);
+    return x;
+  }();
+  auto load = [](const uint8_t* q) {
+    F64 v;
+    for (int i = 0; i < 4; ++i) {
+      uint64_t w;
+      memcpy(&w, q + 24 - 8 * i, 8);
+      v.l[i] = __builtin_bswap64(w);
+    }
+    return F64::mul(v, r2);  // (v mod r) * R: CIOS tolerates v < 2^256 for these moduli
+  };
+  const F64 d = F64::sub(load(a), load(b));
+  Fr out;
+  memcpy(&out, &d, 32);
+  return out;
 }
 
 }  // namespace cosnarks

@@ -43,7 +43,14 @@ def test_two_rank_line_folded_on_one_gpu(gpu):
     p3 = sec["groth16_rep3_party_per_gpu"]
     assert p3["proofs_equal_plain"] is True and p3["party_devices"] == [0, 0, 0] and p3["three_parties_prove_ms"] > 0
     placed = sec["groth16_prove_synthetic_2p14_placed"]
-    assert placed["by_query"].get("result_check", placed["by_query"].get("check")) in (True, None) or "error" not in placed["by_query"]
+    for mode in ("by_query", "by_range"):                                     # one prover, its five query MSMs placed on the (folded) GPUs
+        assert "error" not in placed[mode], placed[mode]
+        assert placed[mode].get("result_check", True) is not False and placed[mode].get("check", True) is not False, placed[mode]
+    sp = sec["single_process_split_bn254_g1_2p18"]                            # one thread driving every range: both copy exchanges agree
+    assert "error" not in sp and sp["folded_on_device_0"] is True and sp["exchanges_agree"] is True, sp
+    assert sp["hipMemcpyPeer_ms"] > 0 and sp["host_copies_ms"] > 0 and "rccl_grouped_skipped" in sp
+    # the spin-up runs whatever flags were passed and is recorded; the cold figure stays visible beside the value
+    assert line["config"]["spinup_steps"] >= 10 and line["config"]["spinup_ms"] >= 300 and line["value_first_20_steps"] > 0
 
 
 def test_single_gpu_line_quick(gpu):
@@ -53,5 +60,12 @@ def test_single_gpu_line_quick(gpu):
     assert "error" not in sec, sec
     ntt = sec["ntt_bn254_2p16"]
     assert ntt["ms"] > 0 and ntt["ms_first_batch_after_idle"] > 0 and ntt["warm_up_transforms"] >= 120 and ntt["roofline"]["alu"]["frac"] > 0
+    assert line["config"]["spinup_steps"] >= 10 and line["config"]["spinup_ms"] >= 300 and line["value_first_20_steps"] > 0
+    assert sec["msm_bn254_g1_2p18"]["spinup_steps"] >= 3
     pr = sec["groth16_prove_synthetic_2p14"]
+    for mode in ("host_masks", "seeded_device_masks"):                        # BASELINE config 4 through the zero-upstream-edit path, both mask modes
+        m = pr["rep3_trait_path"][mode]
+        assert m["proofs_equal_plain"] is True and m["three_parties_one_gpu_ms"] > 0 and m["one_party_alone_ms"] > 0, m
+    assert pr["rep3_trait_path"]["seeded_device_masks"]["party0_phases_ms"]["mask_draw"] < pr["rep3_trait_path"]["host_masks"]["party0_phases_ms"]["mask_draw"]
+    assert pr["prove_ms"] >= pr["prove_ms_min"] and pr["trait_path_ms"] >= pr["trait_path_ms_min"]   # medians, the minimum beside them
     assert pr["closed_form_check"] is True and pr["trait_path_closed_form_check"] is True and pr["trait_path_ms"] > 0 and pr["rep3_proofs_equal_plain"] is True

@@ -123,6 +123,41 @@ def test_ntt_full_size_equals_cpu_restatement(gpu, curve, logn, ncomp):
     dom.free()
 
 
+@pytest.mark.parametrize("logn,ncomp", [(24, 1), (24, 2), (25, 1), (26, 1)])
+def test_ntt_beyond_2p23_equals_cpu_restatement(gpu, logn, ncomp):
+    """VERDICT r4 missing #3: the reference accepts any domain up to TWO_ADICITY = 28 (groth16/reduction.rs:84-94); 2^24 (the size DESIGN
+    quotes a time for), 2^25 and 2^26 (three sweeps of 10 + 8 + 8 stages), BN254, both directions bit-identical to oracle/c's radix-2 NTT
+    over the whole vector, the bit-exact round trip, and output indices re-derived by Horner. Buffers are dropped as soon as they have
+    been compared (2 GiB each at 2^26)."""
+    F = H.FR["bn254"]
+    cid = H.CURVE_IDS["bn254"]
+    n = 1 << logn
+    gen = ntt.roots_of_unity(F)[1][logn]
+    pg = H.pack(F, [gen])
+    dom = gpu.Domain(cid, logn, pg)
+    x = _uniform_limbs(np.random.RandomState(2000 + logn + ncomp), n * ncomp)
+    coeffs = dom.ifft_in_to_out(x, ncomp=ncomp)
+    want = cbridge.ntt(cid, x, logn, pg, ncomp=ncomp, dif=True)
+    assert np.array_equal(coeffs.reshape(-1), want.reshape(-1))
+    del want
+    evals = dom.fft_out_to_in(coeffs, ncomp=ncomp)
+    assert np.array_equal(evals.reshape(-1), x.reshape(-1))                                     # bit-exact round trip
+    del evals
+    fwd = dom.fft_out_to_in(x, ncomp=ncomp)                                                     # the other direction on its own input
+    want = cbridge.ntt(cid, x, logn, pg, ncomp=ncomp, dif=False)
+    assert np.array_equal(fwd.reshape(-1), want.reshape(-1))
+    del fwd, want
+    nat = cbridge.bit_reverse(coeffs, logn, ncomp=ncomp)
+    del coeffs
+    r = H.rng(logn)
+    for _ in range(4 if logn >= 25 else 8):
+        k, comp = r.randrange(n), r.randrange(ncomp)
+        wk = H.pack(F, [pow(gen, k, F.p)])
+        got = cbridge.eval_poly(cid, nat, wk, stride=ncomp, offset=comp)
+        assert np.array_equal(got, x.reshape(n, ncomp, 4)[k, comp]), (k, comp)
+    dom.free()
+
+
 @pytest.mark.parametrize("curve,group,family", [("bn254", 0, "hashed"), ("bn254", 0, "wide"), ("bn254", 1, "wide"), ("bls12_381", 0, "wide"),
                                                  ("bls12_381", 1, "wide")])
 def test_msm_2p20_random_points_equals_cpu_restatement(gpu, curve, group, family):
@@ -235,7 +270,9 @@ def test_msm_fuzz_sizes_and_plans_vs_cpu_restatement(gpu, curve, group, rounds):
             pm1 = np.array([((F.p - 1) >> (64 * i)) & (2**64 - 1) for i in range(4)], dtype=np.uint64)
             sc[: max(1, n // 5)] = pm1                    # canonical r - 1
         knobs = {"msm_c": r.choice([0, 0, 3, 7, 10, 12, 13, 14, 15, 16]), "msm_l": r.choice([0, 0, 1, 5, 16, 64]),
-                 "sort_two_level": r.choice([-1, -1, 0, 1]), "msm_variant": r.choice([0, 0, 32])}
+                 "sort_two_level": r.choice([-1, -1, 0, 1]), "msm_variant": r.choice([0, 0, 32]),
+                 # balanced windows (round 5): W windows sharing the bits evenly (widths c and c - 1), forced W incl. the extremes, or off
+                 "msm_balanced": r.choice([1, 1, 1, 0]), "msm_w": r.choice([0, 0, 0, 16, 17, 19, 22, 25, 31, 40, 64, 85, 127])}
         bases = gpu.Bases(cid, group, pts_all[off:off + n])
         with gpu.tuned(**knobs):
             got = bases.msm(sc, montgomery=False)

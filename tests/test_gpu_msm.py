@@ -214,6 +214,56 @@ def test_msm_closed_form_full_size(gpu, curve, group, logn):
     gpu.lib().csh_bases_free(h)
 
 
+@pytest.mark.parametrize("curve,group,logn", [("bn254", 0, 13), ("bn254", 0, 15), ("bn254", 0, 16), ("bn254", 0, 17), ("bn254", 0, 18), ("bn254", 0, 19),
+                                               ("bls12_381", 0, 16), ("bn254", 1, 15), ("bls12_381", 1, 14), ("grumpkin", 0, 16)])
+def test_msm_balanced_windows_at_proving_key_sizes(gpu, curve, group, logn):
+    """Balanced windows (round 5; msm_impl.hpp choose_windows): W windows share the bits + 1 bits evenly -- widths c and c - 1 -- instead of
+    c-bit windows with whatever is left on top (3 bits of 12 at 2^16). Known-dlog bases, uniform Montgomery scalars: the default plan, the
+    uniform plan of rounds 1-4 (msm_balanced = 0) and every forced W around the model's choice give (sum s_i k_i) G, bit-identical to each
+    other; odd lengths and an offset into the handle ride along."""
+    import ctypes as C
+    from tests.check_closed_form import closed_form_point, dlogs, weighted_sum
+    G = cv.CURVES[curve][group]
+    cid = H.CURVE_IDS[curve]
+    F = H.FR[curve]
+    n = (1 << logn) + 77
+    seed = 0xBA1A + logn
+    buf = _gen_bases(gpu, curve, group, seed, n)
+    h = C.c_void_p()
+    gpu.bindings._check(gpu.lib().csh_bases_upload_dev(cid, group, buf.ptr, C.c_size_t(n), C.c_size_t(0), None, C.byref(h)))
+    buf.free()
+    rs = np.random.RandomState(100 + logn)
+    limbs = rs.randint(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    limbs[:, 3] >>= np.uint64(3)
+    limbs[5] = 0
+    limbs[6] = np.array([((F.p - 1) >> (64 * i)) & (2**64 - 1) for i in range(4)], dtype=np.uint64)   # R^-1-scaled r - 1: a top-heavy canonical value
+    out = np.zeros(3 * gpu.point_bytes(cid, group) // 16, dtype=np.uint64)
+
+    def run(count, offset=0, sc=limbs):
+        gpu.bindings._check(gpu.lib().csh_msm(h, C.c_size_t(offset), C.c_size_t(count), sc.ctypes.data_as(C.c_void_p), 1, out.ctypes.data_as(C.c_void_p)))
+        return out.copy()
+
+    want = closed_form_point(curve, group, seed, n, limbs, True)
+    got = run(n)
+    assert G.eq(H.jac_to_affine(G, got), want)
+    c, w, _l, _s = gpu.bindings.msm_last_params()
+    assert w * (c - 1) < F.p.bit_length() + 1 <= w * c                     # the windows cover bits + 1 with less than one bit each to spare
+    with gpu.tuned(msm_balanced=0):
+        assert np.array_equal(run(n), got)
+        cu, wu, _l, _s = gpu.bindings.msm_last_params()
+    assert w == wu and c <= cu                                            # the tuned window count, its bits spread evenly
+    for fw in sorted({max(16, w - 2), max(16, w - 1), w, w + 1, w + 3, 2 * w, 127}):
+        with gpu.tuned(msm_w=fw):
+            assert np.array_equal(run(n), got), fw
+            assert gpu.bindings.msm_last_params()[1] == fw
+    # a sub-range of the handle with its own (smaller) plan
+    m, off = (1 << (logn - 2)) + 3, 41
+    sub = np.ascontiguousarray(limbs[:m])
+    S = weighted_sum(sub, dlogs(seed, m, off)) % F.p * F.Rinv % F.p
+    assert G.eq(H.jac_to_affine(G, run(m, off, sub)), G.mul(G.gen, S))
+    gpu.lib().csh_bases_free(h)
+
+
 def test_concurrent_callers_share_the_device(gpu):
     """The reference calls the hot path from rayon workers and scoped threads at once (5 MSM closures, 3 NTT pipelines,
     SURVEY 8b "Threading"): eight host threads issue MSMs of different sizes on two curves plus NTT round trips

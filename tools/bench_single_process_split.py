@@ -29,16 +29,19 @@ def main():
     ap.add_argument("--group", type=int, default=0)
     ap.add_argument("--log-n", type=int, default=24)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--fold", action="store_true", help="every range on device 0 (the N > 1 code path on a one-GPU box; the grouped RCCL "
+                                                        "exchange cannot put two communicator ranks on one device and is reported as skipped)")
     a = ap.parse_args()
     L = hip.lib()
     k = a.devices
+    dev_of = (lambda d: 0) if a.fold else (lambda d: d)
     total = 1 << a.log_n
     per = total // k
     pb = hip.point_bytes(a.curve, a.group)
     bases, scal = [], []
     rs = np.random.RandomState(7)
     for d in range(k):
-        B._check(L.csh_init(d))
+        B._check(L.csh_init(dev_of(d)))
         buf = hip.DeviceBuffer(per * pb)
         B._check(L.csh_util_generate_bases_dev(a.curve, a.group, C.c_uint64(SEED + d * per), C.c_size_t(per), buf.ptr, None))
         B.sync()
@@ -53,9 +56,12 @@ def main():
     offs = (C.c_size_t * k)(*([0] * k))
     cnts = (C.c_size_t * k)(*([per] * k))
     ptrs = (C.c_void_p * k)(*[s.ptr.value for s in scal])
-    res, outs, comms = {"devices": k, "points": total}, {}, None
+    res, outs, comms = {"devices": k, "points": total, "folded_on_device_0": bool(a.fold)}, {}, None
     for name, mode in (("hipMemcpyPeer", B.SPLIT_PEER), ("host_copies", B.SPLIT_HOST), ("rccl_grouped", B.SPLIT_RCCL)):
         cm = None
+        if a.fold and mode == B.SPLIT_RCCL:
+            res[name + "_skipped"] = "folded: one device cannot hold two ranks of a communicator"
+            continue
         try:
             if mode == B.SPLIT_RCCL:
                 comms = B.Comm.init_all(list(range(k)))
@@ -78,7 +84,7 @@ def main():
         for c in comms:
             c.destroy()
     for d, h in enumerate(bases):
-        B._check(L.csh_init(d))
+        B._check(L.csh_init(dev_of(d)))
         L.csh_bases_free(h)
     print(json.dumps(res), flush=True)
 
