@@ -844,6 +844,10 @@ def main():
                        "spinup_rule": "untimed steps before the W warm-up steps: batches of 10 for >= %.1f s until two consecutive batch medians agree within 2 %% (cap 3 s)" % args.spinup_s},
             "value_first_20_steps": value_first_20, "ms_per_step_first_20_steps": cold_dt / 20 * 1e3,
             "roofline": roofline, "cpu_baseline": cpu_baseline, "result_check": check, "secondary": extras,
+            # the host side of every large host-pointer result of this process (HostXfer, csrc/capi.hip): page-population worker time, the
+            # callers' wait for it, final stream waits, copies that stalled (> 3 x their PCIe time + 4 ms) and copies that went through the
+            # staged path -- a box whose driver stalls on freshly populated caller pages shows up HERE, on the headline object
+            "host_result_copies": {k[5:]: cx.B.tune_get(k) for k in ("stat_populate_us", "stat_join_wait_us", "stat_finish_us", "stat_d2h_slow", "stat_d2h_staged")},
         }
         print(json.dumps(line))
     sys.stdout.flush()

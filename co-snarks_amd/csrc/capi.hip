@@ -71,6 +71,8 @@ void host_populate_begin(void* p, size_t bytes, std::vector<std::thread>& worker
   }
 }
 
+void lane_d2h_state(int** staged_left, int** slow_run);  // the calling thread's lane on its device (defined with the lanes below)
+
 void HostXfer::join() {
   if (workers.empty()) return;
   const auto t0 = std::chrono::steady_clock::now();
@@ -91,16 +93,21 @@ HostXfer::~HostXfer() {
 // sizes) the host-facing witness map took 12-24 ms instead of 2.4 in steps of ~10 ms while every device-resident path ran at
 // its usual speed, i.e. the stall sits in the driver's handling of freshly populated caller pages.
 int HostXfer::d2h(void* host, const void* dev, size_t bytes, hipStream_t st) {
-  // tune "host_d2h": 0 = always direct, 1 = always staged, 2 (default) = direct, timed; two copies in a row that take more than three times their
-  // PCIe time + 4 ms send the next 256 large results of the process through the staged path, after which a direct copy is tried again.
-  static std::atomic<int> staged_left{0};
+  // tune "host_d2h": 0 = always direct, 1 = always staged, 2 (default) = direct, timed; two copies in a row ON THIS LANE that take more than
+  // three times their PCIe time + 4 ms send the lane's next 256 large results through the staged path, after which a direct copy is tried again.
+  int *staged_left = nullptr, *slow_run = nullptr;
+  lane_d2h_state(&staged_left, &slow_run);
   const int mode = tune().host_d2h.load(std::memory_order_relaxed);
   const bool large = bytes >= (size_t(4) << 20);
   bool stage = large && mode == 1;
-  if (large && mode == 2 && staged_left.load(std::memory_order_relaxed) > 0) {
-    staged_left.fetch_sub(1, std::memory_order_relaxed);
+  if (large && mode == 2 && *staged_left > 0) {
+    --*staged_left;
     stage = true;
   }
+  // ONE staged copy per HostXfer: the lane has one page-locked slot for this purpose (pinned_for(st ^ 0x8)); a second staged copy before
+  // finish() would land in the same buffer -- or free it, if it is larger -- while the first is still waiting to be moved on.
+  // Every caller today copies one result per HostXfer; a second one takes the direct path.
+  if (!staged.empty()) stage = false;
   void *ph = nullptr, *pd = nullptr;
   if (stage && pinned_for((hipStream_t)((uintptr_t)st ^ 0x8), bytes, &ph, &pd)) {
     Staged sg;
@@ -130,15 +137,15 @@ int HostXfer::d2h(void* host, const void* dev, size_t bytes, hipStream_t st) {
     CSH_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, st));
     CSH_HIP(hipStreamSynchronize(st));
     const double ms = us_since(t0) * 1e-3;
-    static std::atomic<int> slow_run{0};  // consecutive stalled copies (one alone may be the process's first: runtime start-up)
+    // consecutive stalled copies of this lane (one alone may be the process's first: runtime start-up)
     if (ms > 3.0 * (double)bytes / 20e6 + 4.0) {
       tune().stat_d2h_slow.fetch_add(1, std::memory_order_relaxed);
-      if (slow_run.fetch_add(1, std::memory_order_relaxed) + 1 >= 2) {
-        staged_left.store(256, std::memory_order_relaxed);
-        slow_run.store(1, std::memory_order_relaxed);  // the probe after the staged spell switches back at once if it stalls again
+      if (++*slow_run >= 2) {
+        *staged_left = 256;
+        *slow_run = 1;  // the probe after the staged spell switches back at once if it stalls again
       }
     } else {
-      slow_run.store(0, std::memory_order_relaxed);
+      *slow_run = 0;
     }
     return CSH_OK;
   }
@@ -211,6 +218,10 @@ struct PinnedSlot {
 struct Lane {
   int device = 0;
   hipStream_t stream = nullptr;
+  // result-copy policy of this lane (HostXfer::d2h, tune host_d2h = 2): a lane is leased to one host thread at a time, so plain ints.
+  // Per lane since round 5: the stall timings of one caller (another device, a caller whose pages sit on another NUMA
+  // node) no longer switch every other caller of the process to the staged path, nor do concurrent callers race on one counter.
+  int d2h_staged_left = 0, d2h_slow_run = 0;
   std::map<hipStream_t, Arena> arenas;
   std::map<hipStream_t, PinnedSlot> pinned;
 };
@@ -248,6 +259,11 @@ struct LaneHolder {
   }
 };
 static thread_local LaneHolder tl_lanes;
+void lane_d2h_state(int** staged_left, int** slow_run) {
+  Lane* l = tl_lanes.get(tl_device < 0 ? 0 : tl_device);
+  *staged_left = &l->d2h_staged_left;
+  *slow_run = &l->d2h_slow_run;
+}
 
 static int env_int(const char* name, int dflt) {
   const char* e = getenv(name);

@@ -259,7 +259,8 @@ int csh_comm_init_rank(const uint8_t id[CSH_COMM_ID_BYTES], int nranks, int rank
         cfg.commName = nullptr;
         cfg.collnetEnable = cfg.CTAPolicy = cfg.shrinkShare = cfg.nvlsCTAs = NCCL_UNDEF_INT;
         int rc = R->CommInitRankConfig(out_comm, nranks, nid, rank, &cfg);
-        if (rc == NCCL_IN_PROGRESS || (rc == 0 && *out_comm)) rc = comm_wait(R, *out_comm, 0);
+        // (the deadline again: on the timeout_ms <= 0 path nobody else watches this poll)
+        if (rc == NCCL_IN_PROGRESS || (rc == 0 && *out_comm)) rc = comm_wait(R, *out_comm, tune().comm_timeout_ms.load(std::memory_order_relaxed));
         *nonblocking = rc == 0;
         return rc;
       }
@@ -507,14 +508,35 @@ int csh_msm_split(const csh_bases_t* bases, const size_t* offsets, const size_t*
         CSH_NCCL(R, R->GroupStart());
         for (size_t i = 0; i < k; ++i) {
           Comm* c = reinterpret_cast<Comm*>(comms[i]);
-          const int rcg = comm_all_gather(R, c, c->part_dev, c->gather_dev, pb, parts[i].st);
+          // inside a group nothing progresses before GroupEnd: no polling here, "in progress" from a non-blocking communicator is fine
+          int rcg = R->AllGather(c->part_dev, c->gather_dev, pb, NCCL_UINT8, c->nccl, parts[i].st);
+          if (rcg == NCCL_IN_PROGRESS && c->nonblocking) rcg = 0;
           if (rcg != 0) {
             (void)R->GroupEnd();
             set_error("ncclAllGather(part %zu) failed: %s", i, R->GetErrorString(rcg));
             return CSH_ERR_HIP;
           }
         }
-        CSH_NCCL(R, R->GroupEnd());
+        {
+          // communicators built non-blocking (tune comm_nonblocking): inside a group the AllGather calls return at once and GroupEnd
+          // itself reports ncclInProgress -- not a failure: every communicator is polled to completion against the deadline
+          const int rce = R->GroupEnd();
+          bool any_nb = false;
+          for (size_t i = 0; i < k; ++i) any_nb = any_nb || reinterpret_cast<Comm*>(comms[i])->nonblocking;
+          if (rce == NCCL_IN_PROGRESS && any_nb) {
+            for (size_t i = 0; i < k; ++i) {
+              Comm* c = reinterpret_cast<Comm*>(comms[i]);
+              if (!c->nonblocking) continue;
+              const int rw = comm_wait(R, c->nccl, tune().comm_timeout_ms.load(std::memory_order_relaxed));
+              if (rw != 0) {
+                set_error("grouped ncclAllGather (non-blocking communicator %zu) did not complete: %s", i, R->GetErrorString(rw));
+                return CSH_ERR_HIP;
+              }
+            }
+          } else {
+            CSH_NCCL(R, rce);
+          }
+        }
       }
       Comm* c0 = reinterpret_cast<Comm*>(comms[0]);
       CSH_TRY(csh_init(parts[0].dev));

@@ -665,23 +665,52 @@ static int plan_passes(int L, int ncomp_log, Pass* out) {
 // the natural-order twiddle tables of the 32-bit pass, (re)built when that pass is asked for on a domain that has released them
 template <class F>
 static int plain_tables(const Domain* cd) {
+  // A Domain is shared across host threads (the mirror's DomainCache, the shim's Arc<HipDomain>): the pointers are only ever read or
+  // written under this mutex (the former unlocked "already built?" test raced with the thread building them). Only the
+  // CSH_NTT_LAZY = 0 A/B path comes here.
   static std::mutex mu;
   std::lock_guard<std::mutex> g(mu);
   Domain* d = const_cast<Domain*>(cd);
   if (d->tw_fwd && d->tw_inv) return CSH_OK;
   const size_t half = d->n / 2 ? d->n / 2 : 1;
-  void *f = nullptr, *i = nullptr;
-  if (hipMalloc(&f, half * sizeof(F)) != hipSuccess || hipMalloc(&i, half * sizeof(F)) != hipSuccess) {
-    if (f) (void)hipFree(f);
-    set_error("hipMalloc of twiddle tables failed");
-    return CSH_ERR_OOM;
+  int prev_dev = -1;
+  (void)hipGetDevice(&prev_dev);
+  const bool switch_dev = prev_dev != d->device;
+  if (switch_dev && hipSetDevice(d->device) != hipSuccess) {  // the tables live where the domain lives, whoever asks first
+    set_error("hipSetDevice(%d) for the domain's twiddle tables failed", d->device);
+    return CSH_ERR_HIP;
   }
-  hipStream_t st = resolve_stream(nullptr);
-  hipLaunchKernelGGL((k_powers<F, false>), dim3(grid_for((half + POW_CHUNK - 1) / POW_CHUNK, 256)), dim3(256), 0, st, (F*)f, f_from_words<F>(d->gen), half, 0);
-  hipLaunchKernelGGL((k_powers<F, false>), dim3(grid_for((half + POW_CHUNK - 1) / POW_CHUNK, 256)), dim3(256), 0, st, (F*)i, f_from_words<F>(d->gen_inv), half, 0);
-  CSH_HIP(hipStreamSynchronize(st));
+  void *f = nullptr, *i = nullptr;
+  hipStream_t st = nullptr;
+  hipError_t e = hipMalloc(&f, half * sizeof(F));
+  if (e == hipSuccess) e = hipMalloc(&i, half * sizeof(F));
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);  // a stream of the domain's device, not the caller's lane
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL((k_powers<F, false>), dim3(grid_for((half + POW_CHUNK - 1) / POW_CHUNK, 256)), dim3(256), 0, st, (F*)f, f_from_words<F>(d->gen), half, 0);
+    hipLaunchKernelGGL((k_powers<F, false>), dim3(grid_for((half + POW_CHUNK - 1) / POW_CHUNK, 256)), dim3(256), 0, st, (F*)i, f_from_words<F>(d->gen_inv), half, 0);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+  }
+  if (st) (void)hipStreamDestroy(st);
+  if (e != hipSuccess) {
+    if (f) (void)hipFree(f);
+    if (i) (void)hipFree(i);
+  }
+  if (switch_dev && prev_dev >= 0) (void)hipSetDevice(prev_dev);
+  if (e != hipSuccess) {
+    set_error("building the natural-order twiddle tables failed: %s", hipGetErrorString(e));
+    return e == hipErrorOutOfMemory ? CSH_ERR_OOM : CSH_ERR_HIP;
+  }
   d->tw_fwd = f;
   d->tw_inv = i;
+  return CSH_OK;
+}
+// the tables of the 32-bit pass, read under plain_tables' rules: (fwd, inv) once they exist
+template <class F>
+static int plain_tables_get(const Domain* d, const void** fwd, const void** inv) {
+  CSH_TRY(plain_tables<F>(d));  // takes the mutex: returns at once when both exist; the pointers never change afterwards (freed with the domain)
+  *fwd = d->tw_fwd;
+  *inv = d->tw_inv;
   return CSH_OK;
 }
 
@@ -698,8 +727,9 @@ static int run_ntt(const Domain* d, F* data, uint32_t ncomp, bool dif, hipStream
     return CSH_ERR_INVALID;
   }
   using LZ = typename LazyOf<F>::type;
-  if (!use_lazy && !(d->tw_fwd && d->tw_inv)) CSH_TRY(plain_tables<F>(d));
-  const F* tw = reinterpret_cast<const F*>(use_lazy ? (dif ? d->tw_inv_lazy : d->tw_fwd_lazy) : (dif ? d->tw_inv : d->tw_fwd));
+  const void *pt_fwd = nullptr, *pt_inv = nullptr;
+  if (!use_lazy) CSH_TRY(plain_tables_get<F>(d, &pt_fwd, &pt_inv));
+  const F* tw = reinterpret_cast<const F*>(use_lazy ? (dif ? d->tw_inv_lazy : d->tw_fwd_lazy) : (dif ? pt_inv : pt_fwd));
   F scale = f_from_words<F>(use_lazy ? d->n_inv_lazy : d->n_inv);
   const int NTT_THREADS_MAX = [] {
     const int v = tune().ntt_threads.load(std::memory_order_relaxed);  // 16 waves per 2^11-element tile: measured best for both field representations

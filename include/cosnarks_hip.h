@@ -29,6 +29,18 @@
  * re-entrant and thread-safe (the reference calls MSMs/NTTs concurrently from rayon workers:
  * groth16.rs:227-294, reduction.rs:135-178).  There is no CPU fallback: without a HIP device every
  * compute entry point fails with CSH_ERR_NO_DEVICE.
+ *
+ * Host threads the library itself starts (all joined before the call returns unless said otherwise; none touches caller memory after
+ * the return):
+ *  - entry points that hand a result of >= 4 MiB back through a HOST pointer -- csh_groth16_witness_map / _masks / _libsnark*,
+ *    csh_groth16_h*, the host-pointer transforms csh_fft / csh_ifft / csh_domain_* without _dev, csh_vec_* / csh_rep3_* without
+ *    _dev -- start ONE short-lived thread that populates the destination's pages while the device works ("host_populate"), and, when
+ *    the copy is staged ("host_d2h"), up to three more that move the chunks on; csh_tune_set("host_populate", 0) + ("host_d2h", 0)
+ *    turns both off (the call then never leaves the calling thread);
+ *  - csh_comm_init_rank with nranks > 1 runs the collective ncclCommInitRank on a helper thread against "comm_timeout_ms"; a helper
+ *    whose peers never arrive is ABANDONED (still blocked inside RCCL after the call returned its error): leave such a process
+ *    through _exit.
+ *  Everything else (csh_msm*, csh_msm_split*, every *_dev entry point) runs on the calling thread only.
  */
 #ifndef COSNARKS_HIP_H
 #define COSNARKS_HIP_H
@@ -78,7 +90,10 @@ int csh_device_count(int* count);
  * "host_populate" (results of >= 4 MiB handed back in pageable memory: low byte = host threads that populate the destination's
  * pages while the device works, 0 = none; bit 8 = transparent-huge-page hint on the range; default 0x101), "host_d2h" (the copy of such
  * a result: 0 = one DMA into the caller's pages, 1 = staged through the lane's page-locked buffer and moved on by host threads,
- * 2 = default: direct and timed, staged for the next 256 results after two stalled copies in a row). Read-only counters
+ * 2 = default: direct and timed, staged for the calling lane's next 256 results after two stalled copies in a row ON THAT LANE -- a lane is
+ * the stream + scratch leased to one host thread at a time, so concurrent callers neither share nor race on this state),
+ * "msm_balanced" (1 = default: the MSM's windows share the scalar bits evenly, widths c and c - 1; 0 = uniform c-bit windows),
+ * "msm_w" (balanced windows: forced number of windows, 0 = the tuned count). Read-only counters
  * (csh_tune_get): "stat_arena_grows", "stat_lanes", "stat_populate_us", "stat_join_wait_us", "stat_finish_us", "stat_d2h_slow",
  * "stat_d2h_staged". */
 int csh_tune_set(const char* key, int value);

@@ -231,3 +231,84 @@ def test_large_results_direct_and_staged_copies_agree(gpu):
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
     assert np.array_equal(np.asarray(dom.fft_out_to_in(outs[1].copy())).reshape(-1), x.reshape(-1))
     dom.free()
+
+
+def test_concurrent_host_pointer_callers_while_the_copy_mode_flips(gpu):
+    """the host result path under the load it is built for -- ten host threads (rayon workers in the reference) calling
+    host-pointer entry points of mixed sizes at once (transforms of 2^12 .. 2^20 elements: below and above the 4 MiB threshold of the
+    page population / staged copy; witness maps of a 2^17-constraint circuit inside trait-path proves) while another thread flips
+    tune host_d2h between direct (0), staged (1) and auto (2) and host_populate on and off. Every result is compared bit for bit with
+    the one computed alone beforehand; the staged path must actually have run."""
+    import threading
+    import time
+    from cosnarks_amd import bindings as B
+    from cosnarks_amd import groth16 as g
+    F = H.FR["bn254"]
+    cid = H.CURVE_IDS["bn254"]
+    sizes = [12, 16, 17, 18, 19, 20, 18, 20]
+    doms, xs, want = {}, {}, {}
+    for logn in sorted(set(sizes)):
+        gen = ntt.roots_of_unity(F)[1][logn]
+        doms[logn] = gpu.Domain(cid, logn, H.pack(F, [gen]))
+        x = np.random.RandomState(50 + logn).randint(0, 1 << 62, size=(1 << logn, 4), dtype=np.uint64)
+        x[:, 3] >>= np.uint64(2)
+        xs[logn] = x
+        want[logn] = np.array(doms[logn].ifft_in_to_out(x.copy()), copy=True)
+    staged0 = B.tune_get("stat_d2h_staged")
+    stop = threading.Event()
+    errs = []
+
+    def transformer(logn, rounds):
+        try:
+            gpu.bindings._check(gpu.lib().csh_init(0))
+            for _ in range(rounds):
+                got = doms[logn].ifft_in_to_out(xs[logn].copy())                 # a fresh destination every time, as a caller's new Vec is
+                if not np.array_equal(np.asarray(got).reshape(-1), want[logn].reshape(-1)):
+                    errs.append(("ifft", logn))
+                    return
+        except Exception as e:  # noqa: BLE001
+            errs.append(("ifft", logn, repr(e)))
+
+    def prover(rounds):
+        try:
+            gpu.bindings._check(gpu.lib().csh_init(0))
+            with g.trait_path():
+                c = g.SynthCircuit(0, 17)
+                for _ in range(rounds):
+                    c.prove()
+                    if not c.check():
+                        errs.append(("prove",))
+                        break
+                c.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append(("prove", repr(e)))
+
+    def flipper():
+        k = 0
+        while not stop.is_set():
+            B.tune_set("host_d2h", (1, 0, 2, 1)[k % 4])
+            B.tune_set("host_populate", (0x101, 0, 0x101, 0x102)[k % 4])
+            k += 1
+            time.sleep(0.003)
+
+    d2h0, pop0 = B.tune_get("host_d2h"), B.tune_get("host_populate")
+    th = [threading.Thread(target=transformer, args=(logn, 12 if logn >= 19 else 30)) for logn in sizes]
+    th += [threading.Thread(target=prover, args=(4,)) for _ in range(2)]
+    fl = threading.Thread(target=flipper)
+    fl.start()
+    try:
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=600)
+    finally:
+        stop.set()
+        fl.join()
+        B.tune_set("host_d2h", d2h0)
+        B.tune_set("host_populate", pop0)
+    assert not errs, errs
+    assert not any(t.is_alive() for t in th)
+    assert B.tune_get("stat_d2h_staged") > staged0
+    for d in doms.values():
+        d.free()
+
