@@ -86,6 +86,19 @@ inline size_t host_threads() {
     if (sched_getaffinity(0, sizeof set, &set) == 0) k = (size_t)CPU_COUNT(&set);
     if (k == 0) k = std::thread::hardware_concurrency();
     if (k == 0) k = 1;
+    // a cgroup CPU quota below the affinity count (16 CPUs' worth of time on a 256-CPU host): more runnable threads than the quota only
+    // get the whole group throttled for the rest of the scheduler period (the mask draw of a Rep3 party took 67 ms with 64 threads on
+    // such a box, profiles/r05_d_bench_20_5.log)
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+      long long quota = 0, period = 0;
+      char q[32] = {0};
+      if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+        quota = atoll(q);
+        const size_t cpus = (size_t)((quota + period - 1) / period);
+        if (cpus >= 1 && cpus < k) k = cpus;
+      }
+      fclose(f);
+    }
     return k > 64 ? (size_t)64 : k;
   }();
   return n;

@@ -123,10 +123,10 @@ def test_ntt_full_size_equals_cpu_restatement(gpu, curve, logn, ncomp):
     dom.free()
 
 
-@pytest.mark.parametrize("logn,ncomp", [(24, 1), (24, 2), (25, 1), (26, 1)])
+@pytest.mark.parametrize("logn,ncomp", [(24, 1), (24, 2), (26, 1)])
 def test_ntt_beyond_2p23_equals_cpu_restatement(gpu, logn, ncomp):
     """VERDICT r4 missing #3: the reference accepts any domain up to TWO_ADICITY = 28 (groth16/reduction.rs:84-94); 2^24 (the size DESIGN
-    quotes a time for), 2^25 and 2^26 (three sweeps of 10 + 8 + 8 stages), BN254, both directions bit-identical to oracle/c's radix-2 NTT
+    quotes a time for) and 2^26 (three sweeps of 10 + 8 + 8 stages), BN254, both directions bit-identical to oracle/c's radix-2 NTT
     over the whole vector, the bit-exact round trip, and output indices re-derived by Horner. Buffers are dropped as soon as they have
     been compared (2 GiB each at 2^26)."""
     F = H.FR["bn254"]
