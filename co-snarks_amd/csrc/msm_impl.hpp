@@ -140,8 +140,9 @@ __global__ __launch_bounds__(ACC_BLK) void k_msm_accum(const Affine<typename Cfg
   if (k >= nlanes[w]) return;
   const uint32_t* st = start + (size_t)w * (p.NB + 2);
   const uint32_t total = st[p.NB + 1];
-  const uint32_t lo = k * p.L;
-  uint32_t hi = lo + p.L;
+  const uint32_t Lw = lane_len(p, w);
+  const uint32_t lo = k * Lw;
+  uint32_t hi = lo + Lw;
   if (hi > total) hi = total;
   uint32_t b = upper_bound_u32(st, 1, p.NB + 1, lo) - 1;  // bucket containing sorted position lo
   uint32_t next = st[b + 1];
@@ -211,8 +212,9 @@ __global__ __launch_bounds__(ACC_BLK) void k_msm_accum_pair(const Affine<typenam
   if (k >= nlanes[w]) return;
   const uint32_t* st = start + (size_t)w * (p.NB + 2);
   const uint32_t total = st[p.NB + 1];
-  const uint32_t lo = k * p.L;
-  uint32_t hi = lo + p.L;
+  const uint32_t Lw = lane_len(p, w);
+  const uint32_t lo = k * Lw;
+  uint32_t hi = lo + Lw;
   if (hi > total) hi = total;
   uint32_t b = upper_bound_u32(st, 1, p.NB + 1, lo) - 1;  // bucket containing sorted position lo
   uint32_t next = st[b + 1];
@@ -295,7 +297,8 @@ __global__ __launch_bounds__(TAIL_BLK) void k_msm_merge(MsmParams p, const uint3
   const uint32_t lo = st[b], hi = st[b + 1];
   QPt<L> acc = qpt_inf<L>();
   if (hi > lo) {
-    const uint32_t k0 = lo / p.L, k1 = (hi - 1) / p.L;
+    const uint32_t Lw = lane_len(p, w);
+    const uint32_t k0 = lo / Lw, k1 = (hi - 1) / Lw;
     const LazyPt<Cfg>* pw = partial + (size_t)w * p.tmax + b;
     if (k1 - k0 >= MERGE_CAP) {
       if (role == 0) giant_enqueue(giant_count, giant_list, big_list, (uint32_t)w, b, k1 - k0 + 1);
@@ -331,7 +334,8 @@ __global__ __launch_bounds__(256) void k_msm_giant_slices(MsmParams p, const uin
   for (uint32_t q = blockIdx.y; q < nbig; q += gridDim.y) {  // usually none: the launch is GIANT_SLICES x GIANT_ROWS blocks that return at once
     const uint32_t w = big_list[2 * q], b = big_list[2 * q + 1];
     const uint32_t* st = start + (size_t)w * (p.NB + 2);
-    const uint32_t k0 = st[b] / p.L, k1 = (st[b + 1] - 1) / p.L;
+    const uint32_t Lw = lane_len(p, (int)w);
+    const uint32_t k0 = st[b] / Lw, k1 = (st[b + 1] - 1) / Lw;
     const uint32_t per = (k1 - k0 + GIANT_SLICES) / GIANT_SLICES;  // ceil((k1 - k0 + 1) / slices)
     const uint32_t a = k0 + sl * per;
     uint32_t e = a + per;  // one past the slice's last partial
@@ -369,13 +373,15 @@ __global__ __launch_bounds__(256) void k_msm_merge_giant(MsmParams p, const uint
         if ((uint32_t)q < GIANT_SLICES) acc = qpt_load<L>(&gscratch[(size_t)slot * GIANT_SLICES + q], role);
       } else {
         const uint32_t* st = start + (size_t)w * (p.NB + 2);
-        const uint32_t k0 = st[b] / p.L, k1 = (st[b + 1] - 1) / p.L;
+        const uint32_t Lw = lane_len(p, (int)w);
+        const uint32_t k0 = st[b] / Lw, k1 = (st[b + 1] - 1) / Lw;
         const LazyPt<Cfg>* pw = partial + (size_t)w * p.tmax + b;
         for (uint32_t k = k0 + q; k <= k1; k += 64) qadd<L>(acc, qpt_load<L>(&pw[k], role), role);
       }
     } else {
       const uint32_t* st = start + (size_t)w * (p.NB + 2);
-      const uint32_t k0 = st[b] / p.L, k1 = (st[b + 1] - 1) / p.L;
+      const uint32_t Lw = lane_len(p, (int)w);
+      const uint32_t k0 = st[b] / Lw, k1 = (st[b + 1] - 1) / Lw;
       const LazyPt<Cfg>* pw = partial + (size_t)w * p.tmax + b;
       for (uint32_t k = k0 + q; k <= k1; k += 64) qadd<L>(acc, qpt_load<L>(&pw[k], role), role);
     }
@@ -398,28 +404,29 @@ __global__ __launch_bounds__(256) void k_msm_mark_giant(MsmParams p, const uint3
   if (b > p.NB) return;
   const uint32_t* st = start + (size_t)w * (p.NB + 2);
   const uint32_t lo = st[b], hi = st[b + 1];
-  if (hi > lo && (hi - 1) / p.L - lo / p.L >= MERGE_CAP) giant_enqueue(giant_count, giant_list, big_list, (uint32_t)w, b, (hi - 1) / p.L - lo / p.L + 1);
+  const uint32_t Lw = lane_len(p, w);
+  if (hi > lo && (hi - 1) / Lw - lo / Lw >= MERGE_CAP) giant_enqueue(giant_count, giant_list, big_list, (uint32_t)w, b, (hi - 1) / Lw - lo / Lw + 1);
 }
 // sum of bucket t of one window: four lanes per point / two lanes per Fp2 point
 template <class Cfg>
-__device__ __forceinline__ QPt<typename Cfg::L> qbucket_merged(const MsmParams& p, const uint32_t* __restrict__ st, const LazyPt<Cfg>* __restrict__ pw,
+__device__ __forceinline__ QPt<typename Cfg::L> qbucket_merged(uint32_t Lw, const uint32_t* __restrict__ st, const LazyPt<Cfg>* __restrict__ pw,
                                                                const LazyPt<Cfg>* __restrict__ dw, uint32_t t, int role) {
   using L = typename Cfg::L;
   const uint32_t lo = st[t], hi = st[t + 1];
   if (hi <= lo) return qpt_inf<L>();
-  const uint32_t k0 = lo / p.L, k1 = (hi - 1) / p.L;
+  const uint32_t k0 = lo / Lw, k1 = (hi - 1) / Lw;
   if (k1 - k0 >= MERGE_CAP) return qpt_load<L>(&dw[t], role);
   QPt<L> acc = qpt_load<L>(&pw[t + k0], role);
   for (uint32_t k = k0 + 1; k <= k1; ++k) qadd<L>(acc, qpt_load<L>(&pw[t + k], role), role);
   return acc;
 }
 template <class Cfg>
-__device__ __forceinline__ XYZZLazy<typename Cfg::LP> pbucket_merged(const MsmParams& p, const uint32_t* __restrict__ st, const LazyPt<Cfg>* __restrict__ pw,
+__device__ __forceinline__ XYZZLazy<typename Cfg::LP> pbucket_merged(uint32_t Lw, const uint32_t* __restrict__ st, const LazyPt<Cfg>* __restrict__ pw,
                                                                      const LazyPt<Cfg>* __restrict__ dw, uint32_t t, int role) {
   using L = typename Cfg::LP;
   const uint32_t lo = st[t], hi = st[t + 1];
   if (hi <= lo) return XYZZLazy<L>::inf();
-  const uint32_t k0 = lo / p.L, k1 = (hi - 1) / p.L;
+  const uint32_t k0 = lo / Lw, k1 = (hi - 1) / Lw;
   if (k1 - k0 >= MERGE_CAP) return dw[t].empty ? XYZZLazy<L>::inf() : pair_load(&dw[t], role);
   XYZZLazy<L> acc = pw[t + k0].empty ? XYZZLazy<L>::inf() : pair_load(&pw[t + k0], role);
   for (uint32_t k = k0 + 1; k <= k1; ++k) {
@@ -452,7 +459,7 @@ __global__ __launch_bounds__(256) void k_msm_reduce(MsmParams p, const LazyPt<Cf
     const LazyPt<Cfg>* pw = FUSED ? partial + (size_t)w * p.tmax : nullptr;
     for (uint32_t t = t1; t-- > t0;) {
       QPt<L> pt;
-      if constexpr (FUSED) pt = qbucket_merged<Cfg>(p, st, pw, dw, t, role);
+      if constexpr (FUSED) pt = qbucket_merged<Cfg>(lane_len(p, w), st, pw, dw, t, role);
       else pt = qpt_load<L>(&dw[t], role);
       if (pt.empty) continue;
       uint32_t gap = prev_b ? prev_b - t : 0;
@@ -544,7 +551,7 @@ __global__ __launch_bounds__(RED_BLK) void k_msm_reduce_pair(MsmParams p, const 
     for (uint32_t t = t1; t-- > t0;) {
       XYZZLazy<L> pt;
       if constexpr (FUSED) {
-        pt = pbucket_merged<Cfg>(p, st, pw, dw, t, role);
+        pt = pbucket_merged<Cfg>(lane_len(p, w), st, pw, dw, t, role);
         if (pt.empty) continue;
       } else {
         if (dw[t].empty) continue;
@@ -676,10 +683,16 @@ inline uint32_t choose_lane_length(size_t n, int W, int occ = 1) {
     }
     if (rounds <= 1) break;  // one round already: longer lanes only cost
   }
+  // Round 5 (after balanced windows; profiles/r05_f_ab_lane_floor.log, r05_g_ab_narrow_lane_length.log, r05_h_ab_lane_lengths_large.log,
+  // interleaved, BN254 G1 / BLS12-381 G1 / Grumpkin): the lane that fills THREE waves per SIMD is the best or within 1 % of it on every G1
+  // group at 2^15 .. 2^18, also where the kernel's registers only admit two (BLS12-381 G1 2^17: 14 against the former 20, -9.7 %; more,
+  // shorter waves beat one full round), and from ~10^6 entries on a lane shorter than 12 entries loses to the partial sums it leaves the
+  // merge kernel (2^16: 12 against 8, -4.3 % BN254 G1, -8.6 % BLS12-381 G1 against its former 11, -4.0 % Grumpkin); 2^15 stays at 8.
   const double entries = (double)n * W;
   if (occ >= 2 && entries >= 6e5) {
-    uint32_t fill = (uint32_t)ceil(entries / (64.0 * simds * occ));
-    if (fill < 8) fill = 8;
+    uint32_t fill = (uint32_t)ceil(entries / (64.0 * simds * 3.0));
+    const uint32_t floor_l = entries >= 1e6 ? 12 : 8;
+    if (fill < floor_l) fill = floor_l;
     if (fill < best_L) best_L = fill;
   }
   return best_L;
@@ -749,6 +762,11 @@ inline MsmParams msm_plan(size_t n, int scalar_bits, int mont, int occ = 1) {
   p.wide = wp.wide;
   p.NB = 1u << (p.c - 1);
   p.L = choose_lane_length(n, p.W, occ);
+  // Narrow windows (balanced plan) hold twice the entries per bucket; giving their lanes 2 L entries would leave k_msm_merge the same
+  // number of partial sums per bucket as in a wide window. Measured (profiles/r05_g_ab_narrow_lane_length.log, interleaved, 2^14 .. 2^18,
+  // three groups): +6 .. +26 % -- at these sizes the accumulate launch is a dependent chain per lane, and doubling it costs more than the
+  // merge saves. One length is the default; tune "msm_variant" bit 6 (64) selects the doubled form (kept parity-tested for A/B).
+  p.Ln = (p.wide < p.W && p.L <= 32 && (tune().msm_variant.load(std::memory_order_relaxed) & 64) != 0) ? 2 * p.L : p.L;
   const uint32_t max_lanes = (uint32_t)((n + p.L - 1) / p.L);
   p.tmax = p.NB + max_lanes + 2;  // partial slots per window: slot = bucket + lane
   p.S = reduce_segments(p.NB, p.W, 1);
@@ -792,6 +810,7 @@ inline MergedPlan msm_plan_merged(size_t n, int scalar_bits, int mont, int c, in
   d.dig_g = (uint32_t)g;
   d.dig_wp = (uint32_t)wp;
   d.wide = d.W;  // table rows are 2^(c W' k) P: uniform windows
+  d.Ln = 0;
   MsmParams& p = m.srt;
   const uint64_t n2 = (uint64_t)n * g;
   p.n = (uint32_t)n2;
@@ -814,6 +833,7 @@ inline MergedPlan msm_plan_merged(size_t n, int scalar_bits, int mont, int c, in
   p.remap_off = (uint32_t)offset;
   p.dig_g = p.dig_wp = 0;
   p.wide = p.W;
+  p.Ln = p.L;
   tl_msm_params[0] = (uint32_t)c;
   tl_msm_params[1] = (uint32_t)p.W;
   tl_msm_params[2] = p.L;
@@ -931,9 +951,11 @@ BucketBufs<Cfg> bucket_take(const MsmParams& p, Arena& ar) {
 // accumulate -> merge -> reduce -> fold tree -> window sums for windows [w0, w0 + nw) on `st`; `group` picks the giant queue.
 // ev (nullable): records ev[4] after the accumulation.
 template <class Cfg>
-int bucket_group(const void* points, const MsmParams& p, const SortOut& so, const BucketBufs<Cfg>& bb, int w0, int nw, int group, hipStream_t st,
+int bucket_group(const void* points, const MsmParams& p_all, const SortOut& so, const BucketBufs<Cfg>& bb, int w0, int nw, int group, hipStream_t st,
                  void* win_out_dev, hipEvent_t* ev) {
   using Fq = typename Cfg::Fq;
+  MsmParams p = p_all;  // the kernels index windows from 0: the wide / narrow boundary moves with the group's first window
+  p.wide = p_all.wide > w0 ? p_all.wide - w0 : 0;
   const size_t len = (size_t)p.NB + 2;
   const uint32_t* start = so.start + len * w0;
   const uint32_t* nlanes = so.nlanes + w0;

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(1024) void k_msm_scan(MsmParams p, uint32_t* hist, 
     st[b] = sc_lds[b];
     h[b] = sc_lds[b];  // the same offsets again, as the global bucket cursors of the tile-parallel level-2 scatter (consumed by atomicAdd)
   }
-  if (threadIdx.x == 0) nlanes[w] = (total + p.L - 1) / p.L;
+  if (threadIdx.x == 0) nlanes[w] = (total + lane_len(p, w) - 1) / lane_len(p, w);
 }
 
 // Block (chunk ch, window w): LDS cursors = bucket start + this chunk's prefix; scatter (index | sign) into

@@ -27,7 +27,12 @@ struct MsmParams {
   // half of the NB buckets; every array keeps the NB stride). wide == W: uniform c-bit windows. Used by the digit kernel and the
   // Horner fold only -- the sort and bucket stages see windows whose upper buckets happen to be empty.
   int wide;
+  // entries per accumulate lane in the narrow windows (w >= wide): their buckets hold twice the entries of a wide window's, so a lane of
+  // 2 L entries leaves the same number of partial sums per bucket for k_msm_merge as L does in a wide window. Ln == L: one length.
+  uint32_t Ln;
 };
+// entries per accumulate lane of window w (absolute window index)
+__host__ __device__ inline uint32_t lane_len(const MsmParams& p, int w) { return w >= p.wide ? p.Ln : p.L; }
 
 // Digit code (one u16 per point and window): bits 0..14 = bucket-1, bit 15 = negative; 0xFFFF = zero digit.
 constexpr uint32_t DIG_ZERO = 0xFFFFu;

@@ -270,7 +270,7 @@ def test_msm_fuzz_sizes_and_plans_vs_cpu_restatement(gpu, curve, group, rounds):
             pm1 = np.array([((F.p - 1) >> (64 * i)) & (2**64 - 1) for i in range(4)], dtype=np.uint64)
             sc[: max(1, n // 5)] = pm1                    # canonical r - 1
         knobs = {"msm_c": r.choice([0, 0, 3, 7, 10, 12, 13, 14, 15, 16]), "msm_l": r.choice([0, 0, 1, 5, 16, 64]),
-                 "sort_two_level": r.choice([-1, -1, 0, 1]), "msm_variant": r.choice([0, 0, 32]),
+                 "sort_two_level": r.choice([-1, -1, 0, 1]), "msm_variant": r.choice([0, 0, 32, 64, 96]),
                  # balanced windows (round 5): W windows sharing the bits evenly (widths c and c - 1), forced W incl. the extremes, or off
                  "msm_balanced": r.choice([1, 1, 1, 0]), "msm_w": r.choice([0, 0, 0, 16, 17, 19, 22, 25, 31, 40, 64, 85, 127])}
         bases = gpu.Bases(cid, group, pts_all[off:off + n])
