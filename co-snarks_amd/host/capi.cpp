@@ -1465,6 +1465,36 @@ int cog16_bench_rep3_party_per_gpu(int curve, int log_domain, int iters, const i
 
 const char* cog16_last_error(void) { return g_err.c_str(); }
 
+// The mirror's Rep3 randomness on its own (host only, no device): three parties with PRF keys k_p = keys[32 p ..] (party p holds its
+// own key as rng1 and its predecessor's as rng2, rep3.rs:71-76). Per party, in this order: a mask vector of n elements
+// (masking_field_elements_vec, rngs.rs:137-156; drawn in parallel over the host's cores), one random_seeds() pair (rngs.rs:233), a second
+// mask vector of n2 elements (the generators must continue where a serial draw would have left them).
+// masks_out: 3 x (n + n2) x 4 limbs (Montgomery); seeds_out: 3 x 64 bytes (seed1 || seed2).
+int cog16_rep3_rand_selftest(int curve, const uint8_t keys[96], size_t n, size_t n2, uint64_t* masks_out, uint8_t* seeds_out) {
+  try {
+    if (!keys || !masks_out || !seeds_out) throw Error("cog16_rep3_rand_selftest: NULL argument");
+    auto run = [&](auto tag) {
+      using Fr = decltype(tag);
+      for (int p = 0; p < 3; ++p) {
+        Rep3Rand r(keys + 32 * p, keys + 32 * ((p + 2) % 3));
+        const UninitBuf<Fr> a = r.masking_field_elements_vec<Fr>(n);
+        r.random_seeds(seeds_out + 64 * p, seeds_out + 64 * p + 32);
+        const UninitBuf<Fr> b = r.masking_field_elements_vec<Fr>(n2);
+        uint64_t* o = masks_out + 4 * (n + n2) * (size_t)p;
+        if (n) memcpy(o, a.data(), 32 * n);
+        if (n2) memcpy(o + 4 * n, b.data(), 32 * n2);
+      }
+    };
+    if (curve == 0) run(Bn254::Fr{});
+    else if (curve == 1) run(Bls12_381::Fr{});
+    else throw Error("unknown curve");
+    return 0;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+
 // 1: every prove_inner of this process runs the "trait path" (groth16.hpp: the sequence rust/co-groth16-hip drives behind the unchanged
 // reference -- host slices at every seam, one witness-map call, five concurrent host-scalar MSMs); 0: the device-resident prove.
 // 2: the trait path with the shim's opt-in seeded Rep3 masks (groth16.hpp witness_map_trait_path).

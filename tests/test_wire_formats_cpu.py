@@ -113,3 +113,41 @@ def test_send_many_points_carry_the_swflags(curve):
     flipped = bytearray(msg)
     flipped[8 + 2 * nb - 1] ^= 0x80
     assert cv.unpack_points(G, g.rep3_recv_many(H.CURVE_IDS[curve], bytes(flipped), points=True))[0] == G.gen
+
+
+@pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
+def test_mirror_rep3_randomness_parallel_draw_and_fresh_seeds(curve):
+    """The mirror's Rep3Rand (host/mpc.hpp) on its own, no device: (1) masking_field_elements_vec -- drawn in parallel over the host's
+    cores from the two counter-mode keystreams -- equals the serial restatement of rngs.rs:137-156 over the oracle's ChaCha12 keystream,
+    for a first vector, and for a second one drawn after a random_seeds() call (the generators continue where a serial draw leaves
+    them: 32 keystream WORDS per seed, rand 0.8's `gen::<[u8; 32]>()`); (2) the three parties' masks sum to zero element by element;
+    (3) random_seeds (rngs.rs:233): the seed party p draws from its own generator is the one party p + 1 draws from its second -- what
+    keeps the opt-in seeded masks of the Rust shim correlated."""
+    import ctypes as C
+
+    import numpy as np
+    from cosnarks_amd import groth16 as g
+    from oracle import chacha, mpc
+    F = H.FR[curve]
+    n, n2 = 20000, 777                                 # spans several parallel chunks, odd tail
+    keys = bytes((37 * i + 11) & 0xFF for i in range(96))
+    masks = np.zeros(3 * (n + n2) * 4, dtype=np.uint64)
+    seeds = (C.c_uint8 * 192)()
+    rc = g.glib().cog16_rep3_rand_selftest(H.CURVE_IDS[curve], keys, C.c_size_t(n), C.c_size_t(n2), masks.ctypes.data_as(C.c_void_p), seeds)
+    assert rc == 0, g.glib().cog16_last_error()
+    got = [H.unpack(F, masks[4 * (n + n2) * p:4 * (n + n2) * (p + 1)]) for p in range(3)]
+    seeds = bytes(seeds)
+    for p in range(3):
+        k1, k2 = keys[32 * p:32 * p + 32], keys[32 * ((p + 2) % 3):32 * ((p + 2) % 3) + 32]
+        s1 = chacha.keystream(k1, 32 * (n + n2) + 128)
+        s2 = chacha.keystream(k2, 32 * (n + n2) + 128)
+        assert got[p][:n] == mpc.masks_from_streams(F, s1, s2, n), p
+        # random_seeds: byte i of a seed = the low byte of the i-th next keystream word
+        want1 = bytes(s1[32 * n + 4 * i] for i in range(32))
+        want2 = bytes(s2[32 * n + 4 * i] for i in range(32))
+        assert seeds[64 * p:64 * p + 32] == want1 and seeds[64 * p + 32:64 * p + 64] == want2, p
+        assert got[p][n:] == mpc.masks_from_streams(F, s1[32 * n + 128:], s2[32 * n + 128:], n2), p
+    assert all((a + b + c) % F.p == 0 for a, b, c in zip(*got))
+    for p in range(3):
+        assert seeds[64 * p:64 * p + 32] == seeds[64 * ((p + 1) % 3) + 32:64 * ((p + 1) % 3) + 64]
+
