@@ -29,8 +29,10 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 try:
-    HOST_CPUS = len(os.sched_getaffinity(0))        # before any OpenMP runtime pins this thread
+    AFFINITY0 = os.sched_getaffinity(0)             # before any OpenMP runtime pins this thread
+    HOST_CPUS = len(AFFINITY0)
 except Exception:
+    AFFINITY0 = None
     HOST_CPUS = os.cpu_count() or 1
 os.environ.setdefault("OMP_PROC_BIND", "spread")   # cpu_baseline leg: one pinned OpenMP thread per core
 os.environ.setdefault("OMP_PLACES", "cores")
@@ -129,6 +131,17 @@ class Ctx:
         from cosnarks_amd import bindings as B
         self.C, self.np, self.hip, self.B = C, np, hip, B
         self.L = hip.lib()
+        # OMP_PROC_BIND (set above for the cpu_baseline leg) makes libgomp bind the INITIAL thread to one core the moment the library is
+        # loaded (torch brings it in), and every host thread created afterwards inherits that one-core mask: the five MSM threads of a
+        # prove, the library's page-population / copy helpers and the mirror's parallel loops all ran on ONE core in rounds 1-4's bench
+        # process (round 5: a Rep3 mask draw took 67 ms in here against 6 ms in a process of its own, profiles/r05_i_mask_draw_probe.log).
+        # The main thread gets its full mask back before anything is measured; OpenMP's own workers keep their places.
+        self.affinity_after_imports = len(os.sched_getaffinity(0)) if AFFINITY0 is not None else None
+        if AFFINITY0 is not None:
+            try:
+                os.sched_setaffinity(0, AFFINITY0)
+            except OSError:
+                pass
         B._check(self.L.csh_init(self.dev_index))
         self.stream = torch.cuda.current_stream().cuda_stream
         self.comm = None
@@ -839,7 +852,10 @@ def main():
             "config": {"workload": f"{label} Pippenger MSM, uniform scalars / known-dlog points, {per_rank}"
                                    + (" (BASELINE config 2)" if args.workload == "bn254_g1" and args.log_n == 20 else "")
                                    + (" (BASELINE config 5)" if args.workload.startswith("bls12_381") and args.log_n == 24 and args.scaling == "strong" else ""),
-                       "points_total": total, "points_per_gpu": n_local, "split": cx.exchange, "spinup_steps": args.spinup + spin_steps,
+                       "points_total": total, "points_per_gpu": n_local, "split": cx.exchange,
+                       "host_cpus": {"affinity_at_start": HOST_CPUS, "affinity_after_imports_before_restore": cx.affinity_after_imports,
+                                     "affinity_measured_under": len(os.sched_getaffinity(0)) if AFFINITY0 is not None else None},
+                       "spinup_steps": args.spinup + spin_steps,
                        "spinup_ms": round(spin_ms, 1), "spinup_last_batch_median_ms": spin_last_ms,
                        "spinup_rule": "untimed steps before the W warm-up steps: batches of 10 for >= %.1f s until two consecutive batch medians agree within 2 %% (cap 3 s)" % args.spinup_s},
             "value_first_20_steps": value_first_20, "ms_per_step_first_20_steps": cold_dt / 20 * 1e3,
