@@ -572,7 +572,8 @@ def secondary_single_gpu(cx: Ctx, rin: dict, args):
     del a, b, m, o
     # Groth16 plain prove, synthetic 2^20-constraint circuit with a known-dlog key (closed-form checked), key resident
     from cosnarks_amd import groth16 as g16
-    xfer_keys = ("stat_populate_us", "stat_join_wait_us", "stat_finish_us", "stat_d2h_slow", "stat_d2h_staged")
+    xfer_keys = ("stat_populate_us", "stat_join_wait_us", "stat_finish_us", "stat_d2h_slow", "stat_d2h_staged", "stat_h2d_slow", "stat_h2d_staged",
+                 "stat_stage_all_switches", "stat_uploads_shared")
     xfer0 = {k: cx.B.tune_get(k) for k in xfer_keys}
     out[f"groth16_prove_synthetic_2p{args.prove_log_n}"] = g16.bench_synthetic(hip.BN254, args.prove_log_n, 7 if args.quick else 21, with_rep3=True)
     # the host side of the trait path on THIS box: page population (worker time, the caller's wait for it), result copies that stalled /
@@ -863,7 +864,8 @@ def main():
             # the host side of every large host-pointer result of this process (HostXfer, csrc/capi.hip): page-population worker time, the
             # callers' wait for it, final stream waits, copies that stalled (> 3 x their PCIe time + 4 ms) and copies that went through the
             # staged path -- a box whose driver stalls on freshly populated caller pages shows up HERE, on the headline object
-            "host_result_copies": {k[5:]: cx.B.tune_get(k) for k in ("stat_populate_us", "stat_join_wait_us", "stat_finish_us", "stat_d2h_slow", "stat_d2h_staged")},
+            "host_result_copies": {k[5:]: cx.B.tune_get(k) for k in ("stat_populate_us", "stat_join_wait_us", "stat_finish_us", "stat_d2h_slow", "stat_d2h_staged",
+                                                                      "stat_h2d_slow", "stat_h2d_staged", "stat_stage_all_switches", "stat_uploads_shared")},
         }
         print(json.dumps(line))
     sys.stdout.flush()

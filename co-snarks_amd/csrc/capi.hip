@@ -7,6 +7,11 @@
 #include <sys/mman.h>
 
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <vector>
 
 #include "common.hpp"
 
@@ -73,6 +78,101 @@ void host_populate_begin(void* p, size_t bytes, std::vector<std::thread>& worker
 
 void lane_d2h_state(int** staged_left, int** slow_run);  // the calling thread's lane on its device (defined with the lanes below)
 
+// Copier pool of the staged transfers: a handful of persistent host threads (started on first use, parked on a condition variable)
+// instead of seven std::thread constructions per staged copy (~40 us each on these hosts: 0.3 ms per transfer, two or three transfers per
+// witness map). run(k, fn): fn runs on the caller and on up to k pool threads at once (each claims chunks from the caller's own atomic
+// counter) and run returns when all of them have returned. Tasks never block on each other; a caller that finds every worker busy with
+// another caller's copy simply does more of its own chunks itself.
+namespace {
+struct CopierPool {
+  static constexpr int THREADS = 8;
+  std::mutex mu;
+  std::condition_variable cv;
+  struct Job {
+    std::function<void()>* fn;
+    std::atomic<int>* pending;
+    std::mutex* done_mu;
+    std::condition_variable* done_cv;
+  };
+  std::vector<Job> queue;
+  int started = 0;
+  void worker() {
+    for (;;) {
+      Job j;
+      {
+        std::unique_lock<std::mutex> g(mu);
+        cv.wait(g, [&] { return !queue.empty(); });
+        j = queue.back();
+        queue.pop_back();
+      }
+      (*j.fn)();
+      {
+        std::lock_guard<std::mutex> g(*j.done_mu);
+        j.pending->fetch_sub(1, std::memory_order_acq_rel);
+      }
+      j.done_cv->notify_one();
+    }
+  }
+  void run(int helpers, std::function<void()> fn) {
+    if (tune().host_copier_pool.load(std::memory_order_relaxed) == 0) {  // A/B: a std::thread per helper, as before round 5
+      std::vector<std::thread> th;
+      try {
+        for (int t = 0; t < helpers; ++t) th.emplace_back(fn);
+      } catch (...) {
+      }
+      fn();
+      for (auto& t : th) t.join();
+      return;
+    }
+    std::atomic<int> pending{0};
+    std::mutex done_mu;
+    std::condition_variable done_cv;
+    if (helpers > 0) {
+      std::lock_guard<std::mutex> g(mu);
+      while (started < THREADS && started < helpers) {
+        try {
+          std::thread([this] { worker(); }).detach();  // process-lifetime threads: they only ever touch memory a caller of run() keeps alive until it returns
+          ++started;
+        } catch (...) {
+          break;
+        }
+      }
+      const int k = helpers < started ? helpers : started;
+      pending.store(k);
+      for (int i = 0; i < k; ++i) queue.push_back(Job{&fn, &pending, &done_mu, &done_cv});
+    }
+    if (pending.load() > 0) cv.notify_all();
+    fn();
+    std::unique_lock<std::mutex> g(done_mu);
+    done_cv.wait(g, [&] { return pending.load(std::memory_order_acquire) == 0; });
+  }
+};
+CopierPool& copiers() {
+  static CopierPool* p = new CopierPool();  // never destroyed: its detached workers may outlive static destruction
+  return *p;
+}
+}  // namespace
+
+// Round 5 root cause of the "stalled copies" (profiles/r05_l .. r05_r_trait_stall_*; reproducer tools/experiments/trait_stall_probe.py): when
+// the runtime copies straight from / into caller memory it pins those pages, and once such memory has been unmapped again (a freed h
+// vector, a dropped witness: from the second proof of a process on) some LATER operation of the process -- any stream, either direction,
+// staged or not -- takes 10, 20 or 30 ms longer, in steps of the kernel's 10 ms tick, on about half the processes of a box. With BOTH
+// directions staged (the runtime never sees caller memory) 16 of 16 probe runs were clean; with either direction direct 5 of 12 stalled.
+// The condition is process-wide, so is the reaction: a stalled large copy in either direction (two in a row on one lane) sends every
+// large transfer of the process through the staged paths for the next STAGE_ALL_SPELL transfers, then direct copies are tried again.
+static std::atomic<int> g_stage_all_left{0};
+constexpr int STAGE_ALL_SPELL = 4096;
+static bool stage_all_take() {
+  int v = g_stage_all_left.load(std::memory_order_relaxed);
+  while (v > 0)
+    if (g_stage_all_left.compare_exchange_weak(v, v - 1, std::memory_order_relaxed)) return true;
+  return false;
+}
+static void stage_all_begin() {
+  g_stage_all_left.store(STAGE_ALL_SPELL, std::memory_order_relaxed);
+  tune().stat_stage_all_switches.fetch_add(1, std::memory_order_relaxed);
+}
+
 void HostXfer::join() {
   if (workers.empty()) return;
   const auto t0 = std::chrono::steady_clock::now();
@@ -93,17 +193,16 @@ HostXfer::~HostXfer() {
 // sizes) the host-facing witness map took 12-24 ms instead of 2.4 in steps of ~10 ms while every device-resident path ran at
 // its usual speed, i.e. the stall sits in the driver's handling of freshly populated caller pages.
 int HostXfer::d2h(void* host, const void* dev, size_t bytes, hipStream_t st) {
-  // tune "host_d2h": 0 = always direct, 1 = always staged, 2 (default) = direct, timed; two copies in a row ON THIS LANE that take more than
-  // three times their PCIe time + 4 ms send the lane's next 256 large results through the staged path, after which a direct copy is tried again.
+  // tune "host_d2h": 0 = always direct, 1 = always staged, 2 (default) = direct, timed; two copies in a row on one lane that take more than
+  // three times their PCIe time + 4 ms send every large transfer of the PROCESS (both directions, see g_stage_all_left) through the staged
+  // paths for a spell, after which a direct copy is tried again.
   int *staged_left = nullptr, *slow_run = nullptr;
   lane_d2h_state(&staged_left, &slow_run);
   const int mode = tune().host_d2h.load(std::memory_order_relaxed);
   const bool large = bytes >= (size_t(4) << 20);
   bool stage = large && mode == 1;
-  if (large && mode == 2 && *staged_left > 0) {
-    --*staged_left;
-    stage = true;
-  }
+  if (large && mode == 2 && stage_all_take()) stage = true;
+  (void)staged_left;
   // ONE staged copy per HostXfer: the lane has one page-locked slot for this purpose (pinned_for(st ^ 0x8)); a second staged copy before
   // finish() would land in the same buffer -- or free it, if it is larger -- while the first is still waiting to be moved on.
   // Every caller today copies one result per HostXfer; a second one takes the direct path.
@@ -141,7 +240,7 @@ int HostXfer::d2h(void* host, const void* dev, size_t bytes, hipStream_t st) {
     if (ms > 3.0 * (double)bytes / 20e6 + 4.0) {
       tune().stat_d2h_slow.fetch_add(1, std::memory_order_relaxed);
       if (++*slow_run >= 2) {
-        *staged_left = 256;
+        stage_all_begin();
         *slow_run = 1;  // the probe after the staged spell switches back at once if it stalls again
       }
     } else {
@@ -175,14 +274,11 @@ int HostXfer::finish(hipStream_t st) {
           memcpy(static_cast<char*>(sg.host) + off, sg.pinned + off, l);
         }
       };
-      std::vector<std::thread> movers;
-      const int extra = nchunks > 1 ? 3 : 0;
-      try {
-        for (int t = 0; t < extra; ++t) movers.emplace_back([&, device] { (void)hipSetDevice(device); work(); });
-      } catch (...) {  // no thread to be had: the caller moves the rest itself
-      }
-      work();
-      for (auto& t : movers) t.join();
+      const int extra = nchunks > 8 ? 7 : (nchunks > 1 ? 3 : 0);
+      copiers().run(extra, [&, device] {
+        (void)hipSetDevice(device);  // pool threads serve callers on any device
+        work();
+      });
     }
     tune().stat_finish_us.fetch_add(us_since(t0), std::memory_order_relaxed);
     if (failed.load()) {
@@ -218,10 +314,11 @@ struct PinnedSlot {
 struct Lane {
   int device = 0;
   hipStream_t stream = nullptr;
-  // result-copy policy of this lane (HostXfer::d2h, tune host_d2h = 2): a lane is leased to one host thread at a time, so plain ints.
-  // Per lane since round 5: the stall timings of one caller (another device, a caller whose pages sit on another NUMA
-  // node) no longer switch every other caller of the process to the staged path, nor do concurrent callers race on one counter.
+  // stall DETECTION is per lane (a lane is leased to one host thread at a time: plain ints, no races between concurrent callers, VERDICT r4
+  // #6): consecutive stalled large copies of this lane, either direction. The REACTION is process-wide (g_stage_all_left): so is the stall.
   int d2h_staged_left = 0, d2h_slow_run = 0;
+  int h2d_staged_left = 0, h2d_slow_run = 0;
+  hipEvent_t h2d_done[4] = {nullptr, nullptr, nullptr, nullptr};  // last DMA out of each page-locked upload slot
   std::map<hipStream_t, Arena> arenas;
   std::map<hipStream_t, PinnedSlot> pinned;
 };
@@ -278,6 +375,17 @@ static const TuneEntry kTune[] = {
     {"msm_timing", "CSH_MSM_TIMING", &Tune::msm_timing},
     {"msm_no_table", "CSH_MSM_NO_TABLE", &Tune::msm_no_table},
     {"msm_multi_overlap", "CSH_MSM_MULTI_OVERLAP", &Tune::msm_multi_overlap},
+    {"msm_share_uploads", "CSH_MSM_SHARE_UPLOADS", &Tune::msm_share_uploads},
+    {"stat_uploads_shared", "CSH_STAT_UPLOADS_SHARED", &Tune::stat_uploads_shared},
+    {"host_h2d", "CSH_HOST_H2D", &Tune::host_h2d},
+    {"stat_h2d_slow", "CSH_STAT_H2D_SLOW", &Tune::stat_h2d_slow},
+    {"stat_h2d_staged", "CSH_STAT_H2D_STAGED", &Tune::stat_h2d_staged},
+    {"stat_stage_all_switches", "CSH_STAT_STAGE_ALL_SWITCHES", &Tune::stat_stage_all_switches},
+    {"host_copier_pool", "CSH_HOST_COPIER_POOL", &Tune::host_copier_pool},
+    {"host_timing", "CSH_HOST_TIMING", &Tune::host_timing},
+    {"stat_wm_h2d_us", "CSH_STAT_WM_H2D_US", &Tune::stat_wm_h2d_us},
+    {"stat_wm_dev_us", "CSH_STAT_WM_DEV_US", &Tune::stat_wm_dev_us},
+    {"stat_wm_d2h_us", "CSH_STAT_WM_D2H_US", &Tune::stat_wm_d2h_us},
     {"acc_blk", "CSH_ACC_BLK", &Tune::acc_blk},
     {"sort_two_level", "CSH_SORT_TWO_LEVEL", &Tune::sort_two_level},
     {"vec_max_blocks", "CSH_VEC_MAX_BLOCKS", &Tune::vec_max_blocks},
@@ -389,6 +497,71 @@ bool pinned_for(hipStream_t s, size_t bytes, void** host, void** dev) {
 
 hipStream_t resolve_aux_stream() { return tl_lanes.get(tl_device + LaneHolder::AUX_KEY)->stream; }
 
+int upload_h2d(void* dev, const void* host, size_t bytes, hipStream_t st, int slot) {
+  if (!bytes) return CSH_OK;
+  const int mode = tune().host_h2d.load(std::memory_order_relaxed);
+  const bool large = bytes >= (size_t(4) << 20);
+  Lane* lane = tl_lanes.get(tl_device < 0 ? 0 : tl_device);
+  bool stage = large && mode == 1;
+  if (large && mode == 2 && stage_all_take()) stage = true;
+  slot &= 3;
+  void *ph = nullptr, *pd = nullptr;
+  if (stage) {
+    // the slot's previous DMAs must have drained before its buffer is overwritten (or regrown)
+    if (lane->h2d_done[slot]) CSH_HIP(hipEventSynchronize(lane->h2d_done[slot]));
+    if (!pinned_for((hipStream_t)((uintptr_t)st ^ (uintptr_t)(0x10 + 0x10 * slot)), bytes, &ph, &pd)) stage = false;
+  }
+  if (stage) {
+    const size_t chunk = (((bytes + 15) / 16) + (size_t(2) << 20) - 1) & ~((size_t(2) << 20) - 1);  // <= 16 chunks, 2 MiB-granular
+    const size_t nchunks = (bytes + chunk - 1) / chunk;
+    std::atomic<size_t> next{0};
+    std::atomic<int> failed{0};
+    std::mutex enq;  // the chunks' DMAs are enqueued by whichever thread finished copying them (disjoint ranges: order is irrelevant)
+    int device = 0;
+    (void)hipGetDevice(&device);
+    auto work = [&] {
+      for (;;) {
+        const size_t c = next.fetch_add(1, std::memory_order_relaxed);
+        if (c >= nchunks) return;
+        const size_t off = c * chunk, l = bytes - off < chunk ? bytes - off : chunk;
+        memcpy(static_cast<char*>(ph) + off, static_cast<const char*>(host) + off, l);
+        std::lock_guard<std::mutex> g(enq);
+        if (hipMemcpyAsync(static_cast<char*>(dev) + off, static_cast<const char*>(ph) + off, l, hipMemcpyHostToDevice, st) != hipSuccess) failed.store(1);
+      }
+    };
+    const int extra = nchunks > 8 ? 7 : (nchunks > 1 ? 3 : 0);  // 32 MB: eight copiers of two chunks each (~0.4 ms of host copy, the DMAs trail by one chunk)
+    copiers().run(extra, [&, device] {
+      (void)hipSetDevice(device);
+      work();
+    });
+    if (failed.load()) {
+      set_error("staged upload: a chunk copy failed");
+      return CSH_ERR_HIP;
+    }
+    if (!lane->h2d_done[slot]) CSH_HIP(hipEventCreateWithFlags(&lane->h2d_done[slot], hipEventDisableTiming));
+    CSH_HIP(hipEventRecord(lane->h2d_done[slot], st));
+    tune().stat_h2d_staged.fetch_add(1, std::memory_order_relaxed);
+    return CSH_OK;
+  }
+  if (large && mode == 2) {  // a copy from pageable memory returns when the source has been consumed: the call itself is what stalls
+    const auto t0 = std::chrono::steady_clock::now();
+    CSH_HIP(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, st));
+    const double ms = us_since(t0) * 1e-3;
+    if (ms > 3.0 * (double)bytes / 20e6 + 4.0) {
+      tune().stat_h2d_slow.fetch_add(1, std::memory_order_relaxed);
+      if (++lane->h2d_slow_run >= 2) {
+        stage_all_begin();
+        lane->h2d_slow_run = 1;
+      }
+    } else {
+      lane->h2d_slow_run = 0;
+    }
+    return CSH_OK;
+  }
+  CSH_HIP(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, st));
+  return CSH_OK;
+}
+
 }  // namespace csh
 
 using namespace csh;
@@ -483,11 +656,25 @@ int csh_free(void* dev_ptr) {
 }
 int csh_memcpy_h2d(void* dev_dst, const void* host_src, size_t bytes) {
   CSH_TRY(ensure_device());
+  if (bytes >= (size_t(4) << 20)) {  // large: the same staged / direct policy as every other upload from caller memory ("host_h2d")
+    hipStream_t st = resolve_stream(nullptr);
+    CSH_TRY(upload_h2d(dev_dst, host_src, bytes, st, 0));
+    CSH_HIP(hipStreamSynchronize(st));
+    return CSH_OK;
+  }
   CSH_HIP(hipMemcpy(dev_dst, host_src, bytes, hipMemcpyHostToDevice));
   return CSH_OK;
 }
 int csh_memcpy_d2h(void* host_dst, const void* dev_src, size_t bytes) {
   CSH_TRY(ensure_device());
+  if (bytes >= (size_t(4) << 20)) {  // large: HostXfer ("host_d2h", "host_populate")
+    hipStream_t st = resolve_stream(nullptr);
+    CSH_HIP(hipDeviceSynchronize());  // hipMemcpy semantics: everything queued on the device before this call is visible to the copy
+    HostXfer x;
+    x.expect_d2h(host_dst, bytes);
+    CSH_TRY(x.d2h(host_dst, dev_src, bytes, st));
+    return x.finish(st);
+  }
   CSH_HIP(hipMemcpy(host_dst, dev_src, bytes, hipMemcpyDeviceToHost));
   return CSH_OK;
 }

@@ -63,10 +63,24 @@ Arena& arena_for(hipStream_t s);
 hipStream_t resolve_aux_stream();  // second pooled stream of the calling thread (may be nullptr)
 bool pinned_for(hipStream_t s, size_t bytes, void** host, void** dev);  // page-locked result buffer of (thread lane, stream)
 
+// Upload of a caller's (pageable) host buffer. Round 5 (profiles/r05_l .. r05_p_trait_stall_*): on some boxes, from the second circuit of a
+// process on, a hipMemcpyAsync FROM caller memory of 32 MB takes 10-20 ms instead of 0.6-1.3 (steps of ~10 ms: the driver's pinning of the
+// source pages retrying with a one-jiffy sleep) -- that, not the result copy, is the "stalled witness map" of round 4. tune "host_h2d":
+// 0 = one copy from the caller's pages, 1 = staged (host threads copy 2 MiB chunks into the lane's page-locked buffer, each chunk's DMA
+// follows at once: the driver never pins caller memory; +0.3-0.5 ms per 32 MB on a healthy box), 2 = direct and timed; two in a row
+// on one lane that took more than three times their PCIe time + 4 ms switch the whole process to staged transfers in BOTH directions for a
+// spell. DEFAULT = 1, and 1 for results too (host_d2h): the stalled state is sticky -- a process that has entered it keeps stalling after the
+// switch (profiles/r05_s_trait_stall_auto_mode.log: 23-33 ms per witness map with every transfer staged by then), whereas a process whose
+// transfers were staged from its first call never entered it in 32 of 32 probe runs (r05_r, r05_t). The price is ~10 % of a trait-path
+// prove at 2^20 on a box that would have stayed healthy (18.3 against 16.6 ms); 0 / 2 remain for hosts known to be fine. `slot` (0..3) names one of the lane's
+// page-locked staging buffers: uploads of one call that are in flight together use different slots. Returns once `host` has been read.
+int upload_h2d(void* dev, const void* host, size_t bytes, hipStream_t st, int slot);
+
 // Host-pointer convenience path: stage inputs into a per-thread arena, run on the thread's stream, copy back.
 struct HostStage {
   hipStream_t st = nullptr;
   Arena* ar = nullptr;
+  int slot = 0;
   int begin(size_t total_bytes) {
     CSH_TRY(ensure_device());
     st = resolve_stream(nullptr);
@@ -76,7 +90,7 @@ struct HostStage {
   template <class T>
   int up(T*& dev, const void* host, size_t bytes) {
     dev = reinterpret_cast<T*>(ar->take<char>(bytes));
-    if (host && bytes) CSH_HIP(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, st));
+    if (host && bytes) CSH_TRY(upload_h2d(dev, host, bytes, st, slot++ & 3));
     return CSH_OK;
   }
   int down(void* host, const void* dev, size_t bytes);  // capi.hip: populates a large destination's pages first (see HostXfer)
@@ -107,8 +121,9 @@ struct HostXfer {
   void join();  // capi.hip (counts the time the caller waited: stat_join_wait_us)
   // call as early as the destination is known: the pages are populated while uploads and kernels run
   void expect_d2h(void* host, size_t bytes) { host_populate_begin(host, bytes, workers); }
+  int h2d_slot = 0;
   int h2d(void* dev, const void* host, size_t bytes, hipStream_t st) {
-    if (bytes) CSH_HIP(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, st));
+    if (bytes) CSH_TRY(upload_h2d(dev, host, bytes, st, h2d_slot++ & 3));
     return CSH_OK;
   }
   int d2h(void* host, const void* dev, size_t bytes, hipStream_t st);  // capi.hip
@@ -142,6 +157,13 @@ struct Tune {
   std::atomic<int> stat_lanes{0};
   std::atomic<int> stat_populate_us{0}, stat_join_wait_us{0}, stat_finish_us{0}, stat_d2h_slow{0}, stat_d2h_staged{0};  // page population: worker time, caller's wait for it, final stream wait
   std::atomic<int> msm_multi_overlap{1}; // alternate bucket stages of csh_msm_multi_dev between two streams
+  std::atomic<int> msm_share_uploads{1}; // csh_msm: concurrent calls handed the same host scalar slice share one upload (msm.hip SharedUpload)
+  std::atomic<int> stat_uploads_shared{0};  // counter: csh_msm calls that reused a concurrent call's upload
+  std::atomic<int> host_h2d{1};  // uploads of >= 4 MiB from pageable caller memory: 0 direct, 1 (default) staged through page-locked chunks, 2 direct + timed, staged after stalls (upload_h2d)
+  std::atomic<int> stat_h2d_slow{0}, stat_h2d_staged{0}, stat_stage_all_switches{0};
+  std::atomic<int> host_copier_pool{1};  // staged transfers: 1 = persistent copier pool, 0 = a std::thread per helper and copy (A/B)
+  std::atomic<int> host_timing{0};  // diagnostics: 1 = the host-facing witness map synchronises after its upload, its kernels and its result copy and adds the three times to the counters below
+  std::atomic<int> stat_wm_h2d_us{0}, stat_wm_dev_us{0}, stat_wm_d2h_us{0};
   std::atomic<int> acc_blk{0};           // accumulate workgroup size (0 = default)
   std::atomic<int> sort_two_level{-1};   // -1 auto, 0 / 1 forced
   std::atomic<int> vec_max_blocks{65536};
@@ -152,8 +174,8 @@ struct Tune {
   std::atomic<int> allow_unmasked_rep3{0};  // Rep3 products without the re-randomising masks: refused unless set (tests)
   std::atomic<int> ntt_variant{0};
   std::atomic<int> h_unfused{0};          // Groth16 h pipeline: 1 = the unfused step-by-step sequence (A/B, tests)
-  std::atomic<int> host_d2h{2};  // large results to pageable memory: 0 = one copy straight into the caller's pages, 1 = staged through a page-locked
-                                 // buffer + host threads, 2 = direct, timed, staged for a while after a copy that stalled (HostXfer::d2h)
+  std::atomic<int> host_d2h{1};  // large results to pageable memory: 0 = one copy straight into the caller's pages, 1 (default since round 5) = staged
+                                 // through a page-locked buffer + host threads, 2 = direct, timed, staged for a while after a copy that stalled (HostXfer::d2h)
   std::atomic<int> comm_timeout_ms{120000};  // deadline of an RCCL communicator's construction (0 = on the calling thread, no deadline)
   std::atomic<int> comm_nonblocking{0};  // csh_comm_init_rank: 1 = ncclCommInitRankConfig(blocking = 0) + polling instead of ncclCommInitRank
   std::atomic<int> host_populate{0x101};  // low byte: threads populating a large D2H destination's pages before the copy (0 = off); bit 8: huge-page hint

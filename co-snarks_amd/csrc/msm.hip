@@ -17,6 +17,8 @@
 // Replaces taceo_ark_algebra::msm::{msm_unchecked, msm_bigint} (see include/cosnarks_hip.h for the call
 // sites). The result is a group element; it is bit-identical to the reference after affine normalisation.
 #include <algorithm>
+#include <condition_variable>
+#include <mutex>
 #include <vector>
 
 #include "msm_impl.hpp"
@@ -37,6 +39,119 @@ static int repack_bases(Bases* B, hipStream_t st);
 }  // namespace csh
 
 using namespace csh;
+
+// ---- one upload for concurrent host-scalar calls over the same slice ----------------------------------------------------------------
+// The reference issues the five MSMs of a proof concurrently (rayon_join5) and four of them read the same `aux_assignment` slice: behind
+// an unchanged reference that is four csh_msm calls with the same host pointer at the same time, i.e. four 32 MB uploads sharing the
+// PCIe link before the first kernel of any of them can start (2^20: ~3 ms during which the GPU idles). A call that finds another call
+// IN FLIGHT with the same (device, pointer, length) waits for that call's upload (a stream-to-stream event wait) and reads its device
+// copy instead. Sound by the ordinary contract of a synchronous entry point -- the caller must not modify an input while a call that
+// was handed it is running -- and only by that: nothing is reused once the last call using it has returned, no content is compared, no
+// copy outlives its callers. Device buffers come from a small per-device pool (no hipMalloc in the steady state).
+namespace {
+struct SharedUpload {
+  int device = 0;
+  const void* host = nullptr;
+  size_t bytes = 0, cap = 0;
+  void* dev = nullptr;
+  hipEvent_t ready = nullptr;
+  int refs = 0;
+  std::mutex m;  // guards `state`
+  std::condition_variable cv;
+  int state = 0;  // 0 = the owner has not recorded `ready` yet, 1 = recorded, -1 = the owner's upload failed
+};
+std::mutex g_up_mu;
+std::vector<SharedUpload*> g_up_live;                       // entries with refs > 0
+std::vector<std::pair<int, std::pair<size_t, void*>>> g_up_pool;  // (device, (capacity, buffer)) free device buffers
+constexpr size_t UP_POOL_MAX = 8;
+
+struct SharedUploadRef {
+  SharedUpload* e = nullptr;
+  hipStream_t stream = nullptr;
+  const void* dev() const { return e->dev; }
+  int acquire(int device, const void* host, size_t bytes, hipStream_t st) {
+    stream = st;
+    bool owner = false;
+    {
+      std::lock_guard<std::mutex> g(g_up_mu);
+      for (SharedUpload* x : g_up_live)
+        if (x->device == device && x->host == host && x->bytes == bytes) {
+          e = x;
+          break;
+        }
+      if (e) {
+        ++e->refs;
+      } else {
+        e = new SharedUpload();
+        e->device = device, e->host = host, e->bytes = bytes, e->refs = 1;
+        size_t best = (size_t)-1;
+        for (size_t i = 0; i < g_up_pool.size(); ++i)
+          if (g_up_pool[i].first == device && g_up_pool[i].second.first >= bytes && (best == (size_t)-1 || g_up_pool[i].second.first < g_up_pool[best].second.first)) best = i;
+        if (best != (size_t)-1) {
+          e->cap = g_up_pool[best].second.first;
+          e->dev = g_up_pool[best].second.second;
+          g_up_pool.erase(g_up_pool.begin() + (ptrdiff_t)best);
+        }
+        g_up_live.push_back(e);
+        owner = true;
+      }
+    }
+    if (owner) {
+      hipError_t rc = hipSuccess;
+      if (!e->dev) {
+        e->cap = (bytes + (size_t(1) << 20) - 1) & ~((size_t(1) << 20) - 1);
+        rc = hipMalloc(&e->dev, e->cap);
+        if (rc != hipSuccess) e->dev = nullptr;
+      }
+      if (rc == hipSuccess) rc = hipEventCreateWithFlags(&e->ready, hipEventDisableTiming);
+      if (rc == hipSuccess && upload_h2d(e->dev, host, bytes, st, 3) != CSH_OK) rc = hipErrorUnknown;
+      if (rc == hipSuccess) rc = hipEventRecord(e->ready, st);
+      {
+        std::lock_guard<std::mutex> g(e->m);
+        e->state = rc == hipSuccess ? 1 : -1;
+      }
+      e->cv.notify_all();
+      if (rc != hipSuccess) {
+        set_error("csh_msm: uploading the scalars failed: %s", hipGetErrorString(rc));
+        return rc == hipErrorOutOfMemory ? CSH_ERR_OOM : CSH_ERR_HIP;
+      }
+      return CSH_OK;
+    }
+    {
+      std::unique_lock<std::mutex> g(e->m);
+      e->cv.wait(g, [&] { return e->state != 0; });
+      if (e->state < 0) {
+        set_error("csh_msm: the concurrent call that was uploading this scalar slice failed");
+        return CSH_ERR_HIP;
+      }
+    }
+    CSH_HIP(hipStreamWaitEvent(st, e->ready, 0));
+    tune().stat_uploads_shared.fetch_add(1, std::memory_order_relaxed);
+    return CSH_OK;
+  }
+  ~SharedUploadRef() {
+    if (!e) return;
+    (void)hipStreamSynchronize(stream);  // a no-op after a successful (synchronous) MSM; after a failed one nothing queued on this stream may still read the copy
+    SharedUpload* dead = nullptr;
+    {
+      std::lock_guard<std::mutex> g(g_up_mu);
+      if (--e->refs == 0) {
+        g_up_live.erase(std::find(g_up_live.begin(), g_up_live.end(), e));
+        dead = e;
+        if (dead->dev && g_up_pool.size() < UP_POOL_MAX) {
+          g_up_pool.push_back({dead->device, {dead->cap, dead->dev}});
+          dead->dev = nullptr;
+        }
+      }
+    }
+    if (dead) {  // every call that used the copy has synchronised its stream (csh_msm_dev is synchronous) or failed before launching
+      if (dead->ready) (void)hipEventDestroy(dead->ready);
+      if (dead->dev) (void)hipFree(dead->dev);
+      delete dead;
+    }
+  }
+};
+}  // namespace
 
 static int csh::repack_bases(Bases* B, hipStream_t st) {
   CURVE_DISPATCH(B->curve, B->group, (repack_bases_t<Cfg>(B, st)));
@@ -76,7 +191,11 @@ static int bases_upload_common(csh_curve_t curve, csh_group_t group, const void*
   if (n) {
     hipStream_t st = resolve_stream(stream);
     const hipMemcpyKind kind = src_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-    e = stride == pb ? hipMemcpyAsync(B->points, pts, n * pb, kind, st) : hipMemcpy2DAsync(B->points, pb, pts, stride, pb, n, kind, st);
+    if (!src_dev && stride == pb) {  // packed host points: the "host_h2d" policy (staged by default: the runtime does not pin the caller's key)
+      if (upload_h2d(B->points, pts, n * pb, st, 0) != CSH_OK) e = hipErrorUnknown;
+    } else {
+      e = stride == pb ? hipMemcpyAsync(B->points, pts, n * pb, kind, st) : hipMemcpy2DAsync(B->points, pb, pts, stride, pb, n, kind, st);
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) {
       (void)hipFree(B->points);
@@ -241,10 +360,22 @@ int csh_msm_dev(csh_bases_t bases, size_t offset, size_t n, const uint64_t* scal
 
 int csh_msm(csh_bases_t bases, size_t offset, size_t n, const uint64_t* scalars, int mont, void* out) {
   CSH_TRY(msm_args(bases, offset, n, scalars, out));
+  const size_t bytes = 32 * n;
+  if (bytes >= (size_t(1) << 20) && tune().msm_share_uploads.load(std::memory_order_relaxed) != 0) {
+    // Concurrent calls over ONE host slice (the reference's rayon_join5, groth16.rs:227-294: four of the five MSM closures of a proof
+    // read the same aux_assignment) share one upload: see SharedUpload above.
+    CSH_TRY(ensure_device());
+    hipStream_t st = resolve_stream(nullptr);
+    int device = 0;
+    (void)hipGetDevice(&device);
+    SharedUploadRef up;
+    CSH_TRY(up.acquire(device, scalars, bytes, st));
+    return csh_msm_dev(bases, offset, n, reinterpret_cast<const uint64_t*>(up.dev()), mont, out, st);
+  }
   HostStage h;
-  CSH_TRY(h.begin(Arena::padded(32 * n)));
+  CSH_TRY(h.begin(Arena::padded(bytes)));
   uint64_t* ds;
-  CSH_TRY(h.up(ds, scalars, 32 * n));
+  CSH_TRY(h.up(ds, scalars, bytes));
   return csh_msm_dev(bases, offset, n, ds, mont, out, h.st);
 }
 

@@ -3,6 +3,8 @@
 // One lane per constraint row (circom rows hold a handful of terms); gathers are 32/64-byte reads through L2.
 #include <string.h>
 
+#include <chrono>
+
 #include "common.hpp"
 #include "field.hpp"
 
@@ -127,10 +129,14 @@ int csh_matrix_upload(csh_curve_t field_of, const uint64_t* row_ptr, const uint3
     set_error("matrix_upload: hipMalloc failed");
     return CSH_ERR_OOM;
   }
-  CSH_HIP(hipMemcpy(m->row_ptr, row_ptr, (n_rows + 1) * 8, hipMemcpyHostToDevice));
-  if (nnz) {
-    CSH_HIP(hipMemcpy(m->col_idx, col_idx, nnz * 4, hipMemcpyHostToDevice));
-    CSH_HIP(hipMemcpy(m->coeffs, coeffs, nnz * 32, hipMemcpyHostToDevice));
+  {  // the caller's CSR arrays are typically temporaries it frees right after this call: uploads follow the "host_h2d" policy (staged by default)
+    hipStream_t st = resolve_stream(nullptr);
+    CSH_TRY(upload_h2d(m->row_ptr, row_ptr, (n_rows + 1) * 8, st, 0));
+    if (nnz) {
+      CSH_TRY(upload_h2d(m->col_idx, col_idx, nnz * 4, st, 1));
+      CSH_TRY(upload_h2d(m->coeffs, coeffs, nnz * 32, st, 2));
+    }
+    CSH_HIP(hipStreamSynchronize(st));
   }
   *out = reinterpret_cast<csh_matrix_t>(m);
   return CSH_OK;
@@ -261,6 +267,15 @@ int witness_map_host(csh_domain_t dom, const uint64_t shift[4], int protocol, in
   pins.expect_d2h(h_out, 32 * n);
   MaskSource ms;
   ms.seed1 = seed1, ms.off1 = off1, ms.seed2 = seed2, ms.off2 = off2;
+  const bool timing = tune().host_timing.load(std::memory_order_relaxed) != 0;  // diagnostics only: the extra synchronisations cost ~20 us each
+  auto t_phase = std::chrono::steady_clock::now();
+  auto phase_done = [&](std::atomic<int>& counter) {
+    if (!timing) return;
+    (void)hipStreamSynchronize(st);
+    const auto now = std::chrono::steady_clock::now();
+    counter.fetch_add((int)std::chrono::duration_cast<std::chrono::microseconds>(now - t_phase).count(), std::memory_order_relaxed);
+    t_phase = now;
+  };
   if (n_witness) CSH_TRY(pins.h2d(dwit, witness, 32 * comp * n_witness, st));
   if (host_masks) {
     uint64_t* dmc = reinterpret_cast<uint64_t*>(ar.take<char>(32 * n));
@@ -269,9 +284,13 @@ int witness_map_host(csh_domain_t dom, const uint64_t shift[4], int protocol, in
     CSH_TRY(pins.h2d(dmab, mask_ab, 32 * n, st));
     ms.mask_c_dev = dmc, ms.mask_ab_dev = dmab;
   }
+  phase_done(tune().stat_wm_h2d_us);
   CSH_TRY(witness_map_core(dom, shift, protocol, party_id, ma, mb, num_constraints, public_inputs, n_public, dwit, n_witness, ms, dh, st));
+  phase_done(tune().stat_wm_dev_us);
   CSH_TRY(pins.d2h(h_out, dh, 32 * n, st));
-  return pins.finish(st);
+  const int rc = pins.finish(st);
+  phase_done(tune().stat_wm_d2h_us);
+  return rc;
 }
 }  // namespace
 

@@ -547,7 +547,16 @@ int bench_synth_t(int log_domain, int iters, double* out_ms, int* check_ok, cons
   using T = PlainGroth16Driver<P>;
   using Fr = typename P::Fr;
   using Fq = typename P::Fq;
-  SynthCircuit<P> sc(log_domain, g1_words, g2_words);
+  // COG16_LEAK_BENCH_CIRCUIT=1 (diagnostics, tools/experiments/trait_stall_probe.py): the circuit of this call is never destroyed, so none of
+  // the host memory the runtime has copied from / to is unmapped while later calls run
+  std::unique_ptr<SynthCircuit<P>> sc_owner(new SynthCircuit<P>(log_domain, g1_words, g2_words));
+  SynthCircuit<P>& sc = *sc_owner;
+  struct Leak {
+    std::unique_ptr<SynthCircuit<P>>& o;
+    ~Leak() {
+      if (getenv("COG16_LEAK_BENCH_CIRCUIT")) (void)o.release();
+    }
+  } leak{sc_owner};
   ProvingKey<P>& pk = sc.pk;
   ConstraintMatrices<P>& m = sc.m;
   SharedWitness<P, Fr>& sw = sc.sw;

@@ -32,11 +32,13 @@
  *
  * Host threads the library itself starts (all joined before the call returns unless said otherwise; none touches caller memory after
  * the return):
- *  - entry points that hand a result of >= 4 MiB back through a HOST pointer -- csh_groth16_witness_map / _masks / _libsnark*,
- *    csh_groth16_h*, the host-pointer transforms csh_fft / csh_ifft / csh_domain_* without _dev, csh_vec_* / csh_rep3_* without
- *    _dev -- start ONE short-lived thread that populates the destination's pages while the device works ("host_populate"), and, when
- *    the copy is staged ("host_d2h"), up to three more that move the chunks on; csh_tune_set("host_populate", 0) + ("host_d2h", 0)
- *    turns both off (the call then never leaves the calling thread);
+ *  - entry points that move >= 4 MiB between caller memory and the device through HOST pointers -- csh_groth16_witness_map / _masks /
+ *    _libsnark*, csh_groth16_h*, the host-pointer transforms and share-vector calls (no _dev suffix), csh_msm / csh_msm_shares with host
+ *    scalars -- start ONE short-lived thread per result that populates the destination's pages while the device works ("host_populate"),
+ *    and hand the chunks of a staged transfer ("host_d2h" / "host_h2d" = 1, the default) to a process-wide pool of up to eight parked
+ *    copier threads, created on first use and kept for the life of the process; they touch caller memory only while the call that
+ *    enlisted them is running. csh_tune_set("host_populate", 0) + ("host_d2h", 0) + ("host_h2d", 0) turns all of it off (the call then
+ *    never leaves the calling thread, and the runtime pins the caller's pages itself);
  *  - csh_comm_init_rank with nranks > 1 runs the collective ncclCommInitRank on a helper thread against "comm_timeout_ms"; a helper
  *    whose peers never arrive is ABANDONED (still blocked inside RCCL after the call returned its error): leave such a process
  *    through _exit.
@@ -89,9 +91,18 @@ int csh_device_count(int* count);
  * two-level sort with one block per partition instead of one per tile-sized slice), "h_unfused", "comm_timeout_ms" (csh_comm_init_rank),
  * "host_populate" (results of >= 4 MiB handed back in pageable memory: low byte = host threads that populate the destination's
  * pages while the device works, 0 = none; bit 8 = transparent-huge-page hint on the range; default 0x101), "host_d2h" (the copy of such
- * a result: 0 = one DMA into the caller's pages, 1 = staged through the lane's page-locked buffer and moved on by host threads,
- * 2 = default: direct and timed, staged for the calling lane's next 256 results after two stalled copies in a row ON THAT LANE -- a lane is
- * the stream + scratch leased to one host thread at a time, so concurrent callers neither share nor race on this state),
+ * a result: 0 = one DMA into the caller's pages, 1 = default since round 5: staged through the lane's page-locked buffer and moved on by
+ * host threads, 2 = direct and timed; two stalled copies in a row on one lane -- the stream + scratch leased to one host thread at a time, so
+ * concurrent callers do not race on the detector -- switch every large transfer of the process, both directions, to the staged paths for
+ * the next 4096 transfers: the stall is a process-wide condition of the runtime having pinned caller memory that was unmapped since, and
+ * it only goes away while the runtime sees no caller memory at all; counter "stat_stage_all_switches"),
+ * "host_h2d" (uploads of >= 4 MiB from caller memory: 0 = one copy from the caller's pages, 1 = staged through the lane's page-locked
+ * buffers in 2 MiB chunks copied by host threads -- the driver never pins caller memory; the default, 2 = direct and timed, feeding the same
+ * process-wide switch as "host_d2h"; counters "stat_h2d_slow", "stat_h2d_staged". Staging is the default in both directions because a
+ * process whose runtime has pinned caller memory that was unmapped afterwards can stall 10-30 ms per later call for the rest of its life
+ * (DESIGN.md 3.4), and that state cannot be left once entered),
+ * "msm_share_uploads" (1 = default: concurrent csh_msm calls handed the same host scalar slice share one upload; counter
+ * "stat_uploads_shared"), "host_timing" (diagnostics: phase times of the host-facing witness map in "stat_wm_h2d_us" / "_dev_us" / "_d2h_us"),
  * "msm_balanced" (1 = default: the MSM's windows share the scalar bits evenly, widths c and c - 1; 0 = uniform c-bit windows),
  * "msm_w" (balanced windows: forced number of windows, 0 = the tuned count). Read-only counters
  * (csh_tune_get): "stat_arena_grows", "stat_lanes", "stat_populate_us", "stat_join_wait_us", "stat_finish_us", "stat_d2h_slow",

@@ -308,6 +308,76 @@ def test_concurrent_callers_share_the_device(gpu):
     assert not errors, errors
 
 
+def test_concurrent_host_scalar_calls_share_one_upload(gpu):
+    """Round 5: concurrent csh_msm calls handed the SAME host scalar slice (the reference's rayon_join5: A, B/G1, B/G2 and L all read
+    aux_assignment, groth16.rs:227-294) share one upload -- a call that finds another one in flight with the same (device, pointer,
+    length) reads that call's device copy. Known-dlog bases of four groups / seeds, 2^17 + 5 scalars (4 MiB: above the sharing threshold),
+    six rounds of four concurrent callers + one caller on a different slice of the same vector: every result equals the closed form and
+    the one computed alone with sharing off; the counter shows that copies were shared; nothing is shared between calls that do not overlap."""
+    import ctypes as C
+    import threading
+    from tests.check_closed_form import closed_form_point, dlogs, weighted_sum
+    from cosnarks_amd import bindings as B
+    n = (1 << 17) + 5
+    F = H.FR["bn254"]
+    jobs = [("bn254", 0, 0x51), ("bn254", 0, 0x52), ("bn254", 1, 0x53), ("bn254", 0, 0x54)]
+    handles = []
+    for curve, group, seed in jobs:
+        buf = _gen_bases(gpu, curve, group, seed, n)
+        h = C.c_void_p()
+        gpu.bindings._check(gpu.lib().csh_bases_upload_dev(H.CURVE_IDS[curve], group, buf.ptr, C.c_size_t(n), C.c_size_t(0), None, C.byref(h)))
+        buf.free()
+        handles.append(h)
+    rs = np.random.RandomState(17)
+    limbs = rs.randint(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    limbs[:, 3] >>= np.uint64(3)
+    want = [closed_form_point(c, g, s, n, limbs, True) for c, g, s in jobs]
+    m, off = n - 4097, 4097                                      # the fifth caller: another slice (other pointer), bases of job 0 from `off`
+    sub = limbs[off:]
+    S = weighted_sum(sub, dlogs(jobs[0][2], m, off)) % F.p * F.Rinv % F.p
+    want_sub = cv.BN254_G1.mul(cv.BN254_G1.gen, S)
+
+    def call(i, out, scalars=limbs, count=n, offset=0):
+        gpu.bindings._check(gpu.lib().csh_init(0))
+        gpu.bindings._check(gpu.lib().csh_msm(handles[i], C.c_size_t(offset), C.c_size_t(count), scalars.ctypes.data_as(C.c_void_p), 1, out.ctypes.data_as(C.c_void_p)))
+
+    outs = [np.zeros(3 * gpu.point_bytes(H.CURVE_IDS[c], g) // 16, dtype=np.uint64) for c, g, _ in jobs]
+    alone = []
+    with gpu.tuned(msm_share_uploads=0):
+        for i in range(4):
+            call(i, outs[i])
+            alone.append(outs[i].copy())
+    shared0 = B.tune_get("stat_uploads_shared")
+    for i in range(4):                                           # sequential calls never overlap: nothing to share
+        call(i, outs[i])
+    assert B.tune_get("stat_uploads_shared") == shared0
+    errs = []
+    for _ in range(6):
+        o5 = np.zeros_like(outs[0])
+        res = [np.zeros_like(o) for o in outs]
+
+        def guarded(fn, *a, **k):
+            try:
+                fn(*a, **k)
+            except Exception as e:  # noqa: BLE001
+                errs.append(repr(e))
+
+        th = [threading.Thread(target=guarded, args=(call, i, res[i])) for i in range(4)]
+        th.append(threading.Thread(target=guarded, args=(call, 0, o5), kwargs=dict(scalars=sub, count=m, offset=off)))
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errs, errs
+        for i, (c, g, _s) in enumerate(jobs):
+            G = cv.CURVES[c][g]
+            assert G.eq(H.jac_to_affine(G, res[i]), want[i]) and np.array_equal(res[i], alone[i]), i
+        assert cv.BN254_G1.eq(H.jac_to_affine(cv.BN254_G1, o5), want_sub)
+    assert B.tune_get("stat_uploads_shared") > shared0
+    for h in handles:
+        gpu.lib().csh_bases_free(h)
+
+
 @pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
 def test_msm_multi_shares_one_sort(gpu, curve):
     """csh_msm_multi_dev: several MSMs (G1 and G2 mixed, different offsets) over one scalar vector, one digit sort;

@@ -204,6 +204,56 @@ def test_trait_path_synthetic_circuit_closed_form(gpu):
     assert ph["msm_groups"] > 0 and ph["witness_upload_and_map"] > 0
 
 
+def test_large_uploads_direct_and_staged_agree(gpu):
+    """Round 5: uploads of >= 4 MiB from caller memory go up in one copy (tune host_h2d = 0), staged through the lane's page-locked
+    buffers in 2 MiB chunks moved by host threads (1), or direct-and-timed (2, the default: staged for a while after two stalled uploads).
+    A host-pointer transform of 2^18 elements (8 MiB up, 8 MiB down), a host-scalar MSM of 2^17 + 3 points (shared-upload path) and a
+    trait-path prove of a 2^17-constraint circuit give the same bytes / the closed form in every mode; mode 1 is seen to stage."""
+    import ctypes as C
+    from cosnarks_amd import bindings as B
+    from cosnarks_amd import groth16 as g
+    from tests.check_closed_form import closed_form_point
+    from tests.test_gpu_msm import _gen_bases
+    F = H.FR["bn254"]
+    logn = 18
+    gen = ntt.roots_of_unity(F)[1][logn]
+    dom = gpu.Domain(H.CURVE_IDS["bn254"], logn, H.pack(F, [gen]))
+    x = np.random.RandomState(5).randint(0, 1 << 62, size=(1 << logn, 4), dtype=np.uint64)
+    x[:, 3] >>= np.uint64(2)
+    n = (1 << 17) + 3
+    buf = _gen_bases(gpu, "bn254", 0, 0x77, n)
+    hb = C.c_void_p()
+    gpu.bindings._check(gpu.lib().csh_bases_upload_dev(0, 0, buf.ptr, C.c_size_t(n), C.c_size_t(0), None, C.byref(hb)))
+    buf.free()
+    limbs = np.random.RandomState(6).randint(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    limbs[:, 3] >>= np.uint64(3)
+    want_pt = closed_form_point("bn254", 0, 0x77, n, limbs, True)
+    G = cv_mod().BN254_G1
+    outs = {}
+    for mode in (0, 1, 2):
+        staged0 = B.tune_get("stat_h2d_staged")
+        with gpu.tuned(host_h2d=mode):
+            outs[mode] = np.array(dom.ifft_in_to_out(x.copy()), copy=True)
+            o = np.zeros(12, dtype=np.uint64)
+            gpu.bindings._check(gpu.lib().csh_msm(hb, C.c_size_t(0), C.c_size_t(n), limbs.ctypes.data_as(C.c_void_p), 1, o.ctypes.data_as(C.c_void_p)))
+            assert G.eq(H.jac_to_affine(G, o), want_pt), mode
+            with g.trait_path():
+                c = g.SynthCircuit(0, 17)
+                c.prove()
+                assert c.check(), mode
+                c.close()
+        if mode != 2:
+            assert (B.tune_get("stat_h2d_staged") > staged0) == (mode == 1), mode
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    gpu.lib().csh_bases_free(hb)
+    dom.free()
+
+
+def cv_mod():
+    from oracle import curves
+    return curves
+
+
 def test_large_results_direct_and_staged_copies_agree(gpu):
     """Results of >= 4 MiB reach the caller's pageable memory either by one copy into its pages or staged through the lane's page-locked
     buffer (tune host_d2h: 0 / 1; 2 = direct, timed, staged after a stalled copy): a 2^18-point host-pointer transform and the h of a
@@ -288,10 +338,12 @@ def test_concurrent_host_pointer_callers_while_the_copy_mode_flips(gpu):
         while not stop.is_set():
             B.tune_set("host_d2h", (1, 0, 2, 1)[k % 4])
             B.tune_set("host_populate", (0x101, 0, 0x101, 0x102)[k % 4])
+            B.tune_set("host_h2d", (1, 2, 0, 1, 1)[k % 5])                      # uploads from caller memory: staged / auto / direct
             k += 1
             time.sleep(0.003)
 
-    d2h0, pop0 = B.tune_get("host_d2h"), B.tune_get("host_populate")
+    d2h0, pop0, h2d0 = B.tune_get("host_d2h"), B.tune_get("host_populate"), B.tune_get("host_h2d")
+    up_staged0 = B.tune_get("stat_h2d_staged")
     th = [threading.Thread(target=transformer, args=(logn, 12 if logn >= 19 else 30)) for logn in sizes]
     th += [threading.Thread(target=prover, args=(4,)) for _ in range(2)]
     fl = threading.Thread(target=flipper)
@@ -306,9 +358,10 @@ def test_concurrent_host_pointer_callers_while_the_copy_mode_flips(gpu):
         fl.join()
         B.tune_set("host_d2h", d2h0)
         B.tune_set("host_populate", pop0)
+        B.tune_set("host_h2d", h2d0)
     assert not errs, errs
     assert not any(t.is_alive() for t in th)
-    assert B.tune_get("stat_d2h_staged") > staged0
+    assert B.tune_get("stat_d2h_staged") > staged0 and B.tune_get("stat_h2d_staged") > up_staged0
     for d in doms.values():
         d.free()
 
