@@ -76,7 +76,7 @@ void host_populate_begin(void* p, size_t bytes, std::vector<std::thread>& worker
   }
 }
 
-void lane_d2h_state(int** staged_left, int** slow_run);  // the calling thread's lane on its device (defined with the lanes below)
+int* lane_d2h_slow_run();  // consecutive stalled result copies of the calling thread's lane on its device (defined with the lanes below)
 
 // Copier pool of the staged transfers: a handful of persistent host threads (started on first use, parked on a condition variable)
 // instead of seven std::thread constructions per staged copy (~40 us each on these hosts: 0.3 ms per transfer, two or three transfers per
@@ -196,13 +196,11 @@ int HostXfer::d2h(void* host, const void* dev, size_t bytes, hipStream_t st) {
   // tune "host_d2h": 0 = always direct, 1 = always staged, 2 (default) = direct, timed; two copies in a row on one lane that take more than
   // three times their PCIe time + 4 ms send every large transfer of the PROCESS (both directions, see g_stage_all_left) through the staged
   // paths for a spell, after which a direct copy is tried again.
-  int *staged_left = nullptr, *slow_run = nullptr;
-  lane_d2h_state(&staged_left, &slow_run);
+  int* slow_run = lane_d2h_slow_run();
   const int mode = tune().host_d2h.load(std::memory_order_relaxed);
   const bool large = bytes >= (size_t(4) << 20);
   bool stage = large && mode == 1;
   if (large && mode == 2 && stage_all_take()) stage = true;
-  (void)staged_left;
   // ONE staged copy per HostXfer: the lane has one page-locked slot for this purpose (pinned_for(st ^ 0x8)); a second staged copy before
   // finish() would land in the same buffer -- or free it, if it is larger -- while the first is still waiting to be moved on.
   // Every caller today copies one result per HostXfer; a second one takes the direct path.
@@ -316,8 +314,7 @@ struct Lane {
   hipStream_t stream = nullptr;
   // stall DETECTION is per lane (a lane is leased to one host thread at a time: plain ints, no races between concurrent callers, VERDICT r4
   // #6): consecutive stalled large copies of this lane, either direction. The REACTION is process-wide (g_stage_all_left): so is the stall.
-  int d2h_staged_left = 0, d2h_slow_run = 0;
-  int h2d_staged_left = 0, h2d_slow_run = 0;
+  int d2h_slow_run = 0, h2d_slow_run = 0;
   hipEvent_t h2d_done[4] = {nullptr, nullptr, nullptr, nullptr};  // last DMA out of each page-locked upload slot
   std::map<hipStream_t, Arena> arenas;
   std::map<hipStream_t, PinnedSlot> pinned;
@@ -356,11 +353,7 @@ struct LaneHolder {
   }
 };
 static thread_local LaneHolder tl_lanes;
-void lane_d2h_state(int** staged_left, int** slow_run) {
-  Lane* l = tl_lanes.get(tl_device < 0 ? 0 : tl_device);
-  *staged_left = &l->d2h_staged_left;
-  *slow_run = &l->d2h_slow_run;
-}
+int* lane_d2h_slow_run() { return &tl_lanes.get(tl_device < 0 ? 0 : tl_device)->d2h_slow_run; }
 
 static int env_int(const char* name, int dflt) {
   const char* e = getenv(name);
