@@ -116,6 +116,32 @@ def test_msm_planner_invariants(hip):
         B.msm_plan(7, 100)
 
 
+def test_msm_planner_balanced_windows(hip):
+    """Round 5 (msm_impl.hpp choose_windows), host-only through csh_msm_plan: the balanced plan keeps the tuned uniform plan's NUMBER of
+    windows and spreads bits + 1 bits evenly over them -- W (c - 1) < bits + 1 <= W c, so no window is left with a few bits on top -- with
+    c never above the uniform width; msm_balanced = 0 gives the uniform plan back; a forced W (msm_w) is honoured inside its range."""
+    B = hip.bindings
+    bits = {0: 254, 1: 255, 2: 254}
+    for curve in (0, 1, 2):
+        total = bits[curve] + 1
+        for n in (1, 300, 1 << 10, 5000, 1 << 13, 1 << 14, 1 << 15, 1 << 16, 70001, 1 << 17, 1 << 18, 1 << 19, 1 << 20, 1 << 22, 1 << 24):
+            with hip.tuned(msm_balanced=0):
+                cu, wu = B.msm_plan(curve, n)[:2]
+            c, w = B.msm_plan(curve, n)[:2]
+            assert wu == -(-total // cu)                                     # the uniform plan: W = ceil((bits + 1) / c)
+            assert w == wu and c <= cu and w * (c - 1) < total <= w * c, (curve, n, c, w, cu, wu)
+            assert c == -(-total // w)
+        for fw in (16, 17, 23, 40, 85, 127):
+            with hip.tuned(msm_w=fw):
+                c, w = B.msm_plan(curve, 1 << 16)[:2]
+            assert w == fw and c == -(-total // fw) and c >= 3
+        with hip.tuned(msm_w=15):                                            # below ceil((bits + 1) / 16): c would exceed 16 -- ignored
+            assert B.msm_plan(curve, 1 << 16)[1] != 15
+        with hip.tuned(msm_c=12):                                            # a forced width means the uniform form
+            c, w = B.msm_plan(curve, 1 << 16)[:2]
+            assert c == 12 and w == -(-total // 12)
+
+
 def test_product_does_not_import_the_oracle():
     """Static check: nothing under co-snarks_amd/ references oracle/ (the oracle is test infrastructure only)."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
