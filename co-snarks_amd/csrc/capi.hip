@@ -107,10 +107,12 @@ struct CopierPool {
       }
       (*j.fn)();
       {
+        // the notification goes out UNDER the caller's mutex: once it is released the caller may return from run() and its mutex,
+        // condition variable and counter (all on its stack) are gone -- nothing of the job is touched after this block
         std::lock_guard<std::mutex> g(*j.done_mu);
         j.pending->fetch_sub(1, std::memory_order_acq_rel);
+        j.done_cv->notify_one();
       }
-      j.done_cv->notify_one();
     }
   }
   void run(int helpers, std::function<void()> fn) {
