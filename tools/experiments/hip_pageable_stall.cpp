@@ -14,10 +14,42 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <string>
 #include <vector>
+#include <sys/resource.h>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s failed: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 __global__ void k_touch(unsigned long long* p, size_t n) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = p[i] * 6364136223846793005ull + 1;
+}
+// STALL_VMSTAT=1: /proc/vmstat and the thread's context-switch counts around every witness upload; the non-zero deltas of uploads slower
+// than 5 ms (and of the first fast one, for contrast) are printed
+static std::map<std::string, long long> vmstat() {
+  std::map<std::string, long long> m;
+  if (FILE* f = fopen("/proc/vmstat", "r")) {
+    char k[128];
+    long long v;
+    while (fscanf(f, "%127s %lld", k, &v) == 2) m[k] = v;
+    fclose(f);
+  }
+  rusage ru;
+  if (getrusage(RUSAGE_THREAD, &ru) == 0) {
+    m["thread_voluntary_ctx_switches"] = ru.ru_nvcsw;
+    m["thread_involuntary_ctx_switches"] = ru.ru_nivcsw;
+    m["thread_minor_faults"] = ru.ru_minflt;
+    m["thread_user_us"] = ru.ru_utime.tv_sec * 1000000LL + ru.ru_utime.tv_usec;
+    m["thread_sys_us"] = ru.ru_stime.tv_sec * 1000000LL + ru.ru_stime.tv_usec;
+  }
+  return m;
+}
+static void print_delta(const char* tag, double t_ms, const std::map<std::string, long long>& a, const std::map<std::string, long long>& b) {
+  printf("  [%s upload %.2f ms]", tag, t_ms);
+  for (auto& kv : b) {
+    auto it = a.find(kv.first);
+    const long long d = kv.second - (it == a.end() ? 0 : it->second);
+    if (d != 0 && kv.first.rfind("nr_", 0) != 0) printf(" %s=%+lld", kv.first.c_str(), d);
+  }
+  printf("\n");
 }
 static double ms(std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
 int main(int argc, char** argv) {
@@ -42,7 +74,11 @@ int main(int argc, char** argv) {
     char* wit = (char*)malloc(W);
     memset(wit, 7, W);
     std::vector<double> up, down, reup;
+    const bool vm = getenv("STALL_VMSTAT") != nullptr;
+    bool fast_shown = false;
     for (int it = 0; it < iters; ++it) {
+      std::map<std::string, long long> v0;
+      if (vm) v0 = vmstat();
       auto t0 = std::chrono::steady_clock::now();
       if (mode == 3) {
         memcpy(pinned, wit, W);
@@ -52,6 +88,11 @@ int main(int argc, char** argv) {
       }
       CK(hipStreamSynchronize(st));
       up.push_back(ms(t0));
+      if (vm) {
+        const auto v1 = vmstat();
+        if (up.back() > 5.0) print_delta("SLOW", up.back(), v0, v1);
+        else if (!fast_shown) { print_delta("fast", up.back(), v0, v1); fast_shown = true; }
+      }
       hipLaunchKernelGGL(k_touch, dim3(1024), dim3(256), 0, st, (unsigned long long*)dw, W / 8);
       CK(hipMemcpyAsync(dh, dw, W, hipMemcpyDeviceToDevice, st));
       char* h = mode == 1 ? reused : (char*)malloc(W + 1);  // mode 0 / 2: never touched before the copy, as a Vec::with_capacity result is
