@@ -195,7 +195,7 @@ HostXfer::~HostXfer() {
 // sizes) the host-facing witness map took 12-24 ms instead of 2.4 in steps of ~10 ms while every device-resident path ran at
 // its usual speed, i.e. the stall sits in the driver's handling of freshly populated caller pages.
 int HostXfer::d2h(void* host, const void* dev, size_t bytes, hipStream_t st) {
-  // tune "host_d2h": 0 = always direct, 1 = always staged, 2 (default) = direct, timed; two copies in a row on one lane that take more than
+  // tune "host_d2h": 0 = always direct, 1 (default since round 5) = always staged, 2 = direct, timed; two copies in a row on one lane that take more than
   // three times their PCIe time + 4 ms send every large transfer of the PROCESS (both directions, see g_stage_all_left) through the staged
   // paths for a spell, after which a direct copy is tried again.
   int* slow_run = lane_d2h_slow_run();
@@ -359,7 +359,7 @@ int* lane_d2h_slow_run() { return &tl_lanes.get(tl_device < 0 ? 0 : tl_device)->
 
 static int env_int(const char* name, int dflt) {
   const char* e = getenv(name);
-  return (e && *e) ? atoi(e) : dflt;
+  return (e && *e) ? (int)strtol(e, nullptr, 0) : dflt;  // decimal, 0x.. or 0.. as the caller writes it
 }
 struct TuneEntry { const char* key; const char* env; std::atomic<int> Tune::*field; };
 static const TuneEntry kTune[] = {
@@ -388,6 +388,8 @@ static const TuneEntry kTune[] = {
     {"ntt_threads", "CSH_NTT_THREADS", &Tune::ntt_threads},
     {"msm_variant", "CSH_MSM_VARIANT", &Tune::msm_variant},
     {"msm_seg_buckets", "CSH_MSM_SEG_BUCKETS", &Tune::msm_seg_buckets},
+    {"msm_wide_lb", "CSH_MSM_WIDE_LB", &Tune::msm_wide_lb},
+    {"msm_wide_chunks", "CSH_MSM_WIDE_CHUNKS", &Tune::msm_wide_chunks},
     {"allow_unmasked_rep3", "CSH_ALLOW_UNMASKED_REP3", &Tune::allow_unmasked_rep3},
     {"ntt_variant", "CSH_NTT_VARIANT", &Tune::ntt_variant},
     {"h_unfused", "CSH_H_UNFUSED", &Tune::h_unfused},
@@ -406,7 +408,14 @@ static const TuneEntry kTune[] = {
 Tune& tune() {
   static Tune* t = [] {
     Tune* x = new Tune();
-    for (const TuneEntry& e : kTune) (x->*(e.field)).store(env_int(e.env, (x->*(e.field)).load()));
+    for (const TuneEntry& e : kTune) {
+      int v = env_int(e.env, (x->*(e.field)).load());
+      // no result-changing knob is readable from the environment (an inherited variable must not make a prover emit invalid proofs):
+      // the experiment bits of ntt_variant are dropped, allow_unmasked_rep3 is never taken from it
+      if (!kExperiments && e.field == &Tune::ntt_variant) v &= ~NTT_VARIANT_EXPERIMENT_BITS;
+      if (e.field == &Tune::allow_unmasked_rep3) v = 0;
+      (x->*(e.field)).store(v);
+    }
     return x;
   }();
   return *t;
@@ -603,6 +612,11 @@ int csh_tune_set(const char* key, int value) {
   CSH_REQUIRE(key, "key is NULL");
   for (const TuneEntry& e : kTune)
     if (!strcmp(e.key, key)) {
+      if (!kExperiments && ((e.field == &Tune::ntt_variant && (value & NTT_VARIANT_EXPERIMENT_BITS) != 0) ||
+                            (e.field == &Tune::allow_unmasked_rep3 && value != 0))) {
+        set_error("csh_tune_set: '%s' = %d selects a timing experiment that returns wrong results; it only exists in builds with -DCSH_EXPERIMENTS", key, value);
+        return CSH_ERR_INVALID;
+      }
       (tune().*(e.field)).store(value);
       return CSH_OK;
     }

@@ -170,6 +170,8 @@ struct Tune {
   std::atomic<int> ntt_lazy{1};
   std::atomic<int> ntt_threads{1024};
   std::atomic<int> msm_variant{0};       // experimental kernel variants (A/B runs)
+  std::atomic<int> msm_wide_lb{0};       // wide sort (msm_sort_wide.hip): log2 buckets per level-2 partition, 8 .. 11 (0 = default)
+  std::atomic<int> msm_wide_chunks{0};   // wide sort: level-1 blocks aimed at (0 = default 1024)
   std::atomic<int> msm_seg_buckets{0};   // buckets per window-reduction segment (0 = as many segments as fit one round)
   std::atomic<int> allow_unmasked_rep3{0};  // Rep3 products without the re-randomising masks: refused unless set (tests)
   std::atomic<int> ntt_variant{0};
@@ -185,12 +187,24 @@ Tune& tune();
 // A Rep3 local multiplication without its correlated mask is not a valid sharing step: once opened, the products leak
 // cross terms (rep3/arithmetic.rs:132-146 always adds masking_field_elements_vec). NULL masks / seeds are therefore an
 // error unless the caller has opted in explicitly with csh_tune_set("allow_unmasked_rep3", 1) (unit tests of the arithmetic).
+// Round 6: the override only exists in builds with -DCSH_EXPERIMENTS (never the product build of build.py).
 inline int require_rep3_masks(bool have_masks, const char* what) {
-  if (have_masks || tune().allow_unmasked_rep3.load(std::memory_order_relaxed)) return CSH_OK;
-  set_error("%s: Rep3 (protocol 1) needs its masks / ChaCha12 seeds; unmasked products leak cross terms when opened "
-            "(csh_tune_set(\"allow_unmasked_rep3\", 1) overrides this for tests)", what);
+  if (have_masks) return CSH_OK;
+#ifdef CSH_EXPERIMENTS
+  if (tune().allow_unmasked_rep3.load(std::memory_order_relaxed)) return CSH_OK;
+#endif
+  set_error("%s: Rep3 (protocol 1) needs its masks / ChaCha12 seeds; unmasked products leak cross terms when opened", what);
   return CSH_ERR_INVALID;
 }
+
+// Knob values that make a kernel skip work (timing experiments: WRONG RESULTS). They exist only in builds with -DCSH_EXPERIMENTS;
+// the product library refuses them in csh_tune_set and never reads them from the environment.
+constexpr int NTT_VARIANT_EXPERIMENT_BITS = 0x3000 | 0xF0000;  // bits 12-13: run one pass of the plan; bits 16-19: skip butterflies / loads / stores / canonicalisation
+#ifdef CSH_EXPERIMENTS
+constexpr bool kExperiments = true;
+#else
+constexpr bool kExperiments = false;
+#endif
 
 inline int grid_for(size_t n, int block, int max_blocks = 256 * 16) {
   size_t g = (n + block - 1) / block;

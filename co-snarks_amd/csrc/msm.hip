@@ -315,7 +315,8 @@ static int bases_precompute(csh_bases_t bases, int c, int groups) {
   CSH_REQUIRE(bases, "bases is NULL");
   CSH_TRY(ensure_device());
   Bases* B = reinterpret_cast<Bases*>(bases);
-  CSH_REQUIRE(c == 0 || (c >= 4 && c <= 16), "window width must be 0 (auto) or in [4, 16]");
+  CSH_REQUIRE(c == 0 || (c >= 4 && c <= 22), "window width must be 0 (auto) or in [4, 22]");
+  CSH_REQUIRE(c <= 16 || groups == 0, "windows wider than 16 bits need one table row per window (csh_bases_precompute)");
   if (B->table) {
     (void)hipFree(B->table);
     B->table = nullptr;
@@ -488,7 +489,7 @@ int csh_msm_multi_dev(const csh_bases_t* bases, const size_t* offsets, size_t k,
   // codes; otherwise one sort serves all
   // two bucket-stage scratch regions: consecutive bucket stages alternate between the caller's stream and a second one, so
   // the latency-bound bucket reduction of MSM i overlaps the throughput-bound accumulation of MSM i + 1
-  CSH_TRY(ar.reserve(msm_sort_bytes(p) + 2 * Arena::padded(bucket_max)));
+  CSH_TRY(ar.reserve(msm_sort_bytes(p, pdig) + 2 * Arena::padded(bucket_max)));
   Arena& wa = arena_for((hipStream_t)((uintptr_t)st ^ 0x2));
   CSH_TRY(wa.reserve(win_bytes));
   auto sort_stage = [&](const MsmParams& ps, SortOut* so) -> int {

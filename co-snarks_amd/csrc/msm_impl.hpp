@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "common.hpp"
 #include "curve.hpp"
@@ -14,6 +15,7 @@
 #include "host_fp64.hpp"
 #include "msm_digits.hpp"
 #include "msm_sort.hpp"
+#include "msm_sort_wide.hpp"
 
 
 namespace csh {
@@ -845,7 +847,15 @@ struct SortOut {  // what the bucket stage consumes
   uint32_t *start, *nlanes, *sorted;
 };
 
-inline size_t msm_sort_bytes(const MsmParams& p) {
+// a merged plan with ONE bucket set and a window wider than the 16-bit digit codes of the plain sort stage: msm_sort_wide.hip
+inline bool msm_sort_is_wide(const MsmParams& p) { return p.c > 16 && p.W == 1 && p.remap_n != 0; }
+template <class Fr>
+constexpr int fr_id_of() {
+  return std::is_same<Fr, Bls381Fr>::value ? 1 : (std::is_same<Fr, Bn254Fq>::value ? 2 : 0);
+}
+
+inline size_t msm_sort_bytes(const MsmParams& p, const MsmParams& pdig) {
+  if (msm_sort_is_wide(p)) return msm_sort_wide_bytes(p, pdig);
   const size_t len = (size_t)p.NB + 2, n = p.n;
   size_t need = 0;
   need += 2 * Arena::padded(sizeof(uint32_t) * len * p.W);       // hist/cursor, start
@@ -896,6 +906,7 @@ int msm_sort_prepare(const MsmParams& p, const MsmParams& pdig, const uint64_t* 
 }
 template <class Fr>
 int msm_sort_stage(const MsmParams& p, const MsmParams& pdig, const uint64_t* scalars_dev, hipStream_t st, Arena& ar, SortOut* out, hipEvent_t* ev) {
+  if (msm_sort_is_wide(p)) return msm_sort_wide_launch(fr_id_of<Fr>(), p, pdig, scalars_dev, st, ar, &out->start, &out->nlanes, &out->sorted, ev);
   SortStageBufs ss;
   CSH_TRY(msm_sort_prepare<Fr>(p, pdig, scalars_dev, st, ar, &ss));
   CSH_TRY(msm_sort_launch(p, ss.sb, st, ev));
@@ -1117,7 +1128,7 @@ int msm_windows_dev(const Bases* B, size_t offset, size_t n, const uint64_t* sca
   }
   *p_out = p;  // merged: W = 1 (the single window sum is the result)
   Arena& ar = arena_for(st);
-  CSH_TRY(ar.reserve(msm_sort_bytes(p) + msm_bucket_bytes<Cfg>(&p)));
+  CSH_TRY(ar.reserve(msm_sort_bytes(p, pdig) + msm_bucket_bytes<Cfg>(&p)));
   const bool timing = tune().msm_timing.load(std::memory_order_relaxed) != 0;
   hipEvent_t ev[7];
   if (timing) {

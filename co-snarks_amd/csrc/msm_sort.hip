@@ -17,33 +17,6 @@ __device__ __forceinline__ uint32_t entry_id(const MsmParams& p, size_t i) {
   return w * p.remap_stride + p.remap_off + (f - w * p.remap_n);
 }
 
-// Wave-aggregated LDS counter increment: returns this lane's slot in counter[b] (old value + rank).
-// Lanes that share the wave leader's bucket are peeled off with one atomic per group (up to 4 rounds), so a
-// skewed digit distribution (top window, 0/1-heavy witnesses) does not serialise on one LDS address.
-__device__ __forceinline__ uint32_t lds_slot(uint32_t* counter, uint32_t b, bool valid) {
-  uint32_t slot = 0;
-  bool todo = valid;
-  for (int round = 0; round < 4; ++round) {
-    const unsigned long long act = __ballot(todo);
-    if (!act) return slot;
-    const int leader = __ffsll((long long)act) - 1;
-    const uint32_t lb = (uint32_t)__shfl((int)b, leader);
-    const unsigned long long grp = __ballot(todo && b == lb);
-    const int cnt = __popcll(grp);
-    if (cnt < 8) break;  // wave-uniform: not worth peeling, fall through to per-lane atomics
-    uint32_t base = 0;
-    const int lane = threadIdx.x & 63;
-    if (lane == leader) base = atomicAdd(&counter[lb], (uint32_t)cnt);
-    base = (uint32_t)__shfl((int)base, leader);
-    if (todo && b == lb) {
-      slot = base + (uint32_t)__popcll(grp & ((1ull << lane) - 1ull));
-      todo = false;
-    }
-  }
-  if (todo) slot = atomicAdd(&counter[b], 1u);
-  return slot;
-}
-
 // Block (chunk ch, window w): LDS histogram of the chunk's digits -> blkcnt[w][ch][0..NB)
 __global__ __launch_bounds__(SORT_BLK) void k_msm_hist_lds(MsmParams p, const uint16_t* __restrict__ dig, uint32_t* __restrict__ blkcnt,
                                                             uint32_t* __restrict__ part_cnt /* two-level mode: [w][ch][NB/256], else NULL */) {

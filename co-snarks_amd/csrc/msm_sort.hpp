@@ -55,6 +55,35 @@ struct SortBuffers {
   uint32_t* part_cnt;  // [W][CH][NB/256] scratch (two-level mode only)
 };
 
+#if defined(__HIPCC__)
+// Wave-aggregated LDS counter increment: returns this lane's slot in counter[b] (old value + rank).
+// Lanes that share the wave leader's bucket are peeled off with one atomic per group (up to 4 rounds), so a
+// skewed digit distribution (top window, 0/1-heavy witnesses) does not serialise on one LDS address.
+__device__ __forceinline__ uint32_t lds_slot(uint32_t* counter, uint32_t b, bool valid) {
+  uint32_t slot = 0;
+  bool todo = valid;
+  for (int round = 0; round < 4; ++round) {
+    const unsigned long long act = __ballot(todo);
+    if (!act) return slot;
+    const int leader = __ffsll((long long)act) - 1;
+    const uint32_t lb = (uint32_t)__shfl((int)b, leader);
+    const unsigned long long grp = __ballot(todo && b == lb);
+    const int cnt = __popcll(grp);
+    if (cnt < 8) break;  // wave-uniform: not worth peeling, fall through to per-lane atomics
+    uint32_t base = 0;
+    const int lane = threadIdx.x & 63;
+    if (lane == leader) base = atomicAdd(&counter[lb], (uint32_t)cnt);
+    base = (uint32_t)__shfl((int)base, leader);
+    if (todo && b == lb) {
+      slot = base + (uint32_t)__popcll(grp & ((1ull << lane) - 1ull));
+      todo = false;
+    }
+  }
+  if (todo) slot = atomicAdd(&counter[b], 1u);
+  return slot;
+}
+#endif
+
 bool msm_sort_two_level(const MsmParams& p);
 size_t msm_sort_extra_bytes(const MsmParams& p);  // arena bytes for inter + part_cnt (0 in single-level mode)
 // Launches hist -> colscan -> scan -> scatter on `st`. ev (nullable): records ev[1] after the histogram, ev[2] after

@@ -241,7 +241,7 @@ __global__ __launch_bounds__(NTT_MAX_THREADS) __attribute__((amdgpu_waves_per_eu
       const int e0 = (t0 << cc_log) | cc;
       const int e1 = e0 + (half << cc_log);
       const size_t imod = ((size_t)t_lo << s0) | (mid << cb) | (size_t)(cc >> ncomp_log);
-#ifdef CSH_NTT_ABLATE_TW  // ablation builds only (tools/experiments/gpu_r3_h.sh): one of 64 table entries -- wrong results, no gather
+#if defined(CSH_EXPERIMENTS) && defined(CSH_NTT_ABLATE_TW)  // ablation builds only (tools/experiments/gpu_r3_h.sh): one of 64 table entries -- wrong results, no gather
       const LZ w = load_sliced_twiddle<F, LZ>(twl, imod & 63, (size_t(1) << L) - 1);
 #else
       const LZ w = load_sliced_twiddle<F, LZ>(twl, stage_base + imod, (size_t(1) << L) - 1);  // staged table: stage s0 + q starts at 2^(s0 + q) - 1
@@ -260,13 +260,13 @@ __global__ __launch_bounds__(NTT_MAX_THREADS) __attribute__((amdgpu_waves_per_eu
       }
       if (DIF) {
         lds.put(e0, LZ::add(u, v).fold_top());   // sums feed sums here: keep the value within (-p, 2p) every stage
-#ifdef CSH_NTT_ABLATE_MUL
+#if defined(CSH_EXPERIMENTS) && defined(CSH_NTT_ABLATE_MUL)
         lds.put(e1, LZ::add(LZ::sub(u, v), w));
 #else
         lds.put(e1, LZ::mul(LZ::sub(u, v), w));  // the two-term difference is an admissible product operand as is
 #endif
       } else {
-#ifdef CSH_NTT_ABLATE_MUL  // ablation builds only: no multiplication (wrong results): the memory / LDS / barrier floor of the pass
+#if defined(CSH_EXPERIMENTS) && defined(CSH_NTT_ABLATE_MUL)  // ablation builds only: no multiplication (wrong results): the memory / LDS / barrier floor of the pass
         const LZ x = LZ::add(v, w);
 #else
         const LZ x = LZ::mul(v, w);
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const int NT = blockDim.x;
   // timing experiments only (tune "ntt_variant" bits 16-19, wrong results): 1 = no butterfly rounds, 2 = no global loads, 4 = no stores,
   // 8 = no canonicalisation before the store
-  const int ablate = (do_scale >> 8) & 0xf;
+  const int ablate = kExperiments ? (do_scale >> 8) & 0xf : 0;  // product builds: constant 0, the branches below fold away
   const bool unit_skip = !(do_scale & 0x2000);  // tune "ntt_variant" bit 20 switches the unit-twiddle rounds off (A/B runs)
   do_scale &= 1;
 
@@ -735,7 +735,7 @@ static int run_ntt(const Domain* d, F* data, uint32_t ncomp, bool dif, hipStream
     const int v = tune().ntt_threads.load(std::memory_order_relaxed);  // 16 waves per 2^11-element tile: measured best for both field representations
     return (v == 256 || v == 512 || v == 1024) ? v : 1024;
   }();
-  const int only_pass = (tune().ntt_variant.load(std::memory_order_relaxed) >> 12) & 3;  // timing experiments: run ONE pass of the plan (wrong results)
+  const int only_pass = kExperiments ? (tune().ntt_variant.load(std::memory_order_relaxed) >> 12) & 3 : 0;  // timing experiments (-DCSH_EXPERIMENTS only): run ONE pass of the plan (wrong results)
   for (int pi = 0; pi < np; ++pi) {
     const Pass& p = dif ? passes[np - 1 - pi] : passes[pi];
     if (only_pass && (dif ? np - 1 - pi : pi) != only_pass - 1) continue;

@@ -247,3 +247,30 @@ def test_rust_sys_crate_covers_every_header_symbol():
     assert have == set(bindings.declared_symbols())
     for f in ("lib.rs", "drivers.rs", "hip_reduction.rs", "layout.rs", "bases.rs", "domain.rs", "split.rs", "error.rs"):
         assert os.path.exists(os.path.join(ROOT, "rust", "co-groth16-hip", "src", f)), f
+
+
+def test_experiment_knobs_are_not_in_the_product_library():
+    """knob values documented as "wrong results" (ntt_variant bits 12-13 and 16-19: skipped passes / butterflies / loads /
+    stores; allow_unmasked_rep3) exist only in builds with -DCSH_EXPERIMENTS. The product library drops them from the environment and
+    refuses them in csh_tune_set; the harmless A/B bits of the same knob still work."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import cosnarks_amd as hip\n"
+        "from cosnarks_amd import bindings as B\n"
+        "assert B.tune_get('ntt_variant') == 0x800, hex(B.tune_get('ntt_variant'))\n"
+        "assert B.tune_get('allow_unmasked_rep3') == 0\n"
+        "for key, v in (('ntt_variant', 0x10000), ('ntt_variant', 0x1000), ('ntt_variant', 0x2800), ('allow_unmasked_rep3', 1)):\n"
+        "    try:\n"
+        "        B.tune_set(key, v)\n"
+        "    except hip.CoSnarksHipError as e:\n"
+        "        assert 'CSH_EXPERIMENTS' in str(e), e\n"
+        "    else:\n"
+        "        raise SystemExit('accepted %s=%#x' % (key, v))\n"
+        "B.tune_set('ntt_variant', 0x100001)\n"
+        "assert B.tune_get('ntt_variant') == 0x100001\n"
+        "print('ok')\n")
+    env = dict(os.environ, CSH_NTT_VARIANT="0x10800", CSH_ALLOW_UNMASKED_REP3="1", PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=root, timeout=120)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout, r.stderr)

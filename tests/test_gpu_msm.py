@@ -433,6 +433,37 @@ def test_msm_fixed_base_tables(gpu, curve, group):
         bases.free()
 
 
+@pytest.mark.parametrize("curve,group", GROUPS)
+def test_msm_wide_window_tables(gpu, curve, group):
+    """Fixed-base tables with ONE bucket set and windows of 17 .. 22 bits (csh_bases_precompute with c > 16: msm_sort_wide.hip, 2^16 ..
+    2^21 buckets, 32-bit digit keys sorted in two levels): full, prefix-with-offset, skewed (0 / 1 / -1-heavy) and canonical scalars equal
+    the oracle for every partition width of the second level (tune msm_wide_lb) and both record sizes (msm_variant bit 3)."""
+    G = cv.CURVES[curve][group]
+    F = H.FR[curve]
+    cid = H.CURVE_IDS[curve]
+    r = H.rng(777 + group)
+    n = 1300
+    pts = H.rand_points(G, n, r, with_inf=True)
+    sc = H.rand_elems(F, n, r)
+    sk = [1] * 300 + [F.p - 1] * 300 + [0] * 100 + H.rand_elems(F, n - 700, r)
+    want_full, want_sk = G.msm(pts, sc), G.msm(pts, sk)
+    want_off = G.msm(pts[37:37 + 900], sc[:900])
+    try:
+        for c, lb, variant in ((17, 0, 0), (19, 9, 0), (20, 11, 8), (22, 10, 0), (22, 0, 8)):
+            bases = gpu.Bases(cid, group, cv.pack_points(G, pts)).precompute(c, 0)
+            gpu.bindings.tune_set("msm_wide_lb", lb)
+            gpu.bindings.tune_set("msm_variant", variant)
+            assert G.eq(H.jac_to_affine(G, bases.msm(H.pack(F, sc))), want_full), c
+            assert gpu.bindings.msm_last_params()[:2] == [c, 1], "the wide single-bucket-set plan must be the one that ran"
+            assert G.eq(H.jac_to_affine(G, bases.msm(H.pack(F, sk))), want_sk), c
+            assert G.eq(H.jac_to_affine(G, bases.msm(H.pack(F, sc[:900]), offset=37, n=900)), want_off), c
+            assert G.eq(H.jac_to_affine(G, bases.msm(H.pack(F, sc, mont=False), montgomery=False)), want_full), c
+            bases.free()
+    finally:
+        gpu.bindings.tune_set("msm_wide_lb", 0)
+        gpu.bindings.tune_set("msm_variant", 0)
+
+
 def test_msm_fixed_base_tables_closed_form_and_multi(gpu):
     """2^20 known-dlog bases with tables: closed form; the shared-sort multi-MSM over handles with tables (mixed G1 / G2,
     different offsets) equals the oracle."""
@@ -450,7 +481,7 @@ def test_msm_fixed_base_tables_closed_form_and_multi(gpu):
     limbs = rs.randint(0, 1 << 63, size=(n, 4), dtype=np.uint64)
     limbs[:, 3] >>= np.uint64(3)
     want = closed_form_point("bn254", 0, seed, n, limbs, True)
-    for c, groups in ((0, 0), (15, 2), (16, 4)):
+    for c, groups in ((0, 0), (15, 2), (16, 4), (18, 0), (20, 0)):
         if groups:
             gpu.bindings._check(L.csh_bases_precompute_grouped(h, c, groups))
         else:
@@ -467,8 +498,8 @@ def test_msm_fixed_base_tables_closed_form_and_multi(gpu):
     sets = [(G1, 0, H.rand_points(G1, m + 3, r), 3), (G1, 0, H.rand_points(G1, m + 3, r), 3), (G2, 1, H.rand_points(G2, m + 3, r), 3),
             (G1, 0, H.rand_points(G1, m, r), 0)]
     sc = H.rand_elems(F, m, r)
-    for groups in (2, 0):
-        handles = [gpu.Bases(0, g, cv.pack_points(Gx, pts)).precompute(0, groups) for Gx, g, pts, _ in sets]
+    for c, groups in ((0, 2), (0, 0), (18, 0)):   # (18, 0): one bucket set of 2^17 buckets, the wide sort stage shared by the four MSMs
+        handles = [gpu.Bases(0, g, cv.pack_points(Gx, pts)).precompute(c, groups) for Gx, g, pts, _ in sets]
         _multi_over_tables(gpu, sets, handles, sc, m)
         for x in handles:
             x.free()

@@ -37,11 +37,12 @@ def test_rep3_ops(gpu, curve, n):
     masks = H.rand_elems(F, n, r)
     pl, pr, pm = H.pack_shares(F, lhs), H.pack_shares(F, rhs), H.pack(F, masks)
     assert H.unpack(F, gpu.rep3_local_mul_vec(cid, pl, pr, pm)) == mpc.rep3_local_mul_vec(F, lhs, rhs, masks)
-    if n:   # an unmasked Rep3 product is refused (it leaks cross terms once opened) unless explicitly allowed
+    if n:   # an unmasked Rep3 product is refused (it leaks cross terms once opened); the product build has no override (round 6)
         with pytest.raises(gpu.CoSnarksHipError, match="needs its masks"):
             gpu.rep3_local_mul_vec(cid, pl, pr, None)
-    with gpu.tuned(allow_unmasked_rep3=1):
-        assert H.unpack(F, gpu.rep3_local_mul_vec(cid, pl, pr, None)) == mpc.rep3_local_mul_vec(F, lhs, rhs, [0] * n)
+        with pytest.raises(gpu.CoSnarksHipError, match="CSH_EXPERIMENTS"):
+            gpu.bindings.tune_set("allow_unmasked_rep3", 1)
+    assert H.unpack(F, gpu.rep3_local_mul_vec(cid, pl, pr, H.pack(F, [0] * n))) == mpc.rep3_local_mul_vec(F, lhs, rhs, [0] * n)
     tbl = H.rand_elems(F, n, r)
     got = H.unpack_shares(F, gpu.vec_mul_table(cid, pl, H.pack(F, tbl), ncomp=2))
     assert got == [mpc.rep3_mul_public(F, s, t) for s, t in zip(lhs, tbl)]
@@ -244,3 +245,32 @@ def test_ntt_32bit_pass_rebuilds_its_tables_on_demand(gpu, curve):
             assert H.unpack(F, dg.ifft_in_to_out(pv)) == want_i
             assert H.unpack(F, dg.fft_out_to_in(pv)) == want_f
         assert H.unpack(F, dg.fft_out_to_in(pv)) == want_f
+
+
+def test_inherited_experiment_environment_cannot_change_a_transform(gpu):
+    """with CSH_NTT_VARIANT carrying the "skip the butterflies" / "run one pass" experiment bits in the environment the
+    product library still returns the oracle's transform (the bits are dropped at load; radix-4 and radix-2 pass forms, 2^12 and 2^20)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import random\n"
+        "import cosnarks_amd as hip\n"
+        "from oracle import fields as fl, ntt\n"
+        "from oracle import cbridge\n"
+        "from tests import helpers as H\n"
+        "F = fl.BN254_FR\n"
+        "r = random.Random(5)\n"
+        "for logn in (12, 20):\n"
+        "    gen = ntt.roots_of_unity(F)[1][logn]\n"
+        "    dg = hip.Domain(hip.BN254, logn, H.pack(F, [gen]))\n"
+        "    import numpy as np\n"
+        "    v = np.random.RandomState(logn).randint(0, 1 << 62, size=(1 << logn, 4), dtype=np.uint64)\n"
+        "    v[:, 3] >>= np.uint64(3)\n"
+        "    want = cbridge.ntt(0, v, logn, H.pack(F, [gen]), dif=True)\n"
+        "    assert np.array_equal(np.asarray(dg.ifft_in_to_out(v)).reshape(-1), np.asarray(want).reshape(-1)), logn\n"
+        "print('ok')\n")
+    env = dict(os.environ, CSH_NTT_VARIANT="0x11000", PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=root, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
