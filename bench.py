@@ -147,6 +147,8 @@ class Ctx:
         self.comm = None
         self.hard_exit = False   # set when csh_comm_init_rank timed out: a detached helper thread is still blocked inside ncclCommInitRank
         self.exchange = "single GPU"
+        self.exchange_mode = "none"       # "rccl" | "harness_gloo" | "none": what the timed steps of an N > 1 run actually used
+        self.rccl_ranks_seen = 0          # ranks of the RCCL communicator the library built (0: no communicator)
         if self.world > 1:
             self._make_comm(args)
 
@@ -174,11 +176,14 @@ class Ctx:
         flag = torch.tensor([ok if want_rccl else 0], dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 1:
+            self.exchange_mode = "rccl"
+            self.rccl_ranks_seen = self.world
             self.exchange = "csh_msm_split_rank_dev: RCCL ncclAllGather of window partials over xGMI, behind the C ABI"
         else:
             if self.comm is not None:
                 self.comm.destroy()
                 self.comm = None
+            self.exchange_mode = "harness_gloo"
             self.exchange = "csh_msm_partial_dev + harness all-gather (gloo) + csh_msm_fold_partials" + (f" [RCCL path unavailable: {err}]" if err else "")
 
     def barrier(self):
@@ -363,9 +368,14 @@ def msm_roofline(job: MsmJob, rin: dict, log_n_local: int):
     lv = [x for x in (live_probe(job.cx, 0, 2000), live_probe(job.cx, 8, 2000)) if x]
     if lv:   # forced v_mad_u64_u32 / v_mad_i64_i32 chains on this box, lane-ops/s
         mad_peak, mad_src = round(max(lv) / 1e12, 2), "csh_microbench on this box, this run (v_mad_u64_u32 / v_mad_i64_i32 chains; file value: %s T/s, %s)" % (rin.get("mad_peak_T"), rin.get("mad_peak_source"))
-    roof = {"bound": "hbm", "kernel": f"k_msm_accum<{kname}Cfg>", "achieved": round(achieved, 2), "peak": hbm_peak, "unit": "GB/s",
+    # `bound`: what bounds the kernel (the driver keeps the scalar fields of this object only, so the integer-issue figures
+    # are flattened into it below). achieved / peak / frac stay the HBM figures the contract asks for: algorithmic bytes per launch over
+    # the kernel's event time against 8 TB/s -- ~1 % by construction, the kernel is bound by v_mad_i64_i32 issue (alu_frac).
+    roof = {"bound": "valu_int_mad", "kernel": f"k_msm_accum<{kname}Cfg>", "achieved": round(achieved, 2), "peak": hbm_peak, "unit": "GB/s",
             "frac": round(achieved / hbm_peak, 5), "traffic": kin.get("traffic_bytes"), "traffic_source": kin.get("file"),
-            "algorithmic_bytes_per_launch": alg_bytes,
+            "algorithmic_bytes_per_launch": alg_bytes, "hbm_frac": round(achieved / hbm_peak, 5),
+            "accum_ms": round(stage_ms[3], 4), "c": c_bits, "windows": n_win, "lane_len": lane_len, "device_ms": round(stage_ms[5], 4),
+            "sort_ms": round(stage_ms[0] + stage_ms[1] + stage_ms[2], 4), "tail_ms": round(stage_ms[4], 4),
             "note": "the MSM is integer-ALU bound (v_mad_i64_i32 issue), not HBM bound, by construction (W mixed additions ~ 160 modmuls per 96 B); "
                     "see `alu` and DESIGN.md 3.1",
             "msm_params": {"c": c_bits, "windows": n_win, "lane_len": lane_len, "segments": n_seg},
@@ -380,6 +390,8 @@ def msm_roofline(job: MsmJob, rin: dict, log_n_local: int):
         nominal = 256 * 4 * 16 * 2.4e9 / 1e12
         roof["alu"]["peak_nominal"] = round(nominal, 1)
         roof["alu"]["frac_vs_nominal"] = round(a / nominal, 3)
+        roof.update({"alu_unit": "Tmad/s", "alu_achieved_Tmad": round(a, 2), "alu_peak_Tmad": mad_peak, "alu_frac": round(a / mad_peak, 3),
+                     "alu_peak_nominal_Tmad": round(nominal, 1), "alu_frac_vs_nominal": round(a / nominal, 3), "mads_per_madd": mads})
         if rin.get("mad_peak_T"):   # the constant of profiles/roofline_inputs.json (tools/gpu_probe.py: one cold pass per process), for continuity with earlier rounds
             roof["alu"]["peak_file"] = rin["mad_peak_T"]
             roof["alu"]["frac_vs_file"] = round(a / rin["mad_peak_T"], 3)
@@ -449,21 +461,32 @@ def secondary_single_gpu(cx: Ctx, rin: dict, args):
             cpu_inputs = (pts_host, job.sc.cpu().numpy().view(np.uint64), job.affine_words(res))
         job.free()
         del job
-    # the headline workload again with fixed-base tables on the handle (opt-in key-load precomputation, csh_bases_precompute_grouped:
-    # 2 rows = 2 x the bases in HBM; the headline itself runs on the plain handle, as the reference's msm_unchecked does)
-    try:
-        job = MsmJob(cx, "bn254_g1", 0, 1 << 20, 1234)
-        job.drop_point_copy()
-        B._check(L.csh_bases_precompute_grouped(job.h, 16, 2))
-        if args.spinup_s > 0:
-            job.spin_up(min_s=args.spinup_s)
-        dt, res = job.timed(20, 5)
-        out["msm_bn254_g1_2p20_fixed_base_tables"] = {"points_per_s": job.n * 20 / dt, "ms": dt / 20 * 1e3, "result_check": job.check(res),
-                                                      "table_rows": 2, "window_bits": 16}
-        job.free()
-        del job
-    except Exception as e:  # noqa: BLE001
-        out["msm_bn254_g1_2p20_fixed_base_tables"] = {"error": repr(e)}
+    # The headline workload and the 2^24 workload again with fixed-base tables on the handle, as a prover holds its key (round 6:
+    # csh_bases_table_policy -> one table row per window, ONE bucket set, 17- / 20-bit windows: 15 / 13 mixed additions per point instead of
+    # 17 / 16; msm_sort_wide.hip). The headline itself stays on the plain handle, as the reference's msm_unchecked is variable-base.
+    for logn, steps, key in ((20, 20, "msm_bn254_g1_2p20_fixed_base_tables"), (args.split_log_n, 5, f"msm_bn254_g1_2p{args.split_log_n}_fixed_base_tables")):
+        try:
+            job = MsmJob(cx, "bn254_g1", 0, 1 << logn, 1234 if logn == 20 else 4321 + logn)
+            job.drop_point_copy()
+            tc, rows = C.c_int(0), C.c_int(0)
+            B._check(L.csh_bases_table_policy(C.c_size_t(job.n), C.byref(tc), C.byref(rows)))
+            t0 = time.perf_counter()
+            B._check(L.csh_bases_precompute_grouped(job.h, tc.value, rows.value))
+            B.sync()
+            build_ms = (time.perf_counter() - t0) * 1e3
+            if args.spinup_s > 0:
+                job.spin_up(min_s=args.spinup_s, batch=10 if logn <= 20 else 3)
+            dt, res = job.timed(steps, 5 if logn <= 20 else 1)
+            stage_ms, (c_bits, n_win, lane_len, n_seg) = job.stage_timing(reps=3)
+            out[key] = {"points_per_s": job.n * steps / dt, "ms": dt / steps * 1e3, "result_check": job.check(res), "steps": steps,
+                        "window_bits": tc.value, "table_rows_asked": rows.value, "bucket_sets": n_win, "table_build_ms": round(build_ms, 1),
+                        "table_bytes": int(job.n) * 64 * (-(-255 // tc.value)),
+                        "stage_ms": {"sort_level1": stage_ms[0], "bucket_hist+scan": stage_ms[1], "sort_level2": stage_ms[2], "accum": stage_ms[3],
+                                     "merge+reduce+fold": stage_ms[4], "total_device": stage_ms[5]}}
+            job.free()
+            del job
+        except Exception as e:  # noqa: BLE001
+            out[key] = {"error": repr(e)}
     # The headline workload issued the way the reference issues its MSMs: two host threads, each calling the synchronous entry point back to
     # back (rayon_join5 in groth16.rs:227-294 runs the five MSM closures of one proof concurrently). Every thread has its own stream in
     # the library (NULL stream = the calling thread's lane), so one call's sort, bucket tail, result copy and host fold overlap the other's
@@ -838,6 +861,20 @@ def main():
                 g2_host = None
             cpu_baseline = cpu_baseline_suite(pts_host, sc_host, job.affine_words(res), p24, s24, a24, host_cpus=HOST_CPUS, pts20_g2=g2_host)
             cpu_baseline["gpu_over_cpu_2p20"] = round(value / cpu_baseline["value"], 1)
+            try:   # a CPU figure beside the GPU's wall ms on the reference's own circuits
+                from oracle.cbridge import groth16_reference_circuit_composition
+                ref = groth16_reference_circuit_composition(os.path.join(ROOT, "tests", "golden", "Groth16", "bn254"), threads=1, reps=20)
+                gpu_ref = (extras or {}).get("groth16_prove_reference_circuits") or {}
+                if gpu_ref:
+                    ref["gpu_wall_ms_beside_it"] = {k: gpu_ref.get(k) for k in ("plain_multiplier2_ms", "plain_poseidon_ms", "rep3_poseidon_3_parties_ms")}
+                    m2c, m2g = ref.get("plain_multiplier2_ms"), gpu_ref.get("plain_multiplier2_ms")
+                    if m2c and m2g:
+                        ref["note"] = ("multiplier2 (domain 4): GPU %.2f ms >= CPU %.2f ms -- at this size the prove is launch latency on the GPU and the CPU wins, as "
+                                       "SURVEY 8d config 1 expects; the GPU figures are whole proves (zkey parse + key upload + finish), the CPU figures the hot stages only"
+                                       % (m2g, m2c))
+                cpu_baseline["groth16_prove_reference_circuits"] = ref
+            except Exception as e:  # noqa: BLE001
+                cpu_baseline["groth16_prove_reference_circuits"] = {"error": repr(e)}
             if extras and "msm_2p24" in cpu_baseline and "msm_bn254_g1_2p24" in extras:
                 cpu_baseline["gpu_over_cpu_2p24"] = round(extras["msm_bn254_g1_2p24"]["points_per_s"] / cpu_baseline["msm_2p24"]["points_per_s"], 1)
         except Exception as e:  # the baseline is a reported extra, never part of the measured path
@@ -854,6 +891,7 @@ def main():
                                    + (" (BASELINE config 2)" if args.workload == "bn254_g1" and args.log_n == 20 else "")
                                    + (" (BASELINE config 5)" if args.workload.startswith("bls12_381") and args.log_n == 24 and args.scaling == "strong" else ""),
                        "points_total": total, "points_per_gpu": n_local, "split": cx.exchange,
+                       "exchange_mode": cx.exchange_mode, "rccl_ranks_seen": cx.rccl_ranks_seen,
                        "host_cpus": {"affinity_at_start": HOST_CPUS, "affinity_after_imports_before_restore": cx.affinity_after_imports,
                                      "affinity_measured_under": len(os.sched_getaffinity(0)) if AFFINITY0 is not None else None},
                        "spinup_steps": args.spinup + spin_steps,

@@ -286,14 +286,27 @@ int csh_bases_table_policy(size_t key_points, int* c_out, int* rows_out) {
   CSH_REQUIRE(c_out && rows_out, "c_out / rows_out is NULL");
   *c_out = 0;
   *rows_out = 0;
-  if (key_points < (size_t(1) << 14) || key_points > (size_t(1) << 21)) return CSH_OK;
-  int c = 16;
-  while (c > 10 && (size_t(1) << (c + 1)) > key_points) --c;
-  // up to 2^18 points one row per window pays (2^16 3.4 -> 3.2 ms, 2^18 5.4 -> 5.0 ms per proof, profiles/r02_g_prove_table_rows.log);
-  // above, 4 / 8 / 16 rows measure the same and 4 cost the least memory. (A 2^18-constraint key has 2^18 + a few wires.)
-  // (16 = "one row per window" at c = 16; with more windows the precompute clamps to the rows its W' = ceil(W / 16) references)
-  *c_out = c;
-  *rows_out = key_points <= (size_t(3) << 17) ? 16 : 4;
+  if (key_points < (size_t(1) << 14) || key_points > (size_t(1) << 26)) return CSH_OK;
+  if (key_points < (size_t(1) << 15)) {
+    // 2^14 .. 2^15: one row per window at c <= 16 (the plain sort stage); measured a tie with the plain handle (profiles/r06_f_policy_fullmerge_small.log)
+    int c = 16;
+    while (c > 10 && (size_t(1) << (c + 1)) > key_points) --c;
+    *c_out = c;
+    *rows_out = 16;
+    return CSH_OK;
+  }
+  // Round 6: ONE bucket set, one table row per window, windows wider than 16 bits (msm_sort_wide.hip). Interleaved with the plain handle
+  // and with every c = 12 .. 18 / 17 .. 22 on the same box (profiles/r06_e_policy_*.log, r06_f_policy_fullmerge_small.log): c = 17 is the
+  // best or within 1 % of it from 2^15 to 2^21 points (2^16 0.355 against 0.40 ms plain, 2^18 0.56 / 0.71, 2^20 +15 %, 2^21 +13 %), c = 20
+  // from 2^22 on (2^22 +10 %, 2^23 +12 %, 2^24 +15 .. 17 %; c = 22 has the fewest additions but its 2^21 buckets cost more tail and
+  // sort than they save). rows = "at least the windows of either scalar field": the precompute clamps to W = ceil((bits + 1) / c).
+  if (key_points <= (size_t(3) << 20)) {
+    *c_out = 17;
+    *rows_out = 16;
+  } else {
+    *c_out = 20;
+    *rows_out = 13;
+  }
   return CSH_OK;
 }
 int csh_bases_drop_tables(csh_bases_t bases) {
@@ -316,7 +329,6 @@ static int bases_precompute(csh_bases_t bases, int c, int groups) {
   CSH_TRY(ensure_device());
   Bases* B = reinterpret_cast<Bases*>(bases);
   CSH_REQUIRE(c == 0 || (c >= 4 && c <= 22), "window width must be 0 (auto) or in [4, 22]");
-  CSH_REQUIRE(c <= 16 || groups == 0, "windows wider than 16 bits need one table row per window (csh_bases_precompute)");
   if (B->table) {
     (void)hipFree(B->table);
     B->table = nullptr;
@@ -523,12 +535,28 @@ int csh_msm_multi_dev(const csh_bases_t* bases, const size_t* offsets, size_t k,
     }
     if (sorted_ev) (void)hipEventDestroy(sorted_ev);
   } else {
-    // handles that share (table stride, offset) share the sorted index list; a different pair needs its own scatter
+    // Handles that share (table stride, offset) share the sorted index list; a different pair needs its own scatter. Round 6: the bucket
+    // stages alternate between the caller's stream and the lane's second stream here too (each with its own scratch region), so the
+    // latency-bound bucket reduction of MSM i runs under the accumulation of MSM i + 1 -- with ONE bucket set per MSM the reduction is
+    // 0.2-0.4 ms of a 1.4 ms G1 MSM. A re-sort waits for the other stream's readers of the previous list.
+    const bool overlap = tune().msm_multi_overlap.load(std::memory_order_relaxed) != 0;
+    if (overlap && k > 1) aux = resolve_aux_stream();
+    const bool two = overlap && k > 1 && aux != nullptr;
     size_t last_stride = (size_t)-1, last_off = (size_t)-1;
     size_t mark = 0;
+    hipEvent_t sorted_ev = nullptr, aux_done = nullptr;
+    if (two) {
+      CSH_HIP(hipEventCreateWithFlags(&sorted_ev, hipEventDisableTiming));
+      CSH_HIP(hipEventCreateWithFlags(&aux_done, hipEventDisableTiming));
+    }
+    bool aux_used = false;
     for (size_t i = 0; i < k; ++i) {
       const Bases* B = reinterpret_cast<const Bases*>(bases[i]);
       if (B->n != last_stride || offsets[i] != last_off) {
+        if (two && aux_used) {  // bucket stages on the second stream still read the list this sort overwrites
+          CSH_HIP(hipEventRecord(aux_done, aux));
+          CSH_HIP(hipStreamWaitEvent(st, aux_done, 0));
+        }
         ar.off = 0;
         p.remap_stride = (uint32_t)B->n;
         p.remap_off = (uint32_t)offsets[i];
@@ -536,11 +564,20 @@ int csh_msm_multi_dev(const csh_bases_t* bases, const size_t* offsets, size_t k,
         mark = ar.off;
         last_stride = B->n;
         last_off = offsets[i];
+        if (two) {
+          CSH_HIP(hipEventRecord(sorted_ev, st));
+          CSH_HIP(hipStreamWaitEvent(aux, sorted_ev, 0));
+        }
       }
-      ar.off = mark;
+      const bool on_aux = two && (i & 1);
+      stage_stream[i] = on_aux ? aux : st;
+      aux_used = aux_used || on_aux;
+      ar.off = mark + (on_aux ? Arena::padded(bucket_max) : 0);
       win_dev[i] = wa.take<char>(ops[i].xyzz_bytes * MAX_WINDOWS);
-      CSH_TRY(ops[i].bucket(B->table, &p, &so, st, &ar, win_dev[i], nullptr));
+      CSH_TRY(ops[i].bucket(B->table, &p, &so, stage_stream[i], &ar, win_dev[i], nullptr));
     }
+    if (sorted_ev) (void)hipEventDestroy(sorted_ev);
+    if (aux_done) (void)hipEventDestroy(aux_done);
   }
   // window sums of all k results through one page-locked buffer of the lane (DMA copies, no staging), pageable fallback
   size_t slice = 0;

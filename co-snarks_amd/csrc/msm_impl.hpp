@@ -1183,6 +1183,7 @@ int precompute_table_t(Bases* B, int c, int groups, hipStream_t st) {
   using Fr = typename Cfg::Fr;
   const int windows = windows_for(Fr::Params::BITS, c);
   const int asked = groups <= 0 || groups > windows ? windows : groups;
+  CSH_REQUIRE(c <= 16 || asked == windows, "windows wider than 16 bits need one table row per window (groups = 0 or >= the window count)");
   const int wp = (windows + asked - 1) / asked;                    // W': windows per bucket set
   const int W = (windows + wp - 1) / wp;                           // table rows actually referenced (rows >= this would never be read)
   const int step = c * wp;                                         // doublings between rows: c * W'

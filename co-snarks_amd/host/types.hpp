@@ -346,17 +346,19 @@ struct ProvingKey {
   std::vector<G1> ic;
   // Fixed-base tables on the five queries (csh_bases_precompute_grouped): rows x the key memory on the device, built once per
   // key. With g rows, windows w, w + W', ..., w + (g - 1) W' share a bucket set, so an MSM reduces W' = ceil(W / g) windows and
-  // the host folds W' window sums (BN254 2^20, 4 rows: G2 query 4.7 -> 4.3 ms, G1 queries -1..3 %). Only for keys of 2^14..2^21 points:
-  // below, the MSM is launch-bound either way; above, the tables fall out of the caches and lose. COG16_TABLES=0 disables,
+  // the host folds W' window sums (BN254 2^20, 4 rows: G2 query 4.7 -> 4.3 ms, G1 queries -1..3 %). Round 6: the policy is one row per
+  // window with 17- / 20-bit windows (ONE bucket set, 15 / 13 additions per point instead of 17 / 16). COG16_TABLES=0 disables,
   // COG16_TABLES=g sets the row count. All queries get the same (c, rows): csh_msm_multi_dev shares one digit pass over them.
   void build_tables() {
     size_t big = 0;
     for (size_t n : {a_query.size(), b_g1_query.size(), l_query.size(), h_query.size(), b_g2_query.size()}) big = n > big ? n : big;
-    // the policy lives in the library (csh_bases_table_policy: 16 rows up to ~2^18 points, 4 above, none outside 2^14..2^21), shared
-    // with the Rust bases cache; profiles/r02_g_prove_table_rows.log
+    // the policy lives in the library (csh_bases_table_policy), shared with the Rust bases cache; profiles/r06_e_policy_*.log
     int c = 0, rows = 0;
     check(csh_bases_table_policy(big, &c, &rows), "csh_bases_table_policy");
-    if (const char* e = getenv("COG16_TABLES")) rows = atoi(e);
+    if (const char* e = getenv("COG16_TABLES")) {
+      rows = atoi(e);
+      if (c > 16 && rows < 16) c = 16;  // fewer rows than windows: the grouped form of rounds 2-5 (c <= 16)
+    }
     if (rows < 2 || c == 0) return;
     for (csh_bases_t h : {a_query.dev, b_g1_query.dev, l_query.dev, h_query.dev, b_g2_query.dev}) {
       if (!h) continue;

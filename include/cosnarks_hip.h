@@ -137,22 +137,23 @@ int csh_bases_upload_dev(csh_curve_t curve, csh_group_t group, const void* affin
                          size_t stride_bytes, void* stream, csh_bases_t* out);
 int csh_bases_len(csh_bases_t bases, size_t* n);
 /* Optional, for bases reused across many MSMs (proving-key queries: uploaded once per key, groth16.rs:219-225): builds
- * fixed-base window tables 2^(c w) P_i on the device (c = 0: automatic; W x the memory of the points). MSMs on the handle
- * then put all windows into ONE set of buckets: one bucket reduction instead of W and no Horner over windows. Results
- * are the same group elements. Handles with fewer than 1024 points are left unchanged. Opt-in: measured on MI355X it
- * saves 7 % on a BN254 G2 MSM of 2^20 points and ~1 % on G1 (the bucket reduction it removes is latency-bound, and the
- * gathers lose the cache reuse of the 64-byte points), and costs 6 % at 2^22; the host mirror does not use it. */
+ * fixed-base window tables 2^(c w) P_i on the device (c = 0: automatic; c in 4 .. 22; W x the memory of the points). MSMs on the
+ * handle then put all windows into ONE set of 2^(c-1) buckets: one bucket reduction instead of W, no Horner over windows, and
+ * -- with c = 17 .. 22, round 6 -- FEWER mixed additions per point than any plain plan (W = ceil((bits + 1) / c): 15 at c = 17, 13
+ * at c = 20, against 17 / 16 at the plain plan's c = 15 / 16). Results are the same group elements. Handles with fewer than 1024
+ * points are left unchanged. Measured on MI355X against the plain handle (profiles/r06_e_*, r06_f_*): BN254 G1 2^16 0.355 against
+ * 0.40 ms, 2^18 0.56 / 0.71, 2^20 +15 %, 2^24 (c = 20) +15 .. 17 % points/s; BN254 G2 +14 %, BLS12-381 G1 / G2 +15 / +10 % at 2^20. */
 int csh_bases_precompute(csh_bases_t bases, int c);
 /* The same with `groups` (2..128) table rows instead of one per window: row k holds 2^(c W' k) P_i, W' = ceil(windows / groups),
  * so that windows w and w + W' k share a bucket set: W' bucket reductions instead of W and a host Horner over W' windows, for
- * groups x the memory of the points. groups = 2 or 4 keeps the sort stage in its efficient regime (the full merge above runs it
- * on a single window). Same results; replaces any tables already on the handle. */
+ * groups x the memory of the points (c <= 16). groups >= the window count is the full merge above (the only form for c > 16).
+ * Same results; replaces any tables already on the handle. */
 int csh_bases_precompute_grouped(csh_bases_t bases, int c, int groups);
 /* The table policy of the library for the queries of ONE proving key whose largest query has `key_points` points (host-only,
  * no device needed): window width *c_out and row count *rows_out to pass to csh_bases_precompute_grouped for every query of
  * the key (equal (c, rows) on all of them lets csh_msm_multi_dev share one digit pass), or *rows_out = 0 when tables do not pay
- * (keys below 2^14 or above 2^21 points). 16 rows up to 3 * 2^17 points (the precompute keeps only the rows its W' = ceil(W / 16)
- * references), 4 rows above. The C++ host mirror
+ * (keys below 2^14 or above 2^26 points). Round 6: one row per window (rows_out >= the window count of either scalar field), c = 17
+ * from 2^15 to 3 * 2^20 points, c = 20 above; 2^14 .. 2^15: c <= 16. The C++ host mirror
  * (ProvingKey::build_tables) and the Rust bases cache (rust/co-groth16-hip/src/bases.rs) both take the policy from here. */
 int csh_bases_table_policy(size_t key_points, int* c_out, int* rows_out);
 /* Free the fixed-base tables of a handle (the plain points stay): the fallback when a key's tables do not fit the device. */

@@ -285,6 +285,102 @@ def groth16_prove_composition(pts_g1, sc, pts_g2, logn, threads):
             "sample": "stage sum of oracle/c routines on prove-shaped inputs (see groth16_prove_composition); no zkey parsing, no openings"}
 
 
+def groth16_reference_circuit_composition(gold_dir, threads=1, reps=20):
+    """CPU figures beside `groth16_prove_reference_circuits`: the hot stages of a plain Groth16 prove of the
+    reference's own BN254 circuits (tests/golden copies of test_vectors/Groth16/bn254/{multiplier2, poseidon}) from this restatement's
+    C routines ON THE CIRCUIT'S OWN DATA -- witness map (3 x ifft_in_to_out / coset table / fft_out_to_in, a.b, a.b - c on the real
+    constraint evaluations) and the five query MSMs (the zkey's points, the witness / h as scalars) -- and the same for one Rep3 party
+    (two-component share vectors through the transforms, local_mul_vec, one MSM per share component; x 3 for three parties on the same
+    cores). Excluded because they are Python in this harness: zkey parsing, the sparse row evaluation (a few hundred rows), the three
+    finishing scalar multiplications. Median of `reps`. A restatement, not arkworks; at these sizes (domain 4 / 256) a CPU wins on latency."""
+    import os
+    import statistics
+    from . import curves as cv
+    from . import groth16 as og
+    from . import ntt as ontt
+    from . import zkey as oz
+    out = {}
+
+    def pack_fr(F, xs):
+        a = np.zeros((len(xs), 4), dtype=np.uint64)
+        for i, x in enumerate(xs):
+            v = x * F.R % F.p
+            for k in range(4):
+                a[i, k] = (v >> (64 * k)) & (2**64 - 1)
+        return a
+
+    for circ in ("multiplier2", "poseidon"):
+        zk = oz.parse_zkey(open(os.path.join(gold_dir, circ, "circuit.zkey"), "rb").read())
+        w = oz.parse_wtns(open(os.path.join(gold_dir, circ, "witness.wtns"), "rb").read())
+        F = zk.Fr
+        npub = zk.num_inputs
+        pub = [x % F.p for x in w[:npub]]
+        wit = [x % F.p for x in w[npub:]]
+        drv = og.PlainDriver(F)
+        A, Bm = zk.matrices()
+        n = 1
+        while n < zk.num_constraints + npub:
+            n *= 2
+        logn = n.bit_length() - 1
+        gen, shift = ontt.groth16_roots_of_unity(F, logn)
+        ev = lambda M: [drv.eval_row(r, pub, wit) for r in M] + [0] * (n - len(M))
+        a = ev(A)
+        a[zk.num_constraints:zk.num_constraints + npub] = pub[:npub]
+        b = ev(Bm)
+        pa, pb = pack_fr(F, a), pack_fr(F, b)
+        table = pack_fr(F, ontt.bit_reversed_coset_table(F, shift, n))
+        pg = pack_fr(F, [gen])
+        fn = lib().oc_ntt
+        aux = pack_fr(F, wit)
+        G1, G2 = zk.G1, zk.G2
+        q = {"a": cv.pack_points(G1, zk.a_query[1 + npub - 1:][: len(wit)] if False else zk.a_query[npub:][: len(wit)]),
+             "b1": cv.pack_points(G1, zk.b_g1_query[npub:][: len(wit)]), "l": cv.pack_points(G1, zk.l_query[: len(wit)]),
+             "h": cv.pack_points(G1, zk.h_query[:n]), "b2": cv.pack_points(G2, zk.b_g2_query[npub:][: len(wit)])}
+        n_l = len(zk.l_query)
+
+        def witness_map(ncomp):
+            rep = lambda x: np.repeat(x, ncomp, axis=0) if ncomp > 1 else x   # a two-component share vector has the same shape of work
+            va, vb = rep(pa).copy(), rep(pb).copy()
+            c = (rep3_local_mul_vec(0, va, vb, None, threads=threads) if ncomp > 1 else vec_mul(0, va, vb, threads=threads)).reshape(-1, 4)
+            vs = [va, vb, np.ascontiguousarray(c)]
+            for k, v in enumerate(vs):
+                nc = ncomp if k < 2 else 1
+                assert fn(0, _p(v), logn, _p(pg), nc, 1, _t(threads)) == 0
+                lib().oc_vec_mul_table(0, _p(v), _p(table), C.c_size_t(n), nc, _t(threads))
+                assert fn(0, _p(v), logn, _p(pg), nc, 0, _t(threads)) == 0
+            ab = (rep3_local_mul_vec(0, vs[0], vs[1], None, threads=threads) if ncomp > 1 else vec_mul(0, vs[0], vs[1], threads=threads)).reshape(-1, 4)
+            return vec_sub(0, ab, vs[2], threads=threads)
+
+        def msms(ncomp, h):
+            for _ in range(ncomp):
+                msm_fast(0, 0, q["a"], aux, True, threads=threads)
+                msm_fast(0, 0, q["b1"], aux, True, threads=threads)
+                msm_fast(0, 1, q["b2"], aux, True, threads=threads)
+                msm_fast(0, 0, q["l"][: n_l], aux[-n_l:] if n_l else aux[:0], True, threads=threads)
+            msm_fast(0, 0, q["h"], h[: len(zk.h_query)], True, threads=threads)     # h is a half share: one component
+
+        def once(ncomp):
+            t0 = time.perf_counter()
+            h = witness_map(ncomp)
+            t1 = time.perf_counter()
+            msms(ncomp, np.ascontiguousarray(h).reshape(-1, 4))
+            return (t1 - t0) * 1e3, (time.perf_counter() - t1) * 1e3
+
+        for ncomp, key in ((1, f"plain_{circ}"),) + (((2, "rep3_poseidon_one_party"),) if circ == "poseidon" else ()):
+            once(ncomp)
+            runs = [once(ncomp) for _ in range(reps)]
+            wm = statistics.median(r[0] for r in runs)
+            ms = statistics.median(r[1] for r in runs)
+            out[key + "_ms"] = round(wm + ms, 3)
+            out[key + "_stages_ms"] = {"witness_map": round(wm, 3), "five_query_msms": round(ms, 3)}
+        if circ == "poseidon":
+            out["rep3_poseidon_3_parties_ms"] = round(3 * out["rep3_poseidon_one_party_ms"], 3)
+    out["threads"] = threads
+    out["sample"] = ("hot-stage sum (witness map + query MSMs) of oracle/c routines on the reference's own circuits, median of %d; excludes zkey parsing, "
+                     "sparse row evaluation and the finishing scalar multiplications (Python in this harness); kind \"port\", not arkworks" % reps)
+    return out
+
+
 def cpu_baseline_suite(pts20, sc20, gpu_affine20=None, pts24=None, sc24=None, gpu_affine24=None, curve=0, group=0, budget_s=30.0, host_cpus=None,
                        pts20_g2=None):
     """bench.py's ``cpu_baseline`` object (kind "port"): the tuned restatement `oc_msm_fast` timed on THIS box's host cores on

@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+    config.addinivalue_line("markers", "gpu_long: needs a real MI355X, tens of seconds each; not part of -m gpu (run by hand: -m gpu_long)")
 
 
 @pytest.fixture(scope="session")

@@ -31,8 +31,14 @@ def test_two_rank_line_folded_on_one_gpu(gpu):
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak" and line["unit"] == "points/s" and line["result_check"] is True
     assert line["config"]["points_total"] == 2 << 16 and "harness all-gather" in line["config"]["split"]         # the exchange that ran is named
     roof = line["roofline"]
-    assert roof["bound"] == "hbm" and roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"], rel=2e-2)
+    assert roof["bound"] == "valu_int_mad" and roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"], rel=2e-2)
     assert roof["alu"]["peak_nominal"] == pytest.approx(39.3, abs=0.1) and 0 < roof["alu"]["frac_vs_nominal"] < 1
+    # the integer-issue figures and the plan as SCALAR fields of the roofline object (the driver's record keeps only those)
+    for k in ("alu_frac", "alu_achieved_Tmad", "alu_peak_Tmad", "alu_frac_vs_nominal", "accum_ms", "c", "windows", "hbm_frac"):
+        assert isinstance(roof[k], (int, float)) and roof[k] > 0, k
+    assert roof["alu_frac"] == roof["alu"]["frac"] and roof["c"] == roof["msm_params"]["c"]
+    # the exchange that ran and the ranks RCCL saw are keys of config, not free text (folded ranks: the harness exchange)
+    assert line["config"]["exchange_mode"] == "harness_gloo" and line["config"]["rccl_ranks_seen"] == 0
     sec = line["secondary"]
     assert "error" not in sec, sec
     for wl in ("bn254_g1", "bls12_381_g1", "bls12_381_g2"):
@@ -62,6 +68,9 @@ def test_single_gpu_line_quick(gpu):
     assert ntt["ms"] > 0 and ntt["ms_first_batch_after_idle"] > 0 and ntt["warm_up_transforms"] >= 120 and ntt["roofline"]["alu"]["frac"] > 0
     assert line["config"]["spinup_steps"] >= 10 and line["config"]["spinup_ms"] >= 300 and line["value_first_20_steps"] > 0
     assert sec["msm_bn254_g1_2p18"]["spinup_steps"] >= 3
+    for key in ("msm_bn254_g1_2p20_fixed_base_tables", "msm_bn254_g1_2p18_fixed_base_tables"):    # round 6: one bucket set, 17-bit windows (the library's policy)
+        t = sec[key]
+        assert "error" not in t and t["result_check"] is True and t["bucket_sets"] == 1 and t["window_bits"] == 17 and t["points_per_s"] > 0, t
     pr = sec["groth16_prove_synthetic_2p14"]
     for mode in ("host_masks", "seeded_device_masks"):                        # BASELINE config 4 through the zero-upstream-edit path, both mask modes
         m = pr["rep3_trait_path"][mode]

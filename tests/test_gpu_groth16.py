@@ -309,9 +309,13 @@ def test_bases_clone_and_peer_copy(gpu):
     assert (o3 == o1).all()
     c, rows = C.c_int(0), C.c_int(0)
     B._check(L.csh_bases_table_policy(C.c_size_t(1 << 20), C.byref(c), C.byref(rows)))
-    assert (c.value, rows.value) == (16, 4)
+    assert (c.value, rows.value) == (17, 16)      # round 6: one bucket set, one row per window, 17-bit windows up to 3 * 2^20 points
     B._check(L.csh_bases_table_policy(C.c_size_t(1 << 16), C.byref(c), C.byref(rows)))
-    assert (c.value, rows.value) == (15, 16)
+    assert (c.value, rows.value) == (17, 16)
+    B._check(L.csh_bases_table_policy(C.c_size_t(1 << 24), C.byref(c), C.byref(rows)))
+    assert (c.value, rows.value) == (20, 13)
+    B._check(L.csh_bases_table_policy(C.c_size_t(1 << 14), C.byref(c), C.byref(rows)))
+    assert (c.value, rows.value) == (13, 16)
     B._check(L.csh_bases_table_policy(C.c_size_t(1000), C.byref(c), C.byref(rows)))
     assert rows.value == 0
     # csh_bases_clone_range: point i of the clone = point offset + i of the source, tables included (placement by range holds 1 / N of a
