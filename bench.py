@@ -134,7 +134,7 @@ class Ctx:
         # OMP_PROC_BIND (set above for the cpu_baseline leg) makes libgomp bind the INITIAL thread to one core the moment the library is
         # loaded (torch brings it in), and every host thread created afterwards inherits that one-core mask: the five MSM threads of a
         # prove, the library's page-population / copy helpers and the mirror's parallel loops all ran on ONE core in rounds 1-4's bench
-        # process (round 5: a Rep3 mask draw took 67 ms in here against 6 ms in a process of its own, profiles/r05_i_mask_draw_probe.log).
+        # process (round 5: a Rep3 mask draw took 67 ms in here against 6 ms in a process of its own, profiles/archive/r05_i_mask_draw_probe.log).
         # The main thread gets its full mask back before anything is measured; OpenMP's own workers keep their places.
         self.affinity_after_imports = len(os.sched_getaffinity(0)) if AFFINITY0 is not None else None
         if AFFINITY0 is not None:
@@ -255,7 +255,7 @@ class MsmJob:
 
     def spin_up(self, min_s: float = 0.3, max_s: float = 3.0, batch: int = 10, tol: float = 0.02):
         """Untimed steps BEFORE the W warm-up steps, whatever flags were passed: an idle MI355X needs a few hundred ms of continuous
-        work to reach its steady clocks (profiles/r04_j_ntt_context.log), and a 20-step region of 1.6 ms steps sits entirely inside that
+        work to reach its steady clocks (profiles/archive/r04_j_ntt_context.log), and a 20-step region of 1.6 ms steps sits entirely inside that
         ramp. Batches of `batch` steps run for at least `min_s` and until two consecutive batch medians agree within `tol` (cap `max_s`).
         -> (steps issued, wall ms, median ms of the last batch)."""
         cx = self.cx
@@ -563,7 +563,7 @@ def secondary_single_gpu(cx: Ctx, rin: dict, args):
     kin = rin.get("kernels", {}).get("k_ntt_pass_lazy 2^22", {}) if logn == 22 else {}
     out[f"ntt_bn254_2p{logn}"] = {"elements_per_s": (1 << logn) / ms * 1e3, "ms": ms,
                              # the same 20 pairs right after ONE warm-up transform (what rounds 1-3 reported): the clocks of an idle GPU take tens of
-                             # ms of continuous work to come up (profiles/r04_j_ntt_context.log: 0.566 -> 0.503 -> 0.480 -> 0.467 ms over four batches)
+                             # ms of continuous work to come up (profiles/archive/r04_j_ntt_context.log: 0.566 -> 0.503 -> 0.480 -> 0.467 ms over four batches)
                              "ms_first_batch_after_idle": nt["ms_first_batch"], "warm_up_transforms": nt["warm_transforms"], "spinup_ms": nt["spinup_ms"],
                              "roofline": {"bound": "hbm", "kernel": "k_ntt_pass_r4 / k_ntt_pass_lazy (all passes of one transform)", "achieved": round(64.0 * (1 << logn) / ms / 1e6, 1),
                                           "peak": float(rin.get("hbm_peak_GBps", 8000.0)), "unit": "GB/s", "frac": round(64.0 * (1 << logn) / ms / 1e6 / float(rin.get("hbm_peak_GBps", 8000.0)), 4), "traffic": kin.get("traffic_bytes"),

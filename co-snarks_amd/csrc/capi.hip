@@ -81,8 +81,9 @@ int* lane_d2h_slow_run();  // consecutive stalled result copies of the calling t
 // Copier pool of the staged transfers: a handful of persistent host threads (started on first use, parked on a condition variable)
 // instead of seven std::thread constructions per staged copy (~40 us each on these hosts: 0.3 ms per transfer, two or three transfers per
 // witness map). run(k, fn): fn runs on the caller and on up to k pool threads at once (each claims chunks from the caller's own atomic
-// counter) and run returns when all of them have returned. Tasks never block on each other; a caller that finds every worker busy with
-// another caller's copy simply does more of its own chunks itself.
+// counter) and run returns when all of them have returned. A caller that finds the workers busy with another caller's copy does more
+// of its own chunks itself AND, once its own fn() has returned, withdraws the jobs no worker has picked up yet (round 6, ADVICE r5: it
+// used to wait until every queued job had been dequeued, i.e. behind workers blocked in another caller's hipEventSynchronize).
 namespace {
 struct CopierPool {
   static constexpr int THREADS = 8;
@@ -145,6 +146,16 @@ struct CopierPool {
     }
     if (pending.load() > 0) cv.notify_all();
     fn();
+    if (pending.load(std::memory_order_acquire) > 0) {  // withdraw this call's jobs that nobody has started: they would find no chunk left anyway
+      std::lock_guard<std::mutex> g(mu);
+      int withdrawn = 0;
+      for (size_t i = queue.size(); i-- > 0;)
+        if (queue[i].fn == &fn) {
+          queue.erase(queue.begin() + (ptrdiff_t)i);
+          ++withdrawn;
+        }
+      if (withdrawn) pending.fetch_sub(withdrawn, std::memory_order_acq_rel);
+    }
     std::unique_lock<std::mutex> g(done_mu);
     done_cv.wait(g, [&] { return pending.load(std::memory_order_acquire) == 0; });
   }
@@ -155,13 +166,17 @@ CopierPool& copiers() {
 }
 }  // namespace
 
-// Round 5 root cause of the "stalled copies" (profiles/r05_l .. r05_r_trait_stall_*; reproducer tools/experiments/trait_stall_probe.py): when
+// Round 5 root cause of the "stalled copies" (profiles/archive/r05_l .. r05_r_trait_stall_*; reproducer tools/experiments/trait_stall_probe.py): when
 // the runtime copies straight from / into caller memory it pins those pages, and once such memory has been unmapped again (a freed h
 // vector, a dropped witness: from the second proof of a process on) some LATER operation of the process -- any stream, either direction,
 // staged or not -- takes 10, 20 or 30 ms longer, in steps of the kernel's 10 ms tick, on about half the processes of a box. With BOTH
 // directions staged (the runtime never sees caller memory) 16 of 16 probe runs were clean; with either direction direct 5 of 12 stalled.
 // The condition is process-wide, so is the reaction: a stalled large copy in either direction (two in a row on one lane) sends every
 // large transfer of the process through the staged paths for the next STAGE_ALL_SPELL transfers, then direct copies are tried again.
+// Page-locked staging is bounded (round 6): a transfer of up to STAGE_RING_BYTES is staged whole (<= 16 chunks, as measured in round 5 for
+// the 32 MB vectors of a 2^20 witness map); a larger one cycles through a ring of that size in generations of eight 2 MiB chunks.
+constexpr size_t STAGE_RING_CHUNK = size_t(2) << 20;
+constexpr size_t STAGE_RING_BYTES = size_t(32) << 20;
 static std::atomic<int> g_stage_all_left{0};
 constexpr int STAGE_ALL_SPELL = 4096;
 static bool stage_all_take() {
@@ -191,7 +206,7 @@ HostXfer::~HostXfer() {
 }
 // Result copy. Direct: one DMA into the caller's pages (the runtime pins them for the duration). Staged (tune "host_d2h" = 1): the
 // driver never touches the caller's memory -- chunks land in the lane's page-locked buffer and host threads move them on. On most
-// boxes the direct copy of 32 MB takes 0.6 ms once the pages are present; on some (profiles/r04_zd_trait_modes.log, same code, same
+// boxes the direct copy of 32 MB takes 0.6 ms once the pages are present; on some (profiles/archive/r04_zd_trait_modes.log, same code, same
 // sizes) the host-facing witness map took 12-24 ms instead of 2.4 in steps of ~10 ms while every device-resident path ran at
 // its usual speed, i.e. the stall sits in the driver's handling of freshly populated caller pages.
 int HostXfer::d2h(void* host, const void* dev, size_t bytes, hipStream_t st) {
@@ -208,6 +223,16 @@ int HostXfer::d2h(void* host, const void* dev, size_t bytes, hipStream_t st) {
   // Every caller today copies one result per HostXfer; a second one takes the direct path.
   if (!staged.empty()) stage = false;
   void *ph = nullptr, *pd = nullptr;
+  if (stage && bytes > STAGE_RING_BYTES && pinned_for((hipStream_t)((uintptr_t)st ^ 0x8), STAGE_RING_BYTES, &ph, &pd)) {
+    // larger than the staging ring: nothing is enqueued here; finish() moves it through the ring's two halves (DMA of generation g
+    // under the copy-out of generation g - 1) once the stream's earlier work has been waited for anyway
+    Staged sg;
+    sg.host = host, sg.pinned = static_cast<const char*>(ph), sg.bytes = bytes, sg.chunk = 0;
+    sg.ring_dev = dev;
+    staged.push_back(std::move(sg));
+    tune().stat_d2h_staged.fetch_add(1, std::memory_order_relaxed);
+    return CSH_OK;
+  }
   if (stage && pinned_for((hipStream_t)((uintptr_t)st ^ 0x8), bytes, &ph, &pd)) {
     Staged sg;
     sg.host = host, sg.pinned = static_cast<const char*>(ph), sg.bytes = bytes;
@@ -260,6 +285,41 @@ int HostXfer::finish(hipStream_t st) {
     const auto t0 = std::chrono::steady_clock::now();
     std::atomic<int> failed{0};
     for (Staged& sg : staged) {
+      if (sg.ring_dev) {  // through the ring: half h receives generation g while the copiers empty the other half
+        const size_t half = STAGE_RING_BYTES / 2, ngen = (sg.bytes + half - 1) / half;
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        hipError_t rc = hipEventCreateWithFlags(&ev[0], hipEventDisableTiming);
+        if (rc == hipSuccess) rc = hipEventCreateWithFlags(&ev[1], hipEventDisableTiming);
+        auto enqueue = [&](size_t g) {
+          const size_t off = g * half, l = sg.bytes - off < half ? sg.bytes - off : half;
+          hipError_t e = hipMemcpyAsync(const_cast<char*>(sg.pinned) + (g & 1) * half, static_cast<const char*>(sg.ring_dev) + off, l, hipMemcpyDeviceToHost, st);
+          if (e == hipSuccess) e = hipEventRecord(ev[g & 1], st);
+          return e;
+        };
+        if (rc == hipSuccess) rc = enqueue(0);
+        for (size_t g = 0; rc == hipSuccess && g < ngen; ++g) {
+          if (g + 1 < ngen) rc = enqueue(g + 1);   // into the half generation g - 1 was copied out of below
+          if (rc == hipSuccess) rc = hipEventSynchronize(ev[g & 1]);
+          if (rc != hipSuccess) break;
+          const size_t off = g * half, l = sg.bytes - off < half ? sg.bytes - off : half;
+          const size_t nch = (l + STAGE_RING_CHUNK - 1) / STAGE_RING_CHUNK;
+          std::atomic<size_t> next{0};
+          const char* src = sg.pinned + (g & 1) * half;
+          char* dst = static_cast<char*>(sg.host) + off;
+          copiers().run(nch > 1 ? 7 : 0, [&] {
+            for (;;) {
+              const size_t c = next.fetch_add(1, std::memory_order_relaxed);
+              if (c >= nch) return;
+              const size_t o = c * STAGE_RING_CHUNK, ll = l - o < STAGE_RING_CHUNK ? l - o : STAGE_RING_CHUNK;
+              memcpy(dst + o, src + o, ll);
+            }
+          });
+        }
+        for (hipEvent_t e : ev)
+          if (e) (void)hipEventDestroy(e);
+        if (rc != hipSuccess) failed.store(1);
+        continue;
+      }
       const size_t nchunks = sg.landed.size();
       std::atomic<size_t> next{0};
       auto work = [&] {
@@ -318,6 +378,7 @@ struct Lane {
   // #6): consecutive stalled large copies of this lane, either direction. The REACTION is process-wide (g_stage_all_left): so is the stall.
   int d2h_slow_run = 0, h2d_slow_run = 0;
   hipEvent_t h2d_done[4] = {nullptr, nullptr, nullptr, nullptr};  // last DMA out of each page-locked upload slot
+  hipEvent_t h2d_ring_ev[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};  // per slot: last DMA out of each half of the staging ring
   std::map<hipStream_t, Arena> arenas;
   std::map<hipStream_t, PinnedSlot> pinned;
 };
@@ -376,6 +437,7 @@ static const TuneEntry kTune[] = {
     {"stat_h2d_slow", "CSH_STAT_H2D_SLOW", &Tune::stat_h2d_slow},
     {"stat_h2d_staged", "CSH_STAT_H2D_STAGED", &Tune::stat_h2d_staged},
     {"stat_stage_all_switches", "CSH_STAT_STAGE_ALL_SWITCHES", &Tune::stat_stage_all_switches},
+    {"stat_pinned_kib", "CSH_STAT_PINNED_KIB", &Tune::stat_pinned_kib},
     {"host_copier_pool", "CSH_HOST_COPIER_POOL", &Tune::host_copier_pool},
     {"host_timing", "CSH_HOST_TIMING", &Tune::host_timing},
     {"stat_wm_h2d_us", "CSH_STAT_WM_H2D_US", &Tune::stat_wm_h2d_us},
@@ -480,7 +542,10 @@ Arena& arena_for(hipStream_t s) { return tl_lanes.get(tl_device)->arenas[s]; }
 bool pinned_for(hipStream_t s, size_t bytes, void** host, void** dev) {
   PinnedSlot& slot = tl_lanes.get(tl_device)->pinned[s];
   if (!slot.host || slot.cap < bytes) {
-    if (slot.host) (void)hipHostFree(slot.host);
+    if (slot.host) {
+      (void)hipHostFree(slot.host);
+      tune().stat_pinned_kib.fetch_sub((int)(slot.cap >> 10), std::memory_order_relaxed);
+    }
     slot = PinnedSlot{};
     const size_t cap = bytes < 16384 ? 16384 : bytes;
     void* h = nullptr;
@@ -493,6 +558,7 @@ bool pinned_for(hipStream_t s, size_t bytes, void** host, void** dev) {
     slot.host = h;
     slot.dev = d;
     slot.cap = cap;
+    tune().stat_pinned_kib.fetch_add((int)(cap >> 10), std::memory_order_relaxed);
   }
   *host = slot.host;
   *dev = slot.dev;
@@ -513,7 +579,52 @@ int upload_h2d(void* dev, const void* host, size_t bytes, hipStream_t st, int sl
   if (stage) {
     // the slot's previous DMAs must have drained before its buffer is overwritten (or regrown)
     if (lane->h2d_done[slot]) CSH_HIP(hipEventSynchronize(lane->h2d_done[slot]));
-    if (!pinned_for((hipStream_t)((uintptr_t)st ^ (uintptr_t)(0x10 + 0x10 * slot)), bytes, &ph, &pd)) stage = false;
+    if (!pinned_for((hipStream_t)((uintptr_t)st ^ (uintptr_t)(0x10 + 0x10 * slot)), bytes < STAGE_RING_BYTES ? bytes : STAGE_RING_BYTES, &ph, &pd)) stage = false;
+  }
+  if (stage && bytes > STAGE_RING_BYTES) {
+    // Round 6: transfers beyond the ring size go through a FIXED page-locked ring (two halves of 8 x 2 MiB, pinned_for above
+    // was asked for STAGE_RING_BYTES): generation g of eight chunks is copied into half g & 1 by the copier threads, each chunk's DMA
+    // following at once, while the DMAs of generation g - 1 drain from the other half; a half is reused once the event recorded after
+    // its previous generation has fired. A key or a 2^24 scalar vector used to leave its FULL size page-locked per (lane, stream, slot)
+    // for the life of the process (2 GB on the witness-map thread of a 2^24 prove).
+    const size_t chunk = STAGE_RING_CHUNK, half = STAGE_RING_BYTES / 2, per_gen = half / chunk;
+    const size_t nchunks = (bytes + chunk - 1) / chunk, ngen = (nchunks + per_gen - 1) / per_gen;
+    hipEvent_t* gen_ev = lane->h2d_ring_ev[slot];
+    int device = 0;
+    (void)hipGetDevice(&device);
+    std::mutex enq;
+    for (size_t g = 0; g < ngen; ++g) {
+      const size_t h = g & 1;
+      if (!gen_ev[h]) CSH_HIP(hipEventCreateWithFlags(&gen_ev[h], hipEventDisableTiming));
+      else if (g >= 2) CSH_HIP(hipEventSynchronize(gen_ev[h]));
+      const size_t c0 = g * per_gen, c1 = c0 + per_gen < nchunks ? c0 + per_gen : nchunks;
+      std::atomic<size_t> next{c0};
+      std::atomic<int> failed{0};
+      auto work = [&] {
+        for (;;) {
+          const size_t c = next.fetch_add(1, std::memory_order_relaxed);
+          if (c >= c1) return;
+          const size_t off = c * chunk, l = bytes - off < chunk ? bytes - off : chunk;
+          char* stage_at = static_cast<char*>(ph) + h * half + (c - c0) * chunk;
+          memcpy(stage_at, static_cast<const char*>(host) + off, l);
+          std::lock_guard<std::mutex> gq(enq);
+          if (hipMemcpyAsync(static_cast<char*>(dev) + off, stage_at, l, hipMemcpyHostToDevice, st) != hipSuccess) failed.store(1);
+        }
+      };
+      copiers().run(c1 - c0 > 1 ? 7 : 0, [&, device] {
+        (void)hipSetDevice(device);
+        work();
+      });
+      if (failed.load()) {
+        set_error("staged upload: a chunk copy failed");
+        return CSH_ERR_HIP;
+      }
+      CSH_HIP(hipEventRecord(gen_ev[h], st));
+    }
+    if (!lane->h2d_done[slot]) CSH_HIP(hipEventCreateWithFlags(&lane->h2d_done[slot], hipEventDisableTiming));
+    CSH_HIP(hipEventRecord(lane->h2d_done[slot], st));
+    tune().stat_h2d_staged.fetch_add(1, std::memory_order_relaxed);
+    return CSH_OK;
   }
   if (stage) {
     const size_t chunk = (((bytes + 15) / 16) + (size_t(2) << 20) - 1) & ~((size_t(2) << 20) - 1);  // <= 16 chunks, 2 MiB-granular
@@ -595,7 +706,10 @@ int csh_shutdown(void) {
       if (kv.second.base) (void)hipFree(kv.second.base);
     l->arenas.clear();
     for (auto& kv : l->pinned)
-      if (kv.second.host) (void)hipHostFree(kv.second.host);
+      if (kv.second.host) {
+        (void)hipHostFree(kv.second.host);
+        tune().stat_pinned_kib.fetch_sub((int)(kv.second.cap >> 10), std::memory_order_relaxed);
+      }
     l->pinned.clear();
   };
   for (auto& kv : tl_lanes.by_device) drop(kv.second);

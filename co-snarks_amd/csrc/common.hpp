@@ -63,14 +63,14 @@ Arena& arena_for(hipStream_t s);
 hipStream_t resolve_aux_stream();  // second pooled stream of the calling thread (may be nullptr)
 bool pinned_for(hipStream_t s, size_t bytes, void** host, void** dev);  // page-locked result buffer of (thread lane, stream)
 
-// Upload of a caller's (pageable) host buffer. Round 5 (profiles/r05_l .. r05_p_trait_stall_*): on some boxes, from the second circuit of a
+// Upload of a caller's (pageable) host buffer. Round 5 (profiles/archive/r05_l .. r05_p_trait_stall_*): on some boxes, from the second circuit of a
 // process on, a hipMemcpyAsync FROM caller memory of 32 MB takes 10-20 ms instead of 0.6-1.3 (steps of ~10 ms: the driver's pinning of the
 // source pages retrying with a one-jiffy sleep) -- that, not the result copy, is the "stalled witness map" of round 4. tune "host_h2d":
 // 0 = one copy from the caller's pages, 1 = staged (host threads copy 2 MiB chunks into the lane's page-locked buffer, each chunk's DMA
 // follows at once: the driver never pins caller memory; +0.3-0.5 ms per 32 MB on a healthy box), 2 = direct and timed; two in a row
 // on one lane that took more than three times their PCIe time + 4 ms switch the whole process to staged transfers in BOTH directions for a
 // spell. DEFAULT = 1, and 1 for results too (host_d2h): the stalled state is sticky -- a process that has entered it keeps stalling after the
-// switch (profiles/r05_s_trait_stall_auto_mode.log: 23-33 ms per witness map with every transfer staged by then), whereas a process whose
+// switch (profiles/archive/r05_s_trait_stall_auto_mode.log: 23-33 ms per witness map with every transfer staged by then), whereas a process whose
 // transfers were staged from its first call never entered it in 32 of 32 probe runs (r05_r, r05_t). The price is ~10 % of a trait-path
 // prove at 2^20 on a box that would have stayed healthy (18.3 against 16.6 ms); 0 / 2 remain for hosts known to be fine. `slot` (0..3) names one of the lane's
 // page-locked staging buffers: uploads of one call that are in flight together use different slots. Returns once `host` has been read.
@@ -97,11 +97,11 @@ struct HostStage {
 };
 
 // Host-pointer entry points that hand the caller LARGE buffers back (h of a witness map, a transformed vector). Measured on the MI355X
-// boxes (profiles/r04_a_pcie_probe.jsonl, r04_b_prefault_probe.jsonl): a copy from / to pageable memory whose pages are present runs
+// boxes (profiles/archive/r04_a_pcie_probe.jsonl, r04_b_prefault_probe.jsonl): a copy from / to pageable memory whose pages are present runs
 // at the PCIe rate (32 MB in 0.60 ms = 56 GB/s, the same as from hipHostMalloc memory; hipHostRegister is a ~1 us no-op on these hosts),
 // but a D2H into memory the caller has only just allocated pays the DMA engine's first touch of every page: 3.9 ms for 32 MB.
 // HostXfer therefore populates the destination's pages from a helper thread (MADV_POPULATE_WRITE: no content change) WHILE the
-// device works, and joins it before the copy is enqueued. Measured (profiles/r04_y_populate.log, six alternating trials per setting,
+// device works, and joins it before the copy is enqueued. Measured (profiles/archive/r04_y_populate.log, six alternating trials per setting,
 // host-facing witness map at 2^20): one thread with a transparent-huge-page hint on the range 2.36-2.47 ms (= upload + device + copy:
 // nothing left exposed); two / four threads with the hint 3.1-3.8 / 2.9-3.4 (they contend); WITHOUT the hint 4.3-22 ms, bimodal
 // (8192 4-KiB faults interleaved with the driver's own page handling) -- the hint is what makes it reliable.
@@ -115,6 +115,7 @@ struct HostXfer {
     const char* pinned = nullptr;
     size_t bytes = 0, chunk = 0;
     std::vector<hipEvent_t> landed;
+    const void* ring_dev = nullptr;  // non-null: larger than the staging ring, moved through it in finish() (capi.hip)
   };
   std::vector<Staged> staged;
   ~HostXfer();
@@ -161,6 +162,7 @@ struct Tune {
   std::atomic<int> stat_uploads_shared{0};  // counter: csh_msm calls that reused a concurrent call's upload
   std::atomic<int> host_h2d{1};  // uploads of >= 4 MiB from pageable caller memory: 0 direct, 1 (default) staged through page-locked chunks, 2 direct + timed, staged after stalls (upload_h2d)
   std::atomic<int> stat_h2d_slow{0}, stat_h2d_staged{0}, stat_stage_all_switches{0};
+  std::atomic<int> stat_pinned_kib{0};  // page-locked host memory currently held by the lanes' staging / result slots, KiB
   std::atomic<int> host_copier_pool{1};  // staged transfers: 1 = persistent copier pool, 0 = a std::thread per helper and copy (A/B)
   std::atomic<int> host_timing{0};  // diagnostics: 1 = the host-facing witness map synchronises after its upload, its kernels and its result copy and adds the three times to the counters below
   std::atomic<int> stat_wm_h2d_us{0}, stat_wm_dev_us{0}, stat_wm_d2h_us{0};

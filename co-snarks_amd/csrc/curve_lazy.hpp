@@ -58,7 +58,7 @@ __device__ void pair_unpack_affine(const AffT* src, L* x, L* y);
 // Rare-path helper of the accumulate kernel for the wide fields: 2 * (the affine point at `src`, negated if asked), re-read
 // from memory INSIDE the out-of-line routine. (The former version took private stack copies of x2 / y2 in the caller's rare
 // branch; the compiler hoisted those stores to the top of the loop body, so every mixed addition wrote 2 field elements of
-// scratch -- 2.5 GB per 2^20 BN254 G2 MSM, 4.2 GB on BLS12-381 G2 by WRITE_SIZE, profiles/r02_a_msm_*_pmc_hbm_bytes.csv.)
+// scratch -- 2.5 GB per 2^20 BN254 G2 MSM, 4.2 GB on BLS12-381 G2 by WRITE_SIZE, profiles/archive/r02_a_msm_*_pmc_hbm_bytes.csv.)
 template <class L, class AffT>
 CSH_HD_NOINLINE void lazy_mdbl_mem(const AffT* src, uint32_t negate, XYZZLazy<L>* out) {
   L x, y;

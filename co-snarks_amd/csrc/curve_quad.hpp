@@ -2,7 +2,7 @@
 //
 // Those stages are a dependent chain of ~45 point operations per window with only ~0.5 wave per SIMD in flight: a lone
 // wave64 issues one VALU instruction per ~4-5 cycles whatever its occupancy, so the chain runs at the latency of a
-// lane-serial point addition (12M + 2S ~ 3200 instructions ~ 6.5 us, profiles/r02_a_msm_stages.log: 0.55-0.59 ms of the
+// lane-serial point addition (12M + 2S ~ 3200 instructions ~ 6.5 us, profiles/archive/r02_a_msm_stages.log: 0.55-0.59 ms of the
 // 2.1 ms BN254 G1 2^20 step). The only lever is parallelism INSIDE one point operation. Here four adjacent lanes (a DPP
 // quad) own one point: lane role 0 holds X, 1 holds Y, 2 holds ZZ, 3 holds ZZZ. The independent field products of the
 // EFD formulas run on different lanes of the quad in the same instruction slot; operands move between the lanes with

@@ -193,7 +193,7 @@ using Fq29 = FpLazy<Bn254Fq29Params, Bn254Fq>;
 // CSH_PIN_MADS: per translation unit. 0 (default): the compiler is free to reassociate a column's terms -- it moves the incoming
 // carry to the end of the chain and pays a separate 64-bit addition per column, i.e. the instruction count of the row-wise form.
 // 3: every partial sum gets a second (empty, input-only asm) use, which keeps the chain in the written order: the carry is the
-// addend of the column's first multiply-add. Worth -4 % on the accumulate kernels and -5.5 % on the NTT passes (profiles/r03_a_*);
+// addend of the column's first multiply-add. Worth -4 % on the accumulate kernels and -5.5 % on the NTT passes (profiles/archive/r03_a_*);
 // set by the translation units of those kernels only (msm_accum_*.hip, ntt.hip): the volatile asm statements are ordered among
 // themselves, and in the four-lane tail kernels (long independent chains the scheduler wants to interleave) that ordering blew the
 // register allocation up to 512 VGPRs + spills (tails +13 % on G1, x2 on G2 / BLS12-381).
@@ -481,8 +481,8 @@ struct FpS {
   // ---- two multiplications in lockstep ---------------------------------------------------------------------------------------
   // A lane's multiply-adds of ONE product-scanning multiplication form a single dependent chain; in a register-only probe a dependent
   // v_mad_i64_i32 chain issues at 21.9 T mad/s (two waves per SIMD) against 26.3 for two chains per lane and 33.4 at the pipe's peak
-  // (tools/gpu_probe_chain.py, profiles/r03_o_probe_chain.log). reduce_scan2 runs two INDEPENDENT multiplications column by column with
-  // their terms alternating A, B, A, B in program order (which the pin of mad_pinned preserves). Measured (profiles/r03_p_*, A/B on one
+  // (tools/gpu_probe_chain.py, profiles/archive/r03_o_probe_chain.log). reduce_scan2 runs two INDEPENDENT multiplications column by column with
+  // their terms alternating A, B, A, B in program order (which the pin of mad_pinned preserves). Measured (profiles/archive/r03_p_*, A/B on one
   // box): the radix-4 NTT pass, whose folds hold two independent products, gains ~1.5 %; the bucket accumulation gains nothing (its
   // mixed addition paired as (u2, s2) (ppp, q) (x3, zzz3) (y3, zz3): BN254 G1 +-0, BN254 G2 +2 %, BLS12-381 G2 +10 % from spills) --
   // the other VALU work between a real multiplication's multiply-adds already fills the chain's latency -- so only the NTT uses it.
@@ -729,7 +729,7 @@ struct FpS {
   // 9 x 29-bit scalar fields) of an integer, and then by one, so its result is in (-p 1e-5, p (1 + 1e-5)). Branch-free: add p when
   // negative, then subtract p unless that borrows -- ~75 straight-line instructions where canonical()'s data-dependent correction
   // loops (a wave executes the union of its lanes' paths) cost 180-250; the canonicalise-and-store tail of an NTT pass, the kernel's
-  // per-sweep fixed cost, spends most of its ~370 instructions per element there (profiles/r04_e_ntt_per_pass.log).
+  // per-sweep fixed cost, spends most of its ~370 instructions per element there (profiles/archive/r04_e_ntt_per_pass.log).
   CSH_HD FpS canonical_narrow() const {
     FpS r;
     const int32_t m = l[NL - 1] >> 31;  // all ones when the value is negative (the top limb carries the sign)

@@ -64,6 +64,7 @@ std::mutex g_up_mu;
 std::vector<SharedUpload*> g_up_live;                       // entries with refs > 0
 std::vector<std::pair<int, std::pair<size_t, void*>>> g_up_pool;  // (device, (capacity, buffer)) free device buffers
 constexpr size_t UP_POOL_MAX = 8;
+constexpr size_t UP_POOL_MAX_BYTES = size_t(1) << 30;  // the free buffers together (a 2^24 scalar vector is 512 MB): beyond it a buffer is freed
 
 struct SharedUploadRef {
   SharedUpload* e = nullptr;
@@ -76,6 +77,12 @@ struct SharedUploadRef {
       std::lock_guard<std::mutex> g(g_up_mu);
       for (SharedUpload* x : g_up_live)
         if (x->device == device && x->host == host && x->bytes == bytes) {
+          bool failed;
+          {
+            std::lock_guard<std::mutex> gs(x->m);
+            failed = x->state < 0;
+          }
+          if (failed) continue;  // an entry whose owner's upload failed only waits for its last waiter: a NEW call uploads for itself
           e = x;
           break;
         }
@@ -138,7 +145,9 @@ struct SharedUploadRef {
       if (--e->refs == 0) {
         g_up_live.erase(std::find(g_up_live.begin(), g_up_live.end(), e));
         dead = e;
-        if (dead->dev && g_up_pool.size() < UP_POOL_MAX) {
+        size_t pooled = 0;
+        for (auto& b : g_up_pool) pooled += b.second.first;
+        if (dead->dev && g_up_pool.size() < UP_POOL_MAX && pooled + dead->cap <= UP_POOL_MAX_BYTES) {
           g_up_pool.push_back({dead->device, {dead->cap, dead->dev}});
           dead->dev = nullptr;
         }

@@ -65,7 +65,7 @@ __device__ __forceinline__ void load_scalar(const Fr* __restrict__ scalars, size
 // Signed-digit codes of every scalar, dig[row(w) * n + i] (row(w) = w, or the grouped-table order (w % W') * g + w / W'). Straight-line
 // per window: the scalar is shifted right by c bits after every digit (constant register indices, no indexed register access), the code
 // is selected without branches and every row gets exactly one 2-byte store per scalar (rows past W hold no digits). Same recoding
-// as for_each_digit (msm_digits.hpp), which the host self-test and the oracle comparison pin. Round 3: stage "digits + histogram" 0.081-0.087 -> 0.071 ms at 2^20, 0.91 -> 0.68 ms at 2^24 (profiles/r03_x_digits_stages.log)
+// as for_each_digit (msm_digits.hpp), which the host self-test and the oracle comparison pin. Round 3: stage "digits + histogram" 0.081-0.087 -> 0.071 ms at 2^20, 0.91 -> 0.68 ms at 2^24 (profiles/archive/r03_x_digits_stages.log)
 // (the former loop over for_each_digit compiled to 116 basic blocks with indexed register moves and an integer division per row).
 template <class Fr>
 __global__ __launch_bounds__(MSM_BLK) void k_msm_digits(const Fr* __restrict__ scalars, MsmParams p, uint16_t* __restrict__ dig) {
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(ACC_BLK) void k_msm_accum(const Affine<typename Cfg
     Affine<Fq> pt_next = bases[e_next & 0x7fffffffu];
     // software prefetch: the gather of the next entry and, on the G1 groups, the sorted index two entries ahead, so that the gather's
     // address never waits for an index load issued in the same iteration: -0.5 .. -1 % on the G1 accumulation, nothing on BN254 G2 and
-    // +8 % on BLS12-381 G2, where the extra live register adds spills (profiles/r03_s_acc_prefetch.log, r03_u_acc_prefetch_groups.log)
+    // +8 % on BLS12-381 G2, where the extra live register adds spills (profiles/archive/r03_s_acc_prefetch.log, r03_u_acc_prefetch_groups.log)
     constexpr bool INDEX_AHEAD = !Cfg::PAIR;
     uint32_t e_next2 = (INDEX_AHEAD && lo + 1 < hi) ? so[lo + 1] : 0;
     for (uint32_t pos = lo; pos < hi; ++pos) {
@@ -263,7 +263,7 @@ constexpr int TAIL_Q = TAIL_BLK / 4;
 // touched it). One quad per bucket folds them into the dense array dense[w][b]; buckets with more than MERGE_CAP
 // partials (heavily repeated scalars) are queued for the block-wide tree kernel below. (One LANE per bucket with whole-point additions,
 // compiled with the accumulate kernel's pinned multiplier, was measured in round 3: tail 0.34 -> 0.55 ms at 2^20, 0.53 -> 1.05 ms at 2^24,
-// profiles/r03_w_merge_lane.log -- 1-3 additions per lane under divergent trip counts and the empty / doubling branches of the full
+// profiles/archive/r03_w_merge_lane.log -- 1-3 additions per lane under divergent trip counts and the empty / doubling branches of the full
 // addition; not kept.)
 constexpr uint32_t MERGE_CAP = 16;
 // Oversized buckets of a witness-like scalar vector are few and huge (every "1" lands in bucket 1 of window 0: a quarter of a 2^20 vector
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(256) void k_msm_reduce(MsmParams p, const LazyPt<Cf
 
 // The lane-serial reductions run in workgroups of four waves: a workgroup's waves spread over the four SIMDs of one CU and the
 // <= 256 workgroups of a one-round launch over the CUs, so every SIMD gets exactly one wave (single-wave workgroups are packed
-// unevenly: 870 of them took 0.38 ms where 544 took 0.26 ms, profiles/r02_g_seg_stages.log).
+// unevenly: 870 of them took 0.38 ms where 544 took 0.26 ms, profiles/archive/r02_g_seg_stages.log).
 constexpr int RED_BLK = 256;
 
 // Lane-serial form of the same reduction (one lane per segment, whole points in registers): 1.75x less total work than the
@@ -640,7 +640,7 @@ inline int choose_c(size_t n, int bits) {
   for (int c = 3; c <= 16; ++c) {  // digit codes are 15 bits + sign
     const double nb = double(size_t(1) << (c - 1));
     // per window: n mixed additions + the bucket stages, ~5 additions' worth per bucket (merge, running sums, segment multiple).
-    // Re-checked after the one-round window reduction (profiles/r02_g_csweep.log, r02_g_c1516.log): at 2^20 c = 15 and 16 tie
+    // Re-checked after the one-round window reduction (profiles/archive/r02_g_csweep.log, r02_g_c1516.log): at 2^20 c = 15 and 16 tie
     // within 1-2 % (G1: 15 ahead, G2: 16 ahead), 2^17-2^19: 13 / 13 / 13-15, >= 2^21: 16.
     const double cost = windows_for(bits, c) * (double(n) + 5.0 * nb);
     if (cost < best) {
@@ -654,7 +654,7 @@ inline int choose_c(size_t n, int bits) {
 // L = sorted entries per accumulate lane. Every lane of every wave performs exactly L mixed additions and one wave of
 // multiply-add code already saturates its SIMD's integer pipe, so the accumulate kernel takes ceil(waves / SIMDs) rounds of L
 // additions: a sawtooth in L (measured, BN254 G1 2^22, 16 windows: L = 128 -> 8192 waves = 8.00 per SIMD, 4.82 ms; L = 112 ->
-// 9.16 per SIMD = 10 rounds, 5.28 ms; L = 144 -> 5.36 ms; profiles/r02_g_lsweep*.log). Longer lanes leave fewer partial sums
+// 9.16 per SIMD = 10 rounds, 5.28 ms; L = 144 -> 5.36 ms; profiles/archive/r02_g_lsweep*.log). Longer lanes leave fewer partial sums
 // to merge (n W / L of them, ~4.6e-5 addition rounds each); with few long rounds the last one is balanced less well (+~0.2 round).
 // The plan takes the L in [16, 1024] with the smallest
 //   (rounds(L) + 0.2) * L + 4.6e-5 * n * W / L.
@@ -662,7 +662,7 @@ inline int choose_c(size_t n, int bits) {
 // n W / 64 is not a multiple of the SIMD count: 17 windows (BN254 at 2^20: L = 32 meant 8.5 waves per SIMD, 9 rounds of 32
 // where 5 of 55 do, accumulate + merge 1.78 -> 1.73 ms; BN254 G2 5.48 -> 5.2 ms; 2^19: 1.33 -> 1.25 ms) and the arbitrary sizes of
 // real proving keys.
-// Small MSMs (round 4, profiles/r04_zj_plan_sweep.log, r04_zk_short_lanes.log, interleaved): the round-count model above prices a
+// Small MSMs (round 4, profiles/archive/r04_zj_plan_sweep.log, r04_zk_short_lanes.log, interleaved): the round-count model above prices a
 // SIMD with ONE wave on it, but a group whose accumulate kernel fits `occ` waves per SIMD (BN254 G1: 144 VGPRs -> 3) runs them
 // interleaved, and with fewer than occ waves per SIMD in the whole launch the shorter lane wins: 2^15 c = 11 L = 16 -> 8 0.440 ->
 // 0.371 ms, 2^16 c = 12 L = 23 -> 12 0.489 -> 0.426, 2^17 c = 13 L = 21 -> 12..16 0.569 -> 0.531..0.534; at 2^18 (L = 27 = exactly
@@ -685,7 +685,7 @@ inline uint32_t choose_lane_length(size_t n, int W, int occ = 1) {
     }
     if (rounds <= 1) break;  // one round already: longer lanes only cost
   }
-  // Round 5 (after balanced windows; profiles/r05_f_ab_lane_floor.log, r05_g_ab_narrow_lane_length.log, r05_h_ab_lane_lengths_large.log,
+  // Round 5 (after balanced windows; profiles/archive/r05_f_ab_lane_floor.log, r05_g_ab_narrow_lane_length.log, r05_h_ab_lane_lengths_large.log,
   // interleaved, BN254 G1 / BLS12-381 G1 / Grumpkin): the lane that fills THREE waves per SIMD is the best or within 1 % of it on every G1
   // group at 2^15 .. 2^18, also where the kernel's registers only admit two (BLS12-381 G1 2^17: 14 against the former 20, -9.7 %; more,
   // shorter waves beat one full round), and from ~10^6 entries on a lane shorter than 12 entries loses to the partial sums it leaves the
@@ -718,7 +718,7 @@ inline uint32_t reduce_segments(uint32_t NB, int W, int lanes_per_segment) {
 
 // Balanced windows (round 5). Uniform c-bit windows leave the top window whatever bits remain: 3 of 12 at 2^16 (c = 12, W = 22), 2 of 11 at
 // 2^15, 8 of 13 at 2^17 / 2^18 -- a window that costs its n additions like every other, whose few buckets hold n / 4 .. n / 128 entries
-// each (the oversized-bucket path: k_msm_giant_slices + k_msm_merge_giant 48 us of a 417 us MSM at 2^16, profiles/r04_zp_msm_2p16_kernel_stats.csv)
+// each (the oversized-bucket path: k_msm_giant_slices + k_msm_merge_giant 48 us of a 417 us MSM at 2^16, profiles/archive/r04_zp_msm_2p16_kernel_stats.csv)
 // and whose bucket stage is sized like a full one. Here W windows share the bits + 1 bits evenly: c = ceil((bits + 1) / W), the low
 // `wide` = bits + 1 - W (c - 1) windows take c bits, the others c - 1. c stays <= 16 (15-bit digit magnitudes). tune "msm_c" forces the
 // uniform form (tests, A/B), "msm_balanced" = 0 turns this off, "msm_w" forces W.
@@ -742,7 +742,7 @@ inline WindowPlan choose_windows(size_t n, int bits) {
   // The number of windows is the one the uniform plan's width gives (choose_c: a cost model re-fitted by sweeps in rounds 2-4); the bits
   // are then spread evenly over them. Letting the cost model pick W freely was measured first and is worse where the model is least
   // exact: 2^19 took W = 18 (c = 15, 3 wide windows) for a modelled tie with the uniform W = 17 and ran 16 % slower, 2^18 W = 19 +1 %
-  // (profiles/r05_b_ab_balanced.log).
+  // (profiles/archive/r05_b_ab_balanced.log).
   return balanced(windows_for(bits, choose_c(n, bits)));
 }
 // width of window w / bit offset of window w in a plan
@@ -765,7 +765,7 @@ inline MsmParams msm_plan(size_t n, int scalar_bits, int mont, int occ = 1) {
   p.NB = 1u << (p.c - 1);
   p.L = choose_lane_length(n, p.W, occ);
   // Narrow windows (balanced plan) hold twice the entries per bucket; giving their lanes 2 L entries would leave k_msm_merge the same
-  // number of partial sums per bucket as in a wide window. Measured (profiles/r05_g_ab_narrow_lane_length.log, interleaved, 2^14 .. 2^18,
+  // number of partial sums per bucket as in a wide window. Measured (profiles/archive/r05_g_ab_narrow_lane_length.log, interleaved, 2^14 .. 2^18,
   // three groups): +6 .. +26 % -- at these sizes the accumulate launch is a dependent chain per lane, and doubling it costs more than the
   // merge saves. One length is the default; tune "msm_variant" bit 6 (64) selects the doubled form (kept parity-tested for A/B).
   p.Ln = (p.wide < p.W && p.L <= 32 && (tune().msm_variant.load(std::memory_order_relaxed) & 64) != 0) ? 2 * p.L : p.L;
@@ -984,11 +984,11 @@ int bucket_group(const void* points, const MsmParams& p_all, const SortOut& so, 
     const int tb = tune().acc_blk.load(std::memory_order_relaxed);
     const int blk = (tb == 64 || tb == 128) ? tb : ACC_BLK;
     // tune "msm_variant" bit 1: two lanes per point on the G2 groups (curve_pair.hpp). Measured a wash against whole points
-    // per lane (profiles/r02_g_pair_stages.log): one wave of multiply-add code already saturates the SIMD's integer pipe, so
+    // per lane (profiles/archive/r02_g_pair_stages.log): one wave of multiply-add code already saturates the SIMD's integer pipe, so
     // the second wave the smaller footprint buys has nothing to fill. Kept for A/B runs and covered by the GPU parity suite.
     // Round 3: on BLS12-381 G2 the lane pair IS the default (304 VGPRs, no VGPR spills, against 419 + 6 spills): the whole-point kernel
     // measured 7.13 .. 7.85 ms at 2^20 from box to box (its accumulation-register traffic makes it the more sensitive one), the pair
-    // 7.24 .. 7.49, and 29.1 against 30.9 ms at 2^22 on the last box (profiles/r03_c_g2_acc_forms.log, r03_v_g2_acc_forms.log). Bit 1
+    // 7.24 .. 7.49, and 29.1 against 30.9 ms at 2^22 on the last box (profiles/archive/r03_c_g2_acc_forms.log, r03_v_g2_acc_forms.log). Bit 1
     // selects the other form of the group's default.
     bool pair = false;
     if constexpr (Cfg::PAIR) pair = Cfg::PAIR_ACC_DEFAULT != ((tune().msm_variant.load(std::memory_order_relaxed) & 2) != 0);
@@ -1009,7 +1009,7 @@ int bucket_group(const void* points, const MsmParams& p_all, const SortOut& so, 
   if constexpr (Cfg::PAIR) form = (variant & 1) ? 1 : ((variant & 4) ? 0 : 2);
   else form = (variant & 1) ? 0 : 1;
   // tune "msm_variant" bit 4 (16): the reduction merges a bucket's partial slots itself (fused merge above) instead of reading the
-  // dense array of a separate merge launch. Measured (profiles/r03_i_fused_merge.log): it LOSES on G1 -- tail 0.36 against 0.33 ms at
+  // dense array of a separate merge launch. Measured (profiles/archive/r03_i_fused_merge.log): it LOSES on G1 -- tail 0.36 against 0.33 ms at
   // 2^20, 0.69 / 0.46 at 2^22, 1.00 / 0.54 at 2^24 (at L = 256 a bucket spans 2-3 lanes: the extra additions sit on the reduction's
   // dependent chain, while the merge launch does them with one quad per bucket, all buckets at once) and gains 5 % of the tail on
   // BLS12-381 G2 only. Kept as a parity-tested variant; the separate merge launch stays the default.
@@ -1024,10 +1024,10 @@ int bucket_group(const void* points, const MsmParams& p_all, const SortOut& so, 
   hipLaunchKernelGGL(k_msm_merge_giant<Cfg>, dim3(bb.giant_blocks), dim3(256), 0, st, p, start, partial, dense, giant, giant + 2, big, gscratch);
   // Window reduction, three forms of the same segment walk, each with as many segments as fit one round of its waves
   // (reduce_segments): four lanes per point (curve_quad.hpp; the default on the G1 groups: BN254 G1 2^20 tail 0.41 -> 0.33 ms,
-  // BLS12-381 G1 0.96 -> 0.80 ms against the lane-serial form at equal launch width, profiles/r02_g_seg_stages3.log), two lanes
+  // BLS12-381 G1 0.96 -> 0.80 ms against the lane-serial form at equal launch width, profiles/archive/r02_g_seg_stages3.log), two lanes
   // per Fp2 point (curve_pair.hpp; the default on the G2 groups: half the registers per lane -- no spills where the whole-point
   // form needs 437-512 VGPRs + scratch -- and half the dependent chain per point operation; BN254 G2 2^20 tail 1.05 -> 0.81 ms,
-  // BLS12-381 G2 3.2 -> 2.1 ms, profiles/r02_g_seg_stages2.log), or one lane per segment. tune "msm_variant" picks another
+  // BLS12-381 G2 3.2 -> 2.1 ms, profiles/archive/r02_g_seg_stages2.log), or one lane per segment. tune "msm_variant" picks another
   // form for A/B runs and tests: G1: bit 0 -> lane-serial; G2: bit 0 -> four lanes, bit 2 -> lane-serial.
   MsmParams pr = p;  // the reduction's own segmentation (never more segments than the plan sized the buffers for)
   if (form == 1) {
@@ -1078,7 +1078,7 @@ int msm_bucket_stage(const void* points, const MsmParams* pp, const SortOut* so,
 
 // (A software pipeline over window groups on two streams -- group g's sort and tail under the accumulation of its
 // neighbours -- was built and measured: BN254 G1 2^20 2.07 -> 2.19 / 2.49 / 2.61 ms with 2 / 3 / 4 groups, 2^24 23.4 -> 25.2 /
-// 23.9 / 24.8 ms, worse on every group and size, profiles/r02_c5_pipeline.log. The accumulate workgroups hold every SIMD's
+// 23.9 / 24.8 ms, worse on every group and size, profiles/archive/r02_c5_pipeline.log. The accumulate workgroups hold every SIMD's
 // register file, so the other stream's kernels wait for them to retire: the stages serialise anyway and each group adds its
 // own ramp-up / ramp-down. Not kept; bucket_group() keeps the window-offset form it needed.)
 

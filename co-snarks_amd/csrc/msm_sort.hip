@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void k_msm_part_offsets(MsmParams p, const uin
 // -- 14 instead of 22 bytes of HBM traffic per entry over the two levels. REC = 0: the 8-byte records.
 #ifndef CSH_L1_WPE
 #define CSH_L1_WPE 8  // two 1024-lane blocks per CU (64 VGPRs instead of 75): one block's barriers and LDS phases under the other's loads;
-                      // scatter stage 0.124 -> 0.110 ms at 2^20, 0.384 -> 0.351 at 2^22 (profiles/r03_y_scatter_l1_occupancy.log)
+                      // scatter stage 0.124 -> 0.110 ms at 2^20, 0.384 -> 0.351 at 2^22 (profiles/archive/r03_y_scatter_l1_occupancy.log)
 #endif
 #if CSH_L1_WPE > 0
 #define CSH_L1_OCC __attribute__((amdgpu_waves_per_eu(CSH_L1_WPE)))
@@ -545,7 +545,7 @@ int msm_sort_launch(const MsmParams& p, const SortBuffers& b, hipStream_t st, hi
     // 4-byte intermediate records when every stored entry id fits 23 bits (n, or rows x bases with tables, <= 2^23); tune "msm_variant"
     // bit 3 forces the 8-byte records (A/B runs, tests). (4-byte records + a separate sign byte for ids up to 2^24 were
     // measured and lose to the 8-byte records: scatter 2.29 against 2.10 ms on BN254 G1 2^24 -- byte-granular scattered
-    // writes cost more than the 3 bytes per entry they save, profiles/r02_g_rec_stages.log.)
+    // writes cost more than the 3 bytes per entry they save, profiles/archive/r02_g_rec_stages.log.)
     const uint64_t max_id = p.remap_n ? (uint64_t)(p.n / p.remap_n) * p.remap_stride : (uint64_t)p.n;  // stored ids: table indices
     const bool wide_only = (tune().msm_variant.load(std::memory_order_relaxed) & 8) != 0;
     // level 2: one block per slice of about one tile of a partition (default), or -- tune "msm_variant" bit 5 -- one block per partition

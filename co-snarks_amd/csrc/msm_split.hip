@@ -233,7 +233,7 @@ int csh_comm_init_rank(const uint8_t id[CSH_COMM_ID_BYTES], int nranks, int rank
     // can act on (fall back to its own exchange) and the helper is left behind: if the bootstrap ever completes it tears the
     // communicator down itself. (RCCL's own non-blocking construction -- ncclCommInitRankConfig with blocking = 0 polled through
     // ncclCommGetAsyncError -- buys nothing on this stack (RCCL 2.27.7, ROCm 7.2): that call itself does not return while a peer is
-    // missing, with or without ncclCommAbort, profiles/r04_s_rccl_deadline.log. The helper therefore makes the plain blocking call,
+    // missing, with or without ncclCommAbort, profiles/archive/r04_s_rccl_deadline.log. The helper therefore makes the plain blocking call,
     // the path every RCCL user exercises; tune "comm_nonblocking" = 1 selects the other one. One rank cannot wait for anybody and is
     // built inline.)
     const long timeout_ms = tune().comm_timeout_ms.load(std::memory_order_relaxed);

@@ -155,7 +155,7 @@ __device__ __forceinline__ LZ load_sliced_twiddle(const F* __restrict__ twl, siz
 // its lane group (checked exhaustively over GF(2) for all rounds q = 0..9, tile and strided passes, with one or two components per entry;
 // only the 32-lane read of the single left-over radix-2 stage at q = 0 keeps a 2-way conflict), while runs of >= 32 consecutive entries
 // (tile load / store, late rounds) stay conflict-free: the map permutes entries inside aligned blocks of 128. Two instructions per address.
-// SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE of k_ntt_pass_r4 before: 0.28-0.30 (profiles/r03_f_vecops_ntt_pmc_sq.csv).
+// SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE of k_ntt_pass_r4 before: 0.28-0.30 (profiles/archive/r03_f_vecops_ntt_pmc_sq.csv).
 template <class LZ>
 struct LazyLds {
   int32_t* base;
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(NTT_MAX_THREADS) __attribute__((amdgpu_waves_per_eu
 
   // Tile load, four entries per lane with all four global loads issued before the first is consumed: written as one rolled loop
   // (load, unpack, put per iteration) every lane paid four SERIAL trips to HBM per tile -- the 0.04-0.05 ms per sweep that no butterfly
-  // stage accounts for (profiles/r04_e_ntt_per_pass.log; shortening the store tail by a third changed nothing, r04_l_ntt.log).
+  // stage accounts for (profiles/archive/r04_e_ntt_per_pass.log; shortening the store tail by a third changed nothing, r04_l_ntt.log).
   for (int base = 0; base < E; base += 4 * NT) {
     F raw[4];
 #pragma unroll
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
   // Tile load, four entries per lane with all four global loads issued before the first is consumed: written as one rolled loop
   // (load, unpack, put per iteration) every lane paid four SERIAL trips to HBM per tile -- the 0.04-0.05 ms per sweep that no butterfly
-  // stage accounts for (profiles/r04_e_ntt_per_pass.log; shortening the store tail by a third changed nothing, r04_l_ntt.log).
+  // stage accounts for (profiles/archive/r04_e_ntt_per_pass.log; shortening the store tail by a third changed nothing, r04_l_ntt.log).
   for (int base = 0; base < E; base += 4 * NT) {
     F raw[4];
 #pragma unroll
@@ -615,7 +615,7 @@ struct Pass {
 
 // log2(field elements per LDS tile) for a transform of 2^L entries of 2^ncomp_log elements. The tile is the unit of parallelism (one
 // workgroup each): 2^11-element tiles give a 2^16-point transform 32 workgroups for 256 CUs and make every workgroup walk 11 dependent
-// stages, so small transforms were latency-bound on a handful of CUs. Measured, interleaved (profiles/r04_o_ntt_small.log, ms per
+// stages, so small transforms were latency-bound on a handful of CUs. Measured, interleaved (profiles/archive/r04_o_ntt_small.log, ms per
 // transform, 2^11-element tiles -> best): 2^12 0.038 -> 0.015 (2^8), 2^14 0.043 -> 0.017 (2^8), 2^16 0.048 -> 0.021 (2^9), 2^17
 // 0.052 -> 0.028 (2^9), 2^18 0.058 -> 0.039 (2^10); 2^19 .. 2^21 are best at 2^11 (more passes cost more than the parallelism gains);
 // from 2^22 elements on 2^10-element tiles (four independent tiles per CU instead of two: their load / compute / store phases
@@ -636,7 +636,7 @@ static int plan_passes(int L, int ncomp_log, Pass* out) {
   // Contiguous run of a strided pass: 2^cb entries of ncomp x 32 bytes. 64-byte runs cost nothing against 256-byte ones and save a whole
   // sweep where the stages then fit two passes: 2^20 points 11 + 9 stages (128-byte runs) instead of 11 + 5 + 4, inverse / forward 0.143 / 0.135 ->
   // 0.132 / 0.123 ms, share pairs 0.258 / 0.259 -> 0.246 / 0.242 ms; 2^21 points 11 + 10 (64-byte runs) 0.268 / 0.285 -> 0.261 / 0.270
-  // (profiles/r03_q_ntt_runs.log, r03_r_ntt_tiles.log, r03_s_ntt_runs64.log).
+  // (profiles/archive/r03_q_ntt_runs.log, r03_r_ntt_tiles.log, r03_s_ntt_runs64.log).
   // 32-byte runs do not pay (2^22 as 11 + 11: 0.53 -> 0.60 ms), nor do 2^12-entry tiles at one tile per CU (2^22 as 12 + 10: 0.53 -> 0.55,
   // 2^24 2.2 -> 2.4 ms). tune "ntt_variant" bits 4-6 = log2(run entries) + 1 overrides the run length for A/B runs (0: this default).
   const int nv_run = (tune().ntt_variant.load(std::memory_order_relaxed) >> 4) & 7;
@@ -760,7 +760,7 @@ static int run_ntt(const Domain* d, F* data, uint32_t ncomp, bool dif, hipStream
       // Radix-4 pass (two stages per LDS round trip, 512 lanes per tile) or radix-2 pass. With the staged twiddle tables and two
       // folds per decimation-in-frequency round the radix-4 pass wins from 2^20 points on (one box, inverse / forward ms: 2^22
       // 0.583 / 0.541 -> 0.553 / 0.526, 2^24 2.36 / 2.04 -> 2.31 / 2.06, 2^20 0.153 / 0.142 -> 0.150 / 0.141; another box 2^22 forward
-      // 0.549 -> 0.510) and ties or loses below (profiles/r03_k_ntt_staged.log, r03_l_ntt_mix.log). Default: transforms of >= 2^20
+      // 0.549 -> 0.510) and ties or loses below (profiles/archive/r03_k_ntt_staged.log, r03_l_ntt_mix.log). Default: transforms of >= 2^20
       // points take it; tune "ntt_variant" 1 forces it everywhere, 2 forces the radix-2 pass.
       const int nv = tune().ntt_variant.load(std::memory_order_relaxed);
       const bool r4_default = L >= 20;

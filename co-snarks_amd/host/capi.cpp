@@ -14,7 +14,29 @@
 #include "plonk_honk.hpp"
 #include "zkey.hpp"
 
+#include <malloc.h>
 #include <sys/random.h>
+
+namespace {
+// The prover's large host vectors (32 MB masks, h, half shares at 2^20) are malloc'ed and freed once per proof; glibc serves blocks of
+// that size with mmap and returns them with munmap, so every proof pays tens of thousands of page faults and two or three multi-ms
+// unmaps that stall every other thread of the process behind the address-space lock (round 6: freeing the two mask vectors of one Rep3
+// witness map cost ~8 ms on the calling thread; moved to a background thread the same cost reappeared in the page faults of the next
+// allocation, profiles/r06_m_retain_ab.log). The mirror therefore asks glibc to keep such blocks in its heap (no mmap per block, no
+// trim): what jemalloc / mimalloc -- the allocators a Rust prover usually links -- do by default. Measured at 2^20 (same log): plain
+// trait-path prove 16.8-18.2 -> 14.7-14.9 ms, a seeded Rep3 party 19.2 -> 16.8-17.0 ms, three of them on one GPU 64 -> 40-47 ms; the
+// host-mask party 40-42 -> 39 ms (its mask draw gets SLOWER on retained pages, 12 -> 20 ms, while everything around it gets faster).
+// COG16_MALLOC_RETAIN=0 leaves glibc alone.
+struct MallocRetain {
+  MallocRetain() {
+    const char* e = getenv("COG16_MALLOC_RETAIN");
+    if (e && atoi(e) == 0) return;
+    (void)mallopt(M_MMAP_THRESHOLD, 1 << 30);
+    (void)mallopt(M_TRIM_THRESHOLD, (int)((1u << 31) - 1));
+    (void)mallopt(M_TOP_PAD, 64 << 20);
+  }
+} g_malloc_retain;
+}  // namespace
 
 namespace cosnarks {
 void secure_random_bytes(void* out, size_t n) {
@@ -536,7 +558,7 @@ static size_t median_index(const std::vector<double>& v) {
 }
 
 // Every figure is the MEDIAN of `iters` runs after warm-up runs (median of >= 20; rounds 1-4 reported the minimum, which hid
-// a 17.7 -> 40 ms spread on one box, profiles/r04_zd_trait_modes.log); *_min entries keep the minimum beside it.
+// a 17.7 -> 40 ms spread on one box, profiles/archive/r04_zd_trait_modes.log); *_min entries keep the minimum beside it.
 // rep3_trait_out (nullable, 2 x 13 doubles: [0..12] host masks = the shim's default, [13..25] seeded device masks = its opt-in
 // all-GPU-parties mode): {three parties on this GPU: wall ms median, min; party 0 of the median run: mask draw, witness map (incl. masks),
 // to_half_share, five MSMs, finish; proofs equal the plain proof (1 / 0); ONE party alone on the GPU, no peers (witness map + to_half_share

@@ -175,11 +175,13 @@ struct CircomReduction {
     const UninitBuf<Fr> mask_c = T::masks(state, domain_size);   // "c: local_mul_vec" (:160)
     const UninitBuf<Fr> mask_ab = T::masks(state, domain_size);  // "ab" (:182)
     last_prove_times().mask_ms = ms_since(t_mask0);
+    const auto t_call0 = std::chrono::steady_clock::now();
     rc = csh_groth16_witness_map_masks(domain, (const uint64_t*)&coset_shift, T::PROTOCOL, state.id, matrices.a_dev, matrices.b_dev, num_constraints,
                                        (const uint64_t*)public_inputs.data(), num_inputs, (const uint64_t*)private_witness.data(), private_witness.size(),
                                        mask_c.empty() ? nullptr : (const uint64_t*)mask_c.data(), mask_ab.empty() ? nullptr : (const uint64_t*)mask_ab.data(),
                                        (uint64_t*)h.data());
     check(rc, "csh_groth16_witness_map_masks");
+    if (getenv("COG16_TRACE_WM")) fprintf(stderr, "[wm trait] draw %.3f ms, call %.3f ms\n", last_prove_times().mask_ms, ms_since(t_call0));
     return h;
   }
 

@@ -88,7 +88,7 @@ inline size_t host_threads() {
     if (k == 0) k = 1;
     // a cgroup CPU quota below the affinity count (16 CPUs' worth of time on a 256-CPU host): more runnable threads than the quota only
     // get the whole group throttled for the rest of the scheduler period (the mask draw of a Rep3 party took 67 ms with 64 threads on
-    // such a box, profiles/r05_d_bench_20_5.log)
+    // such a box, profiles/archive/r05_d_bench_20_5.log)
     if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
       long long quota = 0, period = 0;
       char q[32] = {0};
@@ -142,7 +142,7 @@ struct ProverDevices {
 // the five MSM groups, the finish (openings, a few point operations)
 // Allocated, never zero-filled host memory for a result that is written in full: what `Vec::with_capacity(n)` + `set_len(n)` (or a
 // `.collect()` into a fresh Vec) is in Rust. (A value-initialised std::vector of 32 MB costs 4.7 ms of page faults and zero fill on the
-// GPU hosts, profiles/r04_b_prefault_probe.jsonl; the library populates the pages of its results from helper threads while the device works.)
+// GPU hosts, profiles/archive/r04_b_prefault_probe.jsonl; the library populates the pages of its results from helper threads while the device works.)
 template <class E>
 struct UninitBuf {
   E* p = nullptr;

@@ -42,7 +42,9 @@
  *  - csh_comm_init_rank with nranks > 1 runs the collective ncclCommInitRank on a helper thread against "comm_timeout_ms"; a helper
  *    whose peers never arrive is ABANDONED (still blocked inside RCCL after the call returned its error): leave such a process
  *    through _exit.
- *  Everything else (csh_msm*, csh_msm_split*, every *_dev entry point) runs on the calling thread only.
+ *  Everything else (csh_msm_dev / _multi_dev / _partial_dev, csh_msm_split*, every other *_dev entry point) runs on the calling thread
+ *  only. Page-locked staging memory is bounded: at most 32 MiB per (thread lane, stream, slot) -- larger transfers cycle through a ring
+ *  of 2 MiB chunks (round 6).
  */
 #ifndef COSNARKS_HIP_H
 #define COSNARKS_HIP_H
@@ -83,8 +85,10 @@ int csh_device_count(int* count);
  * no entry point reads the environment afterwards). Keys: "msm_c" (forced window width, 0 = cost model), "msm_l" (entries per
  * accumulate lane, 0 = round-count cost model), "msm_seg_buckets" (buckets per window-reduction segment, 0 = as many segments
  * as fit one round of waves), "msm_timing" (record csh_msm_last_timing), "msm_no_table", "msm_multi_overlap", "acc_blk",
- * "sort_two_level" (-1 auto), "vec_max_blocks", "ntt_lazy", "ntt_threads", "ntt_variant", "allow_unmasked_rep3" (see
- * csh_rep3_local_mul_vec), "msm_variant" (bit mask of non-default kernel forms, same results: bit 0 = window reduction
+ * "sort_two_level" (-1 auto), "vec_max_blocks", "ntt_lazy", "ntt_threads", "ntt_variant" (A/B forms with equal results; its timing-experiment
+ * bits 12-13 / 16-19 and "allow_unmasked_rep3" return WRONG / unmasked results and exist only in builds with -DCSH_EXPERIMENTS: the product
+ * library refuses them with CSH_ERR_INVALID and never takes them from the environment), "msm_wide_lb" / "msm_wide_chunks" (wide sort
+ * stage of the fixed-base MSM: log2 buckets per second-level partition 8 .. 11, first-level blocks; 0 = defaults), "msm_variant" (bit mask of non-default kernel forms, same results: bit 0 = window reduction
  * lane-serial on G1 / four-lane on G2, bit 1 = the other form of the G2 accumulate kernel (BN254 G2: two lanes per point instead of whole points; BLS12-381 G2: whole
  * points instead of two lanes per point), bit 2 = lane-serial window
  * reduction on G2, bit 3 = 8-byte sort records at every size, bit 4 = merge fused into the window reduction, bit 5 = level 2 of the
@@ -276,7 +280,7 @@ int csh_vec_mul_table(csh_curve_t field_of, uint64_t* v, const uint64_t* table, 
 /* out[i] = l.a*r.a + l.a*r.b + l.b*r.a + mask[i]: Rep3 local_mul_vec (rep3/arithmetic.rs:132-146,
  * arithmetic/ops.rs:69-76); mask = Rep3Rand::masking_field_elements_vec (rngs.rs:137-156). The reference always adds the
  * mask: an unmasked product leaks cross terms once opened, so mask == NULL (and NULL masks / seeds of every protocol-1 entry
- * point below) is refused with CSH_ERR_INVALID unless csh_tune_set("allow_unmasked_rep3", 1) was called (arithmetic unit tests). */
+ * point below) is refused with CSH_ERR_INVALID (the override "allow_unmasked_rep3" exists only in builds with -DCSH_EXPERIMENTS; pass an all-zero mask vector to test the arithmetic). */
 int csh_rep3_local_mul_vec(csh_curve_t field_of, const uint64_t* lhs_ab, const uint64_t* rhs_ab,
                            const uint64_t* mask, uint64_t* out, size_t n);
 /* out[i] = in[i].a*x + in[i].b*y: translate_primefield_repshare_vec (bridges/rep3_to_shamir.rs:43-62) */

@@ -365,3 +365,24 @@ def test_concurrent_host_pointer_callers_while_the_copy_mode_flips(gpu):
     for d in doms.values():
         d.free()
 
+
+
+def test_large_host_transfers_go_through_a_bounded_staging_ring(gpu):
+    """staged transfers used to page-lock a buffer of the FULL transfer size per (lane, stream, slot) for the life of
+    the process. Round 6: at most 32 MiB per slot -- larger uploads and results cycle through a ring of 2 MiB chunks. Host-pointer vec_add
+    (two uploads + one staged result) at sizes around the ring boundaries and well beyond is bit-identical to the CPU restatement, and the
+    page-locked memory the library holds afterwards stays within a few ring sizes."""
+    from oracle import cbridge
+    B = gpu.bindings
+    ring = 32 << 20
+    before = B.tune_get("stat_pinned_kib")
+    rs = np.random.RandomState(99)
+    for nbytes in (ring - 32, ring, ring + 32, ring + (16 << 20) + 96, 3 * ring + (2 << 20) + 32, 200 << 20):
+        n = nbytes // 32
+        a = rs.randint(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+        b = rs.randint(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+        got = gpu.vec_add(0, a, b)
+        assert np.array_equal(np.asarray(got).reshape(-1), cbridge.vec_add(0, a, b).reshape(-1)), nbytes
+    held = (B.tune_get("stat_pinned_kib") - before) << 10
+    assert held <= 6 * ring, held          # uploads use two slots of this lane, the result one: nowhere near the 600 MB of the last case
+    assert B.tune_get("stat_h2d_staged") > 0 and B.tune_get("stat_d2h_staged") > 0

@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
 """Back-to-back launches of the share-vector kernels and of one NTT round trip (for rocprofv3 kernel-trace averages that can be
 compared with bench.py's HIP-event averages over the same back-to-back pattern)."""
+import argparse
 import ctypes as C
 import json
 import os
 import sys
+import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -12,7 +14,24 @@ import numpy as np
 import cosnarks_amd as hip
 from cosnarks_amd import bindings as B
 
+ap = argparse.ArgumentParser()
+ap.add_argument("--spinup-s", type=float, default=0.5, help="untimed back-to-back work before each measured loop (the clocks of an idle GPU need "
+                "a few hundred ms to come up: VERDICT r5 #2b -- the round-5 kernel-trace averages were ~20 transforms on a cold GPU)")
+args = ap.parse_args()
 L = hip.lib()
+
+
+def spin(fn, seconds):
+    """fn() back to back for `seconds` (synchronising every 20 calls)"""
+    t0, k = time.perf_counter(), 0
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(20):
+            fn()
+        B.sync()
+        k += 20
+    return k
+
+
 rs = np.random.RandomState(1)
 n = 1 << 24
 a = hip.DeviceBuffer.from_host(rs.randint(0, 1 << 62, size=(2 * n, 4), dtype=np.uint64))
@@ -22,6 +41,7 @@ o = hip.DeviceBuffer(n * 32)
 f = lambda: B._check(L.csh_rep3_local_mul_vec_dev(0, a.ptr, b.ptr, m.ptr, o.ptr, C.c_size_t(n), None))
 for _ in range(3):
     f()
+spun = spin(f, args.spinup_s)
 e0, e1 = B.Event(), B.Event()
 e0.record()
 for _ in range(20):
@@ -43,9 +63,17 @@ dom = hip.Domain(hip.BN254, logn, gen)
 v = rs.randint(0, 1 << 62, size=(1 << logn, 4), dtype=np.uint64)
 d = hip.DeviceBuffer.from_host(v)
 dom.ifft_in_to_out_dev(d, 1)
-e0.record()
-for _ in range(10):
+
+
+def pair():
     dom.ifft_in_to_out_dev(d, 1)
     dom.fft_out_to_in_dev(d, 1)
+
+
+spun_ntt = 2 * spin(pair, args.spinup_s)
+e0.record()
+for _ in range(100):
+    pair()
 e1.record()
-print(json.dumps({"op": "ntt 2^22 x20 back to back", "avg_ms": round(e0.elapsed_ms(e1) / 20, 4)}), flush=True)
+print(json.dumps({"op": "ntt 2^22 x200 back to back", "avg_ms": round(e0.elapsed_ms(e1) / 200, 4), "untimed_transforms_before": spun_ntt,
+                  "spinup_s": args.spinup_s}), flush=True)

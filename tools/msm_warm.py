@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Warm MSM timings: the clocks of an idle GPU take tens of ms of continuous work to come up (profiles/r04_j_ntt_context.log), so a handful of
+"""Warm MSM timings: the clocks of an idle GPU take tens of ms of continuous work to come up (profiles/archive/r04_j_ntt_context.log), so a handful of
 calls after process start under-reports small sizes by 10-20 %. Per job: WARM untimed calls, then the median wall time of REPS synchronous
 csh_msm_dev calls (result on the host, host fold included) and the stage times of the best one.
     python tools/msm_warm.py [--reps 60] [--warm 60] [--c C] curve:group:logn ..."""
