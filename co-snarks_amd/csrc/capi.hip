@@ -454,6 +454,8 @@ static const TuneEntry kTune[] = {
     {"msm_wide_chunks", "CSH_MSM_WIDE_CHUNKS", &Tune::msm_wide_chunks},
     {"allow_unmasked_rep3", "CSH_ALLOW_UNMASKED_REP3", &Tune::allow_unmasked_rep3},
     {"ntt_variant", "CSH_NTT_VARIANT", &Tune::ntt_variant},
+    {"ntt_pair", "CSH_NTT_PAIR", &Tune::ntt_pair},
+    {"ntt_pair_min_log", "CSH_NTT_PAIR_MIN_LOG", &Tune::ntt_pair_min_log},
     {"h_unfused", "CSH_H_UNFUSED", &Tune::h_unfused},
     {"host_populate", "CSH_HOST_POPULATE", &Tune::host_populate},
     {"host_d2h", "CSH_HOST_D2H", &Tune::host_d2h},

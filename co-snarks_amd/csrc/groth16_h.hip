@@ -55,12 +55,10 @@ int csh_groth16_h_dev(csh_domain_t dom, const uint64_t shift[4], int protocol, u
       CSH_TRY(csh_rep3_local_mul_vec_dev(f, a, b, mask_c, ab, n, st));                       // :160
     else
       CSH_TRY(csh_vec_mul_dev(f, a, b, ab, n, st));
-    for (uint64_t* v : {a, b}) {                                                             // :139-155
-      CSH_TRY(ntt_run_dif_table(d, v, ncomp, table, st));                                    // ifft_in_to_out + distribute_powers
-      CSH_TRY(ntt_run(d, v, ncomp, false, st));
-    }
-    CSH_TRY(ntt_run_dif_table(d, ab, 1, table, st));                                         // :163-171
-    CSH_TRY(ntt_run(d, ab, 1, false, st));                                                   // :174
+    // round 6: ifft_in_to_out + distribute_powers + fft_out_to_in per vector with the two passes over the contiguous tiles in ONE launch
+    // (ntt_run_pair_table: the tile stays in LDS across the hand-over; tune "ntt_pair" = 0: two launches as in rounds 3-5)
+    for (uint64_t* v : {a, b}) CSH_TRY(ntt_run_pair_table(d, v, ncomp, table, st));          // :139-155
+    CSH_TRY(ntt_run_pair_table(d, ab, 1, table, st));                                        // :163-174
     if (protocol == 1)
       CSH_TRY(rep3_local_mul_sub_dev(f, a, b, mask_ab, ab, h_out, n, st));                   // :182-190 (ab aliases h_out: element-wise)
     else

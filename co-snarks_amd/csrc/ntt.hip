@@ -312,9 +312,16 @@ __global__ __launch_bounds__(NTT_MAX_THREADS) __attribute__((amdgpu_waves_per_eu
 // operand classes: a round starts from normalised values, the second stage multiplies two-term sums, the outputs are normalised
 // once; in decimation in frequency every sum is folded), so the limb-bound contracts checked by the host self-test carry over.
 // An odd stage count leaves one radix-2 stage (last in DIT, last = local stage 0 in DIF).
-template <class F, class LZ, bool DIF>
+// PAIR (round 6; DIF must be true, s0 = 0): the LAST pass of an inverse transform (decimation in frequency, table `twl`) and the FIRST
+// pass of the forward transform that follows it in a witness map (decimation in time, table `twl_fwd`) work on the same contiguous
+// tiles -- ifft_in_to_out, coset table, fft_out_to_in of reduction.rs:141-174 -- so one launch keeps the tile in LDS across both:
+// DIF rounds, the scale (1/n, or the per-entry table carrying 1/n times the coset power) and the canonical form a store + load would
+// have left, DIT rounds, one store. One HBM sweep, one launch and one LDS fill less per pair; the field elements are the same.
+template <class F, class LZ, bool DIF, bool PAIR = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_ntt_pass_r4(F* __restrict__ data, const F* __restrict__ twl, int L, int s0, int k,
-                                                                                             int cb, int ncomp_log, F scale_lazy, int do_scale, const F* __restrict__ scale_tbl) {
+                                                                                             int cb, int ncomp_log, F scale_lazy, int do_scale, const F* __restrict__ scale_tbl,
+                                                                                             const F* __restrict__ twl_fwd = nullptr) {
+  static_assert(!PAIR || DIF, "the pair kernel starts with the decimation-in-frequency half");
   extern __shared__ uint4 lds_raw[];
   const int cc_log = cb + ncomp_log;
   const int CC = 1 << cc_log;
@@ -356,12 +363,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   __syncthreads();
 
   // twiddle of global stage s0 + q for the pair whose lower index has local stage bits t_lo (< 2^q)
-  auto twiddle = [&](int q, int t_lo, int cc) {
+  auto twiddle = [&](const F* __restrict__ tw, int q, int t_lo, int cc) {
     const size_t imod = ((size_t)t_lo << s0) | (mid << cb) | (size_t)(cc >> ncomp_log);
-    return load_sliced_twiddle<F, LZ>(twl, ((size_t(1) << (s0 + q)) - 1) + imod, (size_t(1) << L) - 1);  // staged table
+    return load_sliced_twiddle<F, LZ>(tw, ((size_t(1) << (s0 + q)) - 1) + imod, (size_t(1) << L) - 1);  // staged table
   };
   // stages (q, q + 1) on the four entries t0 + {0, 1, 2, 3} * 2^q of every unit
-  auto round4 = [&](int q) {
+  auto round4 = [&](auto dif_c, const F* __restrict__ tw, int q) {
+    constexpr bool D = decltype(dif_c)::value;
     const int quarter_E = E >> 2;
     for (int u = tid; u < quarter_E; u += NT) {
       const int cc = u & (CC - 1);
@@ -371,13 +379,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       const int e0 = (t0 << cc_log) | cc;
       const int st = 1 << (q + cc_log);
       LZ x0 = lds.get(e0), x1 = lds.get(e0 + st), x2 = lds.get(e0 + 2 * st), x3 = lds.get(e0 + 3 * st);
-      if (DIF) {
+      if constexpr (D) {
         // Value / limb bounds of a round (inputs: normalised limbs, values within (-p, 2.2 p)): the first stage's sums stay below
         // 4.4 p and only take the parallel carry step (their differences, < 6.5 p in magnitude with two-term limbs, are admissible
         // product operands: the contract is |value| < 8 p); the second stage's sum of sums (< 8.8 p) is folded below 2 p; the sum of
         // the two fresh products (< 2.2 p) again only takes the carry step. Two folds per round instead of four.
         {  // stage q + 1: (x0, x2) with w, (x1, x3) with w * omega^(n/4)
-          const LZ w2 = twiddle(q + 1, t_lo, cc), w3 = twiddle(q + 1, t_lo + (1 << q), cc);
+          const LZ w2 = twiddle(tw, q + 1, t_lo, cc), w3 = twiddle(tw, q + 1, t_lo + (1 << q), cc);
           LZ d02, d13;  // the two products of a fold are independent: their multiply-adds alternate (FpS::mul2)
           LZ::mul2(LZ::sub(x0, x2), w2, LZ::sub(x1, x3), w3, d02, d13);
           x0 = LZ::add(x0, x2).normalized();
@@ -386,7 +394,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
           x3 = d13;
         }
         {  // stage q: (x0, x1), (x2, x3), one twiddle
-          const LZ w1 = twiddle(q, t_lo, cc);
+          const LZ w1 = twiddle(tw, q, t_lo, cc);
           LZ d01, d23;
           LZ::mul2(LZ::sub(x0, x1), w1, LZ::sub(x2, x3), w1, d01, d23);
           x0 = LZ::add(x0, x1).fold_top();
@@ -396,7 +404,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
       } else {
         {  // stage q: inputs normalised, outputs two-term sums (admissible product operands as they are)
-          const LZ w1 = twiddle(q, t_lo, cc);
+          const LZ w1 = twiddle(tw, q, t_lo, cc);
           LZ p1, p3;
           LZ::mul2(x1, w1, x3, w1, p1, p3);
           x1 = LZ::sub(x0, p1);
@@ -405,7 +413,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
           x2 = LZ::add(x2, p3);
         }
         {  // stage q + 1: the carry step runs once per round, on the outputs
-          const LZ w2 = twiddle(q + 1, t_lo, cc), w3 = twiddle(q + 1, t_lo + (1 << q), cc);
+          const LZ w2 = twiddle(tw, q + 1, t_lo, cc), w3 = twiddle(tw, q + 1, t_lo + (1 << q), cc);
           LZ p2, p3;
           LZ::mul2(x2, w2, x3, w3, p2, p3);
           x2 = LZ::sub(x0, p2).normalized();
@@ -429,16 +437,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   // meets it last, on normalised values within (-p, 2.2 p): sums are carried / folded stage by stage as in the general round; the two
   // differences that are no longer passed through a multiplication stay two- or (carried) three-term sums within (-6.4 p, 6.4 p) and
   // leave through the tail's mul / canonical_wide, whose contracts (two-term limbs, |value| < 8 p resp. 32 p) they meet.
-  auto round4_unit = [&]() {
+  auto round4_unit = [&](auto dif_c, const F* __restrict__ tw) {
+    constexpr bool D = decltype(dif_c)::value;
     const int quarter_E = E >> 2;
-    const LZ w4 = twiddle(1, 1, 0);  // omega^(n/4) (forward table) / its inverse (inverse table): staged entry 2
+    const LZ w4 = twiddle(tw, 1, 1, 0);  // omega^(n/4) (forward table) / its inverse (inverse table): staged entry 2
     for (int u = tid; u < quarter_E; u += NT) {
       const int cc = u & (CC - 1);
       const int tb = u >> cc_log;
       const int e0 = ((tb << 2) << cc_log) | cc;
       const int st = 1 << cc_log;
       LZ x0 = lds.get(e0), x1 = lds.get(e0 + st), x2 = lds.get(e0 + 2 * st), x3 = lds.get(e0 + 3 * st);
-      if (DIF) {
+      if constexpr (D) {
         const LZ d13 = LZ::mul(LZ::sub(x1, x3), w4);   // stage 1, second pair
         const LZ d02 = LZ::sub(x0, x2);                // stage 1, first pair: times 1
         x0 = LZ::add(x0, x2).normalized();
@@ -465,7 +474,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   };
   // one radix-2 stage (odd stage counts): the radix-2 pass's butterfly; in DIT it is the pass's last stage (outputs leave
   // through mul / canonical_wide, which take two-term limbs), in DIF its inputs come normalised out of the last round
-  auto stage2 = [&](int q) {
+  auto stage2 = [&](auto dif_c, const F* __restrict__ tw, int q) {
+    constexpr bool D = decltype(dif_c)::value;
     const int half_E = E >> 1;
     const int half = 1 << q;
     for (int bidx = tid; bidx < half_E; bidx += NT) {
@@ -478,12 +488,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       const LZ u = lds.get(e0);
       const LZ v = lds.get(e1);
       if (unit_skip && s0 + q == 0) {  // global stage 0: twiddle 1 everywhere (wave-uniform branch)
-        lds.put(e0, DIF ? LZ::add(u, v).fold_top() : LZ::add(u, v));
+        lds.put(e0, D ? LZ::add(u, v).fold_top() : LZ::add(u, v));
         lds.put(e1, LZ::sub(u, v));
         continue;
       }
-      const LZ w = twiddle(q, t_lo, cc);
-      if (DIF) {
+      const LZ w = twiddle(tw, q, t_lo, cc);
+      if constexpr (D) {
         lds.put(e0, LZ::add(u, v).fold_top());
         lds.put(e1, LZ::mul(LZ::sub(u, v), w));
       } else {
@@ -495,24 +505,44 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     __syncthreads();
   };
   const bool unit_round = unit_skip && s0 == 0 && k >= 2;
+  auto rounds = [&](auto dif_c, const F* __restrict__ tw) {
+    constexpr bool D = decltype(dif_c)::value;
+    if constexpr (D) {
+      int q = k;
+      for (; q >= 2; q -= 2) {
+        if (q == 2 && unit_round) round4_unit(dif_c, tw);
+        else round4(dif_c, tw, q - 2);
+      }
+      if (q == 1) stage2(dif_c, tw, 0);
+    } else {
+      int q = 0;
+      for (; q + 2 <= k; q += 2) {
+        if (q == 0 && unit_round) round4_unit(dif_c, tw);
+        else round4(dif_c, tw, q);
+      }
+      if (q < k) stage2(dif_c, tw, q);
+    }
+  };
+  const LZ sc = LZ::unpack(scale_lazy);
+  if constexpr (PAIR) {
+    rounds(std::true_type{}, twl);
+    // between the two transforms: what the inverse transform's last pass would have stored (scaled, canonical) and the forward
+    // transform's first pass would have loaded and unpacked -- each lane on the entries it will store, no traffic
+    for (int e = tid; e < E; e += NT) {
+      const size_t g = (size_t)tile * (size_t)E + (size_t)e;  // s0 = 0, cb = 0: the tile is contiguous
+      const LZ f = LZ::mul(lds.get(e), scale_tbl ? LZ::unpack(scale_tbl[g >> ncomp_log]) : sc);
+      lds.put(e, LZ::unpack(f.canonical_wide().pack()));
+    }
+    __syncthreads();
+    rounds(std::false_type{}, twl_fwd);
+    for (int e = tid; e < E; e += NT) data[(size_t)tile * (size_t)E + (size_t)e] = lds.get(e).canonical_wide().pack();
+    return;
+  }
   if (ablate & 1) {
-  } else if (DIF) {
-    int q = k;
-    for (; q >= 2; q -= 2) {
-      if (q == 2 && unit_round) round4_unit();
-      else round4(q - 2);
-    }
-    if (q == 1) stage2(0);
   } else {
-    int q = 0;
-    for (; q + 2 <= k; q += 2) {
-      if (q == 0 && unit_round) round4_unit();
-      else round4(q);
-    }
-    if (q < k) stage2(q);
+    rounds(std::integral_constant<bool, DIF>{}, twl);
   }
 
-  const LZ sc = LZ::unpack(scale_lazy);
   for (int e = tid; e < E; e += NT) {
     const int cc = e & (CC - 1);
     const size_t t = e >> cc_log;
@@ -715,7 +745,7 @@ static int plain_tables_get(const Domain* d, const void** fwd, const void** inv)
 }
 
 template <class F>
-static int run_ntt(const Domain* d, F* data, uint32_t ncomp, bool dif, hipStream_t st, const F* scale_tbl = nullptr) {
+static int run_ntt(const Domain* d, F* data, uint32_t ncomp, bool dif, hipStream_t st, const F* scale_tbl = nullptr, bool skip_pass0 = false) {
   const int L = (int)d->log_n;
   if (L == 0) return CSH_OK;  // size-1 transform is the identity (1/n = 1)
   const int ncomp_log = ncomp == 2 ? 1 : 0;
@@ -739,6 +769,7 @@ static int run_ntt(const Domain* d, F* data, uint32_t ncomp, bool dif, hipStream
   for (int pi = 0; pi < np; ++pi) {
     const Pass& p = dif ? passes[np - 1 - pi] : passes[pi];
     if (only_pass && (dif ? np - 1 - pi : pi) != only_pass - 1) continue;
+    if (skip_pass0 && p.s0 == 0) continue;  // run_ntt_pair: the pass over the contiguous tiles runs fused with its neighbour of the other direction
     const int tile_log = p.k + p.cb;  // entries
     const size_t tiles = d->n >> tile_log;
     // radix-2 passes: one lane per butterfly of a stage, at least one wave
@@ -931,6 +962,53 @@ static int coset_table_t(const Domain* d, const uint64_t* shift, uint64_t* out_d
 }
 
 // exposed to other translation units (fused Groth16 h pipeline)
+// ifft_in_to_out (its last pass multiplying entry i by scale_table[i], or by 1/n when the table is NULL) followed by fft_out_to_in
+// on the same vector, the two passes over the contiguous tiles fused into ONE launch (k_ntt_pass_r4<.., PAIR>): reduction.rs:141-174 per
+// vector. Falls back to the two transforms when the radix-4 pass does not apply to the plan's first pass (or tune "ntt_pair" = 0).
+template <class F>
+static int run_ntt_pair(const Domain* d, F* data, uint32_t ncomp, hipStream_t st, const F* scale_tbl) {
+  const int L = (int)d->log_n;
+  if (L == 0) return CSH_OK;
+  using LZ = typename LazyOf<F>::type;
+  const int ncomp_log = ncomp == 2 ? 1 : 0;
+  Pass passes[8];
+  const int np = plan_passes(L, ncomp_log, passes);
+  const Pass& p = passes[0];
+  const int tile_log = p.k + p.cb;
+  const bool use_lazy = tune().ntt_lazy.load(std::memory_order_relaxed) != 0;
+  const int nv = tune().ntt_variant.load(std::memory_order_relaxed);
+  const bool fusable = use_lazy && tune().ntt_pair.load(std::memory_order_relaxed) != 0 && p.s0 == 0 && p.cb == 0 && p.k >= 2 && tile_log + ncomp_log >= 2 &&
+                       (nv & ~0x100800) == 0 && L >= tune().ntt_pair_min_log.load(std::memory_order_relaxed);
+  if (!fusable) {
+    CSH_TRY(run_ntt<F>(d, data, ncomp, true, st, scale_tbl));
+    return run_ntt<F>(d, data, ncomp, false, st);
+  }
+  if (np > 1) CSH_TRY(run_ntt<F>(d, data, ncomp, true, st, scale_tbl, true));   // the strided passes of the inverse transform
+  const size_t tiles = d->n >> tile_log;
+  const size_t lds_bytes = size_t(4 * LZ::NL) << (tile_log + ncomp_log);
+  if (lds_bytes > 48 * 1024) {
+    static thread_local bool raised = false;
+    if (!raised) {
+      CSH_HIP(hipFuncSetAttribute((const void*)k_ntt_pass_r4<F, LZ, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (4 * LZ::NL) << NTT_TILE_LOG));
+      raised = true;
+    }
+  }
+  const size_t units = (size_t(1) << (tile_log + ncomp_log)) >> 2;
+  const int nt = units >= 512 ? 512 : (units >= 64 ? (int)units : 64);
+  const int noswz = ((nv & 0x800) ? 0x1000 : 0) | ((nv & 0x100000) ? 0x2000 : 0);
+  const F scale = f_from_words<F>(d->n_inv_lazy);
+  hipLaunchKernelGGL((k_ntt_pass_r4<F, LZ, true, true>), dim3((unsigned)tiles), dim3(nt), lds_bytes, st, data, reinterpret_cast<const F*>(d->tw_inv_lazy), L, p.s0, p.k,
+                     p.cb, ncomp_log, scale, 1 | noswz, scale_tbl, reinterpret_cast<const F*>(d->tw_fwd_lazy));
+  CSH_HIP(hipGetLastError());
+  if (np > 1) CSH_TRY(run_ntt<F>(d, data, ncomp, false, st, nullptr, true));   // the strided passes of the forward transform
+  return CSH_OK;
+}
+int ntt_run_pair_table(const Domain* d, uint64_t* data, uint32_t ncomp, const uint64_t* scale_table, hipStream_t st) {
+  if (d->curve == CSH_BN254) return run_ntt_pair<Bn254Fr>(d, (Bn254Fr*)data, ncomp, st, (const Bn254Fr*)scale_table);
+  if (d->curve == CSH_BLS12_377) return run_ntt_pair<Bls377Fr>(d, (Bls377Fr*)data, ncomp, st, (const Bls377Fr*)scale_table);
+  return run_ntt_pair<Bls381Fr>(d, (Bls381Fr*)data, ncomp, st, (const Bls381Fr*)scale_table);
+}
+
 int ntt_run(const Domain* d, uint64_t* data, uint32_t ncomp, bool dif, hipStream_t st) {
   if (d->curve == CSH_BN254) return run_ntt<Bn254Fr>(d, (Bn254Fr*)data, ncomp, dif, st);
   if (d->curve == CSH_BLS12_377) return run_ntt<Bls377Fr>(d, (Bls377Fr*)data, ncomp, dif, st);

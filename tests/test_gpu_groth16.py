@@ -6,9 +6,11 @@ proof verifies (tests/tests/circom/e2e_tests/rep3.rs:38-86). Plus bit-exact A/B/
 import json
 import os
 
+import numpy as np
 import pytest
 
 from oracle import groth16 as og
+from oracle import ntt
 from oracle import zkey as oz
 from tests import helpers as H
 
@@ -415,3 +417,33 @@ def test_libsnark_reduction_from_the_reference_file_formats(gpu):
     assert L.cog16_libsnark_from_files(3, a[:-5], C.c_size_t(len(a) - 5), b, C.c_size_t(len(b)), c, C.c_size_t(len(c)), w, C.c_size_t(len(w)),
                                        C.c_size_t(3), out.ctypes.data_as(C.c_void_p), C.c_size_t(exp["domain_size"])) == -1
 
+
+
+@pytest.mark.parametrize("logn", [2, 3, 8, 11, 12, 13, 16, 20, 21])
+def test_h_with_fused_tile_passes_equals_two_launch_and_unfused_forms(gpu, logn):
+    """Round 6: the last pass of each inverse transform and the first pass of the forward transform that follows it work on
+    the same contiguous tiles and run as ONE launch (k_ntt_pass_r4<.., PAIR>, default from 2^20 points; forced here at every size). h of
+    random a, b (plain: one component; Rep3: two components + both masks) is bit-identical in the three forms: fused pair, two launches
+    (tune ntt_pair = 0), and the reference's step-by-step sequence (tune h_unfused = 1) -- one-pass plans (2^2 .. 2^11), two passes, three."""
+    F = H.FR["bn254"]
+    n = 1 << logn
+    gen = ntt.roots_of_unity(F)[1][logn]
+    dom = gpu.Domain(0, logn, H.pack(F, [gen]))
+    rs = np.random.RandomState(600 + logn)
+
+    def limbs(k):
+        v = rs.randint(0, 1 << 63, size=(k, 4), dtype=np.uint64)
+        v[:, 3] >>= np.uint64(3)
+        return v
+
+    shift = H.pack(F, [ntt.roots_of_unity(F)[1][logn + 1]])
+    for protocol, comp in ((0, 1), (1, 2)):
+        a, b = limbs(n * comp), limbs(n * comp)
+        mc, mab = (limbs(n), limbs(n)) if protocol == 1 else (None, None)
+        outs = {}
+        for name, knobs in (("pair", {"ntt_pair": 1, "ntt_pair_min_log": 0}), ("two_launches", {"ntt_pair": 0}), ("unfused", {"h_unfused": 1})):
+            with gpu.tuned(**knobs):
+                outs[name] = gpu.bindings.groth16_h(dom, shift, protocol, a, b, mc, mab)
+        assert np.array_equal(outs["pair"], outs["two_launches"]), (logn, protocol)
+        assert np.array_equal(outs["pair"], outs["unfused"]), (logn, protocol)
+    dom.free()

@@ -66,6 +66,15 @@ def run(mode, persistent, reps=12):
                       "phase_ms_avg": {k[8:-3]: round(v, 3) for k, v in d.items()}}), flush=True)
 
 
+if len(sys.argv) > 2 and sys.argv[2] == "pair":      # A/B of the fused tile passes (tune ntt_pair), device phase from the library's timers
+    B.tune_set("host_timing", 1)
+    for rnd in range(3):
+        for pair in (1, 0):
+            B.tune_set("ntt_pair", pair)
+            print(json.dumps({"ntt_pair": pair, "round": rnd}), end=" ")
+            run("seeds", True, reps=20)
+    B.tune_set("ntt_pair", 1)
+    sys.exit(0)
 for timing in (0, 1):
     B.tune_set("host_timing", timing)
     for mode in ("seeds", "masks"):
