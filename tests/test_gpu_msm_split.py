@@ -76,6 +76,42 @@ def test_partial_ranges_fold_to_the_oracle_msm(gpu, curve, group, k):
     dsc.free()
 
 
+@pytest.mark.parametrize("curve,group", [("bn254", 0), ("bls12_381", 1)])
+def test_split_ranges_over_handles_with_wide_window_tables(gpu, curve, group):
+    """Round 6: ranges of a split MSM on handles that carry fixed-base tables with ONE bucket set (17 / 20-bit windows): a range's partial
+    then holds a single window sum under its own (c, W = 1) header, mixed with plain ranges (W = 17-ish) in one fold; range clones carry the
+    matching table columns. Folded result == oracle."""
+    G = cv.CURVES[curve][group]
+    F = H.FR[curve]
+    cid = H.CURVE_IDS[curve]
+    r = H.rng(4100 + group)
+    n = 2600
+    pts = H.rand_points(G, n, r, with_inf=True)
+    sc = H.rand_elems(F, n, r)
+    want = G.msm(pts, sc)
+    plain = gpu.Bases(cid, group, cv.pack_points(G, pts))
+    tabled = gpu.Bases(cid, group, cv.pack_points(G, pts)).precompute(17, 0)
+    dsc = gpu.DeviceBuffer.from_host(H.pack(F, sc))
+    cuts = [(0, 1200), (1200, 1400)]
+    # both ranges on the table handle; then one range plain and one on tables (different window layouts in one fold)
+    for handles in ([tabled, tabled], [plain, tabled]):
+        got = gpu.msm_split(handles, [o for o, _ in cuts], [c for _, c in cuts], [C.c_void_p(dsc.ptr.value + 32 * o) for o, _ in cuts],
+                            mode=gpu.bindings.SPLIT_HOST)
+        assert G.eq(H.jac_to_affine(G, got), want), [h is tabled for h in handles]
+    # a range clone of the table handle (what placement by range holds per GPU): tables included, 20-bit windows this time
+    tabled.precompute(20, 0)
+    h3 = C.c_void_p()
+    gpu.bindings._check(gpu.lib().csh_bases_clone_range(tabled.h, C.c_size_t(1200), C.c_size_t(1400), 0, C.byref(h3)))
+    out = np.zeros(3 * gpu.point_bytes(cid, group) // 16, dtype=np.uint64)
+    gpu.bindings._check(gpu.lib().csh_msm_dev(h3, C.c_size_t(0), C.c_size_t(1400), C.c_void_p(dsc.ptr.value + 32 * 1200), 1, out.ctypes.data_as(C.c_void_p), None))
+    assert gpu.bindings.msm_last_params()[:2] == [20, 1]
+    assert G.eq(H.jac_to_affine(G, out), G.msm(pts[1200:], sc[1200:]))
+    gpu.lib().csh_bases_free(h3)
+    for b in (plain, tabled):
+        b.free()
+    dsc.free()
+
+
 def test_split_all_ranges_empty_or_cancelling(gpu):
     G = cv.BN254_G1
     F = H.FR["bn254"]
