@@ -567,6 +567,17 @@ bool pinned_for(hipStream_t s, size_t bytes, void** host, void** dev) {
   return true;
 }
 
+int raise_lds_limit(const void* kernel, size_t bytes) {
+  static thread_local std::map<std::pair<const void*, int>, size_t> raised;
+  int dev = tl_device;
+  if (dev < 0 && hipGetDevice(&dev) != hipSuccess) dev = 0;
+  size_t& have = raised[{kernel, dev}];
+  if (have >= bytes) return CSH_OK;
+  CSH_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  have = bytes;
+  return CSH_OK;
+}
+
 hipStream_t resolve_aux_stream() { return tl_lanes.get(tl_device + LaneHolder::AUX_KEY)->stream; }
 
 int upload_h2d(void* dev, const void* host, size_t bytes, hipStream_t st, int slot) {

@@ -212,6 +212,11 @@ constexpr bool kExperiments = true;
 constexpr bool kExperiments = false;
 #endif
 
+// hipFuncSetAttribute(.., hipFuncAttributeMaxDynamicSharedMemorySize, bytes) once per (calling thread, device, kernel): the attribute belongs
+// to the kernel ON A DEVICE, and one host thread may drive several devices (csh_msm_split drives every GPU of the node from one thread), so
+// a per-thread "already raised" flag alone (rounds 1-5) would skip the call on every device after the first. capi.hip.
+int raise_lds_limit(const void* kernel, size_t bytes);
+
 inline int grid_for(size_t n, int block, int max_blocks = 256 * 16) {
   size_t g = (n + block - 1) / block;
   if (g < 1) g = 1;

@@ -518,25 +518,15 @@ int msm_sort_launch(const MsmParams& p, const SortBuffers& b, hipStream_t st, hi
   const uint32_t nparts = p.NB / PART_BUCKETS;
   const size_t sort_lds = sizeof(uint32_t) * p.NB;
   if (sort_lds > 48 * 1024) {
-    static thread_local bool raised = false;
-    if (!raised) {
-      CSH_HIP(hipFuncSetAttribute((const void*)k_msm_hist_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-      CSH_HIP(hipFuncSetAttribute((const void*)k_msm_scatter_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-      raised = true;
-    }
+    CSH_TRY(raise_lds_limit((const void*)k_msm_hist_lds, 128 * 1024));
+    CSH_TRY(raise_lds_limit((const void*)k_msm_scatter_lds, 128 * 1024));
   }
   hipLaunchKernelGGL(k_msm_hist_lds, dim3(p.CH, p.W), dim3(SORT_BLK), sort_lds, st, p, b.dig, b.blkcnt, two_level ? b.part_cnt : nullptr);
   hipLaunchKernelGGL(k_msm_colscan, dim3((p.NB + 255) / 256, p.W), dim3(256), 0, st, p, b.blkcnt, b.hist);
   if (ev) CSH_HIP(hipEventRecord(ev[1], st));
   {
     const size_t scan_lds = sizeof(uint32_t) * ((size_t)p.NB + 2 + 16);
-    if (scan_lds > 48 * 1024) {
-      static thread_local bool raised_scan = false;
-      if (!raised_scan) {
-        CSH_HIP(hipFuncSetAttribute((const void*)k_msm_scan, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
-        raised_scan = true;
-      }
-    }
+    if (scan_lds > 48 * 1024) CSH_TRY(raise_lds_limit((const void*)k_msm_scan, 136 * 1024));
     hipLaunchKernelGGL(k_msm_scan, dim3(p.W), dim3(1024), scan_lds, st, p, b.hist, b.start, b.nlanes);
   }
   if (ev) CSH_HIP(hipEventRecord(ev[2], st));

@@ -521,16 +521,10 @@ static int wide_launch_t(const MsmParams& p, const MsmParams& pd, const uint64_t
   const Fr* sc = reinterpret_cast<const Fr*>(scalars_dev);
   const size_t lds1 = sizeof(uint32_t) * (2 * (size_t)wp.P + 16 + 2 * (size_t)WS_BLK * pd.W);
   const size_t lds2 = sizeof(uint32_t) * (2 * (size_t)wp.B2 + 16 + W2_TILE) + sizeof(uint16_t) * W2_TILE;
-  {
-    static thread_local bool raised = false;
-    if (!raised) {
-      CSH_HIP(hipFuncSetAttribute((const void*)k_wide_scatter1<Fr, CB, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      CSH_HIP(hipFuncSetAttribute((const void*)k_wide_scatter1<Fr, CB, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      CSH_HIP(hipFuncSetAttribute((const void*)k_wide_scatter2<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      CSH_HIP(hipFuncSetAttribute((const void*)k_wide_scatter2<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      raised = true;
-    }
-  }
+  CSH_TRY(raise_lds_limit((const void*)k_wide_scatter1<Fr, CB, 0>, 160 * 1024));
+  CSH_TRY(raise_lds_limit((const void*)k_wide_scatter1<Fr, CB, 1>, 160 * 1024));
+  CSH_TRY(raise_lds_limit((const void*)k_wide_scatter2<0>, 160 * 1024));
+  CSH_TRY(raise_lds_limit((const void*)k_wide_scatter2<1>, 160 * 1024));
   CSH_REQUIRE(lds1 <= 160 * 1024, "wide sort: level-1 tile does not fit the LDS");
   hipLaunchKernelGGL((k_wide_hist1<Fr, CB>), dim3(wp.CH), dim3(WS_BLK), sizeof(uint32_t) * wp.P, st, sc, pd, wp, part_cnt, cursor, (uint32_t)len);
   hipLaunchKernelGGL(k_wide_colscan, dim3((wp.P + 31) / 32), dim3(1024), 0, st, wp, part_cnt, part_start);

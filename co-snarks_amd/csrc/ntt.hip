@@ -780,14 +780,8 @@ static int run_ntt(const Domain* d, F* data, uint32_t ncomp, bool dif, hipStream
     const int noswz = ((tune().ntt_variant.load(std::memory_order_relaxed) & 0x800) ? 0x1000 : 0) |        // LDS bank swizzle off (A/B runs)
                       ((tune().ntt_variant.load(std::memory_order_relaxed) & 0x100000) ? 0x2000 : 0);   // unit-twiddle rounds off (A/B runs)
     if (use_lazy) {
-      if (lds_bytes > 48 * 1024) {
-        static thread_local bool raised_lazy[2] = {false, false};
-        if (!raised_lazy[dif ? 1 : 0]) {
-          const void* fn = dif ? (const void*)k_ntt_pass_lazy<F, LZ, true> : (const void*)k_ntt_pass_lazy<F, LZ, false>;
-          CSH_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (4 * LZ::NL) << NTT_TILE_LOG));
-          raised_lazy[dif ? 1 : 0] = true;
-        }
-      }
+      if (lds_bytes > 48 * 1024)
+        CSH_TRY(raise_lds_limit(dif ? (const void*)k_ntt_pass_lazy<F, LZ, true> : (const void*)k_ntt_pass_lazy<F, LZ, false>, (size_t)(4 * LZ::NL) << NTT_TILE_LOG));
       // Radix-4 pass (two stages per LDS round trip, 512 lanes per tile) or radix-2 pass. With the staged twiddle tables and two
       // folds per decimation-in-frequency round the radix-4 pass wins from 2^20 points on (one box, inverse / forward ms: 2^22
       // 0.583 / 0.541 -> 0.553 / 0.526, 2^24 2.36 / 2.04 -> 2.31 / 2.06, 2^20 0.153 / 0.142 -> 0.150 / 0.141; another box 2^22 forward
@@ -797,14 +791,8 @@ static int run_ntt(const Domain* d, F* data, uint32_t ncomp, bool dif, hipStream
       const bool r4_default = L >= 20;
       const bool r4 = ((nv & 1) != 0 || (r4_default && (nv & 2) == 0)) && p.k >= 2 && tile_log + ncomp_log >= 2;
       if (r4) {
-        if (lds_bytes > 48 * 1024) {
-          static thread_local bool raised_r4[2] = {false, false};
-          if (!raised_r4[dif ? 1 : 0]) {
-            const void* fn = dif ? (const void*)k_ntt_pass_r4<F, LZ, true> : (const void*)k_ntt_pass_r4<F, LZ, false>;
-            CSH_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (4 * LZ::NL) << NTT_TILE_LOG));
-            raised_r4[dif ? 1 : 0] = true;
-          }
-        }
+        if (lds_bytes > 48 * 1024)
+          CSH_TRY(raise_lds_limit(dif ? (const void*)k_ntt_pass_r4<F, LZ, true> : (const void*)k_ntt_pass_r4<F, LZ, false>, (size_t)(4 * LZ::NL) << NTT_TILE_LOG));
         const size_t units = (size_t(1) << (tile_log + ncomp_log)) >> 2;
         const int nt = units >= 512 ? 512 : (units >= 64 ? (int)units : 64);
         if (dif)
@@ -823,14 +811,8 @@ static int run_ntt(const Domain* d, F* data, uint32_t ncomp, bool dif, hipStream
       CSH_HIP(hipGetLastError());
       continue;
     }
-    if (lds_bytes > 48 * 1024) {
-      static thread_local bool raised[2] = {false, false};
-      if (!raised[dif ? 1 : 0]) {
-        const void* fn = dif ? (const void*)k_ntt_pass<F, true> : (const void*)k_ntt_pass<F, false>;
-        CSH_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 32 << NTT_TILE_LOG));
-        raised[dif ? 1 : 0] = true;
-      }
-    }
+    if (lds_bytes > 48 * 1024)
+      CSH_TRY(raise_lds_limit(dif ? (const void*)k_ntt_pass<F, true> : (const void*)k_ntt_pass<F, false>, (size_t)32 << NTT_TILE_LOG));
     if (dif)
       hipLaunchKernelGGL((k_ntt_pass<F, true>), dim3((unsigned)tiles), dim3(NTT_THREADS), lds_bytes, st, data, tw, L, p.s0, p.k, p.cb,
                          ncomp_log, scale, do_scale);
@@ -986,13 +968,7 @@ static int run_ntt_pair(const Domain* d, F* data, uint32_t ncomp, hipStream_t st
   if (np > 1) CSH_TRY(run_ntt<F>(d, data, ncomp, true, st, scale_tbl, true));   // the strided passes of the inverse transform
   const size_t tiles = d->n >> tile_log;
   const size_t lds_bytes = size_t(4 * LZ::NL) << (tile_log + ncomp_log);
-  if (lds_bytes > 48 * 1024) {
-    static thread_local bool raised = false;
-    if (!raised) {
-      CSH_HIP(hipFuncSetAttribute((const void*)k_ntt_pass_r4<F, LZ, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (4 * LZ::NL) << NTT_TILE_LOG));
-      raised = true;
-    }
-  }
+  if (lds_bytes > 48 * 1024) CSH_TRY(raise_lds_limit((const void*)k_ntt_pass_r4<F, LZ, true, true>, (size_t)(4 * LZ::NL) << NTT_TILE_LOG));
   const size_t units = (size_t(1) << (tile_log + ncomp_log)) >> 2;
   const int nt = units >= 512 ? 512 : (units >= 64 ? (int)units : 64);
   const int noswz = ((nv & 0x800) ? 0x1000 : 0) | ((nv & 0x100000) ? 0x2000 : 0);
