@@ -308,8 +308,10 @@ def test_concurrent_callers_share_the_device(gpu):
     assert not errors, errors
 
 
-def test_concurrent_host_scalar_calls_share_one_upload(gpu):
-    """Round 5: concurrent csh_msm calls handed the SAME host scalar slice (the reference's rayon_join5: A, B/G1, B/G2 and L all read
+@pytest.mark.parametrize("tables", [0, 17])
+def test_concurrent_host_scalar_calls_share_one_upload(gpu, tables):
+    """tables = 17: the same on handles that carry the round-6 fixed-base tables (one bucket set, the wide sort stage on five streams at once).
+    Round 5: concurrent csh_msm calls handed the SAME host scalar slice (the reference's rayon_join5: A, B/G1, B/G2 and L all read
     aux_assignment, groth16.rs:227-294) share one upload -- a call that finds another one in flight with the same (device, pointer,
     length) reads that call's device copy. Known-dlog bases of four groups / seeds, 2^17 + 5 scalars (4 MiB: above the sharing threshold),
     six rounds of four concurrent callers + one caller on a different slice of the same vector: every result equals the closed form and
@@ -327,6 +329,8 @@ def test_concurrent_host_scalar_calls_share_one_upload(gpu):
         h = C.c_void_p()
         gpu.bindings._check(gpu.lib().csh_bases_upload_dev(H.CURVE_IDS[curve], group, buf.ptr, C.c_size_t(n), C.c_size_t(0), None, C.byref(h)))
         buf.free()
+        if tables:
+            gpu.bindings._check(gpu.lib().csh_bases_precompute(h, tables))
         handles.append(h)
     rs = np.random.RandomState(17)
     limbs = rs.randint(0, 1 << 63, size=(n, 4), dtype=np.uint64)
