@@ -898,6 +898,10 @@ def main():
                        "spinup_ms": round(spin_ms, 1), "spinup_last_batch_median_ms": spin_last_ms,
                        "spinup_rule": "untimed steps before the W warm-up steps: batches of 10 for >= %.1f s until two consecutive batch medians agree within 2 %% (cap 3 s)" % args.spinup_s},
             "value_first_20_steps": value_first_20, "ms_per_step_first_20_steps": cold_dt / 20 * 1e3,
+            # the same workload on a handle that carries the library's fixed-base tables (round 6: what a prover gets at key load through
+            # csh_bases_table_policy; `value` itself stays the plain handle) -- top-level scalars, copied from `secondary`
+            "value_fixed_base_tables": ((extras or {}).get(f"msm_{args.workload}_2p{args.log_n}_fixed_base_tables") or {}).get("points_per_s"),
+            "ms_per_step_fixed_base_tables": ((extras or {}).get(f"msm_{args.workload}_2p{args.log_n}_fixed_base_tables") or {}).get("ms"),
             "roofline": roofline, "cpu_baseline": cpu_baseline, "result_check": check, "secondary": extras,
             # the host side of every large host-pointer result of this process (HostXfer, csrc/capi.hip): page-population worker time, the
             # callers' wait for it, final stream waits, copies that stalled (> 3 x their PCIe time + 4 ms) and copies that went through the

@@ -26,6 +26,7 @@ ap.add_argument("--lb", type=int, nargs="*", default=[8])
 ap.add_argument("--chunks", type=int, nargs="*", default=[0])
 ap.add_argument("--seg", type=int, nargs="*", default=[0])
 ap.add_argument("--l", type=int, nargs="*", default=[0], help="forced entries per accumulate lane (tune msm_l), 0 = the plan's")
+ap.add_argument("--variant", type=int, nargs="*", default=[0], help="tune msm_variant values to run (bit 7 = 128: result through a copy instead of the direct write)")
 ap.add_argument("--skewed", action="store_true", help="witness-like scalars: half in {0, 1}, a quarter equal")
 ap.add_argument("--profile", action="store_true", help="kernel-trace runs: ONE plain call (the reference result), the rest on the table handle")
 args = ap.parse_args()
@@ -92,7 +93,8 @@ for job in args.jobs:
         build_s = time.perf_counter() - t0
         for lb in args.lb:
             for chunks in args.chunks:
-                for seg, ll in [(sg, l) for sg in args.seg for l in args.l]:
+                for seg, ll, var in [(sg, l, v) for sg in args.seg for l in args.l for v in args.variant]:
+                    B.tune_set("msm_variant", var)
                     B.tune_set("msm_wide_lb", lb)
                     B.tune_set("msm_wide_chunks", chunks)
                     B.tune_set("msm_seg_buckets", seg)
@@ -101,13 +103,14 @@ for job in args.jobs:
                     call()
                     same = bool(np.array_equal(out, ref))
                     med, mn, st = measure(call, args.reps, args.warm)
-                    print(json.dumps({"job": job, "mode": "table", "c": c, "lb": lb, "chunks": chunks, "seg": seg, "l": ll, "equals_plain": same, "params_c_W_L_S": B.msm_last_params(),
+                    print(json.dumps({"job": job, "mode": "table", "c": c, "lb": lb, "chunks": chunks, "seg": seg, "l": ll, "variant": var, "equals_plain": same, "params_c_W_L_S": B.msm_last_params(),
                                       "wall_ms_median": round(med, 4), "wall_ms_min": round(mn, 4), "Mpts_s": round(n / med / 1e3, 1), "stage_ms": st,
                                       "table_build_s": round(build_s, 3)}), flush=True)
         B.tune_set("msm_wide_lb", 0)
         B.tune_set("msm_wide_chunks", 0)
         B.tune_set("msm_seg_buckets", 0)
         B.tune_set("msm_l", 0)
+        B.tune_set("msm_variant", 0)
     L.csh_bases_drop_tables(h)
     L.csh_bases_free(h)
     sc.free()
