@@ -33,6 +33,19 @@ CSH_MSM_INSTANTIATE(extern, Bn254G2Cfg)
 CSH_MSM_INSTANTIATE(extern, Bls381G1Cfg)
 CSH_MSM_INSTANTIATE(extern, Bls381G2Cfg)
 CSH_MSM_INSTANTIATE(extern, GrumpkinG1Cfg)
+// The accumulate kernels live ONLY in msm_accum_*.hip (pinned multiply-add order). This unit names them too (accum_occupancy asks the
+// runtime about them), and without these declarations it instantiated its own UNPINNED copies of the G1 kernels, which the runtime then
+// launched instead of the pinned ones (two code objects registering one host stub: the copy of this unit won; 146 against 144 VGPRs on
+// BN254 G1, 248 against 217 on BLS12-381 G1 -- every G1 accumulate since the occupancy query of round 4 ran 3-4 % slower than the kernel the
+// profiles of round 3 describe; found in round 6 when an experimental variant that existed in one unit only beat it by exactly that margin
+// (profiles/r06_s_ahead_groups_ab.log; the variant itself -- the gather two entries ahead -- is worth nothing: r06_t_ahead_clean_ab.log).
+CSH_MSM_ACCUM_INSTANTIATE(extern, Bn254G1Cfg)
+CSH_MSM_ACCUM_INSTANTIATE(extern, Bn254G2Cfg)
+CSH_MSM_ACCUM_INSTANTIATE(extern, Bls381G1Cfg)
+CSH_MSM_ACCUM_INSTANTIATE(extern, Bls381G2Cfg)
+CSH_MSM_ACCUM_INSTANTIATE(extern, GrumpkinG1Cfg)
+CSH_MSM_ACCUM_PAIR_INSTANTIATE(extern, Bn254G2Cfg)
+CSH_MSM_ACCUM_PAIR_INSTANTIATE(extern, Bls381G2Cfg)
 
 static int repack_bases(Bases* B, hipStream_t st);
 

@@ -274,3 +274,25 @@ def test_experiment_knobs_are_not_in_the_product_library():
     env = dict(os.environ, CSH_NTT_VARIANT="0x10800", CSH_ALLOW_UNMASKED_REP3="1", PYTHONPATH=root)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=root, timeout=120)
     assert r.returncode == 0 and "ok" in r.stdout, (r.stdout, r.stderr)
+
+
+def test_every_accumulate_kernel_is_defined_in_exactly_one_object():
+    """Round 6: the pinned accumulate kernels (msm_accum_*.hip, CSH_PIN_MADS) had been shadowed since round 4 by UNPINNED copies that
+    msm.hip instantiated implicitly for its occupancy query -- two code objects registering one host stub, and the runtime launched the
+    slower one (3-4 % on every G1 MSM). Every k_msm_accum* instantiation must live in one object, and that object must be msm_accum_*.o."""
+    import collections
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.isdir(os.path.join(root, "co-snarks_amd", "build")):
+        pytest.skip("no build directory (prebuilt libraries only)")
+    out = os.path.join(root, "co-snarks_amd", "build", "_kernel_meta_accum.csv")
+    subprocess.run([sys.executable, os.path.join(root, "tools", "kernel_meta.py"), "k_msm_accum", "--csv", out], check=True, capture_output=True, timeout=600)
+    rows = [l.rstrip("\n").rsplit(",", 7) for l in open(out) if l.startswith('"')]
+    os.remove(out)
+    assert len(rows) >= 7, rows                               # five groups + the two lane-pair kernels of the G2 groups
+    where = collections.defaultdict(set)
+    for r in rows:
+        where[r[0]].add(r[-1])
+    for kernel, objs in where.items():
+        assert len(objs) == 1 and next(iter(objs)).startswith("msm_accum_"), (kernel, objs)
