@@ -322,7 +322,11 @@ def test_msm_fuzz_sizes_and_plans_vs_cpu_restatement(gpu, curve, group, rounds):
         assert np.array_equal(got_aff, want), (curve, group, it, n, off, k, knobs)
 
 
-@pytest.mark.parametrize("variant", [0, 2, 1, 0x102, 0x101, 0x201, 0x302, 0x402, 0x401, 0x100801])
+NTT_VARIANTS_DEFAULT = [0, 2, 1, 0x102, 0x401, 0x100801]
+NTT_VARIANTS_LONG = [0x101, 0x201, 0x302, 0x402]   # tests/test_gpu_long.py (-m gpu_long): the other forced tile sizes
+
+
+@pytest.mark.parametrize("variant", NTT_VARIANTS_DEFAULT)
 @pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
 def test_ntt_every_size_up_to_2p19_vs_cpu_restatement(gpu, curve, variant):
     """Every domain size 2^1 .. 2^19 (all pass plans: one, two, three and more sweeps; even and odd stage counts per pass), both

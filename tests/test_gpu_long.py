@@ -33,3 +33,9 @@ def test_msm_fuzz_long(gpu, curve, group, rounds):
 @pytest.mark.parametrize("logn,ncomp", T.NTT_FULL_LONG)
 def test_ntt_full_size_long(gpu, curve, logn, ncomp):
     T.test_ntt_full_size_equals_cpu_restatement(gpu, curve, logn, ncomp)
+
+
+@pytest.mark.parametrize("variant", T.NTT_VARIANTS_LONG)
+@pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
+def test_ntt_every_size_long(gpu, curve, variant):
+    T.test_ntt_every_size_up_to_2p19_vs_cpu_restatement(gpu, curve, variant)
