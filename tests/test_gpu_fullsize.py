@@ -95,8 +95,8 @@ def test_msm_sliced_giant_buckets_equal_cpu_restatement(gpu, curve, group, case)
     assert np.array_equal(got_aff, cbridge.msm_fast(cid, group, pts, sc, montgomery=False)), (curve, group, case)
 
 
-NTT_FULL_DEFAULT = [(20, 1), (20, 2), (21, 1), (21, 2), (22, 1), (22, 2)]
-NTT_FULL_LONG = [(23, 1)]                          # tests/test_gpu_long.py (-m gpu_long)
+NTT_FULL_DEFAULT = [(20, 1), (20, 2), (21, 1), (21, 2), (22, 1)]
+NTT_FULL_LONG = [(22, 2), (23, 1)]                          # tests/test_gpu_long.py (-m gpu_long)
 
 
 @pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
@@ -105,7 +105,7 @@ def test_ntt_full_size_equals_cpu_restatement(gpu, curve, logn, ncomp):
     """BASELINE config 3 (BN254, 2^22) and the Rep3 two-component form: both directions bit-identical to oracle/c's radix-2
     NTT over the whole vector, the round trip, and 16 output indices re-derived by Horner (no NTT code involved). 2^20 / 2^21 run as two
     sweeps (128- and 64-byte runs in the strided pass, 32-byte ones for share pairs at 2^20), 2^22 / 2^23 as three: every pass plan."""
-    if curve == "bls12_381" and (logn, ncomp) not in ((22, 1), (23, 1)):
+    if curve == "bls12_381" and (logn, ncomp) not in ((22, 1), (23, 1), (22, 2)):
         pytest.skip("one full-size BLS12-381 case is enough")
     F = H.FR[curve]
     cid = H.CURVE_IDS[curve]
@@ -170,7 +170,7 @@ def test_ntt_beyond_2p23_equals_cpu_restatement(gpu, logn, ncomp):
     dom.free()
 
 
-RANDOM_POINTS_DEFAULT = [("bn254", 0, "hashed"), ("bn254", 0, "wide"), ("bn254", 1, "wide"), ("bls12_381", 0, "wide")]
+RANDOM_POINTS_DEFAULT = [("bn254", 0, "hashed"), ("bn254", 1, "wide"), ("bls12_381", 0, "wide")]
 RANDOM_POINTS_LONG = [("bls12_381", 1, "wide20"), ("bls12_381", 0, "wide20"), ("bn254", 0, "wide20"), ("bn254", 1, "wide20")]   # tests/test_gpu_long.py (-m gpu_long)
 
 

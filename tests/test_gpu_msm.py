@@ -469,12 +469,12 @@ def test_msm_wide_window_tables(gpu, curve, group):
 
 
 def test_msm_fixed_base_tables_closed_form_and_multi(gpu):
-    """2^20 known-dlog bases with tables: closed form; the shared-sort multi-MSM over handles with tables (mixed G1 / G2,
+    """2^19 known-dlog bases with tables (2^20 on table handles: tests/test_gpu_fullsize.py, the bench line): closed form; the shared-sort multi-MSM over handles with tables (mixed G1 / G2,
     different offsets) equals the oracle."""
     import ctypes as C
     from tests.check_closed_form import closed_form_point
     G = cv.BN254_G1
-    n = 1 << 20
+    n = 1 << 19
     seed = 0xFEED
     buf = _gen_bases(gpu, "bn254", 0, seed, n)
     h = C.c_void_p()
