@@ -11,7 +11,7 @@ import re
 
 import numpy as np
 
-BN254, BLS12_381, GRUMPKIN, BLS12_377 = 0, 1, 2, 3   # GRUMPKIN: MSM only (G1); BLS12_377: scalar-field entry points only
+BN254, BLS12_381, GRUMPKIN, BLS12_377 = 0, 1, 2, 3   # GRUMPKIN: MSM only (G1); BLS12_377: MSM (G1, G2), NTT, share vectors, reductions (no host prover mirror)
 G1, G2 = 0, 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -77,7 +77,7 @@ def fr_bytes(curve: int) -> int:
 
 
 def fq_bytes(curve: int) -> int:
-    return 48 if curve == BLS12_381 else 32
+    return 48 if curve in (BLS12_381, BLS12_377) else 32
 
 
 def point_bytes(curve: int, group: int) -> int:

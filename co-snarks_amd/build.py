@@ -24,7 +24,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -fno-slp-vectorize: the SLP vectorizer finds nothing in straight-line 64-bit multiply-add chains and was a third of the compile time
 CFLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-fno-slp-vectorize"]
 
-HIP_SOURCES = ["capi.hip", "vec_ops.hip", "ntt.hip", "msm.hip", "msm_inst_bn254g1.hip", "msm_inst_bn254g2.hip", "msm_inst_bls381g1.hip", "msm_inst_bls381g2.hip", "msm_inst_grumpking1.hip", "msm_accum_bn254g1.hip", "msm_accum_bn254g2.hip", "msm_accum_bls381g1.hip", "msm_accum_bls381g2.hip", "msm_accum_grumpking1.hip", "msm_sort.hip", "msm_sort_wide.hip", "msm_split.hip", "groth16_h.hip", "microbench.hip", "selftest.hip", "util.hip", "sparse.hip"]
+HIP_SOURCES = ["capi.hip", "vec_ops.hip", "ntt.hip", "msm.hip", "msm_inst_bn254g1.hip", "msm_inst_bn254g2.hip", "msm_inst_bls381g1.hip", "msm_inst_bls381g2.hip", "msm_inst_grumpking1.hip", "msm_inst_bls377g1.hip", "msm_inst_bls377g2.hip", "msm_accum_bn254g1.hip", "msm_accum_bn254g2.hip", "msm_accum_bls381g1.hip", "msm_accum_bls381g2.hip", "msm_accum_grumpking1.hip", "msm_accum_bls377g1.hip", "msm_accum_bls377g2.hip", "msm_sort.hip", "msm_sort_wide.hip", "msm_split.hip", "groth16_h.hip", "microbench.hip", "selftest.hip", "util.hip", "sparse.hip"]
 COMPILE_TIMEOUT_S = 1500
 
 

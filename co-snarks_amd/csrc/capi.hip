@@ -811,6 +811,10 @@ int csh_memcpy_d2h(void* host_dst, const void* dev_src, size_t bytes) {
     CSH_TRY(x.d2h(host_dst, dev_src, bytes, st));
     return x.finish(st);
   }
+  // hipMemcpy orders itself after the NULL stream only, and the lane streams are non-blocking: work the CALLING thread queued with
+  // stream = NULL (e.g. csh_util_generate_bases_dev) must have landed before the copy reads it (found in round 6: the 64-step BLS12-377
+  // G2 generator kernel was still running when a 768-byte copy read its output)
+  CSH_HIP(hipStreamSynchronize(resolve_stream(nullptr)));
   CSH_HIP(hipMemcpy(host_dst, dev_src, bytes, hipMemcpyDeviceToHost));
   return CSH_OK;
 }

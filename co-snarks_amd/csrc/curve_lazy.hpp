@@ -46,12 +46,12 @@ CSH_HD_NOINLINE XYZZLazy<L> lazy_mdbl_v(L x, L y) {  // by value: fine (and fast
 }
 
 // Fp2 values split over a lane pair (curve_pair.hpp): the lane's half of an affine point comes from memory by role
-template <class LF>
+template <class LF, int NR>
 struct Fp2Pair;
 template <class L>
 struct IsPair { static constexpr bool value = false; };
-template <class LF>
-struct IsPair<Fp2Pair<LF>> { static constexpr bool value = true; };
+template <class LF, int NR>
+struct IsPair<Fp2Pair<LF, NR>> { static constexpr bool value = true; };
 template <class L, class AffT>
 __device__ void pair_unpack_affine(const AffT* src, L* x, L* y);
 

@@ -30,9 +30,12 @@ using PairHi = QuadCtrl<1, 1, 3, 3>;    // component 1 on both lanes
 __device__ __forceinline__ int pair_role() { return (int)(threadIdx.x & 1u); }
 __device__ __forceinline__ bool pair_all(bool f) { return f && (quad_mov<PairSwap::value>((int32_t)f) != 0); }
 
-template <class LF>
+// NR: Fp2 = Fp[i]/(i^2 + NR) -- 1 on BN254 / BLS12-381, 5 on BLS12-377 (the factor rides on the operand hi_signed() moves across the
+// pair; four-product columns then no longer fit: mul_sub takes the carry sweep between its two pairs, as the 9 x 29-bit field does)
+template <class LF, int NR = 1>
 struct Fp2Pair {
   using Base = LF;
+  static constexpr bool FOUR_FIT = LF::FOUR_PRODUCTS_FIT && NR == 1;
   static constexpr int NL = LF::NL;
   static constexpr int B = LF::B;
   LF v;  // component pair_role() of the element
@@ -50,9 +53,9 @@ struct Fp2Pair {
   __device__ __forceinline__ Fp2Pair neg_unpacked() const { return {v.neg_unpacked()}; }
   __device__ __forceinline__ Fp2Pair cneg_unpacked(uint32_t neg01) const { return {v.cneg_unpacked(neg01)}; }
 
-  // component 1 of `a` on both lanes, negated on the lane that computes c0 = a0 b0 - a1 b1
+  // component 1 of `a` on both lanes, times -NR on the lane that computes c0 = a0 b0 - NR a1 b1
   __device__ __forceinline__ static LF hi_signed(const LF& a) {
-    const int32_t sgn = 2 * pair_role() - 1;
+    const int32_t sgn = pair_role() ? 1 : -NR;
     LF r = quad_perm<PairHi::value>(a);
 #pragma unroll
     for (int i = 0; i < NL; ++i) r.l[i] *= sgn;
@@ -82,7 +85,7 @@ struct Fp2Pair {
 #endif
   // a*b - c*d
   __device__ __forceinline__ static Fp2Pair mul_sub(const Fp2Pair& a, const Fp2Pair& b, const Fp2Pair& c, const Fp2Pair& d) {
-    if constexpr (LF::FOUR_PRODUCTS_FIT) {
+    if constexpr (FOUR_FIT) {
 #if CSH_REDUCE_SCAN
       const LF alo = quad_perm<PairLo::value>(a.v), ahi = hi_signed(a.v), bsw = quad_perm<PairSwap::value>(b.v);
       const LF nclo = LF::neg(quad_perm<PairLo::value>(c.v)), nchi = LF::neg(hi_signed(c.v)), dsw = quad_perm<PairSwap::value>(d.v);
@@ -110,11 +113,11 @@ struct Fp2Pair {
 
 // ---- memory: the lane's half of points stored in the whole-element layouts -----------------------------------------------
 template <class LF, class F2>
-__device__ __forceinline__ XYZZLazy<Fp2Pair<LF>> pair_load(const XYZZLazy<Fp2S<LF, F2>>* p, int role) {
+__device__ __forceinline__ XYZZLazy<Fp2Pair<LF, F2::NONRESIDUE_NEG>> pair_load(const XYZZLazy<Fp2S<LF, F2>>* p, int role) {
   using Whole = XYZZLazy<Fp2S<LF, F2>>;
   static_assert(sizeof(Fp2S<LF, F2>) == 2 * sizeof(LF) && offsetof(Whole, zzz) == 6 * sizeof(LF), "XYZZLazy<Fp2S> must be 8 consecutive base elements");
   const LF* f = reinterpret_cast<const LF*>(p) + role;
-  XYZZLazy<Fp2Pair<LF>> r;
+  XYZZLazy<Fp2Pair<LF, F2::NONRESIDUE_NEG>> r;
   r.empty = p->empty;
   r.x.v = f[0];
   r.y.v = f[2];
@@ -123,7 +126,7 @@ __device__ __forceinline__ XYZZLazy<Fp2Pair<LF>> pair_load(const XYZZLazy<Fp2S<L
   return r;
 }
 template <class LF, class F2>
-__device__ __forceinline__ void pair_store(XYZZLazy<Fp2S<LF, F2>>* p, int role, const XYZZLazy<Fp2Pair<LF>>& q) {
+__device__ __forceinline__ void pair_store(XYZZLazy<Fp2S<LF, F2>>* p, int role, const XYZZLazy<Fp2Pair<LF, F2::NONRESIDUE_NEG>>& q) {
   LF* f = reinterpret_cast<LF*>(p) + role;
   f[0] = q.x.v;
   f[2] = q.y.v;

@@ -235,13 +235,15 @@ struct Fp {
 
 using Bn254Fq = Fp<Bn254FqParams>;
 using Bn254Fr = Fp<Bn254FrParams>;
-using Bls377Fr = Fp<Bls377FrParams>;  // scalar field only (no BLS12-377 group arithmetic)
+using Bls377Fr = Fp<Bls377FrParams>;
+using Bls377Fq = Fp<Bls377FqParams>;
 using Bls381Fq = Fp<Bls381FqParams>;
 using Bls381Fr = Fp<Bls381FrParams>;
 
-// ---- Fp2 = Fp[i]/(i^2+1) (both curves) ---------------------------------------------------------
-template <class F>
+// ---- Fp2 = Fp[i]/(i^2 + NR): NR = 1 on BN254 / BLS12-381, NR = 5 on BLS12-377 (ark-bls12-377 Fq2Config::NONRESIDUE = -5) ----
+template <class F, int NR = 1>
 struct Fp2T {
+  static constexpr int NONRESIDUE_NEG = NR;  // i^2 = -NR
   F c0, c1;
   CSH_HD static Fp2T zero() { return {F::zero(), F::zero()}; }
   CSH_HD static Fp2T one() { return {F::one(), F::zero()}; }
@@ -252,6 +254,15 @@ struct Fp2T {
   CSH_HD static Fp2T sub(const Fp2T& a, const Fp2T& b) { return {F::sub(a.c0, b.c0), F::sub(a.c1, b.c1)}; }
   CSH_HD static Fp2T neg(const Fp2T& a) { return {F::neg(a.c0), F::neg(a.c1)}; }
   CSH_HD static Fp2T dbl(const Fp2T& a) { return add(a, a); }
+  // NR * v by additions (NR is 1 or 5)
+  CSH_HD static F times_nr(const F& v) {
+    if constexpr (NR == 1) return v;
+    else {
+      static_assert(NR == 5, "Fp2T: nonresidue -1 or -5");
+      const F v2 = F::add(v, v);
+      return F::add(F::add(v2, v2), v);
+    }
+  }
   // Karatsuba: 3 base multiplications (out of line: see CSH_HD_NOINLINE)
   CSH_HD static Fp2T mul(const Fp2T& a, const Fp2T& b) { return mul_call(a, b); }
   CSH_HD static Fp2T sqr(const Fp2T& a) { return sqr_call(a); }
@@ -259,16 +270,20 @@ struct Fp2T {
     F v0 = F::mul(a.c0, b.c0);
     F v1 = F::mul(a.c1, b.c1);
     F s = F::mul(F::add(a.c0, a.c1), F::add(b.c0, b.c1));
-    return {F::sub(v0, v1), F::sub(F::sub(s, v0), v1)};
+    return {F::sub(v0, times_nr(v1)), F::sub(F::sub(s, v0), v1)};
   }
-  // (a+bi)^2 = (a+b)(a-b) + 2ab i
+  // (a+bi)^2 = (a+b)(a-b) + 2ab i for i^2 = -1; a^2 - NR b^2 + 2ab i in general
   CSH_HD_NOINLINE static Fp2T sqr_call(Fp2T a) {
     F ab = F::mul(a.c0, a.c1);
-    F t = F::mul(F::add(a.c0, a.c1), F::sub(a.c0, a.c1));
-    return {t, F::add(ab, ab)};
+    if constexpr (NR == 1) {
+      F t = F::mul(F::add(a.c0, a.c1), F::sub(a.c0, a.c1));
+      return {t, F::add(ab, ab)};
+    } else {
+      return {F::sub(F::sqr(a.c0), times_nr(F::sqr(a.c1))), F::add(ab, ab)};
+    }
   }
   CSH_HD static Fp2T inv(const Fp2T& a) {
-    F n = F::inv(F::add(F::sqr(a.c0), F::sqr(a.c1)));
+    F n = F::inv(F::add(F::sqr(a.c0), times_nr(F::sqr(a.c1))));
     return {F::mul(a.c0, n), F::neg(F::mul(a.c1, n))};
   }
   CSH_HD static Fp2T mul2(const Fp2T& a) { return add(a, a); }
@@ -279,5 +294,6 @@ struct Fp2T {
 
 using Bn254Fq2 = Fp2T<Bn254Fq>;
 using Bls381Fq2 = Fp2T<Bls381Fq>;
+using Bls377Fq2 = Fp2T<Bls377Fq, 5>;
 
 }  // namespace csh

@@ -559,6 +559,45 @@ struct FpS {
                          [&](int k, int i, int64_t acc) CSH_LAMBDA_INLINE { return term_mul(c, d, k, i, acc); }, r1, r2);
   }
 
+  // k * a limb-wise for a small constant k (the Fp2 non-residue 5 of BLS12-377): a normalised, |k| LIM1 < 2^31
+  CSH_HD static FpS scaled(const FpS& a, int32_t k) {
+    CSH_LIMB_BOUND(a, LIM1, "scaled");
+    FpS r;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) r.l[i] = k * a.l[i];
+    return r;
+  }
+  static constexpr int64_t LIM_SCALED = 5 * LIM1;  // scaled() output
+  // column products with a scaled() first operand (its bound is checked as such; the caller accounts for the column sum)
+  CSH_HD static int64_t col_mul_scaled(const FpS& a, const FpS& b, int k, int64_t acc) {
+    CSH_LIMB_BOUND(a, LIM_SCALED, "col_mul_scaled(a)");
+    CSH_LIMB_BOUND(b, LIM1, "col_mul_scaled(b)");
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+      if (k - i >= 0 && k - i < NL) acc = mad_pinned(a.l[i], b.l[k - i], acc);
+    return acc;
+  }
+  // - s b^2 for bs = s b (scaled), nb = -b, nb2 = -2 b
+  CSH_HD static int64_t col_nsqr_scaled(const FpS& bs, const FpS& nb, const FpS& nb2, int k, int64_t acc) {
+    CSH_LIMB_BOUND(bs, LIM_SCALED, "col_nsqr_scaled(bs)");
+    CSH_LIMB_BOUND(nb, LIM1, "col_nsqr_scaled(nb)");
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int j = k - i;
+      if (j == i) acc = mad_pinned(nb.l[i], bs.l[i], acc);
+      else if (j > i && j < NL) acc = mad_pinned(nb2.l[i], bs.l[j], acc);
+    }
+    return acc;
+  }
+  CSH_HD static void mac_wide_scaled(Wide& w, const FpS& a, const FpS& b) {
+    CSH_LIMB_BOUND(a, LIM_SCALED, "mac_wide_scaled(a)");
+    CSH_LIMB_BOUND(b, LIM1, "mac_wide_scaled(b)");
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+#pragma unroll
+      for (int j = 0; j < NL; ++j) w.t[i + j] = (int64_t)a.l[i] * (int64_t)b.l[j] + w.t[i + j];
+    }
+  }
   // operand products of column k
   CSH_HD static int64_t col_mul(const FpS& a, const FpS& b, int k, int64_t acc) {
     CSH_LIMB_BOUND(a, LIM2, "col_mul(a)");
@@ -815,6 +854,7 @@ struct FpS {
 
 using Fq29s = FpS<Bn254Fq29Params, Bn254Fq>;
 using Fq28s = FpS<Bls381Fq28Params, Bls381Fq>;
+using Fq28s377 = FpS<Bls377Fq28Params, Bls377Fq>;
 using Fr29s = FpS<Bn254Fr29Params, Bn254Fr>;  // Grumpkin base field; BN254 NTT butterflies
 using Bls381Fr29s = FpS<Bls381Fr29Params, Bls381Fr>;
 using Bls377Fr29s = FpS<Bls377Fr29Params, Bls377Fr>;
@@ -829,11 +869,16 @@ struct LazyOf<Bls381Fr> { using type = Bls381Fr29s; };
 template <>
 struct LazyOf<Bls377Fr> { using type = Bls377Fr29s; };
 
-// ---- Fp2 = Fp[i]/(i^2+1) over the signed lazy field: schoolbook products accumulated double-width with ONE
+// ---- Fp2 = Fp[i]/(i^2 + NR) over the signed lazy field: schoolbook products accumulated double-width with ONE
 // reduction per output component (2 NL^2 + NL^2 mads per component, cheaper than Karatsuba's three full
-// multiplications and free of the 2^(B+1)-limb operand sums Karatsuba needs) -------------------------------------
+// multiplications and free of the 2^(B+1)-limb operand sums Karatsuba needs).
+// NR = 1 (BN254, BLS12-381) or 5 (BLS12-377, F32x2::NONRESIDUE_NEG): the factor rides on ONE operand of the a1 b1 products
+// (limb-wise -5 a1: |limb| < 5 (2^28 + 8) < 2^31). Column bound with NR = 5, 14 x 28-bit limbs, every operand normalised:
+// (1 + 5) 14 2^56 products + 14 2^56 of the reduction = 98 2^56 < 2^63; four-product sums take the carry sweep between the pairs.
 template <class LF, class F32x2>
 struct Fp2S {
+  static constexpr int NR = F32x2::NONRESIDUE_NEG;
+  static_assert(NR == 1 || (NR == 5 && (6.0 * LF::NL + LF::NL) * (double)(1ull << (2 * LF::B - 40)) < (double)(1ull << 23)), "Fp2S: non-residue / limb layout");
   LF c0, c1;
   CSH_HD static Fp2S zero() { return {LF::zero(), LF::zero()}; }
   CSH_HD static Fp2S one() { return {LF::one(), LF::zero()}; }
@@ -843,25 +888,60 @@ struct Fp2S {
   CSH_HD Fp2S normalized() const { return {c0.normalized(), c1.normalized()}; }
   CSH_HD Fp2S neg_unpacked() const { return {c0.neg_unpacked(), c1.neg_unpacked()}; }
   CSH_HD Fp2S cneg_unpacked(uint32_t neg01) const { return {c0.cneg_unpacked(neg01), c1.cneg_unpacked(neg01)}; }
+  // ---- NR != 1 (BLS12-377): the same sums with the factor on one operand; no four-product columns ----------------------
+  CSH_HD static Fp2S mul_nr(const Fp2S& a, const Fp2S& b) {
+    const LF na1 = LF::scaled(a.c1, -NR);
+    return {LF::reduce_scan([&](int k, int64_t acc) CSH_LAMBDA_INLINE { return LF::col_mul_scaled(na1, b.c1, k, LF::col_mul(a.c0, b.c0, k, acc)); }),
+            LF::reduce_scan([&](int k, int64_t acc) CSH_LAMBDA_INLINE { return LF::col_mul(a.c1, b.c0, k, LF::col_mul(a.c0, b.c1, k, acc)); })};
+  }
+  CSH_HD static Fp2S sqr_nr(const Fp2S& a) {
+    const LF a2 = LF::add(a.c0, a.c0), bs = LF::scaled(a.c1, NR), nb = LF::neg(a.c1), nb2 = LF::add(nb, nb);
+    return {LF::reduce_scan([&](int k, int64_t acc) CSH_LAMBDA_INLINE { return LF::col_nsqr_scaled(bs, nb, nb2, k, LF::col_sqr(a.c0, a2, k, acc)); }),
+            LF::mul(a2, a.c1)};
+  }
+  CSH_HD static Fp2S sqr_sub_nr(const Fp2S& a, const Fp2S& s) {
+    const LF a2 = LF::add(a.c0, a.c0), bs = LF::scaled(a.c1, NR), nb = LF::neg(a.c1), nb2 = LF::add(nb, nb);
+    const int32_t m1 = LF::opaque_minus_one();
+    return {LF::reduce_scan([&](int k, int64_t acc) CSH_LAMBDA_INLINE { return LF::col_sub_hi(s.c0, m1, k, LF::col_nsqr_scaled(bs, nb, nb2, k, LF::col_sqr(a.c0, a2, k, acc))); }),
+            LF::reduce_scan([&](int k, int64_t acc) CSH_LAMBDA_INLINE { return LF::col_sub_hi(s.c1, m1, k, LF::col_mul(a2, a.c1, k, acc)); })};
+  }
+  CSH_HD static Fp2S mul_sub_nr(const Fp2S& a, const Fp2S& b, const Fp2S& c, const Fp2S& d) {
+    typename LF::Wide w0 = LF::mul_wide(a.c0, b.c0);                   //   a0 b0 - NR a1 b1
+    LF::mac_wide_scaled(w0, LF::scaled(a.c1, -NR), b.c1);
+    LF::compress_wide(w0);
+    typename LF::Wide v0 = LF::mul_wide(LF::neg(c.c0), d.c0);          // - c0 d0 + NR c1 d1
+    LF::mac_wide_scaled(v0, LF::scaled(c.c1, NR), d.c1);
+    LF::add_wide(w0, v0);
+    typename LF::Wide w1 = LF::mul_add_wide(a.c0, b.c1, a.c1, b.c0);   //   a0 b1 + a1 b0
+    LF::compress_wide(w1);
+    typename LF::Wide v1 = LF::mul_wide(LF::neg(c.c0), d.c1);          // - c0 d1 - c1 d0
+    LF::mac_wide(v1, c.c1, d.c0, true);
+    LF::add_wide(w1, v1);
+    return {LF::reduce(w0), LF::reduce(w1)};
+  }
 #if CSH_REDUCE_SCAN
   CSH_HD static Fp2S mul(const Fp2S& a, const Fp2S& b) {
+    if constexpr (NR != 1) return mul_nr(a, b);
     const LF na1 = LF::neg(a.c1);
     return {LF::reduce_scan([&](int k, int64_t acc) CSH_LAMBDA_INLINE { return LF::col_mul(na1, b.c1, k, LF::col_mul(a.c0, b.c0, k, acc)); }),
             LF::reduce_scan([&](int k, int64_t acc) CSH_LAMBDA_INLINE { return LF::col_mul(a.c1, b.c0, k, LF::col_mul(a.c0, b.c1, k, acc)); })};
   }
   CSH_HD static Fp2S sqr(const Fp2S& a) {
+    if constexpr (NR != 1) return sqr_nr(a);
     const LF a2 = LF::add(a.c0, a.c0), nb = LF::neg(a.c1), nb2 = LF::add(nb, nb);
     return {LF::reduce_scan([&](int k, int64_t acc) CSH_LAMBDA_INLINE { return LF::col_nsqr(a.c1, nb, nb2, k, LF::col_sqr(a.c0, a2, k, acc)); }),
             LF::mul(a2, a.c1)};
   }
   // a^2 - s (s: |limb| < 2^31)
   CSH_HD static Fp2S sqr_sub(const Fp2S& a, const Fp2S& s) {
+    if constexpr (NR != 1) return sqr_sub_nr(a, s);
     const LF a2 = LF::add(a.c0, a.c0), nb = LF::neg(a.c1), nb2 = LF::add(nb, nb);
     const int32_t m1 = LF::opaque_minus_one();
     return {LF::reduce_scan([&](int k, int64_t acc) CSH_LAMBDA_INLINE { return LF::col_sub_hi(s.c0, m1, k, LF::col_nsqr(a.c1, nb, nb2, k, LF::col_sqr(a.c0, a2, k, acc))); }),
             LF::reduce_scan([&](int k, int64_t acc) CSH_LAMBDA_INLINE { return LF::col_sub_hi(s.c1, m1, k, LF::col_mul(a2, a.c1, k, acc)); })};
   }
 #else
+  static_assert(NR == 1, "the row-wise build has no BLS12-377 Fp2");
   CSH_HD static Fp2S mul(const Fp2S& a, const Fp2S& b) {
     return {LF::reduce(LF::mul_sub_wide(a.c0, b.c0, a.c1, b.c1)), LF::reduce(LF::mul_add_wide(a.c0, b.c1, a.c1, b.c0))};
   }
@@ -875,6 +955,7 @@ struct Fp2S {
 #endif
   // a*b - c*d
   CSH_HD static Fp2S mul_sub(const Fp2S& a, const Fp2S& b, const Fp2S& c, const Fp2S& d) {
+    if constexpr (NR != 1) return mul_sub_nr(a, b, c, d);
     if constexpr (LF::FOUR_PRODUCTS_FIT) {
 #if CSH_REDUCE_SCAN
       const LF na1 = LF::neg(a.c1), nc0 = LF::neg(c.c0), nc1 = LF::neg(c.c1);
@@ -916,5 +997,6 @@ struct Fp2S {
 };
 using Fq29s2 = Fp2S<Fq29s, Bn254Fq2>;
 using Fq28s2 = Fp2S<Fq28s, Bls381Fq2>;
+using Fq28s377x2 = Fp2S<Fq28s377, Bls377Fq2>;
 
 }  // namespace csh

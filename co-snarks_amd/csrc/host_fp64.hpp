@@ -144,9 +144,9 @@ template <class P>
 struct Host64<Fp<P>> {
   using type = Fp64<P>;
 };
-template <class P>
-struct Host64<Fp2T<Fp<P>>> {
-  using type = Fp2T<Fp64<P>>;
+template <class P, int NR>
+struct Host64<Fp2T<Fp<P>, NR>> {
+  using type = Fp2T<Fp64<P>, NR>;
 };
 
 }  // namespace csh

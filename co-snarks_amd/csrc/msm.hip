@@ -33,6 +33,8 @@ CSH_MSM_INSTANTIATE(extern, Bn254G2Cfg)
 CSH_MSM_INSTANTIATE(extern, Bls381G1Cfg)
 CSH_MSM_INSTANTIATE(extern, Bls381G2Cfg)
 CSH_MSM_INSTANTIATE(extern, GrumpkinG1Cfg)
+CSH_MSM_INSTANTIATE(extern, Bls377G1Cfg)
+CSH_MSM_INSTANTIATE(extern, Bls377G2Cfg)
 // The accumulate kernels live ONLY in msm_accum_*.hip (pinned multiply-add order). This unit names them too (accum_occupancy asks the
 // runtime about them), and without these declarations it instantiated its own UNPINNED copies of the G1 kernels, which the runtime then
 // launched instead of the pinned ones (two code objects registering one host stub: the copy of this unit won; 146 against 144 VGPRs on
@@ -44,8 +46,11 @@ CSH_MSM_ACCUM_INSTANTIATE(extern, Bn254G2Cfg)
 CSH_MSM_ACCUM_INSTANTIATE(extern, Bls381G1Cfg)
 CSH_MSM_ACCUM_INSTANTIATE(extern, Bls381G2Cfg)
 CSH_MSM_ACCUM_INSTANTIATE(extern, GrumpkinG1Cfg)
+CSH_MSM_ACCUM_INSTANTIATE(extern, Bls377G1Cfg)
+CSH_MSM_ACCUM_INSTANTIATE(extern, Bls377G2Cfg)
 CSH_MSM_ACCUM_PAIR_INSTANTIATE(extern, Bn254G2Cfg)
 CSH_MSM_ACCUM_PAIR_INSTANTIATE(extern, Bls381G2Cfg)
+CSH_MSM_ACCUM_PAIR_INSTANTIATE(extern, Bls377G2Cfg)
 
 static int repack_bases(Bases* B, hipStream_t st);
 
@@ -180,7 +185,7 @@ static int csh::repack_bases(Bases* B, hipStream_t st) {
 }
 
 static int valid_cg(csh_curve_t c, csh_group_t g) {
-  CSH_REQUIRE(c == CSH_BN254 || c == CSH_BLS12_381 || c == CSH_GRUMPKIN, "unknown curve");
+  CSH_REQUIRE(c == CSH_BN254 || c == CSH_BLS12_381 || c == CSH_GRUMPKIN || c == CSH_BLS12_377, "unknown curve");
   CSH_REQUIRE(g == CSH_G1 || (g == CSH_G2 && c != CSH_GRUMPKIN), "unknown group");
   return CSH_OK;
 }
@@ -493,6 +498,8 @@ int csh_msm_multi_dev(const csh_bases_t* bases, const size_t* offsets, size_t k,
     if (B->curve == CSH_BLS12_381 && B->group == CSH_G1) { CSH_OPS(Bls381G1Cfg); }
     if (B->curve == CSH_BLS12_381 && B->group == CSH_G2) { CSH_OPS(Bls381G2Cfg); }
     if (B->curve == CSH_GRUMPKIN && B->group == CSH_G1) { CSH_OPS(GrumpkinG1Cfg); }
+    if (B->curve == CSH_BLS12_377 && B->group == CSH_G1) { CSH_OPS(Bls377G1Cfg); }
+    if (B->curve == CSH_BLS12_377 && B->group == CSH_G2) { CSH_OPS(Bls377G2Cfg); }
 #undef CSH_OPS
     return false;
   };
@@ -502,7 +509,7 @@ int csh_msm_multi_dev(const csh_bases_t* bases, const size_t* offsets, size_t k,
     for (size_t i = 0; i < k; ++i) ops[i].fold(nullptr, 0, 2, 0, outs_host[i]);
     return CSH_OK;
   }
-  const int bits = B0->curve == CSH_BLS12_381 ? Bls381FrParams::BITS : (B0->curve == CSH_GRUMPKIN ? Bn254FqParams::BITS : Bn254FrParams::BITS);
+  const int bits = scalar_bits_of(B0->curve);
   // merged-window mode needs every handle to carry tables of one window width (the digit codes are shared)
   bool merged = true;
   for (size_t i = 0; i < k; ++i) {
@@ -529,6 +536,7 @@ int csh_msm_multi_dev(const csh_bases_t* bases, const size_t* offsets, size_t k,
   auto sort_stage = [&](const MsmParams& ps, SortOut* so) -> int {
     if (B0->curve == CSH_BLS12_381) return msm_sort_stage<Bls381Fr>(ps, pdig, scalars_dev, st, ar, so, nullptr);
     if (B0->curve == CSH_GRUMPKIN) return msm_sort_stage<Bn254Fq>(ps, pdig, scalars_dev, st, ar, so, nullptr);
+    if (B0->curve == CSH_BLS12_377) return msm_sort_stage<Bls377Fr>(ps, pdig, scalars_dev, st, ar, so, nullptr);
     return msm_sort_stage<Bn254Fr>(ps, pdig, scalars_dev, st, ar, so, nullptr);
   };
   SortOut so;
@@ -649,9 +657,9 @@ int csh_msm_multi_dev(const csh_bases_t* bases, const size_t* offsets, size_t k,
 
 int csh_msm_plan(csh_curve_t curve, size_t n, uint32_t out[6]) {
   CSH_REQUIRE(out, "out is NULL");
-  CSH_REQUIRE(curve == CSH_BN254 || curve == CSH_BLS12_381 || curve == CSH_GRUMPKIN, "unknown curve");
+  CSH_REQUIRE(curve == CSH_BN254 || curve == CSH_BLS12_381 || curve == CSH_GRUMPKIN || curve == CSH_BLS12_377, "unknown curve");
   CSH_REQUIRE(n >= 1 && n < (size_t(1) << 31), "n out of range");
-  const int bits = curve == CSH_BLS12_381 ? Bls381FrParams::BITS : (curve == CSH_GRUMPKIN ? Bn254FqParams::BITS : Bn254FrParams::BITS);
+  const int bits = scalar_bits_of(curve);
   uint32_t keep[4];
   for (int i = 0; i < 4; ++i) keep[i] = tl_msm_params[i];  // planning must not disturb csh_msm_last_params
   const MsmParams p = msm_plan(n, bits, 1);

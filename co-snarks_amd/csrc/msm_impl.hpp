@@ -28,6 +28,10 @@ struct Bn254G2Cfg { using Fq = Bn254Fq2;  using Fr = Bn254Fr; static constexpr b
 struct Bls381G1Cfg { using Fq = Bls381Fq;  using Fr = Bls381Fr; static constexpr bool LAZY = true;  using L = Fq28s; static constexpr bool INLINE_ADD = true; static constexpr bool PAIR = false; };
 // Grumpkin: base field = BN254 Fr, scalars = BN254 Fq (the 2-cycle partner of BN254)
 struct GrumpkinG1Cfg { using Fq = Bn254Fr;   using Fr = Bn254Fq; static constexpr bool LAZY = true;  using L = Fr29s; static constexpr bool INLINE_ADD = true; static constexpr bool PAIR = false; };
+// BLS12-377 (the curve of the reference's LibSnarkReduction fixtures, co-circom/co-groth16/src/lib.rs:231-300): the 377-bit base field in the
+// 14 x 28-bit limbs of BLS12-381's, Fq2 = Fq[u]/(u^2 + 5)
+struct Bls377G1Cfg { using Fq = Bls377Fq;  using Fr = Bls377Fr; static constexpr bool LAZY = true;  using L = Fq28s377; static constexpr bool INLINE_ADD = true; static constexpr bool PAIR = false; };
+struct Bls377G2Cfg { using Fq = Bls377Fq2; using Fr = Bls377Fr; static constexpr bool LAZY = true;  using L = Fq28s377x2; static constexpr bool INLINE_ADD = true; static constexpr bool PAIR = true; static constexpr bool PAIR_ACC_DEFAULT = true; using LP = Fp2Pair<Fq28s377, 5>; };
 struct Bls381G2Cfg { using Fq = Bls381Fq2; using Fr = Bls381Fr; static constexpr bool LAZY = true;  using L = Fq28s2; static constexpr bool INLINE_ADD = true; static constexpr bool PAIR = true; static constexpr bool PAIR_ACC_DEFAULT = true; using LP = Fp2Pair<Fq28s>; };
 
 struct Bases {
@@ -102,8 +106,8 @@ __global__ __launch_bounds__(MSM_BLK) void k_msm_digits(const Fr* __restrict__ s
 // one-word necessary condition for the stored point at infinity (0, 0): the full 16..48-word test only runs behind it
 template <class P>
 __device__ __forceinline__ uint32_t top_word(const Fp<P>& f) { return f.l[Fp<P>::N - 1]; }
-template <class F>
-__device__ __forceinline__ uint32_t top_word(const Fp2T<F>& f) { return top_word(f.c0) | top_word(f.c1); }
+template <class F, int NR>
+__device__ __forceinline__ uint32_t top_word(const Fp2T<F, NR>& f) { return top_word(f.c0) | top_word(f.c1); }
 template <class Fq>
 __device__ __forceinline__ bool stored_is_inf(const Affine<Fq>& pt) {
   return (top_word(pt.x) | top_word(pt.y)) == 0 && pt.is_inf();
@@ -851,7 +855,7 @@ struct SortOut {  // what the bucket stage consumes
 inline bool msm_sort_is_wide(const MsmParams& p) { return p.c > 16 && p.W == 1 && p.remap_n != 0; }
 template <class Fr>
 constexpr int fr_id_of() {
-  return std::is_same<Fr, Bls381Fr>::value ? 1 : (std::is_same<Fr, Bn254Fq>::value ? 2 : 0);
+  return std::is_same<Fr, Bls381Fr>::value ? 1 : (std::is_same<Fr, Bn254Fq>::value ? 2 : (std::is_same<Fr, Bls377Fr>::value ? 3 : 0));
 }
 
 inline size_t msm_sort_bytes(const MsmParams& p, const MsmParams& pdig) {
@@ -1403,7 +1407,7 @@ int repack_bases_t(Bases* B, hipStream_t st) {
   KW template int precompute_table_t<CFG>(Bases*, int, int, hipStream_t);                                                            \
   KW template void fold_windows_erased<CFG>(const void*, int, int, int, void*);
 
-// the five group configurations, by run-time (curve, group)
+// the seven group configurations, by run-time (curve, group)
 #define CURVE_DISPATCH(curve, group, CALL)                                                      \
   do {                                                                                          \
     if ((curve) == CSH_BN254 && (group) == CSH_G1) { using Cfg = csh::Bn254G1Cfg; return CALL; }     \
@@ -1411,12 +1415,17 @@ int repack_bases_t(Bases* B, hipStream_t st) {
     if ((curve) == CSH_BLS12_381 && (group) == CSH_G1) { using Cfg = csh::Bls381G1Cfg; return CALL; } \
     if ((curve) == CSH_BLS12_381 && (group) == CSH_G2) { using Cfg = csh::Bls381G2Cfg; return CALL; } \
     if ((curve) == CSH_GRUMPKIN && (group) == CSH_G1) { using Cfg = csh::GrumpkinG1Cfg; return CALL; }  \
+    if ((curve) == CSH_BLS12_377 && (group) == CSH_G1) { using Cfg = csh::Bls377G1Cfg; return CALL; } \
+    if ((curve) == CSH_BLS12_377 && (group) == CSH_G2) { using Cfg = csh::Bls377G2Cfg; return CALL; } \
     csh::set_error("unknown curve/group %d/%d", (int)(curve), (int)(group));                     \
     return CSH_ERR_INVALID;                                                                     \
   } while (0)
 
+inline int scalar_bits_of(csh_curve_t c) {
+  return c == CSH_BLS12_381 ? Bls381FrParams::BITS : c == CSH_GRUMPKIN ? Bn254FqParams::BITS : c == CSH_BLS12_377 ? Bls377FrParams::BITS : Bn254FrParams::BITS;
+}
 inline size_t point_bytes_of(csh_curve_t c, csh_group_t g) {
-  const size_t fq = c == CSH_BLS12_381 ? 48 : 32;
+  const size_t fq = (c == CSH_BLS12_381 || c == CSH_BLS12_377) ? 48 : 32;
   return 2 * fq * (g == CSH_G2 ? 2 : 1);
 }
 inline size_t partial_bytes_of(csh_curve_t c, csh_group_t g) { return sizeof(PartialHeader) + 2 * point_bytes_of(c, g) * MAX_WINDOWS; }

@@ -567,6 +567,7 @@ int msm_sort_wide_launch(int fr_id, const MsmParams& srt, const MsmParams& dig, 
   CSH_REQUIRE(srt.W == 1 && srt.c >= 17 && srt.c <= 22 && dig.W >= 1 && dig.W <= WS_MAXW && srt.remap_n == dig.n, "wide sort: bad plan");
   if (fr_id == 1) return wide_launch_c<Bls381Fr>(srt, dig, scalars_dev, st, ar, out_start, out_nlanes, out_sorted, ev);
   if (fr_id == 2) return wide_launch_c<Bn254Fq>(srt, dig, scalars_dev, st, ar, out_start, out_nlanes, out_sorted, ev);
+  if (fr_id == 3) return wide_launch_c<Bls377Fr>(srt, dig, scalars_dev, st, ar, out_start, out_nlanes, out_sorted, ev);
   return wide_launch_c<Bn254Fr>(srt, dig, scalars_dev, st, ar, out_start, out_nlanes, out_sorted, ev);
 }
 

@@ -34,6 +34,8 @@ CSH_MSM_INSTANTIATE(extern, Bn254G1Cfg)
 CSH_MSM_INSTANTIATE(extern, Bn254G2Cfg)
 CSH_MSM_INSTANTIATE(extern, Bls381G1Cfg)
 CSH_MSM_INSTANTIATE(extern, Bls381G2Cfg)
+CSH_MSM_INSTANTIATE(extern, Bls377G1Cfg)
+CSH_MSM_INSTANTIATE(extern, Bls377G2Cfg)
 CSH_MSM_INSTANTIATE(extern, GrumpkinG1Cfg)
 
 // ---- RCCL binding (restated from the public nccl.h ABI: opaque communicator, 128-byte unique id by value) --------------

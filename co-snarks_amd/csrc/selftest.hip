@@ -256,17 +256,21 @@ int csh_selftest_lazy_chain_dev(int curve, int group, const void* affine_pts, si
   if (curve == CSH_BLS12_381 && group == CSH_G1) return lazy_chain_check_t<Fq28s, Bls381Fq>(affine_pts, n, len, nthreads, host_samples, mismatches);
   if (curve == CSH_BLS12_381 && group == CSH_G2) return lazy_chain_check_t<Fq28s2, Bls381Fq2>(affine_pts, n, len, nthreads, host_samples, mismatches);
   if (curve == CSH_GRUMPKIN && group == CSH_G1) return lazy_chain_check_t<Fr29s, Bn254Fr>(affine_pts, n, len, nthreads, host_samples, mismatches);
+  if (curve == CSH_BLS12_377 && group == CSH_G1) return lazy_chain_check_t<Fq28s377, Bls377Fq>(affine_pts, n, len, nthreads, host_samples, mismatches);
+  if (curve == CSH_BLS12_377 && group == CSH_G2) return lazy_chain_check_t<Fq28s377x2, Bls377Fq2>(affine_pts, n, len, nthreads, host_samples, mismatches);
   return CSH_ERR_INVALID;
 }
 
 
-// field: 0 BN254 Fq, 1 BN254 Fr, 2 BLS12-381 Fq, 3 BLS12-381 Fr
+// field: 0 BN254 Fq, 1 BN254 Fr, 2 BLS12-381 Fq, 3 BLS12-381 Fr, 4 BLS12-377 Fq, 5 BLS12-377 Fr
 int csh_selftest_field_op(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out) {
   switch (field) {
     case 0: return field_op<Bn254Fq>(op, a, b, out);
     case 1: return field_op<Bn254Fr>(op, a, b, out);
     case 2: return field_op<Bls381Fq>(op, a, b, out);
     case 3: return field_op<Bls381Fr>(op, a, b, out);
+    case 4: return field_op<Bls377Fq>(op, a, b, out);
+    case 5: return field_op<Bls377Fr>(op, a, b, out);
     default: return CSH_ERR_INVALID;
   }
 }
@@ -274,6 +278,7 @@ int csh_selftest_field_op(int field, int op, const uint64_t* a, const uint64_t* 
 int csh_selftest_fp2_op(int curve, int op, const uint64_t* a, const uint64_t* b, uint64_t* out) {
   if (curve == CSH_BN254) return field_op<Bn254Fq2, false>(op, a, b, out);
   if (curve == CSH_BLS12_381) return field_op<Bls381Fq2, false>(op, a, b, out);
+  if (curve == CSH_BLS12_377) return field_op<Bls377Fq2, false>(op, a, b, out);
   return CSH_ERR_INVALID;
 }
 
@@ -283,6 +288,8 @@ int csh_selftest_curve_op(int curve, int group, int op, const void* in1, const v
   if (curve == CSH_BLS12_381 && group == CSH_G1) return curve_op<Bls381Fq>(op, in1, in2, k, out);
   if (curve == CSH_BLS12_381 && group == CSH_G2) return curve_op<Bls381Fq2>(op, in1, in2, k, out);
   if (curve == CSH_GRUMPKIN && group == CSH_G1) return curve_op<Bn254Fr>(op, in1, in2, k, out);
+  if (curve == CSH_BLS12_377 && group == CSH_G1) return curve_op<Bls377Fq>(op, in1, in2, k, out);
+  if (curve == CSH_BLS12_377 && group == CSH_G2) return curve_op<Bls377Fq2>(op, in1, in2, k, out);
   return CSH_ERR_INVALID;
 }
 
@@ -292,6 +299,8 @@ int csh_selftest_lazy_accumulate(int curve, int group, const void* affine_pts, c
   if (curve == CSH_BLS12_381 && group == CSH_G1) return lazy_accumulate_t<Fq28s, Bls381Fq>(affine_pts, neg, npts, out_xyzz);
   if (curve == CSH_BLS12_381 && group == CSH_G2) return lazy_accumulate_t<Fq28s2, Bls381Fq2>(affine_pts, neg, npts, out_xyzz);
   if (curve == CSH_GRUMPKIN && group == CSH_G1) return lazy_accumulate_t<Fr29s, Bn254Fr>(affine_pts, neg, npts, out_xyzz);
+  if (curve == CSH_BLS12_377 && group == CSH_G1) return lazy_accumulate_t<Fq28s377, Bls377Fq>(affine_pts, neg, npts, out_xyzz);
+  if (curve == CSH_BLS12_377 && group == CSH_G2) return lazy_accumulate_t<Fq28s377x2, Bls377Fq2>(affine_pts, neg, npts, out_xyzz);
   return CSH_ERR_INVALID;
 }
 
@@ -303,6 +312,8 @@ int csh_selftest_lazy_tree(int curve, int group, const void* affine_pts, const u
   if (curve == CSH_BLS12_381 && group == CSH_G1) return lazy_tree_t<Fq28s, Bls381Fq>(affine_pts, neg, npts, group_len, weight, out_xyzz);
   if (curve == CSH_BLS12_381 && group == CSH_G2) return lazy_tree_t<Fq28s2, Bls381Fq2>(affine_pts, neg, npts, group_len, weight, out_xyzz);
   if (curve == CSH_GRUMPKIN && group == CSH_G1) return lazy_tree_t<Fr29s, Bn254Fr>(affine_pts, neg, npts, group_len, weight, out_xyzz);
+  if (curve == CSH_BLS12_377 && group == CSH_G1) return lazy_tree_t<Fq28s377, Bls377Fq>(affine_pts, neg, npts, group_len, weight, out_xyzz);
+  if (curve == CSH_BLS12_377 && group == CSH_G2) return lazy_tree_t<Fq28s377x2, Bls377Fq2>(affine_pts, neg, npts, group_len, weight, out_xyzz);
   return CSH_ERR_INVALID;
 }
 
@@ -354,7 +365,7 @@ int csh_selftest_rep3_masks_host(int curve, const uint8_t seed1[32], uint64_t e1
 
 // canonical scalar limbs -> signed digits (digits_out[w], w < *W_out)
 int csh_selftest_digits(int curve, const uint64_t scalar[4], int c, int32_t* digits_out, int* W_out) {
-  const int bits = curve == CSH_BN254 ? Bn254FrParams::BITS : Bls381FrParams::BITS;
+  const int bits = curve == CSH_BN254 ? Bn254FrParams::BITS : curve == CSH_BLS12_377 ? Bls377FrParams::BITS : Bls381FrParams::BITS;
   const int W = windows_for(bits, c);
   uint32_t s[8];
   memcpy(s, scalar, 32);

@@ -54,6 +54,8 @@ int csh_util_generate_bases_dev(csh_curve_t curve, csh_group_t group, uint64_t s
   if (curve == CSH_BLS12_381 && group == CSH_G1) return gen_bases_t<Bls381Fq>(Bls381G1Gen, seed, n, out_dev, st);
   if (curve == CSH_BLS12_381 && group == CSH_G2) return gen_bases_t<Bls381Fq2>(Bls381G2Gen, seed, n, out_dev, st);
   if (curve == CSH_GRUMPKIN && group == CSH_G1) return gen_bases_t<Bn254Fr>(GrumpkinG1Gen, seed, n, out_dev, st);
+  if (curve == CSH_BLS12_377 && group == CSH_G1) return gen_bases_t<Bls377Fq>(Bls377G1Gen, seed, n, out_dev, st);
+  if (curve == CSH_BLS12_377 && group == CSH_G2) return gen_bases_t<Bls377Fq2>(Bls377G2Gen, seed, n, out_dev, st);
   set_error("unknown curve/group");
   return CSH_ERR_INVALID;
 }

@@ -98,6 +98,24 @@ def parse_g1(data: bytes, off: int, p: int, nbytes: int):
     return (x, y), off + 2 * nbytes
 
 
+def parse_g2(data: bytes, off: int, p: int, nbytes: int):
+    """The same encoding over Fp2: x.c0, x.c1, y.c0, y.c1, SWFlags in the top two bits of the last byte (of y.c1); `y > -y` compares
+    c1 first, then c0 (ark-ff's Ord for quadratic extensions). -> ((x0, x1), (y0, y1)) or None, new offset."""
+    c = [bytearray(data[off + i * nbytes:off + (i + 1) * nbytes]) for i in range(4)]
+    flags = c[3][-1] >> 6
+    c[3][-1] &= 0x3F
+    x0, x1, y0, y1 = (int.from_bytes(bytes(b), "little") for b in c)
+    if flags & 1:
+        if x0 or x1 or y0 or y1:
+            raise ValueError("infinity flag with non-zero coordinates")
+        return None, off + 4 * nbytes
+    if max(x0, x1, y0, y1) >= p:
+        raise ValueError("coordinate not canonical")
+    n0, n1 = (-y0) % p, (-y1) % p
+    if bool(flags & 2) != ((y1, y0) > (n1, n0)):
+        raise ValueError("y-sign flag does not match y")
+    return ((x0, x1), (y0, y1)), off + 4 * nbytes
+
 
 # ---- bincode witness-share files (co-circom split-witness / generate-proof) ----------------------------------------
 # Restated from the published bincode 1.3 defaults (u64 little-endian lengths, u32 enum variant index) and the

@@ -62,6 +62,18 @@
 #undef FP_R
 #undef FP_R2
 #undef FP_INV
+
+#define FP(x) b7r_##x
+#define FP_P BLS377_FR_P
+#define FP_R BLS377_FR_R
+#define FP_R2 BLS377_FR_R2
+#define FP_INV BLS377_FR_INV
+#include "fp_impl.h"
+#undef FP
+#undef FP_P
+#undef FP_R
+#undef FP_R2
+#undef FP_INV
 #undef FP_N
 
 #define FP_N 6
@@ -70,6 +82,18 @@
 #define FP_R BLS381_FQ_R
 #define FP_R2 BLS381_FQ_R2
 #define FP_INV BLS381_FQ_INV
+#include "fp_impl.h"
+#undef FP
+#undef FP_P
+#undef FP_R
+#undef FP_R2
+#undef FP_INV
+
+#define FP(x) b7q_##x
+#define FP_P BLS377_FQ_P
+#define FP_R BLS377_FQ_R
+#define FP_R2 BLS377_FQ_R2
+#define FP_INV BLS377_FQ_INV
 #include "fp_impl.h"
 #undef FP
 #undef FP_P
@@ -88,6 +112,14 @@
 #include "fp2_impl.h"
 #undef F2
 #undef BF
+#undef F2_NR
+#define F2_NR 5   /* BLS12-377: Fq2 = Fq[u]/(u^2 + 5) */
+#define F2(x) b7q2_##x
+#define BF(x) b7q_##x
+#include "fp2_impl.h"
+#undef F2
+#undef BF
+#undef F2_NR
 
 /* ---- groups -------------------------------------------------------------------------------------------- */
 #define SF_N 4
@@ -119,6 +151,20 @@
 #undef FE
 #undef SF
 #undef SF_BITS
+#define EC(x) b7_g1_##x
+#define FE(x) b7q_##x
+#define SF(x) b7r_##x
+#define SF_BITS 253
+#include "ec_impl.h"
+#undef EC
+#undef FE
+#define EC(x) b7_g2_##x
+#define FE(x) b7q2_##x
+#include "ec_impl.h"
+#undef EC
+#undef FE
+#undef SF
+#undef SF_BITS
 
 static int threads_or_default(int t) {
 #ifdef _OPENMP
@@ -131,7 +177,7 @@ static int threads_or_default(int t) {
 
 int oc_num_threads(void) { return threads_or_default(0); }
 
-/* curve: 0 BN254, 1 BLS12-381; group: 0 G1, 1 G2. points: packed affine (all-zero = infinity);
+/* curve: 0 BN254, 1 BLS12-381, 3 BLS12-377 (the C ABI's csh_curve_t values); group: 0 G1, 1 G2. points: packed affine (all-zero = infinity);
  * out: packed affine. */
 int oc_msm(int curve, int group, const uint64_t* points, const uint64_t* scalars, size_t n, int mont, int nthreads, uint64_t* out) {
   nthreads = threads_or_default(nthreads);
@@ -139,6 +185,8 @@ int oc_msm(int curve, int group, const uint64_t* points, const uint64_t* scalars
   if (curve == 0 && group == 1) { bn_g2_msm((bn_g2_aff*)out, (const bn_g2_aff*)points, scalars, n, mont, nthreads); return 0; }
   if (curve == 1 && group == 0) { bl_g1_msm((bl_g1_aff*)out, (const bl_g1_aff*)points, scalars, n, mont, nthreads); return 0; }
   if (curve == 1 && group == 1) { bl_g2_msm((bl_g2_aff*)out, (const bl_g2_aff*)points, scalars, n, mont, nthreads); return 0; }
+  if (curve == 3 && group == 0) { b7_g1_msm((b7_g1_aff*)out, (const b7_g1_aff*)points, scalars, n, mont, nthreads); return 0; }
+  if (curve == 3 && group == 1) { b7_g2_msm((b7_g2_aff*)out, (const b7_g2_aff*)points, scalars, n, mont, nthreads); return 0; }
   return -1;
 }
 
@@ -150,6 +198,8 @@ int oc_msm_fast(int curve, int group, const uint64_t* points, const uint64_t* sc
   if (curve == 0 && group == 1) { bn_g2_msm_fast((bn_g2_aff*)out, (const bn_g2_aff*)points, scalars, n, mont, nthreads, force_c, stage_s); return 0; }
   if (curve == 1 && group == 0) { bl_g1_msm_fast((bl_g1_aff*)out, (const bl_g1_aff*)points, scalars, n, mont, nthreads, force_c, stage_s); return 0; }
   if (curve == 1 && group == 1) { bl_g2_msm_fast((bl_g2_aff*)out, (const bl_g2_aff*)points, scalars, n, mont, nthreads, force_c, stage_s); return 0; }
+  if (curve == 3 && group == 0) { b7_g1_msm_fast((b7_g1_aff*)out, (const b7_g1_aff*)points, scalars, n, mont, nthreads, force_c, stage_s); return 0; }
+  if (curve == 3 && group == 1) { b7_g2_msm_fast((b7_g2_aff*)out, (const b7_g2_aff*)points, scalars, n, mont, nthreads, force_c, stage_s); return 0; }
   return -1;
 }
 
@@ -159,6 +209,8 @@ int oc_generate_bases(int curve, int group, uint64_t seed, size_t n, int nthread
   if (curve == 0 && group == 1) { bn_g2_gen_bases((bn_g2_aff*)out, (const bn_g2_aff*)BN254_G2_GEN, seed, n, nthreads); return 0; }
   if (curve == 1 && group == 0) { bl_g1_gen_bases((bl_g1_aff*)out, (const bl_g1_aff*)BLS381_G1_GEN, seed, n, nthreads); return 0; }
   if (curve == 1 && group == 1) { bl_g2_gen_bases((bl_g2_aff*)out, (const bl_g2_aff*)BLS381_G2_GEN, seed, n, nthreads); return 0; }
+  if (curve == 3 && group == 0) { b7_g1_gen_bases((b7_g1_aff*)out, (const b7_g1_aff*)BLS377_G1_GEN, seed, n, nthreads); return 0; }
+  if (curve == 3 && group == 1) { b7_g2_gen_bases((b7_g2_aff*)out, (const b7_g2_aff*)BLS377_G2_GEN, seed, n, nthreads); return 0; }
   return -1;
 }
 
@@ -168,6 +220,8 @@ int oc_generate_bases_wide(int curve, int group, uint64_t seed, size_t n, int nt
   if (curve == 0 && group == 1) { bn_g2_gen_bases_wide((bn_g2_aff*)out, (const bn_g2_aff*)BN254_G2_GEN, seed, n, nthreads); return 0; }
   if (curve == 1 && group == 0) { bl_g1_gen_bases_wide((bl_g1_aff*)out, (const bl_g1_aff*)BLS381_G1_GEN, seed, n, nthreads); return 0; }
   if (curve == 1 && group == 1) { bl_g2_gen_bases_wide((bl_g2_aff*)out, (const bl_g2_aff*)BLS381_G2_GEN, seed, n, nthreads); return 0; }
+  if (curve == 3 && group == 0) { b7_g1_gen_bases_wide((b7_g1_aff*)out, (const b7_g1_aff*)BLS377_G1_GEN, seed, n, nthreads); return 0; }
+  if (curve == 3 && group == 1) { b7_g2_gen_bases_wide((b7_g2_aff*)out, (const b7_g2_aff*)BLS377_G2_GEN, seed, n, nthreads); return 0; }
   return -1;
 }
 
@@ -177,6 +231,8 @@ int oc_generate_bases_progression(int curve, int group, uint64_t seed, size_t n,
   if (curve == 0 && group == 1) { bn_g2_gen_bases_progression((bn_g2_aff*)out, (const bn_g2_aff*)BN254_G2_GEN, seed, n, nthreads); return 0; }
   if (curve == 1 && group == 0) { bl_g1_gen_bases_progression((bl_g1_aff*)out, (const bl_g1_aff*)BLS381_G1_GEN, seed, n, nthreads); return 0; }
   if (curve == 1 && group == 1) { bl_g2_gen_bases_progression((bl_g2_aff*)out, (const bl_g2_aff*)BLS381_G2_GEN, seed, n, nthreads); return 0; }
+  if (curve == 3 && group == 0) { b7_g1_gen_bases_progression((b7_g1_aff*)out, (const b7_g1_aff*)BLS377_G1_GEN, seed, n, nthreads); return 0; }
+  if (curve == 3 && group == 1) { b7_g2_gen_bases_progression((b7_g2_aff*)out, (const b7_g2_aff*)BLS377_G2_GEN, seed, n, nthreads); return 0; }
   return -1;
 }
 

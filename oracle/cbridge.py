@@ -54,7 +54,7 @@ def _t(threads: int) -> int:
 
 
 def point_words(curve: int, group: int) -> int:
-    return (4 if curve == 0 else 6) * 2 * (2 if group else 1)
+    return (4 if curve in (0, 2) else 6) * 2 * (2 if group else 1)   # 0 BN254, 1 BLS12-381, 3 BLS12-377 (48-byte Fq)
 
 
 def msm(curve: int, group: int, points, scalars, montgomery=True, threads=0):

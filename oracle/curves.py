@@ -226,7 +226,26 @@ BLS381_G2 = Curve(
 GRUMPKIN_G1 = Curve("grumpkin.G1", fl.BN254_FR, fl.BN254_R - 17,
                     (1, 17631683881184975370165255887551781615748388533673675138860), fl.BN254_Q, fl.BN254_FQ)
 
-CURVES = {"bn254": (BN254_G1, BN254_G2), "bls12_381": (BLS381_G1, BLS381_G2), "grumpkin": (GRUMPKIN_G1,)}
+# BLS12-377 (ark-bls12-377 0.6, un-vendored; the curve of the reference's LibSnarkReduction fixtures, co-circom/co-groth16/src/lib.rs:
+# 231-300, whose committed circuit.vk files hold G1 / G2 points of it -- tests/test_oracle.py checks them against these equations):
+# q, r from the BLS12 polynomials at x = 0x8508C00000000001; E: y^2 = x^3 + 1; the D-type twist E': y^2 = x^3 + 1/u over Fq[u]/(u^2 + 5).
+_b7x = 0x8508C00000000001
+assert fl.BLS377_R == _b7x**4 - _b7x**2 + 1 and fl.BLS377_Q == (_b7x - 1)**2 * fl.BLS377_R // 3 + _b7x
+BLS377_G1 = Curve(
+    "bls12_377.G1", fl.BLS377_FQ, 1,
+    (0x008848DEFE740A67C8FC6225BF87FF5485951E2CAA9D41BB188282C8BD37CB5CD5481512FFCD394EEAB9B16EB21BE9EF,
+     0x01914A69C5102EFF1F674F5D30AFEEC4BD7FB348CA3E52D96D182AD44FB82305C2FE3D3634A9591AFD82DE55559C8EA6),
+    fl.BLS377_R, fl.BLS377_FR, cofactor=(_b7x - 1)**2 // 3)
+BLS377_G2 = Curve(
+    "bls12_377.G2", fl.BLS377_FQ2, fl.BLS377_FQ2.inv((0, 1)),
+    ((0x018480BE71C785FEC89630A2A3841D01C565F071203E50317EA501F557DB6B9B71889F52BB53540274E3E48F7C005196,
+      0x00EA6040E700403170DC5A51B1B140D5532777EE6651CECBE7223ECE0799C9DE5CF89984BFF76FE6B26BFEFA6EA16AFE),
+     (0x00690D665D446F7BD960736BCBB2EFB4DE03ED7274B49A58E458C282F832D204F2CF88886D8C7C2EF094094409FD4DDF,
+      0x00F8169FD28355189E549DA3151A70AA61EF11AC3D591BF12463B01ACEE304C24279B83F5E52270BD9A1CDD185EB8F93)),
+    fl.BLS377_R, fl.BLS377_FR, cofactor=None)
+
+CURVES = {"bn254": (BN254_G1, BN254_G2), "bls12_381": (BLS381_G1, BLS381_G2), "grumpkin": (GRUMPKIN_G1,),
+          "bls12_377": (BLS377_G1, BLS377_G2)}
 
 
 # --- wire layout at the C ABI -----------------------------------------------------------------

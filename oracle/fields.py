@@ -118,10 +118,13 @@ class PrimeField:
 
 
 class Fp2:
-    """Fp[i]/(i^2+1). Elements are (c0, c1) tuples. Both BN254 and BLS12-381 use i^2 = -1."""
+    """Fp[i]/(i^2 + nr). Elements are (c0, c1) tuples. BN254 and BLS12-381 use i^2 = -1; BLS12-377 uses u^2 = -5
+    (ark-bls12-377 0.6 ``Fq2Config::NONRESIDUE = -5``, un-vendored; checked below: -5 is a non-residue mod q)."""
 
-    def __init__(self, base: PrimeField):
+    def __init__(self, base: PrimeField, nr: int = 1):
         self.base = base
+        self.nr = nr
+        assert pow((-nr) % base.p, (base.p - 1) // 2, base.p) == base.p - 1, "i^2 = -nr must have no root in the base field"
         self.p = base.p
         self.name = base.name + "^2"
         self.zero = (0, 0)
@@ -137,7 +140,7 @@ class Fp2:
 
     def mul(self, a, b):
         p = self.p
-        return ((a[0] * b[0] - a[1] * b[1]) % p, (a[0] * b[1] + a[1] * b[0]) % p)
+        return ((a[0] * b[0] - self.nr * a[1] * b[1]) % p, (a[0] * b[1] + a[1] * b[0]) % p)
 
     def sqr(self, a):
         return self.mul(a, a)
@@ -148,7 +151,7 @@ class Fp2:
 
     def inv(self, a):
         p = self.p
-        n = pow(a[0] * a[0] + a[1] * a[1], -1, p)
+        n = pow(a[0] * a[0] + self.nr * a[1] * a[1], -1, p)
         return (a[0] * n % p, (-a[1]) * n % p)
 
     def is_zero(self, a):
@@ -189,6 +192,9 @@ BLS381_FR = PrimeField(BLS381_R, "bls12_381.Fr")
 # BLS12-377 scalar field: only the LibSnarkReduction fixture path (Penumbra circuits, co-groth16/src/lib.rs:231-300) uses it
 BLS377_R = 8444461749428370424248824938781546531375899335154063827935233455917409239041
 BLS377_FR = PrimeField(BLS377_R, "bls12_377.Fr")
+BLS377_Q = 0x01AE3A4617C510EAC63B05C06CA1493B1A22D9F300F5138F1EF3622FBA094800170B5D44300000008508C00000000001
+BLS377_FQ = PrimeField(BLS377_Q, "bls12_377.Fq")
+BLS377_FQ2 = Fp2(BLS377_FQ, 5)
 BN254_FQ2 = Fp2(BN254_FQ)
 BLS381_FQ2 = Fp2(BLS381_FQ)
 

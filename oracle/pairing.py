@@ -110,7 +110,9 @@ class PairingParams:
 
 BN254 = PairingParams("bn254", fl.BN254_Q, fl.BN254_R, 82, -18, 9, 29793968203157093288, True, True)
 BLS381 = PairingParams("bls12_381", fl.BLS381_Q, fl.BLS381_R, 2, -2, 1, 15132376222941642752, False, False)
-PARAMS = {"bn254": BN254, "bls12_381": BLS381}
+# BLS12-377: Fq12 = Fq[w] / (w^12 + 5) (w^6 = u, u^2 = -5), optimal ate loop x = 0x8508C00000000001 > 0, D-type twist (x w^2, y w^3)
+BLS377 = PairingParams("bls12_377", fl.BLS377_Q, fl.BLS377_R, 5, 0, 0, 0x8508C00000000001, False, True)
+PARAMS = {"bn254": BN254, "bls12_381": BLS381, "bls12_377": BLS377}
 
 
 def _embed_fp(K, a):

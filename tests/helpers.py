@@ -6,7 +6,7 @@ import numpy as np
 from oracle import curves as cv
 from oracle import fields as fl
 
-FIELD_IDS = {"bn254.Fq": 0, "bn254.Fr": 1, "bls12_381.Fq": 2, "bls12_381.Fr": 3}
+FIELD_IDS = {"bn254.Fq": 0, "bn254.Fr": 1, "bls12_381.Fq": 2, "bls12_381.Fr": 3, "bls12_377.Fq": 4, "bls12_377.Fr": 5}
 CURVE_IDS = {"bn254": 0, "bls12_381": 1, "grumpkin": 2, "bls12_377": 3}
 FR = {"bn254": fl.BN254_FR, "bls12_381": fl.BLS381_FR, "grumpkin": fl.BN254_FQ, "bls12_377": fl.BLS377_FR}   # scalar field of each curve
 

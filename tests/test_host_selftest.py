@@ -8,7 +8,7 @@ from oracle import curves as cv
 from oracle import fields as fl
 from tests import helpers as H
 
-FIELDS = [fl.BN254_FQ, fl.BN254_FR, fl.BLS381_FQ, fl.BLS381_FR]
+FIELDS = [fl.BN254_FQ, fl.BN254_FR, fl.BLS381_FQ, fl.BLS381_FR, fl.BLS377_FQ, fl.BLS377_FR]
 
 
 def _fop(hip, F, op, a, b=None):
@@ -62,7 +62,7 @@ def test_bn254_fr_mul_known_answer(hip):
         assert _fop(hip, F, 2, F.to_mont(a), F.to_mont(b)) == F.to_mont(c)
 
 
-@pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
+@pytest.mark.parametrize("curve", ["bn254", "bls12_381", "bls12_377"])
 def test_fp2_ops(hip, curve):
     G2 = cv.CURVES[curve][1]
     F2, Fq = G2.F, G2.F.base
@@ -85,7 +85,7 @@ def _xyzz_to_affine(hip, curve_id, group, curve, xyzz):
     return cv.unpack_points(curve, out)[0]
 
 
-@pytest.mark.parametrize("curve,group", [("bn254", 0), ("bn254", 1), ("bls12_381", 0), ("bls12_381", 1)])
+@pytest.mark.parametrize("curve,group", [("bn254", 0), ("bn254", 1), ("bls12_381", 0), ("bls12_381", 1), ("bls12_377", 0), ("bls12_377", 1)])
 def test_xyzz_group_law(hip, curve, group):
     G = cv.CURVES[curve][group]
     cid = H.CURVE_IDS[curve]
@@ -128,7 +128,7 @@ def test_xyzz_group_law(hip, curve, group):
         assert G.eq(_xyzz_to_affine(hip, cid, group, G, out2), G.mul(want, k))
 
 
-@pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
+@pytest.mark.parametrize("curve", ["bn254", "bls12_381", "bls12_377"])
 @pytest.mark.parametrize("c", [2, 3, 4, 7, 11, 13, 16, 17, 20])
 def test_signed_digit_recoding(hip, curve, c):
     F = H.FR[curve]
@@ -180,7 +180,7 @@ def test_signed_lazy_field_ops(hip):
         assert L.csh_selftest_lazys_op(0, pa, pn, pa, out.ctypes.data_as(C.c_void_p)) == 1
 
 
-@pytest.mark.parametrize("curve,group", [("bn254", 0), ("bn254", 1), ("bls12_381", 0), ("bls12_381", 1), ("grumpkin", 0)])
+@pytest.mark.parametrize("curve,group", [("bn254", 0), ("bn254", 1), ("bls12_381", 0), ("bls12_381", 1), ("grumpkin", 0), ("bls12_377", 0), ("bls12_377", 1)])
 def test_lazy_bucket_accumulation_matches_group_law(hip, curve, group):
     """lazy_madd chain (incl. duplicates -> doubling, P + (-P) -> empty, infinity bases, long chains)."""
     G = cv.CURVES[curve][group]
@@ -211,7 +211,7 @@ def test_lazy_bucket_accumulation_matches_group_law(hip, curve, group):
         assert G.eq(got, want)
 
 
-@pytest.mark.parametrize("curve,group", [("bn254", 0), ("bn254", 1), ("bls12_381", 0), ("bls12_381", 1), ("grumpkin", 0)])
+@pytest.mark.parametrize("curve,group", [("bn254", 0), ("bn254", 1), ("bls12_381", 0), ("bls12_381", 1), ("grumpkin", 0), ("bls12_377", 0), ("bls12_377", 1)])
 def test_lazy_point_tree_matches_group_law(hip, curve, group):
     """General XYZZ + XYZZ / doubling / small scalar in the lazy field (what the merge and reduce kernels run):
     group sums folded pairwise, incl. equal sums (-> doubling), opposite sums (-> infinity), empty groups."""
@@ -259,7 +259,7 @@ def test_rep3_mask_generator_matches_rngs_rs(hip, curve):
         b = chacha.keystream(s2, 32 * n, start_byte=32 * e2)
         assert H.unpack(F, out) == mpc.masks_from_streams(F, a, b, n)
 
-@pytest.mark.parametrize("curve,group", [("bn254", 0), ("bn254", 1), ("bls12_381", 0), ("bls12_381", 1), ("grumpkin", 0)])
+@pytest.mark.parametrize("curve,group", [("bn254", 0), ("bn254", 1), ("bls12_381", 0), ("bls12_381", 1), ("grumpkin", 0), ("bls12_377", 0), ("bls12_377", 1)])
 def test_host_window_fold_64bit_limbs(hip, curve, group):
     """csh_msm_fold_partials (host only: Horner over window sums in 64-bit limbs, host_fp64.hpp) for every group:
     two partials with the same layout (summed window-wise first), one with another layout, one empty."""

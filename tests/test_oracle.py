@@ -258,7 +258,13 @@ def test_ark_point_wire_format_on_the_reference_vk_fixture():
     pts = []
     pt, off = arkfmt.parse_g1(vk, 0, q, 48)            # alpha_g1
     pts.append(pt)
-    off += 3 * 192                                     # beta_g2, gamma_g2, delta_g2
+    # beta_g2, gamma_g2, delta_g2: on the twist y^2 = x^3 + 1/u over Fq[u]/(u^2 + 5) and in the r-torsion -- the reference-held pin of
+    # the oracle's BLS12-377 G2 (non-residue, twist constant, group order)
+    from oracle import curves as cv
+    G2 = cv.BLS377_G2
+    for _ in range(3):
+        Q, off = arkfmt.parse_g2(vk, off, q, 48)
+        assert Q is not None and G2.is_on_curve(Q) and G2.mul(Q, G2.order) is None
     (k,) = __import__("struct").unpack_from("<Q", vk, off)
     off += 8
     for _ in range(k):                                 # gamma_abc_g1
@@ -267,6 +273,7 @@ def test_ark_point_wire_format_on_the_reference_vk_fixture():
     assert off == len(vk) and k == 3
     for x, y in pts:
         assert (y * y - x * x * x - 1) % q == 0
+        assert cv.BLS377_G1.mul((x, y), cv.BLS377_G1.order) is None
     # the serializer is the exact inverse
     assert b"".join(arkfmt.ser_g1(pt, q, 48) for pt in pts[1:]) == vk[-3 * 96:]
 
