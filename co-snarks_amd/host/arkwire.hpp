@@ -121,6 +121,94 @@ inline AffineT<Fq> read_g1(Reader& r, bool check_sign_flag = true) {
   return pt;
 }
 
+// G2 affine over Fq2 = (c0, c1), uncompressed: x.c0, x.c1, y.c0, y.c1, flags in the last byte; `y > -y` orders quadratic-extension
+// elements by c1 first, then c0 (ark-ff's Ord for QuadExtField)
+template <class Fq2>
+inline bool y2_is_negative(const Fq2& y_mont) {
+  using Fq = decltype(y_mont.c0);
+  const Fq2 n = Fq2::neg(y_mont);
+  const Fq y1 = y_mont.c1.from_mont(), n1 = n.c1.from_mont(), y0 = y_mont.c0.from_mont(), n0 = n.c0.from_mont();
+  for (int i = Fq::N - 1; i >= 0; --i)
+    if (y1.l[i] != n1.l[i]) return y1.l[i] > n1.l[i];
+  for (int i = Fq::N - 1; i >= 0; --i)
+    if (y0.l[i] != n0.l[i]) return y0.l[i] > n0.l[i];
+  return false;
+}
+template <class Fq2>
+inline void write_g2(std::vector<uint8_t>& out, const AffineT<Fq2>& pt) {
+  const size_t at = out.size();
+  if (pt.is_inf()) {
+    out.resize(at + 2 * sizeof(Fq2), 0);
+    out.back() |= 0x40;
+    return;
+  }
+  write_field(out, pt.x.c0);
+  write_field(out, pt.x.c1);
+  write_field(out, pt.y.c0);
+  write_field(out, pt.y.c1);
+  if (y2_is_negative(pt.y)) out.back() |= 0x80;
+}
+template <class Fq2>
+inline AffineT<Fq2> read_g2(Reader& r, bool check_sign_flag = true) {
+  using Fq = decltype(Fq2().c0);
+  r.need(2 * sizeof(Fq2));
+  Fq c[4];
+  memcpy(c, r.p + r.off, sizeof c);
+  r.off += sizeof c;
+  const uint32_t flags = c[3].l[Fq::N - 1] >> 30;
+  c[3].l[Fq::N - 1] &= 0x3fffffffu;
+  if (flags & 1) return AffineT<Fq2>::inf();
+  for (auto& v : c)
+    if (csh::limbs_geq<Fq::N>(v.l, Fq::Params::MOD)) throw Error("ark-serialize: coordinate not canonical");
+  AffineT<Fq2> pt{{c[0].to_mont(), c[1].to_mont()}, {c[2].to_mont(), c[3].to_mont()}};
+  if (check_sign_flag && ((flags >> 1) & 1) != (y2_is_negative(pt.y) ? 1u : 0u)) throw Error("ark-serialize: y-sign flag does not match y");
+  return pt;
+}
+
+// ark-groth16 `ProvingKey<E>` as `deserialize_uncompressed_unchecked` reads it (co-groth16/src/lib.rs:257, Validate::No: no curve or
+// subgroup check, the y-sign bit of an uncompressed point is not consulted): vk {alpha_g1, beta_g2, gamma_g2, delta_g2, gamma_abc_g1},
+// beta_g1, delta_g1, a_query, b_g1_query, b_g2_query, h_query, l_query -- CanonicalSerialize's derive order; the leading vk is the
+// layout of the reference's committed circuit.vk. The queries stay on the host here; the caller uploads them.
+template <class P>
+inline void read_proving_key(Reader& r, ProvingKey<P>& pk) {
+  using Fq = typename P::Fq;
+  using Fq2 = typename P::Fq2;
+  auto g1 = [&] { return read_g1<Fq>(r, false); };
+  auto g2 = [&] { return read_g2<Fq2>(r, false); };
+  auto vec1 = [&](std::vector<AffineT<Fq>>& v) {
+    const uint64_t n = r.u64();
+    if (n > (r.n - r.off) / (2 * sizeof(Fq))) throw Error("ark-serialize: Vec length exceeds the input");
+    v.resize(n);
+    for (auto& pt : v) pt = g1();
+  };
+  pk.alpha_g1 = g1();
+  pk.beta_g2 = g2();
+  pk.gamma_g2 = g2();
+  pk.delta_g2 = g2();
+  vec1(pk.ic);
+  pk.beta_g1 = g1();
+  pk.delta_g1 = g1();
+  vec1(pk.a_query.host);
+  vec1(pk.b_g1_query.host);
+  {
+    const uint64_t n = r.u64();
+    if (n > (r.n - r.off) / (2 * sizeof(Fq2))) throw Error("ark-serialize: Vec length exceeds the input");
+    pk.b_g2_query.host.resize(n);
+    for (auto& pt : pk.b_g2_query.host) pt = g2();
+  }
+  vec1(pk.h_query.host);
+  vec1(pk.l_query.host);
+}
+// ark-groth16 `Proof<E>` {a, b, c}, Compress::No
+template <class P>
+inline std::vector<uint8_t> write_proof(const Proof<P>& pr) {
+  std::vector<uint8_t> out;
+  write_g1(out, pr.a);
+  write_g2(out, pr.b);
+  write_g1(out, pr.c);
+  return out;
+}
+
 // ---- Rep3NetworkExt::{send_many, recv_many} payloads (mpc-core/src/protocols/rep3/network.rs:103-109, 152-156) ----------------------------
 // What a GPU party has to put on / take off the wire to face two reference CPU parties: ONE `Network::send(to, Bytes)` per call whose
 // payload is `data.serialize_uncompressed()` of the slice -- ark-serialize's impl for `[T]`: the count as u64 little-endian, then every

@@ -1076,6 +1076,63 @@ static int libsnark_from_files_t(const uint8_t* const mats[3], const size_t lens
   return (int)h.size();
 }
 
+// Groth16::<P>::plain_prove::<LibSnarkReduction> from the files the reference's test reads (co-groth16/src/lib.rs:231-290): ark
+// ProvingKey (deserialize_uncompressed_unchecked), Matrix<F> blobs a / b / c, a wtns container; ConstraintMatrices filled in as :268-279
+// does (num_instance_variables = b_g1_query.len() - l_query.len(), ...). r, s: canonical limbs, nullable (drawn otherwise).
+// out: ark-serialize Proof {a, b, c}, uncompressed; returns its length.
+template <class P>
+static int prove_libsnark_t(const uint8_t* const mats[3], const size_t lens[3], const uint8_t* wtns, size_t wlen, const uint8_t* pkey, size_t pklen,
+                            const uint64_t* r, const uint64_t* s, uint8_t* out, size_t cap, uint64_t* h_out, size_t h_cap) {
+  using T = PlainGroth16Driver<P>;
+  using Fr = typename P::Fr;
+  ProvingKey<P> pk;
+  {
+    ark::Reader rp(pkey, pklen);
+    ark::read_proving_key<P>(rp, pk);
+    if (!rp.done()) throw Error("trailing bytes after ProvingKey");
+  }
+  if (pk.b_g1_query.host.size() < pk.l_query.host.size() || pk.a_query.host.size() != pk.b_g1_query.host.size() ||
+      pk.b_g2_query.host.size() != pk.b_g1_query.host.size())
+    throw Error("ProvingKey: query lengths are inconsistent");
+  ConstraintMatrices<P> m;
+  ark::Reader ra(mats[0], lens[0]), rb(mats[1], lens[1]), rc(mats[2], lens[2]);
+  m.a = ark::read_matrix<Fr>(ra);
+  m.b = ark::read_matrix<Fr>(rb);
+  m.c = ark::read_matrix<Fr>(rc);
+  if (!ra.done() || !rb.done() || !rc.done()) throw Error("trailing bytes after Matrix");
+  if (m.a.size() != m.b.size() || m.a.size() != m.c.size()) throw Error("matrices disagree on the number of constraints");
+  m.num_instance_variables = pk.b_g1_query.host.size() - pk.l_query.host.size();   // lib.rs:269
+  m.num_witness_variables = pk.a_query.host.size() - m.num_instance_variables;     // lib.rs:270-271
+  m.num_constraints = m.a.size();
+  m.upload();
+  pk.a_query.upload(P::ID, CSH_G1);
+  pk.b_g1_query.upload(P::ID, CSH_G1);
+  pk.l_query.upload(P::ID, CSH_G1);
+  pk.h_query.upload(P::ID, CSH_G1);
+  pk.b_g2_query.upload(P::ID, CSH_G2);
+  pk.build_tables();
+  std::vector<Fr> w = ark::read_wtns_positional<Fr>(wtns, wlen);
+  SharedWitness<P, Fr> sw;
+  if (m.num_instance_variables > w.size()) throw Error("more instance variables than witness values");
+  sw.public_inputs.assign(w.begin(), w.begin() + m.num_instance_variables);        // lib.rs:283-287
+  sw.witness.assign(w.begin() + m.num_instance_variables, w.end());
+  UnitState st0, st1;
+  Fr rr, ss;
+  if (r) rr = fr_from_canonical<P>(r);
+  if (s) ss = fr_from_canonical<P>(s);
+  std::vector<Fr> h;
+  const Proof<P> pr = CoGroth16<P, T>::template prove_inner<LibSnarkReduction>(nullptr, nullptr, st0, st1, pk, m, sw, r ? &rr : nullptr,
+                                                                                s ? &ss : nullptr, h_out ? &h : nullptr);
+  if (h_out) {
+    if (h.size() > h_cap) throw Error("h_out too small");
+    memcpy(h_out, h.data(), h.size() * 32);
+  }
+  const std::vector<uint8_t> bytes = ark::write_proof<P>(pr);
+  if (bytes.size() > cap) throw Error("output buffer too small");
+  memcpy(out, bytes.data(), bytes.size());
+  return (int)bytes.size();
+}
+
 }  // namespace
 
 extern "C" {
@@ -1127,6 +1184,25 @@ int cog16_libsnark_from_files(int curve, const uint8_t* a, size_t alen, const ui
     if (curve == 0) return libsnark_from_files_t<Bn254>(mats, lens, wtns, wlen, n_instance, h_out, h_cap_elems);
     if (curve == 1) return libsnark_from_files_t<Bls12_381>(mats, lens, wtns, wlen, n_instance, h_out, h_cap_elems);
     if (curve == 3) return libsnark_from_files_t<Bls12_377>(mats, lens, wtns, wlen, n_instance, h_out, h_cap_elems);
+    g_err = "unknown curve";
+    return -1;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+
+// proof_libsnark_penumbra_bls12_377 (co-groth16/src/lib.rs:231-290) and its counterparts on the other curves: see prove_libsnark_t.
+// Returns the proof's byte length or -1.
+int cog16_prove_libsnark(int curve, const uint8_t* a, size_t alen, const uint8_t* b, size_t blen, const uint8_t* c, size_t clen, const uint8_t* wtns,
+                         size_t wlen, const uint8_t* pkey, size_t pklen, const uint64_t* r, const uint64_t* s, uint8_t* out, size_t cap,
+                         uint64_t* h_out, size_t h_cap_elems) {
+  try {
+    const uint8_t* mats[3] = {a, b, c};
+    const size_t lens[3] = {alen, blen, clen};
+    if (curve == 0) return prove_libsnark_t<Bn254>(mats, lens, wtns, wlen, pkey, pklen, r, s, out, cap, h_out, h_cap_elems);
+    if (curve == 1) return prove_libsnark_t<Bls12_381>(mats, lens, wtns, wlen, pkey, pklen, r, s, out, cap, h_out, h_cap_elems);
+    if (curve == 3) return prove_libsnark_t<Bls12_377>(mats, lens, wtns, wlen, pkey, pklen, r, s, out, cap, h_out, h_cap_elems);
     g_err = "unknown curve";
     return -1;
   } catch (const std::exception& e) {

@@ -55,13 +55,16 @@ struct Bls12_381 {
   static const uint32_t* g1_generator_words() { return csh::Bls381G1Gen; }
 };
 
-// scalar field only: the curve of the reference's LibSnarkReduction fixtures (co-groth16/src/lib.rs:231-300); witness maps,
-// no MSM / proof (the C ABI has no BLS12-377 group arithmetic)
+// the curve of the reference's LibSnarkReduction fixtures (co-groth16/src/lib.rs:231-300): witness maps and, since round 6, the
+// whole plain proof (cog16_prove_libsnark: ark ProvingKey + Matrix blobs + wtns in, ark Proof out)
 struct Bls12_377 {
   static constexpr csh_curve_t ID = CSH_BLS12_377;
   using Fr = csh::Bls377Fr;
+  using Fq = csh::Bls377Fq;
+  using Fq2 = csh::Bls377Fq2;
   static constexpr uint64_t FR_GENERATOR = 22;  // ark_bls12_377::Fr::GENERATOR
   static const char* name() { return "bls12377"; }
+  static const uint32_t* g1_generator_words() { return csh::Bls377G1Gen; }
 };
 
 // Tracing spans mirroring the reference's `tracing::debug_span!` names (groth16.rs:229-331, reduction.rs:97-191):

@@ -58,8 +58,10 @@ extern "C" {
 
 /* CSH_GRUMPKIN (MSM entry points only, group CSH_G1): the BN254 cycle curve y^2 = x^3 - 17 over BN254 Fr with scalar field
  * BN254 Fq -- HonkCurve::fast_msm for short_weierstrass::Projective<GrumpkinConfig> (co-noir-common/src/honk_curve.rs:163-177). */
-/* CSH_BLS12_377: accepted only as `field_of` (its scalar field Fr) by the NTT / share-vector / sparse-matrix / reduction
- * entry points -- the field of the reference's LibSnarkReduction fixtures (co-groth16/src/lib.rs:231-300). No MSM. */
+/* CSH_BLS12_377: the curve of the reference's LibSnarkReduction fixtures (Groth16::<Bls12_377>::plain_prove::<LibSnarkReduction>,
+ * co-groth16/src/lib.rs:231-300): `field_of` of the NTT / share-vector / sparse-matrix / reduction entry points (its scalar field Fr)
+ * and, since round 6, both MSM groups (G1: y^2 = x^3 + 1 over the 377-bit Fq, 96-byte affine points; G2 over Fq[u]/(u^2 + 5),
+ * 192 bytes) through every csh_bases_* / csh_msm* entry point, tables and split ranges included. */
 typedef enum { CSH_BN254 = 0, CSH_BLS12_381 = 1, CSH_GRUMPKIN = 2, CSH_BLS12_377 = 3 } csh_curve_t;
 typedef enum { CSH_G1 = 0, CSH_G2 = 1 } csh_group_t;
 

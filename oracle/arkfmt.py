@@ -98,6 +98,43 @@ def parse_g1(data: bytes, off: int, p: int, nbytes: int):
     return (x, y), off + 2 * nbytes
 
 
+def ser_g2(pt, p: int, nbytes: int) -> bytes:
+    """the G2 counterpart of ser_g1: x.c0, x.c1, y.c0, y.c1; `y > -y` compares c1 first, then c0."""
+    if pt is None:
+        b = bytearray(4 * nbytes)
+        b[-1] |= 0x40
+        return bytes(b)
+    (x0, x1), (y0, y1) = pt
+    b = bytearray(ser_field(x0, nbytes) + ser_field(x1, nbytes) + ser_field(y0, nbytes) + ser_field(y1, nbytes))
+    if (y1, y0) > ((-y1) % p, (-y0) % p):
+        b[-1] |= 0x80
+    return bytes(b)
+
+
+def ser_groth16_proving_key(pk: dict, p: int, nbytes: int) -> bytes:
+    """ark-groth16 0.6 `ProvingKey<E>` under CanonicalSerialize, Compress::No (the `circuit.pk` the reference's LibSnark tests read with
+    deserialize_uncompressed_unchecked, co-circom/co-groth16/src/lib.rs:257; the files themselves are absent upstream): fields in
+    declaration order -- vk {alpha_g1, beta_g2, gamma_g2, delta_g2, gamma_abc_g1: Vec}, beta_g1, delta_g1, a_query, b_g1_query,
+    b_g2_query, h_query, l_query; a Vec is its u64 length followed by the items. The leading vk is byte-for-byte the layout of the
+    reference's committed circuit.vk (tests/test_oracle.py parses those)."""
+    g1 = lambda P: ser_g1(P, p, nbytes)
+    g2 = lambda P: ser_g2(P, p, nbytes)
+    vec = lambda f, v: struct.pack("<Q", len(v)) + b"".join(f(P) for P in v)
+    return (g1(pk["alpha_g1"]) + g2(pk["beta_g2"]) + g2(pk["gamma_g2"]) + g2(pk["delta_g2"]) + vec(g1, pk["gamma_abc_g1"]) +
+            g1(pk["beta_g1"]) + g1(pk["delta_g1"]) + vec(g1, pk["a_query"]) + vec(g1, pk["b_g1_query"]) + vec(g2, pk["b_g2_query"]) +
+            vec(g1, pk["h_query"]) + vec(g1, pk["l_query"]))
+
+
+def parse_groth16_proof(data: bytes, p: int, nbytes: int):
+    """ark-groth16 `Proof<E>` {a: G1, b: G2, c: G1}, Compress::No."""
+    a, off = parse_g1(data, 0, p, nbytes)
+    b, off = parse_g2(data, off, p, nbytes)
+    c, off = parse_g1(data, off, p, nbytes)
+    if off != len(data):
+        raise ValueError("trailing bytes after Proof")
+    return {"a": a, "b": b, "c": c}
+
+
 def parse_g2(data: bytes, off: int, p: int, nbytes: int):
     """The same encoding over Fp2: x.c0, x.c1, y.c0, y.c1, SWFlags in the top two bits of the last byte (of y.c1); `y > -y` compares
     c1 first, then c0 (ark-ff's Ord for quadratic extensions). -> ((x0, x1), (y0, y1)) or None, new offset."""

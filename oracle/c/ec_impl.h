@@ -327,6 +327,17 @@ static void EC(mul_u256)(EC(jac)* r, const EC(aff)* p, const uint64_t k[4]) {
     }
   *r = acc;
 }
+/* out[i] = k_i * gen for canonical 256-bit scalars k_i (the query points of a synthetic Groth16 key with known toxic waste: the
+ * restated trusted setup of oracle/groth16.py) */
+static void EC(mul_batch)(EC(aff)* out, const EC(aff)* gen, const uint64_t* scalars, size_t n, int nthreads) {
+#pragma omp parallel for schedule(dynamic, 64) num_threads(nthreads)
+  for (size_t i = 0; i < n; i++) {
+    const uint64_t* k = scalars + 4 * i;
+    if ((k[0] | k[1] | k[2] | k[3]) == 0) { FE(set_zero)(&out[i].x); FE(set_zero)(&out[i].y); continue; }
+    EC(jac) j; EC(mul_u256)(&j, gen, k);
+    EC(jac_to_aff)(&out[i], &j);
+  }
+}
 /* Full-range bases for direct (non closed-form) parity at BASELINE sizes: bases[i] = k_i * G with a 253-bit k_i drawn from
  * four splitmix64 outputs -- generic points with full-width coordinates, every fourth-thousandth one the point at infinity
  * (the zkey queries contain such points). SURVEY 8d config 2, family (i) in spirit: no structure the MSM could exploit. */

@@ -214,6 +214,18 @@ int oc_generate_bases(int curve, int group, uint64_t seed, size_t n, int nthread
   return -1;
 }
 
+/* out[i] = scalars[i] * G (canonical 4-limb scalars), G = the group's generator */
+int oc_fixed_base_mul(int curve, int group, const uint64_t* scalars, size_t n, int nthreads, uint64_t* out) {
+  nthreads = threads_or_default(nthreads);
+  if (curve == 0 && group == 0) { bn_g1_mul_batch((bn_g1_aff*)out, (const bn_g1_aff*)BN254_G1_GEN, scalars, n, nthreads); return 0; }
+  if (curve == 0 && group == 1) { bn_g2_mul_batch((bn_g2_aff*)out, (const bn_g2_aff*)BN254_G2_GEN, scalars, n, nthreads); return 0; }
+  if (curve == 1 && group == 0) { bl_g1_mul_batch((bl_g1_aff*)out, (const bl_g1_aff*)BLS381_G1_GEN, scalars, n, nthreads); return 0; }
+  if (curve == 1 && group == 1) { bl_g2_mul_batch((bl_g2_aff*)out, (const bl_g2_aff*)BLS381_G2_GEN, scalars, n, nthreads); return 0; }
+  if (curve == 3 && group == 0) { b7_g1_mul_batch((b7_g1_aff*)out, (const b7_g1_aff*)BLS377_G1_GEN, scalars, n, nthreads); return 0; }
+  if (curve == 3 && group == 1) { b7_g2_mul_batch((b7_g2_aff*)out, (const b7_g2_aff*)BLS377_G2_GEN, scalars, n, nthreads); return 0; }
+  return -1;
+}
+
 int oc_generate_bases_wide(int curve, int group, uint64_t seed, size_t n, int nthreads, uint64_t* out) {
   nthreads = threads_or_default(nthreads);
   if (curve == 0 && group == 0) { bn_g1_gen_bases_wide((bn_g1_aff*)out, (const bn_g1_aff*)BN254_G1_GEN, seed, n, nthreads); return 0; }

@@ -86,6 +86,14 @@ def generate_bases(curve: int, group: int, seed: int, n: int, threads=0):
     return out
 
 
+def fixed_base_mul(curve: int, group: int, scalars_canonical, threads=0):
+    """out[i] = k_i * G for canonical scalars (n, 4) u64 -> packed affine points (n, point_words)."""
+    sc = np.ascontiguousarray(scalars_canonical, dtype=np.uint64).reshape(-1, 4)
+    out = np.zeros((len(sc), point_words(curve, group)), dtype=np.uint64)
+    assert lib().oc_fixed_base_mul(curve, group, _p(sc), C.c_size_t(len(sc)), _t(threads), _p(out)) == 0
+    return out
+
+
 def generate_bases_wide(curve: int, group: int, seed: int, n: int, threads=0):
     """bases[i] = k_i * G with 253-bit k_i (four splitmix64 outputs); ~1 in 4096 is the point at infinity."""
     out = np.zeros((n, point_words(curve, group)), dtype=np.uint64)

@@ -382,6 +382,88 @@ def prove_rep3(zk: ZKey, wtns, r: int, s: int, rng, with_masks: bool = True):
     return {"a": g_a, "b": g_b, "c": g_c}, hs
 
 
+# ------------------------------------------------------------------ LibSnark keys and proofs (arkworks' own QAP)
+def libsnark_setup(F, generator: int, G1, G2, A, B, Cm, num_instance: int, num_witness: int, toxic, fixed_base):
+    """ark-groth16 0.6 ``generate_parameters_with_qap::<LibsnarkReduction>`` (un-vendored; the generator behind the ``circuit.pk`` /
+    ``circuit.vk`` of the reference's LibSnark tests, co-circom/co-groth16/src/lib.rs:231-300) with the toxic waste SUPPLIED:
+    ``toxic = (tau, alpha, beta, gamma, delta)``. QAP evaluations per variable as ``LibsnarkReduction::instance_map_with_evaluation``
+    takes them: u_j = L_j(tau) on the arkworks domain of size >= num_constraints + num_instance; a_i = sum_j A[j][i] u_j (+ u_(nc + i)
+    for the instance variables: the input-consistency rows), b_i, c_i alike without the extra term; gamma_abc_i = (beta a_i + alpha b_i
+    + c_i) / gamma, l_i = the same over delta; h_query[k] = tau^k Z(tau) / delta for k < domain - 1 (``h_query_scalars(m_raw - 1, ..)``).
+    ``fixed_base(group, scalars)`` returns [k G] for the group's generator (oracle/c: cbridge.fixed_base_mul). The key exists only because
+    the reference's own ``circuit.pk`` files are absent upstream: it is checked by the pairing equation, not against a reference file.
+    Returns the key as a dict of affine points (vk fields + queries)."""
+    p = F.p
+    tau, alpha, beta, gamma, delta = (x % p for x in toxic)
+    nc = len(A)
+    n = 1
+    while n < nc + num_instance:
+        n *= 2
+    power = n.bit_length() - 1
+    root = pow(ntt.arkworks_two_adic_root(F, generator), 1 << (F.two_adicity - power), p)
+    zt = (pow(tau, n, p) - 1) % p
+    assert zt, "tau lies in the domain"
+    zn = zt * pow(n, -1, p) % p
+    u, w = [], 1
+    for _ in range(n):                                           # evaluate_all_lagrange_coefficients(tau)
+        u.append(zn * w % p * pow((tau - w) % p, -1, p) % p)
+        w = w * root % p
+    nv = num_instance + num_witness
+    a, b, c = [0] * nv, [0] * nv, [0] * nv
+    for i in range(num_instance):
+        a[i] = u[nc + i]
+    for M, acc in ((A, a), (B, b), (Cm, c)):
+        for j, row in enumerate(M):
+            for coeff, idx in row:
+                acc[idx] = (acc[idx] + u[j] * coeff) % p
+    gi, di = pow(gamma, -1, p), pow(delta, -1, p)
+    comb = [(beta * x + alpha * y + z) % p for x, y, z in zip(a, b, c)]
+    gamma_abc = [v * gi % p for v in comb[:num_instance]]
+    l = [v * di % p for v in comb[num_instance:]]
+    hq, cur = [], zt * di % p
+    for _ in range(n - 1):
+        hq.append(cur)
+        cur = cur * tau % p
+    g1 = fixed_base(0, [alpha, beta, delta] + a + b + gamma_abc + l + hq)
+    g2 = fixed_base(1, [beta, gamma, delta] + b)
+    o = 3
+    key = {"alpha_g1": g1[0], "beta_g1": g1[1], "delta_g1": g1[2], "beta_g2": g2[0], "gamma_g2": g2[1], "delta_g2": g2[2]}
+    for name, cnt in (("a_query", nv), ("b_g1_query", nv), ("gamma_abc_g1", num_instance), ("l_query", num_witness), ("h_query", n - 1)):
+        key[name] = g1[o:o + cnt]
+        o += cnt
+    key["b_g2_query"] = g2[3:]
+    return key
+
+
+def prove_libsnark_plain(F, generator: int, G1, G2, key, A, B, Cm, public_inputs, witness, r: int, s: int, msm=None, h=None):
+    """``Groth16::<P>::plain_prove::<LibSnarkReduction>`` (co-circom/co-groth16/src/lib.rs:280-282 -> groth16.rs:125-177, 207-338) over an
+    arkworks ``ProvingKey`` (dict as libsnark_setup returns it) with r, s supplied. ``public_inputs`` includes the constant one.
+    ``msm(G, points, scalars)`` defaults to the oracle's own; ``msm_unchecked`` zips to the shorter side (h has one coefficient more than
+    h_query). Returns (proof, h)."""
+    msm = msm or (lambda G, pts, sc: G.msm(pts, sc))
+    drv = PlainDriver(F)
+    if h is None:
+        h = witness_map_libsnark(F, generator, A, B, Cm, len(A), drv, public_inputs, witness)
+    inp = public_inputs[1:]
+
+    def coeff(G, initial, query, vk_param):                      # calculate_coeff, groth16.rs:179-203
+        npub = len(inp)
+        res = G.add(G.add(initial, query[0]), vk_param)
+        res = G.add(res, G.msm(query[1:1 + npub], inp))
+        return G.add(res, msm(G, query[1 + npub:], witness))
+
+    r_g1 = coeff(G1, G1.mul(key["delta_g1"], r), key["a_query"], key["alpha_g1"])
+    s_g1 = coeff(G1, G1.mul(key["delta_g1"], s), key["b_g1_query"], key["beta_g1"])
+    s_g2 = coeff(G2, G2.mul(key["delta_g2"], s), key["b_g2_query"], key["beta_g2"])
+    l_acc = msm(G1, key["l_query"], witness)
+    k = min(len(h), len(key["h_query"]))
+    h_acc = msm(G1, key["h_query"][:k], h[:k])
+    g_c = G1.add(G1.mul(r_g1, s), G1.mul(s_g1, r))
+    g_c = G1.add(g_c, G1.neg(G1.mul(key["delta_g1"], r * s % F.p)))
+    g_c = G1.add(G1.add(g_c, l_acc), h_acc)
+    return {"a": r_g1, "b": s_g2, "c": g_c}, h
+
+
 # ------------------------------------------------------------------ verify
 def verify(curve: str, G1, vk, proof, public) -> bool:
     """e(-A, B) e(alpha, beta) e(IC0 + sum pub_i IC_{i+1}, gamma) e(C, delta) == 1."""

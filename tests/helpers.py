@@ -83,3 +83,28 @@ def load_penumbra_fixture():
     assert ni == exp["num_instance_variables"] and len(A) == exp["num_constraints"]
     return F, A, B, Cm, w[:ni], w[ni:], exp
 
+
+
+def penumbra_libsnark_key(seed: int = 377):
+    """A Groth16 key for the reference's Penumbra output circuit on BLS12-377 from the restated arkworks LibSnark generator
+    (oracle.groth16.libsnark_setup) with seeded toxic waste -- the reference's own circuit.pk is absent upstream. Returns
+    (fixture tuple, key dict, vk dict, ark-serialized ProvingKey bytes, oracle MSM through oracle/c)."""
+    import random
+    from oracle import arkfmt, cbridge as cb, groth16 as g16
+    fx = load_penumbra_fixture()
+    F, A, B, Cm, pub, wit, exp = fx
+    G1, G2 = cv.BLS377_G1, cv.BLS377_G2
+    rng = random.Random(seed)
+    toxic = tuple(rng.randrange(1, F.p) for _ in range(5))
+
+    def fixed_base(group, scalars):
+        return cv.unpack_points((G1, G2)[group], cb.fixed_base_mul(3, group, fl.pack(F, scalars, mont=False)))
+
+    def msm(G, pts, sc):
+        if not pts:
+            return None
+        return cv.unpack_points(G, cb.msm_fast(3, 0 if G is G1 else 1, cv.pack_points(G, pts), fl.pack(F, sc)))[0]
+
+    key = g16.libsnark_setup(F, exp["generator"], G1, G2, A, B, Cm, len(pub), len(wit), toxic, fixed_base)
+    vk = {"alpha_g1": key["alpha_g1"], "beta_g2": key["beta_g2"], "gamma_g2": key["gamma_g2"], "delta_g2": key["delta_g2"], "ic": key["gamma_abc_g1"]}
+    return fx, key, vk, arkfmt.ser_groth16_proving_key(key, G1.F.p, 48), msm

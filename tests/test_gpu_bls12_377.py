@@ -199,3 +199,38 @@ def test_split_msm_ranges_fold_to_the_whole(gpu, group):
     assert G.eq(H.jac_to_affine(G, got), G.msm(pts, sc))
     dsc.free()
     bases.free()
+
+
+def test_libsnark_proof_on_the_reference_penumbra_circuit(gpu):
+    """proof_libsnark_penumbra_output_bls12_377 (co-circom/co-groth16/src/lib.rs:231-290, 297-299) through the host mirror and the device:
+    ark ProvingKey + a / b / c.bin + witness.wtns in (cog16_prove_libsnark reads the reference's formats itself), LibSnarkReduction's h and
+    the five query MSMs (G1 and G2 of BLS12-377) on the GPU, ark Proof out -- bit-identical to the oracle's restated prover and accepted by
+    the oracle's pairing check under the key's vk. (The key comes from the restated arkworks generator: the reference's circuit.pk is
+    absent upstream.)"""
+    import hashlib
+    from cosnarks_amd import groth16 as dev
+    from oracle import arkfmt, groth16 as g16
+    (F_, A, B, Cm, pub, wit, exp), key, vk, pk_bytes, msm = H.penumbra_libsnark_key()
+    G1, G2 = cv.CURVES[CURVE]
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "Groth16", "bls12_377", "penumbra_output")
+    rd = lambda n: gzip.open(os.path.join(d, n + ".gz"), "rb").read()
+    a, b, c, w = rd("a.bin"), rd("b.bin"), rd("c.bin"), rd("witness.wtns")
+    r, s = 0x1234567890ABCDEF % F.p, (F.p - 5)
+    rl, sl = H.pack(F, [r], mont=False), H.pack(F, [s], mont=False)
+    out = (C.c_uint8 * 512)()
+    hbuf = np.zeros(exp["domain_size"] * 4, dtype=np.uint64)
+    L = dev.glib()
+    n = L.cog16_prove_libsnark(CID, a, C.c_size_t(len(a)), b, C.c_size_t(len(b)), c, C.c_size_t(len(c)), w, C.c_size_t(len(w)), pk_bytes,
+                               C.c_size_t(len(pk_bytes)), rl.ctypes.data_as(C.c_void_p), sl.ctypes.data_as(C.c_void_p), out, C.c_size_t(512),
+                               hbuf.ctypes.data_as(C.c_void_p), C.c_size_t(exp["domain_size"]))
+    assert n == 96 + 192 + 96, L.cog16_last_error()
+    got = arkfmt.parse_groth16_proof(bytes(out[:n]), G1.F.p, 48)
+    hh = H.unpack(F, hbuf)
+    assert hashlib.sha256(b"".join(x.to_bytes(32, "little") for x in hh)).hexdigest() == exp["h_sha256"]
+    want, _ = g16.prove_libsnark_plain(F, exp["generator"], G1, G2, key, A, B, Cm, pub, wit, r, s, msm=msm, h=hh)
+    assert got == want
+    assert g16.verify(CURVE, G1, vk, got, pub[1:])
+    # a key cut short is rejected, not mis-parsed
+    assert L.cog16_prove_libsnark(CID, a, C.c_size_t(len(a)), b, C.c_size_t(len(b)), c, C.c_size_t(len(c)), w, C.c_size_t(len(w)), pk_bytes,
+                                  C.c_size_t(len(pk_bytes) - 7), rl.ctypes.data_as(C.c_void_p), sl.ctypes.data_as(C.c_void_p), out, C.c_size_t(512),
+                                  None, C.c_size_t(0)) == -1

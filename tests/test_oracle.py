@@ -277,3 +277,29 @@ def test_ark_point_wire_format_on_the_reference_vk_fixture():
     # the serializer is the exact inverse
     assert b"".join(arkfmt.ser_g1(pt, q, 48) for pt in pts[1:]) == vk[-3 * 96:]
 
+
+
+def test_libsnark_proof_on_the_reference_penumbra_circuit_verifies():
+    """The whole of proof_libsnark_penumbra_output_bls12_377 (co-circom/co-groth16/src/lib.rs:231-290, 297-299) restated: a key from the
+    arkworks LibSnark generator (the reference's circuit.pk is absent upstream, so the toxic waste is seeded here), the reference's a / b /
+    c.bin + witness.wtns, plain_prove::<LibSnarkReduction>, Groth16::verify by the BLS12-377 pairing. Pins the reduction's root / coset
+    choice (a wrong domain ordering or coset breaks H Z = A B - C at tau, hence the pairing equation) and the oracle's BLS12-377 G1 / G2 /
+    Fq12 together; the serialized key starts with bytes laid out exactly as the reference's committed circuit.vk."""
+    import gzip
+    import os
+    from oracle import arkfmt, curves as cv, groth16 as g16
+    (F, A, B, Cm, pub, wit, exp), key, vk, pk_bytes, msm = H.penumbra_libsnark_key()
+    G1, G2 = cv.BLS377_G1, cv.BLS377_G2
+    r, s = 0x1234567890ABCDEF % F.p, (F.p - 5)
+    proof, h = g16.prove_libsnark_plain(F, exp["generator"], G1, G2, key, A, B, Cm, pub, wit, r, s, msm=msm)
+    assert g16.verify("bls12_377", G1, vk, proof, pub[1:])
+    bad = dict(proof)
+    bad["c"] = G1.add(proof["c"], G1.gen)
+    assert not g16.verify("bls12_377", G1, vk, bad, pub[1:])
+    assert not g16.verify("bls12_377", G1, vk, proof, [pub[1], (pub[2] + 1) % F.p])
+    # the key's leading VerifyingKey has the shape of the reference's own circuit.vk: same length, same Vec count, parses the same way
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "Groth16", "bls12_377", "penumbra_output")
+    ref_vk = gzip.open(os.path.join(d, "circuit.vk.gz"), "rb").read()
+    ours = pk_bytes[:len(ref_vk)]
+    assert ours[96 + 3 * 192:96 + 3 * 192 + 8] == ref_vk[96 + 3 * 192:96 + 3 * 192 + 8]
+    assert arkfmt.vk_num_instance_variables(ours, 96, 192) == exp["num_instance_variables"]
