@@ -44,8 +44,11 @@ WORKLOADS = {
     "bls12_381_g1": (1, 0, 96, "BLS12-381 G1", "i32x14 28-bit-limb lazy Montgomery, i64 accumulate (BLS12-381 Fq 381-bit)"),
     "bls12_381_g2": (1, 1, 192, "BLS12-381 G2", "Fp2 over i32x14 28-bit-limb lazy Montgomery, i64 accumulate (BLS12-381 Fq2)"),
     "grumpkin_g1": (2, 0, 64, "Grumpkin G1", "i32x9 29-bit-limb lazy Montgomery, i64 accumulate (BN254 Fr 254-bit)"),
+    # the curve of the reference's LibSnarkReduction fixtures (co-circom/co-groth16/src/lib.rs:231-300); Fq2 = Fq[u]/(u^2 + 5)
+    "bls12_377_g1": (3, 0, 96, "BLS12-377 G1", "i32x14 28-bit-limb lazy Montgomery, i64 accumulate (BLS12-377 Fq 377-bit)"),
+    "bls12_377_g2": (3, 1, 192, "BLS12-377 G2", "Fp2 (u^2 = -5) over i32x14 28-bit-limb lazy Montgomery, i64 accumulate (BLS12-377 Fq2)"),
 }
-CURVE_NAMES = {0: "bn254", 1: "bls12_381", 2: "grumpkin"}
+CURVE_NAMES = {0: "bn254", 1: "bls12_381", 2: "grumpkin", 3: "bls12_377"}
 SEED = 0x00C0FFEE5EED
 
 
@@ -54,6 +57,7 @@ SCALAR_MODULUS = {
     0: 21888242871839275222246405745257275088548364400416034343698204186575808495617,
     1: 52435875175126190479447740508185965837690552500527637822603658699938581184513,
     2: 21888242871839275222246405745257275088696311157297823662689037894645226208583,
+    3: 8444461749428370424248824938781546531375899335154063827935233455917409239041,
 }
 
 
@@ -358,7 +362,8 @@ def live_probe(cx, kind: int, iters: int):
 def msm_roofline(job: MsmJob, rin: dict, log_n_local: int):
     stage_ms, (c_bits, n_win, lane_len, n_seg) = job.stage_timing()
     t_acc = stage_ms[3] * 1e-3
-    kname = {"bn254_g1": "Bn254G1", "bn254_g2": "Bn254G2", "bls12_381_g1": "Bls381G1", "bls12_381_g2": "Bls381G2", "grumpkin_g1": "GrumpkinG1"}[job.workload]
+    kname = {"bn254_g1": "Bn254G1", "bn254_g2": "Bn254G2", "bls12_381_g1": "Bls381G1", "bls12_381_g2": "Bls381G2", "grumpkin_g1": "GrumpkinG1",
+             "bls12_377_g1": "Bls377G1", "bls12_377_g2": "Bls377G2"}[job.workload]
     alg_bytes = job.n * (32.0 + job.pbytes)                  # scalar + affine base per point
     achieved = alg_bytes / t_acc / 1e9
     hbm_peak = float(rin.get("hbm_peak_GBps", 8000.0))     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
@@ -461,6 +466,19 @@ def secondary_single_gpu(cx: Ctx, rin: dict, args):
             cpu_inputs = (pts_host, job.sc.cpu().numpy().view(np.uint64), job.affine_words(res))
         job.free()
         del job
+    # BLS12-377 (the curve of the reference's LibSnarkReduction fixtures; round 6): both groups at 2^20, closed-form checked
+    for wl, steps in (("bls12_377_g1", 5), ("bls12_377_g2", 3)):
+        try:
+            job = MsmJob(cx, wl, 0, 1 << 20, 377)
+            job.drop_point_copy()
+            if args.spinup_s > 0:
+                job.spin_up(min_s=args.spinup_s, batch=3)
+            dt, res = job.timed(steps, 1)
+            out[f"msm_{wl}_2p20"] = {"points_per_s": job.n * steps / dt, "ms": dt / steps * 1e3, "result_check": job.check(res), "steps": steps}
+            job.free()
+            del job
+        except Exception as e:  # noqa: BLE001
+            out[f"msm_{wl}_2p20"] = {"error": repr(e)}
     # The headline workload and the 2^24 workload again with fixed-base tables on the handle, as a prover holds its key (round 6:
     # csh_bases_table_policy -> one table row per window, ONE bucket set, 17- / 20-bit windows: 15 / 13 mixed additions per point instead of
     # 17 / 16; msm_sort_wide.hip). The headline itself stays on the plain handle, as the reference's msm_unchecked is variable-base.

@@ -122,6 +122,8 @@ int csh_current_device(int* device);
 int csh_malloc(void** dev_ptr, size_t bytes);
 int csh_free(void* dev_ptr);
 int csh_memcpy_h2d(void* dev_dst, const void* host_src, size_t bytes);
+/* waits first for whatever the CALLING thread queued with stream = NULL (its lane stream): a result some csh_*_dev call of this thread
+ * is still producing is complete when the copy reads it */
 int csh_memcpy_d2h(void* host_dst, const void* dev_src, size_t bytes);
 /* device-to-device between GPUs (scalars of one prover to the GPU that runs one of its MSMs). stream NULL = synchronous. */
 int csh_memcpy_peer(void* dst, int dst_device, const void* src, int src_device, size_t bytes, void* stream);

@@ -46,7 +46,7 @@ pub fn curve_id<P: Pairing>() -> c_int {
     match (bits, base_bits) {
         (254, 254) => cosnarks_hip_sys::CSH_BN254,
         (255, 381) => cosnarks_hip_sys::CSH_BLS12_381,
-        (253, 377) => cosnarks_hip_sys::CSH_BLS12_377, // scalar-field entry points only
+        (253, 377) => cosnarks_hip_sys::CSH_BLS12_377, // the LibSnarkReduction fixtures' curve (co-groth16/src/lib.rs:231-300): MSM + NTT + share vectors
         _ => panic!("cosnarks_hip: unsupported pairing ({bits}-bit scalar field, {base_bits}-bit base field)"),
     }
 }

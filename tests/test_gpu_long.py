@@ -5,6 +5,7 @@ seconds of CPU restatement each. NOT part of `-m gpu` (the driver's metered run;
 import pytest
 
 from tests import test_gpu_fullsize as T
+from tests import test_gpu_msm as M
 
 pytestmark = pytest.mark.gpu_long
 
@@ -39,3 +40,8 @@ def test_ntt_full_size_long(gpu, curve, logn, ncomp):
 @pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
 def test_ntt_every_size_long(gpu, curve, variant):
     T.test_ntt_every_size_up_to_2p19_vs_cpu_restatement(gpu, curve, variant)
+
+
+@pytest.mark.parametrize("curve,group", M.GROUPS)
+def test_msm_fixed_base_table_layouts_long(gpu, curve, group):
+    M.test_msm_fixed_base_tables(gpu, curve, group, M.TABLE_LAYOUTS_LONG)

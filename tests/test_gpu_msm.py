@@ -411,8 +411,12 @@ def test_msm_multi_shares_one_sort(gpu, curve):
         h.free()
 
 
+TABLE_LAYOUTS = ((0, 0), (13, 0), (16, 2), (13, 4), (11, 5))       # (c, groups); groups = 0: one row per window
+TABLE_LAYOUTS_LONG = ((8, 0), (16, 0), (15, 2), (9, 3))            # -m gpu_long (tests/test_gpu_long.py)
+
+
 @pytest.mark.parametrize("curve,group", GROUPS)
-def test_msm_fixed_base_tables(gpu, curve, group):
+def test_msm_fixed_base_tables(gpu, curve, group, layouts=TABLE_LAYOUTS):
     """csh_bases_precompute / csh_bases_precompute_grouped: with tables on the handle every MSM (full, prefix, offset, skewed
     scalars, canonical scalars) returns the same group element as the oracle; several table widths and row counts (2, 3, 4, 5
     rows: windows w and w + W' k share a bucket set; the last group is ragged when rows x W' > windows)."""
@@ -426,7 +430,7 @@ def test_msm_fixed_base_tables(gpu, curve, group):
     sk = [1] * 300 + [F.p - 1] * 300 + [0] * 100 + H.rand_elems(F, n - 700, r)
     want_full, want_sk = G.msm(pts, sc), G.msm(pts, sk)
     want_off = G.msm(pts[37:37 + 900], sc[:900])
-    for c, groups in ((0, 0), (8, 0), (13, 0), (16, 0), (15, 2), (16, 2), (13, 4), (9, 3), (11, 5)):   # groups = 0: one row per window
+    for c, groups in layouts:
         bases = gpu.Bases(cid, group, cv.pack_points(G, pts)).precompute(c, groups)
         assert G.eq(H.jac_to_affine(G, bases.msm(H.pack(F, sc))), want_full), c
         assert G.eq(H.jac_to_affine(G, bases.msm(H.pack(F, sk))), want_sk), c
