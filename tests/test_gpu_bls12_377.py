@@ -67,6 +67,8 @@ def _gen_bases(gpu, group, seed, n):
 
 @pytest.mark.parametrize("group", [0, 1])
 def test_generated_bases_have_known_dlog_and_equal_the_cpu_restatement(gpu, group):
+    """Also the regression test of the small-copy race: the G2 generator kernel (64 double-and-add steps in Fq2) outlives the
+    call that queued it on the caller's lane stream; the 57 KB csh_memcpy_d2h behind to_host() must wait for it."""
     from oracle import cbridge as cb
     from tests.check_closed_form import dlogs
     G = cv.CURVES[CURVE][group]
