@@ -1081,36 +1081,55 @@ static int libsnark_from_files_t(const uint8_t* const mats[3], const size_t lens
 // does (num_instance_variables = b_g1_query.len() - l_query.len(), ...). r, s: canonical limbs, nullable (drawn otherwise).
 // out: ark-serialize Proof {a, b, c}, uncompressed; returns its length.
 template <class P>
-static int prove_libsnark_t(const uint8_t* const mats[3], const size_t lens[3], const uint8_t* wtns, size_t wlen, const uint8_t* pkey, size_t pklen,
-                            const uint64_t* r, const uint64_t* s, uint8_t* out, size_t cap, uint64_t* h_out, size_t h_cap) {
-  using T = PlainGroth16Driver<P>;
-  using Fr = typename P::Fr;
-  ProvingKey<P> pk;
-  {
+struct LibsnarkFiles {
+  const uint8_t* const* mats;
+  const size_t* lens;
+  const uint8_t* pkey;
+  size_t pklen;
+  // key + matrices onto the calling thread's device
+  void load(ProvingKey<P>& pk, ConstraintMatrices<P>& m) const {
+    using Fr = typename P::Fr;
     ark::Reader rp(pkey, pklen);
     ark::read_proving_key<P>(rp, pk);
     if (!rp.done()) throw Error("trailing bytes after ProvingKey");
+    if (pk.b_g1_query.host.size() < pk.l_query.host.size() || pk.a_query.host.size() != pk.b_g1_query.host.size() ||
+        pk.b_g2_query.host.size() != pk.b_g1_query.host.size())
+      throw Error("ProvingKey: query lengths are inconsistent");
+    ark::Reader ra(mats[0], lens[0]), rb(mats[1], lens[1]), rc(mats[2], lens[2]);
+    m.a = ark::read_matrix<Fr>(ra);
+    m.b = ark::read_matrix<Fr>(rb);
+    m.c = ark::read_matrix<Fr>(rc);
+    if (!ra.done() || !rb.done() || !rc.done()) throw Error("trailing bytes after Matrix");
+    if (m.a.size() != m.b.size() || m.a.size() != m.c.size()) throw Error("matrices disagree on the number of constraints");
+    m.num_instance_variables = pk.b_g1_query.host.size() - pk.l_query.host.size();   // lib.rs:269
+    m.num_witness_variables = pk.a_query.host.size() - m.num_instance_variables;     // lib.rs:270-271
+    m.num_constraints = m.a.size();
+    m.upload();
+    pk.a_query.upload(P::ID, CSH_G1);
+    pk.b_g1_query.upload(P::ID, CSH_G1);
+    pk.l_query.upload(P::ID, CSH_G1);
+    pk.h_query.upload(P::ID, CSH_G1);
+    pk.b_g2_query.upload(P::ID, CSH_G2);
+    pk.build_tables();
   }
-  if (pk.b_g1_query.host.size() < pk.l_query.host.size() || pk.a_query.host.size() != pk.b_g1_query.host.size() ||
-      pk.b_g2_query.host.size() != pk.b_g1_query.host.size())
-    throw Error("ProvingKey: query lengths are inconsistent");
+};
+
+template <class P>
+static int finish_libsnark(const Proof<P>& pr, uint8_t* out, size_t cap) {
+  const std::vector<uint8_t> bytes = ark::write_proof<P>(pr);
+  if (bytes.size() > cap) throw Error("output buffer too small");
+  memcpy(out, bytes.data(), bytes.size());
+  return (int)bytes.size();
+}
+
+template <class P>
+static int prove_libsnark_t(const LibsnarkFiles<P>& files, const uint8_t* wtns, size_t wlen, const uint64_t* r, const uint64_t* s, uint8_t* out,
+                            size_t cap, uint64_t* h_out, size_t h_cap) {
+  using T = PlainGroth16Driver<P>;
+  using Fr = typename P::Fr;
+  ProvingKey<P> pk;
   ConstraintMatrices<P> m;
-  ark::Reader ra(mats[0], lens[0]), rb(mats[1], lens[1]), rc(mats[2], lens[2]);
-  m.a = ark::read_matrix<Fr>(ra);
-  m.b = ark::read_matrix<Fr>(rb);
-  m.c = ark::read_matrix<Fr>(rc);
-  if (!ra.done() || !rb.done() || !rc.done()) throw Error("trailing bytes after Matrix");
-  if (m.a.size() != m.b.size() || m.a.size() != m.c.size()) throw Error("matrices disagree on the number of constraints");
-  m.num_instance_variables = pk.b_g1_query.host.size() - pk.l_query.host.size();   // lib.rs:269
-  m.num_witness_variables = pk.a_query.host.size() - m.num_instance_variables;     // lib.rs:270-271
-  m.num_constraints = m.a.size();
-  m.upload();
-  pk.a_query.upload(P::ID, CSH_G1);
-  pk.b_g1_query.upload(P::ID, CSH_G1);
-  pk.l_query.upload(P::ID, CSH_G1);
-  pk.h_query.upload(P::ID, CSH_G1);
-  pk.b_g2_query.upload(P::ID, CSH_G2);
-  pk.build_tables();
+  files.load(pk, m);
   std::vector<Fr> w = ark::read_wtns_positional<Fr>(wtns, wlen);
   SharedWitness<P, Fr> sw;
   if (m.num_instance_variables > w.size()) throw Error("more instance variables than witness values");
@@ -1127,12 +1146,103 @@ static int prove_libsnark_t(const uint8_t* const mats[3], const size_t lens[3], 
     if (h.size() > h_cap) throw Error("h_out too small");
     memcpy(h_out, h.data(), h.size() * 32);
   }
-  const std::vector<uint8_t> bytes = ark::write_proof<P>(pr);
-  if (bytes.size() > cap) throw Error("output buffer too small");
-  memcpy(out, bytes.data(), bytes.size());
-  return (int)bytes.size();
+  return finish_libsnark<P>(pr, out, cap);
 }
 
+// Rep3CoGroth16::prove::<LibSnarkReduction> (groth16.rs:360-379 with R = LibSnarkReduction) with three in-process parties, as the reference's
+// Rep3 tests run theirs (tests/tests/circom/e2e_tests/rep3.rs:57-69): the witness is shared with share_field_elements semantics from `seed`,
+// every party runs prove_inner on its shares (one GPU per party when the node has them), the three proofs must agree. h_out (nullable):
+// the three parties' h half-shares, one after the other.
+template <class P>
+static int prove_libsnark_rep3_t(const LibsnarkFiles<P>& files, const uint8_t* wtns, size_t wlen, uint64_t seed, const uint64_t* r, const uint64_t* s,
+                                 uint8_t* out, size_t cap, uint64_t* h_out, size_t h_cap) {
+  using T = Rep3Groth16Driver<P>;
+  using Fr = typename P::Fr;
+  using Share = Rep3PrimeFieldShare<Fr>;
+  int ndev = 1;
+  csh_device_count(&ndev);
+  const bool per_party_keys = ndev > 1;
+  ProvingKey<P> pk_shared;
+  ConstraintMatrices<P> m_shared;
+  if (!per_party_keys) files.load(pk_shared, m_shared);
+  std::vector<Fr> w = ark::read_wtns_positional<Fr>(wtns, wlen);
+  size_t n_instance = 0;
+  {
+    ark::Reader rp(files.pkey, files.pklen);   // the instance count without uploading anything: ic = gamma_abc_g1
+    ProvingKey<P> probe;
+    ark::read_proving_key<P>(rp, probe);
+    n_instance = probe.b_g1_query.host.size() - probe.l_query.host.size();
+  }
+  if (n_instance > w.size()) throw Error("more instance variables than witness values");
+  sharefile::CompressedRep3SharedWitness<P> shares[3];
+  split_witness_rep3<P>(w, n_instance, 0, seed, shares);
+  SeededSharer<Fr> rs_sharer(seed, /*domain=*/11);
+  Share r3[3], s3[3];
+  if (r) rs_sharer.share(fr_from_canonical<P>(r), r3);
+  if (s) rs_sharer.share(fr_from_canonical<P>(s), s3);
+  auto nets0 = LocalNetwork::new_parties(3), nets1 = LocalNetwork::new_parties(3);
+  Proof<P> proofs[3];
+  std::vector<Fr> hs[3];
+  std::string errs[3];
+  std::vector<std::thread> th;
+  for (int p = 0; p < 3; ++p) {
+    th.emplace_back([&, p] {
+      try {
+        check(csh_init(ndev > 0 ? p % ndev : 0), "csh_init");
+        ProvingKey<P> pk_own;
+        ConstraintMatrices<P> m_own;
+        if (per_party_keys) files.load(pk_own, m_own);
+        const ProvingKey<P>& pk = per_party_keys ? pk_own : pk_shared;
+        const ConstraintMatrices<P>& m = per_party_keys ? m_own : m_shared;
+        uint8_t my_seed[32];
+        ShareRng(seed, 100 + p).fill(my_seed, 32);
+        Rep3State state0 = Rep3State::create(nets0[p], my_seed);
+        Rep3State state1 = state0.fork(0);
+        SharedWitness<P, Share> sw = sharefile::uncompress<P>(std::move(shares[p]), nets0[p]);
+        proofs[p] = CoGroth16<P, T>::template prove_inner<LibSnarkReduction>(&nets0[p], &nets1[p], state0, state1, pk, m, sw, r ? &r3[p] : nullptr,
+                                                                              s ? &s3[p] : nullptr, h_out ? &hs[p] : nullptr);
+      } catch (const std::exception& e) {
+        errs[p] = e.what();
+        nets0[p].abort();
+        nets1[p].abort();
+      }
+    });
+  }
+  for (auto& t : th) t.join();
+  throw_first_party_error(errs, 3);
+  const std::vector<uint8_t> b0 = ark::write_proof<P>(proofs[0]);
+  if (b0 != ark::write_proof<P>(proofs[1]) || b0 != ark::write_proof<P>(proofs[2])) throw Error("the three parties disagree on the proof");
+  if (h_out) {
+    const size_t n = hs[0].size();
+    if (3 * n > h_cap) throw Error("h_out too small");
+    for (int p = 0; p < 3; ++p) memcpy(h_out + 4 * n * p, hs[p].data(), 32 * n);
+  }
+  return finish_libsnark<P>(proofs[0], out, cap);
+}
+
+template <class P>
+static int prove_libsnark_any(int rep3, const uint8_t* const mats[3], const size_t lens[3], const uint8_t* wtns, size_t wlen, const uint8_t* pkey,
+                              size_t pklen, uint64_t seed, const uint64_t* r, const uint64_t* s, uint8_t* out, size_t cap, uint64_t* h_out, size_t h_cap) {
+  const LibsnarkFiles<P> files{mats, lens, pkey, pklen};
+  return rep3 ? prove_libsnark_rep3_t<P>(files, wtns, wlen, seed, r, s, out, cap, h_out, h_cap)
+              : prove_libsnark_t<P>(files, wtns, wlen, r, s, out, cap, h_out, h_cap);
+}
+static int prove_libsnark_entry(int curve, int rep3, const uint8_t* a, size_t alen, const uint8_t* b, size_t blen, const uint8_t* c, size_t clen,
+                                const uint8_t* wtns, size_t wlen, const uint8_t* pkey, size_t pklen, uint64_t seed, const uint64_t* r, const uint64_t* s,
+                                uint8_t* out, size_t cap, uint64_t* h_out, size_t h_cap_elems) {
+  try {
+    const uint8_t* mats[3] = {a, b, c};
+    const size_t lens[3] = {alen, blen, clen};
+    if (curve == 0) return prove_libsnark_any<Bn254>(rep3, mats, lens, wtns, wlen, pkey, pklen, seed, r, s, out, cap, h_out, h_cap_elems);
+    if (curve == 1) return prove_libsnark_any<Bls12_381>(rep3, mats, lens, wtns, wlen, pkey, pklen, seed, r, s, out, cap, h_out, h_cap_elems);
+    if (curve == 3) return prove_libsnark_any<Bls12_377>(rep3, mats, lens, wtns, wlen, pkey, pklen, seed, r, s, out, cap, h_out, h_cap_elems);
+    g_err = "unknown curve";
+    return -1;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return -1;
+  }
+}
 }  // namespace
 
 extern "C" {
@@ -1192,23 +1302,18 @@ int cog16_libsnark_from_files(int curve, const uint8_t* a, size_t alen, const ui
   }
 }
 
-// proof_libsnark_penumbra_bls12_377 (co-groth16/src/lib.rs:231-290) and its counterparts on the other curves: see prove_libsnark_t.
-// Returns the proof's byte length or -1.
+// proof_libsnark_penumbra_bls12_377 (co-groth16/src/lib.rs:231-290) and its counterparts on the other curves: see prove_libsnark_t;
+// cog16_prove_libsnark_rep3: the same circuit through three in-process Rep3 parties (prove_libsnark_rep3_t). Return the proof's byte
+// length or -1.
 int cog16_prove_libsnark(int curve, const uint8_t* a, size_t alen, const uint8_t* b, size_t blen, const uint8_t* c, size_t clen, const uint8_t* wtns,
                          size_t wlen, const uint8_t* pkey, size_t pklen, const uint64_t* r, const uint64_t* s, uint8_t* out, size_t cap,
                          uint64_t* h_out, size_t h_cap_elems) {
-  try {
-    const uint8_t* mats[3] = {a, b, c};
-    const size_t lens[3] = {alen, blen, clen};
-    if (curve == 0) return prove_libsnark_t<Bn254>(mats, lens, wtns, wlen, pkey, pklen, r, s, out, cap, h_out, h_cap_elems);
-    if (curve == 1) return prove_libsnark_t<Bls12_381>(mats, lens, wtns, wlen, pkey, pklen, r, s, out, cap, h_out, h_cap_elems);
-    if (curve == 3) return prove_libsnark_t<Bls12_377>(mats, lens, wtns, wlen, pkey, pklen, r, s, out, cap, h_out, h_cap_elems);
-    g_err = "unknown curve";
-    return -1;
-  } catch (const std::exception& e) {
-    g_err = e.what();
-    return -1;
-  }
+  return prove_libsnark_entry(curve, 0, a, alen, b, blen, c, clen, wtns, wlen, pkey, pklen, 0, r, s, out, cap, h_out, h_cap_elems);
+}
+int cog16_prove_libsnark_rep3(int curve, const uint8_t* a, size_t alen, const uint8_t* b, size_t blen, const uint8_t* c, size_t clen,
+                              const uint8_t* wtns, size_t wlen, const uint8_t* pkey, size_t pklen, uint64_t seed, const uint64_t* r, const uint64_t* s,
+                              uint8_t* out, size_t cap, uint64_t* h_shares_out, size_t h_cap_elems) {
+  return prove_libsnark_entry(curve, 1, a, alen, b, blen, c, clen, wtns, wlen, pkey, pklen, seed, r, s, out, cap, h_shares_out, h_cap_elems);
 }
 
 // ark-serialize round trips of the host mirror (arkwire.hpp): mode 0 Vec<Fr> (in: Montgomery limbs of n elements ->

@@ -1,4 +1,5 @@
 """Shared test helpers: seeded inputs and conversions between oracle ints and C-ABI limb arrays."""
+import functools
 import random
 
 import numpy as np
@@ -85,6 +86,7 @@ def load_penumbra_fixture():
 
 
 
+@functools.lru_cache(maxsize=2)
 def penumbra_libsnark_key(seed: int = 377):
     """A Groth16 key for the reference's Penumbra output circuit on BLS12-377 from the restated arkworks LibSnark generator
     (oracle.groth16.libsnark_setup) with seeded toxic waste -- the reference's own circuit.pk is absent upstream. Returns

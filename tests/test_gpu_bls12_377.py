@@ -236,3 +236,36 @@ def test_libsnark_proof_on_the_reference_penumbra_circuit(gpu):
     assert L.cog16_prove_libsnark(CID, a, C.c_size_t(len(a)), b, C.c_size_t(len(b)), c, C.c_size_t(len(c)), w, C.c_size_t(len(w)), pk_bytes,
                                   C.c_size_t(len(pk_bytes) - 7), rl.ctypes.data_as(C.c_void_p), sl.ctypes.data_as(C.c_void_p), out, C.c_size_t(512),
                                   None, C.c_size_t(0)) == -1
+
+
+def test_rep3_libsnark_proof_equals_the_plain_proof(gpu):
+    """Rep3CoGroth16::prove::<LibSnarkReduction> (co-circom/co-groth16/src/groth16.rs:360-379 with the LibSnark reduction) on the reference's
+    Penumbra circuit, three in-process parties as in the reference's Rep3 tests (tests/tests/circom/e2e_tests/rep3.rs:57-69): witness shared
+    from a seed, LibSnark witness map with device masks and the five query MSMs per party on BLS12-377, the parties' proofs agree, equal
+    the plain proof for the same r, s bit for bit, and verify by pairing; the three h half-share vectors sum to the plain h."""
+    import hashlib
+    from cosnarks_amd import groth16 as dev
+    from oracle import arkfmt, groth16 as g16
+    (F_, A, B, Cm, pub, wit, exp), key, vk, pk_bytes, msm = H.penumbra_libsnark_key()
+    G1, G2 = cv.CURVES[CURVE]
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "Groth16", "bls12_377", "penumbra_output")
+    rd = lambda n: gzip.open(os.path.join(d, n + ".gz"), "rb").read()
+    a, b, c, w = rd("a.bin"), rd("b.bin"), rd("c.bin"), rd("witness.wtns")
+    r, s = 0x0123456789ABCDEF0123 % F.p, (F.p - 77)
+    rl, sl = H.pack(F, [r], mont=False), H.pack(F, [s], mont=False)
+    L = dev.glib()
+    n_dom = exp["domain_size"]
+    plain, rep3 = (C.c_uint8 * 512)(), (C.c_uint8 * 512)()
+    hs = np.zeros(3 * n_dom * 4, dtype=np.uint64)
+    args = (CID, a, C.c_size_t(len(a)), b, C.c_size_t(len(b)), c, C.c_size_t(len(c)), w, C.c_size_t(len(w)), pk_bytes, C.c_size_t(len(pk_bytes)))
+    n0 = L.cog16_prove_libsnark(*args, rl.ctypes.data_as(C.c_void_p), sl.ctypes.data_as(C.c_void_p), plain, C.c_size_t(512), None, C.c_size_t(0))
+    assert n0 == 384, L.cog16_last_error()
+    n1 = L.cog16_prove_libsnark_rep3(*args, C.c_uint64(4242), rl.ctypes.data_as(C.c_void_p), sl.ctypes.data_as(C.c_void_p), rep3, C.c_size_t(512),
+                                     hs.ctypes.data_as(C.c_void_p), C.c_size_t(3 * n_dom))
+    assert n1 == 384, L.cog16_last_error()
+    assert bytes(rep3[:384]) == bytes(plain[:384])
+    assert g16.verify(CURVE, G1, vk, arkfmt.parse_groth16_proof(bytes(rep3[:384]), G1.F.p, 48), pub[1:])
+    parts = [H.unpack(F, hs[4 * n_dom * p:4 * n_dom * (p + 1)]) for p in range(3)]
+    h = [(x + y + z) % F.p for x, y, z in zip(*parts)]
+    assert hashlib.sha256(b"".join(x.to_bytes(32, "little") for x in h)).hexdigest() == exp["h_sha256"]
+    assert parts[0] != h
