@@ -46,6 +46,22 @@ def parse_wtns_positional(data: bytes):
     return prime, [int.from_bytes(data[off + i * n8:off + (i + 1) * n8], "little") for i in range(count)]
 
 
+def ser_matrix(rows, nbytes: int = 32) -> bytes:
+    """inverse of parse_matrix: rows of (canonical value, column index)"""
+    out = bytearray(struct.pack("<Q", len(rows)))
+    for row in rows:
+        out += struct.pack("<Q", len(row))
+        for v, idx in row:
+            out += int(v).to_bytes(nbytes, "little") + struct.pack("<Q", idx)
+    return bytes(out)
+
+
+def ser_wtns_positional(prime: int, values, n8: int = 32) -> bytes:
+    """inverse of parse_wtns_positional, section headers written as zeros like the Penumbra fixtures"""
+    return (b"wtns" + bytes(8) + bytes(12) + struct.pack("<I", n8) + prime.to_bytes(n8, "little") + struct.pack("<I", len(values)) + bytes(12) +
+            b"".join(int(v).to_bytes(n8, "little") for v in values))
+
+
 def vk_num_instance_variables(data: bytes, g1_bytes: int, g2_bytes: int) -> int:
     """ark_groth16::VerifyingKey uncompressed: alpha_g1, beta_g2, gamma_g2, delta_g2, gamma_abc_g1: Vec<G1Affine>;
     len(gamma_abc_g1) = num_instance_variables (the reference derives the same number from the proving key)."""

@@ -447,3 +447,46 @@ def test_h_with_fused_tile_passes_equals_two_launch_and_unfused_forms(gpu, logn)
         assert np.array_equal(outs["pair"], outs["two_launches"]), (logn, protocol)
         assert np.array_equal(outs["pair"], outs["unfused"]), (logn, protocol)
     dom.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("curve,generator", [("bn254", 5), ("bls12_381", 7)])
+def test_libsnark_proofs_plain_and_rep3_on_a_random_circuit(gpu, curve, generator):
+    """plain_prove::<LibSnarkReduction> and the three-party Rep3 prove over an arkworks ProvingKey on the two north-star curves
+    (cog16_prove_libsnark / _rep3: ark ProvingKey + Matrix blobs + wtns in, ark Proof out; the BLS12-377 counterpart on the reference's
+    Penumbra circuit is tests/test_gpu_bls12_377.py): a random satisfied R1CS of 300 constraints, key from the restated arkworks generator
+    with seeded toxic waste; the device's proof equals the restated prover's, the Rep3 proof equals the plain one, the pairing accepts it."""
+    import ctypes as C
+    import random
+    import numpy as np
+    from cosnarks_amd import groth16 as dev
+    from oracle import arkfmt, cbridge as cb, curves as cv, fields as fl, groth16 as g16
+    F = H.FR[curve]
+    cid = H.CURVE_IDS[curve]
+    G1, G2 = cv.CURVES[curve]
+    rng = random.Random(2024 + cid)
+    n_public, n_constraints = 3, 300
+    A, B, Cm, w = g16.random_r1cs(F, rng, n_public, n_constraints)
+    pub, wit = w[:n_public], w[n_public:]
+    toxic = tuple(rng.randrange(1, F.p) for _ in range(5))
+    fixed_base = lambda group, sc: cv.unpack_points((G1, G2)[group], cb.fixed_base_mul(cid, group, fl.pack(F, sc, mont=False)))
+    key = g16.libsnark_setup(F, generator, G1, G2, A, B, Cm, n_public, len(wit), toxic, fixed_base)
+    vk = {"alpha_g1": key["alpha_g1"], "beta_g2": key["beta_g2"], "gamma_g2": key["gamma_g2"], "delta_g2": key["delta_g2"], "ic": key["gamma_abc_g1"]}
+    nb = G1.F.nbytes
+    pk_bytes = arkfmt.ser_groth16_proving_key(key, G1.F.p, nb)
+    a, b, c = (arkfmt.ser_matrix(M) for M in (A, B, Cm))
+    wt = arkfmt.ser_wtns_positional(F.p, w)
+    r, s = rng.randrange(F.p), rng.randrange(F.p)
+    rl, sl = H.pack(F, [r], mont=False), H.pack(F, [s], mont=False)
+    L = dev.glib()
+    plen = 8 * nb
+    plain, rep3 = (C.c_uint8 * 512)(), (C.c_uint8 * 512)()
+    args = (cid, a, C.c_size_t(len(a)), b, C.c_size_t(len(b)), c, C.c_size_t(len(c)), wt, C.c_size_t(len(wt)), pk_bytes, C.c_size_t(len(pk_bytes)))
+    assert L.cog16_prove_libsnark(*args, rl.ctypes.data_as(C.c_void_p), sl.ctypes.data_as(C.c_void_p), plain, C.c_size_t(512), None, C.c_size_t(0)) == plen, L.cog16_last_error()
+    got = arkfmt.parse_groth16_proof(bytes(plain[:plen]), G1.F.p, nb)
+    want, _ = g16.prove_libsnark_plain(F, generator, G1, G2, key, A, B, Cm, pub, wit, r, s)
+    assert got == want
+    assert g16.verify(curve, G1, vk, got, pub[1:])
+    assert L.cog16_prove_libsnark_rep3(*args, C.c_uint64(99), rl.ctypes.data_as(C.c_void_p), sl.ctypes.data_as(C.c_void_p), rep3, C.c_size_t(512),
+                                       None, C.c_size_t(0)) == plen, L.cog16_last_error()
+    assert bytes(rep3[:plen]) == bytes(plain[:plen])

@@ -303,3 +303,29 @@ def test_libsnark_proof_on_the_reference_penumbra_circuit_verifies():
     ours = pk_bytes[:len(ref_vk)]
     assert ours[96 + 3 * 192:96 + 3 * 192 + 8] == ref_vk[96 + 3 * 192:96 + 3 * 192 + 8]
     assert arkfmt.vk_num_instance_variables(ours, 96, 192) == exp["num_instance_variables"]
+
+
+@pytest.mark.parametrize("curve,generator", [("bn254", 5), ("bls12_381", 7)])
+def test_libsnark_setup_and_prover_restatements_verify_by_pairing(curve, generator):
+    """The restated arkworks LibSnark generator + prover on the two north-star curves: a random satisfied R1CS, seeded toxic waste, the
+    proof verifies under the key's vk (the same pairing code that accepts the reference's committed snarkjs proofs); a wrong h is rejected."""
+    import random
+    from oracle import cbridge as cb, curves as cv, fields as fl, groth16 as g16
+    from tests import helpers as H
+    F = H.FR[curve]
+    cid = H.CURVE_IDS[curve]
+    G1, G2 = cv.CURVES[curve]
+    rng = random.Random(7 + cid)
+    A, B, Cm, w = g16.random_r1cs(F, rng, 3, 40)
+    pub, wit = w[:3], w[3:]
+    toxic = tuple(rng.randrange(1, F.p) for _ in range(5))
+    fixed_base = lambda group, sc: cv.unpack_points((G1, G2)[group], cb.fixed_base_mul(cid, group, fl.pack(F, sc, mont=False)))
+    key = g16.libsnark_setup(F, generator, G1, G2, A, B, Cm, 3, len(wit), toxic, fixed_base)
+    vk = {"alpha_g1": key["alpha_g1"], "beta_g2": key["beta_g2"], "gamma_g2": key["gamma_g2"], "delta_g2": key["delta_g2"], "ic": key["gamma_abc_g1"]}
+    r, s = rng.randrange(F.p), rng.randrange(F.p)
+    proof, h = g16.prove_libsnark_plain(F, generator, G1, G2, key, A, B, Cm, pub, wit, r, s)
+    assert g16.verify(curve, G1, vk, proof, pub[1:])
+    bad_h = list(h)
+    bad_h[1] = (bad_h[1] + 1) % F.p
+    bad, _ = g16.prove_libsnark_plain(F, generator, G1, G2, key, A, B, Cm, pub, wit, r, s, h=bad_h)
+    assert not g16.verify(curve, G1, vk, bad, pub[1:])
