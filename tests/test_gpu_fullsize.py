@@ -170,8 +170,8 @@ def test_ntt_beyond_2p23_equals_cpu_restatement(gpu, logn, ncomp):
     dom.free()
 
 
-RANDOM_POINTS_DEFAULT = [("bn254", 0, "hashed"), ("bn254", 1, "wide"), ("bls12_381", 0, "wide")]
-RANDOM_POINTS_LONG = [("bls12_381", 1, "wide20"), ("bls12_381", 0, "wide20"), ("bn254", 0, "wide20"), ("bn254", 1, "wide20")]   # tests/test_gpu_long.py (-m gpu_long)
+RANDOM_POINTS_DEFAULT = [("bn254", 0, "hashed"), ("bn254", 1, "wide")]
+RANDOM_POINTS_LONG = [("bls12_381", 0, "wide"), ("bls12_381", 1, "wide20"), ("bls12_381", 0, "wide20"), ("bn254", 0, "wide20"), ("bn254", 1, "wide20")]   # tests/test_gpu_long.py (-m gpu_long)
 
 
 @pytest.mark.parametrize("curve,group,family", RANDOM_POINTS_DEFAULT)
@@ -208,7 +208,10 @@ def test_msm_2p20_random_points_equals_cpu_restatement(gpu, curve, group, family
     bases.free()
 
 
-@pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
+SHARE_VECTOR_CURVES_LONG = ["bls12_381"]          # tests/test_gpu_long.py (-m gpu_long)
+
+
+@pytest.mark.parametrize("curve", ["bn254"])
 def test_share_vector_kernels_beyond_one_launch_width(gpu, curve):
     """2^24 + 5 elements: more than 65536 workgroups x 256 lanes, so every kernel takes its grid-stride branch; each result is
     compared element for element with oracle/c."""

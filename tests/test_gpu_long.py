@@ -45,3 +45,8 @@ def test_ntt_every_size_long(gpu, curve, variant):
 @pytest.mark.parametrize("curve,group", M.GROUPS)
 def test_msm_fixed_base_table_layouts_long(gpu, curve, group):
     M.test_msm_fixed_base_tables(gpu, curve, group, M.TABLE_LAYOUTS_LONG)
+
+
+@pytest.mark.parametrize("curve", T.SHARE_VECTOR_CURVES_LONG)
+def test_share_vector_kernels_beyond_one_launch_width_long(gpu, curve):
+    T.test_share_vector_kernels_beyond_one_launch_width(gpu, curve)
