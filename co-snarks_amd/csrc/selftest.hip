@@ -246,6 +246,24 @@ static int lazy_vec_t(int op, const uint64_t* a, const uint64_t* b, const uint64
   return CSH_OK;
 }
 
+// Fp2 products of the signed lazy field on RAW limbs (no conversion in front): the caller chooses every limb, so the column bound the
+// routines were derived for can be driven to its edge (all limbs at +/-(2^B + 8)) -- the values are arbitrary integers, only defined mod p.
+// limbs: 4 elements x 2 components x NL int32; op 0: a b, 1: a^2, 2: a^2 - b, 3: a b - c d. out: the result as arkworks Montgomery limbs.
+template <class L2, class F2>
+static int fp2s_raw_t(int op, const int32_t* limbs, uint64_t* out) {
+  using LF = decltype(L2().c0);
+  constexpr int NL = LF::NL;
+  L2 v[4];
+  for (int e = 0; e < 4; ++e)
+    for (int i = 0; i < NL; ++i) {
+      v[e].c0.l[i] = limbs[(2 * e) * NL + i];
+      v[e].c1.l[i] = limbs[(2 * e + 1) * NL + i];
+    }
+  const L2 r = op == 0 ? L2::mul(v[0], v[1]) : op == 1 ? L2::sqr(v[0]) : op == 2 ? L2::sqr_sub(v[0], v[1]) : L2::mul_sub(v[0], v[1], v[2], v[3]);
+  const F2 f = r.to_fp();
+  memcpy(out, &f, sizeof f);
+  return CSH_OK;
+}
 extern "C" {
 
 int csh_selftest_lazy_chain_dev(int curve, int group, const void* affine_pts, size_t n, size_t len, size_t nthreads, size_t host_samples,
@@ -344,6 +362,13 @@ int csh_selftest_lazys_op(int op, const uint64_t a[4], const uint64_t b[4], cons
   Bn254Fq r = L::mul(s, lc).to_fp();
   memcpy(out, &r, 32);
   return s.is_zero() ? 1 : 0;   // also reports the zero test of (a +/- b)
+}
+
+int csh_selftest_fp2s_raw(int curve, int op, const int32_t* limbs, uint64_t* out) {
+  if (curve == CSH_BN254) return fp2s_raw_t<Fq29s2, Bn254Fq2>(op, limbs, out);
+  if (curve == CSH_BLS12_381) return fp2s_raw_t<Fq28s2, Bls381Fq2>(op, limbs, out);
+  if (curve == CSH_BLS12_377) return fp2s_raw_t<Fq28s377x2, Bls377Fq2>(op, limbs, out);
+  return CSH_ERR_INVALID;
 }
 
 // host execution of the on-device Rep3 mask generator (same template code as k_rep3_masks)

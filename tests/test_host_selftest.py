@@ -370,3 +370,38 @@ def test_lazy_share_vector_products(hip, curve):
             assert L.csh_selftest_lazy_vec(cid, 1, pk(a), pk(b), pk(c), pk(d), pk(m), out.ctypes.data_as(C.c_void_p)) == 0
             assert H.unpack(F, out) == [(a * (c + d) + b * c + m) % F.p]
 
+
+
+@pytest.mark.parametrize("curve", ["bn254", "bls12_381", "bls12_377"])
+def test_lazy_fp2_products_at_the_edge_of_their_column_bound(hip, curve):
+    """Fp2S mul / sqr / sqr_sub / mul_sub on RAW signed limbs (csh_selftest_fp2s_raw): limbs 0 .. NL-2 of every operand at +/-(2^B + 8) (the top limb within the value contract, |x| < 8p) -- the
+    normalised-operand bound the 63-bit column sums were derived for (BLS12-377: (1 + 5) 14 2^56 products + 14 2^56 of the reduction) --,
+    mixed signs, and random limbs in that range; the result equals big-integer arithmetic on the values the limbs spell (an overflowing
+    column would show here, on the host run of the same template code the kernels use)."""
+    G2 = cv.CURVES[curve][1]
+    F2, Fq = G2.F, G2.F.base
+    p = Fq.p
+    B, NL = (29, 9) if curve == "bn254" else (28, 14)
+    lim = (1 << B) + 8
+    Rinv = pow(1 << (B * NL), -1, p)
+    val = lambda l: sum(int(x) << (B * i) for i, x in enumerate(l))
+    rep = lambda e: (val(e[0]) * Rinv % p, val(e[1]) * Rinv % p)
+    r = H.rng(12377)
+    top = 4 * (p >> (B * (NL - 1)))          # the value contract: operands within (-8p, 8p) -- the top limb carries sign and size, the rest the bound
+    tl = lambda: [r.randrange(-top, top + 1)]
+    patterns = [
+        lambda: [lim] * (NL - 1) + tl(), lambda: [-lim] * (NL - 1) + tl(), lambda: [lim if i % 2 else -lim for i in range(NL - 1)] + tl(),
+        lambda: [r.choice((lim, -lim)) for _ in range(NL - 1)] + tl(), lambda: [r.randrange(-lim, lim + 1) for _ in range(NL - 1)] + tl(),
+    ]
+    L = hip.lib()
+    for trial in range(60):
+        els = [(patterns[r.randrange(5)](), patterns[r.randrange(5)]()) for _ in range(4)]
+        if trial < 5:
+            els = [(patterns[trial](), patterns[trial]()) for _ in range(4)]
+        flat = np.array([x for e in els for comp in e for x in comp], dtype=np.int32)
+        a, b, c, d = (rep(e) for e in els)
+        want = [F2.mul(a, b), F2.sqr(a), F2.sub(F2.sqr(a), b), F2.sub(F2.mul(a, b), F2.mul(c, d))]
+        for op in range(4):
+            out = np.zeros(2 * Fq.nlimbs, dtype=np.uint64)
+            assert L.csh_selftest_fp2s_raw(H.CURVE_IDS[curve], op, flat.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)) == 0
+            assert tuple(H.unpack(Fq, out)) == want[op], (trial, op)
