@@ -1220,22 +1220,90 @@ static int prove_libsnark_rep3_t(const LibsnarkFiles<P>& files, const uint8_t* w
   return finish_libsnark<P>(proofs[0], out, cap);
 }
 
+// ShamirCoGroth16::prove::<LibSnarkReduction> (groth16.rs:439-463 with the LibSnark reduction): n in-process parties, threshold t, the witness
+// shared with share_shamir semantics from `seed`, a dealer standing in for the DN07 preprocessing (as prove_shamir_core); with r / s given the
+// first two double sharings share exactly r and s, so the proof equals the plain one for the same r, s.
 template <class P>
-static int prove_libsnark_any(int rep3, const uint8_t* const mats[3], const size_t lens[3], const uint8_t* wtns, size_t wlen, const uint8_t* pkey,
+static int prove_libsnark_shamir_t(const LibsnarkFiles<P>& files, const uint8_t* wtns, size_t wlen, int n, int t, uint64_t seed, const uint64_t* r,
+                                   const uint64_t* s, uint8_t* out, size_t cap) {
+  using T = ShamirGroth16Driver<P>;
+  using Fr = typename P::Fr;
+  if (n < 2 * t + 1 || t < 1) throw Error("num_parties must be at least 2 * threshold + 1");
+  int ndev = 1;
+  csh_device_count(&ndev);
+  const bool per_party_keys = ndev > 1;
+  ProvingKey<P> pk_shared;
+  ConstraintMatrices<P> m_shared;
+  if (!per_party_keys) files.load(pk_shared, m_shared);
+  size_t n_instance = 0;
+  {
+    ark::Reader rp(files.pkey, files.pklen);
+    ProvingKey<P> probe;
+    ark::read_proving_key<P>(rp, probe);
+    if (probe.b_g1_query.host.size() < probe.l_query.host.size()) throw Error("ProvingKey: query lengths are inconsistent");
+    n_instance = probe.b_g1_query.host.size() - probe.l_query.host.size();
+  }
+  std::vector<Fr> w = ark::read_wtns_positional<Fr>(wtns, wlen);
+  if (n_instance > w.size()) throw Error("more instance variables than witness values");
+  auto sw = split_witness_shamir<P>(w, n_instance, t, n, seed);
+  SeededShamirSharer<Fr> dealer(seed, n, /*domain=*/12);
+  std::vector<std::deque<std::pair<Fr, Fr>>> pairs(n);
+  for (int k = 0; k < 3; ++k) {  // two rand calls + one scalar_mul (groth16.rs:448-449)
+    Fr v = dealer.rnd();
+    if (k == 0 && r) v = fr_from_canonical<P>(r);
+    if (k == 1 && s) v = fr_from_canonical<P>(s);
+    auto st = dealer.share(v, t), s2t = dealer.share(v, 2 * t);
+    for (int p = 0; p < n; ++p) pairs[p].push_back({st[p], s2t[p]});
+  }
+  auto nets0 = LocalNetwork::new_parties(n), nets1 = LocalNetwork::new_parties(n);
+  std::vector<Proof<P>> proofs(n);
+  std::vector<std::string> errs(n);
+  std::vector<std::thread> th;
+  for (int p = 0; p < n; ++p) {
+    th.emplace_back([&, p] {
+      try {
+        check(csh_init(ndev > 0 ? p % ndev : 0), "csh_init");
+        ProvingKey<P> pk_own;
+        ConstraintMatrices<P> m_own;
+        if (per_party_keys) files.load(pk_own, m_own);
+        const ProvingKey<P>& pk = per_party_keys ? pk_own : pk_shared;
+        const ConstraintMatrices<P>& m = per_party_keys ? m_own : m_shared;
+        auto state0 = ShamirState<Fr>::create(p, n, t, pairs[p]);
+        auto state1 = state0.fork(1);
+        proofs[p] = CoGroth16<P, T>::template prove_inner<LibSnarkReduction>(&nets0[p], &nets1[p], state0, state1, pk, m, sw[p], nullptr, nullptr);
+      } catch (const std::exception& e) {
+        errs[p] = e.what();
+        nets0[p].abort();
+        nets1[p].abort();
+      }
+    });
+  }
+  for (auto& x : th) x.join();
+  throw_first_party_error(errs.data(), n);
+  const std::vector<uint8_t> b0 = ark::write_proof<P>(proofs[0]);
+  for (int p = 1; p < n; ++p)
+    if (b0 != ark::write_proof<P>(proofs[p])) throw Error("the parties disagree on the proof");
+  return finish_libsnark<P>(proofs[0], out, cap);
+}
+
+// mode: 0 plain, 1 Rep3 (three parties), 2 + 256 * parties + 65536 * threshold: Shamir
+template <class P>
+static int prove_libsnark_any(int mode, const uint8_t* const mats[3], const size_t lens[3], const uint8_t* wtns, size_t wlen, const uint8_t* pkey,
                               size_t pklen, uint64_t seed, const uint64_t* r, const uint64_t* s, uint8_t* out, size_t cap, uint64_t* h_out, size_t h_cap) {
   const LibsnarkFiles<P> files{mats, lens, pkey, pklen};
-  return rep3 ? prove_libsnark_rep3_t<P>(files, wtns, wlen, seed, r, s, out, cap, h_out, h_cap)
+  if ((mode & 255) == 2) return prove_libsnark_shamir_t<P>(files, wtns, wlen, (mode >> 8) & 255, (mode >> 16) & 255, seed, r, s, out, cap);
+  return mode ? prove_libsnark_rep3_t<P>(files, wtns, wlen, seed, r, s, out, cap, h_out, h_cap)
               : prove_libsnark_t<P>(files, wtns, wlen, r, s, out, cap, h_out, h_cap);
 }
-static int prove_libsnark_entry(int curve, int rep3, const uint8_t* a, size_t alen, const uint8_t* b, size_t blen, const uint8_t* c, size_t clen,
+static int prove_libsnark_entry(int curve, int mode, const uint8_t* a, size_t alen, const uint8_t* b, size_t blen, const uint8_t* c, size_t clen,
                                 const uint8_t* wtns, size_t wlen, const uint8_t* pkey, size_t pklen, uint64_t seed, const uint64_t* r, const uint64_t* s,
                                 uint8_t* out, size_t cap, uint64_t* h_out, size_t h_cap_elems) {
   try {
     const uint8_t* mats[3] = {a, b, c};
     const size_t lens[3] = {alen, blen, clen};
-    if (curve == 0) return prove_libsnark_any<Bn254>(rep3, mats, lens, wtns, wlen, pkey, pklen, seed, r, s, out, cap, h_out, h_cap_elems);
-    if (curve == 1) return prove_libsnark_any<Bls12_381>(rep3, mats, lens, wtns, wlen, pkey, pklen, seed, r, s, out, cap, h_out, h_cap_elems);
-    if (curve == 3) return prove_libsnark_any<Bls12_377>(rep3, mats, lens, wtns, wlen, pkey, pklen, seed, r, s, out, cap, h_out, h_cap_elems);
+    if (curve == 0) return prove_libsnark_any<Bn254>(mode, mats, lens, wtns, wlen, pkey, pklen, seed, r, s, out, cap, h_out, h_cap_elems);
+    if (curve == 1) return prove_libsnark_any<Bls12_381>(mode, mats, lens, wtns, wlen, pkey, pklen, seed, r, s, out, cap, h_out, h_cap_elems);
+    if (curve == 3) return prove_libsnark_any<Bls12_377>(mode, mats, lens, wtns, wlen, pkey, pklen, seed, r, s, out, cap, h_out, h_cap_elems);
     g_err = "unknown curve";
     return -1;
   } catch (const std::exception& e) {
@@ -1309,6 +1377,17 @@ int cog16_prove_libsnark(int curve, const uint8_t* a, size_t alen, const uint8_t
                          size_t wlen, const uint8_t* pkey, size_t pklen, const uint64_t* r, const uint64_t* s, uint8_t* out, size_t cap,
                          uint64_t* h_out, size_t h_cap_elems) {
   return prove_libsnark_entry(curve, 0, a, alen, b, blen, c, clen, wtns, wlen, pkey, pklen, 0, r, s, out, cap, h_out, h_cap_elems);
+}
+// ShamirCoGroth16::prove::<LibSnarkReduction> with num_parties in-process parties and the given threshold (prove_libsnark_shamir_t)
+int cog16_prove_libsnark_shamir(int curve, const uint8_t* a, size_t alen, const uint8_t* b, size_t blen, const uint8_t* c, size_t clen,
+                                const uint8_t* wtns, size_t wlen, const uint8_t* pkey, size_t pklen, int num_parties, int threshold, uint64_t seed,
+                                const uint64_t* r, const uint64_t* s, uint8_t* out, size_t cap) {
+  if (num_parties < 3 || num_parties > 255 || threshold < 1 || threshold > 127) {
+    g_err = "num_parties / threshold out of range";
+    return -1;
+  }
+  return prove_libsnark_entry(curve, 2 + 256 * num_parties + 65536 * threshold, a, alen, b, blen, c, clen, wtns, wlen, pkey, pklen, seed, r, s, out, cap,
+                              nullptr, 0);
 }
 int cog16_prove_libsnark_rep3(int curve, const uint8_t* a, size_t alen, const uint8_t* b, size_t blen, const uint8_t* c, size_t clen,
                               const uint8_t* wtns, size_t wlen, const uint8_t* pkey, size_t pklen, uint64_t seed, const uint64_t* r, const uint64_t* s,

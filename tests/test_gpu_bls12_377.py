@@ -238,7 +238,7 @@ def test_libsnark_proof_on_the_reference_penumbra_circuit(gpu):
                                   None, C.c_size_t(0)) == -1
 
 
-def test_rep3_libsnark_proof_equals_the_plain_proof(gpu):
+def test_rep3_and_shamir_libsnark_proofs_equal_the_plain_proof(gpu):
     """Rep3CoGroth16::prove::<LibSnarkReduction> (co-circom/co-groth16/src/groth16.rs:360-379 with the LibSnark reduction) on the reference's
     Penumbra circuit, three in-process parties as in the reference's Rep3 tests (tests/tests/circom/e2e_tests/rep3.rs:57-69): witness shared
     from a seed, LibSnark witness map with device masks and the five query MSMs per party on BLS12-377, the parties' proofs agree, equal
@@ -269,3 +269,8 @@ def test_rep3_libsnark_proof_equals_the_plain_proof(gpu):
     h = [(x + y + z) % F.p for x, y, z in zip(*parts)]
     assert hashlib.sha256(b"".join(x.to_bytes(32, "little") for x in h)).hexdigest() == exp["h_sha256"]
     assert parts[0] != h
+    # ShamirCoGroth16::prove with the LibSnark reduction (groth16.rs:439-463), 3 parties / threshold 1: the same proof again
+    sham = (C.c_uint8 * 512)()
+    n2 = L.cog16_prove_libsnark_shamir(*args, 3, 1, C.c_uint64(777), rl.ctypes.data_as(C.c_void_p), sl.ctypes.data_as(C.c_void_p), sham, C.c_size_t(512))
+    assert n2 == 384, L.cog16_last_error()
+    assert bytes(sham[:384]) == bytes(plain[:384])

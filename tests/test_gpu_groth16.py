@@ -451,7 +451,7 @@ def test_h_with_fused_tile_passes_equals_two_launch_and_unfused_forms(gpu, logn)
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("curve,generator", [("bn254", 5), ("bls12_381", 7)])
-def test_libsnark_proofs_plain_and_rep3_on_a_random_circuit(gpu, curve, generator):
+def test_libsnark_proofs_plain_rep3_and_shamir_on_a_random_circuit(gpu, curve, generator):
     """plain_prove::<LibSnarkReduction> and the three-party Rep3 prove over an arkworks ProvingKey on the two north-star curves
     (cog16_prove_libsnark / _rep3: ark ProvingKey + Matrix blobs + wtns in, ark Proof out; the BLS12-377 counterpart on the reference's
     Penumbra circuit is tests/test_gpu_bls12_377.py): a random satisfied R1CS of 300 constraints, key from the restated arkworks generator
@@ -490,3 +490,9 @@ def test_libsnark_proofs_plain_and_rep3_on_a_random_circuit(gpu, curve, generato
     assert L.cog16_prove_libsnark_rep3(*args, C.c_uint64(99), rl.ctypes.data_as(C.c_void_p), sl.ctypes.data_as(C.c_void_p), rep3, C.c_size_t(512),
                                        None, C.c_size_t(0)) == plen, L.cog16_last_error()
     assert bytes(rep3[:plen]) == bytes(plain[:plen])
+    sham = (C.c_uint8 * 512)()
+    for parties, thr in ((3, 1), (5, 2)):
+        assert L.cog16_prove_libsnark_shamir(*args, parties, thr, C.c_uint64(5), rl.ctypes.data_as(C.c_void_p), sl.ctypes.data_as(C.c_void_p), sham,
+                                             C.c_size_t(512)) == plen, L.cog16_last_error()
+        assert bytes(sham[:plen]) == bytes(plain[:plen]), (parties, thr)
+    assert L.cog16_prove_libsnark_shamir(*args, 4, 2, C.c_uint64(5), None, None, sham, C.c_size_t(512)) == -1     # n < 2t + 1
