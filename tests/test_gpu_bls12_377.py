@@ -232,6 +232,16 @@ def test_libsnark_proof_on_the_reference_penumbra_circuit(gpu):
     want, _ = g16.prove_libsnark_plain(F, exp["generator"], G1, G2, key, A, B, Cm, pub, wit, r, s, msm=msm, h=hh)
     assert got == want
     assert g16.verify(CURVE, G1, vk, got, pub[1:])
+    # the same files under another curve id are rejected (48-byte coordinates read as 32-byte ones: non-canonical values / lengths off)
+    assert L.cog16_prove_libsnark(0, a, C.c_size_t(len(a)), b, C.c_size_t(len(b)), c, C.c_size_t(len(c)), w, C.c_size_t(len(w)), pk_bytes,
+                                  C.c_size_t(len(pk_bytes)), rl.ctypes.data_as(C.c_void_p), sl.ctypes.data_as(C.c_void_p), out, C.c_size_t(512),
+                                  None, C.c_size_t(0)) == -1
+    # a witness of the wrong length is an error, as in prove_inner (groth16.rs:131-146)
+    w_short = arkfmt.ser_wtns_positional(F.p, (pub + wit)[:-3])
+    assert L.cog16_prove_libsnark(CID, a, C.c_size_t(len(a)), b, C.c_size_t(len(b)), c, C.c_size_t(len(c)), w_short, C.c_size_t(len(w_short)), pk_bytes,
+                                  C.c_size_t(len(pk_bytes)), rl.ctypes.data_as(C.c_void_p), sl.ctypes.data_as(C.c_void_p), out, C.c_size_t(512),
+                                  None, C.c_size_t(0)) == -1
+    assert b"private witness" in L.cog16_last_error()
     # a key cut short is rejected, not mis-parsed
     assert L.cog16_prove_libsnark(CID, a, C.c_size_t(len(a)), b, C.c_size_t(len(b)), c, C.c_size_t(len(c)), w, C.c_size_t(len(w)), pk_bytes,
                                   C.c_size_t(len(pk_bytes) - 7), rl.ctypes.data_as(C.c_void_p), sl.ctypes.data_as(C.c_void_p), out, C.c_size_t(512),
