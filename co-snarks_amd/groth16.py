@@ -17,7 +17,7 @@ def glib():
     global _G
     if _G is None:
         lib()  # libcosnarks_hip.so first (dependency, same HIP runtime)
-        p = os.path.join(_HERE, "lib", "libcosnarks_groth16.so")
+        p = os.environ.get("COSNARKS_GROTH16_LIB") or os.path.join(_HERE, "lib", "libcosnarks_groth16.so")   # (the override: A/B runs of two builds)
         if not os.path.exists(p):
             raise CoSnarksHipError(f"{p} not found: run `python co-snarks_amd/build.py`")
         _G = C.CDLL(p)

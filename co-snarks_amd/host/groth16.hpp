@@ -494,6 +494,18 @@ struct CoGroth16 {
         h_acc = msm_device_resident_ptr<Fq>(BasesView{pkey.h_query.dev, lo, hi - lo}, static_cast<const char*>(h_dev.dev) + lo * sizeof(Half), hi - lo);
       }
     });
+    // calculate_coeff's `initial` points (delta r, delta s in G1, delta_2 s in G2: groth16.rs:230-262) depend on r, s and the key only: a host
+    // thread computes them while the device runs the MSMs (they were computed after the MSMs, on the thread that had just waited for them)
+    Proj<Fq> init_r = Proj<Fq>::inf(), init_s = Proj<Fq>::inf();
+    Proj<Fq2> init_s2 = Proj<Fq2>::inf();
+    std::unique_ptr<Joined> t_init;
+    if (same_len) {
+      t_init.reset(new Joined([&] {
+        init_r = T::template scalar_mul_public_point_hs<Fq>(delta_g1, T::to_half_share(r));
+        init_s = T::template scalar_mul_public_point_hs<Fq>(delta_g1, T::to_half_share(s));
+        init_s2 = T::template scalar_mul_public_point_hs<Fq2>(delta_g2, T::to_half_share(s));
+      }));
+    }
     if (same_len) {
       using PK = ProvingKey<P>;
       // One slot = the work placed on one GPU (ProvingKey::place; without a placement everything is slot 0 = this GPU): whole
@@ -570,11 +582,13 @@ struct CoGroth16 {
         run_aux_queries(0, static_cast<const char*>(aux_dev.dev) + lo * sizeof(Half));
       } catch (...) {
         t5.join_quiet();
+        t_init->join_quiet();
         for (auto& r : remote) r->join_quiet();
         throw;
       }
       for (auto& r : remote) r->join();
       t5.join();
+      t_init->join();
       auto to_proj = [](const auto& j) {
         using F = typename std::decay<decltype(j.x)>::type;
         return j.is_inf() ? Proj<F>::inf() : Proj<F>::from_affine(AffineT<F>{j.x, j.y});
@@ -588,9 +602,9 @@ struct CoGroth16 {
         jb2 = point_add(jb2, to_proj(outs_by_slot[sl].b2));
         if (sl) h_acc = point_add(h_acc, outs_by_slot[sl].h);
       }
-      r_g1 = finish_coeff<Fq>(id, T::template scalar_mul_public_point_hs<Fq>(delta_g1, T::to_half_share(r)), pkey.a_query, pkey.alpha_g1, inputs, ja);
-      s_g1 = finish_coeff<Fq>(id, T::template scalar_mul_public_point_hs<Fq>(delta_g1, T::to_half_share(s)), pkey.b_g1_query, pkey.beta_g1, inputs, jb1);
-      s_g2 = finish_coeff<Fq2>(id, T::template scalar_mul_public_point_hs<Fq2>(delta_g2, T::to_half_share(s)), pkey.b_g2_query, pkey.beta_g2, inputs, jb2);
+      r_g1 = finish_coeff<Fq>(id, init_r, pkey.a_query, pkey.alpha_g1, inputs, ja);
+      s_g1 = finish_coeff<Fq>(id, init_s, pkey.b_g1_query, pkey.beta_g1, inputs, jb1);
+      s_g2 = finish_coeff<Fq2>(id, init_s2, pkey.b_g2_query, pkey.beta_g2, inputs, jb2);
       l_acc = jl;
     } else {
       // (fallback: separate MSMs from separate host threads, each bound to the parent's GPU)
