@@ -416,15 +416,23 @@ int prove_shamir_t(const uint8_t* zkey, size_t zlen, const uint8_t* wtns, size_t
 // k_i * G with k_i = splitmix64(seed + i) | 1, so A, B, C have closed-form discrete logs and are checked with
 // three scalar multiplications instead of a pairing. Constraints: w[j+1] * w[j+2] = w[j+3].
 template <class F>
-void synth_query(csh_curve_t curve, csh_group_t group, uint64_t seed, size_t n, Query<F>& q) {
+void synth_query(csh_curve_t curve, csh_group_t group, uint64_t seed, size_t n, Query<F>& q, size_t lead = 0) {
   void* dev = nullptr;
-  check(csh_malloc(&dev, n * sizeof(AffineT<F>)), "csh_malloc");
-  check(csh_util_generate_bases_dev(curve, group, seed, n, dev, nullptr), "csh_util_generate_bases_dev");
+  const size_t pb = sizeof(AffineT<F>);
+  if (lead > n) lead = 0;
+  check(csh_malloc(&dev, (lead + n) * pb), "csh_malloc");
+  char* pts = static_cast<char*>(dev) + lead * pb;
+  check(csh_util_generate_bases_dev(curve, group, seed, n, pts, nullptr), "csh_util_generate_bases_dev");
   check(csh_sync(nullptr), "csh_sync");
-  check(csh_bases_upload_dev(curve, group, dev, n, 0, nullptr, &q.dev), "csh_bases_upload_dev");
+  int cur = 0;
+  check(csh_current_device(&cur), "csh_current_device");
+  if (lead) check(csh_memcpy_peer(dev, cur, pts, cur, lead * pb, nullptr), "csh_memcpy_peer");  // Query::lead: padding = the first points again
+  check(csh_sync(nullptr), "csh_sync");
+  check(csh_bases_upload_dev(curve, group, dev, lead + n, 0, nullptr, &q.dev), "csh_bases_upload_dev");
   q.len = n;
+  q.lead = lead;
   q.host.resize(n < 4 ? n : 4);
-  check(csh_memcpy_d2h(q.host.data(), dev, q.host.size() * sizeof(AffineT<F>)), "csh_memcpy_d2h");
+  check(csh_memcpy_d2h(q.host.data(), pts, q.host.size() * sizeof(AffineT<F>)), "csh_memcpy_d2h");
   csh_free(dev);
 }
 
@@ -488,7 +496,7 @@ struct SynthCircuit : SynthBase {
     synth_query<Fq>(P::ID, CSH_G1, SA, n_vars, pk.a_query);
     synth_query<Fq>(P::ID, CSH_G1, SB1, n_vars, pk.b_g1_query);
     synth_query<Fq2>(P::ID, CSH_G2, SB2, n_vars, pk.b_g2_query);
-    synth_query<Fq>(P::ID, CSH_G1, SL, n_vars - 2, pk.l_query);
+    synth_query<Fq>(P::ID, CSH_G1, SL, n_vars - 2, pk.l_query, 2);
     synth_query<Fq>(P::ID, CSH_G1, SH, domain, pk.h_query);
     pk.build_tables();
     pk.place_default();
@@ -1107,7 +1115,7 @@ struct LibsnarkFiles {
     m.upload();
     pk.a_query.upload(P::ID, CSH_G1);
     pk.b_g1_query.upload(P::ID, CSH_G1);
-    pk.l_query.upload(P::ID, CSH_G1);
+    pk.l_query.upload(P::ID, CSH_G1, pk.b_g1_query.host.size() - pk.l_query.host.size());
     pk.h_query.upload(P::ID, CSH_G1);
     pk.b_g2_query.upload(P::ID, CSH_G2);
     pk.build_tables();

@@ -444,7 +444,7 @@ struct CoGroth16 {
                                                        msm_device<Fq>(BasesView{pkey.b_g1_query.dev, 1 + pub_len, pkey.b_g1_query.size() - 1 - pub_len}, aux, n_aux)); });
       Joined t3([&] { bind(); g.s_g2 = finish_coeff<Fq2>(id, T::template scalar_mul_public_point_hs<Fq2>(delta_g2, T::to_half_share(s)), pkey.b_g2_query, pkey.beta_g2, inputs,
                                                         msm_device<Fq2>(BasesView{pkey.b_g2_query.dev, 1 + pub_len, pkey.b_g2_query.size() - 1 - pub_len}, aux, n_aux)); });
-      Joined t4([&] { bind(); g.l_acc = msm_device<Fq>(BasesView{pkey.l_query.dev, 0, pkey.l_query.size()}, aux, n_aux); });
+      Joined t4([&] { bind(); g.l_acc = msm_device<Fq>(BasesView{pkey.l_query.dev, pkey.l_query.lead, pkey.l_query.size()}, aux, n_aux); });
       Joined t5([&] { bind(); g.h_acc = msm_device<Fq>(BasesView{pkey.h_query.dev, 0, pkey.h_query.size()}, h, h_len); });
       t1.join(); t2.join(); t3.join(); t4.join(); t5.join();  // the first failure is rethrown; ~Joined reaps the rest
     }
@@ -612,7 +612,7 @@ struct CoGroth16 {
       Joined t1([&] { bind(); r_g1 = calculate_coeff<Fq>(id, T::template scalar_mul_public_point_hs<Fq>(delta_g1, T::to_half_share(r)), pkey.a_query, pkey.alpha_g1, inputs, aux_dev); });
       Joined t2([&] { bind(); s_g1 = calculate_coeff<Fq>(id, T::template scalar_mul_public_point_hs<Fq>(delta_g1, T::to_half_share(s)), pkey.b_g1_query, pkey.beta_g1, inputs, aux_dev); });
       Joined t3([&] { bind(); s_g2 = calculate_coeff<Fq2>(id, T::template scalar_mul_public_point_hs<Fq2>(delta_g2, T::to_half_share(s)), pkey.b_g2_query, pkey.beta_g2, inputs, aux_dev); });
-      Joined t4([&] { bind(); l_acc = T::template msm_public_points_hs<Fq>(BasesView{pkey.l_query.dev, 0, pkey.l_query.size()}, aux_dev); });
+      Joined t4([&] { bind(); l_acc = T::template msm_public_points_hs<Fq>(BasesView{pkey.l_query.dev, pkey.l_query.lead, pkey.l_query.size()}, aux_dev); });
       t1.join(); t2.join(); t3.join(); t4.join(); t5.join();  // the first failure is rethrown; ~Joined reaps the rest
     }
     delete sp_msm;

@@ -301,18 +301,39 @@ struct Query {
   size_t len = 0;                // number of points in the query
   csh_bases_t dev = nullptr;
   size_t size() const { return len ? len : host.size(); }
-  void upload(csh_curve_t curve, csh_group_t group) {
+  // `lead` padding points sit in front of the query on the device (point i of the query is point lead + i of `dev`). The l query is
+  // uploaded with lead = 1 + n_public: its handle then has the length of the a / b queries and takes the aux scalars at the same offset, so
+  // csh_msm_multi_dev sorts the digits ONCE for all four aux MSMs (a fixed-base table's row stride is the handle's length: a handle of a
+  // different length needed its own sort, 0.2 ms of a 2^20 prove). The padding is a copy of the query's first points and is never read.
+  size_t lead = 0;
+  void upload(csh_curve_t curve, csh_group_t group, size_t lead_pad = 0) {
     len = host.size();
-    check(csh_bases_upload(curve, group, host.data(), host.size(), 0, &dev), "csh_bases_upload");
+    lead = host.empty() ? 0 : lead_pad;
+    if (!lead) {
+      check(csh_bases_upload(curve, group, host.data(), host.size(), 0, &dev), "csh_bases_upload");
+      return;
+    }
+    std::vector<AffineT<F>> padded(lead + host.size());
+    for (size_t i = 0; i < lead; ++i) padded[i] = host[i % host.size()];
+    memcpy((void*)(padded.data() + lead), host.data(), host.size() * sizeof(AffineT<F>));
+    check(csh_bases_upload(curve, group, padded.data(), padded.size(), 0, &dev), "csh_bases_upload");
   }
   // straight from a file image (zkey sections hold packed Montgomery little-endian points, the C ABI's own layout):
   // the points go to the device from where they lie; the host keeps only the first `keep_host` entries it reads
-  void upload_from(csh_curve_t curve, csh_group_t group, const uint8_t* packed, size_t count, size_t keep_host, bool to_device) {
+  void upload_from(csh_curve_t curve, csh_group_t group, const uint8_t* packed, size_t count, size_t keep_host, bool to_device, size_t lead_pad = 0) {
     len = count;
     const size_t k = to_device ? (keep_host < count ? keep_host : count) : count;
     host.resize(k);
     if (k) memcpy((void*)host.data(), packed, k * sizeof(AffineT<F>));
-    if (to_device) check(csh_bases_upload(curve, group, packed, count, 0, &dev), "csh_bases_upload");
+    lead = to_device && count ? lead_pad : 0;
+    if (to_device && !lead) check(csh_bases_upload(curve, group, packed, count, 0, &dev), "csh_bases_upload");
+    if (to_device && lead) {
+      const size_t pb = sizeof(AffineT<F>);
+      std::vector<uint8_t> padded((lead + count) * pb);
+      for (size_t i = 0; i < lead; ++i) memcpy(padded.data() + i * pb, packed + (i % count) * pb, pb);
+      memcpy(padded.data() + lead * pb, packed, count * pb);
+      check(csh_bases_upload(curve, group, padded.data(), lead + count, 0, &dev), "csh_bases_upload");
+    }
   }
   void release() {
     if (dev) csh_bases_free(dev);
@@ -407,11 +428,12 @@ struct ProvingKey {
     std::vector<std::array<csh_bases_t, 5>> handles;  // [slot][query]; slot 0 = the home handles (not owned)
     // BY_RANGE: a slot's clone holds only the slot's range of the query: base[slot][q] = index (in the home query) of the clone's
     // first point, count[slot][q] = its length (slot 0 and BY_QUERY clones: 0 and the whole query)
-    std::vector<std::array<size_t, 5>> base, count;
+    std::vector<std::array<size_t, 5>> base, count, lead;
   } placement;
   size_t query_size(int q) const {
     return q == Q_A ? a_query.size() : q == Q_B1 ? b_g1_query.size() : q == Q_B2 ? b_g2_query.size() : q == Q_L ? l_query.size() : h_query.size();
   }
+  size_t query_lead(int q) const { return q == Q_L ? l_query.lead : 0; }  // Query::lead: only the l query is padded
   csh_bases_t home_handle(int q) const {
     return q == Q_A ? a_query.dev : q == Q_B1 ? b_g1_query.dev : q == Q_B2 ? b_g2_query.dev : q == Q_L ? l_query.dev : h_query.dev;
   }
@@ -420,10 +442,10 @@ struct ProvingKey {
   csh_bases_t handle_for(size_t slot, int q) const { return slot == 0 || !placed() ? home_handle(q) : placement.handles[slot][q]; }
   // offset of home-query point `index` inside the handle handle_for(slot, q); throws if the slot's clone does not hold [index, index + n)
   size_t offset_in(size_t slot, int q, size_t index, size_t n) const {
-    if (slot == 0 || !placed() || placement.base.empty()) return index;
+    if (slot == 0 || !placed() || placement.base.empty()) return index + query_lead(q);
     const size_t b = placement.base[slot][q], c = placement.count[slot][q];
     if (index < b || index + n > b + c) throw Error("placement: the slot's clone of the query does not hold the requested range");
-    return index - b;
+    return index - b + placement.lead[slot][q];  // (a whole clone keeps the home handle's padding in front, a range clone has none)
   }
   // does `slot` work on query q, and on which part [lo, hi) of an index space of n entries?
   bool slot_has(size_t slot, int q) const {
@@ -445,6 +467,7 @@ struct ProvingKey {
     placement.handles.clear();
     placement.base.clear();
     placement.count.clear();
+    placement.lead.clear();
     for (auto& sl : placement.slot) sl = 0;
     placement.devices.clear();
   }
@@ -458,6 +481,7 @@ struct ProvingKey {
     placement.handles.assign(ns, std::array<csh_bases_t, 5>{nullptr, nullptr, nullptr, nullptr, nullptr});
     placement.base.assign(ns, std::array<size_t, 5>{0, 0, 0, 0, 0});
     placement.count.assign(ns, std::array<size_t, 5>{sizes[0], sizes[1], sizes[2], sizes[3], sizes[4]});
+    placement.lead.assign(ns, std::array<size_t, 5>{query_lead(0), query_lead(1), query_lead(2), query_lead(3), query_lead(4)});
     for (int q = 0; q < 5; ++q) placement.handles[0][q] = home_handle(q);
     placement.devices = devices;  // (set before the clones: unplace() on a failure below frees what was made)
     // BY_RANGE: slot sl works on the sl-th range of the aux index space (the n_aux = |l_query| private-witness entries; a / b_g1 / b_g2
@@ -479,7 +503,8 @@ struct ProvingKey {
             const size_t first = (q == Q_H || q == Q_L ? 0 : lead) + lo;
             placement.base[sl][q] = first;
             placement.count[sl][q] = hi - lo;
-            if (hi > lo) rc = csh_bases_clone_range(home_handle(q), first, hi - lo, devices[sl], &placement.handles[sl][q]);
+            placement.lead[sl][q] = 0;
+            if (hi > lo) rc = csh_bases_clone_range(home_handle(q), query_lead(q) + first, hi - lo, devices[sl], &placement.handles[sl][q]);
           } else {
             rc = csh_bases_clone(home_handle(q), devices[sl], &placement.handles[sl][q]);
           }

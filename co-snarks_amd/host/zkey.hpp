@@ -112,14 +112,14 @@ void parse_zkey(const uint8_t* d, size_t n, ProvingKey<P>& pk, ConstraintMatrice
     pk.ic.resize(keep);
     memcpy(pk.ic.data(), d + o, l);
   }
-  auto q1 = [&](uint32_t sec, Query<Fq>& q, size_t keep_host, size_t count) {
+  auto q1 = [&](uint32_t sec, Query<Fq>& q, size_t keep_host, size_t count, size_t lead_pad = 0) {
     auto [o, l] = s.at(sec);
     expect(sec, l, 2 * n8q, count);
-    q.upload_from(P::ID, CSH_G1, d + o, count, keep_host, upload);
+    q.upload_from(P::ID, CSH_G1, d + o, count, keep_host, upload, lead_pad);
   };
   q1(5, pk.a_query, keep, n_vars);
   q1(6, pk.b_g1_query, keep, n_vars);
-  q1(8, pk.l_query, 0, (size_t)n_vars - keep);
+  q1(8, pk.l_query, 0, (size_t)n_vars - keep, keep);  // (padded to the a / b queries' length: Query::lead)
   q1(9, pk.h_query, 0, domain);
   {
     auto [o, l] = s.at(7);
