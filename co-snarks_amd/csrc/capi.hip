@@ -457,6 +457,7 @@ static const TuneEntry kTune[] = {
     {"ntt_pair", "CSH_NTT_PAIR", &Tune::ntt_pair},
     {"ntt_pair_min_log", "CSH_NTT_PAIR_MIN_LOG", &Tune::ntt_pair_min_log},
     {"h_unfused", "CSH_H_UNFUSED", &Tune::h_unfused},
+    {"h_table_cache", "CSH_H_TABLE_CACHE", &Tune::h_table_cache},
     {"host_populate", "CSH_HOST_POPULATE", &Tune::host_populate},
     {"host_d2h", "CSH_HOST_D2H", &Tune::host_d2h},
     {"comm_timeout_ms", "CSH_COMM_TIMEOUT_MS", &Tune::comm_timeout_ms},

@@ -139,6 +139,7 @@ bool ntt_scale_table_supported(const Domain* d);
 int ntt_run_dif_table(const Domain* d, uint64_t* data, uint32_t ncomp, const uint64_t* scale_table, hipStream_t st);
 int ntt_run_pair_table(const Domain* d, uint64_t* data, uint32_t ncomp, const uint64_t* scale_table, hipStream_t st);  // ifft (scaled by the table) + fft, tile passes fused
 int ntt_coset_table_scaled(const Domain* d, const uint64_t* shift, uint64_t* out_dev, hipStream_t st);
+int ntt_coset_table_scaled_cached(const Domain* d, const uint64_t* shift, uint64_t* scratch, hipStream_t st, const uint64_t** table);
 // out = a * b - c (plain / Shamir) and out = rep3_local_mul(a, b) + mask - c: the last step of a witness map in one sweep
 int vec_mul_sub_dev(csh_curve_t f, const uint64_t* a, const uint64_t* b, const uint64_t* c, uint64_t* out, size_t n, hipStream_t st);
 int rep3_local_mul_sub_dev(csh_curve_t f, const uint64_t* a, const uint64_t* b, const uint64_t* mask, const uint64_t* c, uint64_t* out, size_t n, hipStream_t st);
@@ -181,6 +182,7 @@ struct Tune {
   std::atomic<int> ntt_pair{1};           // witness maps: fuse the last pass of each inverse transform with the first pass of the forward one (0 = two launches, A/B)
   std::atomic<int> ntt_pair_min_log{20};  // ... for domains of at least 2^this many points (measured, Rep3 witness map device time, profiles/r06_n_pair_ab.log:
                                           // 2^20 1.583 -> 1.542 ms, 2^22 6.64 -> 6.49 ms; 2^16 +3.5 %, 2^12 +6 %: below 2^20 the radix-2 passes it replaces are the faster ones)
+  std::atomic<int> h_table_cache{1};      // Groth16 h pipeline: keep the scaled coset table with the domain (0 = rebuild it per witness map, A/B)
   std::atomic<int> h_unfused{0};          // Groth16 h pipeline: 1 = the unfused step-by-step sequence (A/B, tests)
   std::atomic<int> host_d2h{1};  // large results to pageable memory: 0 = one copy straight into the caller's pages, 1 (default since round 5) = staged
                                  // through a page-locked buffer + host threads, 2 = direct, timed, staged for a while after a copy that stalled (HostXfer::d2h)

@@ -50,15 +50,16 @@ int csh_groth16_h_dev(csh_domain_t dom, const uint64_t shift[4], int protocol, u
   // modmuls less), and h = a b - c is one kernel. The unfused sequence below it is the reference's order step by step and runs
   // when the lazy NTT passes are switched off (CSH_NTT_LAZY=0) or tune "h_unfused" asks for it (A/B, tests).
   if (ntt_scale_table_supported(d) && !tune().h_unfused.load(std::memory_order_relaxed)) {
-    CSH_TRY(ntt_coset_table_scaled(d, shift, table, st));                                    // reduction.rs:100 (45-60), times 1/n
+    const uint64_t* ctab = nullptr;  // (kept with the domain after the first witness map: Domain::cs_table)
+    CSH_TRY(ntt_coset_table_scaled_cached(d, shift, table, st, &ctab));                      // reduction.rs:100 (45-60), times 1/n
     if (protocol == 1)
       CSH_TRY(csh_rep3_local_mul_vec_dev(f, a, b, mask_c, ab, n, st));                       // :160
     else
       CSH_TRY(csh_vec_mul_dev(f, a, b, ab, n, st));
     // round 6: ifft_in_to_out + distribute_powers + fft_out_to_in per vector with the two passes over the contiguous tiles in ONE launch
     // (ntt_run_pair_table: the tile stays in LDS across the hand-over; tune "ntt_pair" = 0: two launches as in rounds 3-5)
-    for (uint64_t* v : {a, b}) CSH_TRY(ntt_run_pair_table(d, v, ncomp, table, st));          // :139-155
-    CSH_TRY(ntt_run_pair_table(d, ab, 1, table, st));                                        // :163-174
+    for (uint64_t* v : {a, b}) CSH_TRY(ntt_run_pair_table(d, v, ncomp, ctab, st));           // :139-155
+    CSH_TRY(ntt_run_pair_table(d, ab, 1, ctab, st));                                         // :163-174
     if (protocol == 1)
       CSH_TRY(rep3_local_mul_sub_dev(f, a, b, mask_ab, ab, h_out, n, st));                   // :182-190 (ab aliases h_out: element-wise)
     else

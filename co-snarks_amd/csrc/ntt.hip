@@ -39,6 +39,13 @@ struct Domain {
   void* tw_inv_lazy;
   uint32_t n_inv_lazy[8];  // (1/n) * R', packed
   uint32_t gen[8], gen_inv[8], n_inv[8];  // Montgomery
+  // The scaled coset table of the witness map (shift^i / n, ntt_coset_table_scaled) for the FIRST shift the domain is asked for: a reduction
+  // always uses the same coset of its domain (reduction.rs:100), so every witness map after the first reads it instead of rebuilding it
+  // (91 us of a 2^20 witness map). Another shift on the same domain is computed into the caller's scratch as before and is not cached.
+  std::mutex cs_mu;
+  uint64_t cs_shift[4] = {0, 0, 0, 0};
+  void* cs_table = nullptr;
+  hipEvent_t cs_ready = nullptr;
 };
 
 template <class F>
@@ -1012,6 +1019,38 @@ int ntt_coset_table_scaled(const Domain* d, const uint64_t* shift, uint64_t* out
   if (d->curve == CSH_BLS12_377) return coset_table_scaled_t<Bls377Fr>(d, shift, out_dev, st);
   return coset_table_scaled_t<Bls381Fr>(d, shift, out_dev, st);
 }
+// The same table, kept with the domain (see Domain::cs_table): *table = the cached copy, valid for work queued on `st` after this call
+// (the builder's stream records an event every other stream waits for), or `scratch` freshly filled when the shift is not the cached one,
+// the domain is too large to keep a copy (> 2^25 points = 1 GiB) or the allocation fails.
+int ntt_coset_table_scaled_cached(const Domain* dc, const uint64_t* shift, uint64_t* scratch, hipStream_t st, const uint64_t** table) {
+  Domain* d = const_cast<Domain*>(dc);
+  *table = scratch;
+  if (d->log_n <= 25 && tune().h_table_cache.load(std::memory_order_relaxed)) {
+    std::lock_guard<std::mutex> g(d->cs_mu);
+    if (!d->cs_table) {
+      void* buf = nullptr;
+      hipEvent_t ev = nullptr;
+      if (hipMalloc(&buf, 32 * d->n) == hipSuccess && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
+        const int rc = ntt_coset_table_scaled(d, shift, static_cast<uint64_t*>(buf), st);
+        if (rc == CSH_OK && hipEventRecord(ev, st) == hipSuccess) {
+          memcpy(d->cs_shift, shift, 32);
+          d->cs_table = buf;
+          d->cs_ready = ev;
+          *table = static_cast<const uint64_t*>(buf);
+          return CSH_OK;
+        }
+      }
+      (void)hipGetLastError();
+      if (ev) (void)hipEventDestroy(ev);
+      if (buf) (void)hipFree(buf);
+    } else if (memcmp(d->cs_shift, shift, 32) == 0) {
+      CSH_HIP(hipStreamWaitEvent(st, d->cs_ready, 0));
+      *table = static_cast<const uint64_t*>(d->cs_table);
+      return CSH_OK;
+    }
+  }
+  return ntt_coset_table_scaled(d, shift, scratch, st);
+}
 int ntt_coset_table(const Domain* d, const uint64_t* shift, uint64_t* out_dev, hipStream_t st) {
   if (d->curve == CSH_BN254) return coset_table_t<Bn254Fr>(d, shift, out_dev, st);
   if (d->curve == CSH_BLS12_377) return coset_table_t<Bls377Fr>(d, shift, out_dev, st);
@@ -1076,6 +1115,8 @@ int csh_domain_free(csh_domain_t dom) {
   if (d->tw_inv) (void)hipFree(d->tw_inv);
   if (d->tw_fwd_lazy) (void)hipFree(d->tw_fwd_lazy);
   if (d->tw_inv_lazy) (void)hipFree(d->tw_inv_lazy);
+  if (d->cs_table) (void)hipFree(d->cs_table);
+  if (d->cs_ready) (void)hipEventDestroy(d->cs_ready);
   delete d;
   return CSH_OK;
 }

@@ -94,7 +94,8 @@ int csh_device_count(int* count);
  * lane-serial on G1 / four-lane on G2, bit 1 = the other form of the G2 accumulate kernel (BN254 G2: two lanes per point instead of whole points; BLS12-381 G2: whole
  * points instead of two lanes per point), bit 2 = lane-serial window
  * reduction on G2, bit 3 = 8-byte sort records at every size, bit 4 = merge fused into the window reduction, bit 5 = level 2 of the
- * two-level sort with one block per partition instead of one per tile-sized slice), "h_unfused", "comm_timeout_ms" (csh_comm_init_rank),
+ * two-level sort with one block per partition instead of one per tile-sized slice), "h_unfused", "h_table_cache" (1 = default: the witness map's scaled coset table stays with the
+ * domain after the first call, 32 bytes per point up to 2^25 points; 0 = rebuilt per call), "comm_timeout_ms" (csh_comm_init_rank),
  * "host_populate" (results of >= 4 MiB handed back in pageable memory: low byte = host threads that populate the destination's
  * pages while the device works, 0 = none; bit 8 = transparent-huge-page hint on the range; default 0x101), "host_d2h" (the copy of such
  * a result: 0 = one DMA into the caller's pages, 1 = default since round 5: staged through the lane's page-locked buffer and moved on by
@@ -237,7 +238,11 @@ int csh_msm_split(const csh_bases_t* bases, const size_t* offsets, const size_t*
 /* k MSMs over ONE device scalar vector -- the four aux-assignment MSMs of a Groth16 proof (a_query, b_g1_query, b_g2_query,
  * l_query: groth16.rs:237-284, calculate_coeff :179-203): the signed-digit decomposition and the bucket sort depend on the
  * scalars only and are computed once. bases[i]: handles of one curve (G1 and G2 may be mixed), each MSM takes n points
- * from offsets[i]; outs_host[i]: Jacobian as csh_msm. Synchronous. */
+ * from offsets[i]; outs_host[i]: Jacobian as csh_msm. Synchronous.
+ * On handles with fixed-base tables the sorted list holds table indices (row * handle length + offset + i), so consecutive handles
+ * share it only while their (length, offset) pair repeats; a handle with another pair gets its own scatter (~0.2 ms at 2^20). A
+ * prover that wants ONE sort for all four uploads the l query behind 1 + n_public padding points (any valid points; never read),
+ * which gives it the length and the offset of the a / b queries: the C++ mirror does (host/types.hpp, Query::lead). */
 int csh_msm_multi_dev(const csh_bases_t* bases, const size_t* offsets, size_t k, size_t n, const uint64_t* scalars_dev,
                       int scalars_are_montgomery, void* const* outs_host, void* stream);
 int csh_msm_partial_bytes(csh_curve_t curve, csh_group_t group, size_t* bytes);

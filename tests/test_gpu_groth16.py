@@ -450,6 +450,44 @@ def test_h_with_fused_tile_passes_equals_two_launch_and_unfused_forms(gpu, logn)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("logn", [10, 16])
+def test_h_coset_table_kept_with_the_domain(gpu, logn):
+    """The scaled coset table of the fused h pipeline stays with the domain after the first witness map (Domain::cs_table, tune
+    h_table_cache). h must not depend on it: the first call (builds the table), a second call (reads the kept one), a call with ANOTHER
+    shift on the same domain (not the kept one: computed into scratch), the first shift again, and a domain with the cache switched off
+    all equal the reference's step-by-step sequence (h_unfused)."""
+    F = H.FR["bn254"]
+    n = 1 << logn
+    gen = ntt.roots_of_unity(F)[1][logn]
+    rs = np.random.RandomState(700 + logn)
+
+    def limbs(k):
+        v = rs.randint(0, 1 << 63, size=(k, 4), dtype=np.uint64)
+        v[:, 3] >>= np.uint64(3)
+        return v
+
+    shift1 = H.pack(F, [ntt.roots_of_unity(F)[1][logn + 1]])
+    shift2 = H.pack(F, [pow(5, 12345, F.p)])
+    a, b = limbs(n), limbs(n)
+    ref_dom = gpu.Domain(0, logn, H.pack(F, [gen]))
+    with gpu.tuned(h_unfused=1):
+        want1 = gpu.bindings.groth16_h(ref_dom, shift1, 0, a, b, None, None)
+        want2 = gpu.bindings.groth16_h(ref_dom, shift2, 0, a, b, None, None)
+    ref_dom.free()
+    assert not np.array_equal(want1, want2)
+    dom = gpu.Domain(0, logn, H.pack(F, [gen]))
+    for shift, want in ((shift1, want1), (shift1, want1), (shift2, want2), (shift1, want1), (shift2, want2)):
+        assert np.array_equal(gpu.bindings.groth16_h(dom, shift, 0, a, b, None, None), want)
+    dom.free()
+    dom = gpu.Domain(0, logn, H.pack(F, [gen]))
+    with gpu.tuned(h_table_cache=0):
+        assert np.array_equal(gpu.bindings.groth16_h(dom, shift2, 0, a, b, None, None), want2)
+    assert np.array_equal(gpu.bindings.groth16_h(dom, shift1, 0, a, b, None, None), want1)   # first KEPT shift of this domain
+    assert np.array_equal(gpu.bindings.groth16_h(dom, shift2, 0, a, b, None, None), want2)
+    dom.free()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("curve,generator", [("bn254", 5), ("bls12_381", 7)])
 def test_libsnark_proofs_plain_rep3_and_shamir_on_a_random_circuit(gpu, curve, generator):
     """plain_prove::<LibSnarkReduction> and the three-party Rep3 prove over an arkworks ProvingKey on the two north-star curves
