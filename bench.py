@@ -126,6 +126,8 @@ class Ctx:
         torch.cuda.set_device(self.dev_index)
         self.dev = torch.device("cuda", self.dev_index)
         if self.world > 1:
+            if os.environ.get("MASTER_ADDR", "") in ("127.0.0.1", "localhost"):
+                os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # one node: never depend on the container's hostname resolving
             dist.init_process_group("gloo", rank=self.rank, world_size=self.world)   # control plane only
         import ctypes as C
 
