@@ -1025,7 +1025,8 @@ int ntt_coset_table_scaled(const Domain* d, const uint64_t* shift, uint64_t* out
 int ntt_coset_table_scaled_cached(const Domain* dc, const uint64_t* shift, uint64_t* scratch, hipStream_t st, const uint64_t** table) {
   Domain* d = const_cast<Domain*>(dc);
   *table = scratch;
-  if (d->log_n <= 25 && tune().h_table_cache.load(std::memory_order_relaxed)) {
+  int cur = -1;
+  if (d->log_n <= 25 && tune().h_table_cache.load(std::memory_order_relaxed) && hipGetDevice(&cur) == hipSuccess && cur == d->device) {  // (the copy is allocated on the domain's GPU)
     std::lock_guard<std::mutex> g(d->cs_mu);
     if (!d->cs_table) {
       void* buf = nullptr;
