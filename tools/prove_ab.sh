@@ -1,3 +1,7 @@
+# Interleaved A/B of two BUILDS on the synthetic 2^20 prove (tools/prove_loop.py): copy the build to compare against to
+# co-snarks_amd/lib_old/ first (cp co-snarks_amd/lib/*.so co-snarks_amd/lib_old/; git-ignored, travels with gpurun), rebuild, then
+#   gpurun -- 'bash tools/prove_ab.sh > gpurun_out/<tag>_ab.log'
+# (A/B of a tune knob inside ONE build: tools/prove_ab_env.sh.)
 R=$PWD
 OLD="COSNARKS_HIP_LIB=$R/co-snarks_amd/lib_old/libcosnarks_hip.so COSNARKS_GROTH16_LIB=$R/co-snarks_amd/lib_old/libcosnarks_groth16.so"
 for round in 1 2 3; do

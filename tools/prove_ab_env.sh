@@ -1,3 +1,4 @@
+# Interleaved A/B of an environment-set tune knob on the synthetic 2^20 prove (here: the witness map's kept coset table, CSH_H_TABLE_CACHE).
 for round in 1 2 3; do
   for mode in off on; do
     if [ $mode = off ]; then E="CSH_H_TABLE_CACHE=0"; else E="X=1"; fi
