@@ -489,7 +489,7 @@ def test_msm_fixed_base_tables_closed_form_and_multi(gpu):
     limbs = rs.randint(0, 1 << 63, size=(n, 4), dtype=np.uint64)
     limbs[:, 3] >>= np.uint64(3)
     want = closed_form_point("bn254", 0, seed, n, limbs, True)
-    for c, groups in ((0, 0), (16, 4), (17, 0)):   # automatic width (c = 16, one row per window), round 5's grouped rows, the policy's one bucket set at this size
+    for c, groups in ((0, 0), (17, 0)):   # automatic width (c = 16, one row per window), the policy's one bucket set at this size (round 5's grouped rows: test_msm_fixed_base_tables, every layout against the oracle)
         if groups:
             gpu.bindings._check(L.csh_bases_precompute_grouped(h, c, groups))
         else:

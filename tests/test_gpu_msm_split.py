@@ -188,15 +188,16 @@ def test_comm_init_deadline_and_blocking_fallback(gpu):
     instead of hanging for good, and the library stays usable. Run in a subprocess that leaves through os._exit: the abandoned
     bootstrap thread of that process is still waiting for its peer. (Round 5: this test took 107 s of the suite's 209 -- two in-process
     one-rank RCCL communicators that test_rccl_rank_path_with_one_rank already builds, and a third inside the subprocess; RCCL's own
-    initialisation is 15-35 s per communicator here. What is left is the 2 s deadline itself plus a communicator that needs no RCCL.)"""
+    initialisation is 15-35 s per communicator here. What is left is the 1 s deadline itself plus a communicator that needs no RCCL.)"""
     import subprocess
     import sys
     import time
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     t0 = time.perf_counter()
-    p = subprocess.run([sys.executable, os.path.join(root, "tools", "experiments", "rccl_deadline_probe.py"), "1", "0"], capture_output=True, text=True, timeout=120)
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "experiments", "rccl_deadline_probe.py"), "1", "0"], capture_output=True, text=True, timeout=120,
+                       env=dict(os.environ, PROBE_TIMEOUT_MS="1000"))
     out = p.stdout
-    assert "did not come up within 2000 ms" in out and "error after 2." in out, (out, p.stderr[-500:])
+    assert "did not come up within 1000 ms" in out and "error after 1." in out, (out, p.stderr[-500:])
     assert "ok (0, 1, 0)" in out and out.rstrip().endswith("done"), out                 # the library is usable right after the abandoned construction
     assert time.perf_counter() - t0 < 60, out
     # comm_timeout_ms = 0 builds on the calling thread (one rank cannot wait for anybody: built inline whatever the deadline says)

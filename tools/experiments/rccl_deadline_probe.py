@@ -4,7 +4,7 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import cosnarks_amd as hip
 from cosnarks_amd import bindings as B
-B.tune_set("comm_timeout_ms", 2000)
+B.tune_set("comm_timeout_ms", int(os.environ.get("PROBE_TIMEOUT_MS", "2000")))
 print("unique id ...", flush=True)
 uid = B.comm_unique_id()
 print("init_rank(2 ranks, rank 0) ...", flush=True)
