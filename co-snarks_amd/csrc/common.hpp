@@ -160,7 +160,7 @@ struct Tune {
   std::atomic<int> stat_lanes{0};
   std::atomic<int> stat_populate_us{0}, stat_join_wait_us{0}, stat_finish_us{0}, stat_d2h_slow{0}, stat_d2h_staged{0};  // page population: worker time, caller's wait for it, final stream wait
   std::atomic<int> msm_multi_overlap{1}; // alternate bucket stages of csh_msm_multi_dev between two streams
-  std::atomic<int> msm_share_uploads{1}; // csh_msm: concurrent calls handed the same host scalar slice share one upload (msm.hip SharedUpload)
+  std::atomic<int> msm_share_uploads{2}; // csh_msm: concurrent calls handed the same host scalar slice share one upload (1) and run as ONE multi-MSM of the uploading call (2, default) (msm.hip SharedUpload)
   std::atomic<int> stat_uploads_shared{0};  // counter: csh_msm calls that reused a concurrent call's upload
   std::atomic<int> host_h2d{1};  // uploads of >= 4 MiB from pageable caller memory: 0 direct, 1 (default) staged through page-locked chunks, 2 direct + timed, staged after stalls (upload_h2d)
   std::atomic<int> stat_h2d_slow{0}, stat_h2d_staged{0}, stat_stage_all_switches{0};

@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <condition_variable>
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "msm_impl.hpp"
@@ -74,9 +75,24 @@ struct SharedUpload {
   void* dev = nullptr;
   hipEvent_t ready = nullptr;
   int refs = 0;
-  std::mutex m;  // guards `state`
+  std::mutex m;  // guards `state` and the batch
   std::condition_variable cv;
   int state = 0;  // 0 = the owner has not recorded `ready` yet, 1 = recorded, -1 = the owner's upload failed
+  // Round 6: calls that arrive while the owner is still uploading do not only share the copy -- they hand the owner their (bases,
+  // offset, out) and wait: the owner runs ALL of them as one csh_msm_multi_dev (ONE digit sort for the handles that share length and
+  // offset, bucket stages alternating between two streams), i.e. the four aux-assignment MSMs of an unchanged reference's rayon_join5
+  // take the device-resident prover's path. tune "msm_share_uploads" = 2 (default); 1 = share the upload only.
+  struct Req {
+    csh_bases_t bases = nullptr;
+    size_t offset = 0;
+    void* out = nullptr;
+    int rc = CSH_OK;
+    std::string err;
+  };
+  std::vector<Req*> batch;  // joiners' requests (the owner's own is not in here)
+  bool sealed = false;      // the owner has taken the batch: later calls share the upload only
+  bool batch_done = false;  // results (or errors) of the batch are in place
+  int curve = -1, mont = -1;  // what the owner's call runs with: only calls of the same curve and scalar encoding join
 };
 std::mutex g_up_mu;
 std::vector<SharedUpload*> g_up_live;                       // entries with refs > 0
@@ -88,7 +104,10 @@ struct SharedUploadRef {
   SharedUpload* e = nullptr;
   hipStream_t stream = nullptr;
   const void* dev() const { return e->dev; }
-  int acquire(int device, const void* host, size_t bytes, hipStream_t st) {
+  bool is_owner = false;
+  // req != nullptr: the caller is willing to be run by the owner (see SharedUpload::batch); *joined = true then means req->rc / req->err hold
+  // its result when acquire returns and it must not run anything itself
+  int acquire(int device, const void* host, size_t bytes, hipStream_t st, SharedUpload::Req* req = nullptr, int curve = -1, int mont = -1, bool* joined = nullptr) {
     stream = st;
     bool owner = false;
     {
@@ -109,6 +128,7 @@ struct SharedUploadRef {
       } else {
         e = new SharedUpload();
         e->device = device, e->host = host, e->bytes = bytes, e->refs = 1;
+        e->curve = curve, e->mont = mont;
         size_t best = (size_t)-1;
         for (size_t i = 0; i < g_up_pool.size(); ++i)
           if (g_up_pool[i].first == device && g_up_pool[i].second.first >= bytes && (best == (size_t)-1 || g_up_pool[i].second.first < g_up_pool[best].second.first)) best = i;
@@ -121,6 +141,7 @@ struct SharedUploadRef {
         owner = true;
       }
     }
+    is_owner = owner;
     if (owner) {
       hipError_t rc = hipSuccess;
       if (!e->dev) {
@@ -144,6 +165,18 @@ struct SharedUploadRef {
     }
     {
       std::unique_lock<std::mutex> g(e->m);
+      if (req && joined && !e->sealed && e->curve == curve && e->mont == mont && curve >= 0 && e->batch.size() < 15) {
+        e->batch.push_back(req);
+        *joined = true;
+        e->cv.wait(g, [&] { return e->batch_done || e->state < 0; });
+        if (!e->batch_done) {  // the owner's upload failed before it took the batch: withdraw the request (it lives on this call's stack)
+          e->batch.erase(std::find(e->batch.begin(), e->batch.end(), req));
+          set_error("csh_msm: the concurrent call that was uploading this scalar slice failed");
+          return CSH_ERR_HIP;
+        }
+        tune().stat_uploads_shared.fetch_add(1, std::memory_order_relaxed);
+        return CSH_OK;
+      }
       e->cv.wait(g, [&] { return e->state != 0; });
       if (e->state < 0) {
         set_error("csh_msm: the concurrent call that was uploading this scalar slice failed");
@@ -154,8 +187,38 @@ struct SharedUploadRef {
     tune().stat_uploads_shared.fetch_add(1, std::memory_order_relaxed);
     return CSH_OK;
   }
+  // owner only, after a successful acquire: closes the batch and returns the joiners' requests (empty: nobody joined)
+  std::vector<SharedUpload::Req*> seal() {
+    std::lock_guard<std::mutex> g(e->m);
+    e->sealed = true;
+    return e->batch;
+  }
+  void finish_batch() {
+    {
+      std::lock_guard<std::mutex> g(e->m);
+      e->batch_done = true;
+    }
+    e->cv.notify_all();
+  }
   ~SharedUploadRef() {
     if (!e) return;
+    if (is_owner) {  // whatever path the owner left on: joiners must not wait for ever (their requests then carry the error set below)
+      bool wake = false;
+      {
+        std::lock_guard<std::mutex> g(e->m);
+        if (!e->batch_done) {
+          e->sealed = true;
+          for (SharedUpload::Req* r : e->batch)
+            if (r->rc == CSH_OK && r->err.empty()) {
+              r->rc = CSH_ERR_HIP;
+              r->err = "csh_msm: the concurrent call that ran this batch failed before it reached this request";
+            }
+          e->batch_done = true;
+          wake = true;
+        }
+      }
+      if (wake) e->cv.notify_all();
+    }
     (void)hipStreamSynchronize(stream);  // a no-op after a successful (synchronous) MSM; after a failed one nothing queued on this stream may still read the copy
     SharedUpload* dead = nullptr;
     {
@@ -408,9 +471,40 @@ int csh_msm(csh_bases_t bases, size_t offset, size_t n, const uint64_t* scalars,
     hipStream_t st = resolve_stream(nullptr);
     int device = 0;
     (void)hipGetDevice(&device);
+    const bool batching = tune().msm_share_uploads.load(std::memory_order_relaxed) >= 2;
+    const Bases* B = reinterpret_cast<const Bases*>(bases);
+    SharedUpload::Req req;
+    req.bases = bases, req.offset = offset, req.out = out;
+    bool joined = false;
     SharedUploadRef up;
-    CSH_TRY(up.acquire(device, scalars, bytes, st));
-    return csh_msm_dev(bases, offset, n, reinterpret_cast<const uint64_t*>(up.dev()), mont, out, st);
+    CSH_TRY(up.acquire(device, scalars, bytes, st, batching ? &req : nullptr, batching ? (int)B->curve : -1, mont != 0, &joined));
+    if (joined) {  // the call that was uploading this slice ran this MSM with its own (csh_msm_multi_dev): the result is in `out`
+      if (req.rc != CSH_OK) set_error("%s", req.err.c_str());
+      return req.rc;
+    }
+    const uint64_t* dsc = reinterpret_cast<const uint64_t*>(up.dev());
+    if (!up.is_owner || !batching) return csh_msm_dev(bases, offset, n, dsc, mont, out, st);
+    const std::vector<SharedUpload::Req*> others = up.seal();
+    if (others.empty()) {
+      up.finish_batch();
+      return csh_msm_dev(bases, offset, n, dsc, mont, out, st);
+    }
+    // G2 handles first: their host fold (Horner over Fp2 windows) then runs under the G1 bucket stages that follow (as the mirror's prover orders them)
+    std::vector<SharedUpload::Req*> all;
+    all.push_back(&req);
+    for (SharedUpload::Req* r : others) all.push_back(r);
+    std::stable_sort(all.begin(), all.end(), [](const SharedUpload::Req* a, const SharedUpload::Req* b) {
+      return reinterpret_cast<const Bases*>(a->bases)->group > reinterpret_cast<const Bases*>(b->bases)->group;
+    });
+    std::vector<csh_bases_t> hs;
+    std::vector<size_t> offs;
+    std::vector<void*> outs;
+    for (SharedUpload::Req* r : all) hs.push_back(r->bases), offs.push_back(r->offset), outs.push_back(r->out);
+    const int rc = csh_msm_multi_dev(hs.data(), offs.data(), all.size(), n, dsc, mont, outs.data(), st);
+    const std::string err = rc == CSH_OK ? std::string() : std::string(csh_last_error());
+    for (SharedUpload::Req* r : others) r->rc = rc, r->err = err;
+    up.finish_batch();
+    return rc;
   }
   HostStage h;
   CSH_TRY(h.begin(Arena::padded(bytes)));

@@ -39,6 +39,9 @@
  *    copier threads, created on first use and kept for the life of the process; they touch caller memory only while the call that
  *    enlisted them is running. csh_tune_set("host_populate", 0) + ("host_d2h", 0) + ("host_h2d", 0) turns all of it off (the call then
  *    never leaves the calling thread, and the runtime pins the caller's pages itself);
+ *  - csh_msm with host scalars ("msm_share_uploads" = 2, the default): a call that finds another call of the same process uploading the
+ *    SAME scalar slice (pointer, length, device, curve, encoding) hands that call its request and blocks; the uploading call's thread
+ *    runs both as one csh_msm_multi_dev and writes the result into the waiting call's `out` before either returns;
  *  - csh_comm_init_rank with nranks > 1 runs the collective ncclCommInitRank on a helper thread against "comm_timeout_ms"; a helper
  *    whose peers never arrive is ABANDONED (still blocked inside RCCL after the call returned its error): leave such a process
  *    through _exit.
@@ -108,7 +111,9 @@ int csh_device_count(int* count);
  * process-wide switch as "host_d2h"; counters "stat_h2d_slow", "stat_h2d_staged". Staging is the default in both directions because a
  * process whose runtime has pinned caller memory that was unmapped afterwards can stall 10-30 ms per later call for the rest of its life
  * (DESIGN.md 3.4), and that state cannot be left once entered),
- * "msm_share_uploads" (1 = default: concurrent csh_msm calls handed the same host scalar slice share one upload; counter
+ * "msm_share_uploads" (concurrent csh_msm calls handed the same host scalar slice: 1 = they share one upload; 2 = default since round 6:
+ * the calls that arrive while the first one is uploading are also RUN by it, as one csh_msm_multi_dev -- one digit sort for the handles of
+ * equal length and offset -- and return when it has written their results; 0 = every call uploads and runs for itself; counter
  * "stat_uploads_shared"), "host_timing" (diagnostics: phase times of the host-facing witness map in "stat_wm_h2d_us" / "_dev_us" / "_d2h_us"),
  * "msm_balanced" (1 = default: the MSM's windows share the scalar bits evenly, widths c and c - 1; 0 = uniform c-bit windows),
  * "msm_w" (balanced windows: forced number of windows, 0 = the tuned count). Read-only counters

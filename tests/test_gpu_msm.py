@@ -308,9 +308,11 @@ def test_concurrent_callers_share_the_device(gpu):
     assert not errors, errors
 
 
-@pytest.mark.parametrize("tables", [0, 17])
-def test_concurrent_host_scalar_calls_share_one_upload(gpu, tables):
-    """tables = 17: the same on handles that carry the round-6 fixed-base tables (one bucket set, the wide sort stage on five streams at once).
+@pytest.mark.parametrize("tables,share", [(0, 2), (17, 2), (17, 1)])
+def test_concurrent_host_scalar_calls_share_one_upload(gpu, tables, share):
+    """share = 2 (the default, round 6): the calls that arrive while the first one uploads are RUN by it as one csh_msm_multi_dev (one digit
+    sort for the handles of equal length and offset: here the three G1 handles and the G2 handle); share = 1: they share the upload only.
+    tables = 17: the same on handles that carry the round-6 fixed-base tables (one bucket set, the wide sort stage on five streams at once).
     Round 5: concurrent csh_msm calls handed the SAME host scalar slice (the reference's rayon_join5: A, B/G1, B/G2 and L all read
     aux_assignment, groth16.rs:227-294) share one upload -- a call that finds another one in flight with the same (device, pointer,
     length) reads that call's device copy. Known-dlog bases of four groups / seeds, 2^17 + 5 scalars (4 MiB: above the sharing threshold),
@@ -356,6 +358,7 @@ def test_concurrent_host_scalar_calls_share_one_upload(gpu, tables):
         call(i, outs[i])
     assert B.tune_get("stat_uploads_shared") == shared0
     errs = []
+    gpu.bindings.tune_set("msm_share_uploads", share)
     for _ in range(6):
         o5 = np.zeros_like(outs[0])
         res = [np.zeros_like(o) for o in outs]
@@ -377,6 +380,7 @@ def test_concurrent_host_scalar_calls_share_one_upload(gpu, tables):
             G = cv.CURVES[c][g]
             assert G.eq(H.jac_to_affine(G, res[i]), want[i]) and np.array_equal(res[i], alone[i]), i
         assert cv.BN254_G1.eq(H.jac_to_affine(cv.BN254_G1, o5), want_sub)
+    gpu.bindings.tune_set("msm_share_uploads", 2)
     assert B.tune_get("stat_uploads_shared") > shared0
     for h in handles:
         gpu.lib().csh_bases_free(h)
