@@ -21,6 +21,11 @@ pub struct DeviceBases {
     host_base: usize, // address of the first uploaded point: sub-slices of the same query map to an offset
     len: usize,
     stride: usize,
+    /// Padding points in front of the query on the device (point i of the host slice is point `lead + i` of the handle). `KeyGuard`
+    /// uploads the l query behind `a_query.len() - l_query.len()` of them: the handle then has the length of the a / b queries and takes
+    /// `aux_assignment` at their offset, which is what lets table handles share ONE digit sort inside the library when the reference's
+    /// four closures call `csh_msm` over the same slice (cosnarks_hip.h, `csh_msm_multi_dev`; `msm_share_uploads` = 2).
+    lead: usize,
     checkpoints: Vec<(usize, u64)>, // (point index, FNV-1a of that point as uploaded), ascending
 }
 unsafe impl Send for DeviceBases {}
@@ -111,6 +116,14 @@ pub fn get_or_upload_sized<P: Pairing, C: SWCurveConfig>(points: &[Affine<C>], k
 /// # Safety
 /// `[ptr, ptr + len * stride)` must be a live slice the caller holds for the duration of the call.
 pub unsafe fn get_or_upload_raw(curve: i32, group: i32, ptr: *const u8, len: usize, stride: usize, key_points: usize) -> (Arc<DeviceBases>, usize) {
+    unsafe { get_or_upload_raw_lead(curve, group, ptr, len, stride, key_points, 0) }
+}
+
+/// The same with `lead` padding points in front of the device copy (copies of the slice's first points; never read by an MSM, which
+/// starts at the returned offset `lead + (offset inside the query)`). A cache hit keeps the lead the entry was uploaded with.
+/// # Safety
+/// As `get_or_upload_raw`.
+pub unsafe fn get_or_upload_raw_lead(curve: i32, group: i32, ptr: *const u8, len: usize, stride: usize, key_points: usize, lead: usize) -> (Arc<DeviceBases>, usize) {
     let dev = current_device();
     let base_addr = ptr as usize;
     let mut cache = CACHE.lock();
@@ -122,7 +135,7 @@ pub unsafe fn get_or_upload_raw(curve: i32, group: i32, ptr: *const u8, len: usi
         }
         if let Some(off) = b.offset_of_raw(base_addr, len) {
             match if b.stride == stride { b.check(base_addr, len, off) } else { Check::Different } {
-                Check::Same => return (b.clone(), off),
+                Check::Same => return (b.clone(), off + b.lead),
                 Check::Different => stale = Some(i), // same addresses, other contents: the key this entry came from is gone
                 Check::Unknown => cacheable = false,  // too short to verify against the entry: upload it on its own, uncached
             }
@@ -138,7 +151,19 @@ pub unsafe fn get_or_upload_raw(curve: i32, group: i32, ptr: *const u8, len: usi
         cache.retain(|b| !(b.device == dev && b.overlaps(lo, hi)));
     }
     let mut handle: sys::CshBases = core::ptr::null_mut();
-    hip_ok(unsafe { sys::csh_bases_upload(curve, group, ptr.cast(), len, stride, &mut handle) });
+    let lead = if len == 0 { 0 } else { lead };
+    if lead == 0 {
+        hip_ok(unsafe { sys::csh_bases_upload(curve, group, ptr.cast(), len, stride, &mut handle) });
+    } else {
+        // SAFETY: the caller holds `[ptr, ptr + len * stride)`
+        let src = unsafe { core::slice::from_raw_parts(ptr, len * stride) };
+        let mut padded = Vec::with_capacity((lead + len) * stride);
+        for i in 0..lead {
+            padded.extend_from_slice(&src[(i % len) * stride..(i % len + 1) * stride]);
+        }
+        padded.extend_from_slice(src);
+        hip_ok(unsafe { sys::csh_bases_upload(curve, group, padded.as_ptr().cast(), lead + len, stride, &mut handle) });
+    }
     // Fixed-base tables, the library's own policy (csh_bases_table_policy; the C++ mirror's ProvingKey::build_tables asks the same
     // function). Tables are an optimisation: when they do not fit the device the MSM runs on the plain points.
     let (mut c, mut rows) = (0i32, 0i32);
@@ -151,11 +176,11 @@ pub unsafe fn get_or_upload_raw(curve: i32, group: i32, ptr: *const u8, len: usi
             hip_ok(rc);
         }
     }
-    let b = Arc::new(DeviceBases { handle, device: dev, host_base: base_addr, len, stride, checkpoints: checkpoints_of(base_addr, len, stride) });
+    let b = Arc::new(DeviceBases { handle, device: dev, host_base: base_addr, len, stride, lead, checkpoints: checkpoints_of(base_addr, len, stride) });
     if cacheable {
         cache.push(b.clone());
     }
-    (b, 0)
+    (b, lead)
 }
 
 /// Scope of one proving key on one GPU: uploads the five queries up front with a common table policy and evicts them on drop.
@@ -173,8 +198,12 @@ impl KeyGuard {
     {
         let big = [pk.a_query.len(), pk.b_g1_query.len(), pk.l_query.len(), pk.h_query.len(), pk.b_g2_query.len()].into_iter().max().unwrap_or(0);
         let mut ranges = Vec::new();
-        for q in [&pk.a_query, &pk.b_g1_query, &pk.l_query, &pk.h_query] {
-            get_or_upload_sized::<P, C1>(q, big);
+        // the l query goes up padded to the length of the a / b queries (DeviceBases::lead) when the key has the usual shape
+        let same_len = pk.a_query.len() == pk.b_g1_query.len() && pk.a_query.len() == pk.b_g2_query.len() && pk.a_query.len() >= pk.l_query.len();
+        let l_lead = if same_len { pk.a_query.len() - pk.l_query.len() } else { 0 };
+        for (q, lead) in [(&pk.a_query, 0), (&pk.b_g1_query, 0), (&pk.l_query, l_lead), (&pk.h_query, 0)] {
+            // SAFETY: `q` is a live slice of the key the caller holds
+            unsafe { get_or_upload_raw_lead(curve_id::<P>(), group_id::<C1>(), q.as_ptr().cast(), q.len(), core::mem::size_of::<Affine<C1>>(), big, lead) };
             ranges.push((q.as_ptr() as usize, q.as_ptr() as usize + q.len() * core::mem::size_of::<Affine<C1>>()));
         }
         get_or_upload_sized::<P, C2>(&pk.b_g2_query, big);
